@@ -1,0 +1,2442 @@
+/*
+ * lewton_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See lewton_oracle.h for the scope statement and the parity-pin status.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  Every f32
+ * operation below is an individually rounded binary32 operation in the order the
+ * reference writes it; there is no fused multiply-add (Rust never contracts).
+ * Transcendentals go through glibc's cosf/sinf/exp2f/... exactly like Rust's
+ * f32::cos/sin/exp2 on linux-gnu.
+ */
+#include "lewton_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define LWO_PI_F 3.14159265358979323846264338327950288f /* std::f32::consts::PI */
+
+/* ------------------------------------------------------------------------------------------
+ * Bit reader -- src/bitpacking.rs:28-161, 285-300, 398-408.
+ * Bits are consumed LSb first; a multi-bit field is little endian.  A read that does not fit
+ * in the remaining bits fails WITHOUT advancing (bpc_read_body returns Err before touching
+ * the cursors); a zero-width read yields 0 and never fails (:291-297).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	const uint8_t *d;
+	uint64_t nbits; /* total bits available */
+	uint64_t pos;   /* bits consumed */
+} bitrd;
+
+static void br_init(bitrd *r, const uint8_t *d, size_t len)
+{
+	r->d = d;
+	r->nbits = (uint64_t)len * 8u;
+	r->pos = 0;
+}
+
+static int br_read(bitrd *r, unsigned n, uint64_t *out)
+{
+	uint64_t v = 0;
+	unsigned i;
+	if (n == 0) {
+		*out = 0;
+		return 0;
+	}
+	if (r->pos + n > r->nbits)
+		return -1;
+	for (i = 0; i < n; i++) {
+		uint64_t p = r->pos + i;
+		v |= (uint64_t)((r->d[p >> 3] >> (p & 7)) & 1u) << i;
+	}
+	r->pos += n;
+	*out = v;
+	return 0;
+}
+
+static int br_u(bitrd *r, unsigned n, uint32_t *out)
+{
+	uint64_t v;
+	if (br_read(r, n, &v))
+		return -1;
+	*out = (uint32_t)v;
+	return 0;
+}
+
+static int br_flag(bitrd *r, int *out)
+{
+	uint64_t v;
+	if (br_read(r, 1, &v))
+		return -1;
+	*out = (int)v;
+	return 0;
+}
+
+/* src/lib.rs:159 */
+uint8_t lwo_ilog(uint64_t v)
+{
+	uint8_t r = 0;
+	while (v) {
+		r++;
+		v >>= 1;
+	}
+	return r;
+}
+
+/* src/bitpacking.rs:304-314 */
+float lwo_float32_unpack(uint32_t val)
+{
+	uint32_t sgn = val & 0x80000000u;
+	uint32_t exp = (val & 0x7fe00000u) >> 21;
+	double mantissa = (double)(val & 0x1fffffu);
+	double signed_mantissa = sgn ? -mantissa : mantissa;
+	return (float)signed_mantissa * exp2f((float)exp - 788.0f);
+}
+
+size_t lwo_bitread_seq(const uint8_t *data, size_t len, const uint8_t *widths, size_t n, uint64_t *vals)
+{
+	bitrd r;
+	size_t i, ok = 0;
+	br_init(&r, data, len);
+	for (i = 0; i < n; i++) {
+		if (br_read(&r, widths[i], &vals[i]) == 0)
+			ok++;
+		else
+			vals[i] = ~(uint64_t)0;
+	}
+	return ok;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Huffman tree -- src/huffman_tree.rs:66-123 (leftmost-free-leaf insertion in entry order),
+ * :183-221 (validation, single-entry book), :362-381 (bit walk, 0 = left).
+ * The 8-bit unrolled lookup of :259-301 is a pure accelerator with identical results and is
+ * not restated.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	int32_t child[2]; /* node indices, -1 = none */
+	int32_t payload;  /* >= 0 for a leaf */
+	uint8_t full;     /* leaf, or both children present and full */
+} hnode;
+
+typedef struct {
+	hnode *nodes;
+	size_t n_nodes, cap;
+	int single; /* >= 0: the one entry every single bit decodes to (:202-217) */
+	size_t used;
+} htree;
+
+static int32_t ht_new_node(htree *t)
+{
+	if (t->n_nodes == t->cap) {
+		t->cap = t->cap ? t->cap * 2 : 64;
+		t->nodes = (hnode *)realloc(t->nodes, t->cap * sizeof(hnode));
+	}
+	t->nodes[t->n_nodes].child[0] = t->nodes[t->n_nodes].child[1] = -1;
+	t->nodes[t->n_nodes].payload = -1;
+	t->nodes[t->n_nodes].full = 0;
+	return (int32_t)t->n_nodes++;
+}
+
+/* huffman_tree.rs:66-123: returns 1 if inserted */
+static int ht_insert(htree *t, int32_t ni, int32_t payload, unsigned depth)
+{
+	int side;
+	if (t->nodes[ni].payload >= 0)
+		return 0; /* occupied as leaf */
+	if (depth == 0) {
+		if (t->nodes[ni].child[0] >= 0 || t->nodes[ni].child[1] >= 0)
+			return 0; /* inner node */
+		t->nodes[ni].payload = payload;
+		t->nodes[ni].full = 1;
+		return 1;
+	}
+	if (t->nodes[ni].full)
+		return 0;
+	for (side = 0; side < 2; side++) {
+		int32_t c = t->nodes[ni].child[side];
+		if (c < 0) {
+			c = ht_new_node(t);
+			t->nodes[ni].child[side] = c;
+		}
+		if (!t->nodes[c].full && ht_insert(t, c, payload, depth - 1)) {
+			int32_t l = t->nodes[ni].child[0], r = t->nodes[ni].child[1];
+			t->nodes[ni].full = (l >= 0 && r >= 0 && t->nodes[l].full && t->nodes[r].full);
+			return 1;
+		}
+	}
+	return 0;
+}
+
+/* every node has zero or two children (the `even_childs` predicate of the root) */
+static int ht_even(const htree *t, int32_t ni)
+{
+	int32_t l = t->nodes[ni].child[0], r = t->nodes[ni].child[1];
+	if (l < 0 && r < 0)
+		return 1;
+	if (l < 0 || r < 0)
+		return 0;
+	return ht_even(t, l) && ht_even(t, r);
+}
+
+static void ht_free(htree *t)
+{
+	free(t->nodes);
+	t->nodes = NULL;
+	t->n_nodes = t->cap = 0;
+}
+
+/* huffman_tree.rs:183-221.  0 ok, 1 overspecified, 2 underpopulated, 3 invalid single entry */
+static int ht_load(htree *t, const uint8_t *lengths, size_t n)
+{
+	size_t i, cnt = 0, last = 0;
+	memset(t, 0, sizeof(*t));
+	t->single = -1;
+	ht_new_node(t);
+	for (i = 0; i < n; i++) {
+		if (lengths[i] == 0)
+			continue;
+		cnt++;
+		last = i;
+		if (!ht_insert(t, 0, (int32_t)i, lengths[i])) {
+			ht_free(t);
+			return 1;
+		}
+	}
+	t->used = cnt;
+	if (cnt == 1) {
+		if (lengths[last] == 1) {
+			t->single = (int)last;
+			return 0;
+		}
+		ht_free(t);
+		return 3;
+	}
+	if (!ht_even(t, 0)) {
+		ht_free(t);
+		return 2;
+	}
+	return 0;
+}
+
+/* bitpacking.rs:455-486 + huffman_tree.rs:362-381 */
+static int ht_read(const htree *t, bitrd *r, uint32_t *out)
+{
+	int32_t pos = 0;
+	for (;;) {
+		int b;
+		if (br_flag(r, &b))
+			return -1;
+		if (t->single >= 0) {
+			*out = (uint32_t)t->single;
+			return 0;
+		}
+		pos = t->nodes[pos].child[b];
+		if (pos < 0)
+			return -1; /* empty tree: the reference panics here; unreachable for valid books */
+		if (t->nodes[pos].payload >= 0) {
+			*out = (uint32_t)t->nodes[pos].payload;
+			return 0;
+		}
+	}
+}
+
+int lwo_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bits, size_t bits_len,
+		uint32_t *syms, size_t max_syms, size_t *n_syms)
+{
+	htree t;
+	int rc = ht_load(&t, lengths, n_entries);
+	if (rc)
+		return rc;
+	if (bits && syms && n_syms) {
+		bitrd r;
+		size_t k = 0;
+		br_init(&r, bits, bits_len);
+		while (k < max_syms) {
+			uint32_t s;
+			if (ht_read(&t, &r, &s))
+				break;
+			syms[k++] = s;
+		}
+		*n_syms = k;
+	}
+	ht_free(&t);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Per-blocksize tables -- src/header_cached.rs:34-110
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	float *A, *B, *C; /* n/2, n/2, n/4 */
+	float *window;    /* n/2 */
+	uint32_t *bitrev; /* n/8 */
+} bsd;
+
+static uint32_t rev32(uint32_t x)
+{
+	x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+	x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+	x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+	x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+	return (x >> 16) | (x << 16);
+}
+
+void lwo_tables(uint8_t bs, float *A, float *B, float *C, float *window, uint32_t *bitrev)
+{
+	uint32_t n = 1u << bs, n4 = n >> 2, n8 = n >> 3, w = n >> 1, k, i;
+	/* header_cached.rs:77-79 */
+	float pi_4_n = 4.0f * LWO_PI_F / (float)n;
+	float pi_05_n = 0.5f * LWO_PI_F / (float)n;
+	float pi_2_n = 2.0f * LWO_PI_F / (float)n;
+	uint32_t k2 = 0;
+	for (k = 0; k < n4; k++) { /* :81-87 */
+		A[2 * k] = cosf((float)k * pi_4_n);
+		A[2 * k + 1] = -sinf((float)k * pi_4_n);
+		B[2 * k] = cosf((float)(k2 + 1) * pi_05_n) * 0.5f;
+		B[2 * k + 1] = sinf((float)(k2 + 1) * pi_05_n) * 0.5f;
+		k2 += 2;
+	}
+	k2 = 0;
+	for (k = 0; k < n8; k++) { /* :89-93 */
+		C[2 * k] = cosf((float)(k2 + 1) * pi_2_n);
+		C[2 * k + 1] = -sinf((float)(k2 + 1) * pi_2_n);
+		k2 += 2;
+	}
+	for (i = 0; i < w; i++) { /* :43-62, Rust evaluates left to right */
+		float v = sinf(0.5f * LWO_PI_F * ((float)i + 0.5f) / (float)w);
+		window[i] = sinf(0.5f * LWO_PI_F * v * v);
+	}
+	for (i = 0; i < n8; i++) /* :101-110 */
+		bitrev[i] = (rev32(i) >> (32 - bs + 3)) << 2;
+}
+
+static void bsd_init(bsd *t, uint8_t bs)
+{
+	uint32_t n = 1u << bs;
+	t->A = (float *)malloc(sizeof(float) * (n / 2));
+	t->B = (float *)malloc(sizeof(float) * (n / 2));
+	t->C = (float *)malloc(sizeof(float) * (n / 4));
+	t->window = (float *)malloc(sizeof(float) * (n / 2));
+	t->bitrev = (uint32_t *)malloc(sizeof(uint32_t) * (n / 8));
+	lwo_tables(bs, t->A, t->B, t->C, t->window, t->bitrev);
+}
+
+static void bsd_free(bsd *t)
+{
+	free(t->A);
+	free(t->B);
+	free(t->C);
+	free(t->window);
+	free(t->bitrev);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * IMDCT -- src/imdct.rs:14-659, sequential loop order of the reference
+ * ------------------------------------------------------------------------------------------ */
+
+/* The butterfly shared by imdct.rs:36-41, :94-99, :161-166 */
+#define LWO_BFLY(e, hi, lo, t0, t1)                         \
+	do {                                                    \
+		float k00_ = (e)[hi] - (e)[lo];                     \
+		float k01_ = (e)[(hi)-1] - (e)[(lo)-1];             \
+		(e)[hi] += (e)[lo];                                 \
+		(e)[(hi)-1] += (e)[(lo)-1];                         \
+		(e)[lo] = k00_ * (t0) - k01_ * (t1);                \
+		(e)[(lo)-1] = k01_ * (t0) + k00_ * (t1);            \
+	} while (0)
+
+/* imdct.rs:14-71: `cnt` outer iterations of four butterflies, twiddle stride 8 */
+static void step3_iter0_loop(size_t n, float *e, size_t i_off, long k_off, const float *a)
+{
+	size_t it, a_offs = 0, i_offs = i_off;
+	long k_offs = (long)i_off + k_off;
+	for (it = 0; it < (n >> 2); it++) {
+		int j;
+		for (j = 0; j < 4; j++) {
+			LWO_BFLY(e, i_offs - 2 * j, (size_t)k_offs - 2 * j, a[a_offs], a[a_offs + 1]);
+			a_offs += 8;
+		}
+		i_offs -= 8;
+		k_offs -= 8;
+	}
+}
+
+/* imdct.rs:73-133 */
+static void step3_inner_r_loop(size_t lim, float *e, size_t d0, long k_off, const float *a, size_t k1)
+{
+	size_t it, a_offs = 0, d0_offs = d0;
+	long k_offs = (long)d0 + k_off;
+	for (it = 0; it < (lim >> 2); it++) {
+		int j;
+		for (j = 0; j < 4; j++) {
+			LWO_BFLY(e, d0_offs - 2 * j, (size_t)k_offs - 2 * j, a[a_offs], a[a_offs + 1]);
+			a_offs += k1;
+		}
+		d0_offs -= 8;
+		k_offs -= 8;
+	}
+}
+
+/* imdct.rs:135-199 */
+static void step3_inner_s_loop(size_t n, float *e, size_t i_off, long k_off, const float *a,
+		size_t a_off, size_t k0)
+{
+	float tw[8];
+	size_t i = 0, i_offs = i_off, k_offs = (size_t)((long)i_off + k_off);
+	int j;
+	for (j = 0; j < 4; j++) {
+		tw[2 * j] = a[a_off * j];
+		tw[2 * j + 1] = a[a_off * j + 1];
+	}
+	for (;;) {
+		for (j = 0; j < 4; j++)
+			LWO_BFLY(e, i_offs - 2 * j, k_offs - 2 * j, tw[2 * j], tw[2 * j + 1]);
+		i++;
+		if (i >= n)
+			break;
+		i_offs -= k0;
+		k_offs -= k0;
+	}
+}
+
+/* imdct.rs:202-232; z points at "z minus 7" */
+static void iter_54(float *zm7)
+{
+	float k00 = zm7[7] - zm7[3];
+	float y0 = zm7[7] + zm7[3];
+	float y2 = zm7[5] + zm7[1];
+	float k22 = zm7[5] - zm7[1];
+	float k33, k11, y1, y3;
+	zm7[7] = y0 + y2;
+	zm7[5] = y0 - y2;
+	k33 = zm7[4] - zm7[0];
+	zm7[3] = k00 + k33;
+	zm7[1] = k00 - k33;
+	k11 = zm7[6] - zm7[2];
+	y1 = zm7[6] + zm7[2];
+	y3 = zm7[4] + zm7[0];
+	zm7[6] = y1 + y3;
+	zm7[4] = y1 - y3;
+	zm7[2] = k11 - k22;
+	zm7[0] = k11 + k22;
+}
+
+/* imdct.rs:234-288 */
+static void step3_inner_s_loop_ld654(size_t n, float *e, size_t i_off, const float *a, size_t base_n)
+{
+	size_t a_off = base_n >> 3;
+	float a2 = a[a_off];
+	size_t z = i_off;
+	size_t basep16 = i_off - 16 * (n - 1);
+	for (;;) {
+		float k00, k11;
+		k00 = e[z - 0] - e[z - 8];
+		k11 = e[z - 1] - e[z - 9];
+		e[z - 0] = e[z - 0] + e[z - 8];
+		e[z - 1] = e[z - 1] + e[z - 9];
+		e[z - 8] = k00;
+		e[z - 9] = k11;
+
+		k00 = e[z - 2] - e[z - 10];
+		k11 = e[z - 3] - e[z - 11];
+		e[z - 2] = e[z - 2] + e[z - 10];
+		e[z - 3] = e[z - 3] + e[z - 11];
+		e[z - 10] = (k00 + k11) * a2;
+		e[z - 11] = (k11 - k00) * a2;
+
+		k00 = e[z - 12] - e[z - 4];
+		k11 = e[z - 5] - e[z - 13];
+		e[z - 4] = e[z - 4] + e[z - 12];
+		e[z - 5] = e[z - 5] + e[z - 13];
+		e[z - 12] = k11;
+		e[z - 13] = k00;
+
+		k00 = e[z - 14] - e[z - 6];
+		k11 = e[z - 7] - e[z - 15];
+		e[z - 6] = e[z - 6] + e[z - 14];
+		e[z - 7] = e[z - 7] + e[z - 15];
+		e[z - 14] = (k00 + k11) * a2;
+		e[z - 15] = (k00 - k11) * a2;
+
+		iter_54(e + z - 7);
+		iter_54(e + z - 7 - 8);
+		if (z <= basep16)
+			break;
+		z -= 16;
+	}
+}
+
+/* imdct.rs:291-659 */
+static void inverse_mdct_tab(const bsd *t, float *buffer, uint8_t bs)
+{
+	size_t n = (size_t)1 << bs, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+	float *buf2 = (float *)calloc(n2, sizeof(float));
+	const float *a = t->A, *b = t->B, *c = t->C;
+	float *u, *v;
+	size_t ld = bs, l;
+
+	/* :337-371 copy-and-reflect + step 0 */
+	{
+		size_t a_offs = 0, d_offs = n2 - 2, e_offs = 0;
+		while (e_offs != n2) {
+			buf2[d_offs + 1] = buffer[e_offs] * a[a_offs] - buffer[e_offs + 2] * a[a_offs + 1];
+			buf2[d_offs] = buffer[e_offs] * a[a_offs + 1] + buffer[e_offs + 2] * a[a_offs];
+			d_offs -= 2;
+			a_offs += 2;
+			e_offs += 4;
+		}
+		e_offs = n2 - 3;
+		for (;;) {
+			buf2[d_offs + 1] = -buffer[e_offs + 2] * a[a_offs] - -buffer[e_offs] * a[a_offs + 1];
+			buf2[d_offs] = -buffer[e_offs + 2] * a[a_offs + 1] + -buffer[e_offs] * a[a_offs];
+			if (d_offs < 2)
+				break;
+			d_offs -= 2;
+			a_offs += 2;
+			e_offs -= 4;
+		}
+	}
+	u = buffer;
+	v = buf2;
+	/* :385-430 step 2 */
+	{
+		size_t a_offs = n2 - 8, d0 = n4, d1 = 0, e0 = n4, e1 = 0;
+		for (;;) {
+			float v41_21 = v[e0 + 1] - v[e1 + 1];
+			float v40_20 = v[e0] - v[e1];
+			u[d0 + 1] = v[e0 + 1] + v[e1 + 1];
+			u[d0] = v[e0] + v[e1];
+			u[d1 + 1] = v41_21 * a[a_offs + 4] - v40_20 * a[a_offs + 5];
+			u[d1] = v40_20 * a[a_offs + 4] + v41_21 * a[a_offs + 5];
+
+			v41_21 = v[e0 + 3] - v[e1 + 3];
+			v40_20 = v[e0 + 2] - v[e1 + 2];
+			u[d0 + 3] = v[e0 + 3] + v[e1 + 3];
+			u[d0 + 2] = v[e0 + 2] + v[e1 + 2];
+			u[d1 + 3] = v41_21 * a[a_offs] - v40_20 * a[a_offs + 1];
+			u[d1 + 2] = v40_20 * a[a_offs] + v41_21 * a[a_offs + 1];
+			if (a_offs < 8)
+				break;
+			a_offs -= 8;
+			d0 += 4;
+			d1 += 4;
+			e0 += 4;
+			e1 += 4;
+		}
+	}
+	/* :445-452 iterations 0 and 1 of step 3 (run unconditionally, also for bs 6/7) */
+	step3_iter0_loop(n >> 4, u, n2 - 1 - n4 * 0, -(long)(n >> 3), a);
+	step3_iter0_loop(n >> 4, u, n2 - 1 - n4 * 1, -(long)(n >> 3), a);
+	step3_inner_r_loop(n >> 5, u, n2 - 1 - n8 * 0, -(long)(n >> 4), a, 16);
+	step3_inner_r_loop(n >> 5, u, n2 - 1 - n8 * 1, -(long)(n >> 4), a, 16);
+	step3_inner_r_loop(n >> 5, u, n2 - 1 - n8 * 2, -(long)(n >> 4), a, 16);
+	step3_inner_r_loop(n >> 5, u, n2 - 1 - n8 * 3, -(long)(n >> 4), a, 16);
+	/* :454-462 */
+	for (l = 2; l < ((ld - 3) >> 1); l++) {
+		size_t k0 = n >> (l + 2), lim = (size_t)1 << (l + 1), i;
+		long k0_2 = (long)(k0 >> 1);
+		for (i = 0; i < lim; i++)
+			step3_inner_r_loop(n >> (l + 4), u, n2 - 1 - k0 * i, -k0_2, a, (size_t)1 << (l + 3));
+	}
+	/* :463-477 */
+	for (l = (ld - 3) >> 1; l < ld - 6; l++) {
+		size_t k0 = n >> (l + 2), k1 = (size_t)1 << (l + 3);
+		long k0_2 = (long)(k0 >> 1);
+		size_t rlim = n >> (l + 6), lim = (size_t)1 << (l + 1), r;
+		size_t i_off = n2 - 1, a_off = 0;
+		for (r = 0; r < rlim; r++) {
+			step3_inner_s_loop(lim, u, i_off, -k0_2, a + a_off, k1, k0);
+			a_off += k1 * 4;
+			i_off -= 8;
+		}
+	}
+	/* :484 */
+	step3_inner_s_loop_ld654(n >> 5, u, n2 - 1, a, n);
+	/* :490-528 steps 4,5,6: bit-reverse */
+	{
+		const uint32_t *br = t->bitrev;
+		size_t d0 = n4 - 4, d1 = n2 - 4, bi = 0;
+		for (;;) {
+			size_t k4 = br[bi];
+			v[d1 + 3] = u[k4 + 0];
+			v[d1 + 2] = u[k4 + 1];
+			v[d0 + 3] = u[k4 + 2];
+			v[d0 + 2] = u[k4 + 3];
+			k4 = br[bi + 1];
+			v[d1 + 1] = u[k4 + 0];
+			v[d1 + 0] = u[k4 + 1];
+			v[d0 + 1] = u[k4 + 2];
+			v[d0 + 0] = u[k4 + 3];
+			if (d0 < 4)
+				break;
+			d0 -= 4;
+			d1 -= 4;
+			bi += 2;
+		}
+	}
+	/* :533-580 step 7 */
+	{
+		size_t c_offs = 0, d = 0, e = n2 - 4;
+		while (d < e) {
+			float a02 = v[d] - v[e + 2];
+			float a11 = v[d + 1] + v[e + 3];
+			float b0 = c[c_offs + 1] * a02 + c[c_offs] * a11;
+			float b1 = c[c_offs + 1] * a11 - c[c_offs] * a02;
+			float b2 = v[d] + v[e + 2];
+			float b3 = v[d + 1] - v[e + 3];
+			v[d] = b2 + b0;
+			v[d + 1] = b3 + b1;
+			v[e + 2] = b2 - b0;
+			v[e + 3] = b1 - b3;
+
+			a02 = v[d + 2] - v[e];
+			a11 = v[d + 3] + v[e + 1];
+			b0 = c[c_offs + 3] * a02 + c[c_offs + 2] * a11;
+			b1 = c[c_offs + 3] * a11 - c[c_offs + 2] * a02;
+			b2 = v[d + 2] + v[e];
+			b3 = v[d + 3] - v[e + 1];
+			v[d + 2] = b2 + b0;
+			v[d + 3] = b3 + b1;
+			v[e] = b2 - b0;
+			v[e + 1] = b1 - b3;
+			c_offs += 4;
+			d += 4;
+			e -= 4;
+		}
+	}
+	/* :589-658 step 8 + decode */
+	{
+		size_t d0 = 0, d1 = n2 - 4, d2 = n2, d3 = n - 4, bo = n2 - 8, eo = n2 - 8;
+		for (;;) {
+			float p3 = buf2[eo + 6] * b[bo + 7] - buf2[eo + 7] * b[bo + 6];
+			float p2 = -buf2[eo + 6] * b[bo + 6] - buf2[eo + 7] * b[bo + 7];
+			float p1, p0;
+			buffer[d0 + 0] = p3;
+			buffer[d1 + 3] = -p3;
+			buffer[d2 + 0] = p2;
+			buffer[d3 + 3] = p2;
+			p1 = buf2[eo + 4] * b[bo + 5] - buf2[eo + 5] * b[bo + 4];
+			p0 = -buf2[eo + 4] * b[bo + 4] - buf2[eo + 5] * b[bo + 5];
+			buffer[d0 + 1] = p1;
+			buffer[d1 + 2] = -p1;
+			buffer[d2 + 1] = p0;
+			buffer[d3 + 2] = p0;
+			p3 = buf2[eo + 2] * b[bo + 3] - buf2[eo + 3] * b[bo + 2];
+			p2 = -buf2[eo + 2] * b[bo + 2] - buf2[eo + 3] * b[bo + 3];
+			buffer[d0 + 2] = p3;
+			buffer[d1 + 1] = -p3;
+			buffer[d2 + 2] = p2;
+			buffer[d3 + 1] = p2;
+			p1 = buf2[eo + 0] * b[bo + 1] - buf2[eo + 1] * b[bo + 0];
+			p0 = -buf2[eo + 0] * b[bo + 0] - buf2[eo + 1] * b[bo + 1];
+			buffer[d0 + 3] = p1;
+			buffer[d1 + 0] = -p1;
+			buffer[d2 + 3] = p0;
+			buffer[d3 + 0] = p0;
+			if (eo < 8)
+				break;
+			eo -= 8;
+			bo -= 8;
+			d0 += 4;
+			d2 += 4;
+			d1 -= 4;
+			d3 -= 4;
+		}
+	}
+	free(buf2);
+}
+
+void lwo_inverse_mdct(uint8_t bs, float *buffer)
+{
+	bsd t;
+	bsd_init(&t, bs);
+	inverse_mdct_tab(&t, buffer, bs);
+	bsd_free(&t);
+}
+
+/* audio.rs:792-825 (the definitional O(n^2) transform; f32 table of cosines as written) */
+void lwo_inverse_mdct_slow(float *buffer, size_t n)
+{
+	size_t n4 = n >> 2, n2 = n >> 1, n3_4 = n - n4, i, j;
+	size_t m = n2; /* dct_iv_slow operates on n2 values */
+	size_t nmask = (m << 3) - 1;
+	float *x = (float *)malloc(sizeof(float) * m);
+	float *temp = (float *)malloc(sizeof(float) * m);
+	float *mcos = (float *)malloc(sizeof(float) * 8 * m);
+	memcpy(x, buffer, sizeof(float) * m);
+	for (i = 0; i < 8 * m; i++)
+		mcos[i] = cosf(0.78539816339744830962f * (float)i / (float)m);
+	for (i = 0; i < m; i++) {
+		float acc = 0.0f;
+		for (j = 0; j < m; j++)
+			acc += x[j] * mcos[((2 * i + 1) * (2 * j + 1)) & nmask];
+		temp[i] = acc;
+	}
+	for (i = 0; i < n4; i++)
+		buffer[i] = temp[i + n4];
+	for (i = n4; i < n3_4; i++)
+		buffer[i] = -temp[n3_4 - i - 1];
+	for (i = n3_4; i < n; i++)
+		buffer[i] = -temp[i - n3_4];
+	free(x);
+	free(temp);
+	free(mcos);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Header model -- src/header.rs:363-481
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	uint16_t dims;
+	uint32_t entries;
+	float *vq; /* entries*dims, NULL if lookup type 0 */
+	htree tree;
+} codebook;
+
+typedef struct {
+	uint8_t multiplier;
+	uint8_t n_partitions;
+	uint8_t partition_class[32];
+	uint8_t class_dim[16], class_sub[16], class_master[16];
+	int16_t sub_books[16][8];
+	uint32_t n_x;
+	uint32_t x_list[65];
+	uint32_t sorted_idx[65], sorted_x[65]; /* floor1_x_list_sorted (idx, x) */
+} floor1;
+
+typedef struct {
+	uint8_t order, amp_bits, amp_offset, n_books;
+	uint8_t book_list[16];
+	float *bark_cos_omega[2];
+	uint32_t bark_n[2];
+} floor0;
+
+typedef struct {
+	int type; /* 0 or 1 */
+	floor0 f0;
+	floor1 f1;
+} floor_cfg;
+
+typedef struct {
+	uint8_t vals_used;
+	uint8_t val_i[8];
+} residue_book;
+
+typedef struct {
+	uint8_t type;
+	uint32_t begin, end, partition_size;
+	uint8_t classifications, classbook;
+	residue_book books[64];
+} residue_cfg;
+
+typedef struct {
+	uint16_t n_steps;
+	uint8_t mag[256], ang[256];
+	uint8_t mux[256];
+	uint8_t n_submaps;
+	uint8_t submap_floor[16], submap_residue[16];
+} mapping_cfg;
+
+typedef struct {
+	uint8_t blockflag, mapping;
+} mode_cfg;
+
+struct lwo_ident {
+	uint8_t channels;
+	uint32_t sample_rate;
+	int32_t br_max, br_nom, br_min;
+	uint8_t bs0, bs1;
+	bsd cached[2];
+};
+
+struct lwo_setup {
+	codebook *codebooks;
+	int n_codebooks;
+	floor_cfg *floors;
+	int n_floors;
+	residue_cfg *residues;
+	int n_residues;
+	mapping_cfg *mappings;
+	int n_mappings;
+	mode_cfg *modes;
+	int n_modes;
+};
+
+struct lwo_pwr {
+	int present;
+	size_t ch, len;
+	float *data; /* [ch][len] */
+};
+
+/* header.rs:124-150 */
+static int read_header_begin(bitrd *r, uint8_t *type, int *err)
+{
+	uint32_t res, c;
+	static const uint8_t pat[6] = {0x76, 0x6f, 0x72, 0x62, 0x69, 0x73};
+	int i, is_vorbis = 1;
+	if (br_u(r, 8, &res)) {
+		*err = LWO_HDR_END_OF_PACKET;
+		return -1;
+	}
+	if ((res & 1) == 0) {
+		*err = LWO_HDR_IS_AUDIO;
+		return -1;
+	}
+	/* `&&` short-circuits: bytes after the first mismatch are not read */
+	for (i = 0; i < 6 && is_vorbis; i++) {
+		if (br_u(r, 8, &c)) {
+			*err = LWO_HDR_END_OF_PACKET;
+			return -1;
+		}
+		if (c != pat[i])
+			is_vorbis = 0;
+	}
+	if (!is_vorbis) {
+		*err = LWO_HDR_NOT_VORBIS;
+		return -1;
+	}
+	*type = (uint8_t)res;
+	return 0;
+}
+
+#define RD(n, dst)                                   \
+	do {                                             \
+		if (br_u(&r, (n), &(dst))) {                 \
+			*err = LWO_HDR_END_OF_PACKET;            \
+			goto fail;                               \
+		}                                            \
+	} while (0)
+#define BAD()                            \
+	do {                                 \
+		*err = LWO_HDR_BAD_FORMAT;       \
+		goto fail;                       \
+	} while (0)
+
+/* header.rs:221-259 */
+lwo_ident *lwo_read_header_ident(const uint8_t *pkt, size_t len, int *err)
+{
+	bitrd r;
+	uint8_t type;
+	uint32_t ver, ch, rate, bmax, bnom, bmin, b0, b1, framing;
+	lwo_ident *id;
+	int e = 0;
+	if (!err)
+		err = &e;
+	*err = 0;
+	br_init(&r, pkt, len);
+	if (read_header_begin(&r, &type, err))
+		return NULL;
+	if (type != 1) {
+		*err = LWO_HDR_BAD_TYPE;
+		return NULL;
+	}
+	RD(32, ver);
+	if (ver != 0) {
+		*err = LWO_HDR_UNSUPPORTED_VERSION;
+		return NULL;
+	}
+	RD(8, ch);
+	RD(32, rate);
+	RD(32, bmax);
+	RD(32, bnom);
+	RD(32, bmin);
+	RD(4, b0);
+	RD(4, b1);
+	RD(8, framing);
+	if (b0 < 6 || b0 > 13 || b1 < 6 || b1 > 13 || framing != 1 || b0 > b1 || ch == 0 || rate == 0)
+		BAD();
+	id = (lwo_ident *)calloc(1, sizeof(*id));
+	id->channels = (uint8_t)ch;
+	id->sample_rate = rate;
+	id->br_max = (int32_t)bmax;
+	id->br_nom = (int32_t)bnom;
+	id->br_min = (int32_t)bmin;
+	id->bs0 = (uint8_t)b0;
+	id->bs1 = (uint8_t)b1;
+	bsd_init(&id->cached[0], id->bs0);
+	bsd_init(&id->cached[1], id->bs1);
+	return id;
+fail:
+	return NULL;
+}
+
+void lwo_ident_free(lwo_ident *id)
+{
+	if (!id)
+		return;
+	bsd_free(&id->cached[0]);
+	bsd_free(&id->cached[1]);
+	free(id);
+}
+
+int64_t lwo_ident_field(const lwo_ident *id, int which)
+{
+	switch (which) {
+	case 0: return id->channels;
+	case 1: return id->sample_rate;
+	case 2: return id->br_max;
+	case 3: return id->br_nom;
+	case 4: return id->br_min;
+	case 5: return id->bs0;
+	case 6: return id->bs1;
+	}
+	return -1;
+}
+
+/* header.rs:562-648 */
+static const uint32_t MAX_BASES[32] = {
+	0xffffffff, 0xffffffff, 0x0000ffff, 0x00000659, 0x000000ff, 0x00000054, 0x00000028, 0x00000017,
+	0x0000000f, 0x0000000b, 0x00000009, 0x00000007, 0x00000006, 0x00000005, 0x00000004, 0x00000004,
+	0x00000003, 0x00000003, 0x00000003, 0x00000003, 0x00000003, 0x00000002, 0x00000002, 0x00000002,
+	0x00000002, 0x00000002, 0x00000002, 0x00000002, 0x00000002, 0x00000002, 0x00000002, 0x00000002};
+static const uint8_t MAX_BASE_BITS[32] = {
+	0x1f, 0x1f, 0x0f, 0x0a, 0x07, 0x06, 0x05, 0x04, 0x03, 0x03, 0x03, 0x02, 0x02, 0x02, 0x02, 0x02,
+	0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01};
+
+/* header.rs:585-607; wrapping u32 multiply like release-mode Rust */
+static uint32_t exp_fast(uint32_t base, uint8_t exponent)
+{
+	uint32_t res = 1, selfmul = base;
+	int i;
+	for (i = 0; i < 8; i++) {
+		uint64_t sq;
+		if ((1u << i) & exponent)
+			res *= selfmul;
+		sq = (uint64_t)selfmul * selfmul;
+		if (sq > 0xffffffffull)
+			return res; /* the panic branch is unreachable under the precondition */
+		selfmul = (uint32_t)sq;
+	}
+	return res;
+}
+
+uint32_t lwo_lookup1_values(uint32_t entries, uint16_t dims)
+{
+	uint8_t max_bits;
+	uint32_t max_base, base_bits = 0;
+	int i;
+	if (dims >= 32)
+		return entries == 0 ? 0 : 1;
+	max_bits = MAX_BASE_BITS[dims];
+	max_base = MAX_BASES[dims];
+	for (i = 0; i <= max_bits; i++) {
+		uint32_t bit = 1u << (max_bits - i);
+		base_bits |= bit;
+		if (max_base < base_bits || exp_fast(base_bits, (uint8_t)dims) > entries)
+			base_bits &= ~bit;
+	}
+	return base_bits;
+}
+
+static void codebook_free(codebook *c)
+{
+	free(c->vq);
+	ht_free(&c->tree);
+}
+
+/* header.rs:673-768 (+ lookup_vec_val_decode :495-531) */
+static int read_codebook(bitrd *rp, codebook *cb, int *err)
+{
+	bitrd r = *rp;
+	uint32_t sync, dims, entries, lookup_type, i;
+	int ordered, rc;
+	uint8_t *lengths = NULL;
+	uint32_t *mult = NULL;
+	memset(cb, 0, sizeof(*cb));
+	cb->tree.single = -1;
+	RD(24, sync);
+	if (sync != 0x564342)
+		BAD();
+	RD(16, dims);
+	RD(24, entries);
+	if (br_flag(&r, &ordered)) {
+		*err = LWO_HDR_END_OF_PACKET;
+		goto fail;
+	}
+	lengths = (uint8_t *)calloc(entries ? entries : 1, 1);
+	if (!ordered) {
+		int sparse;
+		if (br_flag(&r, &sparse)) {
+			*err = LWO_HDR_END_OF_PACKET;
+			goto fail;
+		}
+		for (i = 0; i < entries; i++) {
+			uint32_t l5;
+			if (sparse) {
+				int flag;
+				if (br_flag(&r, &flag)) {
+					*err = LWO_HDR_END_OF_PACKET;
+					goto fail;
+				}
+				if (flag) {
+					RD(5, l5);
+					lengths[i] = (uint8_t)(l5 + 1);
+				} else {
+					lengths[i] = 0;
+				}
+			} else {
+				RD(5, l5);
+				lengths[i] = (uint8_t)(l5 + 1);
+			}
+		}
+	} else {
+		uint32_t cur_entry = 0, cur_len, number, filled = 0;
+		RD(5, cur_len);
+		cur_len += 1;
+		while (cur_entry < entries) {
+			uint64_t end;
+			RD(lwo_ilog(entries - cur_entry), number);
+			end = (uint64_t)cur_entry + number;
+			/* the reference pushes first and checks afterwards (:717-724); the check makes the
+			 * header invalid, so clamping the fill is unobservable */
+			for (; filled < end && filled < entries; filled++)
+				lengths[filled] = (uint8_t)cur_len;
+			cur_entry += number;
+			cur_len += 1;
+			if (cur_entry > entries)
+				BAD();
+		}
+	}
+	RD(4, lookup_type);
+	if (lookup_type > 2)
+		BAD();
+	cb->dims = (uint16_t)dims;
+	cb->entries = entries;
+	if (lookup_type != 0) {
+		uint32_t minv, deltav, vbits;
+		int seq_p;
+		uint64_t lookup_values, k;
+		float fmin, fdelta;
+		size_t e, d;
+		RD(32, minv);
+		RD(32, deltav);
+		fmin = lwo_float32_unpack(minv);
+		fdelta = lwo_float32_unpack(deltav);
+		RD(4, vbits);
+		vbits += 1;
+		if (br_flag(&r, &seq_p)) {
+			*err = LWO_HDR_END_OF_PACKET;
+			goto fail;
+		}
+		if (lookup_type == 1)
+			lookup_values = lwo_lookup1_values(entries, (uint16_t)dims);
+		else
+			lookup_values = (uint64_t)entries * dims;
+		/* refuse absurd sizes before allocating (a truncated header fails with EndOfPacket in the
+		 * reference after the reads run out; same outcome, no giant allocation) */
+		if (lookup_values * vbits > (r.nbits - r.pos)) {
+			*err = LWO_HDR_END_OF_PACKET;
+			goto fail;
+		}
+		mult = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(lookup_values ? lookup_values : 1));
+		for (k = 0; k < lookup_values; k++)
+			RD(vbits, mult[k]);
+		if ((uint64_t)entries * dims > ((uint64_t)1 << 27)) { /* hostile header: the reference would try to allocate this */
+			*err = LWO_HDR_BUFFER_NOT_ADDRESSABLE;
+			goto fail;
+		}
+		/* lookup_vec_val_decode, header.rs:495-531 */
+		cb->vq = (float *)malloc(sizeof(float) * ((size_t)entries * dims + 1));
+		for (e = 0; e < entries; e++) {
+			float last = 0.0f;
+			if (lookup_type == 1) {
+				uint64_t index_divisor = 1; /* usize in the reference */
+				for (d = 0; d < dims; d++) {
+					size_t mo = (size_t)(((uint32_t)e / (uint32_t)index_divisor) % lookup_values);
+					float elem = (float)mult[mo] * fdelta + fmin + last;
+					if (seq_p)
+						last = elem;
+					cb->vq[e * dims + d] = elem;
+					index_divisor *= lookup_values;
+				}
+			} else {
+				size_t mo = e * dims;
+				for (d = 0; d < dims; d++) {
+					float elem = (float)mult[mo] * fdelta + fmin + last;
+					if (seq_p)
+						last = elem;
+					cb->vq[e * dims + d] = elem;
+					mo++;
+				}
+			}
+		}
+		free(mult);
+		mult = NULL;
+	}
+	rc = ht_load(&cb->tree, lengths, entries);
+	if (rc) {
+		*err = LWO_HDR_BAD_FORMAT; /* From<HuffmanError>, header.rs:75-79 */
+		goto fail;
+	}
+	free(lengths);
+	*rp = r;
+	return 0;
+fail:
+	free(lengths);
+	free(mult);
+	free(cb->vq);
+	cb->vq = NULL;
+	return -1;
+}
+
+/* header_cached.rs:129-158 */
+static float bark(float x)
+{
+	return 13.1f * atanf(0.00074f * x) + 2.24f * atanf(0.0000000185f * x * x) + 0.0001f * x;
+}
+
+static float *bark_map_cos_omega(uint32_t n, uint16_t rate, uint16_t bark_map_size)
+{
+	float *res = (float *)malloc(sizeof(float) * (n ? n : 1));
+	float hfl = (float)rate / 2.0f;
+	float hfl_dn = hfl / (float)n;
+	float foobar_const_part = (float)bark_map_size / bark(hfl);
+	float bms_m1 = (float)bark_map_size - 1.0f;
+	float omega_factor = LWO_PI_F / (float)bark_map_size;
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		float foobar = floorf(bark((float)i * hfl_dn) * foobar_const_part);
+		float map_elem = fminf(foobar, bms_m1);
+		res[i] = cosf(map_elem * omega_factor);
+	}
+	return res;
+}
+
+/* header.rs:771-918 */
+static int read_floor(bitrd *rp, floor_cfg *fl, uint16_t codebook_cnt, uint8_t bs0, uint8_t bs1, int *err)
+{
+	bitrd r = *rp;
+	uint32_t ftype, i, j;
+	memset(fl, 0, sizeof(*fl));
+	RD(16, ftype);
+	if (ftype == 0) {
+		uint32_t order, rate, bms, ab, ao, nb;
+		RD(8, order);
+		RD(16, rate);
+		RD(16, bms);
+		RD(6, ab);
+		if (ab > 64)
+			BAD();
+		RD(8, ao);
+		RD(4, nb);
+		nb += 1;
+		fl->type = 0;
+		fl->f0.order = (uint8_t)order;
+		fl->f0.amp_bits = (uint8_t)ab;
+		fl->f0.amp_offset = (uint8_t)ao;
+		fl->f0.n_books = (uint8_t)nb;
+		for (i = 0; i < nb; i++) {
+			uint32_t v;
+			RD(8, v);
+			if (v > codebook_cnt)
+				BAD();
+			fl->f0.book_list[i] = (uint8_t)v;
+		}
+		fl->f0.bark_n[0] = 1u << (bs0 - 1);
+		fl->f0.bark_n[1] = 1u << (bs1 - 1);
+		fl->f0.bark_cos_omega[0] = bark_map_cos_omega(fl->f0.bark_n[0], (uint16_t)rate, (uint16_t)bms);
+		fl->f0.bark_cos_omega[1] = bark_map_cos_omega(fl->f0.bark_n[1], (uint16_t)rate, (uint16_t)bms);
+	} else if (ftype == 1) {
+		floor1 *f = &fl->f1;
+		uint32_t parts, mult, rangebits, values = 2;
+		int maximum_class = -1;
+		fl->type = 1;
+		RD(5, parts);
+		f->n_partitions = (uint8_t)parts;
+		for (i = 0; i < parts; i++) {
+			uint32_t c;
+			RD(4, c);
+			if ((int)c > maximum_class)
+				maximum_class = (int)c;
+			f->partition_class[i] = (uint8_t)c;
+		}
+		for (i = 0; (int)i < maximum_class + 1; i++) {
+			uint32_t dim, sub, nbk;
+			RD(3, dim);
+			f->class_dim[i] = (uint8_t)(dim + 1);
+			RD(2, sub);
+			f->class_sub[i] = (uint8_t)sub;
+			if (sub != 0) {
+				uint32_t mb;
+				RD(8, mb);
+				if (mb >= codebook_cnt)
+					BAD();
+				f->class_master[i] = (uint8_t)mb;
+			} else {
+				f->class_master[i] = 0;
+			}
+			nbk = 1u << sub;
+			for (j = 0; j < nbk; j++) {
+				uint32_t b;
+				int bk;
+				RD(8, b);
+				bk = (int)b - 1;
+				if (bk >= (int)codebook_cnt)
+					BAD();
+				f->sub_books[i][j] = (int16_t)bk;
+			}
+		}
+		RD(2, mult);
+		f->multiplier = (uint8_t)(mult + 1);
+		RD(4, rangebits);
+		for (i = 0; i < parts; i++)
+			values += f->class_dim[f->partition_class[i]];
+		if (values > 65)
+			BAD();
+		f->x_list[0] = 0;
+		f->x_list[1] = 1u << rangebits;
+		f->n_x = 2;
+		for (i = 0; i < parts; i++) {
+			for (j = 0; j < f->class_dim[f->partition_class[i]]; j++) {
+				uint32_t x;
+				RD(rangebits, x);
+				f->x_list[f->n_x++] = x;
+			}
+		}
+		/* stable sort by x (header.rs:887-889) + duplicate check (:892-900) */
+		for (i = 0; i < f->n_x; i++) {
+			uint32_t k = i;
+			while (k > 0 && f->sorted_x[k - 1] > f->x_list[i]) {
+				f->sorted_x[k] = f->sorted_x[k - 1];
+				f->sorted_idx[k] = f->sorted_idx[k - 1];
+				k--;
+			}
+			f->sorted_x[k] = f->x_list[i];
+			f->sorted_idx[k] = i;
+		}
+		{
+			uint32_t last = 1;
+			for (i = 0; i < f->n_x; i++) {
+				if (f->sorted_x[i] == last)
+					BAD();
+				last = f->sorted_x[i];
+			}
+		}
+	} else {
+		BAD();
+	}
+	*rp = r;
+	return 0;
+fail:
+	if (fl->type == 0) {
+		free(fl->f0.bark_cos_omega[0]);
+		free(fl->f0.bark_cos_omega[1]);
+		fl->f0.bark_cos_omega[0] = fl->f0.bark_cos_omega[1] = NULL;
+	}
+	return -1;
+}
+
+/* header.rs:922-981 (+ ResidueBook::read_book :446-469) */
+static int read_residue(bitrd *rp, residue_cfg *rs, const codebook *cbs, int n_cbs, int *err)
+{
+	bitrd r = *rp;
+	uint32_t rtype, begin, end, psize, ncls, cbook, i;
+	uint8_t cascade[64];
+	memset(rs, 0, sizeof(*rs));
+	RD(16, rtype);
+	if (rtype > 2)
+		BAD();
+	RD(24, begin);
+	RD(24, end);
+	if (begin > end)
+		BAD();
+	RD(24, psize);
+	psize += 1;
+	RD(6, ncls);
+	ncls += 1;
+	RD(8, cbook);
+	for (i = 0; i < ncls; i++) {
+		uint32_t low, high = 0;
+		int flag;
+		RD(3, low);
+		if (br_flag(&r, &flag)) {
+			*err = LWO_HDR_END_OF_PACKET;
+			goto fail;
+		}
+		if (flag)
+			RD(5, high);
+		cascade[i] = (uint8_t)((high << 3) | low);
+	}
+	for (i = 0; i < ncls; i++) {
+		int k;
+		rs->books[i].vals_used = cascade[i];
+		for (k = 0; k < 7; k++) { /* only passes 0..6 are read (:450) */
+			uint32_t v;
+			if ((cascade[i] & (1u << k)) == 0)
+				continue;
+			RD(8, v);
+			if ((int)v >= n_cbs || cbs[v].vq == NULL)
+				BAD();
+			rs->books[i].val_i[k] = (uint8_t)v;
+		}
+	}
+	if ((int)cbook >= n_cbs)
+		BAD();
+	rs->type = (uint8_t)rtype;
+	rs->begin = begin;
+	rs->end = end;
+	rs->partition_size = psize;
+	rs->classifications = (uint8_t)ncls;
+	rs->classbook = (uint8_t)cbook;
+	*rp = r;
+	return 0;
+fail:
+	return -1;
+}
+
+/* header.rs:985-1057 */
+static int read_mapping(bitrd *rp, mapping_cfg *m, uint8_t chan_ilog, uint8_t channels,
+		uint8_t floor_count, uint8_t residue_count, int *err)
+{
+	bitrd r = *rp;
+	uint32_t mtype, submaps = 1, steps = 0, reserved, i;
+	int flag;
+	memset(m, 0, sizeof(*m));
+	RD(16, mtype);
+	if (mtype > 0)
+		BAD();
+	if (br_flag(&r, &flag)) {
+		*err = LWO_HDR_END_OF_PACKET;
+		goto fail;
+	}
+	if (flag) {
+		RD(4, submaps);
+		submaps += 1;
+	}
+	if (br_flag(&r, &flag)) {
+		*err = LWO_HDR_END_OF_PACKET;
+		goto fail;
+	}
+	if (flag) {
+		RD(8, steps);
+		steps += 1;
+	}
+	for (i = 0; i < steps; i++) {
+		uint32_t mg, an;
+		RD(chan_ilog, mg);
+		RD(chan_ilog, an);
+		if (an == mg || mg >= channels || an >= channels)
+			BAD();
+		m->mag[i] = (uint8_t)mg;
+		m->ang[i] = (uint8_t)an;
+	}
+	m->n_steps = (uint16_t)steps;
+	RD(2, reserved);
+	if (reserved != 0)
+		BAD();
+	if (submaps > 1) {
+		for (i = 0; i < channels; i++) {
+			uint32_t v;
+			RD(4, v);
+			if (v >= submaps)
+				BAD();
+			m->mux[i] = (uint8_t)v;
+		}
+	}
+	m->n_submaps = (uint8_t)submaps;
+	for (i = 0; i < submaps; i++) {
+		uint32_t dummy, fl, rs;
+		RD(8, dummy);
+		(void)dummy;
+		RD(8, fl);
+		RD(8, rs);
+		if (fl >= floor_count || rs >= residue_count)
+			BAD();
+		m->submap_floor[i] = (uint8_t)fl;
+		m->submap_residue[i] = (uint8_t)rs;
+	}
+	*rp = r;
+	return 0;
+fail:
+	return -1;
+}
+
+void lwo_setup_free(lwo_setup *s)
+{
+	int i;
+	if (!s)
+		return;
+	for (i = 0; i < s->n_codebooks; i++)
+		codebook_free(&s->codebooks[i]);
+	free(s->codebooks);
+	for (i = 0; i < s->n_floors; i++) {
+		if (s->floors[i].type == 0) {
+			free(s->floors[i].f0.bark_cos_omega[0]);
+			free(s->floors[i].f0.bark_cos_omega[1]);
+		}
+	}
+	free(s->floors);
+	free(s->residues);
+	free(s->mappings);
+	free(s->modes);
+	free(s);
+}
+
+int lwo_setup_count(const lwo_setup *s, int which)
+{
+	switch (which) {
+	case 0: return s->n_codebooks;
+	case 1: return s->n_floors;
+	case 2: return s->n_residues;
+	case 3: return s->n_mappings;
+	case 4: return s->n_modes;
+	}
+	return -1;
+}
+
+/* header.rs:1082-1154 */
+lwo_setup *lwo_read_header_setup(const uint8_t *pkt, size_t len, uint8_t channels,
+		uint8_t bs0, uint8_t bs1, int *err)
+{
+	bitrd r;
+	uint8_t type, chan_ilog;
+	uint32_t v, cnt, i;
+	int e = 0, framing;
+	lwo_setup *s;
+	if (!err)
+		err = &e;
+	*err = 0;
+	br_init(&r, pkt, len);
+	if (read_header_begin(&r, &type, err))
+		return NULL;
+	if (type != 5) {
+		*err = LWO_HDR_BAD_TYPE;
+		return NULL;
+	}
+	s = (lwo_setup *)calloc(1, sizeof(*s));
+	chan_ilog = lwo_ilog((uint64_t)(uint8_t)(channels - 1));
+	/* 1. codebooks */
+	RD(8, cnt);
+	cnt += 1;
+	s->codebooks = (codebook *)calloc(cnt, sizeof(codebook));
+	for (i = 0; i < cnt; i++) {
+		if (read_codebook(&r, &s->codebooks[i], err))
+			goto fail;
+		s->n_codebooks++;
+	}
+	/* 2. time domain transforms */
+	RD(6, cnt);
+	cnt += 1;
+	for (i = 0; i < cnt; i++) {
+		RD(16, v);
+		if (v != 0)
+			BAD();
+	}
+	/* 3. floors */
+	RD(6, cnt);
+	cnt += 1;
+	s->floors = (floor_cfg *)calloc(cnt, sizeof(floor_cfg));
+	for (i = 0; i < cnt; i++) {
+		if (read_floor(&r, &s->floors[i], (uint16_t)s->n_codebooks, bs0, bs1, err))
+			goto fail;
+		s->n_floors++;
+	}
+	/* 4. residues */
+	RD(6, cnt);
+	cnt += 1;
+	s->residues = (residue_cfg *)calloc(cnt, sizeof(residue_cfg));
+	for (i = 0; i < cnt; i++) {
+		if (read_residue(&r, &s->residues[i], s->codebooks, s->n_codebooks, err))
+			goto fail;
+		s->n_residues++;
+	}
+	/* 5. mappings */
+	RD(6, cnt);
+	cnt += 1;
+	s->mappings = (mapping_cfg *)calloc(cnt, sizeof(mapping_cfg));
+	for (i = 0; i < cnt; i++) {
+		if (read_mapping(&r, &s->mappings[i], chan_ilog, channels, (uint8_t)s->n_floors,
+					(uint8_t)s->n_residues, err))
+			goto fail;
+		s->n_mappings++;
+	}
+	/* 6. modes (read_mode_info, header.rs:1060-1076) */
+	RD(6, cnt);
+	cnt += 1;
+	s->modes = (mode_cfg *)calloc(cnt, sizeof(mode_cfg));
+	for (i = 0; i < cnt; i++) {
+		int bf;
+		uint32_t wt, tt, mp;
+		if (br_flag(&r, &bf)) {
+			*err = LWO_HDR_END_OF_PACKET;
+			goto fail;
+		}
+		RD(16, wt);
+		RD(16, tt);
+		RD(8, mp);
+		if (wt != 0 || tt != 0 || (int)mp >= s->n_mappings)
+			BAD();
+		s->modes[i].blockflag = (uint8_t)bf;
+		s->modes[i].mapping = (uint8_t)mp;
+		s->n_modes++;
+	}
+	if (br_flag(&r, &framing)) {
+		*err = LWO_HDR_END_OF_PACKET;
+		goto fail;
+	}
+	if (!framing)
+		BAD();
+	return s;
+fail:
+	lwo_setup_free(s);
+	return NULL;
+}
+#undef RD
+#undef BAD
+
+/* ------------------------------------------------------------------------------------------
+ * PreviousWindowRight -- src/audio.rs:847-861
+ * ------------------------------------------------------------------------------------------ */
+lwo_pwr *lwo_pwr_new(void)
+{
+	return (lwo_pwr *)calloc(1, sizeof(lwo_pwr));
+}
+
+lwo_pwr *lwo_pwr_clone(const lwo_pwr *p)
+{
+	lwo_pwr *q = lwo_pwr_new();
+	*q = *p;
+	if (p->present && p->data) {
+		q->data = (float *)malloc(sizeof(float) * (p->ch * p->len + 1));
+		memcpy(q->data, p->data, sizeof(float) * p->ch * p->len);
+	} else {
+		q->data = NULL;
+	}
+	return q;
+}
+
+int lwo_pwr_is_empty(const lwo_pwr *p)
+{
+	return !p->present;
+}
+
+void lwo_pwr_reset(lwo_pwr *p)
+{
+	free(p->data);
+	p->data = NULL;
+	p->present = 0;
+	p->ch = p->len = 0;
+}
+
+void lwo_pwr_free(lwo_pwr *p)
+{
+	if (!p)
+		return;
+	free(p->data);
+	free(p);
+}
+
+size_t lwo_pwr_len(const lwo_pwr *p)
+{
+	return p->present ? p->len : 0;
+}
+
+int lwo_pwr_copy(const lwo_pwr *p, float *dst)
+{
+	if (!p->present)
+		return -1;
+	memcpy(dst, p->data, sizeof(float) * p->ch * p->len);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Floor 1 -- src/audio.rs:215-292, 354-367, 391-435, 503-555
+ * ------------------------------------------------------------------------------------------ */
+
+/* audio.rs:354-367; u32 arithmetic wraps like release-mode Rust */
+uint32_t lwo_render_point(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x)
+{
+	int32_t dy = (int32_t)(y1 - y0);
+	uint32_t adx = x1 - x0;
+	uint32_t ady = (uint32_t)(dy < 0 ? -(uint32_t)dy : (uint32_t)dy);
+	uint32_t err = ady * (x - x0);
+	uint32_t off = err / adx;
+	return dy < 0 ? y0 - off : y0 + off;
+}
+
+/* audio.rs:253-292: among v[0..x) find the entry closest below (low) / above (high) v[x];
+ * first occurrence wins. Returns -1 where the reference panics (no such entry). */
+static int extr_neighbor(const uint32_t *v, size_t x, int want_low, size_t *idx, uint32_t *val)
+{
+	size_t i, best = 0;
+	int found = 0;
+	uint32_t bound = v[x];
+	for (i = 0; i < x; i++) {
+		int ok = want_low ? (v[i] < bound) : (v[i] > bound);
+		if (!ok)
+			continue;
+		if (!found) {
+			found = 1;
+			best = i;
+		} else if (want_low ? (v[i] > v[best]) : (v[i] < v[best])) {
+			best = i;
+		}
+	}
+	if (!found)
+		return -1;
+	*idx = best;
+	*val = v[best];
+	return 0;
+}
+
+int lwo_low_neighbor(const uint32_t *v, size_t x, size_t *idx, uint32_t *val)
+{
+	return extr_neighbor(v, x, 1, idx, val);
+}
+
+int lwo_high_neighbor(const uint32_t *v, size_t x, size_t *idx, uint32_t *val)
+{
+	return extr_neighbor(v, x, 0, idx, val);
+}
+
+/* audio.rs:215-251.  Returns 0 ok, 1 unused (incl. end of packet), 2 undecodable */
+static int floor_one_decode(bitrd *r, const codebook *cbs, const floor1 *fl, uint32_t *y, uint32_t *ny)
+{
+	static const uint32_t ranges[4] = {256, 128, 86, 64};
+	int nonzero;
+	uint32_t range, b, v, k = 0;
+	unsigned pi;
+	if (br_flag(r, &nonzero) || !nonzero)
+		return 1;
+	range = ranges[fl->multiplier - 1];
+	b = lwo_ilog(range - 1);
+	if (br_u(r, b, &v))
+		return 1;
+	y[k++] = v;
+	if (br_u(r, b, &v))
+		return 1;
+	y[k++] = v;
+	for (pi = 0; pi < fl->n_partitions; pi++) {
+		unsigned uclass = fl->partition_class[pi];
+		unsigned cdim = fl->class_dim[uclass];
+		unsigned cbits = fl->class_sub[uclass];
+		uint32_t csub = (1u << cbits) - 1;
+		uint32_t cval = 0;
+		unsigned d;
+		if (cbits > 0) {
+			if (ht_read(&cbs[fl->class_master[uclass]].tree, r, &cval))
+				return 1;
+		}
+		for (d = 0; d < cdim; d++) {
+			int book = fl->sub_books[uclass][cval & csub];
+			cval >>= cbits;
+			if (book >= 0) {
+				if (ht_read(&cbs[book].tree, r, &v))
+					return 1;
+				y[k++] = v;
+			} else {
+				y[k++] = 0;
+			}
+		}
+	}
+	*ny = k;
+	return 0;
+}
+
+/* audio.rs:391-435 */
+static void floor_one_amplitude(const uint32_t *y, const floor1 *fl, uint32_t *final_y, uint8_t *step2)
+{
+	static const int32_t ranges[4] = {256, 128, 86, 64};
+	int32_t range = ranges[fl->multiplier - 1];
+	uint32_t i;
+	step2[0] = step2[1] = 1;
+	final_y[0] = y[0];
+	final_y[1] = y[1];
+	for (i = 2; i < fl->n_x; i++) {
+		size_t lo_i = 0, hi_i = 0;
+		uint32_t lo_x = 0, hi_x = 0;
+		int32_t predicted, val, highroom, lowroom, room;
+		lwo_low_neighbor(fl->x_list, i, &lo_i, &lo_x);
+		lwo_high_neighbor(fl->x_list, i, &hi_i, &hi_x);
+		predicted = (int32_t)lwo_render_point(lo_x, final_y[lo_i], hi_x, final_y[hi_i], fl->x_list[i]);
+		val = (int32_t)y[i];
+		highroom = (int32_t)((uint32_t)range - (uint32_t)predicted);
+		lowroom = predicted;
+		room = (int32_t)((uint32_t)(highroom < lowroom ? highroom : lowroom) * 2u);
+		if (val > 0) {
+			uint32_t fy;
+			step2[lo_i] = 1;
+			step2[hi_i] = 1;
+			step2[i] = 1;
+			if (val >= room) {
+				if (highroom > lowroom)
+					fy = (uint32_t)predicted + (uint32_t)val - (uint32_t)lowroom;
+				else
+					fy = (uint32_t)predicted - (uint32_t)val + (uint32_t)highroom - 1u;
+			} else {
+				/* predicted + ((if val % 2 == 1 { -val - 1 } else { val }) >> 1), arithmetic shift */
+				int32_t t = (val % 2 == 1) ? (int32_t)(0u - (uint32_t)val - 1u) : val;
+				fy = (uint32_t)predicted + (uint32_t)(t >> 1);
+			}
+			final_y[i] = fy;
+		} else {
+			final_y[i] = (uint32_t)predicted;
+			step2[i] = 0;
+		}
+	}
+	for (i = 0; i < fl->n_x; i++) { /* :431-433 clamp after the loop */
+		uint32_t lim = (uint32_t)range - 1u;
+		if (final_y[i] > lim)
+			final_y[i] = lim;
+	}
+}
+
+/* audio.rs:503-524 */
+size_t lwo_render_line(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t *out)
+{
+	int32_t dy = (int32_t)y1 - (int32_t)y0;
+	int32_t adx = (int32_t)x1 - (int32_t)x0;
+	int32_t ady = dy < 0 ? -dy : dy;
+	int32_t base = dy / adx;
+	int32_t y = (int32_t)y0;
+	int32_t err = 0;
+	int32_t sy = base + (dy < 0 ? -1 : 1);
+	size_t k = 0;
+	uint32_t x;
+	ady = ady - (base < 0 ? -base : base) * adx;
+	out[k++] = (uint32_t)y;
+	for (x = x0 + 1; x < x1; x++) {
+		err += ady;
+		if (err >= adx) {
+			err -= adx;
+			y += sy;
+		} else {
+			y += base;
+		}
+		out[k++] = (uint32_t)y;
+	}
+	return k;
+}
+
+/* audio.rs:437-501 -- the Vorbis I specification's floor1_inverse_dB_table (spec section 10.1),
+ * data, not code. */
+static const float FLOOR1_INVERSE_DB_TABLE[256] = {
+	1.0649863e-07f, 1.1341951e-07f, 1.2079015e-07f, 1.2863978e-07f,
+	1.3699951e-07f, 1.4590251e-07f, 1.5538408e-07f, 1.6548181e-07f,
+	1.7623575e-07f, 1.8768855e-07f, 1.9988561e-07f, 2.1287530e-07f,
+	2.2670913e-07f, 2.4144197e-07f, 2.5713223e-07f, 2.7384213e-07f,
+	2.9163793e-07f, 3.1059021e-07f, 3.3077411e-07f, 3.5226968e-07f,
+	3.7516214e-07f, 3.9954229e-07f, 4.2550680e-07f, 4.5315863e-07f,
+	4.8260743e-07f, 5.1396998e-07f, 5.4737065e-07f, 5.8294187e-07f,
+	6.2082472e-07f, 6.6116941e-07f, 7.0413592e-07f, 7.4989464e-07f,
+	7.9862701e-07f, 8.5052630e-07f, 9.0579828e-07f, 9.6466216e-07f,
+	1.0273513e-06f, 1.0941144e-06f, 1.1652161e-06f, 1.2409384e-06f,
+	1.3215816e-06f, 1.4074654e-06f, 1.4989305e-06f, 1.5963394e-06f,
+	1.7000785e-06f, 1.8105592e-06f, 1.9282195e-06f, 2.0535261e-06f,
+	2.1869758e-06f, 2.3290978e-06f, 2.4804557e-06f, 2.6416497e-06f,
+	2.8133190e-06f, 2.9961443e-06f, 3.1908506e-06f, 3.3982101e-06f,
+	3.6190449e-06f, 3.8542308e-06f, 4.1047004e-06f, 4.3714470e-06f,
+	4.6555282e-06f, 4.9580707e-06f, 5.2802740e-06f, 5.6234160e-06f,
+	5.9888572e-06f, 6.3780469e-06f, 6.7925283e-06f, 7.2339451e-06f,
+	7.7040476e-06f, 8.2047000e-06f, 8.7378876e-06f, 9.3057248e-06f,
+	9.9104632e-06f, 1.0554501e-05f, 1.1240392e-05f, 1.1970856e-05f,
+	1.2748789e-05f, 1.3577278e-05f, 1.4459606e-05f, 1.5399272e-05f,
+	1.6400004e-05f, 1.7465768e-05f, 1.8600792e-05f, 1.9809576e-05f,
+	2.1096914e-05f, 2.2467911e-05f, 2.3928002e-05f, 2.5482978e-05f,
+	2.7139006e-05f, 2.8902651e-05f, 3.0780908e-05f, 3.2781225e-05f,
+	3.4911534e-05f, 3.7180282e-05f, 3.9596466e-05f, 4.2169667e-05f,
+	4.4910090e-05f, 4.7828601e-05f, 5.0936773e-05f, 5.4246931e-05f,
+	5.7772202e-05f, 6.1526565e-05f, 6.5524908e-05f, 6.9783085e-05f,
+	7.4317983e-05f, 7.9147585e-05f, 8.4291040e-05f, 8.9768747e-05f,
+	9.5602426e-05f, 0.00010181521f, 0.00010843174f, 0.00011547824f,
+	0.00012298267f, 0.00013097477f, 0.00013948625f, 0.00014855085f,
+	0.00015820453f, 0.00016848555f, 0.00017943469f, 0.00019109536f,
+	0.00020351382f, 0.00021673929f, 0.00023082423f, 0.00024582449f,
+	0.00026179955f, 0.00027881276f, 0.00029693158f, 0.00031622787f,
+	0.00033677814f, 0.00035866388f, 0.00038197188f, 0.00040679456f,
+	0.00043323036f, 0.00046138411f, 0.00049136745f, 0.00052329927f,
+	0.00055730621f, 0.00059352311f, 0.00063209358f, 0.00067317058f,
+	0.00071691700f, 0.00076350630f, 0.00081312324f, 0.00086596457f,
+	0.00092223983f, 0.00098217216f, 0.0010459992f, 0.0011139742f,
+	0.0011863665f, 0.0012634633f, 0.0013455702f, 0.0014330129f,
+	0.0015261382f, 0.0016253153f, 0.0017309374f, 0.0018434235f,
+	0.0019632195f, 0.0020908006f, 0.0022266726f, 0.0023713743f,
+	0.0025254795f, 0.0026895994f, 0.0028643847f, 0.0030505286f,
+	0.0032487691f, 0.0034598925f, 0.0036847358f, 0.0039241906f,
+	0.0041792066f, 0.0044507950f, 0.0047400328f, 0.0050480668f,
+	0.0053761186f, 0.0057254891f, 0.0060975636f, 0.0064938176f,
+	0.0069158225f, 0.0073652516f, 0.0078438871f, 0.0083536271f,
+	0.0088964928f, 0.009474637f, 0.010090352f, 0.010746080f,
+	0.011444421f, 0.012188144f, 0.012980198f, 0.013823725f,
+	0.014722068f, 0.015678791f, 0.016697687f, 0.017782797f,
+	0.018938423f, 0.020169149f, 0.021479854f, 0.022875735f,
+	0.024362330f, 0.025945531f, 0.027631618f, 0.029427276f,
+	0.031339626f, 0.033376252f, 0.035545228f, 0.037855157f,
+	0.040315199f, 0.042935108f, 0.045725273f, 0.048696758f,
+	0.051861348f, 0.055231591f, 0.058820850f, 0.062643361f,
+	0.066714279f, 0.071049749f, 0.075666962f, 0.080584227f,
+	0.085821044f, 0.091398179f, 0.097337747f, 0.10366330f,
+	0.11039993f, 0.11757434f, 0.12521498f, 0.13335215f,
+	0.14201813f, 0.15124727f, 0.16107617f, 0.17154380f,
+	0.18269168f, 0.19456402f, 0.20720788f, 0.22067342f,
+	0.23501402f, 0.25028656f, 0.26655159f, 0.28387361f,
+	0.30232132f, 0.32196786f, 0.34289114f, 0.36517414f,
+	0.38890521f, 0.41417847f, 0.44109412f, 0.46975890f,
+	0.50028648f, 0.53279791f, 0.56742212f, 0.60429640f,
+	0.64356699f, 0.68538959f, 0.72993007f, 0.77736504f,
+	0.82788260f, 0.88168307f, 0.9389798f, 1.0f};
+
+/* audio.rs:526-555; n = number of spectral lines (blocksize/2) */
+static void floor_one_synthesis(const uint32_t *final_y, const uint8_t *step2, const floor1 *fl,
+		uint32_t n, float *out)
+{
+	uint32_t hx = 0, lx = 0, hy = 0, ly, i;
+	/* the rendered line can overshoot n (x up to 2^15); size for the worst case */
+	size_t cap = 65536 + 16, len = 0;
+	uint32_t *fl_y = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+	ly = final_y[fl->sorted_idx[0]] * fl->multiplier;
+	for (i = 1; i < fl->n_x; i++) {
+		uint32_t si = fl->sorted_idx[i];
+		if (step2[si]) {
+			hy = final_y[si] * fl->multiplier;
+			hx = fl->sorted_x[i];
+			len += lwo_render_line(lx, ly, hx, hy, fl_y + len);
+			lx = hx;
+			ly = hy;
+		}
+	}
+	if (hx < n)
+		len += lwo_render_line(hx, hy, n, hy, fl_y + len);
+	else if (hx > n)
+		len = n;
+	for (i = 0; i < n && i < len; i++)
+		out[i] = FLOOR1_INVERSE_DB_TABLE[fl_y[i] & 0xff]; /* index <= 255 for valid streams; the reference would panic above */
+	free(fl_y);
+}
+
+int lwo_floor1_curve(const lwo_setup *s, int floor_idx, const uint32_t *y, uint32_t n_half,
+		float *out, uint32_t *final_y, uint8_t *step2)
+{
+	uint32_t fy[65];
+	uint8_t s2[65];
+	const floor1 *fl;
+	if (floor_idx < 0 || floor_idx >= s->n_floors || s->floors[floor_idx].type != 1)
+		return -1;
+	fl = &s->floors[floor_idx].f1;
+	floor_one_amplitude(y, fl, fy, s2);
+	floor_one_synthesis(fy, s2, fl, n_half, out);
+	if (final_y)
+		memcpy(final_y, fy, sizeof(uint32_t) * fl->n_x);
+	if (step2)
+		memcpy(step2, s2, fl->n_x);
+	return (int)fl->n_x;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Floor 0 -- src/audio.rs:109-212
+ * ------------------------------------------------------------------------------------------ */
+/* returns 0 ok, 1 unused, 2 undecodable */
+static int floor_zero_decode(bitrd *r, const codebook *cbs, const floor0 *fl, float *coeff, uint64_t *amp)
+{
+	uint64_t amplitude;
+	uint32_t booknumber;
+	const codebook *cb;
+	size_t ncoef = 0;
+	float last = 0.0f;
+	if (br_read(r, fl->amp_bits, &amplitude))
+		return 1;
+	if (amplitude == 0)
+		return 1;
+	if (br_u(r, lwo_ilog(fl->n_books), &booknumber))
+		return 1;
+	if (booknumber >= fl->n_books)
+		return 2;
+	cb = &cbs[fl->book_list[booknumber]];
+	for (;;) {
+		float last_new = last;
+		uint32_t idx;
+		size_t d;
+		if (ht_read(&cb->tree, r, &idx))
+			return 1;
+		if (!cb->vq)
+			return 2;
+		for (d = 0; d < cb->dims; d++) {
+			float e = cb->vq[(size_t)idx * cb->dims + d];
+			coeff[ncoef++] = cosf(last + e);
+			last_new = e;
+			if (ncoef == fl->order) {
+				*amp = amplitude;
+				return 0;
+			}
+		}
+		last += last_new;
+		if (ncoef >= fl->order) {
+			*amp = amplitude;
+			return 0;
+		}
+	}
+}
+
+/* audio.rs:160-212 */
+static void floor_zero_curve(const float *cosc, uint64_t amplitude, const floor0 *fl, int blockflag,
+		uint32_t n, float *out)
+{
+	const float *bark_cos = fl->bark_cos_omega[blockflag];
+	uint32_t i = 0;
+	float lfv_common_term = (float)amplitude * (float)fl->amp_offset /
+		(float)(((uint64_t)1 << fl->amp_bits) - 1);
+	while (i < n) {
+		float cos_omega = bark_cos[i];
+		size_t p_ub, q_ub, j;
+		float p, q, lfv;
+		if (fl->order & 1) {
+			p_ub = ((size_t)fl->order - 3) / 2;
+			q_ub = ((size_t)fl->order - 1) / 2;
+			p = 1.0f - cos_omega * cos_omega;
+			q = 0.25f;
+		} else {
+			p_ub = q_ub = ((size_t)fl->order - 2) / 2;
+			p = (1.0f - cos_omega) / 2.0f;
+			q = (1.0f + cos_omega) / 2.0f;
+		}
+		for (j = 0; j < p_ub + 1; j++) {
+			float pm = cosc[2 * j + 1] - cos_omega;
+			p *= 4.0f * pm * pm;
+		}
+		for (j = 0; j < q_ub + 1; j++) {
+			float qm = cosc[2 * j] - cos_omega;
+			q *= 4.0f * qm * qm;
+		}
+		lfv = expf(0.11512925f * (lfv_common_term / sqrtf(p + q) - (float)fl->amp_offset));
+		for (;;) {
+			out[i] = lfv;
+			i++;
+			if (i >= n || bark_cos[i] != cos_omega)
+				break;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Residue -- src/audio.rs:587-760
+ * ------------------------------------------------------------------------------------------ */
+/* audio.rs:587-618. vec_len = floats available from vec_v to the end of this channel's vector.
+ * returns 0 ok, 1 end of packet */
+static int residue_read_partition(bitrd *r, const codebook *cb, const residue_cfg *rs, float *vec_v,
+		size_t vec_len)
+{
+	size_t dims = cb->dims;
+	uint32_t idx;
+	if (rs->type == 0) {
+		size_t step = rs->partition_size / dims, i, j;
+		for (i = 0; i < step; i++) {
+			if (ht_read(&cb->tree, r, &idx))
+				return 1;
+			for (j = 0; j < dims; j++)
+				vec_v[i + j * step] += cb->vq[(size_t)idx * dims + j];
+		}
+	} else {
+		size_t psize = rs->partition_size, i = 0, j;
+		while (i < psize) {
+			if (ht_read(&cb->tree, r, &idx))
+				return 1;
+			if (i + dims > vec_len)
+				break; /* vec_v.get_mut(i..i+len) is None (:604-608) */
+			for (j = 0; j < dims; j++)
+				vec_v[i + j] += cb->vq[(size_t)idx * dims + j];
+			i += dims;
+		}
+	}
+	return 0;
+}
+
+/* audio.rs:620-717. `vectors` must hold ch*actual_size zeros. returns 0 or -1 (Err(())) */
+static int residue_decode_inner(bitrd *r, size_t cur_blocksize, const uint8_t *dnd, size_t ch,
+		const residue_cfg *rs, const codebook *cbs, float *vectors)
+{
+	size_t actual_size = cur_blocksize / 2;
+	size_t lim_begin = rs->begin < actual_size ? rs->begin : actual_size;
+	size_t lim_end = rs->end < actual_size ? rs->end : actual_size;
+	const codebook *classbook = &cbs[rs->classbook];
+	size_t cpc = classbook->dims;
+	size_t n_to_read = lim_end - lim_begin;
+	size_t parts = n_to_read / rs->partition_size;
+	size_t cl_stride, pass, j;
+	uint32_t *cls;
+	if (n_to_read == 0)
+		return 0;
+	if (cpc == 0)
+		return -1;
+	cl_stride = parts + cpc;
+	cls = (uint32_t *)calloc(ch * cl_stride, sizeof(uint32_t));
+	for (pass = 0; pass < 8; pass++) {
+		size_t pc = 0;
+		while (pc < parts) {
+			size_t k;
+			if (pass == 0) {
+				for (j = 0; j < ch; j++) {
+					uint32_t temp;
+					size_t i;
+					if (dnd[j])
+						continue;
+					if (ht_read(&classbook->tree, r, &temp))
+						goto done;
+					for (i = cpc; i-- > 0;) {
+						cls[j * cl_stride + i + pc] = temp % rs->classifications;
+						temp = temp / rs->classifications;
+					}
+				}
+			}
+			for (k = 0; k < cpc; k++) {
+				if (pc >= parts)
+					break;
+				for (j = 0; j < ch; j++) {
+					size_t offs;
+					uint32_t vqclass;
+					const residue_book *rb;
+					if (dnd[j])
+						continue;
+					offs = lim_begin + pc * rs->partition_size;
+					vqclass = cls[j * cl_stride + pc];
+					rb = &rs->books[vqclass];
+					if (rb->vals_used & (1u << pass)) {
+						const codebook *cb = &cbs[rb->val_i[pass]];
+						if (residue_read_partition(r, cb, rs, vectors + j * actual_size + offs,
+									actual_size - offs))
+							goto done;
+					}
+				}
+				pc++;
+			}
+		}
+	}
+done:
+	free(cls);
+	return 0;
+}
+
+/* audio.rs:722-760. out: ch*vec_size floats (zeroed here) */
+static int residue_packet_decode(bitrd *r, size_t cur_blocksize, const uint8_t *dnd, size_t ch,
+		const residue_cfg *rs, const codebook *cbs, float *out)
+{
+	size_t vec_size = cur_blocksize / 2, j, k;
+	memset(out, 0, sizeof(float) * ch * vec_size);
+	if (rs->type == 2) {
+		int found = 0;
+		float *tmp;
+		uint8_t c_dnd[1] = {0};
+		int rc;
+		size_t bs2;
+		for (j = 0; j < ch; j++)
+			if (!dnd[j])
+				found = 1;
+		if (!found)
+			return 0;
+		/* `cur_blocksize * ch as u16` wraps in u16 (audio.rs:745) */
+		bs2 = (size_t)(uint16_t)((uint16_t)cur_blocksize * (uint16_t)ch);
+		tmp = (float *)calloc(ch * vec_size + bs2 / 2 + 1, sizeof(float));
+		rc = residue_decode_inner(r, bs2, c_dnd, 1, rs, cbs, tmp);
+		if (rc) {
+			free(tmp);
+			return -1;
+		}
+		/* vectors.chunks(ch).map(|c| c[j]) over the bs2/2 decoded values (:748-754) */
+		for (j = 0; j < ch; j++)
+			for (k = 0; k < vec_size; k++)
+				out[j * vec_size + k] = (k * ch + j < bs2 / 2) ? tmp[k * ch + j] : 0.0f;
+		free(tmp);
+		return 0;
+	}
+	return residue_decode_inner(r, cur_blocksize, dnd, ch, rs, cbs, out);
+}
+
+/* audio.rs:762-777 */
+void lwo_inverse_couple(float m, float a, float *nm, float *na)
+{
+	if (m > 0.0f) {
+		if (a > 0.0f) {
+			*nm = m;
+			*na = m - a;
+		} else {
+			*nm = m + a;
+			*na = m;
+		}
+	} else {
+		if (a > 0.0f) {
+			*nm = m;
+			*na = m + a;
+		} else {
+			*nm = m - a;
+			*na = m;
+		}
+	}
+}
+
+/* samples.rs:92-103 */
+int16_t lwo_sample_i16(float fl)
+{
+	float f = fl * 32768.0f;
+	if (f > 32767.0f)
+		return 32767;
+	if (f < -32768.0f)
+		return -32768;
+	if (f != f)
+		return 0; /* `as i16` maps NaN to 0 */
+	return (int16_t)f; /* in range: truncation toward zero */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Packet decode -- src/audio.rs:874-1160
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	uint32_t n;
+	uint32_t left_start, right_start, right_end;
+	int left_use_bs1;
+} win_info;
+
+/* audio.rs:1056-1073 (= :889-906) */
+static void window_info(const lwo_ident *id, int blockflag, int have_flags, int prev_flag, int next_flag,
+		win_info *w)
+{
+	uint32_t n = 1u << (blockflag ? id->bs1 : id->bs0);
+	uint32_t center = n >> 1;
+	uint32_t bs0_exp = 1u << id->bs0;
+	w->n = n;
+	if (!have_flags || prev_flag) {
+		w->left_start = 0;
+		w->left_use_bs1 = blockflag;
+	} else {
+		w->left_start = (n - bs0_exp) >> 2;
+		w->left_use_bs1 = 0;
+	}
+	if (!have_flags || next_flag) {
+		w->right_start = center;
+		w->right_end = n;
+	} else {
+		w->right_start = (n * 3 - bs0_exp) >> 2;
+		w->right_end = (n * 3 + bs0_exp) >> 2;
+	}
+}
+
+/* audio.rs:874-909 */
+int lwo_get_decoded_sample_count(const lwo_ident *id, const lwo_setup *s, const uint8_t *pkt, size_t len,
+		size_t *count)
+{
+	bitrd r;
+	int flag, pf = 0, nf = 0;
+	uint32_t mode_number;
+	const mode_cfg *mode;
+	win_info w;
+	br_init(&r, pkt, len);
+	if (br_flag(&r, &flag))
+		return LWO_AUDIO_END_OF_PACKET;
+	if (flag)
+		return LWO_AUDIO_IS_HEADER;
+	if (br_u(&r, lwo_ilog((uint64_t)s->n_modes - 1), &mode_number))
+		return LWO_AUDIO_END_OF_PACKET;
+	if ((int)mode_number >= s->n_modes)
+		return LWO_AUDIO_BAD_FORMAT; /* the reference indexes and would panic (:881) */
+	mode = &s->modes[mode_number];
+	if (mode->blockflag) {
+		if (br_flag(&r, &pf) || br_flag(&r, &nf))
+			return LWO_AUDIO_END_OF_PACKET;
+	}
+	window_info(id, mode->blockflag, mode->blockflag, pf, nf, &w);
+	*count = w.right_start - w.left_start;
+	return LWO_OK;
+}
+
+typedef struct {
+	int kind; /* 0 unused, 1 floor1, 2 floor0 */
+	uint32_t y[65];
+	float coeff[256];
+	uint64_t amp;
+	const floor_cfg *cfg;
+} decoded_floor;
+
+/* audio.rs:919-1160.  On success *chans holds ch pointers-worth of floats in `work`
+ * ([ch][n] layout, valid samples at [0, m)).  Returns AudioReadError. */
+static int read_audio_packet_core(const lwo_ident *id, const lwo_setup *s, const uint8_t *pkt, size_t len,
+		lwo_pwr *pwr, float **work_out, uint32_t *n_out, size_t *m_out, lwo_taps *taps)
+{
+	bitrd r;
+	int flag, pf = 0, nf = 0;
+	uint32_t mode_number, n, n2;
+	const mode_cfg *mode;
+	const mapping_cfg *map;
+	size_t ch = id->channels, i, j, k;
+	decoded_floor *fls;
+	uint8_t no_residue[256];
+	float *residue; /* [ch][n/2] */
+	float *work;    /* [ch][n] */
+	uint8_t bs;
+	win_info w;
+	int rc = LWO_OK;
+
+	br_init(&r, pkt, len);
+	if (br_flag(&r, &flag))
+		return LWO_AUDIO_END_OF_PACKET;
+	if (flag)
+		return LWO_AUDIO_IS_HEADER;
+	if (br_u(&r, lwo_ilog((uint64_t)s->n_modes - 1), &mode_number))
+		return LWO_AUDIO_END_OF_PACKET;
+	if ((int)mode_number >= s->n_modes)
+		return LWO_AUDIO_BAD_FORMAT;
+	mode = &s->modes[mode_number];
+	map = &s->mappings[mode->mapping];
+	bs = mode->blockflag ? id->bs1 : id->bs0;
+	n = 1u << bs;
+	n2 = n >> 1;
+	if (mode->blockflag) {
+		if (br_flag(&r, &pf) || br_flag(&r, &nf))
+			return LWO_AUDIO_END_OF_PACKET;
+	}
+	/* floor_decode, audio.rs:557-585 */
+	fls = (decoded_floor *)calloc(ch, sizeof(decoded_floor));
+	for (i = 0; i < ch; i++) {
+		const floor_cfg *fc = &s->floors[map->submap_floor[map->mux[i]]];
+		int fr;
+		fls[i].cfg = fc;
+		if (fc->type == 0) {
+			fr = floor_zero_decode(&r, s->codebooks, &fc->f0, fls[i].coeff, &fls[i].amp);
+			fls[i].kind = (fr == 0) ? 2 : 0;
+		} else {
+			uint32_t ny = 0;
+			fr = floor_one_decode(&r, s->codebooks, &fc->f1, fls[i].y, &ny);
+			fls[i].kind = (fr == 0) ? 1 : 0;
+		}
+		if (fr == 2) {
+			free(fls);
+			return LWO_AUDIO_END_OF_PACKET; /* Err(()) -> From<()> (:46-50, :940) */
+		}
+	}
+	/* audio.rs:943-955 */
+	for (i = 0; i < ch; i++)
+		no_residue[i] = (fls[i].kind == 0);
+	for (i = 0; i < map->n_steps; i++) {
+		if (!(no_residue[map->mag[i]] && no_residue[map->ang[i]])) {
+			no_residue[map->mag[i]] = 0;
+			no_residue[map->ang[i]] = 0;
+		}
+	}
+	/* audio.rs:957-986 */
+	residue = (float *)calloc(ch * n2 + 1, sizeof(float));
+	for (i = 0; i < map->n_submaps; i++) {
+		uint8_t dnd[256];
+		size_t sub_ch = 0, c = 0;
+		float *vecs;
+		const residue_cfg *rs = &s->residues[map->submap_residue[i]];
+		for (j = 0; j < ch; j++)
+			if (map->mux[j] == i)
+				dnd[sub_ch++] = no_residue[j];
+		vecs = (float *)malloc(sizeof(float) * (sub_ch * n2 + 1));
+		if (residue_packet_decode(&r, n, dnd, sub_ch, rs, s->codebooks, vecs)) {
+			free(vecs);
+			free(residue);
+			free(fls);
+			return LWO_AUDIO_BAD_FORMAT;
+		}
+		for (j = 0; j < ch; j++) {
+			if (map->mux[j] == i) {
+				memcpy(residue + j * n2, vecs + c * n2, sizeof(float) * n2);
+				c++;
+			}
+		}
+		free(vecs);
+	}
+	if (taps && taps->residue_pre_inverse)
+		memcpy(taps->residue_pre_inverse, residue, sizeof(float) * ch * n2);
+	/* inverse coupling, audio.rs:990-1002 (reverse step order) */
+	for (i = map->n_steps; i-- > 0;) {
+		float *mv = residue + (size_t)map->mag[i] * n2;
+		float *av = residue + (size_t)map->ang[i] * n2;
+		for (k = 0; k < n2; k++) {
+			float nm, na;
+			lwo_inverse_couple(mv[k], av[k], &nm, &na);
+			mv[k] = nm;
+			av[k] = na;
+		}
+	}
+	if (taps && taps->residue_post_inverse)
+		memcpy(taps->residue_post_inverse, residue, sizeof(float) * ch * n2);
+	/* dot product, audio.rs:1006-1039; then zero-extend + IMDCT :1044-1052 */
+	work = (float *)calloc(ch * (size_t)n + 1, sizeof(float));
+	for (i = 0; i < ch; i++) {
+		float *spec = work + i * (size_t)n;
+		if (fls[i].kind == 1) {
+			uint32_t fy[65];
+			uint8_t s2[65];
+			floor_one_amplitude(fls[i].y, &fls[i].cfg->f1, fy, s2);
+			floor_one_synthesis(fy, s2, &fls[i].cfg->f1, n2, spec);
+		} else if (fls[i].kind == 2) {
+			floor_zero_curve(fls[i].coeff, fls[i].amp, &fls[i].cfg->f0, mode->blockflag, n2, spec);
+		} /* else zeros */
+		for (k = 0; k < n2; k++)
+			spec[k] *= residue[i * n2 + k];
+	}
+	if (taps && taps->pre_mdct)
+		for (i = 0; i < ch; i++)
+			memcpy(taps->pre_mdct + i * n2, work + i * (size_t)n, sizeof(float) * n2);
+	for (i = 0; i < ch; i++)
+		inverse_mdct_tab(&id->cached[mode->blockflag], work + i * (size_t)n, bs);
+	if (taps && taps->post_mdct)
+		memcpy(taps->post_mdct, work, sizeof(float) * ch * n);
+	if (taps)
+		taps->n = n;
+	free(residue);
+	free(fls);
+
+	window_info(id, mode->blockflag, mode->blockflag, pf, nf, &w);
+	/* overlap add, audio.rs:1082-1154 */
+	{
+		size_t new_len = w.right_end - w.right_start;
+		float *fut = (float *)malloc(sizeof(float) * (ch * new_len + 1));
+		size_t m = 0;
+		if (pwr->present) {
+			const float *slope = id->cached[w.left_use_bs1].window;
+			size_t slope_len = (size_t)1 << ((w.left_use_bs1 ? id->bs1 : id->bs0) - 1);
+			size_t plen = pwr->len;
+			float *prev = pwr->data;
+			/* pwr.data.take(): the state is gone whatever happens next (:1083) */
+			pwr->data = NULL;
+			pwr->present = 0;
+			if (pwr->ch != ch) { /* the reference panics here (assert_eq!, :1086); report instead */
+				free(prev);
+				free(fut);
+				free(work);
+				pwr->ch = pwr->len = 0;
+				return LWO_AUDIO_BAD_FORMAT;
+			}
+			if (slope_len < plen) {
+				free(prev);
+				free(fut);
+				free(work);
+				pwr->ch = pwr->len = 0;
+				return LWO_AUDIO_BAD_FORMAT; /* :1107-1111 */
+			}
+			for (i = 0; i < ch; i++) {
+				float *chan = work + i * (size_t)n;
+				const float *pc = prev + i * plen;
+				for (k = 0; k < plen; k++) /* :1116-1118 */
+					chan[w.left_start + k] = (chan[w.left_start + k] * slope[k]) + (pc[k] * slope[plen - 1 - k]);
+				memcpy(fut + i * new_len, chan + w.right_start, sizeof(float) * new_len);
+				if (w.left_start > 0)
+					memmove(chan, chan + w.left_start, sizeof(float) * (w.right_start - w.left_start));
+			}
+			m = w.right_start - w.left_start;
+			free(prev);
+		} else {
+			for (i = 0; i < ch; i++)
+				memcpy(fut + i * new_len, work + i * (size_t)n + w.right_start, sizeof(float) * new_len);
+			m = 0; /* :1140-1152 */
+		}
+		pwr->data = fut;
+		pwr->present = 1;
+		pwr->ch = ch;
+		pwr->len = new_len;
+		*m_out = m;
+	}
+	*work_out = work;
+	*n_out = n;
+	return rc;
+}
+
+int lwo_read_audio_packet_f32(const lwo_ident *id, const lwo_setup *s, const uint8_t *pkt, size_t len,
+		lwo_pwr *pwr, float *out_planar, size_t cap, size_t *n_samples, lwo_taps *taps)
+{
+	float *work = NULL;
+	uint32_t n = 0;
+	size_t m = 0, i;
+	int rc = read_audio_packet_core(id, s, pkt, len, pwr, &work, &n, &m, taps);
+	if (rc)
+		return rc;
+	if (m > cap) {
+		free(work);
+		return LWO_AUDIO_BUFFER_NOT_ADDRESSABLE;
+	}
+	for (i = 0; i < id->channels; i++)
+		memcpy(out_planar + i * m, work + i * (size_t)n, sizeof(float) * m);
+	*n_samples = m;
+	free(work);
+	return LWO_OK;
+}
+
+int lwo_read_audio_packet_i16(const lwo_ident *id, const lwo_setup *s, const uint8_t *pkt, size_t len,
+		lwo_pwr *pwr, int16_t *out_planar, size_t cap, size_t *n_samples)
+{
+	float *work = NULL;
+	uint32_t n = 0;
+	size_t m = 0, i, k;
+	int rc = read_audio_packet_core(id, s, pkt, len, pwr, &work, &n, &m, NULL);
+	if (rc)
+		return rc;
+	if (m > cap) {
+		free(work);
+		return LWO_AUDIO_BUFFER_NOT_ADDRESSABLE;
+	}
+	for (i = 0; i < id->channels; i++)
+		for (k = 0; k < m; k++)
+			out_planar[i * m + k] = lwo_sample_i16(work[i * (size_t)n + k]);
+	*n_samples = m;
+	free(work);
+	return LWO_OK;
+}
+
+int lwo_read_audio_packet_i16_itl(const lwo_ident *id, const lwo_setup *s, const uint8_t *pkt, size_t len,
+		lwo_pwr *pwr, int16_t *out_itl, size_t cap, size_t *n_samples)
+{
+	float *work = NULL;
+	uint32_t n = 0;
+	size_t m = 0, i, k, ch = id->channels;
+	int rc = read_audio_packet_core(id, s, pkt, len, pwr, &work, &n, &m, NULL);
+	if (rc)
+		return rc;
+	if (m > cap) {
+		free(work);
+		return LWO_AUDIO_BUFFER_NOT_ADDRESSABLE;
+	}
+	for (k = 0; k < m; k++) /* samples.rs:65-71 */
+		for (i = 0; i < ch; i++)
+			out_itl[k * ch + i] = lwo_sample_i16(work[i * (size_t)n + k]);
+	*n_samples = m;
+	free(work);
+	return LWO_OK;
+}
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int lwo_decode_stream_i16(const lwo_ident *id, const lwo_setup *s, const uint8_t *data,
+		const uint64_t *offsets, const uint32_t *lens, size_t n_packets, lwo_pwr *pwr, int16_t *out,
+		size_t out_cap, uint64_t *total_samples, double *seconds)
+{
+	size_t p, ch = id->channels, cap = (size_t)1 << id->bs1, pos = 0;
+	int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * ch * cap);
+	uint64_t total = 0;
+	double t0 = now_s();
+	for (p = 0; p < n_packets; p++) {
+		size_t m = 0;
+		int rc = lwo_read_audio_packet_i16(id, s, data + offsets[p], lens[p], pwr, tmp, cap, &m);
+		if (rc) {
+			free(tmp);
+			return rc;
+		}
+		if (out) {
+			if (pos + ch * m > out_cap) {
+				free(tmp);
+				return LWO_AUDIO_BUFFER_NOT_ADDRESSABLE;
+			}
+			memcpy(out + pos, tmp, sizeof(int16_t) * ch * m);
+			pos += ch * m;
+		}
+		total += m;
+	}
+	if (seconds)
+		*seconds = now_s() - t0;
+	if (total_samples)
+		*total_samples = total;
+	free(tmp);
+	return LWO_OK;
+}
+
+const float *lwo_inverse_db_table(void)
+{
+	return FLOOR1_INVERSE_DB_TABLE;
+}
+
