@@ -2138,6 +2138,12 @@ int lwo_get_decoded_sample_count(const lwo_ident *id, const lwo_setup *s, const 
 	return LWO_OK;
 }
 
+static size_t g_debug_bits_consumed; /* test hook: bit cursor after the entropy stage of the last packet */
+size_t lwo_debug_bits_consumed(void)
+{
+	return g_debug_bits_consumed;
+}
+
 typedef struct {
 	int kind; /* 0 unused, 1 floor1, 2 floor0 */
 	uint32_t y[65];
@@ -2236,6 +2242,7 @@ static int read_audio_packet_core(const lwo_ident *id, const lwo_setup *s, const
 		}
 		free(vecs);
 	}
+	g_debug_bits_consumed = (size_t)r.pos;
 	if (taps && taps->residue_pre_inverse)
 		memcpy(taps->residue_pre_inverse, residue, sizeof(float) * ch * n2);
 	/* inverse coupling, audio.rs:990-1002 (reverse step order) */

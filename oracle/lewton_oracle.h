@@ -109,6 +109,9 @@ int lwo_decode_stream_i16(const lwo_ident *id, const lwo_setup *s,
 		const uint8_t *data, const uint64_t *offsets, const uint32_t *lens, size_t n_packets,
 		lwo_pwr *pwr, int16_t *out, size_t out_cap, uint64_t *total_samples, double *seconds_synth);
 
+/* test hook: bits consumed by the entropy stage of the most recent packet (not thread safe) */
+size_t lwo_debug_bits_consumed(void);
+
 /* ---- unit-level entry points for known-answer tests ---- */
 /* header_cached.rs:34-110 -- tables for one blocksize; arrays sized n/2,n/2,n/4,n/2,n/8 */
 void lwo_tables(uint8_t bs, float *A, float *B, float *C, float *window, uint32_t *bitrev);
