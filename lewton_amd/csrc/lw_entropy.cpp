@@ -1,0 +1,322 @@
+// Host entropy stage (product code).  See lw_entropy.hpp.
+#include "lw_entropy.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace lw {
+
+int read_prologue(const Ident &id, const Setup &s, BitReader &r, Prologue &p)
+{
+	bool hdr;
+	if (!r.flag(hdr))
+		return AUDIO_END_OF_PACKET;
+	if (hdr)
+		return AUDIO_IS_HEADER; // audio.rs:922-924
+	uint32_t mode;
+	if (!r.read(ilog((uint64_t)s.modes.size() - 1), mode))
+		return AUDIO_END_OF_PACKET;
+	if (mode >= s.modes.size())
+		return AUDIO_BAD_FORMAT; // audio.rs:926-930
+	p.mode = (uint8_t)mode;
+	p.blockflag = s.modes[mode].blockflag;
+	p.bs = p.blockflag ? id.bs1 : id.bs0;
+	p.n = 1u << p.bs;
+	p.prev_flag = p.next_flag = false;
+	if (p.blockflag) {
+		if (!r.flag(p.prev_flag) || !r.flag(p.next_flag))
+			return AUDIO_END_OF_PACKET;
+	}
+	return OK;
+}
+
+int decoded_sample_count(const Ident &id, const Setup &s, const uint8_t *pkt, size_t len, size_t &count)
+{
+	BitReader r(pkt, len);
+	Prologue p;
+	const int rc = read_prologue(id, s, r, p);
+	if (rc)
+		return rc;
+	const WindowInfo w = window_info(id, p.blockflag, p.prev_flag, p.next_flag);
+	count = w.right_start - w.left_start;
+	return OK;
+}
+
+namespace {
+
+enum FloorResult { FL_OK, FL_UNUSED, FL_UNDECODABLE };
+
+// audio.rs:215-251
+FloorResult floor_one_decode(BitReader &r, const Setup &s, const Floor1 &fl, uint32_t *y)
+{
+	bool nonzero;
+	if (!r.flag(nonzero) || !nonzero)
+		return FL_UNUSED;
+	const unsigned b = ilog(fl.range() - 1);
+	size_t k = 0;
+	if (!r.read(b, y[k]))
+		return FL_UNUSED;
+	k++;
+	if (!r.read(b, y[k]))
+		return FL_UNUSED;
+	k++;
+	for (uint8_t c : fl.partition_class) {
+		const unsigned cdim = fl.class_dim[c], cbits = fl.class_sub[c];
+		const uint32_t csub = (1u << cbits) - 1;
+		uint32_t cval = 0;
+		if (cbits && !s.codebooks[fl.class_master[c]].huff.decode(r, cval))
+			return FL_UNUSED;
+		for (unsigned d = 0; d < cdim; d++) {
+			const int book = fl.sub_books[c][cval & csub];
+			cval >>= cbits;
+			if (book >= 0) {
+				if (!s.codebooks[book].huff.decode(r, y[k]))
+					return FL_UNUSED;
+			} else {
+				y[k] = 0;
+			}
+			k++;
+		}
+	}
+	return FL_OK;
+}
+
+// audio.rs:354-367 with wrapping u32 arithmetic (release-mode Rust)
+inline uint32_t render_point(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x)
+{
+	const int32_t dy = (int32_t)(y1 - y0);
+	const uint32_t adx = x1 - x0;
+	const uint32_t ady = dy < 0 ? 0u - (uint32_t)dy : (uint32_t)dy;
+	const uint32_t off = (ady * (x - x0)) / adx;
+	return dy < 0 ? y0 - off : y0 + off;
+}
+
+// audio.rs:391-435 -> device record: per post in ascending-x order, (final_y * multiplier) | active flag
+void floor_one_record(const uint32_t *y, const Floor1 &fl, uint16_t *rec)
+{
+	const size_t F = fl.x_list.size();
+	const uint32_t range = fl.range();
+	uint32_t final_y[LW_MAX_POSTS];
+	bool step2[LW_MAX_POSTS];
+	final_y[0] = y[0];
+	final_y[1] = y[1];
+	step2[0] = step2[1] = true;
+	for (size_t i = 2; i < F; i++) {
+		const unsigned lo = fl.lo_idx[i], hi = fl.hi_idx[i];
+		const int32_t predicted =
+			(int32_t)render_point(fl.x_list[lo], final_y[lo], fl.x_list[hi], final_y[hi], fl.x_list[i]);
+		const int32_t val = (int32_t)y[i];
+		const int32_t highroom = (int32_t)(range - (uint32_t)predicted);
+		const int32_t lowroom = predicted;
+		const int32_t room = (int32_t)((uint32_t)std::min(highroom, lowroom) * 2u);
+		if (val > 0) {
+			step2[lo] = step2[hi] = step2[i] = true;
+			uint32_t fy;
+			if (val >= room) {
+				fy = highroom > lowroom ? (uint32_t)predicted + (uint32_t)val - (uint32_t)lowroom
+				                        : (uint32_t)predicted - (uint32_t)val + (uint32_t)highroom - 1u;
+			} else {
+				const int32_t t = (val % 2 == 1) ? (int32_t)(0u - (uint32_t)val - 1u) : val;
+				fy = (uint32_t)predicted + (uint32_t)(t >> 1);
+			}
+			final_y[i] = fy;
+		} else {
+			final_y[i] = (uint32_t)predicted;
+			step2[i] = false;
+		}
+	}
+	for (size_t sidx = 0; sidx < F; sidx++) {
+		const unsigned i = fl.sorted_idx[sidx];
+		const uint32_t fy = std::min(range - 1, final_y[i]); // :431-433
+		rec[sidx] = (uint16_t)((fy * fl.multiplier) & 0xffu) | (step2[i] ? LW_POST_ACTIVE : 0u);
+	}
+}
+
+// audio.rs:587-618
+inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len)
+{
+	const unsigned dims = cb.dims;
+	uint32_t idx;
+	if (rtype == 0) {
+		const unsigned step = psize / dims;
+		for (unsigned i = 0; i < step; i++) {
+			if (!cb.huff.decode(r, idx))
+				return false;
+			const float *e = &cb.vq[(size_t)idx * dims];
+			for (unsigned j = 0; j < dims; j++)
+				v[i + j * step] += e[j];
+		}
+	} else {
+		unsigned i = 0;
+		while (i < psize) {
+			if (!cb.huff.decode(r, idx))
+				return false;
+			if ((size_t)i + dims > vec_len)
+				break;
+			const float *e = &cb.vq[(size_t)idx * dims];
+			for (unsigned j = 0; j < dims; j++)
+				v[i + j] += e[j];
+			i += dims;
+		}
+	}
+	return true;
+}
+
+// audio.rs:620-717; `vectors` = ch * (cur_blocksize/2) zeros.  false = Err(()) (packet undecodable)
+bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_blocksize, const bool *dnd, size_t ch,
+		float *vectors, EntropyScratch &scr)
+{
+	const size_t actual = cur_blocksize / 2;
+	const size_t begin = std::min<size_t>(rs.begin, actual), end = std::min<size_t>(rs.end, actual);
+	const Codebook &classbook = s.codebooks[rs.classbook];
+	const size_t cpc = classbook.dims;
+	const size_t n_to_read = end - begin;
+	const size_t parts = n_to_read / rs.partition_size;
+	if (n_to_read == 0)
+		return true;
+	if (cpc == 0)
+		return false;
+	const size_t stride = parts + cpc;
+	scr.cls.assign(ch * stride, 0);
+	uint32_t *cls = scr.cls.data();
+	const uint32_t ncls = rs.classifications;
+	for (unsigned pass = 0; pass < 8; pass++) {
+		size_t pc = 0;
+		while (pc < parts) {
+			if (pass == 0) {
+				for (size_t j = 0; j < ch; j++) {
+					if (dnd[j])
+						continue;
+					uint32_t t;
+					if (!classbook.huff.decode(r, t))
+						return true; // end of packet is normal (audio.rs:655-660)
+					for (size_t i = cpc; i-- > 0;) {
+						cls[j * stride + pc + i] = t % ncls;
+						t /= ncls;
+					}
+				}
+			}
+			for (size_t k = 0; k < cpc && pc < parts; k++, pc++) {
+				for (size_t j = 0; j < ch; j++) {
+					if (dnd[j])
+						continue;
+					const ResidueBook &rb = rs.books[cls[j * stride + pc]];
+					if (!(rb.vals_used & (1u << pass)))
+						continue;
+					const size_t offs = begin + pc * rs.partition_size;
+					if (!read_partition(r, s.codebooks[rb.val_i[pass]], rs.type, rs.partition_size,
+								vectors + j * actual + offs, actual - offs))
+						return true;
+				}
+			}
+		}
+	}
+	return true;
+}
+
+// audio.rs:722-760
+bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, const bool *dnd, size_t ch, float *out,
+		EntropyScratch &scr)
+{
+	const size_t half = n / 2;
+	std::memset(out, 0, sizeof(float) * ch * half);
+	if (rs.type != 2)
+		return residue_inner(r, s, rs, n, dnd, ch, out, scr);
+	bool any = false;
+	for (size_t j = 0; j < ch; j++)
+		any |= !dnd[j];
+	if (!any)
+		return true;
+	const size_t bs2 = (size_t)(uint16_t)((uint16_t)n * (uint16_t)ch); // `cur_blocksize * ch as u16` wraps (:745)
+	if (bs2 / 2 < ch * half)
+		return false; // wrapped: the reference panics slicing the short vector; report the packet as bad
+	scr.interleaved.assign(ch * half, 0.0f);
+	const bool one_dnd[1] = {false};
+	if (!residue_inner(r, s, rs, bs2, one_dnd, 1, scr.interleaved.data(), scr))
+		return false;
+	const float *v = scr.interleaved.data();
+	if (ch == 2) {
+		float *o0 = out, *o1 = out + half;
+		for (size_t k = 0; k < half; k++) {
+			o0[k] = v[2 * k];
+			o1[k] = v[2 * k + 1];
+		}
+	} else {
+		for (size_t j = 0; j < ch; j++)
+			for (size_t k = 0; k < half; k++)
+				out[j * half + k] = v[k * ch + j];
+	}
+	return true;
+}
+
+} // namespace
+
+int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t len, Prologue &p, uint16_t *floor_out,
+		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed)
+{
+	BitReader r(pkt, len);
+	int rc = read_prologue(id, s, r, p);
+	if (rc)
+		return rc;
+	const Mapping &map = s.mappings[s.modes[p.mode].mapping];
+	const size_t ch = id.channels;
+	const size_t half = p.n / 2;
+	bool no_residue[256];
+	// floor_decode, audio.rs:557-585
+	for (size_t c = 0; c < ch; c++) {
+		const Floor &fl = s.floors[map.submap_floor[map.mux[c]]];
+		uint16_t *rec = floor_out + c * fstride;
+		if (fl.type != 1)
+			return AUDIO_BAD_FORMAT; // floor 0 streams are rejected at decoder creation; defensive
+		uint32_t y[LW_MAX_POSTS];
+		const FloorResult fr = floor_one_decode(r, s, fl.f1, y);
+		if (fr == FL_UNDECODABLE)
+			return AUDIO_END_OF_PACKET;
+		if (fr == FL_UNUSED) {
+			rec[0] = LW_FLOOR_UNUSED;
+			no_residue[c] = true;
+		} else {
+			floor_one_record(y, fl.f1, rec);
+			no_residue[c] = false;
+		}
+	}
+	// audio.rs:948-955
+	for (size_t i = 0; i < map.mag.size(); i++) {
+		const unsigned m = map.mag[i], a = map.ang[i];
+		if (!(no_residue[m] && no_residue[a]))
+			no_residue[m] = no_residue[a] = false;
+	}
+	// audio.rs:957-986
+	const size_t n_submaps = map.submap_floor.size();
+	for (size_t sm = 0; sm < n_submaps; sm++) {
+		bool dnd[256];
+		size_t chans[256];
+		size_t sub_ch = 0;
+		for (size_t c = 0; c < ch; c++) {
+			if (map.mux[c] == sm) {
+				dnd[sub_ch] = no_residue[c];
+				chans[sub_ch++] = c;
+			}
+		}
+		const Residue &rs = s.residues[map.submap_residue[sm]];
+		// channels of a submap are usually contiguous and in order: decode straight into the output block
+		bool contiguous = sub_ch > 0;
+		for (size_t k = 1; k < sub_ch; k++)
+			contiguous &= chans[k] == chans[0] + k;
+		if (contiguous) {
+			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, residue_out + chans[0] * half, scr))
+				return AUDIO_BAD_FORMAT;
+		} else {
+			scr.sub.assign(sub_ch * half + 1, 0.0f);
+			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, scr.sub.data(), scr))
+				return AUDIO_BAD_FORMAT;
+			for (size_t k = 0; k < sub_ch; k++)
+				std::memcpy(residue_out + chans[k] * half, scr.sub.data() + k * half, sizeof(float) * half);
+		}
+	}
+	if (bits_consumed)
+		*bits_consumed = r.pos;
+	return OK;
+}
+
+} // namespace lw

@@ -1,0 +1,382 @@
+// HIP kernels of the Vorbis audio-packet synthesis path for gfx950 (MI355X) -- GENERIC kernels.
+//
+// These kernels handle every block size (64..8192), every window shape and any channel count /
+// coupling list; they are the correctness backbone and the fallback.  The specialised long-block
+// kernel lives in lw_kernels_long.hip.
+//
+// Arithmetic contract: every f32 operation below is the same individually
+// rounded operation, on the same operands, as in the reference; this file is compiled with
+// -ffp-contract=off so hipcc never forms v_fma_f32.  Parallelism only ever comes from running
+// independent index tuples of one step at the same time.
+//
+// Reference restated (paths relative to RustAudio/lewton 0.10.2):
+//   k_decouple       src/audio.rs:762-777, :990-1002
+//   k_imdct_generic  src/audio.rs:526-555 (floor curve, closed form of render_line :503-524),
+//                    :1006-1039 (floor x residue), src/imdct.rs:291-659 (all steps)
+//   k_ola_generic    src/audio.rs:1082-1154 (overlap add, state), src/samples.rs:32-103 (conversion)
+#include "lw_kernels.hpp"
+
+#define LW_BLOCK 256
+
+// ---------------------------------------------------------------------------------------------
+// inverse coupling
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LW_BLOCK) k_decouple(LwDevTables T, LwBatchDev B, uint32_t skip_mask)
+{
+	const uint32_t pkt = blockIdx.x;
+	const LwPacketRec rec = B.recs[pkt];
+	if (rec.flags & skip_mask)
+		return;
+	const uint32_t n2 = (1u << rec.bs) >> 1;
+	const uint32_t s0 = T.couple_off[rec.mode], s1 = T.couple_off[rec.mode + 1];
+	const float *src = B.residue + rec.res_off;
+	float *dst = B.decoupled + rec.res_off;
+	for (uint32_t k = threadIdx.x; k < n2; k += LW_BLOCK) {
+		for (uint32_t c = 0; c < T.ch; c++)
+			dst[c * n2 + k] = src[c * n2 + k];
+		for (uint32_t s = s1; s-- > s0;) { // reverse step order, audio.rs:991-992
+			const uint32_t mi = T.couple[2 * s] * n2 + k, ai = T.couple[2 * s + 1] * n2 + k;
+			const float m = dst[mi], a = dst[ai];
+			float nm, na;
+			if (m > 0.0f) {
+				if (a > 0.0f) {
+					nm = m;
+					na = m - a;
+				} else {
+					nm = m + a;
+					na = m;
+				}
+			} else {
+				if (a > 0.0f) {
+					nm = m;
+					na = m + a;
+				} else {
+					nm = m - a;
+					na = m;
+				}
+			}
+			dst[mi] = nm;
+			dst[ai] = na;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// floor curve + multiply + IMDCT, one workgroup per (packet, channel)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bfly(float *u, uint32_t hi, uint32_t lo, float t0, float t1)
+{
+	const float k00 = u[hi] - u[lo];
+	const float k01 = u[hi - 1] - u[lo - 1];
+	u[hi] = u[hi] + u[lo];
+	u[hi - 1] = u[hi - 1] + u[lo - 1];
+	u[lo] = k00 * t0 - k01 * t1;
+	u[lo - 1] = k01 * t0 + k00 * t1;
+}
+
+// imdct.rs:202-232 on w[0..8)
+__device__ __forceinline__ void iter54(float *w)
+{
+	const float k00 = w[7] - w[3];
+	const float y0 = w[7] + w[3];
+	const float y2 = w[5] + w[1];
+	const float k22 = w[5] - w[1];
+	const float k33 = w[4] - w[0];
+	const float k11 = w[6] - w[2];
+	const float y1 = w[6] + w[2];
+	const float y3 = w[4] + w[0];
+	w[7] = y0 + y2;
+	w[5] = y0 - y2;
+	w[3] = k00 + k33;
+	w[1] = k00 - k33;
+	w[6] = y1 + y3;
+	w[4] = y1 - y3;
+	w[2] = k11 - k22;
+	w[0] = k11 + k22;
+}
+
+__global__ void __launch_bounds__(LW_BLOCK)
+k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled, uint32_t skip_mask)
+{
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	const uint32_t pkt = blockIdx.x / T.ch, c = blockIdx.x % T.ch;
+	const LwPacketRec rec = B.recs[pkt];
+	if (rec.flags & skip_mask)
+		return;
+	const uint32_t tid = threadIdx.x;
+	const LwDevBs tb = T.bs[(rec.flags & LW_RF_LONG) ? 1 : 0];
+	const uint32_t bs = rec.bs, n = 1u << bs, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+	float *u = smem, *v = smem + n2;
+	uint16_t *px = (uint16_t *)(smem + 2 * n2);
+	uint8_t *py = (uint8_t *)(px + LW_XSTRIDE);
+	__shared__ int s_K;
+
+	// ---- active floor posts, ascending x (audio.rs:536-545 walks exactly these)
+	const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
+	const uint32_t fl = T.mode_floor[rec.mode * T.ch + c];
+	const bool unused = frec[0] == LW_FLOOR_UNUSED;
+	if (tid == 0) {
+		int K = 0;
+		if (!unused) {
+			const uint32_t F = T.floor_F[fl];
+			for (uint32_t s = 0; s < F; s++) {
+				const uint16_t e = frec[s];
+				if (e & LW_POST_ACTIVE) {
+					px[K] = T.floor_x[fl * LW_XSTRIDE + s];
+					py[K] = (uint8_t)(e & 0xff);
+					K++;
+				}
+			}
+		}
+		s_K = K;
+	}
+	__syncthreads();
+	const int K = s_K;
+
+	// ---- spectrum = floor * residue (audio.rs:1035-1037); zero floor for an unused channel (:1021-1024)
+	const float *src = (use_decoupled ? B.decoupled : B.residue) + rec.res_off + c * n2;
+	for (uint32_t k = tid; k < n2; k += LW_BLOCK) {
+		float f;
+		if (unused) {
+			f = 0.0f;
+		} else {
+			int lo = 0, hi = K - 1; // largest i with px[i] <= k
+			while (lo < hi) {
+				const int mid = (lo + hi + 1) >> 1;
+				if (px[mid] <= k)
+					lo = mid;
+				else
+					hi = mid - 1;
+			}
+			int y;
+			if (lo == K - 1) {
+				y = py[lo]; // flat extension to n/2, audio.rs:546-548
+			} else {
+				const int x0 = px[lo], x1 = px[lo + 1], y0 = py[lo], y1 = py[lo + 1];
+				const int dy = y1 - y0, adx = x1 - x0;
+				const int ady = dy < 0 ? -dy : dy;
+				const int off = (ady * ((int)k - x0)) / adx; // closed form of render_line
+				y = dy < 0 ? y0 - off : y0 + off;
+			}
+			f = T.inv_db[y];
+		}
+		const float x = f * src[k];
+		u[k] = x;
+		if (tap_spec)
+			tap_spec[rec.res_off + c * n2 + k] = x;
+	}
+	__syncthreads();
+
+	const float *A = tb.A, *Bt = tb.B, *C = tb.C;
+	// ---- imdct.rs:337-371: X = u -> v
+	for (uint32_t j = tid; j < n8; j += LW_BLOCK) {
+		const float x0 = u[4 * j], x2 = u[4 * j + 2];
+		v[n2 - 1 - 2 * j] = x0 * A[2 * j] - x2 * A[2 * j + 1];
+		v[n2 - 2 - 2 * j] = x0 * A[2 * j + 1] + x2 * A[2 * j];
+		const uint32_t e = n2 - 3 - 4 * j, a = n4 + 2 * j, d = n4 - 2 - 2 * j;
+		const float me2 = -u[e + 2], me0 = -u[e];
+		v[d + 1] = me2 * A[a] - me0 * A[a + 1];
+		v[d] = me2 * A[a + 1] + me0 * A[a];
+	}
+	__syncthreads();
+	// ---- imdct.rs:385-430 (step 2): v -> u
+	for (uint32_t i = tid; i < (n >> 4); i += LW_BLOCK) {
+		const uint32_t a = n2 - 8 - 8 * i, lo = 4 * i, hi = n4 + 4 * i;
+		{
+			const float p = v[hi + 1] - v[lo + 1], q = v[hi] - v[lo];
+			u[hi + 1] = v[hi + 1] + v[lo + 1];
+			u[hi] = v[hi] + v[lo];
+			u[lo + 1] = p * A[a + 4] - q * A[a + 5];
+			u[lo] = q * A[a + 4] + p * A[a + 5];
+		}
+		{
+			const float p = v[hi + 3] - v[lo + 3], q = v[hi + 2] - v[lo + 2];
+			u[hi + 3] = v[hi + 3] + v[lo + 3];
+			u[hi + 2] = v[hi + 2] + v[lo + 2];
+			u[lo + 3] = p * A[a] - q * A[a + 1];
+			u[lo + 2] = q * A[a] + p * A[a + 1];
+		}
+	}
+	__syncthreads();
+	// ---- imdct.rs:445-477 (step 3): stages 0 and 1 always run, then up to ld-7 (for bs 6/7 this is the
+	//      literal behaviour of the reference: see DESIGN.md "small block sizes")
+	const int last_stage = (int)bs - 7 > 1 ? (int)bs - 7 : 1;
+	for (int l = 0; l <= last_stage; l++) {
+		const uint32_t per_s = n >> (l + 4);
+		if (l == 1 && per_s < 4) // imdct_step3_inner_r_loop runs lim>>2 groups of four (imdct.rs:93)
+			break;
+		const uint32_t k0 = n >> (l + 2), k1 = 1u << (l + 3);
+		for (uint32_t b = tid; b < n8; b += LW_BLOCK) {
+			const uint32_t s = b / per_s, r = b - s * per_s;
+			const uint32_t hi = n2 - 1 - k0 * s - 2 * r;
+			bfly(u, hi, hi - (k0 >> 1), A[r * k1], A[r * k1 + 1]);
+		}
+		__syncthreads();
+	}
+	// ---- imdct.rs:234-288 fused last three stages, one 16-float group per thread
+	{
+		const float a2 = A[n8];
+		for (uint32_t g = tid; g < (n >> 5); g += LW_BLOCK) {
+			float *z = u + (n2 - 16 - 16 * g); // z[15 - k] is the reference's z![-k]
+			float k00, k11;
+			k00 = z[15] - z[7];
+			k11 = z[14] - z[6];
+			z[15] = z[15] + z[7];
+			z[14] = z[14] + z[6];
+			z[7] = k00;
+			z[6] = k11;
+			k00 = z[13] - z[5];
+			k11 = z[12] - z[4];
+			z[13] = z[13] + z[5];
+			z[12] = z[12] + z[4];
+			z[5] = (k00 + k11) * a2;
+			z[4] = (k11 - k00) * a2;
+			k00 = z[3] - z[11];
+			k11 = z[10] - z[2];
+			z[11] = z[11] + z[3];
+			z[10] = z[10] + z[2];
+			z[3] = k11;
+			z[2] = k00;
+			k00 = z[1] - z[9];
+			k11 = z[8] - z[0];
+			z[9] = z[9] + z[1];
+			z[8] = z[8] + z[0];
+			z[1] = (k00 + k11) * a2;
+			z[0] = (k00 - k11) * a2;
+			iter54(z + 8);
+			iter54(z);
+		}
+	}
+	__syncthreads();
+	// ---- imdct.rs:490-528 bit-reverse: u -> v
+	for (uint32_t t = tid; t < (n >> 4); t += LW_BLOCK) {
+		uint32_t k = tb.bitrev[2 * t];
+		const uint32_t d1 = n2 - 4 - 4 * t, d0 = n4 - 4 - 4 * t;
+		v[d1 + 3] = u[k];
+		v[d1 + 2] = u[k + 1];
+		v[d0 + 3] = u[k + 2];
+		v[d0 + 2] = u[k + 3];
+		k = tb.bitrev[2 * t + 1];
+		v[d1 + 1] = u[k];
+		v[d1] = u[k + 1];
+		v[d0 + 1] = u[k + 2];
+		v[d0] = u[k + 3];
+	}
+	__syncthreads();
+	// ---- imdct.rs:533-580 step 7, in place on v
+	for (uint32_t m = tid; m < (n >> 4); m += LW_BLOCK) {
+		const uint32_t d = 4 * m, e = n2 - 4 - 4 * m;
+		{
+			const float a02 = v[d] - v[e + 2], a11 = v[d + 1] + v[e + 3];
+			const float b0 = C[d + 1] * a02 + C[d] * a11, b1 = C[d + 1] * a11 - C[d] * a02;
+			const float b2 = v[d] + v[e + 2], b3 = v[d + 1] - v[e + 3];
+			v[d] = b2 + b0;
+			v[d + 1] = b3 + b1;
+			v[e + 2] = b2 - b0;
+			v[e + 3] = b1 - b3;
+		}
+		{
+			const float a02 = v[d + 2] - v[e], a11 = v[d + 3] + v[e + 1];
+			const float b0 = C[d + 3] * a02 + C[d + 2] * a11, b1 = C[d + 3] * a11 - C[d + 2] * a02;
+			const float b2 = v[d + 2] + v[e], b3 = v[d + 3] - v[e + 1];
+			v[d + 2] = b2 + b0;
+			v[d + 3] = b3 + b1;
+			v[e] = b2 - b0;
+			v[e + 1] = b1 - b3;
+		}
+	}
+	__syncthreads();
+	// ---- imdct.rs:589-658 step 8 + output mapping -> time-domain block in HBM
+	float *out = B.td + 2u * rec.res_off + c * n;
+	for (uint32_t p = tid; p < n4; p += LW_BLOCK) {
+		const float w0 = v[2 * p], w1 = v[2 * p + 1];
+		const float pa = w0 * Bt[2 * p + 1] - w1 * Bt[2 * p];
+		const float pb = (-w0) * Bt[2 * p] - w1 * Bt[2 * p + 1];
+		const uint32_t q = n4 - 1 - p;
+		out[q] = pa;
+		out[n2 - 1 - q] = -pa;
+		out[n2 + q] = pb;
+		out[n - 1 - q] = pb;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// window + overlap-add + state + sample conversion, one workgroup per (packet, channel)
+// ---------------------------------------------------------------------------------------------
+// samples.rs:92-103: x*32768, clamp to [-32768, 32767], truncate toward zero; NaN -> 0
+__device__ __forceinline__ int16_t to_i16(float x)
+{
+	const float t = x * 32768.0f;
+	if (t > 32767.0f)
+		return 32767;
+	if (t < -32768.0f)
+		return -32768;
+	return (int16_t)(int)t; // in range: truncation toward zero; NaN -> 0 (v_cvt_i32_f32), like Rust `as`
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatchDev B, void *out_v, uint32_t skip_mask)
+{
+	const uint32_t pkt = blockIdx.x / T.ch, c = blockIdx.x % T.ch;
+	const LwPacketRec rec = B.recs[pkt];
+	if (rec.flags & skip_mask)
+		return;
+	const uint32_t n = 1u << rec.bs;
+	const float *cur = B.td + 2u * rec.res_off + c * n;
+	const uint32_t ls = rec.ls, rs = rec.rs, re = rec.re, plen = rec.plen;
+	if (rec.prev != -1) {
+		const uint32_t m = rs - ls;
+		const float *slope = T.bs[(rec.flags & LW_RF_SLOPE_BS1) ? 1 : 0].window;
+		const float *prev;
+		if (rec.prev >= 0) {
+			const LwPacketRec pr = B.recs[rec.prev];
+			prev = B.td + 2u * pr.res_off + c * (1u << pr.bs) + pr.rs;
+		} else {
+			const uint32_t slot = (uint32_t)(-(rec.prev + 2));
+			const uint32_t par = (rec.flags & LW_RF_PARITY_IN) ? 1u : 0u;
+			prev = B.state + ((size_t)slot * 2 + par) * T.state_stride + c * T.state_chan_stride;
+		}
+		for (uint32_t i = threadIdx.x; i < m; i += LW_BLOCK) {
+			float x = cur[ls + i];
+			if (i < plen)
+				x = (x * slope[i]) + (prev[i] * slope[plen - 1 - i]); // audio.rs:1116-1118
+			if (FMT == LW_OUT_I16_PLANAR)
+				((int16_t *)out_v)[rec.out_off + c * m + i] = to_i16(x);
+			else if (FMT == LW_OUT_I16_INTERLEAVED)
+				((int16_t *)out_v)[rec.out_off + i * T.ch + c] = to_i16(x);
+			else
+				((float *)out_v)[rec.out_off + c * m + i] = x;
+		}
+	}
+	if (rec.state_out >= 0) { // audio.rs:1121, :1142-1147: the raw (un-windowed) right part
+		const uint32_t par = (rec.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
+		float *st = B.state + ((size_t)rec.state_out * 2 + par) * T.state_stride + c * T.state_chan_stride;
+		for (uint32_t i = threadIdx.x; i < re - rs; i += LW_BLOCK)
+			st[i] = cur[rs + i];
+	}
+}
+
+void lw_launch_generic(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, float *tap_spec, hipStream_t st,
+		uint32_t max_n, bool any_coupling, bool include_fast)
+{
+	if (B.n_packets == 0)
+		return;
+	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
+	if (any_coupling)
+		hipLaunchKernelGGL(k_decouple, dim3(B.n_packets), dim3(LW_BLOCK), 0, st, T, B, skip_mask);
+	const size_t lds = (size_t)max_n * sizeof(float) + LW_XSTRIDE * 3 + 16;
+	hipLaunchKernelGGL(k_imdct_generic, dim3(B.n_packets * T.ch), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
+			any_coupling ? 1 : 0, skip_mask);
+	const dim3 g(B.n_packets * T.ch), b(LW_BLOCK);
+	if (fmt == LW_OUT_I16_PLANAR)
+		hipLaunchKernelGGL(k_ola_generic<LW_OUT_I16_PLANAR>, g, b, 0, st, T, B, out, skip_mask);
+	else if (fmt == LW_OUT_I16_INTERLEAVED)
+		hipLaunchKernelGGL(k_ola_generic<LW_OUT_I16_INTERLEAVED>, g, b, 0, st, T, B, out, skip_mask);
+	else
+		hipLaunchKernelGGL(k_ola_generic<LW_OUT_F32_PLANAR>, g, b, 0, st, T, B, out, skip_mask);
+}
+
+bool lw_fast_supported(const LwDevTables &, uint32_t, uint32_t)
+{
+	return false; // lw_kernels_long.hip replaces this when present
+}

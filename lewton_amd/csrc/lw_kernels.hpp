@@ -1,0 +1,49 @@
+// Device-side tables and kernel launchers of the audio-packet synthesis path (gfx950).
+#pragma once
+
+#include "lw_records.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// CachedBlocksizeDerived (header_cached.rs:19-110) in HBM; computed on the host, never on the device.
+struct LwDevBs {
+	const float *A, *B, *C, *window;
+	const uint32_t *bitrev;
+	uint32_t bs, n;
+};
+
+#define LW_XSTRIDE 66 // u16 entries per floor in floor_x (LW_MAX_POSTS + 1)
+
+struct LwDevTables {
+	LwDevBs bs[2];
+	const float *inv_db;          // FLOOR1_INVERSE_DB_TABLE, audio.rs:437-501
+	const uint16_t *floor_x;      // [n_floors][LW_XSTRIDE] ascending x of each floor-1 config (header.rs:887-889)
+	const uint8_t *floor_F;       // [n_floors] post count
+	const uint8_t *mode_floor;    // [n_modes][ch] floor index of each channel (mapping_mux -> submap floor)
+	const uint16_t *couple_off;   // [n_modes + 1] offsets (in steps) into `couple`
+	const uint8_t *couple;        // (magnitude, angle) channel pairs in header order (audio.rs:990-1002 walks them reversed)
+	const uint8_t *sid;           // fast path: [n_floors][2][n_max/2] static interval index per bin (may be null)
+	uint32_t ch, fstride, n_modes, n_floors;
+	uint32_t state_stride;        // floats per (slot, parity): ch * (n1 / 2)
+	uint32_t state_chan_stride;   // n1 / 2
+};
+
+enum LwOutFmt { LW_OUT_I16_PLANAR = 0, LW_OUT_I16_INTERLEAVED = 1, LW_OUT_F32_PLANAR = 2 };
+
+struct LwBatchDev {
+	const LwPacketRec *recs;
+	const uint16_t *floors;
+	const float *residue;
+	float *decoupled; // scratch [same layout as residue]
+	float *td;        // scratch: per packet [ch][n] time-domain blocks at float offset 2 * res_off
+	float *state;     // state pool [slots][2][ch][n1/2]
+	uint32_t n_packets;
+};
+
+// Generic path (any block size 64..8192, any window shape, any channel count / coupling list).
+void lw_launch_generic(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, float *tap_spec, hipStream_t st,
+		uint32_t max_n, bool any_coupling, bool include_fast);
+
+// Specialised long-block path; returns false if this build has no kernel for the stream shape.
+bool lw_fast_supported(const LwDevTables &T, uint32_t bs1, uint32_t ch);

@@ -1,0 +1,46 @@
+// GPU-stage input records: what the host entropy stage hands to the HIP kernels.
+// Plain-old-data shared by host (lw_entropy.cpp, lw_device.hip host code) and device code.
+//
+// Per batch, in HBM (structure of arrays):
+//   recs    [n_packets]                 LwPacketRec, 32 B each
+//   floor   [n_packets][ch][fstride]    u16 per floor-1 post in ascending-x order:
+//                                       bits 0-7 = final_y * multiplier (<= 255), bit 15 = post is active
+//                                       (step2 flag); entry 0 == 0xFFFF marks an unused floor (audio.rs:66-70)
+//   residue [sum over packets ch*n/2]   f32, per packet [ch][n/2], BEFORE inverse coupling
+//                                       (the vectors of audio.rs:957-986, type-2 already de-interleaved)
+// Algorithmic bytes per packet: ch*(n/2)*4 + ch*F*2 + 16 in, ch*m*2 out.
+#pragma once
+
+#include <stdint.h>
+
+#define LW_MAX_POSTS 65       // header.rs:873
+#define LW_FLOOR_UNUSED 0xFFFFu
+#define LW_POST_ACTIVE 0x8000u
+
+// rec.flags
+#define LW_RF_LONG 1u          // mode blockflag
+#define LW_RF_SLOPE_BS1 2u     // overlap window slope comes from blocksize_1 (left_n_use_bs1, audio.rs:1058-1064)
+#define LW_RF_SKIP 4u          // packet failed in the entropy stage: no device work, no output
+#define LW_RF_FAST 8u          // handled by the specialised long-block kernel
+
+struct LwPacketRec {
+	uint32_t res_off;   // float offset of this packet's [ch][n/2] residue block
+	uint32_t floor_off; // u16 offset of this packet's [ch][fstride] floor block
+	uint32_t out_off;   // element offset of this packet's output block
+	int32_t prev;       // >= 0: batch index of the previous packet of the same stream; -1: no state
+	                    // (0 samples out); <= -2: state slot -(prev + 2), read buffer parity in `flags` bit 7
+	int32_t state_out;  // state slot that receives cur[rs..re) (written to the parity NOT being read), or -1
+	uint16_t ls, rs;    // left_win_start, right_win_start (audio.rs:1058-1073)
+	uint16_t re, plen;  // right_win_end; per-channel length of the stored right part to overlap (0 = none)
+	uint8_t bs;         // log2(n)
+	uint8_t mode;       // mode number
+	uint8_t flags;      // LW_RF_*; bit 6: state_out parity, bit 7: state-in parity
+	uint8_t reserved;
+};                      // samples per channel = (prev == -1) ? 0 : rs - ls
+
+#ifdef __cplusplus
+static_assert(sizeof(LwPacketRec) == 32, "LwPacketRec must stay 32 bytes");
+#endif
+
+#define LW_RF_PARITY_OUT 64u
+#define LW_RF_PARITY_IN 128u

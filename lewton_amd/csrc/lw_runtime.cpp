@@ -1,0 +1,997 @@
+// Runtime + C ABI of the MI355X audio-packet decode path (product code, compiled with hipcc).
+//
+// Implements include/lewton_amd.h: header objects, the device context (tables in HBM), the
+// device-resident PreviousWindowRight pool, batches with pinned staging, and the drop-in
+// single-packet call.  There is no CPU fallback for the synthesis stage: without a usable GPU every
+// device call returns LW_ERR_DEVICE.
+#include "../../include/lewton_amd.h"
+
+#include "lw_entropy.hpp"
+#include "lw_host.hpp"
+#include "lw_kernels.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#define LW_ERR_UNSUPPORTED_STREAM LW_AUDIO_BAD_FORMAT
+
+namespace {
+
+thread_local std::string g_dev_err;
+
+bool hip_ok(hipError_t e, const char *what)
+{
+	if (e == hipSuccess)
+		return true;
+	g_dev_err = std::string(what) + ": " + hipGetErrorString(e);
+	(void)hipGetLastError();
+	return false;
+}
+
+#define HIP_TRY(expr)                        \
+	do {                                     \
+		if (!hip_ok((expr), #expr))          \
+			return LW_ERR_DEVICE;            \
+	} while (0)
+
+extern const float kInverseDbTable[256];
+
+} // namespace
+
+struct lw_ident {
+	std::shared_ptr<lw::Ident> p;
+};
+struct lw_setup {
+	std::shared_ptr<lw::Setup> p;
+};
+struct lw_comment {
+	std::unique_ptr<lw::Comment> p;
+};
+
+struct lw_decoder {
+	std::shared_ptr<lw::Ident> id;
+	std::shared_ptr<lw::Setup> setup;
+	int device = 0;
+	LwDevTables T{};
+	void *d_blob = nullptr; // one allocation holding every table
+	bool any_coupling = false;
+	uint32_t max_posts = 2;
+	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
+	std::mutex mu;
+	float *d_state = nullptr;
+	size_t state_cap = 0;
+	std::vector<int> free_slots;
+	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
+	void *one_out = nullptr; // pinned host output for the single-packet path
+	size_t one_out_bytes = 0;
+};
+
+struct lw_pwr {
+	lw_decoder *dec = nullptr;
+	int slot = -1;
+	bool present = false;
+	uint32_t len = 0;   // per-channel length
+	uint8_t parity = 0; // which of the two buffers holds the valid state
+};
+
+struct lw_batch {
+	lw_decoder *dec = nullptr;
+	size_t max_packets = 0;
+	int fmt = 0;
+	LwPacketRec *h_recs = nullptr;
+	uint16_t *h_floor = nullptr;
+	float *h_res = nullptr;
+	LwPacketRec *d_recs = nullptr;
+	uint16_t *d_floor = nullptr;
+	float *d_res = nullptr;
+	float *d_decoupled = nullptr, *d_td = nullptr, *d_tap = nullptr;
+	void *d_out = nullptr;
+	size_t d_out_elems = 0;
+	size_t n = 0, res_floats = 0, out_elems = 0;
+	uint32_t max_n = 0;
+	bool has_generic = false, has_fast = false, force_generic = false;
+	std::vector<lw_packet_result> results;
+	uint64_t alg_bytes = 0;
+	std::string last_kernels;
+	std::vector<lw::Prologue> prologues;
+	std::vector<int> status;
+	std::vector<int32_t> slot_last; // per state slot: last ok packet index in this batch (-1 none)
+	std::vector<uint32_t> slot_seen; // per state slot: epoch of the batch that last touched it
+	uint32_t epoch = 0;
+	std::vector<lw_pwr *> touched;
+};
+
+namespace {
+
+size_t elem_size(int fmt)
+{
+	return fmt == LW_FMT_F32_PLANAR ? 4 : 2;
+}
+
+int decoder_set_device(const lw_decoder *d)
+{
+	HIP_TRY(hipSetDevice(d->device));
+	return LW_OK;
+}
+
+// grow the state pool to at least `slots` (caller holds d->mu)
+int grow_state(lw_decoder *d, size_t slots)
+{
+	if (slots <= d->state_cap)
+		return LW_OK;
+	size_t cap = std::max<size_t>(slots, d->state_cap ? d->state_cap * 2 : 64);
+	const size_t per = (size_t)2 * d->T.state_stride;
+	float *nb = nullptr;
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMalloc((void **)&nb, cap * per * sizeof(float)));
+	if (d->d_state) {
+		HIP_TRY(hipMemcpy(nb, d->d_state, d->state_cap * per * sizeof(float), hipMemcpyDeviceToDevice));
+		(void)hipFree(d->d_state);
+	}
+	for (size_t s = cap; s-- > d->state_cap;)
+		d->free_slots.push_back((int)s);
+	d->d_state = nb;
+	d->state_cap = cap;
+	return LW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *lw_version(void)
+{
+	return "lewton_amd 0.1 (gfx950)";
+}
+
+const char *lw_last_device_error(void)
+{
+	return g_dev_err.c_str();
+}
+
+// ---- headers ----------------------------------------------------------------------------------
+lw_ident *lw_read_header_ident(const uint8_t *packet, size_t len, int *err)
+{
+	int e = 0;
+	if (!packet) {
+		if (err)
+			*err = LW_ERR_NULL_ARG;
+		return nullptr;
+	}
+	auto p = lw::read_header_ident(packet, len, e);
+	if (err)
+		*err = e;
+	if (!p)
+		return nullptr;
+	auto *h = new lw_ident;
+	h->p = std::move(p);
+	return h;
+}
+
+int lw_ident_get_info(const lw_ident *id, lw_ident_info *out)
+{
+	if (!id || !out)
+		return LW_ERR_NULL_ARG;
+	out->audio_channels = id->p->channels;
+	out->audio_sample_rate = id->p->sample_rate;
+	out->bitrate_maximum = id->p->br_max;
+	out->bitrate_nominal = id->p->br_nom;
+	out->bitrate_minimum = id->p->br_min;
+	out->blocksize_0 = id->p->bs0;
+	out->blocksize_1 = id->p->bs1;
+	return LW_OK;
+}
+
+void lw_ident_free(lw_ident *id)
+{
+	delete id;
+}
+
+lw_setup *lw_read_header_setup(const uint8_t *packet, size_t len, uint8_t ch, uint8_t bs0, uint8_t bs1, int *err)
+{
+	int e = 0;
+	if (!packet) {
+		if (err)
+			*err = LW_ERR_NULL_ARG;
+		return nullptr;
+	}
+	auto p = lw::read_header_setup(packet, len, ch, bs0, bs1, e);
+	if (err)
+		*err = e;
+	if (!p)
+		return nullptr;
+	auto *h = new lw_setup;
+	h->p = std::move(p);
+	return h;
+}
+
+void lw_setup_free(lw_setup *s)
+{
+	delete s;
+}
+
+lw_comment *lw_read_header_comment(const uint8_t *packet, size_t len, int *err)
+{
+	int e = 0;
+	if (!packet) {
+		if (err)
+			*err = LW_ERR_NULL_ARG;
+		return nullptr;
+	}
+	auto p = lw::read_header_comment(packet, len, e);
+	if (err)
+		*err = e;
+	if (!p)
+		return nullptr;
+	auto *h = new lw_comment;
+	h->p = std::move(p);
+	return h;
+}
+
+const char *lw_comment_vendor(const lw_comment *c, size_t *len)
+{
+	if (len)
+		*len = c->p->vendor.size();
+	return c->p->vendor.data();
+}
+
+size_t lw_comment_count(const lw_comment *c)
+{
+	return c->p->list.size();
+}
+
+int lw_comment_get(const lw_comment *c, size_t i, const char **key, size_t *key_len, const char **val, size_t *val_len)
+{
+	if (!c || i >= c->p->list.size())
+		return LW_ERR_CAPACITY;
+	*key = c->p->list[i].first.data();
+	*key_len = c->p->list[i].first.size();
+	*val = c->p->list[i].second.data();
+	*val_len = c->p->list[i].second.size();
+	return LW_OK;
+}
+
+void lw_comment_free(lw_comment *c)
+{
+	delete c;
+}
+
+int lw_get_decoded_sample_count(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len, size_t *count)
+{
+	if (!id || !s || !packet || !count)
+		return LW_ERR_NULL_ARG;
+	return lw::decoded_sample_count(*id->p, *s->p, packet, len, *count);
+}
+
+static uint32_t floor_stride_of(const lw::Setup &s)
+{
+	uint32_t mp = 2;
+	for (const auto &fl : s.floors)
+		if (fl.type == 1)
+			mp = std::max<uint32_t>(mp, (uint32_t)fl.f1.x_list.size());
+	return (mp + 1) & ~1u;
+}
+
+uint32_t lw_setup_floor_stride(const lw_setup *s)
+{
+	return s ? floor_stride_of(*s->p) : 0;
+}
+
+int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len, uint16_t *floor_out,
+		float *residue_out, size_t residue_cap_floats, uint8_t *blocksize_log2, uint8_t *mode, uint8_t *flags,
+		uint64_t *bits_consumed)
+{
+	if (!id || !s || !packet || !floor_out || !residue_out)
+		return LW_ERR_NULL_ARG;
+	lw::BitReader br(packet, len);
+	lw::Prologue p;
+	int rc = lw::read_prologue(*id->p, *s->p, br, p);
+	if (rc)
+		return rc;
+	if ((size_t)id->p->channels * (p.n / 2) > residue_cap_floats)
+		return LW_ERR_CAPACITY;
+	lw::EntropyScratch scr;
+	rc = lw::entropy_decode(*id->p, *s->p, packet, len, p, floor_out, floor_stride_of(*s->p), residue_out, scr,
+			bits_consumed);
+	if (blocksize_log2)
+		*blocksize_log2 = p.bs;
+	if (mode)
+		*mode = p.mode;
+	if (flags)
+		*flags = (uint8_t)((p.blockflag ? 1 : 0) | (p.prev_flag ? 2 : 0) | (p.next_flag ? 4 : 0));
+	return rc;
+}
+
+int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bits, size_t bits_len, uint32_t *syms,
+		size_t max_syms, size_t *n_syms)
+{
+	lw::Huffman h;
+	const int rc = (int)h.build(lengths, n_entries);
+	if (rc)
+		return rc;
+	if (bits && syms && n_syms) {
+		lw::BitReader r(bits, bits_len);
+		size_t k = 0;
+		while (k < max_syms) {
+			uint32_t sym;
+			if (!h.decode(r, sym))
+				break;
+			syms[k++] = sym;
+		}
+		*n_syms = k;
+	}
+	return 0;
+}
+
+// ---- device context -------------------------------------------------------------------------
+int lw_device_count(void)
+{
+	int n = 0;
+	if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount"))
+		return 0;
+	return n;
+}
+
+lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int device, int *err)
+{
+	int dummy;
+	if (!err)
+		err = &dummy;
+	*err = LW_OK;
+	if (!idh || !sh) {
+		*err = LW_ERR_NULL_ARG;
+		return nullptr;
+	}
+	const lw::Ident &id = *idh->p;
+	const lw::Setup &s = *sh->p;
+	for (const auto &fl : s.floors) {
+		if (fl.type != 1) {
+			// floor 0 is "next" row f4 of the scope table; refuse loudly instead of decoding wrongly
+			*err = LW_ERR_UNSUPPORTED_STREAM;
+			g_dev_err = "floor type 0 streams are not supported by the device path yet";
+			return nullptr;
+		}
+	}
+	for (const auto &m : s.mappings)
+		if (m.mux.size() != id.channels) {
+			*err = LW_ERR_STATE_MISMATCH;
+			return nullptr;
+		}
+	int ndev = 0;
+	if (!hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || device < 0 || device >= ndev ||
+			!hip_ok(hipSetDevice(device), "hipSetDevice")) {
+		if (g_dev_err.empty())
+			g_dev_err = "no such HIP device";
+		*err = LW_ERR_DEVICE;
+		return nullptr;
+	}
+	auto d = std::make_unique<lw_decoder>();
+	d->id = idh->p;
+	d->setup = sh->p;
+	d->device = device;
+
+	// ---- build one blob with all tables
+	std::vector<uint8_t> blob;
+	auto put = [&](const void *p, size_t bytes) {
+		const size_t off = (blob.size() + 255) & ~(size_t)255;
+		blob.resize(off + bytes);
+		std::memcpy(blob.data() + off, p, bytes);
+		return off;
+	};
+	size_t offA[2], offB[2], offC[2], offW[2], offR[2];
+	for (int b = 0; b < 2; b++) {
+		const lw::BlocksizeTables &t = id.tab[b];
+		offA[b] = put(t.A.data(), t.A.size() * 4);
+		offB[b] = put(t.B.data(), t.B.size() * 4);
+		offC[b] = put(t.C.data(), t.C.size() * 4);
+		offW[b] = put(t.window.data(), t.window.size() * 4);
+		offR[b] = put(t.bitrev.data(), t.bitrev.size() * 4);
+	}
+	const size_t off_db = put(kInverseDbTable, sizeof(float) * 256);
+	const size_t nfl = s.floors.size(), nmodes = s.modes.size(), ch = id.channels;
+	std::vector<uint16_t> fx(nfl * LW_XSTRIDE, 0);
+	std::vector<uint8_t> fF(nfl, 0);
+	for (size_t f = 0; f < nfl; f++) {
+		const lw::Floor1 &f1 = s.floors[f].f1;
+		fF[f] = (uint8_t)f1.sorted_x.size();
+		d->max_posts = std::max<uint32_t>(d->max_posts, (uint32_t)f1.sorted_x.size());
+		for (size_t i = 0; i < f1.sorted_x.size(); i++)
+			fx[f * LW_XSTRIDE + i] = (uint16_t)std::min<uint32_t>(f1.sorted_x[i], 65535u);
+	}
+	std::vector<uint8_t> mode_floor(nmodes * ch, 0);
+	std::vector<uint16_t> couple_off(nmodes + 1, 0);
+	std::vector<uint8_t> couple;
+	for (size_t m = 0; m < nmodes; m++) {
+		const lw::Mapping &mp = s.mappings[s.modes[m].mapping];
+		for (size_t c = 0; c < ch; c++)
+			mode_floor[m * ch + c] = mp.submap_floor[mp.mux[c]];
+		couple_off[m] = (uint16_t)(couple.size() / 2);
+		for (size_t k = 0; k < mp.mag.size(); k++) {
+			couple.push_back(mp.mag[k]);
+			couple.push_back(mp.ang[k]);
+		}
+		if (!mp.mag.empty())
+			d->any_coupling = true;
+	}
+	couple_off[nmodes] = (uint16_t)(couple.size() / 2);
+	if (couple.empty())
+		couple.push_back(0);
+	const size_t off_fx = put(fx.data(), fx.size() * 2);
+	const size_t off_fF = put(fF.data(), fF.size());
+	const size_t off_mf = put(mode_floor.data(), mode_floor.size());
+	const size_t off_co = put(couple_off.data(), couple_off.size() * 2);
+	const size_t off_cp = put(couple.data(), couple.size());
+
+	if (!hip_ok(hipMalloc(&d->d_blob, blob.size()), "hipMalloc(tables)") ||
+			!hip_ok(hipMemcpy(d->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(tables)")) {
+		*err = LW_ERR_DEVICE;
+		if (d->d_blob)
+			(void)hipFree(d->d_blob);
+		return nullptr;
+	}
+	const uint8_t *base = (const uint8_t *)d->d_blob;
+	for (int b = 0; b < 2; b++) {
+		d->T.bs[b].A = (const float *)(base + offA[b]);
+		d->T.bs[b].B = (const float *)(base + offB[b]);
+		d->T.bs[b].C = (const float *)(base + offC[b]);
+		d->T.bs[b].window = (const float *)(base + offW[b]);
+		d->T.bs[b].bitrev = (const uint32_t *)(base + offR[b]);
+		d->T.bs[b].bs = b ? id.bs1 : id.bs0;
+		d->T.bs[b].n = 1u << d->T.bs[b].bs;
+	}
+	d->T.inv_db = (const float *)(base + off_db);
+	d->T.floor_x = (const uint16_t *)(base + off_fx);
+	d->T.floor_F = base + off_fF;
+	d->T.mode_floor = base + off_mf;
+	d->T.couple_off = (const uint16_t *)(base + off_co);
+	d->T.couple = base + off_cp;
+	d->T.sid = nullptr;
+	d->T.ch = (uint32_t)ch;
+	d->T.fstride = floor_stride_of(s);
+	d->T.n_modes = (uint32_t)nmodes;
+	d->T.n_floors = (uint32_t)nfl;
+	d->T.state_chan_stride = (1u << id.bs1) / 2;
+	d->T.state_stride = d->T.ch * d->T.state_chan_stride;
+	return d.release();
+}
+
+void lw_decoder_destroy(lw_decoder *d)
+{
+	if (!d)
+		return;
+	(void)hipSetDevice(d->device);
+	(void)hipDeviceSynchronize();
+	if (d->one)
+		lw_batch_destroy(d->one);
+	if (d->one_out)
+		(void)hipHostFree(d->one_out);
+	if (d->d_state)
+		(void)hipFree(d->d_state);
+	if (d->d_blob)
+		(void)hipFree(d->d_blob);
+	delete d;
+}
+
+// ---- PreviousWindowRight ----------------------------------------------------------------------
+lw_pwr *lw_pwr_new(lw_decoder *d)
+{
+	if (!d)
+		return nullptr;
+	std::lock_guard<std::mutex> g(d->mu);
+	if (hipSetDevice(d->device) != hipSuccess)
+		return nullptr;
+	if (d->free_slots.empty() && grow_state(d, d->state_cap + 1) != LW_OK)
+		return nullptr;
+	auto *p = new lw_pwr;
+	p->dec = d;
+	p->slot = d->free_slots.back();
+	d->free_slots.pop_back();
+	return p;
+}
+
+int lw_pwr_is_empty(const lw_pwr *p)
+{
+	return p ? !p->present : 1;
+}
+
+void lw_pwr_reset(lw_pwr *p)
+{
+	if (p) {
+		p->present = false;
+		p->len = 0;
+	}
+}
+
+size_t lw_pwr_len(const lw_pwr *p)
+{
+	return (p && p->present) ? p->len : 0;
+}
+
+lw_pwr *lw_pwr_clone(const lw_pwr *p)
+{
+	if (!p)
+		return nullptr;
+	lw_pwr *q = lw_pwr_new(p->dec);
+	if (!q)
+		return nullptr;
+	q->present = p->present;
+	q->len = p->len;
+	q->parity = p->parity;
+	if (p->present) {
+		lw_decoder *d = p->dec;
+		std::lock_guard<std::mutex> g(d->mu);
+		const size_t per = (size_t)2 * d->T.state_stride;
+		if (!hip_ok(hipDeviceSynchronize(), "sync") ||
+				!hip_ok(hipMemcpy(d->d_state + (size_t)q->slot * per, d->d_state + (size_t)p->slot * per,
+							per * sizeof(float), hipMemcpyDeviceToDevice),
+					"hipMemcpy(state clone)")) {
+			q->present = false;
+		}
+	}
+	return q;
+}
+
+void lw_pwr_free(lw_pwr *p)
+{
+	if (!p)
+		return;
+	{
+		std::lock_guard<std::mutex> g(p->dec->mu);
+		p->dec->free_slots.push_back(p->slot);
+	}
+	delete p;
+}
+
+int lw_pwr_copy_to_host(const lw_pwr *p, float *dst)
+{
+	if (!p || !dst)
+		return LW_ERR_NULL_ARG;
+	if (!p->present)
+		return LW_ERR_CAPACITY;
+	lw_decoder *d = p->dec;
+	if (int rc = decoder_set_device(d))
+		return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	const float *src = d->d_state + ((size_t)p->slot * 2 + p->parity) * d->T.state_stride;
+	HIP_TRY(hipMemcpy2D(dst, p->len * sizeof(float), src, d->T.state_chan_stride * sizeof(float), p->len * sizeof(float),
+				d->T.ch, hipMemcpyDeviceToHost));
+	return LW_OK;
+}
+
+// ---- batches ----------------------------------------------------------------------------------
+lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
+{
+	int dummy;
+	if (!err)
+		err = &dummy;
+	*err = LW_OK;
+	if (!d || max_packets == 0 || fmt < 0 || fmt > 2) {
+		*err = LW_ERR_NULL_ARG;
+		return nullptr;
+	}
+	if (decoder_set_device(d)) {
+		*err = LW_ERR_DEVICE;
+		return nullptr;
+	}
+	auto b = std::make_unique<lw_batch>();
+	b->dec = d;
+	b->max_packets = max_packets;
+	b->fmt = fmt;
+	const size_t ch = d->T.ch, half1 = d->T.state_chan_stride;
+	const size_t rec_b = max_packets * sizeof(LwPacketRec);
+	const size_t fl_b = max_packets * ch * d->T.fstride * sizeof(uint16_t);
+	const size_t res_b = max_packets * ch * half1 * sizeof(float);
+	bool ok = hip_ok(hipHostMalloc((void **)&b->h_recs, rec_b), "hipHostMalloc(recs)") &&
+		hip_ok(hipHostMalloc((void **)&b->h_floor, fl_b), "hipHostMalloc(floor)") &&
+		hip_ok(hipHostMalloc((void **)&b->h_res, res_b), "hipHostMalloc(residue)") &&
+		hip_ok(hipMalloc((void **)&b->d_recs, rec_b), "hipMalloc(recs)") &&
+		hip_ok(hipMalloc((void **)&b->d_floor, fl_b), "hipMalloc(floor)") &&
+		hip_ok(hipMalloc((void **)&b->d_res, res_b), "hipMalloc(residue)");
+	if (!ok) {
+		*err = LW_ERR_DEVICE;
+		lw_batch_destroy(b.release());
+		return nullptr;
+	}
+	b->results.resize(max_packets);
+	b->prologues.resize(max_packets);
+	b->status.resize(max_packets);
+	return b.release();
+}
+
+void lw_batch_destroy(lw_batch *b)
+{
+	if (!b)
+		return;
+	(void)hipSetDevice(b->dec->device);
+	(void)hipDeviceSynchronize();
+	if (b->h_recs)
+		(void)hipHostFree(b->h_recs);
+	if (b->h_floor)
+		(void)hipHostFree(b->h_floor);
+	if (b->h_res)
+		(void)hipHostFree(b->h_res);
+	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_decoupled, b->d_td, b->d_tap, b->d_out};
+	for (void *p : dev)
+		if (p)
+			(void)hipFree(p);
+	delete b;
+}
+
+void lw_batch_set_force_generic(lw_batch *b, int on)
+{
+	if (b)
+		b->force_generic = on != 0;
+}
+
+size_t lw_batch_size(const lw_batch *b)
+{
+	return b ? b->n : 0;
+}
+
+size_t lw_batch_out_elems(const lw_batch *b)
+{
+	return b ? b->out_elems : 0;
+}
+
+const lw_packet_result *lw_batch_results(const lw_batch *b)
+{
+	return b ? b->results.data() : nullptr;
+}
+
+uint64_t lw_batch_algorithmic_bytes(const lw_batch *b)
+{
+	return b ? b->alg_bytes : 0;
+}
+
+const char *lw_batch_last_kernels(const lw_batch *b)
+{
+	return b ? b->last_kernels.c_str() : "";
+}
+
+int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads)
+{
+	if (!b || (!pkts && n))
+		return LW_ERR_NULL_ARG;
+	if (n > b->max_packets)
+		return LW_ERR_CAPACITY;
+	lw_decoder *d = b->dec;
+	const lw::Ident &id = *d->id;
+	const lw::Setup &s = *d->setup;
+	const size_t ch = d->T.ch, fstride = d->T.fstride;
+	b->n = n;
+
+	// pass 1 (sequential, cheap): prologues -> block sizes -> residue offsets
+	size_t res_off = 0;
+	uint32_t max_n = 0;
+	for (size_t i = 0; i < n; i++) {
+		LwPacketRec &r = b->h_recs[i];
+		std::memset(&r, 0, sizeof(r));
+		r.prev = -1;
+		r.state_out = -1;
+		r.floor_off = (uint32_t)(i * ch * fstride);
+		r.res_off = (uint32_t)res_off;
+		if (!pkts[i].data || !pkts[i].pwr) {
+			b->status[i] = LW_ERR_NULL_ARG;
+			continue;
+		}
+		if (pkts[i].pwr->dec != d) {
+			b->status[i] = LW_ERR_STATE_MISMATCH;
+			continue;
+		}
+		lw::BitReader br(pkts[i].data, pkts[i].len);
+		b->status[i] = lw::read_prologue(id, s, br, b->prologues[i]);
+		if (b->status[i] == LW_OK) {
+			res_off += ch * (b->prologues[i].n / 2);
+			max_n = std::max(max_n, b->prologues[i].n);
+		}
+	}
+	b->res_floats = res_off;
+	b->max_n = max_n;
+
+	// pass 2 (parallel): entropy decode straight into the pinned staging buffers
+	unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+	nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n / 8));
+	std::atomic<size_t> next{0};
+	auto worker = [&]() {
+		lw::EntropyScratch scr;
+		for (;;) {
+			const size_t i0 = next.fetch_add(16);
+			if (i0 >= n)
+				break;
+			for (size_t i = i0; i < std::min(n, i0 + 16); i++) {
+				if (b->status[i] != LW_OK)
+					continue;
+				LwPacketRec &r = b->h_recs[i];
+				b->status[i] = lw::entropy_decode(id, s, pkts[i].data, pkts[i].len, b->prologues[i],
+						b->h_floor + r.floor_off, (unsigned)fstride, b->h_res + r.res_off, scr);
+			}
+		}
+	};
+	if (nt <= 1) {
+		worker();
+	} else {
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < nt; t++)
+			th.emplace_back(worker);
+		for (auto &t : th)
+			t.join();
+	}
+
+	// pass 3 (sequential): window geometry, state hand-over, output offsets, error semantics
+	if (b->slot_last.size() < d->state_cap) {
+		b->slot_last.assign(d->state_cap, -1);
+		b->slot_seen.assign(d->state_cap, 0);
+	}
+	b->epoch++;
+	b->touched.clear();
+	size_t out_off = 0;
+	uint64_t alg = 0;
+	const size_t esz = elem_size(b->fmt);
+	b->has_generic = b->has_fast = false;
+	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
+	for (size_t i = 0; i < n; i++) {
+		LwPacketRec &r = b->h_recs[i];
+		lw_packet_result &res = b->results[i];
+		res.status = b->status[i];
+		res.n_samples = 0;
+		res.out_offset = out_off;
+		r.out_off = (uint32_t)out_off;
+		if (b->status[i] != LW_OK) {
+			r.flags = LW_RF_SKIP;
+			continue;
+		}
+		lw_pwr *pw = pkts[i].pwr;
+		const lw::Prologue &p = b->prologues[i];
+		const lw::WindowInfo w = lw::window_info(id, p.blockflag, p.prev_flag, p.next_flag);
+		r.bs = p.bs;
+		r.mode = p.mode;
+		r.ls = (uint16_t)w.left_start;
+		r.rs = (uint16_t)w.right_start;
+		r.re = (uint16_t)w.right_end;
+		r.flags = (p.blockflag ? LW_RF_LONG : 0) | (w.left_use_bs1 ? LW_RF_SLOPE_BS1 : 0);
+		if (b->slot_seen[pw->slot] != b->epoch) {
+			b->slot_seen[pw->slot] = b->epoch;
+			b->touched.push_back(pw);
+		}
+		if (pw->present) {
+			const uint32_t slope_len = w.left_use_bs1 ? n1h : n0h;
+			if (slope_len < pw->len) {
+				// audio.rs:1107-1111: error after pwr.data.take() -> the state is gone
+				pw->present = false;
+				pw->len = 0;
+				b->slot_last[pw->slot] = -1;
+				res.status = b->status[i] = LW_AUDIO_BAD_FORMAT;
+				r.flags = LW_RF_SKIP;
+				continue;
+			}
+			r.plen = (uint16_t)pw->len;
+			const int32_t last = b->slot_last[pw->slot];
+			if (last >= 0) {
+				r.prev = last;
+			} else {
+				r.prev = -(pw->slot + 2);
+				if (pw->parity)
+					r.flags |= LW_RF_PARITY_IN;
+			}
+			res.n_samples = w.right_start - w.left_start;
+		} else {
+			r.prev = -1; // audio.rs:1140-1152: no previous window -> zero samples
+			r.plen = 0;
+		}
+		pw->present = true;
+		pw->len = w.right_end - w.right_start;
+		b->slot_last[pw->slot] = (int32_t)i;
+		out_off += (size_t)res.n_samples * ch;
+		alg += (uint64_t)ch * (p.n / 2) * 4 + 16 + (uint64_t)res.n_samples * ch * esz;
+		for (size_t c = 0; c < ch; c++) {
+			const lw::Mapping &mp = s.mappings[s.modes[p.mode].mapping];
+			alg += (uint64_t)s.floors[mp.submap_floor[mp.mux[c]]].f1.x_list.size() * 2;
+		}
+		b->has_generic = true;
+	}
+	// the last ok packet of every stream hands its right part to the stream's state slot
+	for (lw_pwr *pw : b->touched) {
+		const int32_t last = b->slot_last[pw->slot];
+		if (last >= 0) {
+			LwPacketRec &r = b->h_recs[last];
+			r.state_out = pw->slot;
+			const uint8_t outp = pw->parity ^ 1;
+			if (outp)
+				r.flags |= LW_RF_PARITY_OUT;
+			pw->parity = outp;
+		}
+		b->slot_last[pw->slot] = -1;
+	}
+	b->out_elems = out_off;
+	b->alg_bytes = alg;
+	return LW_OK;
+}
+
+int lw_batch_upload(lw_batch *b, void *hip_stream)
+{
+	if (!b)
+		return LW_ERR_NULL_ARG;
+	if (int rc = decoder_set_device(b->dec))
+		return rc;
+	hipStream_t st = (hipStream_t)hip_stream;
+	const size_t ch = b->dec->T.ch;
+	if (b->n == 0)
+		return LW_OK;
+	HIP_TRY(hipMemcpyAsync(b->d_recs, b->h_recs, b->n * sizeof(LwPacketRec), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(b->d_floor, b->h_floor, b->n * ch * b->dec->T.fstride * sizeof(uint16_t),
+				hipMemcpyHostToDevice, st));
+	if (b->res_floats)
+		HIP_TRY(hipMemcpyAsync(b->d_res, b->h_res, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
+	return LW_OK;
+}
+
+static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_generic, float *tap)
+{
+	lw_decoder *d = b->dec;
+	if (b->n == 0)
+		return LW_OK;
+	if (b->has_generic || all_generic) {
+		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
+		if (d->any_coupling && !b->d_decoupled)
+			HIP_TRY(hipMalloc((void **)&b->d_decoupled, maxres * sizeof(float)));
+		if (!b->d_td)
+			HIP_TRY(hipMalloc((void **)&b->d_td, 2 * maxres * sizeof(float)));
+	}
+	LwBatchDev B{};
+	B.recs = b->d_recs;
+	B.floors = b->d_floor;
+	B.residue = b->d_res;
+	B.decoupled = b->d_decoupled;
+	B.td = b->d_td;
+	B.state = d->d_state;
+	B.n_packets = (uint32_t)b->n;
+	b->last_kernels.clear();
+	if (b->has_generic || all_generic) {
+		lw_launch_generic(d->T, B, d_out, b->fmt, tap, st, b->max_n, d->any_coupling, all_generic);
+		b->last_kernels = d->any_coupling ? "k_decouple,k_imdct_generic,k_ola_generic" : "k_imdct_generic,k_ola_generic";
+	}
+	HIP_TRY(hipGetLastError());
+	return LW_OK;
+}
+
+int lw_batch_synth(lw_batch *b, void *d_out, size_t out_capacity_elems, void *hip_stream)
+{
+	if (!b || (!d_out && b->out_elems))
+		return LW_ERR_NULL_ARG;
+	if (out_capacity_elems < b->out_elems)
+		return LW_ERR_CAPACITY;
+	if (int rc = decoder_set_device(b->dec))
+		return rc;
+	return batch_launch(b, d_out, (hipStream_t)hip_stream, b->force_generic, nullptr);
+}
+
+static int ensure_internal_out(lw_batch *b)
+{
+	if (b->d_out_elems >= b->out_elems && b->d_out)
+		return LW_OK;
+	if (b->d_out)
+		(void)hipFree(b->d_out);
+	b->d_out = nullptr;
+	const size_t cap = std::max<size_t>(b->out_elems, b->max_packets * b->dec->T.ch * b->dec->T.state_chan_stride);
+	HIP_TRY(hipMalloc(&b->d_out, cap * elem_size(b->fmt)));
+	b->d_out_elems = cap;
+	return LW_OK;
+}
+
+int lw_batch_synth_to_host(lw_batch *b, void *h_out, size_t out_capacity_elems, void *hip_stream)
+{
+	if (!b || (!h_out && b->out_elems))
+		return LW_ERR_NULL_ARG;
+	if (out_capacity_elems < b->out_elems)
+		return LW_ERR_CAPACITY;
+	if (int rc = decoder_set_device(b->dec))
+		return rc;
+	if (int rc = ensure_internal_out(b))
+		return rc;
+	hipStream_t st = (hipStream_t)hip_stream;
+	if (int rc = batch_launch(b, b->d_out, st, b->force_generic, nullptr))
+		return rc;
+	if (b->out_elems)
+		HIP_TRY(hipMemcpyAsync(h_out, b->d_out, b->out_elems * elem_size(b->fmt), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	return LW_OK;
+}
+
+int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats)
+{
+	if (!b || !dst)
+		return LW_ERR_NULL_ARG;
+	if (idx >= b->n || b->status[idx] != LW_OK)
+		return LW_ERR_CAPACITY;
+	lw_decoder *d = b->dec;
+	if (int rc = decoder_set_device(d))
+		return rc;
+	const LwPacketRec &r = b->h_recs[idx];
+	const size_t n = (size_t)1 << r.bs, ch = d->T.ch;
+	const size_t want = tap == LW_TAP_POST_MDCT ? ch * n : ch * n / 2;
+	if (cap_floats < want)
+		return LW_ERR_CAPACITY;
+	if (tap == LW_TAP_RESIDUE_PRE_INVERSE) {
+		std::memcpy(dst, b->h_res + r.res_off, want * sizeof(float));
+		return LW_OK;
+	}
+	if (int rc = ensure_internal_out(b))
+		return rc;
+	if (!b->d_tap)
+		HIP_TRY(hipMalloc((void **)&b->d_tap, b->max_packets * ch * d->T.state_chan_stride * sizeof(float)));
+	if (int rc = batch_launch(b, b->d_out, nullptr, true, b->d_tap))
+		return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	const float *src;
+	if (tap == LW_TAP_RESIDUE_POST_INVERSE)
+		src = (d->any_coupling ? b->d_decoupled : b->d_res) + r.res_off;
+	else if (tap == LW_TAP_PRE_MDCT)
+		src = b->d_tap + r.res_off;
+	else
+		src = b->d_td + 2 * (size_t)r.res_off;
+	HIP_TRY(hipMemcpy(dst, src, want * sizeof(float), hipMemcpyDeviceToHost));
+	return LW_OK;
+}
+
+// ---- one packet ---------------------------------------------------------------------------------
+int lw_read_audio_packet(lw_decoder *d, const uint8_t *packet, size_t len, lw_pwr *pwr, int fmt, void *out,
+		size_t cap_per_channel, size_t *n_samples)
+{
+	if (!d || !packet || !pwr || !out || !n_samples)
+		return LW_ERR_NULL_ARG;
+	if (pwr->dec != d)
+		return LW_ERR_STATE_MISMATCH;
+	if (fmt < 0 || fmt > 2)
+		return LW_ERR_NULL_ARG;
+	if (int rc = decoder_set_device(d))
+		return rc;
+	if (!d->one || d->one->fmt != fmt) {
+		if (d->one)
+			lw_batch_destroy(d->one);
+		int e = 0;
+		d->one = lw_batch_create(d, 1, fmt, &e);
+		if (!d->one)
+			return e ? e : LW_ERR_DEVICE;
+	}
+	lw_batch *b = d->one;
+	lw_packet pk{packet, len, pwr};
+	if (int rc = lw_batch_entropy(b, &pk, 1, 1))
+		return rc;
+	const lw_packet_result &res = b->results[0];
+	if (res.status != LW_OK)
+		return res.status;
+	if (res.n_samples > cap_per_channel)
+		return LW_AUDIO_BUFFER_NOT_ADDRESSABLE;
+	if (int rc = lw_batch_upload(b, nullptr))
+		return rc;
+	const size_t need = std::max<size_t>(b->out_elems, 1) * elem_size(fmt);
+	if (d->one_out_bytes < need) {
+		if (d->one_out)
+			(void)hipHostFree(d->one_out);
+		d->one_out = nullptr;
+		HIP_TRY(hipHostMalloc(&d->one_out, std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4)));
+		d->one_out_bytes = std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4);
+	}
+	if (int rc = lw_batch_synth_to_host(b, d->one_out, b->out_elems, nullptr))
+		return rc;
+	std::memcpy(out, d->one_out, b->out_elems * elem_size(fmt));
+	*n_samples = res.n_samples;
+	return LW_OK;
+}
+
+} // extern "C"
+
+namespace {
+// FLOOR1_INVERSE_DB_TABLE: the Vorbis I specification's floor1_inverse_dB_table (spec 10.1; audio.rs:437-501).
+// The spec defines it by value; entry i is approximately 1.0649863e-07 * exp(i * 0.06264...) but decoders must
+// use the printed constants.
+const float kInverseDbTable[256] = {
+#include "lw_inverse_db.inc"
+};
+} // namespace

@@ -470,6 +470,18 @@ LONG_X = [93, 23, 372, 6, 46, 186, 750, 14, 33, 65, 130, 260, 556, 3, 10, 18, 28
 SHORT_X = [14, 4, 58, 2, 8, 28, 90]
 
 
+def _scale_x(base, base_half, half):
+    """Scale a post list made for `base_half` spectral lines to `half` lines, keeping values distinct and in (0, half)."""
+    out, seen = [], {0, half}
+    for x in base:
+        v = x * half // base_half
+        if v in seen or v <= 0 or v >= half:
+            continue
+        seen.add(v)
+        out.append(v)
+    return out
+
+
 def _std_books():
     """Shared codebook set. Returns (list, index dict)."""
     books, idx = [], {}
@@ -522,8 +534,8 @@ def stereo_setup(sample_rate: int = 44100, bs0: int = 8, bs1: int = 11, residue_
     """2 ch, bs 8/11 (the sizes of lewton's ident-header test, src/header.rs:264-276)."""
     books, ix = _std_books()
     n0h, n1h = (1 << bs0) // 2, (1 << bs1) // 2
-    fl_short = _floor1(SHORT_X, bs0 - 1, 4, ix["y16"], ix["master8"], ix["y16"])
-    fl_long = _floor1(LONG_X, bs1 - 1, 2, ix["y16"], ix["master8"], ix["y32"])
+    fl_short = _floor1(_scale_x(SHORT_X, 128, n0h), bs0 - 1, 4, ix["y16"], ix["master8"], ix["y16"])
+    fl_long = _floor1(_scale_x(LONG_X, 1024, n1h), bs1 - 1, 2, ix["y16"], ix["master8"], ix["y32"])
     mulch = 2 if residue_type == 2 else 1
     rs_short = Residue(residue_type, 0, mulch * (n0h * 13 // 16), 16, 4, ix["class16"], _res_books(ix))
     rs_long = Residue(residue_type, 0, mulch * 800 * n1h // 1024, 32, 4, ix["class16"], _res_books(ix))
@@ -537,8 +549,8 @@ def surround51_setup(sample_rate: int = 48000, bs0: int = 8, bs1: int = 11) -> S
     coupling steps (0,2),(3,4) applied in reverse order at decode (BASELINE config 4)."""
     books, ix = _std_books()
     n0h, n1h = (1 << bs0) // 2, (1 << bs1) // 2
-    fl_short = _floor1(SHORT_X, bs0 - 1, 4, ix["y16"], ix["master8"], ix["y16"])
-    fl_long = _floor1(LONG_X, bs1 - 1, 2, ix["y16"], ix["master8"], ix["y32"])
+    fl_short = _floor1(_scale_x(SHORT_X, 128, n0h), bs0 - 1, 4, ix["y16"], ix["master8"], ix["y16"])
+    fl_long = _floor1(_scale_x(LONG_X, 1024, n1h), bs1 - 1, 2, ix["y16"], ix["master8"], ix["y32"])
     fl_lfe_s = _floor1([16, 64, 32], bs0 - 1, 1, ix["y32"], ix["master8"], ix["y16"])
     fl_lfe_l = _floor1([64, 16, 256, 128, 32, 512], bs1 - 1, 1, ix["y32"], ix["master8"], ix["y16"])
     rs = [

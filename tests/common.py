@@ -1,0 +1,55 @@
+"""Shared helpers for the test-suite: stream fixtures and a numpy model of the floor record."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from lewton_amd import streamgen as sg  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+SETUPS = {
+    "stereo": lambda: sg.stereo_setup(),
+    "stereo_t1": lambda: sg.stereo_setup(residue_type=1),
+    "surround51": lambda: sg.surround51_setup(),
+    "mono_small": lambda: sg.mono_setup(),
+    "stereo_9_12": lambda: sg.stereo_setup(bs0=9, bs1=12),
+    "stereo_6_13": lambda: sg.stereo_setup(bs0=6, bs1=13),
+    "stereo_7_7": lambda: sg.stereo_setup(bs0=7, bs1=7),
+}
+
+
+def oracle_headers(setup):
+    idp, cmt, stp = setup.headers()
+    ident = po.Ident(idp)
+    return ident, po.Setup(stp, ident)
+
+
+def floor_x_sorted(setup, mode, channel):
+    mp = setup.mappings[setup.modes[mode].mapping]
+    fl = setup.floors[mp.submap_floor[mp.mux[channel]]]
+    return sorted(fl.x_list)
+
+
+def floor_from_record(rec, xs, n2, inv_db):
+    """numpy model of the device floor rendering: record (u16 per ascending-x post) -> n2 floor values.
+    Closed form of render_line; an unused floor gives zeros (audio.rs:1021-1024)."""
+    if rec[0] == 0xFFFF:
+        return np.zeros(n2, np.float32)
+    F = len(xs)
+    act = [(xs[i], int(rec[i] & 0xFF)) for i in range(F) if rec[i] & 0x8000]
+    y = np.zeros(n2, np.int64)
+    for (x0, y0), (x1, y1) in zip(act[:-1], act[1:]):
+        if x0 >= n2:
+            break
+        k = np.arange(x0, min(x1, n2))
+        dy, adx = y1 - y0, x1 - x0
+        off = (abs(dy) * (k - x0)) // adx
+        y[x0:min(x1, n2)] = y0 - off if dy < 0 else y0 + off
+    lx, ly = act[-1]
+    if lx < n2:
+        y[lx:] = ly
+    return inv_db[y].astype(np.float32)

@@ -1,0 +1,190 @@
+"""CPU tests of the product's HOST side (C++ headers + entropy stage) against the oracle and the
+reference's known answers.  No GPU needed: these run in `-m "not gpu"`."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import ROOT, SETUPS, floor_from_record, floor_x_sorted, oracle_headers, po, sg
+from lewton_amd import _native as N
+from lewton_amd import audio, header
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lewton_amd.h")).read()
+    declared = set(re.findall(r"\b(lw_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    for name in sorted(declared):
+        assert hasattr(N.lib, name), name
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+
+
+def test_ident_header_golden():
+    # src/header.rs:262-276
+    idh = header.read_header_ident(bytes(G["ident_header"]["packet"]))
+    for k, v in G["ident_header"]["fields"].items():
+        assert getattr(idh, k) == v
+    with pytest.raises(header.HeaderReadError) as e:
+        header.read_header_ident(bytes(G["ident_header_bad_capture"]))
+    assert e.value.kind == "NotVorbisHeader"
+
+
+def _pack(cws):
+    bits = []
+    for path, ln in cws:
+        bits += [(path >> (ln - 1 - i)) & 1 for i in range(ln)]
+    out = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        out[i >> 3] |= b << (i & 7)
+    return bytes(out)
+
+
+def test_huffman_golden():
+    # src/huffman_tree.rs:396-486 through the product's decoder
+    for h in G["huffman"]:
+        lengths = (C.c_uint8 * len(h["lengths"]))(*h["lengths"])
+        cws = h["codewords"]
+        data = _pack([(p, l) for p, l, _ in cws])
+        syms = (C.c_uint32 * (len(cws) + 4))()
+        n = C.c_size_t(0)
+        rc = N.lw_huffman_check(lengths, len(h["lengths"]), data, len(data), syms, len(cws), C.byref(n))
+        if h["valid"] is True:
+            assert rc == 0
+            assert [syms[i] for i in range(n.value)] == [v for _, _, v in cws]
+        elif h["valid"] is False:
+            assert rc != 0
+
+
+def test_huffman_product_vs_oracle_random():
+    rng = np.random.default_rng(5)
+    L = po.lib()
+    for trial in range(300):
+        n = int(rng.integers(1, 40))
+        if trial % 3 == 0:
+            lens = np.array(sg.huffman_lengths(rng.random(n) ** 3 + 1e-3, 32), np.uint8)
+            if trial % 6 == 0 and n > 2:
+                lens[rng.integers(0, n)] = int(rng.integers(0, 6))  # usually breaks completeness
+        else:
+            lens = rng.integers(0, 7, n).astype(np.uint8)
+        arr = (C.c_uint8 * n)(*lens.tolist())
+        bits = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+        s1, s2 = (C.c_uint32 * 600)(), (C.c_uint32 * 600)()
+        n1, n2 = C.c_size_t(0), C.c_size_t(0)
+        r1 = L.lwo_huffman_check(arr, n, bits, len(bits), s1, 600, C.byref(n1))
+        r2 = N.lw_huffman_check(arr, n, bits, len(bits), s2, 600, C.byref(n2))
+        assert (r1 == 0) == (r2 == 0), (lens, r1, r2)
+        if r1 == 0 and lens.astype(bool).sum() > 0:
+            assert n1.value == n2.value and list(s1[: n1.value]) == list(s2[: n2.value]), lens
+
+
+@pytest.mark.parametrize("name", sorted(SETUPS))
+def test_headers_parse_like_oracle(name):
+    setup = SETUPS[name]()
+    idp, cmt, stp = setup.headers()
+    ident = header.read_header_ident(idp)
+    assert (ident.audio_channels, ident.audio_sample_rate, ident.blocksize_0, ident.blocksize_1) == \
+        (setup.channels, setup.sample_rate, setup.bs0, setup.bs1)
+    header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    oracle_headers(setup)
+    c = header.read_header_comment(cmt)
+    assert c.vendor == "lewton_amd streamgen" and c.comment_list == [("TITLE", "synthetic")]
+    # truncations and bit flips must fail the same way in both parsers
+    rng = np.random.default_rng(1)
+    for trial in range(40):
+        bad = bytearray(stp)
+        if trial % 2:
+            bad = bad[: int(rng.integers(8, len(bad)))]
+        else:
+            for _ in range(3):
+                bad[int(rng.integers(7, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        e1 = e2 = 0
+        try:
+            po.Setup(bytes(bad), po.Ident(idp))
+        except po.OracleError as e:
+            e1 = e.code
+        try:
+            header.read_header_setup(bytes(bad), ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+        except header.HeaderReadError as e:
+            e2 = e.code
+        assert (e1 == 0) == (e2 == 0), (trial, e1, e2)
+
+
+PATTERNS = {"stereo": "LLSSSSSSSSL", "stereo_t1": "LSLLS", "surround51": "LLSSL", "mono_small": "LSSLLSL",
+            "stereo_9_12": "LLSL", "stereo_6_13": "LSSL", "stereo_7_7": "LSLL"}
+
+
+@pytest.mark.parametrize("name", sorted(SETUPS))
+def test_entropy_stage_matches_oracle(name):
+    setup = SETUPS[name]()
+    idp, _, stp = setup.headers()
+    o_id, o_st = oracle_headers(setup)
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    pkts = sg.make_stream(setup, PATTERNS[name], 24, seed=11, p_floor_unused=0.15)
+    inv_db = po.inverse_db_table()
+    L = po.lib()
+    L.lwo_debug_bits_consumed.restype = C.c_size_t
+    pwr = po.Pwr()
+    rng = np.random.default_rng(2)
+    for i, p in enumerate(pkts):
+        if i % 5 == 4:  # truncated packet: "end of packet is normal" paths (audio.rs:655-660)
+            p = p[: max(1, int(rng.integers(1, max(2, len(p)))))]
+        assert audio.get_decoded_sample_count(ident, st, p) == po.get_decoded_sample_count(o_id, o_st, p)
+        try:
+            out, taps = po.read_audio_packet(o_id, o_st, p, pwr, "f32", taps=True)
+            o_rc = 0
+        except po.OracleError as e:
+            o_rc = e.code
+        try:
+            rec = audio.entropy_decode_host(ident, st, p)
+            rc = 0
+        except audio.AudioReadError as e:
+            rc = e.code
+        assert rc == o_rc, (i, rc, o_rc)
+        if rc:
+            continue
+        assert rec["bits"] == L.lwo_debug_bits_consumed()
+        n = taps["n"]
+        assert 1 << rec["bs"] == n
+        assert np.array_equal(rec["residue"].view(np.uint32), taps["residue_pre_inverse"].view(np.uint32))
+        for c in range(setup.channels):
+            fl = floor_from_record(rec["floor"][c], floor_x_sorted(setup, rec["mode"], c), n // 2, inv_db)
+            spec = fl * taps["residue_post_inverse"][c]
+            assert np.array_equal(spec.view(np.uint32), taps["pre_mdct"][c].view(np.uint32)), (i, c)
+
+
+def test_entropy_stage_corrupted_packets():
+    setup = SETUPS["stereo"]()
+    idp, _, stp = setup.headers()
+    o_id, o_st = oracle_headers(setup)
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, 2, (8, 11))
+    pkts = sg.make_stream(setup, "LLSSL", 10, seed=3)
+    rng = np.random.default_rng(9)
+    n_ok = 0
+    for trial in range(200):
+        p = bytearray(pkts[trial % len(pkts)])
+        for _ in range(int(rng.integers(1, 6))):
+            p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8))
+        p = bytes(p)
+        pwr = po.Pwr()
+        try:
+            _, taps = po.read_audio_packet(o_id, o_st, p, pwr, "f32", taps=True)
+            o_rc = 0
+        except po.OracleError as e:
+            o_rc = e.code
+        try:
+            rec = audio.entropy_decode_host(ident, st, p)
+            rc = 0
+        except audio.AudioReadError as e:
+            rc = e.code
+        assert rc == o_rc
+        if rc == 0:
+            n_ok += 1
+            assert np.array_equal(rec["residue"].view(np.uint32), taps["residue_pre_inverse"].view(np.uint32))
+    assert n_ok > 50
