@@ -174,6 +174,11 @@ const char *lw_batch_last_kernels(const lw_batch *b);
 int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bits, size_t bits_len,
 		uint32_t *syms, size_t max_syms, size_t *n_syms);
 
+/* Test hook: run the device IMDCT (src/imdct.rs:291) of block size blocksize_0 (blockflag 0) or blocksize_1
+ * (blockflag 1) on `spectrum` (n/2 floats) and return the n time-domain values.  Implemented as a packet
+ * record with a unit floor (inverse-dB index 255 = 1.0) through the generic kernels. */
+int lw_debug_imdct(lw_decoder *d, int blockflag, const float *spectrum, float *out);
+
 /* Library/version introspection */
 const char *lw_version(void);
 

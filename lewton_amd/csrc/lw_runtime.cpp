@@ -939,6 +939,62 @@ int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats
 	return LW_OK;
 }
 
+int lw_debug_imdct(lw_decoder *d, int blockflag, const float *spectrum, float *out)
+{
+	if (!d || !spectrum || !out)
+		return LW_ERR_NULL_ARG;
+	if (int rc = decoder_set_device(d))
+		return rc;
+	const lw::Setup &s = *d->setup;
+	int mode = -1;
+	for (size_t m = 0; m < s.modes.size(); m++)
+		if ((int)s.modes[m].blockflag == (blockflag ? 1 : 0))
+			mode = (int)m;
+	if (mode < 0)
+		return LW_ERR_CAPACITY;
+	int e = 0;
+	lw_batch *b = lw_batch_create(d, 1, LW_FMT_F32_PLANAR, &e);
+	if (!b)
+		return e ? e : LW_ERR_DEVICE;
+	const uint32_t bs = blockflag ? d->id->bs1 : d->id->bs0, n = 1u << bs, ch = d->T.ch;
+	LwPacketRec &r = b->h_recs[0];
+	std::memset(&r, 0, sizeof(r));
+	r.prev = -1;
+	r.state_out = -1;
+	r.bs = (uint8_t)bs;
+	r.mode = (uint8_t)mode;
+	r.flags = blockflag ? LW_RF_LONG : 0;
+	r.rs = (uint16_t)(n / 2);
+	r.re = (uint16_t)(n / 2); // nothing to hand over
+	std::memset(b->h_res, 0, sizeof(float) * ch * n / 2);
+	std::memcpy(b->h_res, spectrum, sizeof(float) * n / 2);
+	const lw::Mapping &mp = s.mappings[s.modes[mode].mapping];
+	for (uint32_t c = 0; c < ch; c++) {
+		uint16_t *rec = b->h_floor + c * d->T.fstride;
+		const size_t F = s.floors[mp.submap_floor[mp.mux[c]]].f1.x_list.size();
+		for (size_t i = 0; i < F; i++)
+			rec[i] = 0;
+		rec[0] = LW_POST_ACTIVE | 255u;     // x = 0
+		rec[F - 1] = LW_POST_ACTIVE | 255u; // largest x; beyond it the curve stays flat
+	}
+	b->n = 1;
+	b->res_floats = (size_t)ch * n / 2;
+	b->max_n = n;
+	b->out_elems = 0;
+	b->status[0] = LW_OK;
+	int rc = lw_batch_upload(b, nullptr);
+	if (!rc)
+		rc = ensure_internal_out(b);
+	if (!rc)
+		rc = batch_launch(b, b->d_out, nullptr, true, nullptr);
+	if (!rc && !hip_ok(hipDeviceSynchronize(), "sync"))
+		rc = LW_ERR_DEVICE;
+	if (!rc && !hip_ok(hipMemcpy(out, b->d_td, sizeof(float) * n, hipMemcpyDeviceToHost), "memcpy td"))
+		rc = LW_ERR_DEVICE;
+	lw_batch_destroy(b);
+	return rc;
+}
+
 // ---- one packet ---------------------------------------------------------------------------------
 int lw_read_audio_packet(lw_decoder *d, const uint8_t *packet, size_t len, lw_pwr *pwr, int fmt, void *out,
 		size_t cap_per_channel, size_t *n_samples)
