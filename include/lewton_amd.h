@@ -179,6 +179,11 @@ int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bi
  * record with a unit floor (inverse-dB index 255 = 1.0) through the generic kernels. */
 int lw_debug_imdct(lw_decoder *d, int blockflag, const float *spectrum, float *out);
 
+/* Test hook (host only): the LDS table image of the specialised long-block kernel and its 16 section
+ * offsets (order of struct LwFastImage in csrc/lw_fast.hpp).  Returns the image size in bytes, 0 if the
+ * stream shape is not covered by that kernel; copies min(size, cap) bytes. */
+size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint32_t *offsets16);
+
 /* Library/version introspection */
 const char *lw_version(void);
 

@@ -1,0 +1,205 @@
+// Host side of the specialised long-block kernel: see lw_fast.hpp.  Product code.
+#include "lw_fast.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace lw {
+
+namespace {
+struct Writer {
+	std::vector<uint8_t> &buf;
+	uint32_t reserve(size_t bytes)
+	{
+		const size_t off = (buf.size() + 15) & ~(size_t)15;
+		buf.resize(off + bytes, 0);
+		return (uint32_t)off;
+	}
+	float *f(uint32_t off) { return reinterpret_cast<float *>(buf.data() + off); }
+	uint16_t *h(uint32_t off) { return reinterpret_cast<uint16_t *>(buf.data() + off); }
+};
+} // namespace
+
+void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
+{
+	plan = LwFastPlan();
+	if (id.bs1 != LW_FAST_BS) {
+		plan.why_not = "blocksize_1 is not 11";
+		return;
+	}
+	const uint32_t n = 1u << id.bs1, n2 = n / 2, n8 = n / 8;
+	const size_t ch = id.channels;
+	// every long mode must use the same mapping shape: same mux/floors/coupling
+	const Mapping *ref = nullptr;
+	for (size_t m = 0; m < s.modes.size() && m < 256; m++) {
+		if (!s.modes[m].blockflag)
+			continue;
+		const Mapping &mp = s.mappings[s.modes[m].mapping];
+		if (!ref) {
+			ref = &mp;
+		} else if (mp.mag != ref->mag || mp.ang != ref->ang || mp.mux != ref->mux || mp.submap_floor != ref->submap_floor) {
+			plan.why_not = "long modes with different mappings";
+			return;
+		}
+		plan.long_mode_mask[m >> 3] |= (uint8_t)(1u << (m & 7));
+	}
+	if (!ref) {
+		plan.why_not = "no long mode";
+		return;
+	}
+	// coupling steps must be disjoint pairs
+	std::vector<int> partner(ch, -1), role(ch, 0);
+	for (size_t k = 0; k < ref->mag.size(); k++) {
+		const int m = ref->mag[k], a = ref->ang[k];
+		if (partner[m] != -1 || partner[a] != -1) {
+			plan.why_not = "a channel takes part in more than one coupling step";
+			return;
+		}
+		partner[m] = a;
+		partner[a] = m;
+		role[m] = 1;
+		role[a] = 2;
+	}
+	// staged floors
+	std::vector<int> floor_slot(s.floors.size(), -1);
+	auto slot_of = [&](size_t c) -> int {
+		const uint8_t fl = ref->submap_floor[ref->mux[c]];
+		if (floor_slot[fl] < 0) {
+			if (plan.n_staged_floors == LW_FAST_MAX_FLOORS)
+				return -1;
+			const Floor1 &f1 = s.floors[fl].f1;
+			if (s.floors[fl].type != 1 || f1.sorted_x.size() > 64)
+				return -1;
+			floor_slot[fl] = (int)plan.n_staged_floors;
+			plan.staged_floor_F[plan.n_staged_floors++] = (uint8_t)f1.sorted_x.size();
+		}
+		return floor_slot[fl];
+	};
+	std::vector<bool> done(ch, false);
+	for (size_t c = 0; c < ch; c++) {
+		if (done[c])
+			continue;
+		LwFastUnit u{};
+		if (partner[c] >= 0) {
+			const int m = role[c] == 1 ? (int)c : partner[c], a = role[c] == 1 ? partner[c] : (int)c;
+			u.ch_a = (int8_t)m;
+			u.ch_b = (int8_t)a;
+			u.coupled = 1;
+			done[m] = done[a] = true;
+		} else {
+			u.ch_a = (int8_t)c;
+			u.ch_b = -1;
+			u.coupled = 0;
+			done[c] = true;
+		}
+		const int sa = slot_of((size_t)u.ch_a), sb = u.ch_b >= 0 ? slot_of((size_t)u.ch_b) : 0;
+		if (sa < 0 || sb < 0) {
+			plan.why_not = "more than two distinct floor configurations (or > 64 posts) in long blocks";
+			plan.units.clear();
+			return;
+		}
+		u.floor_a = (uint8_t)sa;
+		u.floor_b = (uint8_t)sb;
+		plan.units.push_back(u);
+	}
+	if (LW_FAST_WAVES % plan.units.size() != 0) {
+		plan.why_not = "unit count does not divide the workgroup";
+		return;
+	}
+
+	// ---- LDS image
+	const BlocksizeTables &t = id.tab[1];
+	const float *A = t.A.data(), *B = t.B.data(), *C = t.C.data(), *W = t.window.data();
+	Writer w{plan.image};
+	LwFastImage &o = plan.off;
+	o.apair = w.reserve(n2 * 4);
+	std::memcpy(w.f(o.apair), A, n2 * 4);
+	o.tw_s2 = w.reserve(4 * 64 * 8);
+	for (uint32_t x = 0; x < 4; x++)
+		for (uint32_t l = 0; l < 64; l++) {
+			const uint32_t p = 64 * x + l, a = n2 - 4 - 4 * p;
+			w.f(o.tw_s2)[2 * (64 * x + l)] = A[a];
+			w.f(o.tw_s2)[2 * (64 * x + l) + 1] = A[a + 1];
+		}
+	o.tw_l0 = w.reserve(2 * 64 * 8);
+	for (uint32_t b = 0; b < 2; b++)
+		for (uint32_t l = 0; l < 64; l++) {
+			const uint32_t r = 127 - 64 * b - l;
+			w.f(o.tw_l0)[2 * (64 * b + l)] = A[8 * r];
+			w.f(o.tw_l0)[2 * (64 * b + l) + 1] = A[8 * r + 1];
+		}
+	o.tw_l1 = w.reserve(64 * 8);
+	for (uint32_t l = 0; l < 64; l++) {
+		const uint32_t r = 63 - l;
+		w.f(o.tw_l1)[2 * l] = A[16 * r];
+		w.f(o.tw_l1)[2 * l + 1] = A[16 * r + 1];
+	}
+	o.tw_l2 = w.reserve(4 * 8 * 8);
+	for (uint32_t yy = 0; yy < 4; yy++)
+		for (uint32_t lo3 = 0; lo3 < 8; lo3++) {
+			const uint32_t r = 31 - (8 * yy + lo3);
+			w.f(o.tw_l2)[2 * (8 * yy + lo3)] = A[32 * r];
+			w.f(o.tw_l2)[2 * (8 * yy + lo3) + 1] = A[32 * r + 1];
+		}
+	o.tw_l3 = w.reserve(2 * 8 * 8);
+	for (uint32_t b = 0; b < 2; b++)
+		for (uint32_t lo3 = 0; lo3 < 8; lo3++) {
+			const uint32_t r = 15 - (8 * b + lo3);
+			w.f(o.tw_l3)[2 * (8 * b + lo3)] = A[64 * r];
+			w.f(o.tw_l3)[2 * (8 * b + lo3) + 1] = A[64 * r + 1];
+		}
+	o.tw_l4 = w.reserve(8 * 8);
+	for (uint32_t lo3 = 0; lo3 < 8; lo3++) {
+		const uint32_t r = 7 - lo3;
+		w.f(o.tw_l4)[2 * lo3] = A[128 * r];
+		w.f(o.tw_l4)[2 * lo3 + 1] = A[128 * r + 1];
+	}
+	o.a2 = w.reserve(16);
+	w.f(o.a2)[0] = A[n8];
+	o.c4 = w.reserve(2 * 64 * 16);
+	o.b_lo = w.reserve(2 * 64 * 16);
+	o.b_hi = w.reserve(2 * 64 * 16);
+	o.win = w.reserve(2 * 64 * 32);
+	for (uint32_t c = 0; c < 2; c++)
+		for (uint32_t l = 0; l < 64; l++) {
+			const uint32_t mp = 2 * l + c, e = 64 * c + l;
+			for (uint32_t j = 0; j < 4; j++) {
+				w.f(o.c4)[4 * e + j] = C[4 * mp + j];
+				w.f(o.b_lo)[4 * e + j] = B[4 * mp + j];
+				w.f(o.b_hi)[4 * e + j] = B[4 * (255 - mp) + j];
+			}
+			const uint32_t q[4] = {511 - 2 * mp, 510 - 2 * mp, 1 + 2 * mp, 2 * mp};
+			for (uint32_t k = 0; k < 4; k++) {
+				w.f(o.win)[8 * e + 2 * k] = W[q[k]];
+				w.f(o.win)[8 * e + 2 * k + 1] = W[n2 - 1 - q[k]];
+			}
+		}
+	o.inv_db = w.reserve(256 * 4); // filled by the runtime (it owns the spec table)
+	o.xsf = w.reserve(LW_FAST_MAX_FLOORS * 64 * 4);
+	o.sid16 = w.reserve(LW_FAST_MAX_FLOORS * 4 * 64 * 4 * 2);
+	for (size_t fl = 0; fl < s.floors.size(); fl++) {
+		const int slot = floor_slot[fl];
+		if (slot < 0)
+			continue;
+		const Floor1 &f1 = s.floors[fl].f1;
+		const size_t F = f1.sorted_x.size();
+		for (size_t i = 0; i < 64; i++)
+			w.f(o.xsf)[64 * slot + i] = i < F ? (float)f1.sorted_x[i] : std::numeric_limits<float>::infinity();
+		for (uint32_t x = 0; x < 4; x++)
+			for (uint32_t l = 0; l < 64; l++)
+				for (uint32_t j = 0; j < 4; j++) {
+					const uint32_t k = 4 * (64 * x + l) + j;
+					size_t sidx = 0; // largest s with xs[s] <= k (xs[0] = 0)
+					while (sidx + 1 < F && f1.sorted_x[sidx + 1] <= k)
+						sidx++;
+					w.h(o.sid16)[((slot * 4 + x) * 64 + l) * 4 + j] = (uint16_t)(16 * sidx);
+				}
+	}
+	o.total = (uint32_t)((plan.image.size() + 15) & ~(size_t)15);
+	plan.image.resize(o.total, 0);
+	plan.eligible = true;
+}
+
+} // namespace lw

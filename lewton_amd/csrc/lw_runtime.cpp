@@ -7,6 +7,7 @@
 #include "../../include/lewton_amd.h"
 
 #include "lw_entropy.hpp"
+#include "lw_fast.hpp"
 #include "lw_host.hpp"
 #include "lw_kernels.hpp"
 
@@ -306,6 +307,22 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 	if (flags)
 		*flags = (uint8_t)((p.blockflag ? 1 : 0) | (p.prev_flag ? 2 : 0) | (p.next_flag ? 4 : 0));
 	return rc;
+}
+
+size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint32_t *offsets16)
+{
+	if (!id || !s)
+		return 0;
+	LwFastPlan plan;
+	lw::build_fast_plan(*id->p, *s->p, plan);
+	if (!plan.eligible)
+		return 0;
+	std::memcpy(plan.image.data() + plan.off.inv_db, kInverseDbTable, sizeof(float) * 256);
+	if (dst)
+		std::memcpy(dst, plan.image.data(), std::min(cap, plan.image.size()));
+	if (offsets16)
+		std::memcpy(offsets16, &plan.off, sizeof(uint32_t) * 16);
+	return plan.image.size();
 }
 
 int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bits, size_t bits_len, uint32_t *syms,

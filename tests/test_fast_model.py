@@ -1,0 +1,101 @@
+"""CPU tests of the specialised long-block kernel's design: the numpy lane model (tests/fast_model.py)
+fed with the product's LDS table image must reproduce the oracle bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fast_model as fm
+from common import SETUPS, floor_from_record, floor_x_sorted, oracle_headers, po, sg
+from lewton_amd import _native as N
+from lewton_amd import audio, header
+
+NAMES = ["apair", "tw_s2", "tw_l0", "tw_l1", "tw_l2", "tw_l3", "tw_l4", "a2", "c4", "b_lo", "b_hi", "win", "inv_db",
+         "xsf", "sid16", "total"]
+
+
+def _image(setup):
+    idp, _, stp = setup.headers()
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    offs = (C.c_uint32 * 16)()
+    size = N.lw_debug_fast_image(ident._h, st._h, None, 0, offs)
+    if size == 0:
+        return None, None, ident, st
+    buf = (C.c_uint8 * size)()
+    N.lw_debug_fast_image(ident._h, st._h, buf, size, offs)
+    return bytes(buf), dict(zip(NAMES, list(offs))), ident, st
+
+
+def test_fast_image_eligibility():
+    assert _image(SETUPS["stereo"]())[0] is not None
+    assert _image(SETUPS["surround51"]())[0] is not None
+    assert _image(SETUPS["stereo_9_12"]())[0] is None  # blocksize_1 != 11 -> generic kernels
+    blob, offs, _, _ = _image(SETUPS["stereo"]())
+    assert offs["total"] == len(blob) and len(blob) < 28 * 1024
+    assert all(offs[k] % 16 == 0 for k in NAMES)
+
+
+def test_lane_model_imdct_bit_exact():
+    blob, offs, _, _ = _image(SETUPS["stereo"]())
+    img = fm.Image(blob, offs)
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        x = (rng.standard_normal(1024) * (0.3 if trial else 1e-20)).astype(np.float32)
+        if trial == 3:
+            x[rng.integers(0, 1024, 900)] = 0.0
+        got = fm.imdct_wave(x, img)
+        want = po.inverse_mdct(x, 11)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_lds_slot_functions_are_bijections_and_conflict_free():
+    p = np.arange(512)
+    for f in (fm.slot_t2, fm.slot_t3, fm.slot_t4):
+        assert sorted(f(p).tolist()) == list(range(512))
+    lam = np.arange(64)
+    # reads of one ds_read_b64 instruction are serviced in two 32-lane halves over 32 bank pairs
+    for half in (lam[:32], lam[32:]):
+        for y in range(8):  # T2 read (layout C)
+            assert len(set((fm.slot_t2(64 * (half >> 3) + 8 * y + (half & 7)) % 32).tolist())) == 32
+        for z in range(8):  # T3 read (layout D)
+            assert len(set((fm.slot_t3(8 * half + z) % 32).tolist())) == 32
+        for c in range(2):  # T4 gather
+            q2 = 2 * fm.rev_bits(2 * half + c, 7)
+            for pp in (q2, q2 + 256, 255 - q2, 511 - q2):
+                assert len(set((fm.slot_t4(pp) % 32).tolist())) == 32
+
+
+def test_lane_model_floor_matches_oracle():
+    setup = SETUPS["stereo"]()
+    blob, offs, ident, st = _image(setup)
+    img = fm.Image(blob, offs)
+    o_id, o_st = oracle_headers(setup)
+    pkts = sg.make_stream(setup, "L", 12, seed=4, p_floor_unused=0.0)
+    pwr = po.Pwr()
+    for p in pkts:
+        _, taps = po.read_audio_packet(o_id, o_st, p, pwr, "f32", taps=True)
+        rec = audio.entropy_decode_host(ident, st, p)
+        for c in range(2):
+            xs = floor_x_sorted(setup, rec["mode"], c)
+            a = fm.floor_lane_model(rec["floor"][c], xs, img.inv_db)
+            b = floor_from_record(rec["floor"][c], xs, 1024, img.inv_db)
+            assert np.array_equal(a, b)
+            spec = a * taps["residue_post_inverse"][c]
+            assert np.array_equal(spec.view(np.uint32), taps["pre_mdct"][c].view(np.uint32))
+
+
+def test_floor_division_by_reciprocal_is_exact():
+    """trunc((t*dy +- 0.5) * fl(1/adx)) == trunc(t*dy/adx) for every segment the long-block kernel can meet:
+    0 <= t < adx <= 32768 (t < 1024 rendered), |dy| <= 255; checked exhaustively on a 1-ulp-perturbed reciprocal
+    as well (the device uses v_rcp_f32, 1 ulp)."""
+    t = np.arange(0, 1024, dtype=np.int64)
+    for adx in list(range(1, 1100)) + [2048, 4096, 8191, 32768]:
+        tt = t[t < adx] if adx < 1024 else t
+        for rinv in (np.float32(1.0) / np.float32(adx), np.nextafter(np.float32(1.0) / np.float32(adx), np.float32(2)),
+                     np.nextafter(np.float32(1.0) / np.float32(adx), np.float32(0))):
+            for dy in (-255, -254, -129, -3, -1, 0, 1, 2, 77, 128, 255):
+                z = (tt * dy).astype(np.float32) + np.float32(0.5 if dy >= 0 else -0.5)
+                q = np.trunc(z * rinv).astype(np.int64)
+                want = np.sign(dy) * ((tt * abs(dy)) // adx)
+                assert np.array_equal(q, want), (adx, dy)
