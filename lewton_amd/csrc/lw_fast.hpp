@@ -49,6 +49,23 @@ struct LwFastPlan {
 	uint8_t staged_floor_F[LW_FAST_MAX_FLOORS] = {0};
 };
 
+struct LwFastItem {
+	uint32_t pkt;  // index into the batch's records
+	uint32_t halo; // halo slot that holds (main pass) / receives (pre-pass) the predecessor's right half, or 0xFFFFFFFF
+};
+
+struct LwFastLaunch {
+	LwFastImage off;
+	const uint8_t *d_image;
+	const LwFastItem *d_items;
+	uint32_t n_items;
+	const LwFastItem *d_halo_items;
+	uint32_t n_halo_items;
+	uint32_t n_units;
+	LwFastUnit units[LW_FAST_WAVES];
+	float *d_halo;
+};
+
 namespace lw {
 // Decide whether the stream shape is covered by the specialised kernel and build its LDS image.
 void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan);

@@ -356,8 +356,8 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 	}
 }
 
-void lw_launch_generic(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, float *tap_spec, hipStream_t st,
-		uint32_t max_n, bool any_coupling, bool include_fast)
+void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
+		bool any_coupling, bool include_fast)
 {
 	if (B.n_packets == 0)
 		return;
@@ -367,6 +367,13 @@ void lw_launch_generic(const LwDevTables &T, const LwBatchDev &B, void *out, int
 	const size_t lds = (size_t)max_n * sizeof(float) + LW_XSTRIDE * 3 + 16;
 	hipLaunchKernelGGL(k_imdct_generic, dim3(B.n_packets * T.ch), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
 			any_coupling ? 1 : 0, skip_mask);
+}
+
+void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast)
+{
+	if (B.n_packets == 0)
+		return;
+	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
 	const dim3 g(B.n_packets * T.ch), b(LW_BLOCK);
 	if (fmt == LW_OUT_I16_PLANAR)
 		hipLaunchKernelGGL(k_ola_generic<LW_OUT_I16_PLANAR>, g, b, 0, st, T, B, out, skip_mask);
@@ -374,9 +381,4 @@ void lw_launch_generic(const LwDevTables &T, const LwBatchDev &B, void *out, int
 		hipLaunchKernelGGL(k_ola_generic<LW_OUT_I16_INTERLEAVED>, g, b, 0, st, T, B, out, skip_mask);
 	else
 		hipLaunchKernelGGL(k_ola_generic<LW_OUT_F32_PLANAR>, g, b, 0, st, T, B, out, skip_mask);
-}
-
-bool lw_fast_supported(const LwDevTables &, uint32_t, uint32_t)
-{
-	return false; // lw_kernels_long.hip replaces this when present
 }

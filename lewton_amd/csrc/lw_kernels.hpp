@@ -41,9 +41,13 @@ struct LwBatchDev {
 	uint32_t n_packets;
 };
 
-// Generic path (any block size 64..8192, any window shape, any channel count / coupling list).
-void lw_launch_generic(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, float *tap_spec, hipStream_t st,
-		uint32_t max_n, bool any_coupling, bool include_fast);
+// Generic path (any block size 64..8192, any window shape, any channel count / coupling list), two phases so
+// that the specialised kernel can run in between (it reads td blocks of generic predecessors and writes td
+// right halves for generic successors).
+void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
+		bool any_coupling, bool include_fast);
+void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast);
 
-// Specialised long-block path; returns false if this build has no kernel for the stream shape.
-bool lw_fast_supported(const LwDevTables &T, uint32_t bs1, uint32_t ch);
+// Specialised long-block path (lw_kernels_long.hip): optional halo pre-pass + main pass.
+struct LwFastLaunch;
+void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);

@@ -22,6 +22,7 @@
 #define LW_RF_SLOPE_BS1 2u     // overlap window slope comes from blocksize_1 (left_n_use_bs1, audio.rs:1058-1064)
 #define LW_RF_SKIP 4u          // packet failed in the entropy stage: no device work, no output
 #define LW_RF_FAST 8u          // handled by the specialised long-block kernel
+#define LW_RF_WRITE_TD 16u     // fast packet must also store its raw right half into its td block (generic successor)
 
 struct LwPacketRec {
 	uint32_t res_off;   // float offset of this packet's [ch][n/2] residue block

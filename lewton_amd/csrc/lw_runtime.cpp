@@ -68,6 +68,8 @@ struct lw_decoder {
 	float *d_state = nullptr;
 	size_t state_cap = 0;
 	std::vector<int> free_slots;
+	LwFastPlan fast;               // specialised long-block kernel: eligibility, units, LDS image
+	uint8_t *d_fast_image = nullptr;
 	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
 	void *one_out = nullptr; // pinned host output for the single-packet path
 	size_t one_out_bytes = 0;
@@ -94,6 +96,11 @@ struct lw_batch {
 	float *d_decoupled = nullptr, *d_td = nullptr, *d_tap = nullptr;
 	void *d_out = nullptr;
 	size_t d_out_elems = 0;
+	LwFastItem *h_items = nullptr, *d_items = nullptr;           // [max_packets] main pass
+	LwFastItem *h_halo_items = nullptr, *d_halo_items = nullptr; // [max_packets] halo pre-pass
+	float *d_halo = nullptr;
+	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
+	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
 	bool has_generic = false, has_fast = false, force_generic = false;
@@ -475,6 +482,17 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	d->T.n_floors = (uint32_t)nfl;
 	d->T.state_chan_stride = (1u << id.bs1) / 2;
 	d->T.state_stride = d->T.ch * d->T.state_chan_stride;
+	lw::build_fast_plan(id, s, d->fast);
+	if (d->fast.eligible) {
+		std::memcpy(d->fast.image.data() + d->fast.off.inv_db, kInverseDbTable, sizeof(float) * 256);
+		if (!hip_ok(hipMalloc((void **)&d->d_fast_image, d->fast.image.size()), "hipMalloc(fast image)") ||
+				!hip_ok(hipMemcpy(d->d_fast_image, d->fast.image.data(), d->fast.image.size(), hipMemcpyHostToDevice),
+					"hipMemcpy(fast image)")) {
+			*err = LW_ERR_DEVICE;
+			(void)hipFree(d->d_blob);
+			return nullptr;
+		}
+	}
 	return d.release();
 }
 
@@ -492,6 +510,8 @@ void lw_decoder_destroy(lw_decoder *d)
 		(void)hipFree(d->d_state);
 	if (d->d_blob)
 		(void)hipFree(d->d_blob);
+	if (d->d_fast_image)
+		(void)hipFree(d->d_fast_image);
 	delete d;
 }
 
@@ -609,7 +629,11 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		hip_ok(hipHostMalloc((void **)&b->h_res, res_b), "hipHostMalloc(residue)") &&
 		hip_ok(hipMalloc((void **)&b->d_recs, rec_b), "hipMalloc(recs)") &&
 		hip_ok(hipMalloc((void **)&b->d_floor, fl_b), "hipMalloc(floor)") &&
-		hip_ok(hipMalloc((void **)&b->d_res, res_b), "hipMalloc(residue)");
+		hip_ok(hipMalloc((void **)&b->d_res, res_b), "hipMalloc(residue)") &&
+		hip_ok(hipHostMalloc((void **)&b->h_items, max_packets * sizeof(LwFastItem)), "hipHostMalloc(items)") &&
+		hip_ok(hipHostMalloc((void **)&b->h_halo_items, max_packets * sizeof(LwFastItem)), "hipHostMalloc(halo items)") &&
+		hip_ok(hipMalloc((void **)&b->d_items, max_packets * sizeof(LwFastItem)), "hipMalloc(items)") &&
+		hip_ok(hipMalloc((void **)&b->d_halo_items, max_packets * sizeof(LwFastItem)), "hipMalloc(halo items)");
 	if (!ok) {
 		*err = LW_ERR_DEVICE;
 		lw_batch_destroy(b.release());
@@ -633,7 +657,11 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_floor);
 	if (b->h_res)
 		(void)hipHostFree(b->h_res);
-	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_decoupled, b->d_td, b->d_tap, b->d_out};
+	if (b->h_items)
+		(void)hipHostFree(b->h_items);
+	if (b->h_halo_items)
+		(void)hipHostFree(b->h_halo_items);
+	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -747,6 +775,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	b->epoch++;
 	b->touched.clear();
+	b->fast_idx.clear();
+	b->fast_slot.clear();
 	size_t out_off = 0;
 	uint64_t alg = 0;
 	const size_t esz = elem_size(b->fmt);
@@ -801,6 +831,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			r.prev = -1; // audio.rs:1140-1152: no previous window -> zero samples
 			r.plen = 0;
 		}
+		// specialised kernel: long block, both neighbours long, stored right part (if any) is a full long half
+		if (d->fast.eligible && !b->force_generic && p.blockflag && p.prev_flag && p.next_flag &&
+				(d->fast.long_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) && (r.prev == -1 || r.plen == n1h)) {
+			r.flags |= LW_RF_FAST;
+			b->fast_idx.push_back((uint32_t)i);
+			b->fast_slot.push_back((uint32_t)pw->slot);
+		}
 		pw->present = true;
 		pw->len = w.right_end - w.right_start;
 		b->slot_last[pw->slot] = (int32_t)i;
@@ -810,7 +847,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			const lw::Mapping &mp = s.mappings[s.modes[p.mode].mapping];
 			alg += (uint64_t)s.floors[mp.submap_floor[mp.mux[c]]].f1.x_list.size() * 2;
 		}
-		b->has_generic = true;
+		if (!(r.flags & LW_RF_FAST))
+			b->has_generic = true;
 	}
 	// the last ok packet of every stream hands its right part to the stream's state slot
 	for (lw_pwr *pw : b->touched) {
@@ -827,6 +865,39 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	b->out_elems = out_off;
 	b->alg_bytes = alg;
+
+	// ---- work plan of the specialised kernel: items sorted by stream so that consecutive packets of a
+	// stream sit in consecutive waves; a predecessor outside the workgroup is recomputed by the halo pre-pass
+	b->n_items = b->n_halo_items = 0;
+	b->has_fast = !b->fast_idx.empty();
+	if (b->has_fast) {
+		const size_t nf = b->fast_idx.size();
+		b->fast_order.resize(nf);
+		for (size_t k = 0; k < nf; k++)
+			b->fast_order[k] = (uint32_t)k;
+		std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
+				[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
+		const uint32_t per_wg = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
+		for (size_t k = 0; k < nf; k++) {
+			const uint32_t idx = b->fast_idx[b->fast_order[k]];
+			const LwPacketRec &r = b->h_recs[idx];
+			LwFastItem it{idx, 0xFFFFFFFFu};
+			if (r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST)) {
+				const bool in_wg = (k % per_wg) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev;
+				if (!in_wg) {
+					it.halo = (uint32_t)b->n_halo_items;
+					b->h_halo_items[b->n_halo_items++] = LwFastItem{(uint32_t)r.prev, it.halo};
+				}
+			}
+			b->h_items[k] = it;
+		}
+		b->n_items = nf;
+		for (size_t i = 0; i < n; i++) { // generic successors of fast packets read the td block
+			const LwPacketRec &r = b->h_recs[i];
+			if (!(r.flags & (LW_RF_SKIP | LW_RF_FAST)) && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
+				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
+		}
+	}
 	return LW_OK;
 }
 
@@ -845,6 +916,10 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 				hipMemcpyHostToDevice, st));
 	if (b->res_floats)
 		HIP_TRY(hipMemcpyAsync(b->d_res, b->h_res, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
+	if (b->n_items)
+		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
+	if (b->n_halo_items)
+		HIP_TRY(hipMemcpyAsync(b->d_halo_items, b->h_halo_items, b->n_halo_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	return LW_OK;
 }
 
@@ -853,12 +928,24 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	lw_decoder *d = b->dec;
 	if (b->n == 0)
 		return LW_OK;
-	if (b->has_generic || all_generic) {
+	const bool run_generic = b->has_generic || all_generic;
+	const bool run_fast = b->has_fast && !all_generic;
+	if (run_generic) {
 		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
 		if (d->any_coupling && !b->d_decoupled)
 			HIP_TRY(hipMalloc((void **)&b->d_decoupled, maxres * sizeof(float)));
 		if (!b->d_td)
 			HIP_TRY(hipMalloc((void **)&b->d_td, 2 * maxres * sizeof(float)));
+	}
+	if (run_fast && b->n_halo_items > b->halo_cap) {
+		if (b->d_halo) {
+			HIP_TRY(hipStreamSynchronize(st));
+			(void)hipFree(b->d_halo);
+			b->d_halo = nullptr;
+		}
+		const size_t cap = std::max<size_t>(b->n_halo_items, 64);
+		HIP_TRY(hipMalloc((void **)&b->d_halo, cap * d->T.ch * 512 * sizeof(float)));
+		b->halo_cap = cap;
 	}
 	LwBatchDev B{};
 	B.recs = b->d_recs;
@@ -869,10 +956,31 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.state = d->d_state;
 	B.n_packets = (uint32_t)b->n;
 	b->last_kernels.clear();
-	if (b->has_generic || all_generic) {
-		lw_launch_generic(d->T, B, d_out, b->fmt, tap, st, b->max_n, d->any_coupling, all_generic);
-		b->last_kernels = d->any_coupling ? "k_decouple,k_imdct_generic,k_ola_generic" : "k_imdct_generic,k_ola_generic";
+	if (run_generic) {
+		lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic);
+		b->last_kernels = d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 	}
+	if (run_fast) {
+		LwFastLaunch L{};
+		L.off = d->fast.off;
+		L.d_image = d->d_fast_image;
+		L.d_items = b->d_items;
+		L.n_items = (uint32_t)b->n_items;
+		L.d_halo_items = b->d_halo_items;
+		L.n_halo_items = (uint32_t)b->n_halo_items;
+		L.n_units = (uint32_t)d->fast.units.size();
+		for (size_t i = 0; i < d->fast.units.size(); i++)
+			L.units[i] = d->fast.units[i];
+		L.d_halo = b->d_halo;
+		lw_launch_long(d->T, B, L, d_out, b->fmt, st);
+		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
+	}
+	if (run_generic) {
+		lw_launch_generic_ola(d->T, B, d_out, b->fmt, st, all_generic);
+		b->last_kernels += "k_ola_generic,";
+	}
+	if (!b->last_kernels.empty())
+		b->last_kernels.pop_back();
 	HIP_TRY(hipGetLastError());
 	return LW_OK;
 }

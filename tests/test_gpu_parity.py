@@ -190,3 +190,85 @@ def test_batch_many_streams_matches_oracle(name):
         for s in range(n_streams):
             assert np.array_equal(pwrs[s].data().view(np.uint32), o_pwrs[s].data(ch).view(np.uint32))
     assert "k_imdct_generic" in batch.last_kernels or "k_long" in batch.last_kernels
+
+
+def _decode_batch(setup, items_streams, fmt="i16", force_generic=False, batch=None):
+    """items_streams: list of (packet, stream_index). Returns (per-packet outputs, batch, pwrs)."""
+    from lewton_amd.batch import Batch
+    audio, ident, st = _product(setup)
+    dec = audio.decoder_for(ident, st)
+    n_streams = 1 + max(s for _, s in items_streams)
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    b = batch or Batch(dec, len(items_streams), fmt)
+    b.set_force_generic(force_generic)
+    b.entropy([(p, pwrs[s]) for p, s in items_streams], n_threads=2)
+    b.upload()
+    return b.split(b.synth_to_host(), setup.channels), b, pwrs
+
+
+@pytest.mark.parametrize("name,pattern,count", [
+    ("stereo", "L", 100), ("stereo", "LLLLLSLLLLLLLLLLLLLLLLLLLSSLLLLL", 90), ("surround51", "L", 40),
+    ("surround51", "LLLLLLLSLLLLL", 40), ("stereo_t1", "LLLS", 50)])
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_long_block_kernel_matches_oracle(name, pattern, count, fmt):
+    """The specialised n=2048 kernel: runs crossing workgroup boundaries (halo pre-pass), generic<->fast hand-over
+    around short blocks, unused floors, all three sample formats."""
+    setup = SETUPS[name]()
+    o_id, o_st = oracle_headers(setup)
+    pkts = sg.make_stream(setup, pattern, count, seed=31, p_floor_unused=0.08)
+    got, b, pwrs = _decode_batch(setup, [(p, 0) for p in pkts], fmt)
+    assert "k_long" in b.last_kernels
+    if count > 40 and pattern == "L":
+        assert "k_long<halo>" in b.last_kernels
+    o_pwr = po.Pwr()
+    ofmt = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}[fmt]
+    for i, p in enumerate(pkts):
+        want = po.read_audio_packet(o_id, o_st, p, o_pwr, ofmt)
+        g = got[i]
+        assert g.shape == want.shape, (i, g.shape, want.shape)
+        if fmt == "f32":
+            assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), (i, np.abs(g - want).max())
+        else:
+            assert np.array_equal(g, want), i
+    assert np.array_equal(pwrs[0].data().view(np.uint32), o_pwr.data(setup.channels).view(np.uint32))
+
+
+def test_long_block_kernel_equals_generic_kernels_many_streams():
+    """Same batch through the specialised and the generic kernels: identical PCM; streams interleaved round-robin,
+    state carried over three consecutive batches."""
+    setup = SETUPS["stereo"]()
+    n_streams, per = 37, 9
+    streams = [sg.make_stream(setup, "L", 3 * per, seed=500 + s) for s in range(n_streams)]
+    from lewton_amd.batch import Batch
+    audio, ident, st = _product(setup)
+    dec = audio.decoder_for(ident, st)
+    pw_a = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    pw_b = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    ba, bb = Batch(dec, n_streams * per, "i16"), Batch(dec, n_streams * per, "i16")
+    bb.set_force_generic(True)
+    for r in range(3):
+        items = [(streams[s][r * per + t], s) for t in range(per) for s in range(n_streams)]
+        ba.entropy([(p, pw_a[s]) for p, s in items]); ba.upload(); fa = ba.synth_to_host()
+        bb.entropy([(p, pw_b[s]) for p, s in items]); bb.upload(); fb = bb.synth_to_host()
+        assert "k_long" in ba.last_kernels and "k_long" not in bb.last_kernels
+        assert fa.shape == fb.shape and np.array_equal(fa, fb), r
+    for s in range(n_streams):
+        assert np.array_equal(pw_a[s].data().view(np.uint32), pw_b[s].data().view(np.uint32))
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[1] size (4096 stereo long packets): checksum-of-checksums equality between the two kernel
+    families, plus idempotence of re-launching an uploaded batch."""
+    setup = SETUPS["stereo"]()
+    pool = sg.make_stream(setup, "L", 64, seed=77)
+    rng = np.random.default_rng(3)
+    pkts = [pool[int(i)] for i in rng.integers(0, 64, 4096)]
+    got_f, bf, _ = _decode_batch(setup, [(p, 0) for p in pkts], "i16")
+    got_g, bg, _ = _decode_batch(setup, [(p, 0) for p in pkts], "i16", force_generic=True)
+    fa = np.concatenate([g.reshape(-1) for g in got_f])
+    ga = np.concatenate([g.reshape(-1) for g in got_g])
+    assert fa.size == 4095 * 2 * 1024
+    assert np.array_equal(fa, ga)
+    again = bf.synth_to_host()
+    assert np.array_equal(again, fa)
+    assert bf.algorithmic_bytes == 4096 * (8192 + 132) + 4095 * 4096
