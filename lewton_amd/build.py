@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(LIBDIR, s + ".o")
         objs.append(obj)
-        cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc()] + FLAGS + os.environ.get("LW_EXTRA_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -35,6 +35,7 @@ struct LwFastArgs {
 	const LwFastItem *items;   // (packet index, halo slot) in stream-sorted order
 	uint32_t n_items;
 	uint32_t n_units;
+	uint32_t items_per_wg;     // packets per workgroup (<= LW_FAST_WAVES / n_units)
 	LwFastUnit units[LW_FAST_WAVES];
 	float *halo;               // [slots][ch][512]
 	void *out;
@@ -90,393 +91,389 @@ __device__ __forceinline__ uint32_t pack2(float a, float b)
 	return ((uint32_t)to_i16s(a) & 0xffffu) | ((uint32_t)to_i16s(b) << 16);
 }
 
-template <int FMT, bool RIGHT_ONLY>
-__global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwFastArgs F)
-{
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-	// ---- stage the table image (all waves), then everything below is wave-private until the hand-over
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(F.image);
-		uint4 *dst = reinterpret_cast<uint4 *>(smem);
-		for (uint32_t i = threadIdx.x; i < F.off.total / 16; i += LW_WG)
-			dst[i] = src[i];
+// ---------------------------------------------------------------------------------------------
+// Packed f32 arithmetic.  Every multiply/add of the transform is issued as v_pk_mul_f32 / v_pk_add_f32 on
+// register pairs, with op_sel / op_sel_hi choosing the half of each source that feeds the low / high result
+// and neg_lo / neg_hi negating sources (exact).  Written as inline asm so that the operation tree is exactly
+// the reference's (no contraction, no re-association) and no register shuffling is left to the vectoriser.
+// tests/fast_model.py emulates these very modifier sets and is checked bit-for-bit against the oracle.
+// ---------------------------------------------------------------------------------------------
+#define LW_PK(name, op, mods)                                                              \
+	__device__ __forceinline__ float2_t name(float2_t a, float2_t b)                       \
+	{                                                                                      \
+		float2_t d;                                                                        \
+		asm(op " %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b));                            \
+		return d;                                                                          \
 	}
-	__syncthreads();
-	const char *img = smem;
-	float *scr = reinterpret_cast<float *>(smem + F.off.total) + wave * LW_SCR_FLOATS;
-	char *scrb = reinterpret_cast<char *>(scr);
+LW_PK(pk_add, "v_pk_add_f32", "")                                                              // (a.lo+b.lo, a.hi+b.hi)
+LW_PK(pk_sub, "v_pk_add_f32", "neg_lo:[0,1] neg_hi:[0,1]")                                     // (a.lo-b.lo, a.hi-b.hi)
+LW_PK(pk_add_A2, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")                  // (a.lo-b.hi, a.hi+b.lo)
+LW_PK(pk_add_A3, "v_pk_add_f32", "op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]")     // (a.hi-b.hi, b.lo-a.lo)
+LW_PK(pk_add_A4, "v_pk_add_f32", "op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]")     // (b.lo-a.lo, a.hi-b.hi)
+LW_PK(pk_add_A5, "v_pk_add_f32", "op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]")                  // (a.hi-b.lo, a.hi+b.lo)
+LW_PK(pk_add_A6, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")                  // (a.lo+b.hi, a.hi-b.lo)
+LW_PK(pk_add_A7, "v_pk_add_f32", "neg_hi:[0,1]")                                               // (a.lo+b.lo, a.hi-b.hi)
+LW_PK(pk_add_A8, "v_pk_add_f32", "neg_lo:[0,1]")                                               // (a.lo-b.lo, a.hi+b.hi)
+LW_PK(pk_add_A9, "v_pk_add_f32", "neg_lo:[0,1] neg_hi:[1,0]")                                  // (a.lo-b.lo, b.hi-a.hi)
+LW_PK(pk_mul, "v_pk_mul_f32", "")                                                              // (a.lo*b.lo, a.hi*b.hi)
+LW_PK(pk_mul_M1, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[1,0]")                               // (a.lo*b.lo, a.hi*b.lo)
+LW_PK(pk_mul_M2, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]")                  // (a.hi*b.hi, -a.lo*b.hi)
+LW_PK(pk_mul_M3, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[0,0]")                               // (a.lo*b.hi, a.lo*b.lo)
+LW_PK(pk_mul_M4, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]")                  // (a.lo*b.lo, -a.lo*b.hi)
+LW_PK(pk_mul_M5, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]")     // (-a.hi*b.hi, -a.hi*b.lo)
+LW_PK(pk_mul_M6, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0]")                  // (-a.hi*b.lo, a.hi*b.hi)
+LW_PK(pk_mul_M7, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1]")                               // (a.lo*b.hi, a.hi*b.hi)
+LW_PK(pk_mul_M8, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[0,1]")                  // (-a.hi*b.lo, a.lo*b.lo)
+LW_PK(pk_mul_M9, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[1,0]")                  // (a.hi*b.hi, -a.hi*b.lo)
+LW_PK(pk_mul_M10, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]")    // (-a.lo*b.lo, -a.lo*b.hi)
+LW_PK(pk_mul_M12lo, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[0,0]")                            // (a.lo*b.hi, a.lo*b.lo)
+LW_PK(pk_mul_M12hi, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0]")                            // (a.hi*b.hi, a.hi*b.lo)
 
-	const uint32_t g = blockIdx.x * LW_FAST_WAVES + wave;
-	const uint32_t item = g / F.n_units, uidx = g - item * F.n_units;
-	const bool valid = item < F.n_items;
+// imdct.rs:36-41 on pairs (e0, e1) = (u[hi-1], u[hi]); t = (t0, t1)
+__device__ __forceinline__ void bfly2(float2_t &H, float2_t &L, float2_t t)
+{
+	const float2_t S = pk_add(H, L);
+	const float2_t K = pk_sub(H, L);                  // (k01, k00)
+	L = pk_add(pk_mul_M1(K, t), pk_mul_M2(K, t));     // (k01 t0 + k00 t1, k00 t0 - k01 t1)
+	H = S;
+}
 
-	// per-channel results that live across the barrier
-	float pbv[2][2][4]; // [channel][c][k] un-windowed right half at q_k(c)
-	float pav[2][2][4];
-	LwPacketRec rec{};
-	LwFastUnit un{};
-	int nch = 0;
-	uint32_t pkt = 0;
+// imdct.rs:548-560 (one half of a step-7 iteration): P = (D1, D0), Q = (E3, E2), C2 = (C0, C1)
+__device__ __forceinline__ void step7_block(float2_t P, float2_t Q, float2_t C2, float2_t &Dn, float2_t &En)
+{
+	const float2_t Aa = pk_add_A7(P, Q);              // (a11, a02)
+	const float2_t Bb = pk_add_A8(P, Q);              // (b3, b2)
+	const float2_t Bv = pk_add(pk_mul_M7(Aa, C2), pk_mul_M8(Aa, C2)); // (b1, b0)
+	Dn = pk_add(Bb, Bv);                              // (b3 + b1, b2 + b0)
+	En = pk_add_A9(Bv, Bb);                           // (b1 - b3, b2 - b0)
+}
 
-	if (valid) {
-		pkt = F.items[item].pkt;
-		rec = B.recs[pkt];
-		un = F.units[uidx];
-		nch = un.ch_b >= 0 ? 2 : 1;
-		const int chn[2] = {un.ch_a, un.ch_b >= 0 ? un.ch_b : un.ch_a};
-		const int fslot[2] = {un.floor_a, un.floor_b};
+// imdct.rs:619-620: Wv = (w1, w0), Bq = (Bc, Bs) -> (pa, pb)
+__device__ __forceinline__ float2_t step8(float2_t Wv, float2_t Bq)
+{
+	return pk_add(pk_mul_M9(Wv, Bq), pk_mul_M10(Wv, Bq));
+}
 
-		// ---- residue loads: lane holds float4 groups m = 64x + lane (coalesced 1 KB per instruction)
-		float4_t r[2][4];
+// ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private)
+template <int NCH>
+__device__ __forceinline__ void long_phase1(const LwDevTables &T, const LwBatchDev &B, const LwFastArgs &F, const char *img,
+		char *scrb, uint32_t lane, const LwPacketRec &rec, const LwFastUnit &un, float4_t (&r)[2][4],
+		float2_t (&R)[2][2][4])
+{
+	const int chn[2] = {un.ch_a, un.ch_b >= 0 ? un.ch_b : un.ch_a};
+	const int fslot[2] = {un.floor_a, un.floor_b};
+	// ---- floor segment tables (one 16-byte entry per static interval), built by lanes = posts:
+	//      {dy, 0.5*sgn(dy) - x0*dy, 1/adx, 4*y0}; y(k) = y0 + trunc((k*dy + c0) * rinv)
+	bool unused[2] = {false, false};
 #pragma unroll
-		for (int c = 0; c < 2; c++) {
-			if (c < nch) {
-				const float4_t *src = reinterpret_cast<const float4_t *>(B.residue + rec.res_off + (uint32_t)chn[c] * 1024u);
+	for (int c = 0; c < 2; c++) {
+		if (c < NCH) {
+			const uint32_t Fp = T.floor_F[T.mode_floor[rec.mode * T.ch + chn[c]]];
+			const uint16_t *frec = B.floors + rec.floor_off + (uint32_t)chn[c] * T.fstride;
+			const uint32_t e = lane < Fp ? frec[lane] : 0u;
+			unused[c] = __builtin_amdgcn_readfirstlane(e) == LW_FLOOR_UNUSED;
+			const unsigned long long M = __ballot((e & LW_POST_ACTIVE) != 0);
+			const unsigned long long lowmask = (2ull << lane) - 1ull;
+			const unsigned long long below = M & lowmask, above = M & ~lowmask;
+			const int lo = below ? 63 - __builtin_clzll(below) : 0;
+			const int hi = above ? __builtin_ctzll(above) : lo;
+			const int y = (int)(e & 0xffu);
+			const float xs = *reinterpret_cast<const float *>(img + F.off.xsf + 4u * (64u * fslot[c] + lane));
+			const int ylo = __builtin_amdgcn_ds_bpermute(lo << 2, y);
+			const int yhi = __builtin_amdgcn_ds_bpermute(hi << 2, y);
+			const float xlo = __int_as_float(__builtin_amdgcn_ds_bpermute(lo << 2, __float_as_int(xs)));
+			const float xhi = __int_as_float(__builtin_amdgcn_ds_bpermute(hi << 2, __float_as_int(xs)));
+			const float dy = (float)(yhi - ylo); // 0 when there is no later active post (flat, audio.rs:546-548)
+			float4_t ent;
+			ent.x = dy;
+			ent.y = __builtin_copysignf(0.5f, dy) - xlo * dy; // exact
+			ent.z = above ? __builtin_amdgcn_rcpf(xhi - xlo) : 1.0f;
+			ent.w = __int_as_float(ylo << 2);
+			if (lane < Fp)
+				*reinterpret_cast<float4_t *>(scrb + 4096 * c + 16 * lane) = ent;
+		}
+	}
+	lds_fence();
+	// ---- inverse coupling (audio.rs:762-777, :990-1002) on the raw residues
+	if (NCH == 2 && un.coupled) {
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const float m = r[0][x][j], a = r[1][x][j];
+				const float ap = m > 0.0f ? a : -a; // (m, a) -> a>0 ? (m, m-a') : (m+a', m)
+				const float s = m + ap, d = m - ap;
+				const bool apos = a > 0.0f;
+				r[0][x][j] = apos ? m : s;
+				r[1][x][j] = apos ? d : m;
+			}
+		}
+	}
+	// ---- floor value per bin; spectrum = floor * residue in place (audio.rs:1035-1037)
+	const float kf0 = (float)(4 * (int)lane);
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+		if (c < NCH) {
+			if (unused[c]) {
 #pragma unroll
 				for (int x = 0; x < 4; x++)
-					r[c][x] = src[64 * x + lane];
-			}
-		}
-		// ---- floor segment tables (one 16-byte entry per static interval), built by lanes = posts
-		bool unused[2] = {false, false};
+					r[c][x] = r[c][x] * 0.0f; // zero floor (audio.rs:1021-1024)
+			} else {
 #pragma unroll
-		for (int c = 0; c < 2; c++) {
-			if (c < nch) {
-				const uint32_t Fp = T.floor_F[T.mode_floor[rec.mode * T.ch + chn[c]]];
-				const uint16_t *frec = B.floors + rec.floor_off + (uint32_t)chn[c] * T.fstride;
-				const uint32_t e = lane < Fp ? frec[lane] : 0u;
-				unused[c] = __builtin_amdgcn_readfirstlane(e) == LW_FLOOR_UNUSED;
-				const unsigned long long M = __ballot((e & LW_POST_ACTIVE) != 0);
-				const unsigned long long lowmask = (2ull << lane) - 1ull;
-				const unsigned long long below = M & lowmask, above = M & ~lowmask;
-				const int lo = below ? 63 - __builtin_clzll(below) : 0;
-				const int hi = above ? __builtin_ctzll(above) : -1;
-				const int y = (int)(e & 0xffu);
-				const float xs = *reinterpret_cast<const float *>(img + F.off.xsf + 4u * (64u * fslot[c] + lane));
-				const int ylo = __builtin_amdgcn_ds_bpermute(lo << 2, y);
-				const int yhi = __builtin_amdgcn_ds_bpermute((hi < 0 ? lo : hi) << 2, y);
-				const float xlo = __int_as_float(__builtin_amdgcn_ds_bpermute(lo << 2, __float_as_int(xs)));
-				const float xhi = __int_as_float(__builtin_amdgcn_ds_bpermute((hi < 0 ? lo : hi) << 2, __float_as_int(xs)));
-				float4_t ent;
-				ent.x = xlo;
-				ent.y = hi < 0 ? 0.0f : (float)(yhi - ylo);
-				ent.z = hi < 0 ? 1.0f : __builtin_amdgcn_rcpf(xhi - xlo);
-				ent.w = __int_as_float(ylo << 2);
-				if (lane < Fp)
-					*reinterpret_cast<float4_t *>(scrb + 4096 * c + 16 * lane) = ent;
-			}
-		}
-		lds_fence();
-		// ---- inverse coupling (audio.rs:762-777, :990-1002) on the raw residues
-		if (nch == 2 && un.coupled) {
+				for (int x = 0; x < 4; x++) {
+					const uint2_t sw = *reinterpret_cast<const uint2_t *>(
+							img + F.off.sid16 + 8u * ((fslot[c] * 4 + x) * 64u + lane));
+					const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
+					float4_t fl;
 #pragma unroll
-			for (int x = 0; x < 4; x++) {
-#pragma unroll
-				for (int j = 0; j < 4; j++) {
-					const float m = r[0][x][j], a = r[1][x][j];
-					const float s = m + a, d = m - a;
-					const bool mp = m > 0.0f, ap = a > 0.0f;
-					r[0][x][j] = mp ? (ap ? m : s) : (ap ? m : d);
-					r[1][x][j] = mp ? (ap ? d : m) : (ap ? s : m);
-				}
-			}
-		}
-		// ---- floor value per bin; spectrum = floor * residue in place (audio.rs:1035-1037)
-#pragma unroll
-		for (int c = 0; c < 2; c++) {
-			if (c < nch) {
-				if (unused[c]) {
-#pragma unroll
-					for (int x = 0; x < 4; x++)
-#pragma unroll
-						for (int j = 0; j < 4; j++)
-							r[c][x][j] = 0.0f * r[c][x][j]; // zero floor (audio.rs:1021-1024)
-				} else {
-#pragma unroll
-					for (int x = 0; x < 4; x++) {
-						const uint2_t sw = *reinterpret_cast<const uint2_t *>(
-								img + F.off.sid16 + 8u * ((fslot[c] * 4 + x) * 64u + lane));
-						const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
-						const float kf = (float)(256 * x + 4 * (int)lane);
-#pragma unroll
-						for (int j = 0; j < 4; j++) {
-							const float4_t ent = lds4(scrb + 4096 * c, s16[j]);
-							const float tf = (kf + (float)j) - ent.x;
-							const float z = __builtin_fmaf(tf, ent.y, __builtin_copysignf(0.5f, ent.y)); // exact: |t*dy| < 2^18
-							const int q = (int)(z * ent.z);
-							const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
-							r[c][x][j] = *reinterpret_cast<const float *>(img + F.off.inv_db + idx) * r[c][x][j];
-						}
+					for (int j = 0; j < 4; j++) {
+						const float4_t ent = lds4(scrb + 4096 * c, s16[j]);
+						const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
+						const int q = (int)(z * ent.z);
+						const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
+						fl[j] = *reinterpret_cast<const float *>(img + F.off.inv_db + idx);
 					}
+					const float2_t lo2 = pk_mul(float2_t{fl.x, fl.y}, float2_t{r[c][x].x, r[c][x].y});
+					const float2_t hi2 = pk_mul(float2_t{fl.z, fl.w}, float2_t{r[c][x].z, r[c][x].w});
+					r[c][x] = float4_t{lo2.x, lo2.y, hi2.x, hi2.y};
 				}
 			}
 		}
-		lds_fence();
+	}
+	lds_fence();
 
-		// ---- IMDCT step 1 (imdct.rs:337-371) in the load layout, exchange with the mirror lane -> layout B
-		Pair P[2][8];
-		const uint32_t mirror = (63u - lane) << 2;
+	// ---- IMDCT step 1 (imdct.rs:337-371) in the load layout; exchange with the mirror lane -> layout B
+	float2_t P[2][8];
+	const uint32_t mirror = (63u - lane) << 2;
 #pragma unroll
-		for (int x = 0; x < 4; x++) {
-			const uint32_t m = 64u * x + lane;
-			const float2_t au = lds2(img + F.off.apair, 8u * m);
-			const float2_t al = lds2(img + F.off.apair, 8u * (511u - m));
+	for (int x = 0; x < 4; x++) {
+		const uint32_t m = 64u * x + lane;
+		const float2_t au = lds2(img + F.off.apair, 8u * m);          // (A[2m], A[2m+1])
+		const float2_t al = lds2(img + F.off.apair, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
 #pragma unroll
-			for (int c = 0; c < 2; c++) {
-				if (c < nch) {
-					const float X0 = r[c][x][0], X1 = r[c][x][1], X2 = r[c][x][2], X3 = r[c][x][3];
-					const float u1 = X0 * au.x - X2 * au.y;
-					const float u0 = X0 * au.y + X2 * au.x;
-					P[c][x].e1 = (-X3) * al.x - (-X1) * al.y;
-					P[c][x].e0 = (-X3) * al.y + (-X1) * al.x;
-					P[c][7 - x].e0 = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(u0)));
-					P[c][7 - x].e1 = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(u1)));
-				}
+		for (int c = 0; c < 2; c++) {
+			if (c < NCH) {
+				const float2_t Xa = float2_t{r[c][x].x, r[c][x].y}, Xb = float2_t{r[c][x].z, r[c][x].w};
+				const float2_t U = pk_add(pk_mul_M3(Xa, au), pk_mul_M4(Xb, au)); // pair 511 - m
+				P[c][x] = pk_add(pk_mul_M5(Xb, al), pk_mul_M6(Xa, al));          // pair m
+				P[c][7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.x)));
+				P[c][7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.y)));
 			}
 		}
-		// ---- step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452)
+	}
+	// ---- step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452)
 #pragma unroll
-		for (int x = 0; x < 4; x++) {
-			const float2_t t = lds2(img + F.off.tw_s2, 8u * (64u * x + lane));
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch)
-					bfly(P[c][x + 4], P[c][x], t);
-		}
-#pragma unroll
-		for (int b = 0; b < 2; b++) {
-			const float2_t t = lds2(img + F.off.tw_l0, 8u * (64u * b + lane));
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch) {
-					bfly(P[c][2 + b], P[c][b], t);
-					bfly(P[c][6 + b], P[c][4 + b], t);
-				}
-		}
-		{
-			const float2_t t = lds2(img + F.off.tw_l1, 8u * lane);
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch) {
-#pragma unroll
-					for (int x = 1; x < 8; x += 2)
-						bfly(P[c][x], P[c][x - 1], t);
-				}
-		}
-		// ---- T2: layout B -> C.  slot(p) = p ^ ((p>>6 & 3) << 3)
-		const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
+	for (int x = 0; x < 4; x++) {
+		const float2_t t = lds2(img + F.off.tw_s2, 8u * (64u * x + lane));
 #pragma unroll
 		for (int c = 0; c < 2; c++)
-			if (c < nch) {
+			if (c < NCH)
+				bfly2(P[c][x + 4], P[c][x], t);
+	}
 #pragma unroll
-				for (int x = 0; x < 8; x++) {
-					const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
-					*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = float2_t{P[c][x].e0, P[c][x].e1};
-				}
-			}
-		lds_fence();
-		Pair Q[2][8];
+	for (int b = 0; b < 2; b++) {
+		const float2_t t = lds2(img + F.off.tw_l0, 8u * (64u * b + lane));
 #pragma unroll
 		for (int c = 0; c < 2; c++)
-			if (c < nch) {
-#pragma unroll
-				for (int y = 0; y < 8; y++) {
-					const uint32_t slot = 64u * X3b + lo3 + 8u * ((uint32_t)y ^ (X3b & 3u));
-					const float2_t v = lds2(scrb + 4096 * c, 8u * slot);
-					Q[c][y].e0 = v.x;
-					Q[c][y].e1 = v.y;
-				}
-			}
-		lds_fence();
-		// ---- stages l = 2, 3, 4 (imdct.rs:454-477)
-#pragma unroll
-		for (int yy = 0; yy < 4; yy++) {
-			const float2_t t = lds2(img + F.off.tw_l2, 8u * (8u * yy + lo3));
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch)
-					bfly(Q[c][4 + yy], Q[c][yy], t);
-		}
-#pragma unroll
-		for (int b = 0; b < 2; b++) {
-			const float2_t t = lds2(img + F.off.tw_l3, 8u * (8u * b + lo3));
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch) {
-					bfly(Q[c][2 + b], Q[c][b], t);
-					bfly(Q[c][6 + b], Q[c][4 + b], t);
-				}
-		}
-		{
-			const float2_t t = lds2(img + F.off.tw_l4, 8u * lo3);
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch) {
-#pragma unroll
-					for (int y = 1; y < 8; y += 2)
-						bfly(Q[c][y], Q[c][y - 1], t);
-				}
-		}
-		// ---- T3: layout C -> D.  slot(p) = 8 nu + (z ^ (nu>>2 & 7)), nu = p>>3, z = p&7
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < nch) {
-#pragma unroll
-				for (int y = 0; y < 8; y++) {
-					const uint32_t nu = 8u * X3b + y;
-					const uint32_t slot = 8u * nu + (lo3 ^ ((nu >> 2) & 7u));
-					*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = float2_t{Q[c][y].e0, Q[c][y].e1};
-				}
-			}
-		lds_fence();
-		float z[2][16];
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < nch) {
-#pragma unroll
-				for (int zz = 0; zz < 8; zz++) {
-					const uint32_t slot = 8u * lane + ((uint32_t)zz ^ ((lane >> 2) & 7u));
-					const float2_t v = lds2(scrb + 4096 * c, 8u * slot);
-					z[c][2 * zz] = v.x;
-					z[c][2 * zz + 1] = v.y;
-				}
-			}
-		lds_fence();
-		// ---- fused last three stages (imdct.rs:234-288), lane-local on z[0..16) = u[16 lane ..]
-		const float a2 = *reinterpret_cast<const float *>(img + F.off.a2);
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < nch) {
-				float *zc = z[c];
-				float k00, k11;
-				k00 = zc[15] - zc[7];
-				k11 = zc[14] - zc[6];
-				zc[15] = zc[15] + zc[7];
-				zc[14] = zc[14] + zc[6];
-				zc[7] = k00;
-				zc[6] = k11;
-				k00 = zc[13] - zc[5];
-				k11 = zc[12] - zc[4];
-				zc[13] = zc[13] + zc[5];
-				zc[12] = zc[12] + zc[4];
-				zc[5] = (k00 + k11) * a2;
-				zc[4] = (k11 - k00) * a2;
-				k00 = zc[3] - zc[11];
-				k11 = zc[10] - zc[2];
-				zc[11] = zc[11] + zc[3];
-				zc[10] = zc[10] + zc[2];
-				zc[3] = k11;
-				zc[2] = k00;
-				k00 = zc[1] - zc[9];
-				k11 = zc[8] - zc[0];
-				zc[9] = zc[9] + zc[1];
-				zc[8] = zc[8] + zc[0];
-				zc[1] = (k00 + k11) * a2;
-				zc[0] = (k00 - k11) * a2;
-#pragma unroll
-				for (int b = 8; b >= 0; b -= 8) { // imdct.rs:202-232
-					float *w = zc + b;
-					const float i00 = w[7] - w[3], y0 = w[7] + w[3], y2 = w[5] + w[1], k22 = w[5] - w[1];
-					const float k33 = w[4] - w[0], i11 = w[6] - w[2], y1 = w[6] + w[2], y3 = w[4] + w[0];
-					w[7] = y0 + y2;
-					w[5] = y0 - y2;
-					w[3] = i00 + k33;
-					w[1] = i00 - k33;
-					w[6] = y1 + y3;
-					w[4] = y1 - y3;
-					w[2] = i11 - k22;
-					w[0] = i11 + k22;
-				}
-			}
-		// ---- T4: layout D -> bit-reverse gather.  slot(p) = (p & ~127) | ((p & 3) << 5) | ((p >> 2) & 31)
-		{
-			const uint32_t base = 128u * (lane >> 4) + 2u * (lane & 15u);
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch) {
-#pragma unroll
-					for (int zz = 0; zz < 8; zz++) {
-						const uint32_t slot = base + 32u * (zz & 3) + (zz >> 2);
-						*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = float2_t{z[c][2 * zz], z[c][2 * zz + 1]};
-					}
-				}
-		}
-		lds_fence();
-		// rho = rev6(lane); s0 = slot(2 * rho): pairs 2v, 2v+256, 255-2v, 511-2v
-		const uint32_t rho = __builtin_bitreverse32(lane) >> 26;
-		const uint32_t s0 = ((rho & 1u) << 6) | (rho >> 1);
-#pragma unroll
-		for (int c2 = 0; c2 < 2; c2++) { // m' = 2 lane + c2
-			const float4_t Cq = lds4(img + F.off.c4, 16u * (64u * c2 + lane));
-			const float4_t Bl = lds4(img + F.off.b_lo, 16u * (64u * c2 + lane));
-			const float4_t Bh = lds4(img + F.off.b_hi, 16u * (64u * c2 + lane));
-			const uint32_t sa = 128u * c2 + s0;         // slot of pair 2v
-			const uint32_t sb = 255u - sa;              // slot of pair 255 - 2v
-#pragma unroll
-			for (int c = 0; c < 2; c++)
-				if (c < nch) {
-					const char *sc = scrb + 4096 * c;
-					const float2_t pq = lds2(sc, 8u * sa), pq256 = lds2(sc, 8u * (sa + 256u));
-					const float2_t p255 = lds2(sc, 8u * sb), p511 = lds2(sc, 8u * (sb + 256u));
-					const float D0i = p511.y, D1i = p511.x, D2i = p255.y, D3i = p255.x;
-					const float E0i = pq256.y, E1i = pq256.x, E2i = pq.y, E3i = pq.x;
-					// step 7 (imdct.rs:547-579)
-					float a02 = D0i - E2i, a11 = D1i + E3i;
-					float b0 = Cq.y * a02 + Cq.x * a11, b1 = Cq.y * a11 - Cq.x * a02;
-					float b2 = D0i + E2i, b3 = D1i - E3i;
-					const float D0 = b2 + b0, D1 = b3 + b1, E2 = b2 - b0, E3 = b1 - b3;
-					a02 = D2i - E0i;
-					a11 = D3i + E1i;
-					b0 = Cq.w * a02 + Cq.z * a11;
-					b1 = Cq.w * a11 - Cq.z * a02;
-					b2 = D2i + E0i;
-					b3 = D3i - E1i;
-					const float D2 = b2 + b0, D3 = b3 + b1, E0 = b2 - b0, E1 = b1 - b3;
-					// step 8 (imdct.rs:618-657): q = 511-2m', 510-2m', 1+2m', 2m'
-					pav[c][c2][0] = D0 * Bl.y - D1 * Bl.x;
-					pbv[c][c2][0] = (-D0) * Bl.x - D1 * Bl.y;
-					pav[c][c2][1] = D2 * Bl.w - D3 * Bl.z;
-					pbv[c][c2][1] = (-D2) * Bl.z - D3 * Bl.w;
-					pav[c][c2][2] = E0 * Bh.y - E1 * Bh.x;
-					pbv[c][c2][2] = (-E0) * Bh.x - E1 * Bh.y;
-					pav[c][c2][3] = E2 * Bh.w - E3 * Bh.z;
-					pbv[c][c2][3] = (-E2) * Bh.z - E3 * Bh.w;
-				}
-		}
-		lds_fence();
-		// ---- publish the right half for the successor wave (own scratch, [channel][c2][lane] float4)
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < nch) {
-#pragma unroll
-				for (int c2 = 0; c2 < 2; c2++)
-					*reinterpret_cast<float4_t *>(scrb + 4096 * c + 16u * (64u * c2 + lane)) =
-						float4_t{pbv[c][c2][0], pbv[c][c2][1], pbv[c][c2][2], pbv[c][c2][3]};
+			if (c < NCH) {
+				bfly2(P[c][2 + b], P[c][b], t);
+				bfly2(P[c][6 + b], P[c][4 + b], t);
 			}
 	}
-	__syncthreads();
-	if (!valid)
-		return;
+	{
+		const float2_t t = lds2(img + F.off.tw_l1, 8u * lane);
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+			if (c < NCH) {
+#pragma unroll
+				for (int x = 1; x < 8; x += 2)
+					bfly2(P[c][x], P[c][x - 1], t);
+			}
+	}
+	// ---- T2: layout B -> C.  slot(p) = p ^ ((p>>6 & 3) << 3)
+	const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
+#pragma unroll
+	for (int c = 0; c < 2; c++)
+		if (c < NCH) {
+#pragma unroll
+			for (int x = 0; x < 8; x++) {
+				const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
+				*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = P[c][x];
+			}
+		}
+	lds_fence();
+	float2_t Q[2][8];
+#pragma unroll
+	for (int c = 0; c < 2; c++)
+		if (c < NCH) {
+#pragma unroll
+			for (int y = 0; y < 8; y++) {
+				const uint32_t slot = 64u * X3b + lo3 + 8u * ((uint32_t)y ^ (X3b & 3u));
+				Q[c][y] = lds2(scrb + 4096 * c, 8u * slot);
+			}
+		}
+	lds_fence();
+	// ---- stages l = 2, 3, 4 (imdct.rs:454-477)
+#pragma unroll
+	for (int yy = 0; yy < 4; yy++) {
+		const float2_t t = lds2(img + F.off.tw_l2, 8u * (8u * yy + lo3));
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+			if (c < NCH)
+				bfly2(Q[c][4 + yy], Q[c][yy], t);
+	}
+#pragma unroll
+	for (int b = 0; b < 2; b++) {
+		const float2_t t = lds2(img + F.off.tw_l3, 8u * (8u * b + lo3));
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+			if (c < NCH) {
+				bfly2(Q[c][2 + b], Q[c][b], t);
+				bfly2(Q[c][6 + b], Q[c][4 + b], t);
+			}
+	}
+	{
+		const float2_t t = lds2(img + F.off.tw_l4, 8u * lo3);
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+			if (c < NCH) {
+#pragma unroll
+				for (int y = 1; y < 8; y += 2)
+					bfly2(Q[c][y], Q[c][y - 1], t);
+			}
+	}
+	// ---- T3: layout C -> D.  slot(p) = 8 nu + (z ^ (nu>>2 & 7)), nu = p>>3, z = p&7
+#pragma unroll
+	for (int c = 0; c < 2; c++)
+		if (c < NCH) {
+#pragma unroll
+			for (int y = 0; y < 8; y++) {
+				const uint32_t nu = 8u * X3b + y;
+				const uint32_t slot = 8u * nu + (lo3 ^ ((nu >> 2) & 7u));
+				*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = Q[c][y];
+			}
+		}
+	lds_fence();
+	float2_t Z[2][8]; // Z[j] = (u[16 lane + 2j], u[16 lane + 2j + 1])
+#pragma unroll
+	for (int c = 0; c < 2; c++)
+		if (c < NCH) {
+#pragma unroll
+			for (int zz = 0; zz < 8; zz++) {
+				const uint32_t slot = 8u * lane + ((uint32_t)zz ^ ((lane >> 2) & 7u));
+				Z[c][zz] = lds2(scrb + 4096 * c, 8u * slot);
+			}
+		}
+	lds_fence();
+	// ---- fused last three stages (imdct.rs:234-288), lane-local, 28 packed operations per channel
+	{
+		const float a2s = *reinterpret_cast<const float *>(img + F.off.a2);
+		const float2_t a2 = float2_t{a2s, a2s};
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+			if (c < NCH) {
+				float2_t *z = Z[c];
+				float2_t t0, t1;
+				t0 = pk_add(z[7], z[3]);
+				z[3] = pk_sub(z[7], z[3]);
+				z[7] = t0;
+				t0 = pk_add(z[6], z[2]);
+				t1 = pk_sub(z[6], z[2]);                    // (k11, k00)
+				z[2] = pk_mul(pk_add_A2(t1, t1), a2);       // ((k11-k00) a2, (k00+k11) a2)
+				z[6] = t0;
+				t0 = pk_add(z[5], z[1]);
+				z[1] = pk_add_A3(z[1], z[5]);               // (z3 - z11, z10 - z2)
+				z[5] = t0;
+				t0 = pk_add(z[4], z[0]);
+				t1 = pk_add_A4(z[0], z[4]);                 // (k11, k00)
+				z[0] = pk_mul(pk_add_A5(t1, t1), a2);       // ((k00-k11) a2, (k00+k11) a2)
+				z[4] = t0;
+#pragma unroll
+				for (int b = 4; b >= 0; b -= 4) { // imdct.rs:202-232 on w[0..8) = z[b..b+4)
+					const float2_t A = pk_add(z[b + 3], z[b + 1]);  // (y1, y0)
+					const float2_t Bm = pk_sub(z[b + 3], z[b + 1]); // (k11, k00)
+					const float2_t Cc = pk_add(z[b + 2], z[b]);     // (y3, y2)
+					const float2_t Dm = pk_sub(z[b + 2], z[b]);     // (k33, k22)
+					z[b + 3] = pk_add(A, Cc);
+					z[b + 2] = pk_sub(A, Cc);
+					z[b + 1] = pk_add_A2(Bm, Dm);                   // (k11 - k22, k00 + k33)
+					z[b] = pk_add_A6(Bm, Dm);                       // (k11 + k22, k00 - k33)
+				}
+			}
+	}
+	// ---- T4: layout D -> bit-reverse gather.  slot(p) = (p & ~127) | ((p & 3) << 5) | ((p >> 2) & 31)
+	{
+		const uint32_t base = 128u * (lane >> 4) + 2u * (lane & 15u);
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+			if (c < NCH) {
+#pragma unroll
+				for (int zz = 0; zz < 8; zz++) {
+					const uint32_t slot = base + 32u * (zz & 3) + (zz >> 2);
+					*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = Z[c][zz];
+				}
+			}
+	}
+	lds_fence();
+	// rho = rev6(lane); s0 = slot(2 rho): pairs 2v, 2v+256, 255-2v, 511-2v of m' = 2 lane + c2
+	const uint32_t rho = __builtin_bitreverse32(lane) >> 26;
+	const uint32_t s0 = ((rho & 1u) << 6) | (rho >> 1);
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) {
+		const float4_t Cq = lds4(img + F.off.c4, 16u * (64u * c2 + lane));
+		const float4_t Bl = lds4(img + F.off.b_lo, 16u * (64u * c2 + lane));
+		const float4_t Bh = lds4(img + F.off.b_hi, 16u * (64u * c2 + lane));
+		const uint32_t sa = 128u * c2 + s0; // slot of pair 2v
+		const uint32_t sb = 255u - sa;      // slot of pair 255 - 2v
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+			if (c < NCH) {
+				const char *sc = scrb + 4096 * c;
+				const float2_t pq = lds2(sc, 8u * sa), pq256 = lds2(sc, 8u * (sa + 256u));   // (E3,E2), (E1,E0)
+				const float2_t p255 = lds2(sc, 8u * sb), p511 = lds2(sc, 8u * (sb + 256u));  // (D3,D2), (D1,D0)
+				float2_t Dn1, En1, Dn2, En2;
+				step7_block(p511, pq, float2_t{Cq.x, Cq.y}, Dn1, En1);    // (D1',D0'), (E3',E2')
+				step7_block(p255, pq256, float2_t{Cq.z, Cq.w}, Dn2, En2); // (D3',D2'), (E1',E0')
+				// step 8 (imdct.rs:618-657): q = 511-2m', 510-2m', 1+2m', 2m'
+				R[c][c2][0] = step8(Dn1, float2_t{Bl.x, Bl.y});
+				R[c][c2][1] = step8(Dn2, float2_t{Bl.z, Bl.w});
+				R[c][c2][2] = step8(En2, float2_t{Bh.x, Bh.y});
+				R[c][c2][3] = step8(En1, float2_t{Bh.z, Bh.w});
+			}
+	}
+	lds_fence();
+	// ---- publish the un-windowed right half for the successor wave (own scratch, [channel][c2][lane] float4)
+#pragma unroll
+	for (int c = 0; c < 2; c++)
+		if (c < NCH) {
+#pragma unroll
+			for (int c2 = 0; c2 < 2; c2++)
+				*reinterpret_cast<float4_t *>(scrb + 4096 * c + 16u * (64u * c2 + lane)) =
+					float4_t{R[c][c2][0].y, R[c][c2][1].y, R[c][c2][2].y, R[c][c2][3].y};
+		}
+}
 
+// ---- phase 2: overlap-add with the predecessor's right half, sample conversion, stores, state hand-over
+template <int NCH, int FMT, bool RIGHT_ONLY>
+__device__ __forceinline__ void long_phase2(const LwDevTables &T, const LwBatchDev &B, const LwFastArgs &F, const char *img,
+		float *scr, uint32_t lane, uint32_t wave, uint32_t item, const LwPacketRec &rec, const LwFastUnit &un,
+		float2_t (&R)[2][2][4])
+{
 	const int chn[2] = {un.ch_a, un.ch_b >= 0 ? un.ch_b : un.ch_a};
-	// q positions: group 0 = [4 lane .. +3], group 1 = [508 - 4 lane .. +3] (ascending); value order per DESIGN.md
+	// pb at this lane's q positions: group 0 = q in [4 lane, +4), group 1 = q in [508 - 4 lane, +4) (ascending)
+#define LW_PB_LO0(c) float4_t{R[c][0][3].y, R[c][0][2].y, R[c][1][3].y, R[c][1][2].y}
+#define LW_PB_LO1(c) float4_t{R[c][1][1].y, R[c][1][0].y, R[c][0][1].y, R[c][0][0].y}
 	if (RIGHT_ONLY) {
 		const uint32_t hs = F.items[item].halo;
 #pragma unroll
 		for (int c = 0; c < 2; c++)
-			if (c < nch) {
+			if (c < NCH) {
 				float *dst = F.halo + ((size_t)hs * T.ch + chn[c]) * 512u;
-				*reinterpret_cast<float4_t *>(dst + 4u * lane) =
-					float4_t{pbv[c][0][3], pbv[c][0][2], pbv[c][1][3], pbv[c][1][2]};
-				*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) =
-					float4_t{pbv[c][1][1], pbv[c][1][0], pbv[c][0][1], pbv[c][0][0]};
+				*reinterpret_cast<float4_t *>(dst + 4u * lane) = LW_PB_LO0(c);
+				*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
 			}
 		return;
 	}
-
 	// ---- previous right half: LDS (predecessor wave), state slot, halo buffer, or a generic packet's td block
 	if (rec.prev != -1) {
 		bool from_lds = false;
@@ -500,72 +497,92 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 			gsrc[1] = td + (uint32_t)chn[1] * 2048u;
 		}
 		const float *pscr = scr - (size_t)F.n_units * LW_SCR_FLOATS; // predecessor wave's scratch
+		const float2_t k32768 = float2_t{32768.0f, 32768.0f};
 #pragma unroll
 		for (int c = 0; c < 2; c++)
-			if (c < nch) {
-				float pp[2][4]; // previous packet's pb at this lane's q positions
+			if (c < NCH) {
+				float2_t pp[2][2]; // previous pb: pp[c2][0] = (k=0, k=1), pp[c2][1] = (k=2, k=3)
 				if (from_lds) {
 #pragma unroll
 					for (int c2 = 0; c2 < 2; c2++) {
 						const float4_t v = *reinterpret_cast<const float4_t *>(
 								reinterpret_cast<const char *>(pscr) + 4096 * c + 16u * (64u * c2 + lane));
-						pp[c2][0] = v.x;
-						pp[c2][1] = v.y;
-						pp[c2][2] = v.z;
-						pp[c2][3] = v.w;
+						pp[c2][0] = float2_t{v.x, v.y};
+						pp[c2][1] = float2_t{v.z, v.w};
 					}
 				} else {
-					const float4_t g0 = *reinterpret_cast<const float4_t *>(gsrc[c] + 4u * lane);
-					const float4_t g1 = *reinterpret_cast<const float4_t *>(gsrc[c] + 508u - 4u * lane);
-					pp[0][3] = g0.x; // q = 4 lane
-					pp[0][2] = g0.y; // 4 lane + 1
-					pp[1][3] = g0.z; // 4 lane + 2
-					pp[1][2] = g0.w; // 4 lane + 3
-					pp[1][1] = g1.x; // 508 - 4 lane
-					pp[1][0] = g1.y; // 509 - 4 lane
-					pp[0][1] = g1.z; // 510 - 4 lane
-					pp[0][0] = g1.w; // 511 - 4 lane
+					const float4_t g0 = *reinterpret_cast<const float4_t *>(gsrc[c] + 4u * lane);        // q = 4l .. 4l+3
+					const float4_t g1 = *reinterpret_cast<const float4_t *>(gsrc[c] + 508u - 4u * lane); // q = 508-4l ..
+					pp[0][1] = float2_t{g0.y, g0.x}; // (c2=0: k=2 -> q=4l+1, k=3 -> q=4l)
+					pp[1][1] = float2_t{g0.w, g0.z}; // (c2=1: k=2 -> 4l+3, k=3 -> 4l+2)
+					pp[1][0] = float2_t{g1.y, g1.x}; // (c2=1: k=0 -> 509-4l, k=1 -> 508-4l)
+					pp[0][0] = float2_t{g1.w, g1.z}; // (c2=0: k=0 -> 511-4l, k=1 -> 510-4l)
 				}
-				// ---- window + overlap-add (audio.rs:1116-1118): out[q] and out[1023-q] from (pa, pb', s[q], s[1023-q])
-				float oq[2][4], om[2][4];
+				// ---- window + overlap-add (audio.rs:1116-1118): (out[q], out[1023-q]) = (pa s[q] + pb' s[r], -pa s[r] + pb' s[q])
+				float2_t O[2][4];
 #pragma unroll
 				for (int c2 = 0; c2 < 2; c2++) {
 					const float4_t w0 = lds4(img + F.off.win, 32u * (64u * c2 + lane));
 					const float4_t w1 = lds4(img + F.off.win, 32u * (64u * c2 + lane) + 16u);
-					const float sq[4] = {w0.x, w0.z, w1.x, w1.z}, sr[4] = {w0.y, w0.w, w1.y, w1.w};
+					const float2_t S2[4] = {float2_t{w0.x, w0.y}, float2_t{w0.z, w0.w}, float2_t{w1.x, w1.y}, float2_t{w1.z, w1.w}};
 #pragma unroll
 					for (int k = 0; k < 4; k++) {
-						oq[c2][k] = (pav[c][c2][k] * sq[k]) + (pp[c2][k] * sr[k]);
-						om[c2][k] = ((-pav[c][c2][k]) * sr[k]) + (pp[c2][k] * sq[k]);
+						const float2_t o1 = pk_mul_M4(R[c][c2][k], S2[k]); // (pa s[q], -pa s[r])
+						const float2_t o2 = (k & 1) ? pk_mul_M12hi(pp[c2][k >> 1], S2[k]) : pk_mul_M12lo(pp[c2][k >> 1], S2[k]);
+						O[c2][k] = pk_add(o1, o2);
 					}
 				}
-				// positions: [4l..4l+3] = oq(0,3) oq(0,2) oq(1,3) oq(1,2); [508-4l..] = oq(1,1) oq(1,0) oq(0,1) oq(0,0)
-				//            [512+4l..] = om(0,0) om(0,1) om(1,0) om(1,1); [1020-4l..] = om(1,2) om(1,3) om(0,2) om(0,3)
-				const float g0[4] = {oq[0][3], oq[0][2], oq[1][3], oq[1][2]};
-				const float g1[4] = {oq[1][1], oq[1][0], oq[0][1], oq[0][0]};
-				const float g2[4] = {om[0][0], om[0][1], om[1][0], om[1][1]};
-				const float g3[4] = {om[1][2], om[1][3], om[0][2], om[0][3]};
+				// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [508-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
+				//            [512+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [1020-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
 				const uint32_t p0 = 4u * lane, p1 = 508u - 4u * lane, p2 = 512u + 4u * lane, p3 = 1020u - 4u * lane;
-				if (FMT == LW_OUT_I16_PLANAR) {
-					int16_t *o = reinterpret_cast<int16_t *>(F.out) + rec.out_off + (uint32_t)chn[c] * 1024u;
-					*reinterpret_cast<uint2_t *>(o + p0) = uint2_t{pack2(g0[0], g0[1]), pack2(g0[2], g0[3])};
-					*reinterpret_cast<uint2_t *>(o + p1) = uint2_t{pack2(g1[0], g1[1]), pack2(g1[2], g1[3])};
-					*reinterpret_cast<uint2_t *>(o + p2) = uint2_t{pack2(g2[0], g2[1]), pack2(g2[2], g2[3])};
-					*reinterpret_cast<uint2_t *>(o + p3) = uint2_t{pack2(g3[0], g3[1]), pack2(g3[2], g3[3])};
-				} else if (FMT == LW_OUT_F32_PLANAR) {
+				if (FMT == LW_OUT_F32_PLANAR) {
 					float *o = reinterpret_cast<float *>(F.out) + rec.out_off + (uint32_t)chn[c] * 1024u;
-					*reinterpret_cast<float4_t *>(o + p0) = float4_t{g0[0], g0[1], g0[2], g0[3]};
-					*reinterpret_cast<float4_t *>(o + p1) = float4_t{g1[0], g1[1], g1[2], g1[3]};
-					*reinterpret_cast<float4_t *>(o + p2) = float4_t{g2[0], g2[1], g2[2], g2[3]};
-					*reinterpret_cast<float4_t *>(o + p3) = float4_t{g3[0], g3[1], g3[2], g3[3]};
+					*reinterpret_cast<float4_t *>(o + p0) = float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x};
+					*reinterpret_cast<float4_t *>(o + p1) = float4_t{O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x};
+					*reinterpret_cast<float4_t *>(o + p2) = float4_t{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y};
+					*reinterpret_cast<float4_t *>(o + p3) = float4_t{O[1][2].y, O[1][3].y, O[0][2].y, O[0][3].y};
 				} else {
-					int16_t *o = reinterpret_cast<int16_t *>(F.out) + rec.out_off + (uint32_t)chn[c];
+					// samples.rs:92-103: x*32768, truncate toward zero (v_cvt_i32_f32: saturating, NaN -> 0), clamp to
+					// i16 by the saturating pack v_cvt_pk_i16_i32 -- equal to the reference's compare/clamp/`as i16`
+					int iq[2][4], im[2][4];
 #pragma unroll
-					for (int i = 0; i < 4; i++) {
-						o[(p0 + i) * T.ch] = (int16_t)to_i16s(g0[i]);
-						o[(p1 + i) * T.ch] = (int16_t)to_i16s(g1[i]);
-						o[(p2 + i) * T.ch] = (int16_t)to_i16s(g2[i]);
-						o[(p3 + i) * T.ch] = (int16_t)to_i16s(g3[i]);
+					for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+						for (int k = 0; k < 4; k++) {
+							const float2_t t = pk_mul(O[c2][k], k32768);
+							iq[c2][k] = (int)t.x;
+							im[c2][k] = (int)t.y;
+						}
+					if (FMT == LW_OUT_I16_PLANAR) {
+						typedef short short2_t __attribute__((ext_vector_type(2)));
+						union {
+							short2_t s;
+							uint32_t u;
+						} a, b;
+						int16_t *o = reinterpret_cast<int16_t *>(F.out) + rec.out_off + (uint32_t)chn[c] * 1024u;
+						a.s = __builtin_amdgcn_cvt_pk_i16(iq[0][3], iq[0][2]);
+						b.s = __builtin_amdgcn_cvt_pk_i16(iq[1][3], iq[1][2]);
+						*reinterpret_cast<uint2_t *>(o + p0) = uint2_t{a.u, b.u};
+						a.s = __builtin_amdgcn_cvt_pk_i16(iq[1][1], iq[1][0]);
+						b.s = __builtin_amdgcn_cvt_pk_i16(iq[0][1], iq[0][0]);
+						*reinterpret_cast<uint2_t *>(o + p1) = uint2_t{a.u, b.u};
+						a.s = __builtin_amdgcn_cvt_pk_i16(im[0][0], im[0][1]);
+						b.s = __builtin_amdgcn_cvt_pk_i16(im[1][0], im[1][1]);
+						*reinterpret_cast<uint2_t *>(o + p2) = uint2_t{a.u, b.u};
+						a.s = __builtin_amdgcn_cvt_pk_i16(im[1][2], im[1][3]);
+						b.s = __builtin_amdgcn_cvt_pk_i16(im[0][2], im[0][3]);
+						*reinterpret_cast<uint2_t *>(o + p3) = uint2_t{a.u, b.u};
+					} else {
+						int16_t *o = reinterpret_cast<int16_t *>(F.out) + rec.out_off + (uint32_t)chn[c];
+						const int g0[4] = {iq[0][3], iq[0][2], iq[1][3], iq[1][2]}, g1[4] = {iq[1][1], iq[1][0], iq[0][1], iq[0][0]};
+						const int g2[4] = {im[0][0], im[0][1], im[1][0], im[1][1]}, g3[4] = {im[1][2], im[1][3], im[0][2], im[0][3]};
+#pragma unroll
+						for (int i = 0; i < 4; i++) {
+							o[(p0 + i) * T.ch] = (int16_t)min(max(g0[i], -32768), 32767);
+							o[(p1 + i) * T.ch] = (int16_t)min(max(g1[i], -32768), 32767);
+							o[(p2 + i) * T.ch] = (int16_t)min(max(g2[i], -32768), 32767);
+							o[(p3 + i) * T.ch] = (int16_t)min(max(g3[i], -32768), 32767);
+						}
 					}
 				}
 			}
@@ -575,10 +592,10 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 	if (to_state || to_td) {
 #pragma unroll
 		for (int c = 0; c < 2; c++)
-			if (c < nch) {
-				const float4_t lo0 = float4_t{pbv[c][0][3], pbv[c][0][2], pbv[c][1][3], pbv[c][1][2]}; // q = 4l..4l+3
-				const float4_t lo1 = float4_t{pbv[c][1][1], pbv[c][1][0], pbv[c][0][1], pbv[c][0][0]}; // q = 508-4l..511-4l
-				const float4_t hi0 = float4_t{lo1.w, lo1.z, lo1.y, lo1.x};                               // 1023-q for q = 511-4l..508-4l
+			if (c < NCH) {
+				const float4_t lo0 = LW_PB_LO0(c); // q = 4l .. 4l+3
+				const float4_t lo1 = LW_PB_LO1(c); // q = 508-4l .. 511-4l
+				const float4_t hi0 = float4_t{lo1.w, lo1.z, lo1.y, lo1.x}; // 1023-q for q = 511-4l .. 508-4l
 				const float4_t hi1 = float4_t{lo0.w, lo0.z, lo0.y, lo0.x};
 				for (int t = 0; t < 2; t++) {
 					float *dst;
@@ -599,6 +616,64 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 				}
 			}
 	}
+#undef LW_PB_LO0
+#undef LW_PB_LO1
+}
+
+template <int FMT, bool RIGHT_ONLY>
+__global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwFastArgs F)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t g = blockIdx.x * F.items_per_wg * F.n_units + wave;
+	const uint32_t item = g / F.n_units, uidx = g - item * F.n_units;
+	const bool valid = wave < F.items_per_wg * F.n_units && item < F.n_items;
+
+	// ---- issue this wave's residue loads first (coalesced float4, lane holds groups m = 64x + lane) ...
+	LwPacketRec rec{};
+	LwFastUnit un{};
+	float4_t r[2][4];
+	if (valid) {
+		rec = B.recs[F.items[item].pkt];
+		un = F.units[uidx];
+		const float4_t *s0 = reinterpret_cast<const float4_t *>(B.residue + rec.res_off + (uint32_t)un.ch_a * 1024u);
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+			r[0][x] = s0[64 * x + lane];
+		if (un.ch_b >= 0) {
+			const float4_t *s1 = reinterpret_cast<const float4_t *>(B.residue + rec.res_off + (uint32_t)un.ch_b * 1024u);
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+				r[1][x] = s1[64 * x + lane];
+		}
+	}
+	// ---- ... then stage the table image while they are in flight
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(F.image);
+		uint4 *dst = reinterpret_cast<uint4 *>(smem);
+		for (uint32_t i = threadIdx.x; i < F.off.total / 16; i += LW_WG)
+			dst[i] = src[i];
+	}
+	__syncthreads();
+	const char *img = smem;
+	float *scr = reinterpret_cast<float *>(smem + F.off.total) + wave * LW_SCR_FLOATS;
+	char *scrb = reinterpret_cast<char *>(scr);
+	float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb) at q_k(m' = 2 lane + c2): un-windowed left / right halves
+	const bool two = un.ch_b >= 0;
+	if (valid) {
+		if (two)
+			long_phase1<2>(T, B, F, img, scrb, lane, rec, un, r, R);
+		else
+			long_phase1<1>(T, B, F, img, scrb, lane, rec, un, r, R);
+	}
+	__syncthreads();
+	if (!valid)
+		return;
+	if (two)
+		long_phase2<2, FMT, RIGHT_ONLY>(T, B, F, img, scr, lane, wave, item, rec, un, R);
+	else
+		long_phase2<1, FMT, RIGHT_ONLY>(T, B, F, img, scr, lane, wave, item, rec, un, R);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -627,12 +702,14 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 	if (L.n_halo_items) {
 		F.items = L.d_halo_items;
 		F.n_items = L.n_halo_items;
-		const uint32_t grid = (L.n_halo_items + per_wg - 1) / per_wg;
+		F.items_per_wg = 1; // spread the few halo packets over the whole chip: one packet per workgroup
+		const uint32_t grid = L.n_halo_items;
 		hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(grid), dim3(LW_WG), lds, st, T, B, F);
 	}
 	if (L.n_items) {
 		F.items = L.d_items;
 		F.n_items = L.n_items;
+		F.items_per_wg = per_wg;
 		const uint32_t grid = (L.n_items + per_wg - 1) / per_wg;
 		if (fmt == LW_OUT_I16_PLANAR)
 			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, T, B, F);

@@ -212,3 +212,165 @@ def floor_lane_model(rec, xs, img_inv_db):
         q = np.trunc((zf * rinv).astype(F)).astype(np.int64)
         out[sel] = img_inv_db[y0 + q]
     return out
+
+
+# =================================================================================================
+# Packed-op formulation (v2 of the kernel): every arithmetic step as v_pk_mul_f32 / v_pk_add_f32 with
+# op_sel / op_sel_hi / neg_lo / neg_hi modifiers.  A "register pair" is an array [2][64] (lo, hi).
+# Semantics (VOP3P): res.lo = f(s0[op_sel[0]], s1[op_sel[1]]) with neg_lo applied per source,
+#                    res.hi = f(s0[op_sel_hi[0]], s1[op_sel_hi[1]]) with neg_hi applied per source.
+# =================================================================================================
+def _src(a, sel, neg):
+    v = a[sel]
+    return -v if neg else v
+
+
+def pk(op, a, b, sel=(0, 0), selhi=(1, 1), nlo=(0, 0), nhi=(0, 0)):
+    lo0, lo1 = _src(a, sel[0], nlo[0]), _src(b, sel[1], nlo[1])
+    hi0, hi1 = _src(a, selhi[0], nhi[0]), _src(b, selhi[1], nhi[1])
+    if op == "mul":
+        return np.stack([(lo0 * lo1).astype(F), (hi0 * hi1).astype(F)])
+    return np.stack([(lo0 + lo1).astype(F), (hi0 + hi1).astype(F)])
+
+
+def bfly_pk(H, L, t):
+    """t = (t0, t1) as a pair.  5 packed ops."""
+    S = pk("add", H, L)
+    K = pk("add", H, L, nlo=(0, 1), nhi=(0, 1))                    # (k01, k00)
+    M1 = pk("mul", K, t, sel=(0, 0), selhi=(1, 0))                 # (k01 t0, k00 t0)
+    M2 = pk("mul", K, t, sel=(1, 1), selhi=(0, 1), nhi=(0, 1))     # (k00 t1, -k01 t1)
+    return S, pk("add", M1, M2)
+
+
+def last3_pk(Z, a2):
+    """Z: list of 8 pairs (z[2j], z[2j+1]); a2 as pair (a2, a2).  imdct.rs:234-288 in 28 packed ops."""
+    Z = list(Z)
+    Z7n = pk("add", Z[7], Z[3]); Z3n = pk("add", Z[7], Z[3], nlo=(0, 1), nhi=(0, 1))
+    Z[7], Z[3] = Z7n, Z3n
+    Z6n = pk("add", Z[6], Z[2]); D = pk("add", Z[6], Z[2], nlo=(0, 1), nhi=(0, 1))      # (k11, k00)
+    E = pk("add", D, D, sel=(0, 1), selhi=(1, 0), nlo=(0, 1))                            # (k11-k00, k00+k11)
+    Z[6], Z[2] = Z6n, pk("mul", E, a2)
+    Z5n = pk("add", Z[5], Z[1])
+    Z1n = pk("add", Z[1], Z[5], sel=(1, 1), selhi=(0, 0), nlo=(0, 1), nhi=(1, 0))        # (z3-z11, z10-z2)
+    Z[5], Z[1] = Z5n, Z1n
+    Z4n = pk("add", Z[4], Z[0])
+    Kq = pk("add", Z[0], Z[4], sel=(0, 0), selhi=(1, 1), nlo=(1, 0), nhi=(0, 1))         # (k11, k00)
+    E = pk("add", Kq, Kq, sel=(1, 0), selhi=(1, 0), nlo=(0, 1))                          # (k00-k11, k00+k11)
+    Z[4], Z[0] = Z4n, pk("mul", E, a2)
+    for b in (4, 0):
+        W0, W1, W2, W3 = Z[b], Z[b + 1], Z[b + 2], Z[b + 3]
+        A = pk("add", W3, W1)                                        # (y1, y0)
+        Bm = pk("add", W3, W1, nlo=(0, 1), nhi=(0, 1))               # (k11, k00)
+        Cc = pk("add", W2, W0)                                       # (y3, y2)
+        Dm = pk("add", W2, W0, nlo=(0, 1), nhi=(0, 1))               # (k33, k22)
+        Z[b + 3] = pk("add", A, Cc)
+        Z[b + 2] = pk("add", A, Cc, nlo=(0, 1), nhi=(0, 1))
+        Z[b + 1] = pk("add", Bm, Dm, sel=(0, 1), selhi=(1, 0), nlo=(0, 1))   # (k11-k22, k00+k33)
+        Z[b] = pk("add", Bm, Dm, sel=(0, 1), selhi=(1, 0), nhi=(0, 1))       # (k11+k22, k00-k33)
+    return Z
+
+
+def step7_block_pk(P, Q, C2):
+    """P = (D1, D0), Q = (E3, E2), C2 = (C0, C1) -> (D1', D0'), (E3', E2')  (imdct.rs:548-560). 7 packed ops."""
+    Aa = pk("add", P, Q, nhi=(0, 1))                                  # (a11, a02)
+    Bb = pk("add", P, Q, nlo=(0, 1))                                  # (b3, b2)
+    M1 = pk("mul", Aa, C2, sel=(0, 1), selhi=(1, 1))                  # (C1 a11, C1 a02)
+    M2 = pk("mul", Aa, C2, sel=(1, 0), selhi=(0, 0), nlo=(0, 1))      # (-C0 a02, C0 a11)
+    Bv = pk("add", M1, M2)                                            # (b1, b0)
+    Dn = pk("add", Bb, Bv)                                            # (b3+b1, b2+b0)
+    En = pk("add", Bv, Bb, nlo=(0, 1), nhi=(1, 0))                    # (b1-b3, b2-b0)
+    return Dn, En
+
+
+def step8_pk(Wv, Bq):
+    """Wv = (w1, w0), Bq = (Bc, Bs) -> (pa, pb)  (imdct.rs:619-620). 3 packed ops."""
+    N1 = pk("mul", Wv, Bq, sel=(1, 1), selhi=(1, 0), nhi=(1, 0))      # (w0 Bs, -w0 Bc)
+    N2 = pk("mul", Wv, Bq, sel=(0, 0), selhi=(0, 1), nlo=(0, 1), nhi=(0, 1))  # (-w1 Bc, -w1 Bs)
+    return pk("add", N1, N2)
+
+
+def ola_pk(R, PP, ppsel, S2):
+    """R = (pa, pb), PP pair holding pp at index ppsel, S2 = (s[q], s[1023-q]) -> (out[q], out[1023-q]). 3 packed ops."""
+    O1 = pk("mul", R, S2, sel=(0, 0), selhi=(0, 1), nhi=(1, 0))       # (pa sq, -pa sr)
+    O2 = pk("mul", PP, S2, sel=(ppsel, 1), selhi=(ppsel, 0))          # (pp sr, pp sq)
+    return pk("add", O1, O2)
+
+
+def imdct_wave_pk(X, img, prev_pb=None, window=None):
+    """Packed-op version of imdct_wave.  Returns the n-sample block; if prev_pb (512 values) and the image window are
+    given also returns the 1024 overlap-added output samples (audio.rs:1116-1118)."""
+    X = np.asarray(X, F)
+    lam = LANES
+    P = [None] * 8
+    up = [None] * 4
+    for x in range(4):
+        m = 64 * x + lam
+        Xa = np.stack([X[4 * m], X[4 * m + 1]])
+        Xb = np.stack([X[4 * m + 2], X[4 * m + 3]])
+        au = img.apair[m].T.copy()
+        al = img.apair[511 - m].T.copy()
+        T1 = pk("mul", Xa, au, sel=(0, 1), selhi=(0, 0))                       # (X0 a1, X0 a0)
+        T2 = pk("mul", Xb, au, sel=(0, 0), selhi=(0, 1), nhi=(0, 1))           # (X2 a0, -X2 a1)
+        up[x] = pk("add", T1, T2)
+        T3 = pk("mul", Xb, al, sel=(1, 1), selhi=(1, 0), nlo=(1, 0), nhi=(1, 0))  # (-X3 b1, -X3 b0)
+        T4 = pk("mul", Xa, al, sel=(1, 0), selhi=(1, 1), nlo=(1, 0))           # (-X1 b0, X1 b1)
+        P[x] = pk("add", T3, T4)
+    for xs in range(4):
+        P[7 - xs] = up[xs][:, 63 - lam]
+    for x in range(4):
+        P[x + 4], P[x] = bfly_pk(P[x + 4], P[x], img.tw_s2[x].T)
+    for x in (2, 3, 6, 7):
+        P[x], P[x - 2] = bfly_pk(P[x], P[x - 2], img.tw_l0[x & 1].T)
+    for x in (1, 3, 5, 7):
+        P[x], P[x - 1] = bfly_pk(P[x], P[x - 1], img.tw_l1.T)
+    lds = np.zeros((576, 2), F)
+    for x in range(8):
+        lds[slot_t2(64 * x + lam)] = P[x].T
+    Xc, lo3 = lam >> 3, lam & 7
+    Q = [lds[slot_t2(64 * Xc + 8 * y + lo3)].T.copy() for y in range(8)]
+    for y in (4, 5, 6, 7):
+        Q[y], Q[y - 4] = bfly_pk(Q[y], Q[y - 4], img.tw_l2[y & 3][lo3].T)
+    for y in (2, 3, 6, 7):
+        Q[y], Q[y - 2] = bfly_pk(Q[y], Q[y - 2], img.tw_l3[y & 1][lo3].T)
+    for y in (1, 3, 5, 7):
+        Q[y], Q[y - 1] = bfly_pk(Q[y], Q[y - 1], img.tw_l4[lo3].T)
+    for y in range(8):
+        lds[slot_t3(64 * Xc + 8 * y + lo3)] = Q[y].T
+    Z = [lds[slot_t3(8 * lam + zz)].T.copy() for zz in range(8)]
+    a2 = np.stack([np.full(64, img.a2, F)] * 2)
+    Z = last3_pk(Z, a2)
+    for zz in range(8):
+        lds[slot_t4(8 * lam + zz)] = Z[zz].T
+    pa, pb, outq = {}, {}, {}
+    for c in range(2):
+        mp = 2 * lam + c
+        q2 = 2 * rev_bits(mp, 7)
+        pq, pq256 = lds[slot_t4(q2)].T.copy(), lds[slot_t4(q2 + 256)].T.copy()
+        p255, p511 = lds[slot_t4(255 - q2)].T.copy(), lds[slot_t4(511 - q2)].T.copy()
+        C = img.c4[c]
+        Dn1, En1 = step7_block_pk(p511, pq, np.stack([C[:, 0], C[:, 1]]))      # (D1',D0'), (E3',E2')
+        Dn2, En2 = step7_block_pk(p255, pq256, np.stack([C[:, 2], C[:, 3]]))   # (D3',D2'), (E1',E0')
+        Bl, Bh = img.b_lo[c], img.b_hi[c]
+        R = [step8_pk(Dn1, np.stack([Bl[:, 0], Bl[:, 1]])), step8_pk(Dn2, np.stack([Bl[:, 2], Bl[:, 3]])),
+             step8_pk(En2, np.stack([Bh[:, 0], Bh[:, 1]])), step8_pk(En1, np.stack([Bh[:, 2], Bh[:, 3]]))]
+        qs = [511 - 2 * mp, 510 - 2 * mp, 1 + 2 * mp, 2 * mp]
+        for k in range(4):
+            for l in range(64):
+                pa[int(qs[k][l])] = R[k][0][l]
+                pb[int(qs[k][l])] = R[k][1][l]
+            if prev_pb is not None:
+                PP = np.stack([np.asarray(prev_pb, F)[qs[k]], np.zeros(64, F)])
+                S2 = np.stack([img.win[c][:, 2 * k], img.win[c][:, 2 * k + 1]])
+                O = ola_pk(R[k], PP, 0, S2)
+                for l in range(64):
+                    outq[int(qs[k][l])] = O[0][l]
+                    outq[1023 - int(qs[k][l])] = O[1][l]
+    out = np.zeros(N, F)
+    for q in range(N4):
+        out[q] = pa[q]
+        out[N2 - 1 - q] = -pa[q]
+        out[N2 + q] = pb[q]
+        out[N - 1 - q] = pb[q]
+    if prev_pb is not None:
+        return out, np.array([outq[i] for i in range(1024)], F)
+    return out

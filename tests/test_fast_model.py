@@ -99,3 +99,21 @@ def test_floor_division_by_reciprocal_is_exact():
                 q = np.trunc(z * rinv).astype(np.int64)
                 want = np.sign(dy) * ((tt * abs(dy)) // adx)
                 assert np.array_equal(q, want), (adx, dy)
+
+
+def test_packed_op_model_bit_exact():
+    """The v_pk_mul/add formulation (op_sel / neg modifiers emulated in numpy) == oracle, incl. window/overlap-add."""
+    blob, offs, _, _ = _image(SETUPS["stereo"]())
+    img = fm.Image(blob, offs)
+    rng = np.random.default_rng(1)
+    W = po.tables(11)[3]
+    for trial in range(3):
+        x = (rng.standard_normal(1024) * 0.3).astype(np.float32)
+        xprev = (rng.standard_normal(1024) * 0.3).astype(np.float32)
+        prev = po.inverse_mdct(xprev, 11)[1024:]
+        got, ola = fm.imdct_wave_pk(x, img, prev_pb=prev[:512], window=W)
+        want = po.inverse_mdct(x, 11)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        i = np.arange(1024)
+        ref = (want[:1024] * W[i]).astype(np.float32) + (prev * W[1023 - i]).astype(np.float32)
+        assert np.array_equal(ola.view(np.uint32), ref.astype(np.float32).view(np.uint32))
