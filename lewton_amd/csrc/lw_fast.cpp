@@ -102,10 +102,12 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 		}
 		u.floor_a = (uint8_t)sa;
 		u.floor_b = (uint8_t)sb;
+		u.F_a = plan.staged_floor_F[sa];
+		u.F_b = plan.staged_floor_F[sb];
 		plan.units.push_back(u);
 	}
-	if (LW_FAST_WAVES % plan.units.size() != 0) {
-		plan.why_not = "unit count does not divide the workgroup";
+	if (plan.units.size() > LW_FAST_WAVES) {
+		plan.why_not = "more units than waves in a workgroup";
 		return;
 	}
 
@@ -197,7 +199,9 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 					w.h(o.sid16)[((slot * 4 + x) * 64 + l) * 4 + j] = (uint16_t)(16 * sidx);
 				}
 	}
-	o.total = (uint32_t)((plan.image.size() + 15) & ~(size_t)15);
+	// the kernel stages the image with 3 x 16-byte loads per thread of a LW_FAST_WAVES-wave workgroup
+	const size_t quantum = (size_t)3 * 64 * LW_FAST_WAVES * 16;
+	o.total = (uint32_t)((plan.image.size() + quantum - 1) / quantum * quantum);
 	plan.image.resize(o.total, 0);
 	plan.eligible = true;
 }

@@ -9,7 +9,8 @@
 
 #define LW_FAST_BS 11          // the kernel is specialised for blocksize_1 = 11 (n = 2048)
 #define LW_FAST_MAX_FLOORS 2   // distinct floor-1 configurations staged in LDS
-#define LW_FAST_WAVES 16       // waves (packet-units) per workgroup
+#define LW_FAST_WAVES 8        // waves (packet-units) per workgroup and round: 2 per SIMD, <= 256 VGPRs each
+#define LW_FAST_MAX_ROUNDS 16  // rounds per workgroup (chunk = rounds * packets per round consecutive items)
 
 // Byte offsets inside the LDS image (all 16-byte aligned).  Index conventions: lane = 0..63,
 // p = pair index (u[2p], u[2p+1]) of the n/2-point butterfly array, m' = 2*lane + c.
@@ -36,6 +37,8 @@ struct LwFastUnit {
 	int8_t ch_a, ch_b;  // channels handled by one wave; ch_b = -1 for a single channel
 	uint8_t coupled;    // (ch_a = magnitude, ch_b = angle) form a coupling step
 	uint8_t floor_a, floor_b; // staged floor slot (0 / 1) of each channel
+	uint8_t F_a, F_b;   // floor-1 post count of each channel (<= 64)
+	uint8_t pad;
 };
 
 struct LwFastPlan {
@@ -49,10 +52,28 @@ struct LwFastPlan {
 	uint8_t staged_floor_F[LW_FAST_MAX_FLOORS] = {0};
 };
 
+// where the previous packet's un-windowed right half comes from
+#define LW_SRC_NONE 0u   // no previous window: 0 samples out (audio.rs:1140-1152)
+#define LW_SRC_LDS 1u    // the previous item of the work list, same workgroup (hand-over buffer in LDS)
+#define LW_SRC_STATE 2u  // state slot src_arg (parity in flags)
+#define LW_SRC_HALO 3u   // halo slot src_arg, filled by the RIGHT_ONLY pre-pass
+#define LW_SRC_TD 4u     // time-domain block at float offset src_arg of B.td (generic-kernel predecessor)
+
+// One work item of the specialised kernel = one packet; everything the kernel needs, in one 32-byte scalar load.
 struct LwFastItem {
-	uint32_t pkt;  // index into the batch's records
-	uint32_t halo; // halo slot that holds (main pass) / receives (pre-pass) the predecessor's right half, or 0xFFFFFFFF
+	uint32_t res_off;   // float offset of the packet's [ch][1024] residue block
+	uint32_t floor_off; // u16 offset of its [ch][fstride] floor block
+	uint32_t out_off;   // element offset of its output block
+	uint32_t src_arg;   // see LW_SRC_*
+	int32_t state_out;  // state slot that receives the raw right half, or -1
+	uint32_t halo_out;  // RIGHT_ONLY pre-pass: halo slot to fill
+	uint8_t src_kind;   // LW_SRC_*
+	uint8_t mode;
+	uint8_t flags;      // LW_RF_PARITY_IN / LW_RF_PARITY_OUT / LW_RF_WRITE_TD
+	uint8_t pad;
+	uint32_t pkt;       // index into the batch's records (host bookkeeping)
 };
+static_assert(sizeof(LwFastItem) == 32, "LwFastItem must stay 32 bytes");
 
 struct LwFastLaunch {
 	LwFastImage off;
@@ -62,7 +83,9 @@ struct LwFastLaunch {
 	const LwFastItem *d_halo_items;
 	uint32_t n_halo_items;
 	uint32_t n_units;
-	LwFastUnit units[LW_FAST_WAVES];
+	uint32_t per_round; // packets per workgroup and round
+	uint32_t rounds;    // rounds per workgroup
+	const LwFastUnit *d_units;
 	float *d_halo;
 };
 

@@ -5,11 +5,15 @@
 //     residue load (coalesced float4) -> inverse coupling -> floor-1 curve -> floor x residue
 //     -> IMDCT entirely in registers with three wave-private LDS transposes -> window/overlap-add
 //     -> i16/f32 store (coalesced).
-// 16 waves form a workgroup (one per CU, 150 KB LDS: 22 KB re-ordered twiddle/window tables staged once
-// + 8 KB transpose scratch per wave).  Consecutive packets of a stream sit in consecutive waves; a packet's
-// un-windowed right half is handed to its successor through LDS (one s_barrier per workgroup); across
-// workgroup boundaries it comes from a halo buffer filled by a RIGHT_ONLY pre-pass of this same kernel, at
-// run starts from the stream's state slot.
+// A workgroup is 8 waves (one per CU: 2 waves per SIMD, up to 256 VGPRs each) and works through a chunk of
+// `rounds` x `per_round` consecutive items of the stream-sorted work list in `rounds` rounds.  While a wave
+// computes round j its residue/floor loads for round j+1 are already in flight (register double buffer), and
+// its stores of round j drain while round j+1 computes: HBM traffic and arithmetic overlap inside one launch.
+// LDS: 22 KB re-ordered twiddle/window tables staged once per workgroup + 8 KB transpose scratch per wave
+// + 2 x 4 KB hand-over buffers per wave.  A packet's un-windowed right half reaches its successor through
+// the hand-over buffer (same round: wave - n_units; previous round: the last waves), one s_barrier per round;
+// at chunk starts it comes from the stream's state slot, from a halo buffer filled by a RIGHT_ONLY pre-pass of
+// this same kernel, or from the time-domain block of a generic-kernel predecessor.
 //
 // Register layouts of the 512 complex pairs p (u[2p], u[2p+1]) of imdct.rs's butterfly array, 8 per lane:
 //   B: lane = p[5:0], reg = p[8:6]   step 2 and stages l = 0,1   (pair bits 8,7,6 are lane-local)
@@ -25,21 +29,42 @@
 #include "lw_fast.hpp"
 #include "lw_kernels.hpp"
 
-#define LW_NONE 0xFFFFFFFFu
 #define LW_WG (64 * LW_FAST_WAVES)
-#define LW_SCR_FLOATS 2048 // per wave: [2 channels][1024 floats]
+#define LW_SCR_BYTES 8192u // per wave: [2 channels][4096 bytes] transposes / floor segment tables
+#define LW_PUB_BYTES 4096u // per wave and parity: [2 channels][2][64] float4 un-windowed right half
 
 struct LwFastArgs {
 	LwFastImage off;
 	const uint8_t *image;      // LDS image in HBM
-	const LwFastItem *items;   // (packet index, halo slot) in stream-sorted order
+	const LwFastItem *items;   // work list in stream-sorted order
 	uint32_t n_items;
 	uint32_t n_units;
-	uint32_t items_per_wg;     // packets per workgroup (<= LW_FAST_WAVES / n_units)
-	LwFastUnit units[LW_FAST_WAVES];
+	uint32_t per_round;        // packets per workgroup and round (<= LW_FAST_WAVES / n_units)
+	uint32_t rounds;           // rounds per workgroup
+	const LwFastUnit *units;   // [n_units] in HBM
 	float *halo;               // [slots][ch][512]
 	void *out;
 };
+
+#ifdef LW_STAMPS
+__device__ unsigned long long *g_lw_stamps = nullptr;
+extern "C" int lw_debug_set_stamp_buffer(void *dptr)
+{
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lw_stamps), &dptr, sizeof(dptr));
+}
+#define LW_STAMP_AT(i, waitstr)                                                                               \
+	do {                                                                                                      \
+		unsigned long long t_;                                                                                \
+		asm volatile(waitstr "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+		if (g_lw_stamps && (threadIdx.x & 63u) == 0 && (i) + 16 * sj < 64)                                    \
+			g_lw_stamps[((size_t)blockIdx.x * LW_FAST_WAVES + (threadIdx.x >> 6)) * 64 + (i) + 16 * sj] = t_; \
+	} while (0)
+#define LW_STAMP(i) LW_STAMP_AT(i, "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
+#define LW_STAMP_NW(i) LW_STAMP_AT(i, "")
+#else
+#define LW_STAMP(i)
+#define LW_STAMP_NW(i)
+#endif
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -50,21 +75,6 @@ __device__ __forceinline__ void lds_fence()
 	asm volatile("" ::: "memory"); // wave-private LDS traffic is in order in hardware; stop compiler motion only
 }
 
-struct Pair {
-	float e0, e1;
-};
-
-// imdct.rs:36-41 / :94-99 / :161-166 on (hi, lo) pairs
-__device__ __forceinline__ void bfly(Pair &H, Pair &L, float2_t t)
-{
-	const float k00 = H.e1 - L.e1;
-	const float k01 = H.e0 - L.e0;
-	H.e1 = H.e1 + L.e1;
-	H.e0 = H.e0 + L.e0;
-	L.e1 = k00 * t.x - k01 * t.y;
-	L.e0 = k01 * t.x + k00 * t.y;
-}
-
 __device__ __forceinline__ float2_t lds2(const char *base, uint32_t byte_off)
 {
 	return *reinterpret_cast<const float2_t *>(base + byte_off);
@@ -73,22 +83,6 @@ __device__ __forceinline__ float2_t lds2(const char *base, uint32_t byte_off)
 __device__ __forceinline__ float4_t lds4(const char *base, uint32_t byte_off)
 {
 	return *reinterpret_cast<const float4_t *>(base + byte_off);
-}
-
-// samples.rs:92-103
-__device__ __forceinline__ int to_i16s(float x)
-{
-	const float t = x * 32768.0f;
-	if (t > 32767.0f)
-		return 32767;
-	if (t < -32768.0f)
-		return -32768;
-	return (int)t;
-}
-
-__device__ __forceinline__ uint32_t pack2(float a, float b)
-{
-	return ((uint32_t)to_i16s(a) & 0xffffu) | ((uint32_t)to_i16s(b) << 16);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -154,45 +148,260 @@ __device__ __forceinline__ float2_t step8(float2_t Wv, float2_t Bq)
 	return pk_add(pk_mul_M9(Wv, Bq), pk_mul_M10(Wv, Bq));
 }
 
-// ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private)
-template <int NCH>
-__device__ __forceinline__ void long_phase1(const LwDevTables &T, const LwBatchDev &B, const LwFastArgs &F, const char *img,
-		char *scrb, uint32_t lane, const LwPacketRec &rec, const LwFastUnit &un, float4_t (&r)[2][4],
-		float2_t (&R)[2][2][4])
+// ---------------------------------------------------------------------------------------------
+// Per-round register state
+// ---------------------------------------------------------------------------------------------
+struct Pref {          // what one wave loads from HBM for one item
+	float4_t r[2][4];  // residues: lane holds bins 4 (64 x + lane) + j of each channel
+	uint32_t fe[2];    // floor-1 post entry of post `lane` of each channel (lanes >= F hold 0)
+};
+
+struct Twid1 {         // per-lane twiddles of step 1, step 2 and stages l = 0, 1
+	float2_t au[4], al[4], s2[4], l0[2], l1;
+};
+
+__device__ __forceinline__ void issue_loads(const LwDevTables &T, const LwBatchDev &B, const LwFastItem &it,
+		const LwFastUnit &un, uint32_t lane, Pref &p)
 {
-	const int chn[2] = {un.ch_a, un.ch_b >= 0 ? un.ch_b : un.ch_a};
-	const int fslot[2] = {un.floor_a, un.floor_b};
-	// ---- floor segment tables (one 16-byte entry per static interval), built by lanes = posts:
-	//      {dy, 0.5*sgn(dy) - x0*dy, 1/adx, 4*y0}; y(k) = y0 + trunc((k*dy + c0) * rinv)
-	bool unused[2] = {false, false};
+	const float4_t *s0 = reinterpret_cast<const float4_t *>(B.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
 #pragma unroll
-	for (int c = 0; c < 2; c++) {
-		if (c < NCH) {
-			const uint32_t Fp = T.floor_F[T.mode_floor[rec.mode * T.ch + chn[c]]];
-			const uint16_t *frec = B.floors + rec.floor_off + (uint32_t)chn[c] * T.fstride;
-			const uint32_t e = lane < Fp ? frec[lane] : 0u;
-			unused[c] = __builtin_amdgcn_readfirstlane(e) == LW_FLOOR_UNUSED;
-			const unsigned long long M = __ballot((e & LW_POST_ACTIVE) != 0);
-			const unsigned long long lowmask = (2ull << lane) - 1ull;
-			const unsigned long long below = M & lowmask, above = M & ~lowmask;
-			const int lo = below ? 63 - __builtin_clzll(below) : 0;
-			const int hi = above ? __builtin_ctzll(above) : lo;
-			const int y = (int)(e & 0xffu);
-			const float xs = *reinterpret_cast<const float *>(img + F.off.xsf + 4u * (64u * fslot[c] + lane));
-			const int ylo = __builtin_amdgcn_ds_bpermute(lo << 2, y);
-			const int yhi = __builtin_amdgcn_ds_bpermute(hi << 2, y);
-			const float xlo = __int_as_float(__builtin_amdgcn_ds_bpermute(lo << 2, __float_as_int(xs)));
-			const float xhi = __int_as_float(__builtin_amdgcn_ds_bpermute(hi << 2, __float_as_int(xs)));
-			const float dy = (float)(yhi - ylo); // 0 when there is no later active post (flat, audio.rs:546-548)
-			float4_t ent;
-			ent.x = dy;
-			ent.y = __builtin_copysignf(0.5f, dy) - xlo * dy; // exact
-			ent.z = above ? __builtin_amdgcn_rcpf(xhi - xlo) : 1.0f;
-			ent.w = __int_as_float(ylo << 2);
-			if (lane < Fp)
-				*reinterpret_cast<float4_t *>(scrb + 4096 * c + 16 * lane) = ent;
-		}
+	for (int x = 0; x < 4; x++)
+		p.r[0][x] = s0[64 * x + lane];
+	const uint16_t *f0 = B.floors + it.floor_off + (uint32_t)un.ch_a * T.fstride;
+	p.fe[0] = lane < un.F_a ? (uint32_t)f0[lane] : 0u;
+	p.fe[1] = 0u;
+	if (un.ch_b >= 0) {
+		const float4_t *s1 = reinterpret_cast<const float4_t *>(B.residue + it.res_off + (uint32_t)un.ch_b * 1024u);
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+			p.r[1][x] = s1[64 * x + lane];
+		const uint16_t *f1 = B.floors + it.floor_off + (uint32_t)un.ch_b * T.fstride;
+		p.fe[1] = lane < un.F_b ? (uint32_t)f1[lane] : 0u;
 	}
+}
+
+// ---- floor segment table of one channel (one 16-byte entry per static interval), built by lanes = posts:
+//      {dy, 0.5*sgn(dy) - x0*dy, 1/adx, 4*y0}; y(k) = y0 + trunc((k*dy + c0) * rinv)
+__device__ __forceinline__ bool floor_table(const LwFastArgs &F, const char *img, char *sc, uint32_t lane, uint32_t e,
+		uint32_t fslot, uint32_t Fp)
+{
+	const bool unused = __builtin_amdgcn_readfirstlane(e) == LW_FLOOR_UNUSED;
+	const unsigned long long M = __ballot((e & LW_POST_ACTIVE) != 0);
+	const unsigned long long lowmask = (2ull << lane) - 1ull;
+	const unsigned long long below = M & lowmask, above = M & ~lowmask;
+	const int lo = below ? 63 - __builtin_clzll(below) : 0;
+	const int hi = above ? __builtin_ctzll(above) : lo;
+	const int y = (int)(e & 0xffu);
+	const float xs = *reinterpret_cast<const float *>(img + F.off.xsf + 4u * (64u * fslot + lane));
+	const int ylo = __builtin_amdgcn_ds_bpermute(lo << 2, y);
+	const int yhi = __builtin_amdgcn_ds_bpermute(hi << 2, y);
+	const float xlo = __int_as_float(__builtin_amdgcn_ds_bpermute(lo << 2, __float_as_int(xs)));
+	const float xhi = __int_as_float(__builtin_amdgcn_ds_bpermute(hi << 2, __float_as_int(xs)));
+	const float dy = (float)(yhi - ylo); // 0 when there is no later active post (flat, audio.rs:546-548)
+	float4_t ent;
+	ent.x = dy;
+	ent.y = __builtin_copysignf(0.5f, dy) - xlo * dy; // exact
+	ent.z = above ? __builtin_amdgcn_rcpf(xhi - xlo) : 1.0f;
+	ent.w = __int_as_float(ylo << 2);
+	if (lane < Fp)
+		*reinterpret_cast<float4_t *>(sc + 16 * lane) = ent;
+	return unused;
+}
+
+// ---- floor value per bin; spectrum = floor * residue in place (audio.rs:1035-1037)
+__device__ __forceinline__ void spectrum(const LwFastArgs &F, const char *img, const char *sc, uint32_t lane, uint32_t fslot,
+		bool unused, float4_t (&r)[4])
+{
+	if (unused) {
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+			r[x] = r[x] * 0.0f; // zero floor (audio.rs:1021-1024)
+		return;
+	}
+	const float kf0 = (float)(4 * (int)lane);
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		const uint2_t sw = *reinterpret_cast<const uint2_t *>(img + F.off.sid16 + 8u * ((fslot * 4 + x) * 64u + lane));
+		const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
+		float4_t fl;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const float4_t ent = lds4(sc, s16[j]);
+			const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
+			const int q = (int)(z * ent.z);
+			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
+			fl[j] = *reinterpret_cast<const float *>(img + F.off.inv_db + idx);
+		}
+		const float2_t lo2 = pk_mul(float2_t{fl.x, fl.y}, float2_t{r[x].x, r[x].y});
+		const float2_t hi2 = pk_mul(float2_t{fl.z, fl.w}, float2_t{r[x].z, r[x].w});
+		r[x] = float4_t{lo2.x, lo2.y, hi2.x, hi2.y};
+	}
+}
+
+// ---- IMDCT step 1 (imdct.rs:337-371) in the load layout, exchange with the mirror lane -> layout B;
+//      step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452)
+__device__ __forceinline__ void stage_b(const Twid1 &tw, uint32_t lane, const float4_t (&r)[4], float2_t (&P)[8])
+{
+	const uint32_t mirror = (63u - lane) << 2;
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		const float2_t Xa = float2_t{r[x].x, r[x].y}, Xb = float2_t{r[x].z, r[x].w};
+		const float2_t U = pk_add(pk_mul_M3(Xa, tw.au[x]), pk_mul_M4(Xb, tw.au[x])); // pair 511 - m
+		P[x] = pk_add(pk_mul_M5(Xb, tw.al[x]), pk_mul_M6(Xa, tw.al[x]));            // pair m
+		P[7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.x)));
+		P[7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.y)));
+	}
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+		bfly2(P[x + 4], P[x], tw.s2[x]);
+#pragma unroll
+	for (int b = 0; b < 2; b++) {
+		bfly2(P[2 + b], P[b], tw.l0[b]);
+		bfly2(P[6 + b], P[4 + b], tw.l0[b]);
+	}
+#pragma unroll
+	for (int x = 1; x < 8; x += 2)
+		bfly2(P[x], P[x - 1], tw.l1);
+}
+
+// ---- T2: layout B -> C.  slot(p) = p ^ ((p>>6 & 3) << 3)
+__device__ __forceinline__ void t2_write(char *sc, uint32_t lane, const float2_t (&P)[8])
+{
+#pragma unroll
+	for (int x = 0; x < 8; x++) {
+		const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
+		*reinterpret_cast<float2_t *>(sc + 8u * slot) = P[x];
+	}
+}
+
+__device__ __forceinline__ void t2_read(const char *sc, uint32_t lane, float2_t (&Q)[8])
+{
+	const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
+#pragma unroll
+	for (int y = 0; y < 8; y++) {
+		const uint32_t slot = 64u * X3b + lo3 + 8u * ((uint32_t)y ^ (X3b & 3u));
+		Q[y] = lds2(sc, 8u * slot);
+	}
+}
+
+// ---- stages l = 2, 3, 4 (imdct.rs:454-477)
+__device__ __forceinline__ void stage_c(const float2_t (&t2)[4], const float2_t (&t3)[2], float2_t t4, float2_t (&Q)[8])
+{
+#pragma unroll
+	for (int yy = 0; yy < 4; yy++)
+		bfly2(Q[4 + yy], Q[yy], t2[yy]);
+#pragma unroll
+	for (int b = 0; b < 2; b++) {
+		bfly2(Q[2 + b], Q[b], t3[b]);
+		bfly2(Q[6 + b], Q[4 + b], t3[b]);
+	}
+#pragma unroll
+	for (int y = 1; y < 8; y += 2)
+		bfly2(Q[y], Q[y - 1], t4);
+}
+
+// ---- T3: layout C -> D.  slot(p) = 8 nu + (z ^ (nu>>2 & 7)), nu = p>>3, z = p&7
+__device__ __forceinline__ void t3_write(char *sc, uint32_t lane, const float2_t (&Q)[8])
+{
+	const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
+#pragma unroll
+	for (int y = 0; y < 8; y++) {
+		const uint32_t nu = 8u * X3b + y;
+		const uint32_t slot = 8u * nu + (lo3 ^ ((nu >> 2) & 7u));
+		*reinterpret_cast<float2_t *>(sc + 8u * slot) = Q[y];
+	}
+}
+
+__device__ __forceinline__ void t3_read(const char *sc, uint32_t lane, float2_t (&Z)[8])
+{
+#pragma unroll
+	for (int zz = 0; zz < 8; zz++) { // Z[j] = (u[16 lane + 2j], u[16 lane + 2j + 1])
+		const uint32_t slot = 8u * lane + ((uint32_t)zz ^ ((lane >> 2) & 7u));
+		Z[zz] = lds2(sc, 8u * slot);
+	}
+}
+
+// ---- fused last three stages (imdct.rs:234-288), lane-local, 28 packed operations per channel
+__device__ __forceinline__ void stage_d(float2_t a2, float2_t (&z)[8])
+{
+	float2_t t0, t1;
+	t0 = pk_add(z[7], z[3]);
+	z[3] = pk_sub(z[7], z[3]);
+	z[7] = t0;
+	t0 = pk_add(z[6], z[2]);
+	t1 = pk_sub(z[6], z[2]);                    // (k11, k00)
+	z[2] = pk_mul(pk_add_A2(t1, t1), a2);       // ((k11-k00) a2, (k00+k11) a2)
+	z[6] = t0;
+	t0 = pk_add(z[5], z[1]);
+	z[1] = pk_add_A3(z[1], z[5]);               // (z3 - z11, z10 - z2)
+	z[5] = t0;
+	t0 = pk_add(z[4], z[0]);
+	t1 = pk_add_A4(z[0], z[4]);                 // (k11, k00)
+	z[0] = pk_mul(pk_add_A5(t1, t1), a2);       // ((k00-k11) a2, (k00+k11) a2)
+	z[4] = t0;
+#pragma unroll
+	for (int b = 4; b >= 0; b -= 4) { // imdct.rs:202-232 on w[0..8) = z[b..b+4)
+		const float2_t A = pk_add(z[b + 3], z[b + 1]);  // (y1, y0)
+		const float2_t Bm = pk_sub(z[b + 3], z[b + 1]); // (k11, k00)
+		const float2_t Cc = pk_add(z[b + 2], z[b]);     // (y3, y2)
+		const float2_t Dm = pk_sub(z[b + 2], z[b]);     // (k33, k22)
+		z[b + 3] = pk_add(A, Cc);
+		z[b + 2] = pk_sub(A, Cc);
+		z[b + 1] = pk_add_A2(Bm, Dm);                   // (k11 - k22, k00 + k33)
+		z[b] = pk_add_A6(Bm, Dm);                       // (k11 + k22, k00 - k33)
+	}
+}
+
+// ---- T4: layout D -> bit-reverse gather.  slot(p) = (p & ~127) | ((p & 3) << 5) | ((p >> 2) & 31)
+__device__ __forceinline__ void t4_write(char *sc, uint32_t lane, const float2_t (&Z)[8])
+{
+	const uint32_t base = 128u * (lane >> 4) + 2u * (lane & 15u);
+#pragma unroll
+	for (int zz = 0; zz < 8; zz++) {
+		const uint32_t slot = base + 32u * (zz & 3) + (zz >> 2);
+		*reinterpret_cast<float2_t *>(sc + 8u * slot) = Z[zz];
+	}
+}
+
+struct TwidE { // tables of layout E for one c2
+	float4_t Cq, Bl, Bh;
+};
+
+// ---- bit-reverse gather (imdct.rs:490-528), step 7 (:533-580), step 8 (:589-658) of m' = 2 lane + c2
+__device__ __forceinline__ void stage_e(const char *sc, uint32_t lane, int c2, const TwidE &tw, float2_t (&R)[4])
+{
+	// rho = rev6(lane); s0 = slot(2 rho): pairs 2v, 2v+256, 255-2v, 511-2v of m' = 2 lane + c2
+	const uint32_t rho = __builtin_bitreverse32(lane) >> 26;
+	const uint32_t s0 = ((rho & 1u) << 6) | (rho >> 1);
+	const uint32_t sa = 128u * c2 + s0; // slot of pair 2v
+	const uint32_t sb = 255u - sa;      // slot of pair 255 - 2v
+	const float2_t pq = lds2(sc, 8u * sa), pq256 = lds2(sc, 8u * (sa + 256u));   // (E3,E2), (E1,E0)
+	const float2_t p255 = lds2(sc, 8u * sb), p511 = lds2(sc, 8u * (sb + 256u));  // (D3,D2), (D1,D0)
+	float2_t Dn1, En1, Dn2, En2;
+	step7_block(p511, pq, float2_t{tw.Cq.x, tw.Cq.y}, Dn1, En1);    // (D1',D0'), (E3',E2')
+	step7_block(p255, pq256, float2_t{tw.Cq.z, tw.Cq.w}, Dn2, En2); // (D3',D2'), (E1',E0')
+	// step 8 (imdct.rs:618-657): q = 511-2m', 510-2m', 1+2m', 2m'
+	R[0] = step8(Dn1, float2_t{tw.Bl.x, tw.Bl.y});
+	R[1] = step8(Dn2, float2_t{tw.Bl.z, tw.Bl.w});
+	R[2] = step8(En2, float2_t{tw.Bh.x, tw.Bh.y});
+	R[3] = step8(En1, float2_t{tw.Bh.z, tw.Bh.w});
+}
+
+// ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private).
+// The two channels of a pair are software-pipelined against each other: while one channel's transpose is
+// in flight in LDS the other channel's butterflies issue.
+template <int NCH>
+__device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img, char *scrb, char *pub, uint32_t lane,
+		const LwFastUnit &un, Pref &pf, float2_t (&R)[2][2][4], uint32_t sj)
+{
+	(void)sj;
+	char *sc0 = scrb, *sc1 = scrb + 4096;
+	const uint32_t lo3 = lane & 7u;
+	// ---- floor segment tables
+	const bool unused0 = floor_table(F, img, sc0, lane, pf.fe[0], un.floor_a, un.F_a);
+	bool unused1 = false;
+	if (NCH == 2)
+		unused1 = floor_table(F, img, sc1, lane, pf.fe[1], un.floor_b, un.F_b);
 	lds_fence();
 	// ---- inverse coupling (audio.rs:762-777, :990-1002) on the raw residues
 	if (NCH == 2 && un.coupled) {
@@ -200,424 +409,214 @@ __device__ __forceinline__ void long_phase1(const LwDevTables &T, const LwBatchD
 		for (int x = 0; x < 4; x++) {
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
-				const float m = r[0][x][j], a = r[1][x][j];
+				const float m = pf.r[0][x][j], a = pf.r[1][x][j];
 				const float ap = m > 0.0f ? a : -a; // (m, a) -> a>0 ? (m, m-a') : (m+a', m)
 				const float s = m + ap, d = m - ap;
 				const bool apos = a > 0.0f;
-				r[0][x][j] = apos ? m : s;
-				r[1][x][j] = apos ? d : m;
+				pf.r[0][x][j] = apos ? m : s;
+				pf.r[1][x][j] = apos ? d : m;
 			}
 		}
 	}
-	// ---- floor value per bin; spectrum = floor * residue in place (audio.rs:1035-1037)
-	const float kf0 = (float)(4 * (int)lane);
-#pragma unroll
-	for (int c = 0; c < 2; c++) {
-		if (c < NCH) {
-			if (unused[c]) {
-#pragma unroll
-				for (int x = 0; x < 4; x++)
-					r[c][x] = r[c][x] * 0.0f; // zero floor (audio.rs:1021-1024)
-			} else {
-#pragma unroll
-				for (int x = 0; x < 4; x++) {
-					const uint2_t sw = *reinterpret_cast<const uint2_t *>(
-							img + F.off.sid16 + 8u * ((fslot[c] * 4 + x) * 64u + lane));
-					const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
-					float4_t fl;
-#pragma unroll
-					for (int j = 0; j < 4; j++) {
-						const float4_t ent = lds4(scrb + 4096 * c, s16[j]);
-						const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
-						const int q = (int)(z * ent.z);
-						const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
-						fl[j] = *reinterpret_cast<const float *>(img + F.off.inv_db + idx);
-					}
-					const float2_t lo2 = pk_mul(float2_t{fl.x, fl.y}, float2_t{r[c][x].x, r[c][x].y});
-					const float2_t hi2 = pk_mul(float2_t{fl.z, fl.w}, float2_t{r[c][x].z, r[c][x].w});
-					r[c][x] = float4_t{lo2.x, lo2.y, hi2.x, hi2.y};
-				}
-			}
-		}
-	}
+	spectrum(F, img, sc0, lane, un.floor_a, unused0, pf.r[0]);
+	if (NCH == 2)
+		spectrum(F, img, sc1, lane, un.floor_b, unused1, pf.r[1]);
 	lds_fence();
+	LW_STAMP(4);
 
-	// ---- IMDCT step 1 (imdct.rs:337-371) in the load layout; exchange with the mirror lane -> layout B
-	float2_t P[2][8];
-	const uint32_t mirror = (63u - lane) << 2;
+	// ---- twiddles of layout B
+	Twid1 tw;
 #pragma unroll
 	for (int x = 0; x < 4; x++) {
 		const uint32_t m = 64u * x + lane;
-		const float2_t au = lds2(img + F.off.apair, 8u * m);          // (A[2m], A[2m+1])
-		const float2_t al = lds2(img + F.off.apair, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
-#pragma unroll
-		for (int c = 0; c < 2; c++) {
-			if (c < NCH) {
-				const float2_t Xa = float2_t{r[c][x].x, r[c][x].y}, Xb = float2_t{r[c][x].z, r[c][x].w};
-				const float2_t U = pk_add(pk_mul_M3(Xa, au), pk_mul_M4(Xb, au)); // pair 511 - m
-				P[c][x] = pk_add(pk_mul_M5(Xb, al), pk_mul_M6(Xa, al));          // pair m
-				P[c][7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.x)));
-				P[c][7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.y)));
-			}
-		}
+		tw.au[x] = lds2(img + F.off.apair, 8u * m);          // (A[2m], A[2m+1])
+		tw.al[x] = lds2(img + F.off.apair, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
+		tw.s2[x] = lds2(img + F.off.tw_s2, 8u * (64u * x + lane));
 	}
-	// ---- step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452)
-#pragma unroll
-	for (int x = 0; x < 4; x++) {
-		const float2_t t = lds2(img + F.off.tw_s2, 8u * (64u * x + lane));
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH)
-				bfly2(P[c][x + 4], P[c][x], t);
-	}
-#pragma unroll
-	for (int b = 0; b < 2; b++) {
-		const float2_t t = lds2(img + F.off.tw_l0, 8u * (64u * b + lane));
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-				bfly2(P[c][2 + b], P[c][b], t);
-				bfly2(P[c][6 + b], P[c][4 + b], t);
-			}
-	}
-	{
-		const float2_t t = lds2(img + F.off.tw_l1, 8u * lane);
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-#pragma unroll
-				for (int x = 1; x < 8; x += 2)
-					bfly2(P[c][x], P[c][x - 1], t);
-			}
-	}
-	// ---- T2: layout B -> C.  slot(p) = p ^ ((p>>6 & 3) << 3)
-	const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
-#pragma unroll
-	for (int c = 0; c < 2; c++)
-		if (c < NCH) {
-#pragma unroll
-			for (int x = 0; x < 8; x++) {
-				const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
-				*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = P[c][x];
-			}
-		}
+	tw.l0[0] = lds2(img + F.off.tw_l0, 8u * lane);
+	tw.l0[1] = lds2(img + F.off.tw_l0, 8u * (64u + lane));
+	tw.l1 = lds2(img + F.off.tw_l1, 8u * lane);
+	float2_t P0[8], P1[8];
+	stage_b(tw, lane, pf.r[0], P0);
+	t2_write(sc0, lane, P0);
+	if (NCH == 2)
+		stage_b(tw, lane, pf.r[1], P1);
 	lds_fence();
-	float2_t Q[2][8];
+	LW_STAMP(5);
+	// ---- twiddles of layout C
+	float2_t t2[4], t3[2], t4;
 #pragma unroll
-	for (int c = 0; c < 2; c++)
-		if (c < NCH) {
-#pragma unroll
-			for (int y = 0; y < 8; y++) {
-				const uint32_t slot = 64u * X3b + lo3 + 8u * ((uint32_t)y ^ (X3b & 3u));
-				Q[c][y] = lds2(scrb + 4096 * c, 8u * slot);
-			}
-		}
+	for (int yy = 0; yy < 4; yy++)
+		t2[yy] = lds2(img + F.off.tw_l2, 8u * (8u * yy + lo3));
+	t3[0] = lds2(img + F.off.tw_l3, 8u * lo3);
+	t3[1] = lds2(img + F.off.tw_l3, 8u * (8u + lo3));
+	t4 = lds2(img + F.off.tw_l4, 8u * lo3);
+	t2_read(sc0, lane, P0); // P0 now holds layout C
+	if (NCH == 2)
+		t2_write(sc1, lane, P1);
 	lds_fence();
-	// ---- stages l = 2, 3, 4 (imdct.rs:454-477)
-#pragma unroll
-	for (int yy = 0; yy < 4; yy++) {
-		const float2_t t = lds2(img + F.off.tw_l2, 8u * (8u * yy + lo3));
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH)
-				bfly2(Q[c][4 + yy], Q[c][yy], t);
-	}
-#pragma unroll
-	for (int b = 0; b < 2; b++) {
-		const float2_t t = lds2(img + F.off.tw_l3, 8u * (8u * b + lo3));
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-				bfly2(Q[c][2 + b], Q[c][b], t);
-				bfly2(Q[c][6 + b], Q[c][4 + b], t);
-			}
-	}
-	{
-		const float2_t t = lds2(img + F.off.tw_l4, 8u * lo3);
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-#pragma unroll
-				for (int y = 1; y < 8; y += 2)
-					bfly2(Q[c][y], Q[c][y - 1], t);
-			}
-	}
-	// ---- T3: layout C -> D.  slot(p) = 8 nu + (z ^ (nu>>2 & 7)), nu = p>>3, z = p&7
-#pragma unroll
-	for (int c = 0; c < 2; c++)
-		if (c < NCH) {
-#pragma unroll
-			for (int y = 0; y < 8; y++) {
-				const uint32_t nu = 8u * X3b + y;
-				const uint32_t slot = 8u * nu + (lo3 ^ ((nu >> 2) & 7u));
-				*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = Q[c][y];
-			}
-		}
+	stage_c(t2, t3, t4, P0);
+	t3_write(sc0, lane, P0);
 	lds_fence();
-	float2_t Z[2][8]; // Z[j] = (u[16 lane + 2j], u[16 lane + 2j + 1])
-#pragma unroll
-	for (int c = 0; c < 2; c++)
-		if (c < NCH) {
-#pragma unroll
-			for (int zz = 0; zz < 8; zz++) {
-				const uint32_t slot = 8u * lane + ((uint32_t)zz ^ ((lane >> 2) & 7u));
-				Z[c][zz] = lds2(scrb + 4096 * c, 8u * slot);
-			}
-		}
-	lds_fence();
-	// ---- fused last three stages (imdct.rs:234-288), lane-local, 28 packed operations per channel
-	{
-		const float a2s = *reinterpret_cast<const float *>(img + F.off.a2);
-		const float2_t a2 = float2_t{a2s, a2s};
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-				float2_t *z = Z[c];
-				float2_t t0, t1;
-				t0 = pk_add(z[7], z[3]);
-				z[3] = pk_sub(z[7], z[3]);
-				z[7] = t0;
-				t0 = pk_add(z[6], z[2]);
-				t1 = pk_sub(z[6], z[2]);                    // (k11, k00)
-				z[2] = pk_mul(pk_add_A2(t1, t1), a2);       // ((k11-k00) a2, (k00+k11) a2)
-				z[6] = t0;
-				t0 = pk_add(z[5], z[1]);
-				z[1] = pk_add_A3(z[1], z[5]);               // (z3 - z11, z10 - z2)
-				z[5] = t0;
-				t0 = pk_add(z[4], z[0]);
-				t1 = pk_add_A4(z[0], z[4]);                 // (k11, k00)
-				z[0] = pk_mul(pk_add_A5(t1, t1), a2);       // ((k00-k11) a2, (k00+k11) a2)
-				z[4] = t0;
-#pragma unroll
-				for (int b = 4; b >= 0; b -= 4) { // imdct.rs:202-232 on w[0..8) = z[b..b+4)
-					const float2_t A = pk_add(z[b + 3], z[b + 1]);  // (y1, y0)
-					const float2_t Bm = pk_sub(z[b + 3], z[b + 1]); // (k11, k00)
-					const float2_t Cc = pk_add(z[b + 2], z[b]);     // (y3, y2)
-					const float2_t Dm = pk_sub(z[b + 2], z[b]);     // (k33, k22)
-					z[b + 3] = pk_add(A, Cc);
-					z[b + 2] = pk_sub(A, Cc);
-					z[b + 1] = pk_add_A2(Bm, Dm);                   // (k11 - k22, k00 + k33)
-					z[b] = pk_add_A6(Bm, Dm);                       // (k11 + k22, k00 - k33)
-				}
-			}
+	if (NCH == 2) {
+		t2_read(sc1, lane, P1);
+		lds_fence();
+		stage_c(t2, t3, t4, P1);
 	}
-	// ---- T4: layout D -> bit-reverse gather.  slot(p) = (p & ~127) | ((p & 3) << 5) | ((p >> 2) & 31)
-	{
-		const uint32_t base = 128u * (lane >> 4) + 2u * (lane & 15u);
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-#pragma unroll
-				for (int zz = 0; zz < 8; zz++) {
-					const uint32_t slot = base + 32u * (zz & 3) + (zz >> 2);
-					*reinterpret_cast<float2_t *>(scrb + 4096 * c + 8u * slot) = Z[c][zz];
-				}
-			}
-	}
+	LW_STAMP(6);
+	const float a2s = *reinterpret_cast<const float *>(img + F.off.a2);
+	const float2_t a2 = float2_t{a2s, a2s};
+	t3_read(sc0, lane, P0); // layout D
+	if (NCH == 2)
+		t3_write(sc1, lane, P1);
 	lds_fence();
-	// rho = rev6(lane); s0 = slot(2 rho): pairs 2v, 2v+256, 255-2v, 511-2v of m' = 2 lane + c2
-	const uint32_t rho = __builtin_bitreverse32(lane) >> 26;
-	const uint32_t s0 = ((rho & 1u) << 6) | (rho >> 1);
+	stage_d(a2, P0);
+	t4_write(sc0, lane, P0);
+	lds_fence();
+	if (NCH == 2) {
+		t3_read(sc1, lane, P1);
+		lds_fence();
+		stage_d(a2, P1);
+		t4_write(sc1, lane, P1);
+		lds_fence();
+	}
+	LW_STAMP(7);
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) {
-		const float4_t Cq = lds4(img + F.off.c4, 16u * (64u * c2 + lane));
-		const float4_t Bl = lds4(img + F.off.b_lo, 16u * (64u * c2 + lane));
-		const float4_t Bh = lds4(img + F.off.b_hi, 16u * (64u * c2 + lane));
-		const uint32_t sa = 128u * c2 + s0; // slot of pair 2v
-		const uint32_t sb = 255u - sa;      // slot of pair 255 - 2v
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-				const char *sc = scrb + 4096 * c;
-				const float2_t pq = lds2(sc, 8u * sa), pq256 = lds2(sc, 8u * (sa + 256u));   // (E3,E2), (E1,E0)
-				const float2_t p255 = lds2(sc, 8u * sb), p511 = lds2(sc, 8u * (sb + 256u));  // (D3,D2), (D1,D0)
-				float2_t Dn1, En1, Dn2, En2;
-				step7_block(p511, pq, float2_t{Cq.x, Cq.y}, Dn1, En1);    // (D1',D0'), (E3',E2')
-				step7_block(p255, pq256, float2_t{Cq.z, Cq.w}, Dn2, En2); // (D3',D2'), (E1',E0')
-				// step 8 (imdct.rs:618-657): q = 511-2m', 510-2m', 1+2m', 2m'
-				R[c][c2][0] = step8(Dn1, float2_t{Bl.x, Bl.y});
-				R[c][c2][1] = step8(Dn2, float2_t{Bl.z, Bl.w});
-				R[c][c2][2] = step8(En2, float2_t{Bh.x, Bh.y});
-				R[c][c2][3] = step8(En1, float2_t{Bh.z, Bh.w});
-			}
+		TwidE te;
+		te.Cq = lds4(img + F.off.c4, 16u * (64u * c2 + lane));
+		te.Bl = lds4(img + F.off.b_lo, 16u * (64u * c2 + lane));
+		te.Bh = lds4(img + F.off.b_hi, 16u * (64u * c2 + lane));
+		stage_e(sc0, lane, c2, te, R[0][c2]);
+		if (NCH == 2)
+			stage_e(sc1, lane, c2, te, R[1][c2]);
 	}
 	lds_fence();
-	// ---- publish the un-windowed right half for the successor wave (own scratch, [channel][c2][lane] float4)
+	LW_STAMP(8);
+	// ---- publish the un-windowed right half for the successor ([channel][c2][lane] float4)
 #pragma unroll
 	for (int c = 0; c < 2; c++)
 		if (c < NCH) {
 #pragma unroll
 			for (int c2 = 0; c2 < 2; c2++)
-				*reinterpret_cast<float4_t *>(scrb + 4096 * c + 16u * (64u * c2 + lane)) =
+				*reinterpret_cast<float4_t *>(pub + 2048 * c + 16u * (64u * c2 + lane)) =
 					float4_t{R[c][c2][0].y, R[c][c2][1].y, R[c][c2][2].y, R[c][c2][3].y};
 		}
 }
 
-// ---- phase 2: overlap-add with the predecessor's right half, sample conversion, stores, state hand-over
-template <int NCH, int FMT, bool RIGHT_ONLY>
-__device__ __forceinline__ void long_phase2(const LwDevTables &T, const LwBatchDev &B, const LwFastArgs &F, const char *img,
-		float *scr, uint32_t lane, uint32_t wave, uint32_t item, const LwPacketRec &rec, const LwFastUnit &un,
-		float2_t (&R)[2][2][4])
-{
-	const int chn[2] = {un.ch_a, un.ch_b >= 0 ? un.ch_b : un.ch_a};
-	// pb at this lane's q positions: group 0 = q in [4 lane, +4), group 1 = q in [508 - 4 lane, +4) (ascending)
+// pb at this lane's q positions: group 0 = q in [4 lane, +4), group 1 = q in [508 - 4 lane, +4) (ascending)
 #define LW_PB_LO0(c) float4_t{R[c][0][3].y, R[c][0][2].y, R[c][1][3].y, R[c][1][2].y}
 #define LW_PB_LO1(c) float4_t{R[c][1][1].y, R[c][1][0].y, R[c][0][1].y, R[c][0][0].y}
-	if (RIGHT_ONLY) {
-		const uint32_t hs = F.items[item].halo;
+
+// previous right half of one channel as the overlap-add consumes it: pp[c2][0] = (k=0, k=1), pp[c2][1] = (k=2, k=3)
+struct PrevHalf {
+	float2_t pp[2][2];
+};
+
+__device__ __forceinline__ void prev_from_lds(const char *src, uint32_t lane, PrevHalf &h)
+{
 #pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-				float *dst = F.halo + ((size_t)hs * T.ch + chn[c]) * 512u;
-				*reinterpret_cast<float4_t *>(dst + 4u * lane) = LW_PB_LO0(c);
-				*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
-			}
-		return;
+	for (int c2 = 0; c2 < 2; c2++) {
+		const float4_t v = *reinterpret_cast<const float4_t *>(src + 16u * (64u * c2 + lane));
+		h.pp[c2][0] = float2_t{v.x, v.y};
+		h.pp[c2][1] = float2_t{v.z, v.w};
 	}
-	// ---- previous right half: LDS (predecessor wave), state slot, halo buffer, or a generic packet's td block
-	if (rec.prev != -1) {
-		bool from_lds = false;
-		const float *gsrc[2] = {nullptr, nullptr};
-		if (rec.prev <= -2) {
-			const uint32_t slot = (uint32_t)(-(rec.prev + 2));
-			const uint32_t par = (rec.flags & LW_RF_PARITY_IN) ? 1u : 0u;
-			const float *st = B.state + ((size_t)slot * 2 + par) * T.state_stride;
-			gsrc[0] = st + (uint32_t)chn[0] * T.state_chan_stride;
-			gsrc[1] = st + (uint32_t)chn[1] * T.state_chan_stride;
-		} else if (wave >= F.n_units && F.items[item - 1].pkt == (uint32_t)rec.prev) {
-			from_lds = true;
-		} else if (F.items[item].halo != LW_NONE) {
-			const float *h = F.halo + (size_t)F.items[item].halo * T.ch * 512u;
-			gsrc[0] = h + (uint32_t)chn[0] * 512u;
-			gsrc[1] = h + (uint32_t)chn[1] * 512u;
-		} else {
-			const LwPacketRec pr = B.recs[rec.prev];
-			const float *td = B.td + 2u * (size_t)pr.res_off + 1024u;
-			gsrc[0] = td + (uint32_t)chn[0] * 2048u;
-			gsrc[1] = td + (uint32_t)chn[1] * 2048u;
+}
+
+__device__ __forceinline__ void prev_from_global(const float *g, uint32_t lane, PrevHalf &h)
+{
+	const float4_t g0 = *reinterpret_cast<const float4_t *>(g + 4u * lane);        // q = 4l .. 4l+3
+	const float4_t g1 = *reinterpret_cast<const float4_t *>(g + 508u - 4u * lane); // q = 508-4l ..
+	h.pp[0][1] = float2_t{g0.y, g0.x}; // (c2=0: k=2 -> q=4l+1, k=3 -> q=4l)
+	h.pp[1][1] = float2_t{g0.w, g0.z}; // (c2=1: k=2 -> 4l+3, k=3 -> 4l+2)
+	h.pp[1][0] = float2_t{g1.y, g1.x}; // (c2=1: k=0 -> 509-4l, k=1 -> 508-4l)
+	h.pp[0][0] = float2_t{g1.w, g1.z}; // (c2=0: k=0 -> 511-4l, k=1 -> 510-4l)
+}
+
+// ---- window + overlap-add (audio.rs:1116-1118), sample conversion (samples.rs:92-103), stores of one channel
+template <int FMT>
+__device__ __forceinline__ void ola_store(const LwDevTables &T, const LwFastArgs &F, const char *img, uint32_t lane, int chn,
+		uint32_t out_off, const float2_t (&Rc)[2][4], const PrevHalf &h)
+{
+	// (out[q], out[1023-q]) = (pa s[q] + pb' s[r], -pa s[r] + pb' s[q])
+	float2_t O[2][4];
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) {
+		const float4_t w0 = lds4(img + F.off.win, 32u * (64u * c2 + lane));
+		const float4_t w1 = lds4(img + F.off.win, 32u * (64u * c2 + lane) + 16u);
+		const float2_t S2[4] = {float2_t{w0.x, w0.y}, float2_t{w0.z, w0.w}, float2_t{w1.x, w1.y}, float2_t{w1.z, w1.w}};
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const float2_t o1 = pk_mul_M4(Rc[c2][k], S2[k]); // (pa s[q], -pa s[r])
+			const float2_t o2 = (k & 1) ? pk_mul_M12hi(h.pp[c2][k >> 1], S2[k]) : pk_mul_M12lo(h.pp[c2][k >> 1], S2[k]);
+			O[c2][k] = pk_add(o1, o2);
 		}
-		const float *pscr = scr - (size_t)F.n_units * LW_SCR_FLOATS; // predecessor wave's scratch
+	}
+	// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [508-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
+	//            [512+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [1020-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
+	const uint32_t p0 = 4u * lane, p1 = 508u - 4u * lane, p2 = 512u + 4u * lane, p3 = 1020u - 4u * lane;
+	if (FMT == LW_OUT_F32_PLANAR) {
+		float *o = reinterpret_cast<float *>(F.out) + out_off + (uint32_t)chn * 1024u;
+		*reinterpret_cast<float4_t *>(o + p0) = float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x};
+		*reinterpret_cast<float4_t *>(o + p1) = float4_t{O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x};
+		*reinterpret_cast<float4_t *>(o + p2) = float4_t{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y};
+		*reinterpret_cast<float4_t *>(o + p3) = float4_t{O[1][2].y, O[1][3].y, O[0][2].y, O[0][3].y};
+	} else {
+		// samples.rs:92-103: x*32768, truncate toward zero (v_cvt_i32_f32: saturating, NaN -> 0), clamp to
+		// i16 by the saturating pack v_cvt_pk_i16_i32 -- equal to the reference's compare/clamp/`as i16`
 		const float2_t k32768 = float2_t{32768.0f, 32768.0f};
+		int iq[2][4], im[2][4];
 #pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-				float2_t pp[2][2]; // previous pb: pp[c2][0] = (k=0, k=1), pp[c2][1] = (k=2, k=3)
-				if (from_lds) {
+		for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
-					for (int c2 = 0; c2 < 2; c2++) {
-						const float4_t v = *reinterpret_cast<const float4_t *>(
-								reinterpret_cast<const char *>(pscr) + 4096 * c + 16u * (64u * c2 + lane));
-						pp[c2][0] = float2_t{v.x, v.y};
-						pp[c2][1] = float2_t{v.z, v.w};
-					}
-				} else {
-					const float4_t g0 = *reinterpret_cast<const float4_t *>(gsrc[c] + 4u * lane);        // q = 4l .. 4l+3
-					const float4_t g1 = *reinterpret_cast<const float4_t *>(gsrc[c] + 508u - 4u * lane); // q = 508-4l ..
-					pp[0][1] = float2_t{g0.y, g0.x}; // (c2=0: k=2 -> q=4l+1, k=3 -> q=4l)
-					pp[1][1] = float2_t{g0.w, g0.z}; // (c2=1: k=2 -> 4l+3, k=3 -> 4l+2)
-					pp[1][0] = float2_t{g1.y, g1.x}; // (c2=1: k=0 -> 509-4l, k=1 -> 508-4l)
-					pp[0][0] = float2_t{g1.w, g1.z}; // (c2=0: k=0 -> 511-4l, k=1 -> 510-4l)
-				}
-				// ---- window + overlap-add (audio.rs:1116-1118): (out[q], out[1023-q]) = (pa s[q] + pb' s[r], -pa s[r] + pb' s[q])
-				float2_t O[2][4];
-#pragma unroll
-				for (int c2 = 0; c2 < 2; c2++) {
-					const float4_t w0 = lds4(img + F.off.win, 32u * (64u * c2 + lane));
-					const float4_t w1 = lds4(img + F.off.win, 32u * (64u * c2 + lane) + 16u);
-					const float2_t S2[4] = {float2_t{w0.x, w0.y}, float2_t{w0.z, w0.w}, float2_t{w1.x, w1.y}, float2_t{w1.z, w1.w}};
-#pragma unroll
-					for (int k = 0; k < 4; k++) {
-						const float2_t o1 = pk_mul_M4(R[c][c2][k], S2[k]); // (pa s[q], -pa s[r])
-						const float2_t o2 = (k & 1) ? pk_mul_M12hi(pp[c2][k >> 1], S2[k]) : pk_mul_M12lo(pp[c2][k >> 1], S2[k]);
-						O[c2][k] = pk_add(o1, o2);
-					}
-				}
-				// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [508-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
-				//            [512+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [1020-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
-				const uint32_t p0 = 4u * lane, p1 = 508u - 4u * lane, p2 = 512u + 4u * lane, p3 = 1020u - 4u * lane;
-				if (FMT == LW_OUT_F32_PLANAR) {
-					float *o = reinterpret_cast<float *>(F.out) + rec.out_off + (uint32_t)chn[c] * 1024u;
-					*reinterpret_cast<float4_t *>(o + p0) = float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x};
-					*reinterpret_cast<float4_t *>(o + p1) = float4_t{O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x};
-					*reinterpret_cast<float4_t *>(o + p2) = float4_t{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y};
-					*reinterpret_cast<float4_t *>(o + p3) = float4_t{O[1][2].y, O[1][3].y, O[0][2].y, O[0][3].y};
-				} else {
-					// samples.rs:92-103: x*32768, truncate toward zero (v_cvt_i32_f32: saturating, NaN -> 0), clamp to
-					// i16 by the saturating pack v_cvt_pk_i16_i32 -- equal to the reference's compare/clamp/`as i16`
-					int iq[2][4], im[2][4];
-#pragma unroll
-					for (int c2 = 0; c2 < 2; c2++)
-#pragma unroll
-						for (int k = 0; k < 4; k++) {
-							const float2_t t = pk_mul(O[c2][k], k32768);
-							iq[c2][k] = (int)t.x;
-							im[c2][k] = (int)t.y;
-						}
-					if (FMT == LW_OUT_I16_PLANAR) {
-						typedef short short2_t __attribute__((ext_vector_type(2)));
-						union {
-							short2_t s;
-							uint32_t u;
-						} a, b;
-						int16_t *o = reinterpret_cast<int16_t *>(F.out) + rec.out_off + (uint32_t)chn[c] * 1024u;
-						a.s = __builtin_amdgcn_cvt_pk_i16(iq[0][3], iq[0][2]);
-						b.s = __builtin_amdgcn_cvt_pk_i16(iq[1][3], iq[1][2]);
-						*reinterpret_cast<uint2_t *>(o + p0) = uint2_t{a.u, b.u};
-						a.s = __builtin_amdgcn_cvt_pk_i16(iq[1][1], iq[1][0]);
-						b.s = __builtin_amdgcn_cvt_pk_i16(iq[0][1], iq[0][0]);
-						*reinterpret_cast<uint2_t *>(o + p1) = uint2_t{a.u, b.u};
-						a.s = __builtin_amdgcn_cvt_pk_i16(im[0][0], im[0][1]);
-						b.s = __builtin_amdgcn_cvt_pk_i16(im[1][0], im[1][1]);
-						*reinterpret_cast<uint2_t *>(o + p2) = uint2_t{a.u, b.u};
-						a.s = __builtin_amdgcn_cvt_pk_i16(im[1][2], im[1][3]);
-						b.s = __builtin_amdgcn_cvt_pk_i16(im[0][2], im[0][3]);
-						*reinterpret_cast<uint2_t *>(o + p3) = uint2_t{a.u, b.u};
-					} else {
-						int16_t *o = reinterpret_cast<int16_t *>(F.out) + rec.out_off + (uint32_t)chn[c];
-						const int g0[4] = {iq[0][3], iq[0][2], iq[1][3], iq[1][2]}, g1[4] = {iq[1][1], iq[1][0], iq[0][1], iq[0][0]};
-						const int g2[4] = {im[0][0], im[0][1], im[1][0], im[1][1]}, g3[4] = {im[1][2], im[1][3], im[0][2], im[0][3]};
-#pragma unroll
-						for (int i = 0; i < 4; i++) {
-							o[(p0 + i) * T.ch] = (int16_t)min(max(g0[i], -32768), 32767);
-							o[(p1 + i) * T.ch] = (int16_t)min(max(g1[i], -32768), 32767);
-							o[(p2 + i) * T.ch] = (int16_t)min(max(g2[i], -32768), 32767);
-							o[(p3 + i) * T.ch] = (int16_t)min(max(g3[i], -32768), 32767);
-						}
-					}
-				}
+			for (int k = 0; k < 4; k++) {
+				const float2_t t = pk_mul(O[c2][k], k32768);
+				iq[c2][k] = (int)t.x;
+				im[c2][k] = (int)t.y;
 			}
-	}
-	// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
-	const bool to_state = rec.state_out >= 0, to_td = (rec.flags & LW_RF_WRITE_TD) != 0;
-	if (to_state || to_td) {
+		if (FMT == LW_OUT_I16_PLANAR) {
+			typedef short short2_t __attribute__((ext_vector_type(2)));
+			union {
+				short2_t s;
+				uint32_t u;
+			} a, b;
+			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn * 1024u;
+			a.s = __builtin_amdgcn_cvt_pk_i16(iq[0][3], iq[0][2]);
+			b.s = __builtin_amdgcn_cvt_pk_i16(iq[1][3], iq[1][2]);
+			*reinterpret_cast<uint2_t *>(o + p0) = uint2_t{a.u, b.u};
+			a.s = __builtin_amdgcn_cvt_pk_i16(iq[1][1], iq[1][0]);
+			b.s = __builtin_amdgcn_cvt_pk_i16(iq[0][1], iq[0][0]);
+			*reinterpret_cast<uint2_t *>(o + p1) = uint2_t{a.u, b.u};
+			a.s = __builtin_amdgcn_cvt_pk_i16(im[0][0], im[0][1]);
+			b.s = __builtin_amdgcn_cvt_pk_i16(im[1][0], im[1][1]);
+			*reinterpret_cast<uint2_t *>(o + p2) = uint2_t{a.u, b.u};
+			a.s = __builtin_amdgcn_cvt_pk_i16(im[1][2], im[1][3]);
+			b.s = __builtin_amdgcn_cvt_pk_i16(im[0][2], im[0][3]);
+			*reinterpret_cast<uint2_t *>(o + p3) = uint2_t{a.u, b.u};
+		} else {
+			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn;
+			const int g0[4] = {iq[0][3], iq[0][2], iq[1][3], iq[1][2]}, g1[4] = {iq[1][1], iq[1][0], iq[0][1], iq[0][0]};
+			const int g2[4] = {im[0][0], im[0][1], im[1][0], im[1][1]}, g3[4] = {im[1][2], im[1][3], im[0][2], im[0][3]};
 #pragma unroll
-		for (int c = 0; c < 2; c++)
-			if (c < NCH) {
-				const float4_t lo0 = LW_PB_LO0(c); // q = 4l .. 4l+3
-				const float4_t lo1 = LW_PB_LO1(c); // q = 508-4l .. 511-4l
-				const float4_t hi0 = float4_t{lo1.w, lo1.z, lo1.y, lo1.x}; // 1023-q for q = 511-4l .. 508-4l
-				const float4_t hi1 = float4_t{lo0.w, lo0.z, lo0.y, lo0.x};
-				for (int t = 0; t < 2; t++) {
-					float *dst;
-					if (t == 0) {
-						if (!to_state)
-							continue;
-						const uint32_t par = (rec.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
-						dst = B.state + ((size_t)rec.state_out * 2 + par) * T.state_stride + (uint32_t)chn[c] * T.state_chan_stride;
-					} else {
-						if (!to_td)
-							continue;
-						dst = B.td + 2u * (size_t)rec.res_off + (uint32_t)chn[c] * 2048u + 1024u;
-					}
-					*reinterpret_cast<float4_t *>(dst + 4u * lane) = lo0;
-					*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = lo1;
-					*reinterpret_cast<float4_t *>(dst + 512u + 4u * lane) = hi0;
-					*reinterpret_cast<float4_t *>(dst + 1020u - 4u * lane) = hi1;
-				}
+			for (int i = 0; i < 4; i++) {
+				o[(p0 + i) * T.ch] = (int16_t)min(max(g0[i], -32768), 32767);
+				o[(p1 + i) * T.ch] = (int16_t)min(max(g1[i], -32768), 32767);
+				o[(p2 + i) * T.ch] = (int16_t)min(max(g2[i], -32768), 32767);
+				o[(p3 + i) * T.ch] = (int16_t)min(max(g3[i], -32768), 32767);
 			}
+		}
 	}
-#undef LW_PB_LO0
-#undef LW_PB_LO1
+}
+
+// ---- raw right half of one channel to a [1024]-float block (state slot / td block): q ascending, then mirrored
+__device__ __forceinline__ void store_right_half(float *dst, uint32_t lane, float4_t lo0, float4_t lo1)
+{
+	const float4_t hi0 = float4_t{lo1.w, lo1.z, lo1.y, lo1.x}; // 1023-q for q = 511-4l .. 508-4l
+	const float4_t hi1 = float4_t{lo0.w, lo0.z, lo0.y, lo0.x};
+	*reinterpret_cast<float4_t *>(dst + 4u * lane) = lo0;
+	*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = lo1;
+	*reinterpret_cast<float4_t *>(dst + 512u + 4u * lane) = hi0;
+	*reinterpret_cast<float4_t *>(dst + 1020u - 4u * lane) = hi1;
 }
 
 template <int FMT, bool RIGHT_ONLY>
@@ -626,54 +625,149 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t g = blockIdx.x * F.items_per_wg * F.n_units + wave;
-	const uint32_t item = g / F.n_units, uidx = g - item * F.n_units;
-	const bool valid = wave < F.items_per_wg * F.n_units && item < F.n_items;
+	const uint32_t n_units = F.n_units, per_round = F.per_round, rounds = F.rounds;
+	const uint32_t slot = wave / n_units, uidx = wave - slot * n_units; // packet slot of the round, unit of the packet
+	const bool active = slot < per_round;
+	const uint32_t item0 = blockIdx.x * per_round * rounds + slot;      // item of round j = item0 + j * per_round
+	const LwFastUnit un = F.units[uidx];
+	const bool two = un.ch_b >= 0;
+	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
+	uint32_t sj = 0;
+	(void)sj;
+	LW_STAMP_NW(0);
 
-	// ---- issue this wave's residue loads first (coalesced float4, lane holds groups m = 64x + lane) ...
-	LwPacketRec rec{};
-	LwFastUnit un{};
-	float4_t r[2][4];
-	if (valid) {
-		rec = B.recs[F.items[item].pkt];
-		un = F.units[uidx];
-		const float4_t *s0 = reinterpret_cast<const float4_t *>(B.residue + rec.res_off + (uint32_t)un.ch_a * 1024u);
-#pragma unroll
-		for (int x = 0; x < 4; x++)
-			r[0][x] = s0[64 * x + lane];
-		if (un.ch_b >= 0) {
-			const float4_t *s1 = reinterpret_cast<const float4_t *>(B.residue + rec.res_off + (uint32_t)un.ch_b * 1024u);
-#pragma unroll
-			for (int x = 0; x < 4; x++)
-				r[1][x] = s1[64 * x + lane];
+	// ---- items of rounds 0 and 1 (scalar loads), then the table image (L2-resident, 3 x 16 B per thread, padded by
+	//      the host to a multiple of 3 * LW_WG * 16 bytes), then the residues/floors of round 0 (HBM)
+	LwFastItem it{}, itn{};
+	Pref pf{}, pfn{};
+	bool valid = active && item0 < F.n_items;
+	bool valid_n = active && rounds > 1 && item0 + per_round < F.n_items;
+	if (valid)
+		it = F.items[item0];
+	if (valid_n)
+		itn = F.items[item0 + per_round];
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(F.image) + threadIdx.x;
+		uint4 *dst = reinterpret_cast<uint4 *>(smem) + threadIdx.x;
+		const uint32_t n16 = F.off.total / 16;
+		const uint4 v0 = src[0], v1 = src[LW_WG], v2 = src[2 * LW_WG];
+		lds_fence();
+		if (valid)
+			issue_loads(T, B, it, un, lane, pf);
+		LW_STAMP_NW(1);
+		dst[0] = v0;
+		dst[LW_WG] = v1;
+		dst[2 * LW_WG] = v2;
+		for (uint32_t i = 3 * LW_WG; i < n16; i += 3 * LW_WG) { // larger images (not with today's layout)
+			const uint4 w0 = src[i], w1 = src[i + LW_WG], w2 = src[i + 2 * LW_WG];
+			dst[i] = w0;
+			dst[i + LW_WG] = w1;
+			dst[i + 2 * LW_WG] = w2;
 		}
 	}
-	// ---- ... then stage the table image while they are in flight
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(F.image);
-		uint4 *dst = reinterpret_cast<uint4 *>(smem);
-		for (uint32_t i = threadIdx.x; i < F.off.total / 16; i += LW_WG)
-			dst[i] = src[i];
-	}
 	__syncthreads();
+	LW_STAMP_NW(2);
 	const char *img = smem;
-	float *scr = reinterpret_cast<float *>(smem + F.off.total) + wave * LW_SCR_FLOATS;
-	char *scrb = reinterpret_cast<char *>(scr);
-	float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb) at q_k(m' = 2 lane + c2): un-windowed left / right halves
-	const bool two = un.ch_b >= 0;
-	if (valid) {
-		if (two)
-			long_phase1<2>(T, B, F, img, scrb, lane, rec, un, r, R);
-		else
-			long_phase1<1>(T, B, F, img, scrb, lane, rec, un, r, R);
+	char *scrb = smem + F.off.total + wave * LW_SCR_BYTES;
+	char *pub0 = smem + F.off.total + LW_FAST_WAVES * LW_SCR_BYTES; // [parity][wave][LW_PUB_BYTES]
+
+	for (uint32_t j = 0; j < rounds; j++) {
+		const uint32_t par = j & 1u;
+		sj = j;
+		char *pub = pub0 + (par * LW_FAST_WAVES + wave) * LW_PUB_BYTES;
+		// ---- prefetch: residues/floors of round j+1, item of round j+2
+		const bool valid_nn = active && j + 2 < rounds && item0 + (j + 2) * per_round < F.n_items;
+		LwFastItem itnn{};
+		if (valid_n)
+			issue_loads(T, B, itn, un, lane, pfn);
+		if (valid_nn)
+			itnn = F.items[item0 + (j + 2) * per_round];
+		// ---- previous right half that does not come from LDS: issue its loads now, consume them in phase 2
+		PrevHalf ph[2];
+		float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb) at q_k(m' = 2 lane + c2): un-windowed left / right halves
+		if (valid) {
+			if (!RIGHT_ONLY && it.src_kind >= LW_SRC_STATE) {
+				const float *g;
+				uint32_t cstride;
+				if (it.src_kind == LW_SRC_STATE) {
+					const uint32_t pin = (it.flags & LW_RF_PARITY_IN) ? 1u : 0u;
+					g = B.state + ((size_t)it.src_arg * 2 + pin) * T.state_stride;
+					cstride = T.state_chan_stride;
+				} else if (it.src_kind == LW_SRC_HALO) {
+					g = F.halo + (size_t)it.src_arg * T.ch * 512u;
+					cstride = 512u;
+				} else { // LW_SRC_TD: second half of the predecessor's [ch][2048] time-domain block
+					g = B.td + (size_t)it.src_arg + 1024u;
+					cstride = 2048u;
+				}
+				prev_from_global(g + (uint32_t)chn[0] * cstride, lane, ph[0]);
+				if (two)
+					prev_from_global(g + (uint32_t)chn[1] * cstride, lane, ph[1]);
+			}
+			LW_STAMP(3);
+			if (two)
+				long_phase1<2>(F, img, scrb, pub, lane, un, pf, R, j);
+			else
+				long_phase1<1>(F, img, scrb, pub, lane, un, pf, R, j);
+			// hand-over across rounds: the last packet slot of round j-1 published into the other parity
+			if (!RIGHT_ONLY && it.src_kind == LW_SRC_LDS && slot == 0) {
+				const char *src = pub0 + ((par ^ 1u) * LW_FAST_WAVES + (per_round - 1) * n_units + uidx) * LW_PUB_BYTES;
+				prev_from_lds(src, lane, ph[0]);
+				if (two)
+					prev_from_lds(src + 2048, lane, ph[1]);
+			}
+		}
+		if (!RIGHT_ONLY)
+			__syncthreads();
+		LW_STAMP_NW(9);
+		if (valid) {
+			if (RIGHT_ONLY) {
+#pragma unroll
+				for (int c = 0; c < 2; c++)
+					if (c == 0 || two) {
+						float *dst = F.halo + ((size_t)it.halo_out * T.ch + chn[c]) * 512u;
+						*reinterpret_cast<float4_t *>(dst + 4u * lane) = LW_PB_LO0(c);
+						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
+					}
+			} else {
+				if (it.src_kind == LW_SRC_LDS && slot != 0) {
+					const char *src = pub - n_units * LW_PUB_BYTES; // same round, previous packet slot, same unit
+					prev_from_lds(src, lane, ph[0]);
+					if (two)
+						prev_from_lds(src + 2048, lane, ph[1]);
+				}
+				if (it.src_kind != LW_SRC_NONE) {
+					ola_store<FMT>(T, F, img, lane, chn[0], it.out_off, R[0], ph[0]);
+					if (two)
+						ola_store<FMT>(T, F, img, lane, chn[1], it.out_off, R[1], ph[1]);
+				}
+				// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
+				const bool to_state = it.state_out >= 0, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
+				if (to_state || to_td) {
+#pragma unroll
+					for (int c = 0; c < 2; c++)
+						if (c == 0 || two) {
+							const float4_t lo0 = LW_PB_LO0(c), lo1 = LW_PB_LO1(c);
+							if (to_state) {
+								const uint32_t pout = (it.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
+								store_right_half(B.state + ((size_t)it.state_out * 2 + pout) * T.state_stride +
+										(uint32_t)chn[c] * T.state_chan_stride, lane, lo0, lo1);
+							}
+							if (to_td)
+								store_right_half(B.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u + 1024u, lane, lo0, lo1);
+						}
+				}
+			}
+		}
+		LW_STAMP_NW(10);
+		it = itn;
+		itn = itnn;
+		pf = pfn;
+		valid = valid_n;
+		valid_n = valid_nn;
 	}
-	__syncthreads();
-	if (!valid)
-		return;
-	if (two)
-		long_phase2<2, FMT, RIGHT_ONLY>(T, B, F, img, scr, lane, wave, item, rec, un, R);
-	else
-		long_phase2<1, FMT, RIGHT_ONLY>(T, B, F, img, scr, lane, wave, item, rec, un, R);
+	sj = 3;
+	LW_STAMP(11);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -685,12 +779,10 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 	F.off = L.off;
 	F.image = L.d_image;
 	F.n_units = L.n_units;
-	for (uint32_t i = 0; i < L.n_units && i < LW_FAST_WAVES; i++)
-		F.units[i] = L.units[i];
+	F.units = L.d_units;
 	F.halo = L.d_halo;
 	F.out = out;
-	const size_t lds = (size_t)L.off.total + (size_t)LW_FAST_WAVES * LW_SCR_FLOATS * sizeof(float);
-	const uint32_t per_wg = LW_FAST_WAVES / L.n_units;
+	const size_t lds = (size_t)L.off.total + (size_t)LW_FAST_WAVES * (LW_SCR_BYTES + 2 * LW_PUB_BYTES);
 	static bool attr_done = false;
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -702,15 +794,17 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 	if (L.n_halo_items) {
 		F.items = L.d_halo_items;
 		F.n_items = L.n_halo_items;
-		F.items_per_wg = 1; // spread the few halo packets over the whole chip: one packet per workgroup
-		const uint32_t grid = L.n_halo_items;
-		hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(grid), dim3(LW_WG), lds, st, T, B, F);
+		F.per_round = 1; // spread the few halo packets over the whole chip: one packet per workgroup
+		F.rounds = 1;
+		hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, T, B, F);
 	}
 	if (L.n_items) {
 		F.items = L.d_items;
 		F.n_items = L.n_items;
-		F.items_per_wg = per_wg;
-		const uint32_t grid = (L.n_items + per_wg - 1) / per_wg;
+		F.per_round = L.per_round;
+		F.rounds = L.rounds;
+		const uint32_t chunk = L.per_round * L.rounds;
+		const uint32_t grid = (L.n_items + chunk - 1) / chunk;
 		if (fmt == LW_OUT_I16_PLANAR)
 			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, T, B, F);
 		else if (fmt == LW_OUT_I16_INTERLEAVED)

@@ -59,6 +59,7 @@ struct lw_decoder {
 	std::shared_ptr<lw::Ident> id;
 	std::shared_ptr<lw::Setup> setup;
 	int device = 0;
+	int n_cus = 256;
 	LwDevTables T{};
 	void *d_blob = nullptr; // one allocation holding every table
 	bool any_coupling = false;
@@ -70,6 +71,7 @@ struct lw_decoder {
 	std::vector<int> free_slots;
 	LwFastPlan fast;               // specialised long-block kernel: eligibility, units, LDS image
 	uint8_t *d_fast_image = nullptr;
+	LwFastUnit *d_fast_units = nullptr;
 	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
 	void *one_out = nullptr; // pinned host output for the single-packet path
 	size_t one_out_bytes = 0;
@@ -101,6 +103,7 @@ struct lw_batch {
 	float *d_halo = nullptr;
 	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
+	uint32_t fast_per_round = 1, fast_rounds = 1;
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
 	bool has_generic = false, has_fast = false, force_generic = false;
@@ -399,6 +402,8 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	d->id = idh->p;
 	d->setup = sh->p;
 	d->device = device;
+	if (hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || d->n_cus <= 0)
+		d->n_cus = 256;
 
 	// ---- build one blob with all tables
 	std::vector<uint8_t> blob;
@@ -485,9 +490,12 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	lw::build_fast_plan(id, s, d->fast);
 	if (d->fast.eligible) {
 		std::memcpy(d->fast.image.data() + d->fast.off.inv_db, kInverseDbTable, sizeof(float) * 256);
+		const size_t ub = d->fast.units.size() * sizeof(LwFastUnit);
 		if (!hip_ok(hipMalloc((void **)&d->d_fast_image, d->fast.image.size()), "hipMalloc(fast image)") ||
 				!hip_ok(hipMemcpy(d->d_fast_image, d->fast.image.data(), d->fast.image.size(), hipMemcpyHostToDevice),
-					"hipMemcpy(fast image)")) {
+					"hipMemcpy(fast image)") ||
+				!hip_ok(hipMalloc((void **)&d->d_fast_units, ub), "hipMalloc(fast units)") ||
+				!hip_ok(hipMemcpy(d->d_fast_units, d->fast.units.data(), ub, hipMemcpyHostToDevice), "hipMemcpy(fast units)")) {
 			*err = LW_ERR_DEVICE;
 			(void)hipFree(d->d_blob);
 			return nullptr;
@@ -512,6 +520,8 @@ void lw_decoder_destroy(lw_decoder *d)
 		(void)hipFree(d->d_blob);
 	if (d->d_fast_image)
 		(void)hipFree(d->d_fast_image);
+	if (d->d_fast_units)
+		(void)hipFree(d->d_fast_units);
 	delete d;
 }
 
@@ -867,36 +877,67 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->alg_bytes = alg;
 
 	// ---- work plan of the specialised kernel: items sorted by stream so that consecutive packets of a
-	// stream sit in consecutive waves; a predecessor outside the workgroup is recomputed by the halo pre-pass
+	// stream sit in consecutive items; a workgroup works through a chunk of rounds * per_round consecutive
+	// items and hands right halves over in LDS; a predecessor outside the chunk is recomputed by the halo pre-pass
 	b->n_items = b->n_halo_items = 0;
 	b->has_fast = !b->fast_idx.empty();
 	if (b->has_fast) {
 		const size_t nf = b->fast_idx.size();
-		b->fast_order.resize(nf);
-		for (size_t k = 0; k < nf; k++)
-			b->fast_order[k] = (uint32_t)k;
-		std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
-				[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
-		const uint32_t per_wg = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
-		for (size_t k = 0; k < nf; k++) {
-			const uint32_t idx = b->fast_idx[b->fast_order[k]];
-			const LwPacketRec &r = b->h_recs[idx];
-			LwFastItem it{idx, 0xFFFFFFFFu};
-			if (r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST)) {
-				const bool in_wg = (k % per_wg) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev;
-				if (!in_wg) {
-					it.halo = (uint32_t)b->n_halo_items;
-					b->h_halo_items[b->n_halo_items++] = LwFastItem{(uint32_t)r.prev, it.halo};
-				}
-			}
-			b->h_items[k] = it;
-		}
-		b->n_items = nf;
 		for (size_t i = 0; i < n; i++) { // generic successors of fast packets read the td block
 			const LwPacketRec &r = b->h_recs[i];
 			if (!(r.flags & (LW_RF_SKIP | LW_RF_FAST)) && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
 				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
 		}
+		b->fast_order.resize(nf);
+		for (size_t k = 0; k < nf; k++)
+			b->fast_order[k] = (uint32_t)k;
+		std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
+				[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
+		const uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
+		// enough rounds per workgroup that one workgroup per CU covers the batch (prefetch overlap inside a launch)
+		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
+		const uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
+		const uint32_t chunk = per_round * rounds;
+		b->fast_per_round = per_round;
+		b->fast_rounds = rounds;
+		auto fill = [&](LwFastItem &it, uint32_t idx) {
+			const LwPacketRec &r = b->h_recs[idx];
+			std::memset(&it, 0, sizeof(it));
+			it.res_off = r.res_off;
+			it.floor_off = r.floor_off;
+			it.out_off = r.out_off;
+			it.state_out = r.state_out;
+			it.mode = r.mode;
+			it.flags = (uint8_t)(r.flags & (LW_RF_PARITY_IN | LW_RF_PARITY_OUT | LW_RF_WRITE_TD));
+			it.pkt = idx;
+		};
+		for (size_t k = 0; k < nf; k++) {
+			const uint32_t idx = b->fast_idx[b->fast_order[k]];
+			const LwPacketRec &r = b->h_recs[idx];
+			LwFastItem &it = b->h_items[k];
+			fill(it, idx);
+			if (r.prev == -1) {
+				it.src_kind = LW_SRC_NONE;
+			} else if (r.prev <= -2) {
+				it.src_kind = LW_SRC_STATE;
+				it.src_arg = (uint32_t)(-(r.prev + 2));
+			} else if (b->h_recs[r.prev].flags & LW_RF_FAST) {
+				if ((k % chunk) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev) {
+					it.src_kind = LW_SRC_LDS;
+				} else {
+					it.src_kind = LW_SRC_HALO;
+					it.src_arg = (uint32_t)b->n_halo_items;
+					LwFastItem &h = b->h_halo_items[b->n_halo_items];
+					fill(h, (uint32_t)r.prev);
+					h.state_out = -1;
+					h.halo_out = (uint32_t)b->n_halo_items++;
+				}
+			} else {
+				it.src_kind = LW_SRC_TD;
+				it.src_arg = 2u * b->h_recs[r.prev].res_off;
+			}
+		}
+		b->n_items = nf;
 	}
 	return LW_OK;
 }
@@ -969,8 +1010,9 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.d_halo_items = b->d_halo_items;
 		L.n_halo_items = (uint32_t)b->n_halo_items;
 		L.n_units = (uint32_t)d->fast.units.size();
-		for (size_t i = 0; i < d->fast.units.size(); i++)
-			L.units[i] = d->fast.units[i];
+		L.per_round = b->fast_per_round;
+		L.rounds = b->fast_rounds;
+		L.d_units = d->d_fast_units;
 		L.d_halo = b->d_halo;
 		lw_launch_long(d->T, B, L, d_out, b->fmt, st);
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
