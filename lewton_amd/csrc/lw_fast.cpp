@@ -203,6 +203,13 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 	const size_t quantum = (size_t)3 * 64 * LW_FAST_WAVES * 16;
 	o.total = (uint32_t)((plan.image.size() + quantum - 1) / quantum * quantum);
 	plan.image.resize(o.total, 0);
+	if (o.apair != LWI_APAIR || o.tw_s2 != LWI_TW_S2 || o.tw_l0 != LWI_TW_L0 || o.tw_l1 != LWI_TW_L1 || o.tw_l2 != LWI_TW_L2 ||
+			o.tw_l3 != LWI_TW_L3 || o.tw_l4 != LWI_TW_L4 || o.a2 != LWI_A2 || o.c4 != LWI_C4 || o.b_lo != LWI_B_LO ||
+			o.b_hi != LWI_B_HI || o.win != LWI_WIN || o.inv_db != LWI_INV_DB || o.xsf != LWI_XSF || o.sid16 != LWI_SID16 ||
+			o.total != LWI_TOTAL) {
+		plan.why_not = "LDS image layout differs from the kernel's compile-time layout (LWI_*)";
+		return;
+	}
 	plan.eligible = true;
 }
 

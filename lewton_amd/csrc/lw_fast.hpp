@@ -33,6 +33,27 @@ struct LwFastImage {
 	uint32_t total;  // bytes
 };
 
+// The layout is fixed at compile time (LWI_*): the kernel folds these offsets into its ds_read instructions instead
+// of holding sixteen of them in scalar registers; build_fast_plan() checks that the image it writes agrees.
+enum : uint32_t {
+	LWI_APAIR = 0,      // 4096
+	LWI_TW_S2 = 4096,   // 2048
+	LWI_TW_L0 = 6144,   // 1024
+	LWI_TW_L1 = 7168,   // 512
+	LWI_TW_L2 = 7680,   // 256
+	LWI_TW_L3 = 7936,   // 128
+	LWI_TW_L4 = 8064,   // 64
+	LWI_A2 = 8128,      // 16
+	LWI_C4 = 8144,      // 2048
+	LWI_B_LO = 10192,   // 2048
+	LWI_B_HI = 12240,   // 2048
+	LWI_WIN = 14288,    // 4096
+	LWI_INV_DB = 18384, // 1024
+	LWI_XSF = 19408,    // LW_FAST_MAX_FLOORS * 256
+	LWI_SID16 = 19920,  // LW_FAST_MAX_FLOORS * 2048
+	LWI_TOTAL = 24576   // 24016 padded to the staging quantum 3 * 64 * LW_FAST_WAVES * 16
+};
+
 struct LwFastUnit {
 	int8_t ch_a, ch_b;  // channels handled by one wave; ch_b = -1 for a single channel
 	uint8_t coupled;    // (ch_a = magnitude, ch_b = angle) form a coupling step
@@ -85,6 +106,8 @@ struct LwFastLaunch {
 	uint32_t n_units;
 	uint32_t per_round; // packets per workgroup and round
 	uint32_t rounds;    // rounds per workgroup
+	uint32_t dense;     // item k == packet k with uniform block sizes
+	uint32_t late_from; // first workgroup of the half of the grid that issues its HBM loads late
 	const LwFastUnit *d_units;
 	float *d_halo;
 };

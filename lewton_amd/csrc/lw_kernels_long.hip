@@ -5,15 +5,17 @@
 //     residue load (coalesced float4) -> inverse coupling -> floor-1 curve -> floor x residue
 //     -> IMDCT entirely in registers with three wave-private LDS transposes -> window/overlap-add
 //     -> i16/f32 store (coalesced).
-// A workgroup is 8 waves (one per CU: 2 waves per SIMD, up to 256 VGPRs each) and works through a chunk of
-// `rounds` x `per_round` consecutive items of the stream-sorted work list in `rounds` rounds.  While a wave
-// computes round j its residue/floor loads for round j+1 are already in flight (register double buffer), and
-// its stores of round j drain while round j+1 computes: HBM traffic and arithmetic overlap inside one launch.
-// LDS: 22 KB re-ordered twiddle/window tables staged once per workgroup + 8 KB transpose scratch per wave
-// + 2 x 4 KB hand-over buffers per wave.  A packet's un-windowed right half reaches its successor through
-// the hand-over buffer (same round: wave - n_units; previous round: the last waves), one s_barrier per round;
-// at chunk starts it comes from the stream's state slot, from a halo buffer filled by a RIGHT_ONLY pre-pass of
-// this same kernel, or from the time-domain block of a generic-kernel predecessor.
+// A workgroup is 8 waves and works through a chunk of `rounds` x `per_round` consecutive items of the
+// stream-sorted work list, one round at a time.  LDS: 24 KB re-ordered twiddle/window tables staged once per
+// workgroup + 4 KB transpose scratch per wave + 2 x 4 KB carry buffers per unit = 64 KB for stereo, so two
+// workgroups (16 waves, <= 128 VGPRs each) share a CU and drift apart in phase: one group's HBM loads and
+// stores overlap the other's arithmetic.  The second half of the grid issues its HBM loads only after staging
+// the tables, so that the first half's data is queued -- and arrives -- first.
+// A packet's un-windowed right half reaches its successor through LDS (same round: the scratch of wave -
+// n_units; previous round: the carry buffer written by the last packet slot), one s_barrier per round (two
+// when there are several rounds); at chunk starts it comes from the stream's state slot, from a halo buffer
+// filled by a RIGHT_ONLY pre-pass of this same kernel, or from the time-domain block of a generic-kernel
+// predecessor.
 //
 // Register layouts of the 512 complex pairs p (u[2p], u[2p+1]) of imdct.rs's butterfly array, 8 per lane:
 //   B: lane = p[5:0], reg = p[8:6]   step 2 and stages l = 0,1   (pair bits 8,7,6 are lane-local)
@@ -30,20 +32,28 @@
 #include "lw_kernels.hpp"
 
 #define LW_WG (64 * LW_FAST_WAVES)
-#define LW_SCR_BYTES 8192u // per wave: [2 channels][4096 bytes] transposes / floor segment tables
-#define LW_PUB_BYTES 4096u // per wave and parity: [2 channels][2][64] float4 un-windowed right half
+#define LW_SCR_BYTES 4096u // per wave: transposes of one channel at a time / 2 x 1 KB floor segment tables / published
+                           // right half [2 channels][2][64] float4
+#define LW_CARRY_BYTES 4096u // per parity and unit: right half of the last packet slot of a round
 
 struct LwFastArgs {
-	LwFastImage off;
-	const uint8_t *image;      // LDS image in HBM
+	const uint8_t *image;      // LDS image in HBM (LWI_TOTAL bytes)
 	const LwFastItem *items;   // work list in stream-sorted order
+	const LwFastUnit *units;   // [n_units]
+	const float *residue;      // batch arrays (lw_records.h)
+	const uint16_t *floors;
+	float *state;              // state pool [slots][2][ch][n1/2]
+	float *td;                 // time-domain blocks of the generic kernels
+	float *halo;               // [slots][ch][512]
+	void *out;
 	uint32_t n_items;
 	uint32_t n_units;
 	uint32_t per_round;        // packets per workgroup and round (<= LW_FAST_WAVES / n_units)
 	uint32_t rounds;           // rounds per workgroup
-	const LwFastUnit *units;   // [n_units] in HBM
-	float *halo;               // [slots][ch][512]
-	void *out;
+	uint32_t dense;            // item k of the list is packet k and every packet block has the same size
+	uint32_t late_from;        // workgroups >= late_from issue their first HBM loads after staging the tables
+	uint32_t ch, fstride;      // channels, u16 entries per channel in a floor block
+	uint32_t state_stride, state_chan_stride;
 };
 
 #ifdef LW_STAMPS
@@ -156,26 +166,23 @@ struct Pref {          // what one wave loads from HBM for one item
 	uint32_t fe[2];    // floor-1 post entry of post `lane` of each channel (lanes >= F hold 0)
 };
 
-struct Twid1 {         // per-lane twiddles of step 1, step 2 and stages l = 0, 1
-	float2_t au[4], al[4], s2[4], l0[2], l1;
-};
 
-__device__ __forceinline__ void issue_loads(const LwDevTables &T, const LwBatchDev &B, const LwFastItem &it,
+__device__ __forceinline__ void issue_loads(const LwFastArgs &F, const LwFastItem &it,
 		const LwFastUnit &un, uint32_t lane, Pref &p)
 {
-	const float4_t *s0 = reinterpret_cast<const float4_t *>(B.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
+	const float4_t *s0 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
 #pragma unroll
 	for (int x = 0; x < 4; x++)
 		p.r[0][x] = s0[64 * x + lane];
-	const uint16_t *f0 = B.floors + it.floor_off + (uint32_t)un.ch_a * T.fstride;
+	const uint16_t *f0 = F.floors + it.floor_off + (uint32_t)un.ch_a * F.fstride;
 	p.fe[0] = lane < un.F_a ? (uint32_t)f0[lane] : 0u;
 	p.fe[1] = 0u;
 	if (un.ch_b >= 0) {
-		const float4_t *s1 = reinterpret_cast<const float4_t *>(B.residue + it.res_off + (uint32_t)un.ch_b * 1024u);
+		const float4_t *s1 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_b * 1024u);
 #pragma unroll
 		for (int x = 0; x < 4; x++)
 			p.r[1][x] = s1[64 * x + lane];
-		const uint16_t *f1 = B.floors + it.floor_off + (uint32_t)un.ch_b * T.fstride;
+		const uint16_t *f1 = F.floors + it.floor_off + (uint32_t)un.ch_b * F.fstride;
 		p.fe[1] = lane < un.F_b ? (uint32_t)f1[lane] : 0u;
 	}
 }
@@ -192,7 +199,7 @@ __device__ __forceinline__ bool floor_table(const LwFastArgs &F, const char *img
 	const int lo = below ? 63 - __builtin_clzll(below) : 0;
 	const int hi = above ? __builtin_ctzll(above) : lo;
 	const int y = (int)(e & 0xffu);
-	const float xs = *reinterpret_cast<const float *>(img + F.off.xsf + 4u * (64u * fslot + lane));
+	const float xs = *reinterpret_cast<const float *>(img + LWI_XSF + 4u * (64u * fslot + lane));
 	const int ylo = __builtin_amdgcn_ds_bpermute(lo << 2, y);
 	const int yhi = __builtin_amdgcn_ds_bpermute(hi << 2, y);
 	const float xlo = __int_as_float(__builtin_amdgcn_ds_bpermute(lo << 2, __float_as_int(xs)));
@@ -221,7 +228,7 @@ __device__ __forceinline__ void spectrum(const LwFastArgs &F, const char *img, c
 	const float kf0 = (float)(4 * (int)lane);
 #pragma unroll
 	for (int x = 0; x < 4; x++) {
-		const uint2_t sw = *reinterpret_cast<const uint2_t *>(img + F.off.sid16 + 8u * ((fslot * 4 + x) * 64u + lane));
+		const uint2_t sw = *reinterpret_cast<const uint2_t *>(img + LWI_SID16 + 8u * ((fslot * 4 + x) * 64u + lane));
 		const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
 		float4_t fl;
 #pragma unroll
@@ -230,7 +237,7 @@ __device__ __forceinline__ void spectrum(const LwFastArgs &F, const char *img, c
 			const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
 			const int q = (int)(z * ent.z);
 			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
-			fl[j] = *reinterpret_cast<const float *>(img + F.off.inv_db + idx);
+			fl[j] = *reinterpret_cast<const float *>(img + LWI_INV_DB + idx);
 		}
 		const float2_t lo2 = pk_mul(float2_t{fl.x, fl.y}, float2_t{r[x].x, r[x].y});
 		const float2_t hi2 = pk_mul(float2_t{fl.z, fl.w}, float2_t{r[x].z, r[x].w});
@@ -239,29 +246,51 @@ __device__ __forceinline__ void spectrum(const LwFastArgs &F, const char *img, c
 }
 
 // ---- IMDCT step 1 (imdct.rs:337-371) in the load layout, exchange with the mirror lane -> layout B;
-//      step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452)
-__device__ __forceinline__ void stage_b(const Twid1 &tw, uint32_t lane, const float4_t (&r)[4], float2_t (&P)[8])
+//      step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452); twiddles shared by the channels
+template <int NCH>
+__device__ __forceinline__ void stage_b(const LwFastArgs &F, const char *img, uint32_t lane, const float4_t (&r)[2][4],
+		float2_t (&P)[2][8])
 {
 	const uint32_t mirror = (63u - lane) << 2;
 #pragma unroll
 	for (int x = 0; x < 4; x++) {
-		const float2_t Xa = float2_t{r[x].x, r[x].y}, Xb = float2_t{r[x].z, r[x].w};
-		const float2_t U = pk_add(pk_mul_M3(Xa, tw.au[x]), pk_mul_M4(Xb, tw.au[x])); // pair 511 - m
-		P[x] = pk_add(pk_mul_M5(Xb, tw.al[x]), pk_mul_M6(Xa, tw.al[x]));            // pair m
-		P[7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.x)));
-		P[7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.y)));
+		const uint32_t m = 64u * x + lane;
+		const float2_t au = lds2(img + LWI_APAIR, 8u * m);          // (A[2m], A[2m+1])
+		const float2_t al = lds2(img + LWI_APAIR, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const float2_t Xa = float2_t{r[c][x].x, r[c][x].y}, Xb = float2_t{r[c][x].z, r[c][x].w};
+			const float2_t U = pk_add(pk_mul_M3(Xa, au), pk_mul_M4(Xb, au)); // pair 511 - m
+			P[c][x] = pk_add(pk_mul_M5(Xb, al), pk_mul_M6(Xa, al));          // pair m
+			P[c][7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.x)));
+			P[c][7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.y)));
+		}
 	}
 #pragma unroll
-	for (int x = 0; x < 4; x++)
-		bfly2(P[x + 4], P[x], tw.s2[x]);
+	for (int x = 0; x < 4; x++) {
+		const float2_t t = lds2(img + LWI_TW_S2, 8u * (64u * x + lane));
+#pragma unroll
+		for (int c = 0; c < NCH; c++)
+			bfly2(P[c][x + 4], P[c][x], t);
+	}
 #pragma unroll
 	for (int b = 0; b < 2; b++) {
-		bfly2(P[2 + b], P[b], tw.l0[b]);
-		bfly2(P[6 + b], P[4 + b], tw.l0[b]);
-	}
+		const float2_t t = lds2(img + LWI_TW_L0, 8u * (64u * b + lane));
 #pragma unroll
-	for (int x = 1; x < 8; x += 2)
-		bfly2(P[x], P[x - 1], tw.l1);
+		for (int c = 0; c < NCH; c++) {
+			bfly2(P[c][2 + b], P[c][b], t);
+			bfly2(P[c][6 + b], P[c][4 + b], t);
+		}
+	}
+	{
+		const float2_t t = lds2(img + LWI_TW_L1, 8u * lane);
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+#pragma unroll
+			for (int x = 1; x < 8; x += 2)
+				bfly2(P[c][x], P[c][x - 1], t);
+		}
+	}
 }
 
 // ---- T2: layout B -> C.  slot(p) = p ^ ((p>>6 & 3) << 3)
@@ -285,19 +314,35 @@ __device__ __forceinline__ void t2_read(const char *sc, uint32_t lane, float2_t 
 }
 
 // ---- stages l = 2, 3, 4 (imdct.rs:454-477)
-__device__ __forceinline__ void stage_c(const float2_t (&t2)[4], const float2_t (&t3)[2], float2_t t4, float2_t (&Q)[8])
+template <int NCH>
+__device__ __forceinline__ void stage_c(const LwFastArgs &F, const char *img, uint32_t lane, float2_t (&Q)[2][8])
 {
+	const uint32_t lo3 = lane & 7u;
 #pragma unroll
-	for (int yy = 0; yy < 4; yy++)
-		bfly2(Q[4 + yy], Q[yy], t2[yy]);
+	for (int yy = 0; yy < 4; yy++) {
+		const float2_t t = lds2(img + LWI_TW_L2, 8u * (8u * yy + lo3));
 #pragma unroll
-	for (int b = 0; b < 2; b++) {
-		bfly2(Q[2 + b], Q[b], t3[b]);
-		bfly2(Q[6 + b], Q[4 + b], t3[b]);
+		for (int c = 0; c < NCH; c++)
+			bfly2(Q[c][4 + yy], Q[c][yy], t);
 	}
 #pragma unroll
-	for (int y = 1; y < 8; y += 2)
-		bfly2(Q[y], Q[y - 1], t4);
+	for (int b = 0; b < 2; b++) {
+		const float2_t t = lds2(img + LWI_TW_L3, 8u * (8u * b + lo3));
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			bfly2(Q[c][2 + b], Q[c][b], t);
+			bfly2(Q[c][6 + b], Q[c][4 + b], t);
+		}
+	}
+	{
+		const float2_t t = lds2(img + LWI_TW_L4, 8u * lo3);
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+#pragma unroll
+			for (int y = 1; y < 8; y += 2)
+				bfly2(Q[c][y], Q[c][y - 1], t);
+		}
+	}
 }
 
 // ---- T3: layout C -> D.  slot(p) = 8 nu + (z ^ (nu>>2 & 7)), nu = p>>3, z = p&7
@@ -388,20 +433,18 @@ __device__ __forceinline__ void stage_e(const char *sc, uint32_t lane, int c2, c
 }
 
 // ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private).
-// The two channels of a pair are software-pipelined against each other: while one channel's transpose is
-// in flight in LDS the other channel's butterflies issue.
+// Both channels of a pair advance through the stages together (shared twiddles); their transposes go through
+// ONE 4 KB buffer one after the other (LDS operations of a wave execute in order).
 template <int NCH>
-__device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img, char *scrb, char *pub, uint32_t lane,
+__device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img, char *sc, uint32_t lane,
 		const LwFastUnit &un, Pref &pf, float2_t (&R)[2][2][4], uint32_t sj)
 {
 	(void)sj;
-	char *sc0 = scrb, *sc1 = scrb + 4096;
-	const uint32_t lo3 = lane & 7u;
-	// ---- floor segment tables
-	const bool unused0 = floor_table(F, img, sc0, lane, pf.fe[0], un.floor_a, un.F_a);
+	// ---- floor segment tables (1 KB each)
+	const bool unused0 = floor_table(F, img, sc, lane, pf.fe[0], un.floor_a, un.F_a);
 	bool unused1 = false;
 	if (NCH == 2)
-		unused1 = floor_table(F, img, sc1, lane, pf.fe[1], un.floor_b, un.F_b);
+		unused1 = floor_table(F, img, sc + 1024, lane, pf.fe[1], un.floor_b, un.F_b);
 	lds_fence();
 	// ---- inverse coupling (audio.rs:762-777, :990-1002) on the raw residues
 	if (NCH == 2 && un.coupled) {
@@ -418,88 +461,65 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 			}
 		}
 	}
-	spectrum(F, img, sc0, lane, un.floor_a, unused0, pf.r[0]);
+	spectrum(F, img, sc, lane, un.floor_a, unused0, pf.r[0]);
 	if (NCH == 2)
-		spectrum(F, img, sc1, lane, un.floor_b, unused1, pf.r[1]);
+		spectrum(F, img, sc + 1024, lane, un.floor_b, unused1, pf.r[1]);
 	lds_fence();
 	LW_STAMP(4);
-
-	// ---- twiddles of layout B
-	Twid1 tw;
-#pragma unroll
-	for (int x = 0; x < 4; x++) {
-		const uint32_t m = 64u * x + lane;
-		tw.au[x] = lds2(img + F.off.apair, 8u * m);          // (A[2m], A[2m+1])
-		tw.al[x] = lds2(img + F.off.apair, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
-		tw.s2[x] = lds2(img + F.off.tw_s2, 8u * (64u * x + lane));
-	}
-	tw.l0[0] = lds2(img + F.off.tw_l0, 8u * lane);
-	tw.l0[1] = lds2(img + F.off.tw_l0, 8u * (64u + lane));
-	tw.l1 = lds2(img + F.off.tw_l1, 8u * lane);
-	float2_t P0[8], P1[8];
-	stage_b(tw, lane, pf.r[0], P0);
-	t2_write(sc0, lane, P0);
-	if (NCH == 2)
-		stage_b(tw, lane, pf.r[1], P1);
-	lds_fence();
+	float2_t P[2][8];
+	stage_b<NCH>(F, img, lane, pf.r, P);
 	LW_STAMP(5);
-	// ---- twiddles of layout C
-	float2_t t2[4], t3[2], t4;
 #pragma unroll
-	for (int yy = 0; yy < 4; yy++)
-		t2[yy] = lds2(img + F.off.tw_l2, 8u * (8u * yy + lo3));
-	t3[0] = lds2(img + F.off.tw_l3, 8u * lo3);
-	t3[1] = lds2(img + F.off.tw_l3, 8u * (8u + lo3));
-	t4 = lds2(img + F.off.tw_l4, 8u * lo3);
-	t2_read(sc0, lane, P0); // P0 now holds layout C
-	if (NCH == 2)
-		t2_write(sc1, lane, P1);
-	lds_fence();
-	stage_c(t2, t3, t4, P0);
-	t3_write(sc0, lane, P0);
-	lds_fence();
-	if (NCH == 2) {
-		t2_read(sc1, lane, P1);
+	for (int c = 0; c < NCH; c++) { // T2
+		t2_write(sc, lane, P[c]);
 		lds_fence();
-		stage_c(t2, t3, t4, P1);
+		t2_read(sc, lane, P[c]);
+		lds_fence();
 	}
+	stage_c<NCH>(F, img, lane, P);
 	LW_STAMP(6);
-	const float a2s = *reinterpret_cast<const float *>(img + F.off.a2);
-	const float2_t a2 = float2_t{a2s, a2s};
-	t3_read(sc0, lane, P0); // layout D
-	if (NCH == 2)
-		t3_write(sc1, lane, P1);
-	lds_fence();
-	stage_d(a2, P0);
-	t4_write(sc0, lane, P0);
-	lds_fence();
-	if (NCH == 2) {
-		t3_read(sc1, lane, P1);
+#pragma unroll
+	for (int c = 0; c < NCH; c++) { // T3
+		t3_write(sc, lane, P[c]);
 		lds_fence();
-		stage_d(a2, P1);
-		t4_write(sc1, lane, P1);
+		t3_read(sc, lane, P[c]);
 		lds_fence();
+	}
+	{
+		const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
+		const float2_t a2 = float2_t{a2s, a2s};
+#pragma unroll
+		for (int c = 0; c < NCH; c++)
+			stage_d(a2, P[c]);
 	}
 	LW_STAMP(7);
 #pragma unroll
-	for (int c2 = 0; c2 < 2; c2++) {
-		TwidE te;
-		te.Cq = lds4(img + F.off.c4, 16u * (64u * c2 + lane));
-		te.Bl = lds4(img + F.off.b_lo, 16u * (64u * c2 + lane));
-		te.Bh = lds4(img + F.off.b_hi, 16u * (64u * c2 + lane));
-		stage_e(sc0, lane, c2, te, R[0][c2]);
-		if (NCH == 2)
-			stage_e(sc1, lane, c2, te, R[1][c2]);
+	for (int c = 0; c < NCH; c++) { // T4 + layout E
+		t4_write(sc, lane, P[c]);
+		lds_fence();
+#pragma unroll
+		for (int c2 = 0; c2 < 2; c2++) {
+			TwidE te;
+			te.Cq = lds4(img + LWI_C4, 16u * (64u * c2 + lane));
+			te.Bl = lds4(img + LWI_B_LO, 16u * (64u * c2 + lane));
+			te.Bh = lds4(img + LWI_B_HI, 16u * (64u * c2 + lane));
+			stage_e(sc, lane, c2, te, R[c][c2]);
+		}
+		lds_fence();
 	}
-	lds_fence();
 	LW_STAMP(8);
-	// ---- publish the un-windowed right half for the successor ([channel][c2][lane] float4)
+}
+
+// ---- publish the un-windowed right half for the successor ([channel][c2][lane] float4)
+template <int NCH>
+__device__ __forceinline__ void publish(char *dst, uint32_t lane, const float2_t (&R)[2][2][4])
+{
 #pragma unroll
 	for (int c = 0; c < 2; c++)
 		if (c < NCH) {
 #pragma unroll
 			for (int c2 = 0; c2 < 2; c2++)
-				*reinterpret_cast<float4_t *>(pub + 2048 * c + 16u * (64u * c2 + lane)) =
+				*reinterpret_cast<float4_t *>(dst + 2048 * c + 16u * (64u * c2 + lane)) =
 					float4_t{R[c][c2][0].y, R[c][c2][1].y, R[c][c2][2].y, R[c][c2][3].y};
 		}
 }
@@ -535,15 +555,15 @@ __device__ __forceinline__ void prev_from_global(const float *g, uint32_t lane, 
 
 // ---- window + overlap-add (audio.rs:1116-1118), sample conversion (samples.rs:92-103), stores of one channel
 template <int FMT>
-__device__ __forceinline__ void ola_store(const LwDevTables &T, const LwFastArgs &F, const char *img, uint32_t lane, int chn,
+__device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, uint32_t lane, int chn,
 		uint32_t out_off, const float2_t (&Rc)[2][4], const PrevHalf &h)
 {
 	// (out[q], out[1023-q]) = (pa s[q] + pb' s[r], -pa s[r] + pb' s[q])
 	float2_t O[2][4];
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) {
-		const float4_t w0 = lds4(img + F.off.win, 32u * (64u * c2 + lane));
-		const float4_t w1 = lds4(img + F.off.win, 32u * (64u * c2 + lane) + 16u);
+		const float4_t w0 = lds4(img + LWI_WIN, 32u * (64u * c2 + lane));
+		const float4_t w1 = lds4(img + LWI_WIN, 32u * (64u * c2 + lane) + 16u);
 		const float2_t S2[4] = {float2_t{w0.x, w0.y}, float2_t{w0.z, w0.w}, float2_t{w1.x, w1.y}, float2_t{w1.z, w1.w}};
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
@@ -599,10 +619,10 @@ __device__ __forceinline__ void ola_store(const LwDevTables &T, const LwFastArgs
 			const int g2[4] = {im[0][0], im[0][1], im[1][0], im[1][1]}, g3[4] = {im[1][2], im[1][3], im[0][2], im[0][3]};
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				o[(p0 + i) * T.ch] = (int16_t)min(max(g0[i], -32768), 32767);
-				o[(p1 + i) * T.ch] = (int16_t)min(max(g1[i], -32768), 32767);
-				o[(p2 + i) * T.ch] = (int16_t)min(max(g2[i], -32768), 32767);
-				o[(p3 + i) * T.ch] = (int16_t)min(max(g3[i], -32768), 32767);
+				o[(p0 + i) * F.ch] = (int16_t)min(max(g0[i], -32768), 32767);
+				o[(p1 + i) * F.ch] = (int16_t)min(max(g1[i], -32768), 32767);
+				o[(p2 + i) * F.ch] = (int16_t)min(max(g2[i], -32768), 32767);
+				o[(p3 + i) * F.ch] = (int16_t)min(max(g3[i], -32768), 32767);
 			}
 		}
 	}
@@ -619,8 +639,16 @@ __device__ __forceinline__ void store_right_half(float *dst, uint32_t lane, floa
 	*reinterpret_cast<float4_t *>(dst + 1020u - 4u * lane) = hi1;
 }
 
+// item k of a dense list: packet k of a batch whose packets all have the same block sizes (no item load needed
+// before the HBM loads can be issued)
+__device__ __forceinline__ void dense_offsets(const LwFastArgs &F, uint32_t item, LwFastItem &it)
+{
+	it.res_off = item * F.ch * 1024u;
+	it.floor_off = item * F.ch * F.fstride;
+}
+
 template <int FMT, bool RIGHT_ONLY>
-__global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwFastArgs F)
+__global__ void __launch_bounds__(LW_WG, 4) k_long(LwFastArgs F)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const uint32_t lane = threadIdx.x & 63u;
@@ -632,28 +660,30 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 	const LwFastUnit un = F.units[uidx];
 	const bool two = un.ch_b >= 0;
 	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
+	const bool late = !RIGHT_ONLY && blockIdx.x >= F.late_from;
 	uint32_t sj = 0;
 	(void)sj;
 	LW_STAMP_NW(0);
 
-	// ---- items of rounds 0 and 1 (scalar loads), then the table image (L2-resident, 3 x 16 B per thread, padded by
-	//      the host to a multiple of 3 * LW_WG * 16 bytes), then the residues/floors of round 0 (HBM)
-	LwFastItem it{}, itn{};
-	Pref pf{}, pfn{};
+	// ---- round 0: item (scalar load), table image (L2-resident, 3 x 16 B per thread, padded by the host to a
+	//      multiple of 3 * LW_WG * 16 bytes), residues/floors (HBM)
+	LwFastItem it{};
+	Pref pf{};
 	bool valid = active && item0 < F.n_items;
-	bool valid_n = active && rounds > 1 && item0 + per_round < F.n_items;
-	if (valid)
-		it = F.items[item0];
-	if (valid_n)
-		itn = F.items[item0 + per_round];
+	if (valid) {
+		if (F.dense)
+			dense_offsets(F, item0, it);
+		else
+			it = F.items[item0];
+	}
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(F.image) + threadIdx.x;
 		uint4 *dst = reinterpret_cast<uint4 *>(smem) + threadIdx.x;
-		const uint32_t n16 = F.off.total / 16;
-		const uint4 v0 = src[0], v1 = src[LW_WG], v2 = src[2 * LW_WG];
+		const uint32_t n16 = LWI_TOTAL / 16;
+		if (valid && !late)
+			issue_loads(F, it, un, lane, pf);
 		lds_fence();
-		if (valid)
-			issue_loads(T, B, it, un, lane, pf);
+		const uint4 v0 = src[0], v1 = src[LW_WG], v2 = src[2 * LW_WG];
 		LW_STAMP_NW(1);
 		dst[0] = v0;
 		dst[LW_WG] = v1;
@@ -664,57 +694,81 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 			dst[i + LW_WG] = w1;
 			dst[i + 2 * LW_WG] = w2;
 		}
+		lds_fence();
+		if (valid && late)
+			issue_loads(F, it, un, lane, pf);
 	}
+	if (valid && F.dense)
+		it = F.items[item0]; // the rest of the item is only needed in phase 2
 	__syncthreads();
 	LW_STAMP_NW(2);
 	const char *img = smem;
-	char *scrb = smem + F.off.total + wave * LW_SCR_BYTES;
-	char *pub0 = smem + F.off.total + LW_FAST_WAVES * LW_SCR_BYTES; // [parity][wave][LW_PUB_BYTES]
+	char *scr0 = smem + LWI_TOTAL;                         // [wave][LW_SCR_BYTES]
+	char *sc = scr0 + wave * LW_SCR_BYTES;
+	char *carry0 = scr0 + LW_FAST_WAVES * LW_SCR_BYTES;      // [parity][unit][LW_CARRY_BYTES]
 
+	const uint32_t lane_id = lane;
 	for (uint32_t j = 0; j < rounds; j++) {
 		const uint32_t par = j & 1u;
 		sj = j;
-		char *pub = pub0 + (par * LW_FAST_WAVES + wave) * LW_PUB_BYTES;
-		// ---- prefetch: residues/floors of round j+1, item of round j+2
-		const bool valid_nn = active && j + 2 < rounds && item0 + (j + 2) * per_round < F.n_items;
-		LwFastItem itnn{};
-		if (valid_n)
-			issue_loads(T, B, itn, un, lane, pfn);
-		if (valid_nn)
-			itnn = F.items[item0 + (j + 2) * per_round];
-		// ---- previous right half that does not come from LDS: issue its loads now, consume them in phase 2
+		// launder the lane id once per round: everything derived from it (LDS addresses, bin numbers as floats) is
+		// recomputed where it is used instead of being hoisted out of the loop and kept in registers
+		uint32_t lane = lane_id;
+		asm volatile("" : "+v"(lane));
 		PrevHalf ph[2];
 		float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb) at q_k(m' = 2 lane + c2): un-windowed left / right halves
+		const uint32_t item_n = item0 + (j + 1) * per_round;
+		const bool valid_n = active && j + 1 < rounds && item_n < F.n_items;
+		LwFastItem itn{};
+		if (valid_n && !F.dense)
+			itn = F.items[item_n];
 		if (valid) {
-			if (!RIGHT_ONLY && it.src_kind >= LW_SRC_STATE) {
-				const float *g;
-				uint32_t cstride;
-				if (it.src_kind == LW_SRC_STATE) {
-					const uint32_t pin = (it.flags & LW_RF_PARITY_IN) ? 1u : 0u;
-					g = B.state + ((size_t)it.src_arg * 2 + pin) * T.state_stride;
-					cstride = T.state_chan_stride;
-				} else if (it.src_kind == LW_SRC_HALO) {
-					g = F.halo + (size_t)it.src_arg * T.ch * 512u;
-					cstride = 512u;
-				} else { // LW_SRC_TD: second half of the predecessor's [ch][2048] time-domain block
-					g = B.td + (size_t)it.src_arg + 1024u;
-					cstride = 2048u;
-				}
-				prev_from_global(g + (uint32_t)chn[0] * cstride, lane, ph[0]);
-				if (two)
-					prev_from_global(g + (uint32_t)chn[1] * cstride, lane, ph[1]);
-			}
 			LW_STAMP(3);
 			if (two)
-				long_phase1<2>(F, img, scrb, pub, lane, un, pf, R, j);
+				long_phase1<2>(F, img, sc, lane, un, pf, R, j);
 			else
-				long_phase1<1>(F, img, scrb, pub, lane, un, pf, R, j);
-			// hand-over across rounds: the last packet slot of round j-1 published into the other parity
-			if (!RIGHT_ONLY && it.src_kind == LW_SRC_LDS && slot == 0) {
-				const char *src = pub0 + ((par ^ 1u) * LW_FAST_WAVES + (per_round - 1) * n_units + uidx) * LW_PUB_BYTES;
-				prev_from_lds(src, lane, ph[0]);
+				long_phase1<1>(F, img, sc, lane, un, pf, R, j);
+			if (!RIGHT_ONLY) {
+				// previous right half that does not come from LDS: loads in flight across the barrier
+				if (it.src_kind >= LW_SRC_STATE) {
+					const float *g;
+					uint32_t cstride;
+					if (it.src_kind == LW_SRC_STATE) {
+						const uint32_t pin = (it.flags & LW_RF_PARITY_IN) ? 1u : 0u;
+						g = F.state + ((size_t)it.src_arg * 2 + pin) * F.state_stride;
+						cstride = F.state_chan_stride;
+					} else if (it.src_kind == LW_SRC_HALO) {
+						g = F.halo + (size_t)it.src_arg * F.ch * 512u;
+						cstride = 512u;
+					} else { // LW_SRC_TD: second half of the predecessor's [ch][2048] time-domain block
+						g = F.td + (size_t)it.src_arg + 1024u;
+						cstride = 2048u;
+					}
+					prev_from_global(g + (uint32_t)chn[0] * cstride, lane, ph[0]);
+					if (two)
+						prev_from_global(g + (uint32_t)chn[1] * cstride, lane, ph[1]);
+				}
 				if (two)
-					prev_from_lds(src + 2048, lane, ph[1]);
+					publish<2>(sc, lane, R);
+				else
+					publish<1>(sc, lane, R);
+				if (slot == per_round - 1 && rounds > 1) { // next round's first packet slot reads it from the carry buffer
+					char *cb = carry0 + (par * n_units + uidx) * LW_CARRY_BYTES;
+					if (two)
+						publish<2>(cb, lane, R);
+					else
+						publish<1>(cb, lane, R);
+				}
+			}
+		}
+		// ---- HBM loads of the next round (pf is dead by now): in flight during phase 2 and the barriers
+		if (valid_n) {
+			if (F.dense) {
+				dense_offsets(F, item_n, itn);
+				issue_loads(F, itn, un, lane, pf);
+				itn = F.items[item_n];
+			} else {
+				issue_loads(F, itn, un, lane, pf);
 			}
 		}
 		if (!RIGHT_ONLY)
@@ -725,21 +779,23 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 #pragma unroll
 				for (int c = 0; c < 2; c++)
 					if (c == 0 || two) {
-						float *dst = F.halo + ((size_t)it.halo_out * T.ch + chn[c]) * 512u;
+						float *dst = F.halo + ((size_t)it.halo_out * F.ch + chn[c]) * 512u;
 						*reinterpret_cast<float4_t *>(dst + 4u * lane) = LW_PB_LO0(c);
 						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
 					}
 			} else {
-				if (it.src_kind == LW_SRC_LDS && slot != 0) {
-					const char *src = pub - n_units * LW_PUB_BYTES; // same round, previous packet slot, same unit
+				if (it.src_kind == LW_SRC_LDS) {
+					// same round: scratch of the previous packet slot, same unit; slot 0: carry buffer of round j-1
+					const char *src = slot != 0 ? sc - n_units * LW_SCR_BYTES
+					                            : carry0 + ((par ^ 1u) * n_units + uidx) * LW_CARRY_BYTES;
 					prev_from_lds(src, lane, ph[0]);
 					if (two)
 						prev_from_lds(src + 2048, lane, ph[1]);
 				}
 				if (it.src_kind != LW_SRC_NONE) {
-					ola_store<FMT>(T, F, img, lane, chn[0], it.out_off, R[0], ph[0]);
+					ola_store<FMT>(F, img, lane, chn[0], it.out_off, R[0], ph[0]);
 					if (two)
-						ola_store<FMT>(T, F, img, lane, chn[1], it.out_off, R[1], ph[1]);
+						ola_store<FMT>(F, img, lane, chn[1], it.out_off, R[1], ph[1]);
 				}
 				// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
 				const bool to_state = it.state_out >= 0, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
@@ -750,21 +806,20 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 							const float4_t lo0 = LW_PB_LO0(c), lo1 = LW_PB_LO1(c);
 							if (to_state) {
 								const uint32_t pout = (it.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
-								store_right_half(B.state + ((size_t)it.state_out * 2 + pout) * T.state_stride +
-										(uint32_t)chn[c] * T.state_chan_stride, lane, lo0, lo1);
+								store_right_half(F.state + ((size_t)it.state_out * 2 + pout) * F.state_stride +
+										(uint32_t)chn[c] * F.state_chan_stride, lane, lo0, lo1);
 							}
 							if (to_td)
-								store_right_half(B.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u + 1024u, lane, lo0, lo1);
+								store_right_half(F.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u + 1024u, lane, lo0, lo1);
 						}
 				}
 			}
 		}
 		LW_STAMP_NW(10);
+		if (!RIGHT_ONLY && j + 1 < rounds)
+			__syncthreads(); // every hand-over read of this round is done before the next round reuses the scratch
 		it = itn;
-		itn = itnn;
-		pf = pfn;
 		valid = valid_n;
-		valid_n = valid_nn;
 	}
 	sj = 3;
 	LW_STAMP(11);
@@ -776,13 +831,21 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwDevTables T, LwBatchDev B, LwF
 void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st)
 {
 	LwFastArgs F{};
-	F.off = L.off;
 	F.image = L.d_image;
+	F.residue = B.residue;
+	F.floors = B.floors;
+	F.state = B.state;
+	F.td = B.td;
+	F.ch = T.ch;
+	F.fstride = T.fstride;
+	F.state_stride = T.state_stride;
+	F.state_chan_stride = T.state_chan_stride;
 	F.n_units = L.n_units;
 	F.units = L.d_units;
 	F.halo = L.d_halo;
 	F.out = out;
-	const size_t lds = (size_t)L.off.total + (size_t)LW_FAST_WAVES * (LW_SCR_BYTES + 2 * LW_PUB_BYTES);
+	const size_t lds = (size_t)LWI_TOTAL + (size_t)LW_FAST_WAVES * LW_SCR_BYTES + (size_t)2 * L.n_units * LW_CARRY_BYTES;
+	F.late_from = 0xFFFFFFFFu;
 	static bool attr_done = false;
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -796,20 +859,22 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 		F.n_items = L.n_halo_items;
 		F.per_round = 1; // spread the few halo packets over the whole chip: one packet per workgroup
 		F.rounds = 1;
-		hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, T, B, F);
+		hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
 	}
 	if (L.n_items) {
 		F.items = L.d_items;
 		F.n_items = L.n_items;
 		F.per_round = L.per_round;
 		F.rounds = L.rounds;
+		F.dense = L.dense;
 		const uint32_t chunk = L.per_round * L.rounds;
 		const uint32_t grid = (L.n_items + chunk - 1) / chunk;
+		F.late_from = L.late_from;
 		if (fmt == LW_OUT_I16_PLANAR)
-			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, T, B, F);
+			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, F);
 		else if (fmt == LW_OUT_I16_INTERLEAVED)
-			hipLaunchKernelGGL((k_long<LW_OUT_I16_INTERLEAVED, false>), dim3(grid), dim3(LW_WG), lds, st, T, B, F);
+			hipLaunchKernelGGL((k_long<LW_OUT_I16_INTERLEAVED, false>), dim3(grid), dim3(LW_WG), lds, st, F);
 		else
-			hipLaunchKernelGGL((k_long<LW_OUT_F32_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, T, B, F);
+			hipLaunchKernelGGL((k_long<LW_OUT_F32_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, F);
 	}
 }

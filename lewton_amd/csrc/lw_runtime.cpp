@@ -103,7 +103,7 @@ struct lw_batch {
 	float *d_halo = nullptr;
 	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
-	uint32_t fast_per_round = 1, fast_rounds = 1;
+	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0;
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
 	bool has_generic = false, has_fast = false, force_generic = false;
@@ -894,12 +894,14 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
 				[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
 		const uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
-		// enough rounds per workgroup that one workgroup per CU covers the batch (prefetch overlap inside a launch)
-		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
+		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
+		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
+		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus) * 2;
 		const uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
 		b->fast_rounds = rounds;
+		b->fast_dense = 1;
 		auto fill = [&](LwFastItem &it, uint32_t idx) {
 			const LwPacketRec &r = b->h_recs[idx];
 			std::memset(&it, 0, sizeof(it));
@@ -916,6 +918,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			const LwPacketRec &r = b->h_recs[idx];
 			LwFastItem &it = b->h_items[k];
 			fill(it, idx);
+			if (it.res_off != (uint32_t)(k * ch * n1h) || it.floor_off != (uint32_t)(k * ch * fstride))
+				b->fast_dense = 0;
 			if (r.prev == -1) {
 				it.src_kind = LW_SRC_NONE;
 			} else if (r.prev <= -2) {
@@ -1012,6 +1016,12 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.n_units = (uint32_t)d->fast.units.size();
 		L.per_round = b->fast_per_round;
 		L.rounds = b->fast_rounds;
+		L.dense = b->fast_dense;
+		{
+			const uint32_t chunk = L.per_round * L.rounds;
+			const uint32_t grid = (L.n_items + chunk - 1) / chunk;
+			L.late_from = grid > (uint32_t)d->n_cus ? (uint32_t)d->n_cus : 0xFFFFFFFFu;
+		}
 		L.d_units = d->d_fast_units;
 		L.d_halo = b->d_halo;
 		lw_launch_long(d->T, B, L, d_out, b->fmt, st);
