@@ -199,8 +199,7 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 					w.h(o.sid16)[((slot * 4 + x) * 64 + l) * 4 + j] = (uint16_t)(16 * sidx);
 				}
 	}
-	// the kernel stages the image with 3 x 16-byte loads per thread of a LW_FAST_WAVES-wave workgroup
-	const size_t quantum = (size_t)3 * 64 * LW_FAST_WAVES * 16;
+	const size_t quantum = 1024;
 	o.total = (uint32_t)((plan.image.size() + quantum - 1) / quantum * quantum);
 	plan.image.resize(o.total, 0);
 	if (o.apair != LWI_APAIR || o.tw_s2 != LWI_TW_S2 || o.tw_l0 != LWI_TW_L0 || o.tw_l1 != LWI_TW_L1 || o.tw_l2 != LWI_TW_L2 ||

@@ -9,7 +9,7 @@
 
 #define LW_FAST_BS 11          // the kernel is specialised for blocksize_1 = 11 (n = 2048)
 #define LW_FAST_MAX_FLOORS 2   // distinct floor-1 configurations staged in LDS
-#define LW_FAST_WAVES 8        // waves (packet-units) per workgroup and round: 2 per SIMD, <= 256 VGPRs each
+#define LW_FAST_WAVES 16       // waves (packet-units) per workgroup and round: 4 per SIMD, <= 128 VGPRs each
 #define LW_FAST_MAX_ROUNDS 16  // rounds per workgroup (chunk = rounds * packets per round consecutive items)
 
 // Byte offsets inside the LDS image (all 16-byte aligned).  Index conventions: lane = 0..63,
@@ -51,7 +51,7 @@ enum : uint32_t {
 	LWI_INV_DB = 18384, // 1024
 	LWI_XSF = 19408,    // LW_FAST_MAX_FLOORS * 256
 	LWI_SID16 = 19920,  // LW_FAST_MAX_FLOORS * 2048
-	LWI_TOTAL = 24576   // 24016 padded to the staging quantum 3 * 64 * LW_FAST_WAVES * 16
+	LWI_TOTAL = 24576   // 24016 padded to a multiple of 1024
 };
 
 struct LwFastUnit {
@@ -80,6 +80,8 @@ struct LwFastPlan {
 #define LW_SRC_HALO 3u   // halo slot src_arg, filled by the RIGHT_ONLY pre-pass
 #define LW_SRC_TD 4u     // time-domain block at float offset src_arg of B.td (generic-kernel predecessor)
 
+#define LW_IF_NEXT_LDS 1u // the next item of the list takes this packet's right half through LDS
+
 // One work item of the specialised kernel = one packet; everything the kernel needs, in one 32-byte scalar load.
 struct LwFastItem {
 	uint32_t res_off;   // float offset of the packet's [ch][1024] residue block
@@ -90,7 +92,7 @@ struct LwFastItem {
 	uint32_t halo_out;  // RIGHT_ONLY pre-pass: halo slot to fill
 	uint8_t src_kind;   // LW_SRC_*
 	uint8_t mode;
-	uint8_t flags;      // LW_RF_PARITY_IN / LW_RF_PARITY_OUT / LW_RF_WRITE_TD
+	uint8_t flags;      // LW_RF_PARITY_IN / LW_RF_PARITY_OUT / LW_RF_WRITE_TD / LW_IF_NEXT_LDS
 	uint8_t pad;
 	uint32_t pkt;       // index into the batch's records (host bookkeeping)
 };
@@ -107,8 +109,8 @@ struct LwFastLaunch {
 	uint32_t per_round; // packets per workgroup and round
 	uint32_t rounds;    // rounds per workgroup
 	uint32_t dense;     // item k == packet k with uniform block sizes
-	uint32_t late_from; // first workgroup of the half of the grid that issues its HBM loads late
-	const LwFastUnit *d_units;
+	uint32_t late_from; // first wave of a workgroup that issues its first HBM loads late
+	LwFastUnit units[LW_FAST_WAVES];
 	float *d_halo;
 };
 

@@ -5,17 +5,16 @@
 //     residue load (coalesced float4) -> inverse coupling -> floor-1 curve -> floor x residue
 //     -> IMDCT entirely in registers with three wave-private LDS transposes -> window/overlap-add
 //     -> i16/f32 store (coalesced).
-// A workgroup is 8 waves and works through a chunk of `rounds` x `per_round` consecutive items of the
-// stream-sorted work list, one round at a time.  LDS: 24 KB re-ordered twiddle/window tables staged once per
-// workgroup + 4 KB transpose scratch per wave + 2 x 4 KB carry buffers per unit = 64 KB for stereo, so two
-// workgroups (16 waves, <= 128 VGPRs each) share a CU and drift apart in phase: one group's HBM loads and
-// stores overlap the other's arithmetic.  The second half of the grid issues its HBM loads only after staging
-// the tables, so that the first half's data is queued -- and arrives -- first.
-// A packet's un-windowed right half reaches its successor through LDS (same round: the scratch of wave -
-// n_units; previous round: the carry buffer written by the last packet slot), one s_barrier per round (two
-// when there are several rounds); at chunk starts it comes from the stream's state slot, from a halo buffer
-// filled by a RIGHT_ONLY pre-pass of this same kernel, or from the time-domain block of a generic-kernel
-// predecessor.
+// A workgroup is 16 waves (one per CU, 4 waves per SIMD, <= 128 VGPRs) and works through a chunk of
+// `rounds` x `per_round` consecutive items of the stream-sorted work list, one round at a time.  There is no
+// s_barrier after the table image is staged: a packet's un-windowed right half reaches its successor through a
+// 4 KB hand-over buffer in LDS guarded by a pair of LDS counters (published / consumed), so every wave runs
+// ahead as far as its own data allows.  The second half of the waves issues its HBM loads only after staging
+// the tables, so the first half's data is queued -- and arrives -- first: HBM traffic of one half overlaps the
+// arithmetic of the other inside a single launch.
+// LDS: 24 KB re-ordered twiddle/window tables + per wave 4 KB transpose scratch + 4 KB hand-over buffer.
+// At chunk starts the previous right half comes from the stream's state slot, from a halo buffer filled by a
+// RIGHT_ONLY pre-pass of this same kernel, or from the time-domain block of a generic-kernel predecessor.
 //
 // Register layouts of the 512 complex pairs p (u[2p], u[2p+1]) of imdct.rs's butterfly array, 8 per lane:
 //   B: lane = p[5:0], reg = p[8:6]   step 2 and stages l = 0,1   (pair bits 8,7,6 are lane-local)
@@ -32,14 +31,14 @@
 #include "lw_kernels.hpp"
 
 #define LW_WG (64 * LW_FAST_WAVES)
-#define LW_SCR_BYTES 4096u // per wave: transposes of one channel at a time / 2 x 1 KB floor segment tables / published
-                           // right half [2 channels][2][64] float4
-#define LW_CARRY_BYTES 4096u // per parity and unit: right half of the last packet slot of a round
+#define LW_SCR_BYTES 4096u // per wave: transposes of one channel at a time / 2 x 1 KB floor segment tables
+#define LW_PUB_BYTES 4096u // per wave: published right half [2 channels][2][64] float4
+#define LW_LDS_BYTES (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES) + 2 * LW_FAST_WAVES * 4)
 
 struct LwFastArgs {
 	const uint8_t *image;      // LDS image in HBM (LWI_TOTAL bytes)
 	const LwFastItem *items;   // work list in stream-sorted order
-	const LwFastUnit *units;   // [n_units]
+	LwFastUnit units[LW_FAST_WAVES]; // read with compile-time indices only (no scratch copy, no dependent load)
 	const float *residue;      // batch arrays (lw_records.h)
 	const uint16_t *floors;
 	float *state;              // state pool [slots][2][ch][n1/2]
@@ -51,29 +50,53 @@ struct LwFastArgs {
 	uint32_t per_round;        // packets per workgroup and round (<= LW_FAST_WAVES / n_units)
 	uint32_t rounds;           // rounds per workgroup
 	uint32_t dense;            // item k of the list is packet k and every packet block has the same size
-	uint32_t late_from;        // workgroups >= late_from issue their first HBM loads after staging the tables
+	uint32_t late_from;        // waves >= late_from issue their first HBM loads after staging the tables
 	uint32_t ch, fstride;      // channels, u16 entries per channel in a floor block
 	uint32_t state_stride, state_chan_stride;
 };
 
 #ifdef LW_STAMPS
+// Debug build: s_memtime stamps collected in two VGPRs (lane i = stamp i) and stored once at the end of the kernel,
+// so that the instrumentation adds no memory traffic or waits of its own (LW_STAMP_W also drains the wave's loads).
 __device__ unsigned long long *g_lw_stamps = nullptr;
 extern "C" int lw_debug_set_stamp_buffer(void *dptr)
 {
 	return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lw_stamps), &dptr, sizeof(dptr));
 }
+#define LW_STAMP_DECL uint32_t st_lo_ = 0, st_hi_ = 0; unsigned long long *st_buf_ = g_lw_stamps
+#define LW_STAMP_ARGS , uint32_t &st_lo_, uint32_t &st_hi_
+#define LW_STAMP_PASS , st_lo_, st_hi_
 #define LW_STAMP_AT(i, waitstr)                                                                               \
 	do {                                                                                                      \
 		unsigned long long t_;                                                                                \
 		asm volatile(waitstr "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-		if (g_lw_stamps && (threadIdx.x & 63u) == 0 && (i) + 16 * sj < 64)                                    \
-			g_lw_stamps[((size_t)blockIdx.x * LW_FAST_WAVES + (threadIdx.x >> 6)) * 64 + (i) + 16 * sj] = t_; \
+		if (sj == 0)                                                                                          \
+			asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                 \
+					: "+v"(st_lo_), "+v"(st_hi_) : "s"((uint32_t)t_), "s"((uint32_t)(t_ >> 32)), "n"(i));    \
+		else if (sj == 1)                                                                                     \
+			asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                 \
+					: "+v"(st_lo_), "+v"(st_hi_) : "s"((uint32_t)t_), "s"((uint32_t)(t_ >> 32)), "n"((i) + 16)); \
+		else if (sj == 3)                                                                                     \
+			asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                 \
+					: "+v"(st_lo_), "+v"(st_hi_) : "s"((uint32_t)t_), "s"((uint32_t)(t_ >> 32)), "n"((i) + 48)); \
 	} while (0)
-#define LW_STAMP(i) LW_STAMP_AT(i, "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
+#define LW_STAMP(i) LW_STAMP_AT(i, "")
 #define LW_STAMP_NW(i) LW_STAMP_AT(i, "")
+#define LW_STAMP_W(i) LW_STAMP_AT(i, "s_waitcnt vmcnt(0)\n\t")
+#define LW_STAMP_FLUSH                                                                                        \
+	do {                                                                                                      \
+		if (st_buf_)                                                                                          \
+			st_buf_[((size_t)blockIdx.x * LW_FAST_WAVES + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63u)] =   \
+				((unsigned long long)st_hi_ << 32) | st_lo_;                                                  \
+	} while (0)
 #else
+#define LW_STAMP_DECL
+#define LW_STAMP_ARGS
+#define LW_STAMP_PASS
 #define LW_STAMP(i)
 #define LW_STAMP_NW(i)
+#define LW_STAMP_W(i)
+#define LW_STAMP_FLUSH
 #endif
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -170,6 +193,13 @@ struct Pref {          // what one wave loads from HBM for one item
 __device__ __forceinline__ void issue_loads(const LwFastArgs &F, const LwFastItem &it,
 		const LwFastUnit &un, uint32_t lane, Pref &p)
 {
+#ifdef LW_EXP_NOLOAD // experiment: no HBM reads (synthetic register contents)
+	for (int c = 0; c < 2; c++)
+		for (int x = 0; x < 4; x++)
+			p.r[c][x] = float4_t{(float)lane, 1.0f, (float)x, 2.0f};
+	p.fe[0] = p.fe[1] = lane == 0 ? (0x8000u | 100u) : (lane == (uint32_t)un.F_a - 1 ? (0x8000u | 90u) : 0u);
+	return;
+#endif
 	const float4_t *s0 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
 #pragma unroll
 	for (int x = 0; x < 4; x++)
@@ -437,7 +467,7 @@ __device__ __forceinline__ void stage_e(const char *sc, uint32_t lane, int c2, c
 // ONE 4 KB buffer one after the other (LDS operations of a wave execute in order).
 template <int NCH>
 __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img, char *sc, uint32_t lane,
-		const LwFastUnit &un, Pref &pf, float2_t (&R)[2][2][4], uint32_t sj)
+		const LwFastUnit &un, Pref &pf, float2_t (&R)[2][2][4], uint32_t sj LW_STAMP_ARGS)
 {
 	(void)sj;
 	// ---- floor segment tables (1 KB each)
@@ -647,26 +677,43 @@ __device__ __forceinline__ void dense_offsets(const LwFastArgs &F, uint32_t item
 	it.floor_off = item * F.ch * F.fstride;
 }
 
+// LDS counters of the hand-over protocol (one producer, one consumer per counter)
+__device__ __forceinline__ void lds_wait_ge(const volatile uint32_t *p, uint32_t need)
+{
+	while (*p < need)
+		__builtin_amdgcn_s_sleep(1);
+}
+
 template <int FMT, bool RIGHT_ONLY>
-__global__ void __launch_bounds__(LW_WG, 4) k_long(LwFastArgs F)
+__global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t lane_id = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t n_units = F.n_units, per_round = F.per_round, rounds = F.rounds;
 	const uint32_t slot = wave / n_units, uidx = wave - slot * n_units; // packet slot of the round, unit of the packet
 	const bool active = slot < per_round;
 	const uint32_t item0 = blockIdx.x * per_round * rounds + slot;      // item of round j = item0 + j * per_round
-	const LwFastUnit un = F.units[uidx];
+	LwFastUnit un = F.units[0];
+#pragma unroll
+	for (int i = 1; i < LW_FAST_WAVES; i++)
+		if (uidx == (uint32_t)i)
+			un = F.units[i];
+#ifdef LW_EXP_STEREO_ONLY // instruction-count experiments: only the two-channel path is compiled
+	const bool two = true;
+#else
 	const bool two = un.ch_b >= 0;
+#endif
 	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
-	const bool late = !RIGHT_ONLY && blockIdx.x >= F.late_from;
+	const bool late = !RIGHT_ONLY && wave >= F.late_from;
 	uint32_t sj = 0;
 	(void)sj;
+	LW_STAMP_DECL;
 	LW_STAMP_NW(0);
 
-	// ---- round 0: item (scalar load), table image (L2-resident, 3 x 16 B per thread, padded by the host to a
-	//      multiple of 3 * LW_WG * 16 bytes), residues/floors (HBM)
+	volatile uint32_t *pubcnt = reinterpret_cast<volatile uint32_t *>(smem + LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES));
+	volatile uint32_t *ackcnt = pubcnt + LW_FAST_WAVES;
+	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
 	LwFastItem it{};
 	Pref pf{};
 	bool valid = active && item0 < F.n_items;
@@ -677,23 +724,24 @@ __global__ void __launch_bounds__(LW_WG, 4) k_long(LwFastArgs F)
 			it = F.items[item0];
 	}
 	{
+		uint32_t lane = lane_id;
 		const uint4 *src = reinterpret_cast<const uint4 *>(F.image) + threadIdx.x;
 		uint4 *dst = reinterpret_cast<uint4 *>(smem) + threadIdx.x;
-		const uint32_t n16 = LWI_TOTAL / 16;
 		if (valid && !late)
 			issue_loads(F, it, un, lane, pf);
 		lds_fence();
-		const uint4 v0 = src[0], v1 = src[LW_WG], v2 = src[2 * LW_WG];
+		static_assert(LWI_TOTAL / 16 > LW_WG && LWI_TOTAL / 16 <= 2 * LW_WG && (LWI_TOTAL / 16 - LW_WG) % 64 == 0, "image staging");
+		const bool second = wave < (LWI_TOTAL / 16 - LW_WG) / 64; // wave-uniform
+		const uint4 v0 = src[0];
+		uint4 v1 = v0;
+		if (second)
+			v1 = src[LW_WG];
 		LW_STAMP_NW(1);
+		if (threadIdx.x < 2 * LW_FAST_WAVES)
+			pubcnt[threadIdx.x] = 0u;
 		dst[0] = v0;
-		dst[LW_WG] = v1;
-		dst[2 * LW_WG] = v2;
-		for (uint32_t i = 3 * LW_WG; i < n16; i += 3 * LW_WG) { // larger images (not with today's layout)
-			const uint4 w0 = src[i], w1 = src[i + LW_WG], w2 = src[i + 2 * LW_WG];
-			dst[i] = w0;
-			dst[i + LW_WG] = w1;
-			dst[i + 2 * LW_WG] = w2;
-		}
+		if (second)
+			dst[LW_WG] = v1;
 		lds_fence();
 		if (valid && late)
 			issue_loads(F, it, un, lane, pf);
@@ -703,13 +751,15 @@ __global__ void __launch_bounds__(LW_WG, 4) k_long(LwFastArgs F)
 	__syncthreads();
 	LW_STAMP_NW(2);
 	const char *img = smem;
-	char *scr0 = smem + LWI_TOTAL;                         // [wave][LW_SCR_BYTES]
-	char *sc = scr0 + wave * LW_SCR_BYTES;
-	char *carry0 = scr0 + LW_FAST_WAVES * LW_SCR_BYTES;      // [parity][unit][LW_CARRY_BYTES]
+	char *sc = smem + LWI_TOTAL + wave * LW_SCR_BYTES;
+	char *pub0 = smem + LWI_TOTAL + LW_FAST_WAVES * LW_SCR_BYTES; // [wave][LW_PUB_BYTES]
+	char *pub = pub0 + wave * LW_PUB_BYTES;
+	uint32_t n_pub_used = 0; // hand-overs published by this wave (only those a successor reads are published)
+	uint32_t n_got = 0;      // hand-overs consumed from the predecessor wave
+	// predecessor waves: same round (slot > 0) / previous round (slot == 0)
+	const uint32_t wprev = slot != 0 ? wave - n_units : (per_round - 1) * n_units + uidx;
 
-	const uint32_t lane_id = lane;
 	for (uint32_t j = 0; j < rounds; j++) {
-		const uint32_t par = j & 1u;
 		sj = j;
 		// launder the lane id once per round: everything derived from it (LDS addresses, bin numbers as floats) is
 		// recomputed where it is used instead of being hoisted out of the loop and kept in registers
@@ -723,13 +773,41 @@ __global__ void __launch_bounds__(LW_WG, 4) k_long(LwFastArgs F)
 		if (valid_n && !F.dense)
 			itn = F.items[item_n];
 		if (valid) {
-			LW_STAMP(3);
+			LW_STAMP_W(3);
+#ifdef LW_EXP_NOCOMPUTE // experiment: no arithmetic, only the HBM traffic
+			for (int c = 0; c < 2; c++)
+				for (int c2 = 0; c2 < 2; c2++)
+					for (int k = 0; k < 4; k++)
+						R[c][c2][k] = float2_t{pf.r[c][2 * c2 + (k >> 1)][2 * (k & 1)], pf.r[c][2 * c2 + (k >> 1)][2 * (k & 1) + 1]} *
+							__uint_as_float(pf.fe[c] + 0x3f800000u);
+#else
 			if (two)
-				long_phase1<2>(F, img, sc, lane, un, pf, R, j);
+				long_phase1<2>(F, img, sc, lane, un, pf, R, j LW_STAMP_PASS);
 			else
-				long_phase1<1>(F, img, sc, lane, un, pf, R, j);
-			if (!RIGHT_ONLY) {
-				// previous right half that does not come from LDS: loads in flight across the barrier
+				long_phase1<1>(F, img, sc, lane, un, pf, R, j LW_STAMP_PASS);
+#endif
+		}
+		// ---- HBM loads of the next round (pf is dead by now): in flight during phase 2
+		if (valid_n) {
+			if (F.dense) {
+				dense_offsets(F, item_n, itn);
+				issue_loads(F, itn, un, lane, pf);
+				itn = F.items[item_n];
+			} else {
+				issue_loads(F, itn, un, lane, pf);
+			}
+		}
+		if (valid) {
+			if (RIGHT_ONLY) {
+#pragma unroll
+				for (int c = 0; c < 2; c++)
+					if (c == 0 || two) {
+						float *dst = F.halo + ((size_t)it.halo_out * F.ch + chn[c]) * 512u;
+						*reinterpret_cast<float4_t *>(dst + 4u * lane) = LW_PB_LO0(c);
+						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
+					}
+			} else {
+				// previous right half that does not come from LDS: global loads, in flight during the hand-over
 				if (it.src_kind >= LW_SRC_STATE) {
 					const float *g;
 					uint32_t cstride;
@@ -748,50 +826,29 @@ __global__ void __launch_bounds__(LW_WG, 4) k_long(LwFastArgs F)
 					if (two)
 						prev_from_global(g + (uint32_t)chn[1] * cstride, lane, ph[1]);
 				}
-				if (two)
-					publish<2>(sc, lane, R);
-				else
-					publish<1>(sc, lane, R);
-				if (slot == per_round - 1 && rounds > 1) { // next round's first packet slot reads it from the carry buffer
-					char *cb = carry0 + (par * n_units + uidx) * LW_CARRY_BYTES;
+				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
+				if (it.flags & LW_IF_NEXT_LDS) {
+					lds_wait_ge(&ackcnt[wave], n_pub_used);
 					if (two)
-						publish<2>(cb, lane, R);
+						publish<2>(pub, lane, R);
 					else
-						publish<1>(cb, lane, R);
+						publish<1>(pub, lane, R);
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					n_pub_used++;
+					pubcnt[wave] = n_pub_used;
 				}
-			}
-		}
-		// ---- HBM loads of the next round (pf is dead by now): in flight during phase 2 and the barriers
-		if (valid_n) {
-			if (F.dense) {
-				dense_offsets(F, item_n, itn);
-				issue_loads(F, itn, un, lane, pf);
-				itn = F.items[item_n];
-			} else {
-				issue_loads(F, itn, un, lane, pf);
-			}
-		}
-		if (!RIGHT_ONLY)
-			__syncthreads();
-		LW_STAMP_NW(9);
-		if (valid) {
-			if (RIGHT_ONLY) {
-#pragma unroll
-				for (int c = 0; c < 2; c++)
-					if (c == 0 || two) {
-						float *dst = F.halo + ((size_t)it.halo_out * F.ch + chn[c]) * 512u;
-						*reinterpret_cast<float4_t *>(dst + 4u * lane) = LW_PB_LO0(c);
-						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
-					}
-			} else {
+				// ---- read my predecessor's right half
 				if (it.src_kind == LW_SRC_LDS) {
-					// same round: scratch of the previous packet slot, same unit; slot 0: carry buffer of round j-1
-					const char *src = slot != 0 ? sc - n_units * LW_SCR_BYTES
-					                            : carry0 + ((par ^ 1u) * n_units + uidx) * LW_CARRY_BYTES;
+					const uint32_t need = ++n_got;
+					lds_wait_ge(&pubcnt[wprev], need);
+					const char *src = pub0 + wprev * LW_PUB_BYTES;
 					prev_from_lds(src, lane, ph[0]);
 					if (two)
 						prev_from_lds(src + 2048, lane, ph[1]);
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					ackcnt[wprev] = need;
 				}
+				LW_STAMP_NW(9);
 				if (it.src_kind != LW_SRC_NONE) {
 					ola_store<FMT>(F, img, lane, chn[0], it.out_off, R[0], ph[0]);
 					if (two)
@@ -816,13 +873,12 @@ __global__ void __launch_bounds__(LW_WG, 4) k_long(LwFastArgs F)
 			}
 		}
 		LW_STAMP_NW(10);
-		if (!RIGHT_ONLY && j + 1 < rounds)
-			__syncthreads(); // every hand-over read of this round is done before the next round reuses the scratch
 		it = itn;
 		valid = valid_n;
 	}
 	sj = 3;
-	LW_STAMP(11);
+	LW_STAMP_W(11);
+	LW_STAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -841,10 +897,11 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 	F.state_stride = T.state_stride;
 	F.state_chan_stride = T.state_chan_stride;
 	F.n_units = L.n_units;
-	F.units = L.d_units;
 	F.halo = L.d_halo;
 	F.out = out;
-	const size_t lds = (size_t)LWI_TOTAL + (size_t)LW_FAST_WAVES * LW_SCR_BYTES + (size_t)2 * L.n_units * LW_CARRY_BYTES;
+	const size_t lds = LW_LDS_BYTES;
+	for (uint32_t i = 0; i < LW_FAST_WAVES; i++)
+		F.units[i] = L.units[i < L.n_units ? i : 0];
 	F.late_from = 0xFFFFFFFFu;
 	static bool attr_done = false;
 	if (!attr_done) {

@@ -103,7 +103,7 @@ struct lw_batch {
 	float *d_halo = nullptr;
 	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
-	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0;
+	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = LW_FAST_WAVES / 2;
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
 	bool has_generic = false, has_fast = false, force_generic = false;
@@ -896,7 +896,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		const uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
 		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
-		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus) * 2;
+		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
 		const uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
@@ -928,6 +928,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			} else if (b->h_recs[r.prev].flags & LW_RF_FAST) {
 				if ((k % chunk) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev) {
 					it.src_kind = LW_SRC_LDS;
+					b->h_items[k - 1].flags |= LW_IF_NEXT_LDS;
 				} else {
 					it.src_kind = LW_SRC_HALO;
 					it.src_arg = (uint32_t)b->n_halo_items;
@@ -1017,12 +1018,9 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.per_round = b->fast_per_round;
 		L.rounds = b->fast_rounds;
 		L.dense = b->fast_dense;
-		{
-			const uint32_t chunk = L.per_round * L.rounds;
-			const uint32_t grid = (L.n_items + chunk - 1) / chunk;
-			L.late_from = grid > (uint32_t)d->n_cus ? (uint32_t)d->n_cus : 0xFFFFFFFFu;
-		}
-		L.d_units = d->d_fast_units;
+		L.late_from = b->fast_late_from;
+		for (size_t i = 0; i < d->fast.units.size() && i < LW_FAST_WAVES; i++)
+			L.units[i] = d->fast.units[i];
 		L.d_halo = b->d_halo;
 		lw_launch_long(d->T, B, L, d_out, b->fmt, st);
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";

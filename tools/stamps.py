@@ -40,7 +40,7 @@ for b in range(4):
     outs.append(torch.empty(bt.out_elems, dtype=torch.int16, device="cuda"))
     batches.append((bt, spw))
 torch.cuda.synchronize()
-nslots = 4096 * 8 * NSTAMP
+nslots = 4096 * 16 * NSTAMP
 buf = torch.zeros(nslots, dtype=torch.int64, device="cuda")
 N.lib.lw_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 assert N.lib.lw_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())) == 0
@@ -59,16 +59,27 @@ for rep in range(6):
     if rep < 2:
         continue
     print("rep %d: kernel(event) %.1f us, waves stamped %d" % (rep, ms * 1e3, len(a)))
-    names = [(0, "entry"), (1, "items+loads issued"), (2, "image+sync"), (3, "r0 residue landed"), (4, "r0 floor+spec"),
-             (5, "r0 stage B"), (6, "r0 stage C"), (7, "r0 stage D"), (8, "r0 stage E"), (9, "r0 barrier"), (10, "r0 phase2 issued"),
+    names = [(0, "entry"), (1, "loads issued"), (2, "image+sync"), (3, "r0 residue landed"), (4, "r0 floor+spec"),
+             (5, "r0 stage B"), (6, "r0 stage C"), (7, "r0 stage D"), (8, "r0 stage E"), (9, "r0 handover done"), (10, "r0 phase2 issued"),
              (19, "r1 residue landed"), (20, "r1 floor+spec"), (21, "r1 stage B"), (22, "r1 stage C"), (23, "r1 stage D"),
-             (24, "r1 stage E"), (25, "r1 barrier"), (26, "r1 phase2 issued"), (59, "all stores done")]
-    prev = None
+             (24, "r1 stage E"), (25, "r1 handover"), (26, "r1 phase2 issued"), (59, "all stores done")]
+    # s_memtime counters are not synchronised across the chip: reference every wave to the earliest entry of its
+    # own workgroup (all its waves run on one CU)
+    full = buf.cpu().numpy().reshape(-1, 16, NSTAMP)   # [block][wave][stamp]
+    ent = np.where(full[:, :, 0] != 0, full[:, :, 0], np.iinfo(np.int64).max).min(axis=1)
+    absd = full - ent[:, None, None]
+    ok = full[:, :, 0] != 0
     for i, nm in names:
-        if a[:, i].max() == 0:
+        if full[:, :, i].max() == 0:
             continue
-        rel = a[:, i] - a[:, 0]           # per-wave time since its own entry (same XCD counter)
-        d = (a[:, i] - a[:, prev]) if prev is not None else rel
-        print("  %2d %-20s since entry min/med/max %7d %7d %7d   delta med %6d max %6d" % (
-            i, nm, rel.min(), np.median(rel), rel.max(), np.median(d), d.max()))
-        prev = i
+        m = ok & (full[:, :, i] != 0)
+        col = absd[:, :, i][m]
+        early = absd[:, :8, i][m[:, :8]]
+        lateh = absd[:, 8:, i][m[:, 8:]]
+        print("  %2d %-20s since WG entry min/med/max %7d %7d %7d | waves0-7 med %7d max %7d | waves8-15 med %7d max %7d" % (
+            i, nm, col.min(), np.median(col), col.max(), np.median(early) if len(early) else -1, early.max() if len(early) else -1,
+            np.median(lateh) if len(lateh) else -1, lateh.max() if len(lateh) else -1))
+    if rep == 5:
+        e = full[:, 0, 0]
+        print("entry stamps of wave 0, blocks 0..23:", [int(x) for x in e[:24]])
+        print("end stamps  of wave 0, blocks 0..23:", [int(x) for x in full[:24, 0, 59]])
