@@ -33,7 +33,7 @@
 #define LW_WG (64 * LW_FAST_WAVES)
 #define LW_SCR_BYTES 4096u // per wave: transposes of one channel at a time / 2 x 1 KB floor segment tables
 #define LW_PUB_BYTES 4096u // per wave: published right half [2 channels][2][64] float4
-#define LW_LDS_BYTES (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES) + 2 * LW_FAST_WAVES * 4)
+#define LW_LDS_BYTES (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES) + 3 * LW_FAST_WAVES * 4)
 
 struct LwFastArgs {
 	const uint8_t *image;      // LDS image in HBM (LWI_TOTAL bytes)
@@ -275,6 +275,65 @@ __device__ __forceinline__ void spectrum(const LwFastArgs &F, const char *img, c
 	}
 }
 
+// ---- the same for both channels of a pair as ONE software pipeline over 8 steps of 4 bins (step b = 4 c + x):
+//      the interval-entry gathers of step b+2 and the inverse-dB gathers of step b are in flight while step b+1's
+//      indices are computed, so the three dependent LDS round trips per bin are paid once, not 24 times.
+__device__ __forceinline__ void spectrum_pair(const char *img, const char *sc, uint32_t lane, uint32_t fslot_a, uint32_t fslot_b,
+		float4_t (&r)[2][4])
+{
+	const float kf0 = (float)(4 * (int)lane);
+	uint2_t sid[2][4];
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		sid[0][x] = *reinterpret_cast<const uint2_t *>(img + LWI_SID16 + 8u * ((fslot_a * 4 + x) * 64u + lane));
+		sid[1][x] = *reinterpret_cast<const uint2_t *>(img + LWI_SID16 + 8u * ((fslot_b * 4 + x) * 64u + lane));
+	}
+	float4_t ent[2][4];
+	float fl[2][4];
+#define LW_SP_G(b)                                                                     \
+	do {                                                                               \
+		const uint2_t sw = sid[(b) >> 2][(b) & 3];                                     \
+		const char *t = sc + 1024 * ((b) >> 2);                                        \
+		ent[(b) & 1][0] = lds4(t, sw.x & 0xffffu);                                     \
+		ent[(b) & 1][1] = lds4(t, sw.x >> 16);                                         \
+		ent[(b) & 1][2] = lds4(t, sw.y & 0xffffu);                                     \
+		ent[(b) & 1][3] = lds4(t, sw.y >> 16);                                         \
+	} while (0)
+#define LW_SP_XI(b)                                                                    \
+	do {                                                                               \
+		_Pragma("unroll") for (int j = 0; j < 4; j++) {                                \
+			const float4_t e = ent[(b) & 1][j];                                        \
+			const float z = __builtin_fmaf(kf0 + (float)(256 * ((b) & 3) + j), e.x, e.y); /* exact: |k*dy| < 2^18 */ \
+			const int q = (int)(z * e.z);                                              \
+			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(e.w));           \
+			fl[(b) & 1][j] = *reinterpret_cast<const float *>(img + LWI_INV_DB + idx); \
+		}                                                                              \
+	} while (0)
+#define LW_SP_M(b)                                                                     \
+	do {                                                                               \
+		float4_t &rr = r[(b) >> 2][(b) & 3];                                           \
+		const float2_t lo2 = pk_mul(float2_t{fl[(b) & 1][0], fl[(b) & 1][1]}, float2_t{rr.x, rr.y}); \
+		const float2_t hi2 = pk_mul(float2_t{fl[(b) & 1][2], fl[(b) & 1][3]}, float2_t{rr.z, rr.w}); \
+		rr = float4_t{lo2.x, lo2.y, hi2.x, hi2.y};                                     \
+	} while (0)
+	LW_SP_G(0);
+	LW_SP_G(1);
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int b = 0; b < 8; b++) {
+		LW_SP_XI(b);
+		if (b + 2 < 8)
+			LW_SP_G(b + 2);
+		if (b >= 1)
+			LW_SP_M(b - 1);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	LW_SP_M(7);
+#undef LW_SP_G
+#undef LW_SP_XI
+#undef LW_SP_M
+}
+
 // ---- IMDCT step 1 (imdct.rs:337-371) in the load layout, exchange with the mirror lane -> layout B;
 //      step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452); twiddles shared by the channels
 template <int NCH>
@@ -491,9 +550,13 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 			}
 		}
 	}
-	spectrum(F, img, sc, lane, un.floor_a, unused0, pf.r[0]);
-	if (NCH == 2)
-		spectrum(F, img, sc + 1024, lane, un.floor_b, unused1, pf.r[1]);
+	if (NCH == 2 && !unused0 && !unused1) {
+		spectrum_pair(img, sc, lane, un.floor_a, un.floor_b, pf.r);
+	} else {
+		spectrum(F, img, sc, lane, un.floor_a, unused0, pf.r[0]);
+		if (NCH == 2)
+			spectrum(F, img, sc + 1024, lane, un.floor_b, unused1, pf.r[1]);
+	}
 	lds_fence();
 	LW_STAMP(4);
 	float2_t P[2][8];
@@ -669,6 +732,28 @@ __device__ __forceinline__ void store_right_half(float *dst, uint32_t lane, floa
 	*reinterpret_cast<float4_t *>(dst + 1020u - 4u * lane) = hi1;
 }
 
+// One work item = one 32-byte scalar load (the vector-memory path would park it in eight VGPRs per item)
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ LwFastItem load_item(const LwFastItem *items, uint32_t idx)
+{
+	const LwFastItem *p = items + __builtin_amdgcn_readfirstlane(idx);
+	u32x8_t v;
+	asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+	LwFastItem it;
+	it.res_off = v[0];
+	it.floor_off = v[1];
+	it.out_off = v[2];
+	it.src_arg = v[3];
+	it.state_out = (int32_t)v[4];
+	it.halo_out = v[5];
+	it.src_kind = (uint8_t)(v[6] & 0xffu);
+	it.mode = (uint8_t)((v[6] >> 8) & 0xffu);
+	it.flags = (uint8_t)((v[6] >> 16) & 0xffu);
+	it.pad = 0;
+	it.pkt = v[7];
+	return it;
+}
+
 // item k of a dense list: packet k of a batch whose packets all have the same block sizes (no item load needed
 // before the HBM loads can be issued)
 __device__ __forceinline__ void dense_offsets(const LwFastArgs &F, uint32_t item, LwFastItem &it)
@@ -713,6 +798,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 
 	volatile uint32_t *pubcnt = reinterpret_cast<volatile uint32_t *>(smem + LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES));
 	volatile uint32_t *ackcnt = pubcnt + LW_FAST_WAVES;
+	volatile uint32_t *landed = ackcnt + LW_FAST_WAVES; // early wave w: "my first HBM loads have arrived"
 	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
 	LwFastItem it{};
 	Pref pf{};
@@ -721,7 +807,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		if (F.dense)
 			dense_offsets(F, item0, it);
 		else
-			it = F.items[item0];
+			it = load_item(F.items, item0);
 	}
 	{
 		uint32_t lane = lane_id;
@@ -737,19 +823,29 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		if (second)
 			v1 = src[LW_WG];
 		LW_STAMP_NW(1);
-		if (threadIdx.x < 2 * LW_FAST_WAVES)
+		if (threadIdx.x < 3 * LW_FAST_WAVES)
 			pubcnt[threadIdx.x] = 0u;
 		dst[0] = v0;
 		if (second)
 			dst[LW_WG] = v1;
 		lds_fence();
-		if (valid && late)
-			issue_loads(F, it, un, lane, pf);
 	}
-	if (valid && F.dense)
-		it = F.items[item0]; // the rest of the item is only needed in phase 2
 	__syncthreads();
 	LW_STAMP_NW(2);
+	if (!RIGHT_ONLY && F.late_from < LW_FAST_WAVES) {
+		// pace the HBM queue: the late half of the waves issues its loads when the early half's data has landed,
+		// so that the early half computes while the late half's data is in flight
+		if (!late) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			landed[wave] = 1u;
+		} else {
+			lds_wait_ge(&landed[wave - F.late_from], 1u);
+			if (valid)
+				issue_loads(F, it, un, lane_id, pf);
+		}
+	}
+	if (valid && F.dense)
+		it = load_item(F.items, item0); // the rest of the item is only needed in phase 2
 	const char *img = smem;
 	char *sc = smem + LWI_TOTAL + wave * LW_SCR_BYTES;
 	char *pub0 = smem + LWI_TOTAL + LW_FAST_WAVES * LW_SCR_BYTES; // [wave][LW_PUB_BYTES]
@@ -765,13 +861,12 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		// recomputed where it is used instead of being hoisted out of the loop and kept in registers
 		uint32_t lane = lane_id;
 		asm volatile("" : "+v"(lane));
-		PrevHalf ph[2];
 		float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb) at q_k(m' = 2 lane + c2): un-windowed left / right halves
 		const uint32_t item_n = item0 + (j + 1) * per_round;
 		const bool valid_n = active && j + 1 < rounds && item_n < F.n_items;
 		LwFastItem itn{};
 		if (valid_n && !F.dense)
-			itn = F.items[item_n];
+			itn = load_item(F.items, item_n);
 		if (valid) {
 			LW_STAMP_W(3);
 #ifdef LW_EXP_NOCOMPUTE // experiment: no arithmetic, only the HBM traffic
@@ -787,16 +882,6 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 				long_phase1<1>(F, img, sc, lane, un, pf, R, j LW_STAMP_PASS);
 #endif
 		}
-		// ---- HBM loads of the next round (pf is dead by now): in flight during phase 2
-		if (valid_n) {
-			if (F.dense) {
-				dense_offsets(F, item_n, itn);
-				issue_loads(F, itn, un, lane, pf);
-				itn = F.items[item_n];
-			} else {
-				issue_loads(F, itn, un, lane, pf);
-			}
-		}
 		if (valid) {
 			if (RIGHT_ONLY) {
 #pragma unroll
@@ -807,25 +892,6 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
 					}
 			} else {
-				// previous right half that does not come from LDS: global loads, in flight during the hand-over
-				if (it.src_kind >= LW_SRC_STATE) {
-					const float *g;
-					uint32_t cstride;
-					if (it.src_kind == LW_SRC_STATE) {
-						const uint32_t pin = (it.flags & LW_RF_PARITY_IN) ? 1u : 0u;
-						g = F.state + ((size_t)it.src_arg * 2 + pin) * F.state_stride;
-						cstride = F.state_chan_stride;
-					} else if (it.src_kind == LW_SRC_HALO) {
-						g = F.halo + (size_t)it.src_arg * F.ch * 512u;
-						cstride = 512u;
-					} else { // LW_SRC_TD: second half of the predecessor's [ch][2048] time-domain block
-						g = F.td + (size_t)it.src_arg + 1024u;
-						cstride = 2048u;
-					}
-					prev_from_global(g + (uint32_t)chn[0] * cstride, lane, ph[0]);
-					if (two)
-						prev_from_global(g + (uint32_t)chn[1] * cstride, lane, ph[1]);
-				}
 				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
 				if (it.flags & LW_IF_NEXT_LDS) {
 					lds_wait_ge(&ackcnt[wave], n_pub_used);
@@ -837,22 +903,43 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 					n_pub_used++;
 					pubcnt[wave] = n_pub_used;
 				}
-				// ---- read my predecessor's right half
-				if (it.src_kind == LW_SRC_LDS) {
-					const uint32_t need = ++n_got;
-					lds_wait_ge(&pubcnt[wprev], need);
-					const char *src = pub0 + wprev * LW_PUB_BYTES;
-					prev_from_lds(src, lane, ph[0]);
-					if (two)
-						prev_from_lds(src + 2048, lane, ph[1]);
-					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-					ackcnt[wprev] = need;
-				}
-				LW_STAMP_NW(9);
+				// ---- the previous packet's right half: from my predecessor wave through LDS, or (chunk starts) from the
+				//      stream's state slot / the halo buffer / a generic predecessor's time-domain block; then window,
+				//      overlap-add, conversion and stores, one channel at a time (register pressure)
 				if (it.src_kind != LW_SRC_NONE) {
-					ola_store<FMT>(F, img, lane, chn[0], it.out_off, R[0], ph[0]);
-					if (two)
-						ola_store<FMT>(F, img, lane, chn[1], it.out_off, R[1], ph[1]);
+					const float *g = nullptr;
+					uint32_t cstride = 0;
+					const char *src = nullptr;
+					if (it.src_kind == LW_SRC_LDS) {
+						++n_got;
+						lds_wait_ge(&pubcnt[wprev], n_got);
+						src = pub0 + wprev * LW_PUB_BYTES;
+					} else if (it.src_kind == LW_SRC_STATE) {
+						const uint32_t pin = (it.flags & LW_RF_PARITY_IN) ? 1u : 0u;
+						g = F.state + ((size_t)it.src_arg * 2 + pin) * F.state_stride;
+						cstride = F.state_chan_stride;
+					} else if (it.src_kind == LW_SRC_HALO) {
+						g = F.halo + (size_t)it.src_arg * F.ch * 512u;
+						cstride = 512u;
+					} else { // LW_SRC_TD: second half of the predecessor's [ch][2048] time-domain block
+						g = F.td + (size_t)it.src_arg + 1024u;
+						cstride = 2048u;
+					}
+					LW_STAMP_NW(9);
+#pragma unroll
+					for (int c = 0; c < 2; c++)
+						if (c == 0 || two) {
+							PrevHalf ph;
+							if (src)
+								prev_from_lds(src + 2048 * c, lane, ph);
+							else
+								prev_from_global(g + (uint32_t)chn[c] * cstride, lane, ph);
+							ola_store<FMT>(F, img, lane, chn[c], it.out_off, R[c], ph);
+						}
+					if (src) {
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						ackcnt[wprev] = n_got;
+					}
 				}
 				// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
 				const bool to_state = it.state_out >= 0, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
@@ -873,6 +960,16 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 			}
 		}
 		LW_STAMP_NW(10);
+		// ---- HBM loads of the next round
+		if (valid_n) {
+			if (F.dense) {
+				dense_offsets(F, item_n, itn);
+				issue_loads(F, itn, un, lane, pf);
+				itn = load_item(F.items, item_n);
+			} else {
+				issue_loads(F, itn, un, lane, pf);
+			}
+		}
 		it = itn;
 		valid = valid_n;
 	}

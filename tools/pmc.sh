@@ -2,7 +2,7 @@
 # PMC passes for the dominant kernel (run on the GPU box through gpurun). Usage: tools_pmc.sh <tag> [bench args...]
 # Counters are collected in their own rocprofv3 runs with --kernel-trace only (no other trace domains).
 TAG=$1; shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG/pmc
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -22,6 +22,6 @@ for f in sorted(glob.glob("$OUT/p*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in agg.items():
-        if "k_long" in k or "generic" in k:
+        if ("k_long" in k or "generic" in k) and len(next(iter(v.values()))) > 4:
             print(f.split("/")[-2], k, {c:(sum(x)/len(x)) for c,x in v.items()}, "n=",len(next(iter(v.values()))))
 PY
