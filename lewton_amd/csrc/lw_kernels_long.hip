@@ -99,6 +99,12 @@ extern "C" int lw_debug_set_stamp_buffer(void *dptr)
 #define LW_STAMP_FLUSH
 #endif
 
+#ifdef LW_MARKS
+#define LW_MARK(name) asm volatile("; LWMARK " name)
+#else
+#define LW_MARK(name)
+#endif
+
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
@@ -179,6 +185,162 @@ __device__ __forceinline__ void step7_block(float2_t P, float2_t Q, float2_t C2,
 __device__ __forceinline__ float2_t step8(float2_t Wv, float2_t Bq)
 {
 	return pk_add(pk_mul_M9(Wv, Bq), pk_mul_M10(Wv, Bq));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped arithmetic blocks: the same packed operations as the single-instruction helpers above, but several
+// independent chains per asm statement, interleaved so that dependent instructions are >= 4 issue slots apart.
+// One statement = one scheduling unit for hipcc: no per-instruction hazard pads, no register shuffling between
+// the operations of a butterfly.  Modifier sets (see LW_PK above): SUB, M1, M2, ...
+// ---------------------------------------------------------------------------------------------
+#define LW_M_SUB " neg_lo:[0,1] neg_hi:[0,1]"
+#define LW_M_M1 " op_sel:[0,0] op_sel_hi:[1,0]"
+#define LW_M_M2 " op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]"
+#define LW_M_M3 " op_sel:[0,1] op_sel_hi:[0,0]"
+#define LW_M_M4 " op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]"
+#define LW_M_M5 " op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]"
+#define LW_M_M6 " op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0]"
+#define LW_M_M7 " op_sel:[0,1] op_sel_hi:[1,1]"
+#define LW_M_M8 " op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[0,1]"
+#define LW_M_M9 " op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[1,0]"
+#define LW_M_M10 " op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
+#define LW_M_M12LO " op_sel:[0,1] op_sel_hi:[0,0]"
+#define LW_M_M12HI " op_sel:[1,1] op_sel_hi:[1,0]"
+#define LW_M_A2 " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+#define LW_M_A3 " op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]"
+#define LW_M_A4 " op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]"
+#define LW_M_A5 " op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]"
+#define LW_M_A6 " op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"
+#define LW_M_A7 " neg_hi:[0,1]"
+#define LW_M_A8 " neg_lo:[0,1]"
+#define LW_M_A9 " neg_lo:[0,1] neg_hi:[1,0]"
+#define LW_ADD(d, a, b, m) "v_pk_add_f32 " d ", " a ", " b m "\n\t"
+#define LW_MUL(d, a, b, m) "v_pk_mul_f32 " d ", " a ", " b m "\n\t"
+
+// four butterflies (imdct.rs:36-41 / :94-99 / :161-166): (H_i, L_i, t_i) in place
+__device__ __forceinline__ void bfly2x4(float2_t &H0, float2_t &L0, float2_t t0, float2_t &H1, float2_t &L1, float2_t t1,
+		float2_t &H2, float2_t &L2, float2_t t2, float2_t &H3, float2_t &L3, float2_t t3)
+{
+	float2_t K0, K1, K2, K3;
+	asm(LW_ADD("%8", "%0", "%1", LW_M_SUB) LW_ADD("%9", "%2", "%3", LW_M_SUB) LW_ADD("%10", "%4", "%5", LW_M_SUB) LW_ADD("%11", "%6", "%7", LW_M_SUB)
+	    LW_ADD("%0", "%0", "%1", "") LW_ADD("%2", "%2", "%3", "") LW_ADD("%4", "%4", "%5", "") LW_ADD("%6", "%6", "%7", "")
+	    LW_MUL("%1", "%8", "%12", LW_M_M1) LW_MUL("%3", "%9", "%13", LW_M_M1) LW_MUL("%5", "%10", "%14", LW_M_M1) LW_MUL("%7", "%11", "%15", LW_M_M1)
+	    LW_MUL("%8", "%8", "%12", LW_M_M2) LW_MUL("%9", "%9", "%13", LW_M_M2) LW_MUL("%10", "%10", "%14", LW_M_M2) LW_MUL("%11", "%11", "%15", LW_M_M2)
+	    LW_ADD("%1", "%1", "%8", "") LW_ADD("%3", "%3", "%9", "") LW_ADD("%5", "%5", "%10", "") LW_ADD("%7", "%7", "%11", "")
+	    : "+v"(H0), "+v"(L0), "+v"(H1), "+v"(L1), "+v"(H2), "+v"(L2), "+v"(H3), "+v"(L3), "=&v"(K0), "=&v"(K1), "=&v"(K2), "=&v"(K3)
+	    : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+}
+
+// step 1 (imdct.rs:337-371) of two float4 groups: X = (X0, X1, X2, X3) -> U (pair 511 - m, still on the mirror lane), P (pair m)
+__device__ __forceinline__ void step1x2(float4_t Xa, float2_t aua, float2_t ala, float4_t Xb, float2_t aub, float2_t alb,
+		float2_t &Ua, float2_t &Pa, float2_t &Ub, float2_t &Pb)
+{
+	float2_t Ta, Tb;
+	const float2_t Xa0 = float2_t{Xa.x, Xa.y}, Xa1 = float2_t{Xa.z, Xa.w}, Xb0 = float2_t{Xb.x, Xb.y}, Xb1 = float2_t{Xb.z, Xb.w};
+	asm(LW_MUL("%0", "%6", "%10", LW_M_M3) LW_MUL("%3", "%8", "%12", LW_M_M3)
+	    LW_MUL("%2", "%7", "%10", LW_M_M4) LW_MUL("%5", "%9", "%12", LW_M_M4)
+	    LW_MUL("%1", "%7", "%11", LW_M_M5) LW_MUL("%4", "%9", "%13", LW_M_M5)
+	    LW_ADD("%0", "%0", "%2", "") LW_ADD("%3", "%3", "%5", "")
+	    LW_MUL("%2", "%6", "%11", LW_M_M6) LW_MUL("%5", "%8", "%13", LW_M_M6)
+	    LW_ADD("%1", "%1", "%2", "") LW_ADD("%4", "%4", "%5", "")
+	    : "=&v"(Ua), "=&v"(Pa), "=&v"(Ta), "=&v"(Ub), "=&v"(Pb), "=&v"(Tb)
+	    : "v"(Xa0), "v"(Xa1), "v"(Xb0), "v"(Xb1), "v"(aua), "v"(ala), "v"(aub), "v"(alb));
+}
+
+// fused last three stages (imdct.rs:234-288) of one 16-float group, 28 packed operations, no register moves:
+// z4..z7 are updated in place, the new z0..z3 come out in fresh registers
+__device__ __forceinline__ void stage_d_block(float2_t a2, float2_t (&z)[8])
+{
+	float2_t n0, n1, n2, n3, t0, t1, t2, t3;
+	// %0-%3 = z4..z7 (in/out)   %4-%7 = n0..n3   %8-%11 = t0..t3   %12-%15 = z0..z3 (in)   %16 = a2
+	asm(// imdct.rs:240-275: pairs (7,3) (6,2) (5,1) (4,0); t0..t3 = the new z3, z2, z1, z0
+	    LW_ADD("%8", "%3", "%15", LW_M_SUB)     // t0 = z7 - z3
+	    LW_ADD("%9", "%2", "%14", LW_M_SUB)     // t1 = z6 - z2 = (k11, k00)
+	    LW_ADD("%10", "%13", "%1", LW_M_A3)     // t2 = A3(z1, z5)
+	    LW_ADD("%11", "%12", "%0", LW_M_A4)     // t3 = A4(z0, z4) = (k11, k00)
+	    LW_ADD("%3", "%3", "%15", "")           // z7 += z3
+	    LW_ADD("%2", "%2", "%14", "")           // z6 += z2
+	    LW_ADD("%1", "%1", "%13", "")           // z5 += z1
+	    LW_ADD("%0", "%0", "%12", "")           // z4 += z0
+	    LW_ADD("%9", "%9", "%9", LW_M_A2)
+	    LW_ADD("%11", "%11", "%11", LW_M_A5)
+	    // iter_54 (imdct.rs:202-232) on z[4..8)
+	    LW_ADD("%7", "%3", "%1", "")            // A  = z7 + z5
+	    LW_ADD("%6", "%2", "%0", "")            // Cc = z6 + z4
+	    LW_MUL("%9", "%9", "%16", "")           // t1 = new z2
+	    LW_MUL("%11", "%11", "%16", "")         // t3 = new z0
+	    LW_ADD("%5", "%3", "%1", LW_M_SUB)      // Bm = z7 - z5
+	    LW_ADD("%4", "%2", "%0", LW_M_SUB)      // Dm = z6 - z4
+	    LW_ADD("%3", "%7", "%6", "")            // z7 = A + Cc
+	    LW_ADD("%2", "%7", "%6", LW_M_SUB)      // z6 = A - Cc
+	    LW_ADD("%1", "%5", "%4", LW_M_A2)       // z5 = A2(Bm, Dm)
+	    LW_ADD("%0", "%5", "%4", LW_M_A6)       // z4 = A6(Bm, Dm)
+	    // iter_54 on the new z[0..4) = (t3, t2, t1, t0)
+	    LW_ADD("%5", "%8", "%10", LW_M_SUB)     // Bm = z3 - z1
+	    LW_ADD("%4", "%9", "%11", LW_M_SUB)     // Dm = z2 - z0
+	    LW_ADD("%8", "%8", "%10", "")           // A  = z3 + z1
+	    LW_ADD("%9", "%9", "%11", "")           // Cc = z2 + z0
+	    LW_ADD("%10", "%5", "%4", LW_M_A2)      // new z1 = A2(Bm, Dm)
+	    LW_ADD("%4", "%5", "%4", LW_M_A6)       // new z0 = A6(Bm, Dm)
+	    LW_ADD("%7", "%8", "%9", "")            // new z3 = A + Cc
+	    LW_ADD("%6", "%8", "%9", LW_M_SUB)      // new z2 = A - Cc
+	    : "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3),
+	      "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+	    : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "v"(a2));
+	z[3] = n3;
+	z[2] = n2;
+	z[1] = t2;
+	z[0] = n0;
+}
+
+// step 7 (imdct.rs:533-580) + step 8 (:589-658) of one m': (p511, pq, p255, pq256) -> R[0..4) = (pa, pb) at q = 511-2m', 510-2m', 1+2m', 2m'
+__device__ __forceinline__ void step78_block(float2_t p511, float2_t pq, float2_t p255, float2_t pq256, float4_t Cq, float4_t Bl, float4_t Bh,
+		float2_t (&R)[4])
+{
+	float2_t A1, B1, T1, A2, B2, T2;
+	const float2_t C0 = float2_t{Cq.x, Cq.y}, C1 = float2_t{Cq.z, Cq.w}, Bl0 = float2_t{Bl.x, Bl.y}, Bl1 = float2_t{Bl.z, Bl.w};
+	const float2_t Bh0 = float2_t{Bh.x, Bh.y}, Bh1 = float2_t{Bh.z, Bh.w};
+	asm(LW_ADD("%4", "%10", "%11", LW_M_A7) LW_ADD("%7", "%12", "%13", LW_M_A7)       // Aa = A7(P, Q)
+	    LW_ADD("%5", "%10", "%11", LW_M_A8) LW_ADD("%8", "%12", "%13", LW_M_A8)       // Bb = A8(P, Q)
+	    LW_MUL("%6", "%4", "%14", LW_M_M7) LW_MUL("%9", "%7", "%15", LW_M_M7)         // T = M7(Aa, C)
+	    LW_MUL("%4", "%4", "%14", LW_M_M8) LW_MUL("%7", "%7", "%15", LW_M_M8)         // Aa = M8(Aa, C)
+	    LW_ADD("%6", "%6", "%4", "") LW_ADD("%9", "%9", "%7", "")                     // Bv = T + Aa
+	    LW_ADD("%4", "%5", "%6", "") LW_ADD("%7", "%8", "%9", "")                     // Dn = Bb + Bv     (A1 = Dn1, A2 = Dn2)
+	    LW_ADD("%5", "%6", "%5", LW_M_A9) LW_ADD("%8", "%9", "%8", LW_M_A9)           // En = A9(Bv, Bb)  (B1 = En1, B2 = En2)
+	    LW_MUL("%6", "%4", "%16", LW_M_M9) LW_MUL("%9", "%7", "%17", LW_M_M9)         // step 8 of Dn1 / Dn2
+	    LW_MUL("%0", "%4", "%16", LW_M_M10) LW_MUL("%1", "%7", "%17", LW_M_M10)
+	    LW_ADD("%0", "%6", "%0", "") LW_ADD("%1", "%9", "%1", "")
+	    LW_MUL("%6", "%8", "%18", LW_M_M9) LW_MUL("%9", "%5", "%19", LW_M_M9)         // step 8 of En2 / En1
+	    LW_MUL("%2", "%8", "%18", LW_M_M10) LW_MUL("%3", "%5", "%19", LW_M_M10)
+	    LW_ADD("%2", "%6", "%2", "") LW_ADD("%3", "%9", "%3", "")
+	    : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(A1), "=&v"(B1), "=&v"(T1), "=&v"(A2), "=&v"(B2), "=&v"(T2)
+	    : "v"(p511), "v"(pq), "v"(p255), "v"(pq256), "v"(C0), "v"(C1), "v"(Bl0), "v"(Bl1), "v"(Bh0), "v"(Bh1));
+}
+
+// window + overlap-add (audio.rs:1116-1118) of the four pairs of one c2, optionally scaled by 32768 (samples.rs:92-103)
+template <bool SCALE>
+__device__ __forceinline__ void ola_block(const float2_t (&Rc)[4], float2_t pp0, float2_t pp1, float4_t w0, float4_t w1, float2_t (&O)[4])
+{
+	float2_t T0, T1;
+	const float2_t S0 = float2_t{w0.x, w0.y}, S1 = float2_t{w0.z, w0.w}, S2 = float2_t{w1.x, w1.y}, S3 = float2_t{w1.z, w1.w};
+	const float2_t k = float2_t{32768.0f, 32768.0f};
+	if (SCALE)
+		asm(LW_MUL("%0", "%6", "%12", LW_M_M4) LW_MUL("%1", "%7", "%13", LW_M_M4) LW_MUL("%2", "%8", "%14", LW_M_M4) LW_MUL("%3", "%9", "%15", LW_M_M4)
+		    LW_MUL("%4", "%10", "%12", LW_M_M12LO) LW_MUL("%5", "%10", "%13", LW_M_M12HI)
+		    LW_ADD("%0", "%0", "%4", "") LW_ADD("%1", "%1", "%5", "")
+		    LW_MUL("%4", "%11", "%14", LW_M_M12LO) LW_MUL("%5", "%11", "%15", LW_M_M12HI)
+		    LW_ADD("%2", "%2", "%4", "") LW_ADD("%3", "%3", "%5", "")
+		    LW_MUL("%0", "%0", "%16", "") LW_MUL("%1", "%1", "%16", "") LW_MUL("%2", "%2", "%16", "") LW_MUL("%3", "%3", "%16", "")
+		    : "=&v"(O[0]), "=&v"(O[1]), "=&v"(O[2]), "=&v"(O[3]), "=&v"(T0), "=&v"(T1)
+		    : "v"(Rc[0]), "v"(Rc[1]), "v"(Rc[2]), "v"(Rc[3]), "v"(pp0), "v"(pp1), "v"(S0), "v"(S1), "v"(S2), "v"(S3), "v"(k));
+	else
+		asm(LW_MUL("%0", "%6", "%12", LW_M_M4) LW_MUL("%1", "%7", "%13", LW_M_M4) LW_MUL("%2", "%8", "%14", LW_M_M4) LW_MUL("%3", "%9", "%15", LW_M_M4)
+		    LW_MUL("%4", "%10", "%12", LW_M_M12LO) LW_MUL("%5", "%10", "%13", LW_M_M12HI)
+		    LW_ADD("%0", "%0", "%4", "") LW_ADD("%1", "%1", "%5", "")
+		    LW_MUL("%4", "%11", "%14", LW_M_M12LO) LW_MUL("%5", "%11", "%15", LW_M_M12HI)
+		    LW_ADD("%2", "%2", "%4", "") LW_ADD("%3", "%3", "%5", "")
+		    : "=&v"(O[0]), "=&v"(O[1]), "=&v"(O[2]), "=&v"(O[3]), "=&v"(T0), "=&v"(T1)
+		    : "v"(Rc[0]), "v"(Rc[1]), "v"(Rc[2]), "v"(Rc[3]), "v"(pp0), "v"(pp1), "v"(S0), "v"(S1), "v"(S2), "v"(S3));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,44 +503,37 @@ __device__ __forceinline__ void stage_b(const LwFastArgs &F, const char *img, ui
 		float2_t (&P)[2][8])
 {
 	const uint32_t mirror = (63u - lane) << 2;
+	float2_t au[4], al[4];
 #pragma unroll
 	for (int x = 0; x < 4; x++) {
 		const uint32_t m = 64u * x + lane;
-		const float2_t au = lds2(img + LWI_APAIR, 8u * m);          // (A[2m], A[2m+1])
-		const float2_t al = lds2(img + LWI_APAIR, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			const float2_t Xa = float2_t{r[c][x].x, r[c][x].y}, Xb = float2_t{r[c][x].z, r[c][x].w};
-			const float2_t U = pk_add(pk_mul_M3(Xa, au), pk_mul_M4(Xb, au)); // pair 511 - m
-			P[c][x] = pk_add(pk_mul_M5(Xb, al), pk_mul_M6(Xa, al));          // pair m
-			P[c][7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.x)));
-			P[c][7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U.y)));
-		}
+		au[x] = lds2(img + LWI_APAIR, 8u * m);          // (A[2m], A[2m+1])
+		al[x] = lds2(img + LWI_APAIR, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
 	}
 #pragma unroll
-	for (int x = 0; x < 4; x++) {
-		const float2_t t = lds2(img + LWI_TW_S2, 8u * (64u * x + lane));
+	for (int c = 0; c < NCH; c++) {
+		float2_t U[4];
+		step1x2(r[c][0], au[0], al[0], r[c][1], au[1], al[1], U[0], P[c][0], U[1], P[c][1]);
+		step1x2(r[c][2], au[2], al[2], r[c][3], au[3], al[3], U[2], P[c][2], U[3], P[c][3]);
 #pragma unroll
-		for (int c = 0; c < NCH; c++)
-			bfly2(P[c][x + 4], P[c][x], t);
-	}
-#pragma unroll
-	for (int b = 0; b < 2; b++) {
-		const float2_t t = lds2(img + LWI_TW_L0, 8u * (64u * b + lane));
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			bfly2(P[c][2 + b], P[c][b], t);
-			bfly2(P[c][6 + b], P[c][4 + b], t);
+		for (int x = 0; x < 4; x++) { // pair 511 - m lives on the mirror lane
+			P[c][7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U[x].x)));
+			P[c][7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U[x].y)));
 		}
 	}
-	{
-		const float2_t t = lds2(img + LWI_TW_L1, 8u * lane);
+	float2_t s2[4], l0[2], l1;
 #pragma unroll
-		for (int c = 0; c < NCH; c++) {
+	for (int x = 0; x < 4; x++)
+		s2[x] = lds2(img + LWI_TW_S2, 8u * (64u * x + lane));
+	l0[0] = lds2(img + LWI_TW_L0, 8u * lane);
+	l0[1] = lds2(img + LWI_TW_L0, 8u * (64u + lane));
+	l1 = lds2(img + LWI_TW_L1, 8u * lane);
 #pragma unroll
-			for (int x = 1; x < 8; x += 2)
-				bfly2(P[c][x], P[c][x - 1], t);
-		}
+	for (int c = 0; c < NCH; c++) {
+		float2_t(&Q)[8] = P[c];
+		bfly2x4(Q[4], Q[0], s2[0], Q[5], Q[1], s2[1], Q[6], Q[2], s2[2], Q[7], Q[3], s2[3]); // step 2
+		bfly2x4(Q[2], Q[0], l0[0], Q[6], Q[4], l0[0], Q[3], Q[1], l0[1], Q[7], Q[5], l0[1]); // l = 0
+		bfly2x4(Q[1], Q[0], l1, Q[3], Q[2], l1, Q[5], Q[4], l1, Q[7], Q[6], l1);             // l = 1
 	}
 }
 
@@ -404,33 +559,22 @@ __device__ __forceinline__ void t2_read(const char *sc, uint32_t lane, float2_t 
 
 // ---- stages l = 2, 3, 4 (imdct.rs:454-477)
 template <int NCH>
-__device__ __forceinline__ void stage_c(const LwFastArgs &F, const char *img, uint32_t lane, float2_t (&Q)[2][8])
+__device__ __forceinline__ void stage_c(const LwFastArgs &F, const char *img, uint32_t lane, float2_t (&P)[2][8])
 {
 	const uint32_t lo3 = lane & 7u;
+	float2_t t2[4], t3[2], t4;
 #pragma unroll
-	for (int yy = 0; yy < 4; yy++) {
-		const float2_t t = lds2(img + LWI_TW_L2, 8u * (8u * yy + lo3));
+	for (int yy = 0; yy < 4; yy++)
+		t2[yy] = lds2(img + LWI_TW_L2, 8u * (8u * yy + lo3));
+	t3[0] = lds2(img + LWI_TW_L3, 8u * lo3);
+	t3[1] = lds2(img + LWI_TW_L3, 8u * (8u + lo3));
+	t4 = lds2(img + LWI_TW_L4, 8u * lo3);
 #pragma unroll
-		for (int c = 0; c < NCH; c++)
-			bfly2(Q[c][4 + yy], Q[c][yy], t);
-	}
-#pragma unroll
-	for (int b = 0; b < 2; b++) {
-		const float2_t t = lds2(img + LWI_TW_L3, 8u * (8u * b + lo3));
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			bfly2(Q[c][2 + b], Q[c][b], t);
-			bfly2(Q[c][6 + b], Q[c][4 + b], t);
-		}
-	}
-	{
-		const float2_t t = lds2(img + LWI_TW_L4, 8u * lo3);
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-#pragma unroll
-			for (int y = 1; y < 8; y += 2)
-				bfly2(Q[c][y], Q[c][y - 1], t);
-		}
+	for (int c = 0; c < NCH; c++) {
+		float2_t(&Q)[8] = P[c];
+		bfly2x4(Q[4], Q[0], t2[0], Q[5], Q[1], t2[1], Q[6], Q[2], t2[2], Q[7], Q[3], t2[3]); // l = 2
+		bfly2x4(Q[2], Q[0], t3[0], Q[6], Q[4], t3[0], Q[3], Q[1], t3[1], Q[7], Q[5], t3[1]); // l = 3
+		bfly2x4(Q[1], Q[0], t4, Q[3], Q[2], t4, Q[5], Q[4], t4, Q[7], Q[6], t4);             // l = 4
 	}
 }
 
@@ -511,14 +655,7 @@ __device__ __forceinline__ void stage_e(const char *sc, uint32_t lane, int c2, c
 	const uint32_t sb = 255u - sa;      // slot of pair 255 - 2v
 	const float2_t pq = lds2(sc, 8u * sa), pq256 = lds2(sc, 8u * (sa + 256u));   // (E3,E2), (E1,E0)
 	const float2_t p255 = lds2(sc, 8u * sb), p511 = lds2(sc, 8u * (sb + 256u));  // (D3,D2), (D1,D0)
-	float2_t Dn1, En1, Dn2, En2;
-	step7_block(p511, pq, float2_t{tw.Cq.x, tw.Cq.y}, Dn1, En1);    // (D1',D0'), (E3',E2')
-	step7_block(p255, pq256, float2_t{tw.Cq.z, tw.Cq.w}, Dn2, En2); // (D3',D2'), (E1',E0')
-	// step 8 (imdct.rs:618-657): q = 511-2m', 510-2m', 1+2m', 2m'
-	R[0] = step8(Dn1, float2_t{tw.Bl.x, tw.Bl.y});
-	R[1] = step8(Dn2, float2_t{tw.Bl.z, tw.Bl.w});
-	R[2] = step8(En2, float2_t{tw.Bh.x, tw.Bh.y});
-	R[3] = step8(En1, float2_t{tw.Bh.z, tw.Bh.w});
+	step78_block(p511, pq, p255, pq256, tw.Cq, tw.Bl, tw.Bh, R);
 }
 
 // ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private).
@@ -529,12 +666,14 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		const LwFastUnit &un, Pref &pf, float2_t (&R)[2][2][4], uint32_t sj LW_STAMP_ARGS)
 {
 	(void)sj;
+	LW_MARK("floor_table");
 	// ---- floor segment tables (1 KB each)
 	const bool unused0 = floor_table(F, img, sc, lane, pf.fe[0], un.floor_a, un.F_a);
 	bool unused1 = false;
 	if (NCH == 2)
 		unused1 = floor_table(F, img, sc + 1024, lane, pf.fe[1], un.floor_b, un.F_b);
 	lds_fence();
+	LW_MARK("decouple");
 	// ---- inverse coupling (audio.rs:762-777, :990-1002) on the raw residues
 	if (NCH == 2 && un.coupled) {
 #pragma unroll
@@ -550,6 +689,7 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 			}
 		}
 	}
+	LW_MARK("spectrum");
 	if (NCH == 2 && !unused0 && !unused1) {
 		spectrum_pair(img, sc, lane, un.floor_a, un.floor_b, pf.r);
 	} else {
@@ -559,9 +699,11 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 	}
 	lds_fence();
 	LW_STAMP(4);
+	LW_MARK("stage_b");
 	float2_t P[2][8];
 	stage_b<NCH>(F, img, lane, pf.r, P);
 	LW_STAMP(5);
+	LW_MARK("t2");
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T2
 		t2_write(sc, lane, P[c]);
@@ -569,8 +711,10 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		t2_read(sc, lane, P[c]);
 		lds_fence();
 	}
+	LW_MARK("stage_c");
 	stage_c<NCH>(F, img, lane, P);
 	LW_STAMP(6);
+	LW_MARK("t3");
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T3
 		t3_write(sc, lane, P[c]);
@@ -578,14 +722,16 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		t3_read(sc, lane, P[c]);
 		lds_fence();
 	}
+	LW_MARK("stage_d");
 	{
 		const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
 		const float2_t a2 = float2_t{a2s, a2s};
 #pragma unroll
 		for (int c = 0; c < NCH; c++)
-			stage_d(a2, P[c]);
+			stage_d_block(a2, P[c]);
 	}
 	LW_STAMP(7);
+	LW_MARK("t4_stage_e");
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T4 + layout E
 		t4_write(sc, lane, P[c]);
@@ -601,6 +747,7 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		lds_fence();
 	}
 	LW_STAMP(8);
+	LW_MARK("phase1_end");
 }
 
 // ---- publish the un-windowed right half for the successor ([channel][c2][lane] float4)
@@ -651,19 +798,13 @@ template <int FMT>
 __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, uint32_t lane, int chn,
 		uint32_t out_off, const float2_t (&Rc)[2][4], const PrevHalf &h)
 {
-	// (out[q], out[1023-q]) = (pa s[q] + pb' s[r], -pa s[r] + pb' s[q])
+	// (out[q], out[1023-q]) = (pa s[q] + pb' s[r], -pa s[r] + pb' s[q]), times 32768 for the i16 formats
 	float2_t O[2][4];
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) {
 		const float4_t w0 = lds4(img + LWI_WIN, 32u * (64u * c2 + lane));
 		const float4_t w1 = lds4(img + LWI_WIN, 32u * (64u * c2 + lane) + 16u);
-		const float2_t S2[4] = {float2_t{w0.x, w0.y}, float2_t{w0.z, w0.w}, float2_t{w1.x, w1.y}, float2_t{w1.z, w1.w}};
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const float2_t o1 = pk_mul_M4(Rc[c2][k], S2[k]); // (pa s[q], -pa s[r])
-			const float2_t o2 = (k & 1) ? pk_mul_M12hi(h.pp[c2][k >> 1], S2[k]) : pk_mul_M12lo(h.pp[c2][k >> 1], S2[k]);
-			O[c2][k] = pk_add(o1, o2);
-		}
+		ola_block<FMT != LW_OUT_F32_PLANAR>(Rc[c2], h.pp[c2][0], h.pp[c2][1], w0, w1, O[c2]);
 	}
 	// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [508-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
 	//            [512+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [1020-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
@@ -677,15 +818,13 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 	} else {
 		// samples.rs:92-103: x*32768, truncate toward zero (v_cvt_i32_f32: saturating, NaN -> 0), clamp to
 		// i16 by the saturating pack v_cvt_pk_i16_i32 -- equal to the reference's compare/clamp/`as i16`
-		const float2_t k32768 = float2_t{32768.0f, 32768.0f};
 		int iq[2][4], im[2][4];
 #pragma unroll
 		for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				const float2_t t = pk_mul(O[c2][k], k32768);
-				iq[c2][k] = (int)t.x;
-				im[c2][k] = (int)t.y;
+				iq[c2][k] = (int)O[c2][k].x;
+				im[c2][k] = (int)O[c2][k].y;
 			}
 		if (FMT == LW_OUT_I16_PLANAR) {
 			typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -855,6 +994,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	// predecessor waves: same round (slot > 0) / previous round (slot == 0)
 	const uint32_t wprev = slot != 0 ? wave - n_units : (per_round - 1) * n_units + uidx;
 
+	LW_MARK("loop");
 	for (uint32_t j = 0; j < rounds; j++) {
 		sj = j;
 		// launder the lane id once per round: everything derived from it (LDS addresses, bin numbers as floats) is
@@ -892,6 +1032,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
 					}
 			} else {
+				LW_MARK("publish");
 				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
 				if (it.flags & LW_IF_NEXT_LDS) {
 					lds_wait_ge(&ackcnt[wave], n_pub_used);
@@ -903,6 +1044,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 					n_pub_used++;
 					pubcnt[wave] = n_pub_used;
 				}
+				LW_MARK("phase2");
 				// ---- the previous packet's right half: from my predecessor wave through LDS, or (chunk starts) from the
 				//      stream's state slot / the halo buffer / a generic predecessor's time-domain block; then window,
 				//      overlap-add, conversion and stores, one channel at a time (register pressure)
@@ -941,6 +1083,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						ackcnt[wprev] = n_got;
 					}
 				}
+				LW_MARK("state_out");
 				// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
 				const bool to_state = it.state_out >= 0, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
 				if (to_state || to_td) {
@@ -959,6 +1102,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 				}
 			}
 		}
+		LW_MARK("round_end");
 		LW_STAMP_NW(10);
 		// ---- HBM loads of the next round
 		if (valid_n) {
