@@ -666,6 +666,7 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		const LwFastUnit &un, Pref &pf, float2_t (&R)[2][2][4], uint32_t sj LW_STAMP_ARGS)
 {
 	(void)sj;
+#ifndef LW_EXP_NOFLOOR
 	LW_MARK("floor_table");
 	// ---- floor segment tables (1 KB each)
 	const bool unused0 = floor_table(F, img, sc, lane, pf.fe[0], un.floor_a, un.F_a);
@@ -698,12 +699,14 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 			spectrum(F, img, sc + 1024, lane, un.floor_b, unused1, pf.r[1]);
 	}
 	lds_fence();
+#endif
 	LW_STAMP(4);
 	LW_MARK("stage_b");
 	float2_t P[2][8];
 	stage_b<NCH>(F, img, lane, pf.r, P);
 	LW_STAMP(5);
 	LW_MARK("t2");
+#ifndef LW_EXP_NOTRANSPOSE
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T2
 		t2_write(sc, lane, P[c]);
@@ -711,10 +714,12 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		t2_read(sc, lane, P[c]);
 		lds_fence();
 	}
+#endif
 	LW_MARK("stage_c");
 	stage_c<NCH>(F, img, lane, P);
 	LW_STAMP(6);
 	LW_MARK("t3");
+#ifndef LW_EXP_NOTRANSPOSE
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T3
 		t3_write(sc, lane, P[c]);
@@ -722,6 +727,7 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		t3_read(sc, lane, P[c]);
 		lds_fence();
 	}
+#endif
 	LW_MARK("stage_d");
 	{
 		const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
@@ -972,15 +978,16 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	__syncthreads();
 	LW_STAMP_NW(2);
 	if (!RIGHT_ONLY && F.late_from < LW_FAST_WAVES) {
-		// pace the HBM queue: the late half of the waves issues its loads when the early half's data has landed,
-		// so that the early half computes while the late half's data is in flight
-		if (!late) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			landed[wave] = 1u;
-		} else {
+		// pace the HBM queue in groups of late_from waves: a group issues its loads when the data of the group before
+		// it has landed, so that the earlier groups compute while the later groups' data is in flight
+		if (late) {
 			lds_wait_ge(&landed[wave - F.late_from], 1u);
 			if (valid)
 				issue_loads(F, it, un, lane_id, pf);
+		}
+		if (wave + F.late_from < LW_FAST_WAVES) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			landed[wave] = 1u;
 		}
 	}
 	if (valid && F.dense)

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -103,7 +104,8 @@ struct lw_batch {
 	float *d_halo = nullptr;
 	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
-	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = LW_FAST_WAVES / 2;
+	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = LW_FAST_WAVES / 4;
+	// (debug: LW_PACE_GROUP=<waves per pacing group> overrides)
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
 	bool has_generic = false, has_fast = false, force_generic = false;
@@ -1019,6 +1021,8 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.rounds = b->fast_rounds;
 		L.dense = b->fast_dense;
 		L.late_from = b->fast_late_from;
+		if (const char *e = getenv("LW_PACE_GROUP"))
+			L.late_from = (uint32_t)atoi(e);
 		for (size_t i = 0; i < d->fast.units.size() && i < LW_FAST_WAVES; i++)
 			L.units[i] = d->fast.units[i];
 		L.d_halo = b->d_halo;
