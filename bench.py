@@ -139,10 +139,8 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from lewton_amd import shard
+    elapsed = shard.max_elapsed(elapsed, dist if world > 1 else None, "cuda")
     # device time of the K steps on the launch stream (HIP events), per step
     launch_ms = ev0.elapsed_time(ev1) / args.steps
 
@@ -189,6 +187,15 @@ def main():
                "sample": "%d stereo long packets (same generator as the GPU workload), oracle/lewton_oracle.c "
                          "(C restatement of lewton incl. entropy decode), 1 thread, %.1f s" % (npk, secs)}
 
+    # HBM traffic of one launch from the PMC passes (tools/pmc.sh -> profiles/): measured in separate rocprofv3 runs of
+    # this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; null if no profile is committed
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        traffic = pm.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+
     if rank == 0:
         total_packets = args.steps * PACKETS_PER_BATCH * world
         value = total_packets / elapsed
@@ -214,7 +221,8 @@ def main():
                        "output": "i16 planar", "kernels": kernels, "parity": parity,
                        "parallelism": "streams sharded across GPUs, no collectives"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_summary.json)",
                          "kernel": kernels, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }

@@ -899,7 +899,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
 		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
-		const uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
+		uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
+		if (const char *e = getenv("LW_FAST_ROUNDS")) // test hook: force the number of rounds per workgroup
+			rounds = (uint32_t)std::min(LW_FAST_MAX_ROUNDS, std::max(1, atoi(e)));
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
 		b->fast_rounds = rounds;

@@ -256,6 +256,29 @@ def test_long_block_kernel_equals_generic_kernels_many_streams():
         assert np.array_equal(pw_a[s].data().view(np.uint32), pw_b[s].data().view(np.uint32))
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 3, 5])
+@pytest.mark.parametrize("name", ["stereo", "surround51"])
+def test_long_block_kernel_rounds_and_handover(name, rounds, monkeypatch):
+    """The specialised kernel with a forced number of rounds per workgroup: right halves travel through LDS inside a
+    round, across rounds, through the halo pre-pass at chunk boundaries and through the state pool; streams of
+    different lengths so that chunks start and end in the middle of streams.  Bit-exact vs the oracle per stream."""
+    monkeypatch.setenv("LW_FAST_ROUNDS", str(rounds))
+    setup = SETUPS[name]()
+    lens = [1, 2, 5, 16, 17, 33, 40, 7]
+    streams = [sg.make_stream(setup, "L", n + 1, seed=900 + i) for i, n in enumerate(lens)]
+    items = [(p, s) for s, st in enumerate(streams) for p in st]
+    got, b, _ = _decode_batch(setup, items, "i16")
+    assert "k_long" in b.last_kernels
+    o_id, o_st = oracle_headers(setup)
+    k = 0
+    for s, st in enumerate(streams):
+        opw = po.Pwr()
+        for p in st:
+            want = po.read_audio_packet(o_id, o_st, p, opw, "i16")
+            assert got[k].shape == want.shape and np.array_equal(got[k], want), (s, k)
+            k += 1
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[1] size (4096 stereo long packets): checksum-of-checksums equality between the two kernel
     families, plus idempotence of re-launching an uploaded batch."""
