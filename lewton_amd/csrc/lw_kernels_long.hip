@@ -658,6 +658,124 @@ __device__ __forceinline__ void stage_e(const char *sc, uint32_t lane, int c2, c
 	step78_block(p511, pq, p255, pq256, tw.Cq, tw.Bl, tw.Bh, R);
 }
 
+// ---- per-channel pieces of the stages with the twiddles passed in (shared by the two channels of a pair)
+struct TwB {
+	float2_t au[4], al[4], s2[4], l0[2], l1;
+};
+struct TwC {
+	float2_t t2[4], t3[2], t4;
+};
+
+__device__ __forceinline__ void load_tw_b(const char *img, uint32_t lane, TwB &t)
+{
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		const uint32_t m = 64u * x + lane;
+		t.au[x] = lds2(img + LWI_APAIR, 8u * m);          // (A[2m], A[2m+1])
+		t.al[x] = lds2(img + LWI_APAIR, 8u * (511u - m)); // (A[1022-2m], A[1023-2m])
+		t.s2[x] = lds2(img + LWI_TW_S2, 8u * (64u * x + lane));
+	}
+	t.l0[0] = lds2(img + LWI_TW_L0, 8u * lane);
+	t.l0[1] = lds2(img + LWI_TW_L0, 8u * (64u + lane));
+	t.l1 = lds2(img + LWI_TW_L1, 8u * lane);
+}
+
+__device__ __forceinline__ void load_tw_c(const char *img, uint32_t lane, TwC &t)
+{
+	const uint32_t lo3 = lane & 7u;
+#pragma unroll
+	for (int yy = 0; yy < 4; yy++)
+		t.t2[yy] = lds2(img + LWI_TW_L2, 8u * (8u * yy + lo3));
+	t.t3[0] = lds2(img + LWI_TW_L3, 8u * lo3);
+	t.t3[1] = lds2(img + LWI_TW_L3, 8u * (8u + lo3));
+	t.t4 = lds2(img + LWI_TW_L4, 8u * lo3);
+}
+
+// step 1 + mirror exchange + step 2 + stages l = 0, 1 of one channel
+__device__ __forceinline__ void stage_b1(const TwB &t, uint32_t lane, const float4_t (&r)[4], float2_t (&Q)[8])
+{
+	const uint32_t mirror = (63u - lane) << 2;
+	float2_t U[4];
+	step1x2(r[0], t.au[0], t.al[0], r[1], t.au[1], t.al[1], U[0], Q[0], U[1], Q[1]);
+	step1x2(r[2], t.au[2], t.al[2], r[3], t.au[3], t.al[3], U[2], Q[2], U[3], Q[3]);
+#pragma unroll
+	for (int x = 0; x < 4; x++) { // pair 511 - m lives on the mirror lane
+		Q[7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U[x].x)));
+		Q[7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U[x].y)));
+	}
+	bfly2x4(Q[4], Q[0], t.s2[0], Q[5], Q[1], t.s2[1], Q[6], Q[2], t.s2[2], Q[7], Q[3], t.s2[3]); // step 2
+	bfly2x4(Q[2], Q[0], t.l0[0], Q[6], Q[4], t.l0[0], Q[3], Q[1], t.l0[1], Q[7], Q[5], t.l0[1]); // l = 0
+	bfly2x4(Q[1], Q[0], t.l1, Q[3], Q[2], t.l1, Q[5], Q[4], t.l1, Q[7], Q[6], t.l1);             // l = 1
+}
+
+__device__ __forceinline__ void stage_c1(const TwC &t, float2_t (&Q)[8])
+{
+	bfly2x4(Q[4], Q[0], t.t2[0], Q[5], Q[1], t.t2[1], Q[6], Q[2], t.t2[2], Q[7], Q[3], t.t2[3]); // l = 2
+	bfly2x4(Q[2], Q[0], t.t3[0], Q[6], Q[4], t.t3[0], Q[3], Q[1], t.t3[1], Q[7], Q[5], t.t3[1]); // l = 3
+	bfly2x4(Q[1], Q[0], t.t4, Q[3], Q[2], t.t4, Q[5], Q[4], t.t4, Q[7], Q[6], t.t4);             // l = 4
+}
+
+__device__ __forceinline__ void stage_e1(const char *img, const char *sc, uint32_t lane, float2_t (&Rc)[2][4])
+{
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) {
+		TwidE te;
+		te.Cq = lds4(img + LWI_C4, 16u * (64u * c2 + lane));
+		te.Bl = lds4(img + LWI_B_LO, 16u * (64u * c2 + lane));
+		te.Bh = lds4(img + LWI_B_HI, 16u * (64u * c2 + lane));
+		stage_e(sc, lane, c2, te, Rc[c2]);
+	}
+}
+
+// ---- the IMDCT of a channel pair as one software pipeline through ONE 4 KB transpose buffer (LDS operations of a
+//      wave execute in order): while channel 0's transposed data is on its way back from LDS, channel 1's
+//      butterflies issue, and vice versa:
+//        B0 W2_0 R2_0 | B1 W2_1 R2_1 | C0 W3_0 R3_0 | C1 W3_1 R3_1 | D0 W4_0 E0 | D1 W4_1 E1
+//      (sched_barrier pins this order; without it the scheduler moves each consumer right behind its loads)
+__device__ __forceinline__ void imdct_pair(const char *img, char *sc, uint32_t lane, const float4_t (&r)[2][4],
+		float2_t (&R)[2][2][4])
+{
+	float2_t P0[8], P1[8];
+	{
+		TwB tb;
+		load_tw_b(img, lane, tb);
+		stage_b1(tb, lane, r[0], P0);
+		t2_write(sc, lane, P0);
+		__builtin_amdgcn_sched_barrier(0);
+		t2_read(sc, lane, P0);
+		stage_b1(tb, lane, r[1], P1);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	TwC tc;
+	load_tw_c(img, lane, tc);
+	t2_write(sc, lane, P1);
+	__builtin_amdgcn_sched_barrier(0);
+	t2_read(sc, lane, P1);
+	stage_c1(tc, P0);
+	__builtin_amdgcn_sched_barrier(0);
+	t3_write(sc, lane, P0);
+	__builtin_amdgcn_sched_barrier(0);
+	t3_read(sc, lane, P0);
+	stage_c1(tc, P1);
+	__builtin_amdgcn_sched_barrier(0);
+	const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
+	const float2_t a2 = float2_t{a2s, a2s};
+	t3_write(sc, lane, P1);
+	__builtin_amdgcn_sched_barrier(0);
+	t3_read(sc, lane, P1);
+	stage_d_block(a2, P0);
+	__builtin_amdgcn_sched_barrier(0);
+	t4_write(sc, lane, P0);
+	__builtin_amdgcn_sched_barrier(0);
+	stage_e1(img, sc, lane, R[0]);
+	stage_d_block(a2, P1);
+	__builtin_amdgcn_sched_barrier(0);
+	t4_write(sc, lane, P1);
+	__builtin_amdgcn_sched_barrier(0);
+	stage_e1(img, sc, lane, R[1]);
+	__builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private).
 // Both channels of a pair advance through the stages together (shared twiddles); their transposes go through
 // ONE 4 KB buffer one after the other (LDS operations of a wave execute in order).
@@ -701,6 +819,11 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 	lds_fence();
 #endif
 	LW_STAMP(4);
+	if (NCH == 2) {
+		imdct_pair(img, sc, lane, pf.r, R);
+		LW_STAMP(8);
+		return;
+	}
 	LW_MARK("stage_b");
 	float2_t P[2][8];
 	stage_b<NCH>(F, img, lane, pf.r, P);
@@ -839,6 +962,12 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 				uint32_t u;
 			} a, b;
 			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn * 1024u;
+#ifdef LW_EXP_NOSTORE // experiment: keep the conversion, drop the HBM writes (never-true runtime condition)
+			if (F.n_items != 0xFFFFFFFFu)
+				o = nullptr;
+			if (o)
+#endif
+			{
 			a.s = __builtin_amdgcn_cvt_pk_i16(iq[0][3], iq[0][2]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(iq[1][3], iq[1][2]);
 			*reinterpret_cast<uint2_t *>(o + p0) = uint2_t{a.u, b.u};
@@ -851,6 +980,7 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 			a.s = __builtin_amdgcn_cvt_pk_i16(im[1][2], im[1][3]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(im[0][2], im[0][3]);
 			*reinterpret_cast<uint2_t *>(o + p3) = uint2_t{a.u, b.u};
+			}
 		} else {
 			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn;
 			const int g0[4] = {iq[0][3], iq[0][2], iq[1][3], iq[1][2]}, g1[4] = {iq[1][1], iq[1][0], iq[0][1], iq[0][0]};
