@@ -59,8 +59,9 @@ struct LwFastUnit {
 	uint8_t coupled;    // (ch_a = magnitude, ch_b = angle) form a coupling step
 	uint8_t floor_a, floor_b; // staged floor slot (0 / 1) of each channel
 	uint8_t F_a, F_b;   // floor-1 post count of each channel (<= 64)
-	uint8_t pad;
+	uint8_t slot;       // kernel argument copy only: packet slot of the wave inside a round (0xFF = idle wave)
 };
+static_assert(sizeof(LwFastUnit) == 8, "LwFastUnit is loaded as one 8-byte scalar");
 
 struct LwFastPlan {
 	bool eligible = false;

@@ -27,6 +27,8 @@
 // Arithmetic contract: identical to lw_kernels.hip -- same f32 operations on the same operands as the
 // reference, compiled with -ffp-contract=off.  The floor curve uses trunc((t*dy +- 0.5) * (1/adx)), proven
 // equal to the reference's integer render_line for every reachable segment (tests/test_fast_model.py).
+#include <cstddef>
+
 #include "lw_fast.hpp"
 #include "lw_kernels.hpp"
 
@@ -36,24 +38,26 @@
 #define LW_LDS_BYTES (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES) + 3 * LW_FAST_WAVES * 4)
 
 struct LwFastArgs {
-	const uint8_t *image;      // LDS image in HBM (LWI_TOTAL bytes)
-	const LwFastItem *items;   // work list in stream-sorted order
-	LwFastUnit units[LW_FAST_WAVES]; // read with compile-time indices only (no scratch copy, no dependent load)
+	// hot scalars first: everything the first HBM loads depend on sits in the first kernel-argument cache lines
 	const float *residue;      // batch arrays (lw_records.h)
 	const uint16_t *floors;
-	float *state;              // state pool [slots][2][ch][n1/2]
-	float *td;                 // time-domain blocks of the generic kernels
-	float *halo;               // [slots][ch][512]
-	void *out;
 	uint32_t n_items;
 	uint32_t n_units;
 	uint32_t per_round;        // packets per workgroup and round (<= LW_FAST_WAVES / n_units)
 	uint32_t rounds;           // rounds per workgroup
 	uint32_t dense;            // item k of the list is packet k and every packet block has the same size
-	uint32_t late_from;        // waves >= late_from issue their first HBM loads after staging the tables
+	uint32_t late_from;        // pacing group size: wave w issues its first HBM loads when wave w - late_from has its data
 	uint32_t ch, fstride;      // channels, u16 entries per channel in a floor block
+	LwFastUnit waves[LW_FAST_WAVES]; // per wave: its unit and packet slot (one 8-byte scalar load at kernarg + 48 + 8 * wave)
+	const uint8_t *image;      // LDS image in HBM (LWI_TOTAL bytes)
+	const LwFastItem *items;   // work list in stream-sorted order
+	float *state;              // state pool [slots][2][ch][n1/2]
+	float *td;                 // time-domain blocks of the generic kernels
+	float *halo;               // [slots][ch][512]
+	void *out;
 	uint32_t state_stride, state_chan_stride;
 };
+static_assert(offsetof(LwFastArgs, waves) == 48, "kernel reads waves[] through the kernarg segment pointer");
 
 #ifdef LW_STAMPS
 // Debug build: s_memtime stamps collected in two VGPRs (lane i = stamp i) and stored once at the end of the kernel,
@@ -1051,14 +1055,24 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	const uint32_t lane_id = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t n_units = F.n_units, per_round = F.per_round, rounds = F.rounds;
-	const uint32_t slot = wave / n_units, uidx = wave - slot * n_units; // packet slot of the round, unit of the packet
+	// pull every scalar the first HBM loads depend on into SGPRs with ONE batch of kernel-argument loads (the compiler
+	// would otherwise load them one by one, each behind its own s_waitcnt, on the critical path to the first load)
+	asm volatile("" ::"s"(F.residue), "s"(F.floors), "s"(F.n_items), "s"(n_units), "s"(per_round), "s"(rounds), "s"(F.dense),
+			"s"(F.late_from), "s"(F.ch), "s"(F.fstride), "s"(F.image));
+	// this wave's unit and packet slot: one 8-byte scalar load from the kernel-argument segment
+	LwFastUnit un;
+#if defined(__HIP_DEVICE_COMPILE__)
+	{
+		typedef const unsigned long long __attribute__((address_space(4))) *ka_ptr;
+		const unsigned long long w = ((ka_ptr)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(LwFastArgs, waves) / 8 + wave];
+		__builtin_memcpy(&un, &w, 8);
+	}
+#else
+	un = F.waves[0];
+#endif
+	const uint32_t slot = un.slot, uidx = wave - slot * n_units; // packet slot of the round, unit of the packet
 	const bool active = slot < per_round;
 	const uint32_t item0 = blockIdx.x * per_round * rounds + slot;      // item of round j = item0 + j * per_round
-	LwFastUnit un = F.units[0];
-#pragma unroll
-	for (int i = 1; i < LW_FAST_WAVES; i++)
-		if (uidx == (uint32_t)i)
-			un = F.units[i];
 #ifdef LW_EXP_STEREO_ONLY // instruction-count experiments: only the two-channel path is compiled
 	const bool two = true;
 #else
@@ -1278,8 +1292,10 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 	F.halo = L.d_halo;
 	F.out = out;
 	const size_t lds = LW_LDS_BYTES;
-	for (uint32_t i = 0; i < LW_FAST_WAVES; i++)
-		F.units[i] = L.units[i < L.n_units ? i : 0];
+	for (uint32_t w = 0; w < LW_FAST_WAVES; w++) {
+		F.waves[w] = L.units[w % L.n_units];
+		F.waves[w].slot = (uint8_t)(w / L.n_units);
+	}
 	F.late_from = 0xFFFFFFFFu;
 	static bool attr_done = false;
 	if (!attr_done) {
