@@ -1054,11 +1054,16 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const uint32_t lane_id = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint32_t sj = 0;
+	(void)sj;
+	LW_STAMP_DECL;
+	LW_STAMP_NW(0);
 	const uint32_t n_units = F.n_units, per_round = F.per_round, rounds = F.rounds;
 	// pull every scalar the first HBM loads depend on into SGPRs with ONE batch of kernel-argument loads (the compiler
 	// would otherwise load them one by one, each behind its own s_waitcnt, on the critical path to the first load)
 	asm volatile("" ::"s"(F.residue), "s"(F.floors), "s"(F.n_items), "s"(n_units), "s"(per_round), "s"(rounds), "s"(F.dense),
 			"s"(F.late_from), "s"(F.ch), "s"(F.fstride), "s"(F.image));
+	LW_STAMP_NW(12);
 	// this wave's unit and packet slot: one 8-byte scalar load from the kernel-argument segment
 	LwFastUnit un;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1080,10 +1085,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 #endif
 	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
 	const bool late = !RIGHT_ONLY && wave >= F.late_from;
-	uint32_t sj = 0;
-	(void)sj;
-	LW_STAMP_DECL;
-	LW_STAMP_NW(0);
+	LW_STAMP_NW(13);
 
 	volatile uint32_t *pubcnt = reinterpret_cast<volatile uint32_t *>(smem + LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES));
 	volatile uint32_t *ackcnt = pubcnt + LW_FAST_WAVES;
@@ -1092,32 +1094,37 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	LwFastItem it{};
 	Pref pf{};
 	bool valid = active && item0 < F.n_items;
+#ifdef LW_EXP_ACTIVE_WAVES // experiment: only the first K waves of every workgroup work
+	valid = valid && wave < LW_EXP_ACTIVE_WAVES;
+#endif
 	if (valid) {
 		if (F.dense)
 			dense_offsets(F, item0, it);
 		else
 			it = load_item(F.items, item0);
 	}
-	{
-		uint32_t lane = lane_id;
-		const uint4 *src = reinterpret_cast<const uint4 *>(F.image) + threadIdx.x;
-		uint4 *dst = reinterpret_cast<uint4 *>(smem) + threadIdx.x;
+	// Waves 0-3 (the first pacing group) only queue their HBM loads; waves 4-15 stage the table image (1536 x 16 bytes =
+	// 2 per thread, no tail) and clear the hand-over counters.  A wave that waits for image data therefore never has
+	// residue loads in flight (s_waitcnt vmcnt counts in order), and the first group's loads are issued ~1 us after launch.
+	static_assert(LWI_TOTAL / 16 == 2 * (LW_WG - 256), "image staging: 12 waves x 2 x 16 bytes per thread");
+	if (wave < 4) {
+		LW_STAMP_NW(14);
 		if (valid && !late)
-			issue_loads(F, it, un, lane, pf);
-		lds_fence();
-		static_assert(LWI_TOTAL / 16 > LW_WG && LWI_TOTAL / 16 <= 2 * LW_WG && (LWI_TOTAL / 16 - LW_WG) % 64 == 0, "image staging");
-		const bool second = wave < (LWI_TOTAL / 16 - LW_WG) / 64; // wave-uniform
-		const uint4 v0 = src[0];
-		uint4 v1 = v0;
-		if (second)
-			v1 = src[LW_WG];
-		LW_STAMP_NW(1);
-		if (threadIdx.x < 3 * LW_FAST_WAVES)
-			pubcnt[threadIdx.x] = 0u;
+			issue_loads(F, it, un, lane_id, pf);
+		LW_STAMP_NW(15);
+	} else {
+		const uint32_t t = threadIdx.x - 256u;
+		const uint4 *src = reinterpret_cast<const uint4 *>(F.image) + t;
+		uint4 *dst = reinterpret_cast<uint4 *>(smem) + t;
+		const uint4 v0 = src[0], v1 = src[LW_WG - 256];
+		if (t < 3 * LW_FAST_WAVES)
+			pubcnt[t] = 0u;
 		dst[0] = v0;
-		if (second)
-			dst[LW_WG] = v1;
+		dst[LW_WG - 256] = v1;
+		LW_STAMP_NW(1);
 		lds_fence();
+		if (valid && !late)
+			issue_loads(F, it, un, lane_id, pf);
 	}
 	__syncthreads();
 	LW_STAMP_NW(2);

@@ -59,7 +59,7 @@ for rep in range(6):
     if rep < 2:
         continue
     print("rep %d: kernel(event) %.1f us, waves stamped %d" % (rep, ms * 1e3, len(a)))
-    names = [(0, "entry"), (1, "loads issued"), (2, "image+sync"), (3, "r0 residue landed"), (4, "r0 floor+spec"),
+    names = [(0, "entry"), (12, "kernargs in SGPRs"), (13, "unit loaded"), (14, "before issue_loads"), (15, "after issue_loads"), (1, "image loads issued"), (2, "image+sync"), (3, "r0 residue landed"), (4, "r0 floor+spec"),
              (5, "r0 stage B"), (6, "r0 stage C"), (7, "r0 stage D"), (8, "r0 stage E"), (9, "r0 handover done"), (10, "r0 phase2 issued"),
              (19, "r1 residue landed"), (20, "r1 floor+spec"), (21, "r1 stage B"), (22, "r1 stage C"), (23, "r1 stage D"),
              (24, "r1 stage E"), (25, "r1 handover"), (26, "r1 phase2 issued"), (59, "all stores done")]
