@@ -789,6 +789,9 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 {
 	(void)sj;
 #ifndef LW_EXP_NOFLOOR
+#ifndef LW_EXP_NOPRIO
+	__builtin_amdgcn_s_setprio(2); // latency-bound phase (LDS round trips, few VALU): issue ahead of waves in the IMDCT
+#endif
 	LW_MARK("floor_table");
 	// ---- floor segment tables (1 KB each)
 	const bool unused0 = floor_table(F, img, sc, lane, pf.fe[0], un.floor_a, un.F_a);
@@ -821,6 +824,9 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 			spectrum(F, img, sc + 1024, lane, un.floor_b, unused1, pf.r[1]);
 	}
 	lds_fence();
+#endif
+#ifndef LW_EXP_NOPRIO
+	__builtin_amdgcn_s_setprio(0);
 #endif
 	LW_STAMP(4);
 	if (NCH == 2) {
@@ -1190,6 +1196,9 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
 					}
 			} else {
+#ifndef LW_EXP_NOPRIO
+				__builtin_amdgcn_s_setprio(3); // finish: hand-over, overlap-add, stores
+#endif
 				LW_MARK("publish");
 				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
 				if (it.flags & LW_IF_NEXT_LDS) {
@@ -1260,6 +1269,9 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 				}
 			}
 		}
+#ifndef LW_EXP_NOPRIO
+		__builtin_amdgcn_s_setprio(0);
+#endif
 		LW_MARK("round_end");
 		LW_STAMP_NW(10);
 		// ---- HBM loads of the next round
