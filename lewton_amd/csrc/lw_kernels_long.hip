@@ -33,6 +33,16 @@
 #include "lw_kernels.hpp"
 
 #define LW_WG (64 * LW_FAST_WAVES)
+// wave priorities (s_setprio 0..3) of the three kinds of phases; measured on MI355X (tools/exp.sh)
+#ifndef LW_PRIO_FLOOR
+#define LW_PRIO_FLOOR 2
+#endif
+#ifndef LW_PRIO_IMDCT
+#define LW_PRIO_IMDCT 0
+#endif
+#ifndef LW_PRIO_FINISH
+#define LW_PRIO_FINISH 3
+#endif
 #define LW_SCR_BYTES 4096u // per wave: transposes of one channel at a time / 2 x 1 KB floor segment tables
 #define LW_PUB_BYTES 4096u // per wave: published right half [2 channels][2][64] float4
 #define LW_LDS_BYTES (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES) + 3 * LW_FAST_WAVES * 4)
@@ -790,7 +800,7 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 	(void)sj;
 #ifndef LW_EXP_NOFLOOR
 #ifndef LW_EXP_NOPRIO
-	__builtin_amdgcn_s_setprio(2); // latency-bound phase (LDS round trips, few VALU): issue ahead of waves in the IMDCT
+	__builtin_amdgcn_s_setprio(LW_PRIO_FLOOR); // latency-bound phase (LDS round trips, few VALU): issue ahead of waves in the IMDCT
 #endif
 	LW_MARK("floor_table");
 	// ---- floor segment tables (1 KB each)
@@ -826,7 +836,7 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 	lds_fence();
 #endif
 #ifndef LW_EXP_NOPRIO
-	__builtin_amdgcn_s_setprio(0);
+	__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT);
 #endif
 	LW_STAMP(4);
 	if (NCH == 2) {
@@ -1047,10 +1057,29 @@ __device__ __forceinline__ void dense_offsets(const LwFastArgs &F, uint32_t item
 	it.floor_off = item * F.ch * F.fstride;
 }
 
-// LDS counters of the hand-over protocol (one producer, one consumer per counter)
-__device__ __forceinline__ void lds_wait_ge(const volatile uint32_t *p, uint32_t need)
+// LDS counters of the hand-over protocol (one producer, one consumer per counter), addressed by their LDS byte offset
+// (the kernel has no static LDS, so the dynamic segment starts at 0).  Written as ds_ instructions: through a generic
+// `volatile` pointer hipcc emits flat loads with system-scope cache bits and waits for every outstanding HBM access.
+#define LW_CNT_BASE (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES))
+#define LW_CNT_PUB(w) (LW_CNT_BASE + 4u * (w))
+#define LW_CNT_ACK(w) (LW_CNT_BASE + 4u * (LW_FAST_WAVES + (w)))
+#define LW_CNT_LANDED(w) (LW_CNT_BASE + 4u * (2 * LW_FAST_WAVES + (w)))
+
+__device__ __forceinline__ uint32_t lds_load_u32(uint32_t byte_addr)
 {
-	while (*p < need)
+	uint32_t v;
+	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr) : "memory");
+	return v;
+}
+
+__device__ __forceinline__ void lds_store_u32(uint32_t byte_addr, uint32_t v)
+{
+	asm volatile("ds_write_b32 %0, %1" ::"v"(byte_addr), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void lds_wait_ge(uint32_t byte_addr, uint32_t need)
+{
+	while (__builtin_amdgcn_readfirstlane(lds_load_u32(byte_addr)) < need)
 		__builtin_amdgcn_s_sleep(1);
 }
 
@@ -1093,9 +1122,6 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	const bool late = !RIGHT_ONLY && wave >= F.late_from;
 	LW_STAMP_NW(13);
 
-	volatile uint32_t *pubcnt = reinterpret_cast<volatile uint32_t *>(smem + LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES));
-	volatile uint32_t *ackcnt = pubcnt + LW_FAST_WAVES;
-	volatile uint32_t *landed = ackcnt + LW_FAST_WAVES; // early wave w: "my first HBM loads have arrived"
 	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
 	LwFastItem it{};
 	Pref pf{};
@@ -1124,7 +1150,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		uint4 *dst = reinterpret_cast<uint4 *>(smem) + t;
 		const uint4 v0 = src[0], v1 = src[LW_WG - 256];
 		if (t < 3 * LW_FAST_WAVES)
-			pubcnt[t] = 0u;
+			lds_store_u32(LW_CNT_BASE + 4u * t, 0u);
 		dst[0] = v0;
 		dst[LW_WG - 256] = v1;
 		LW_STAMP_NW(1);
@@ -1138,13 +1164,13 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		// pace the HBM queue in groups of late_from waves: a group issues its loads when the data of the group before
 		// it has landed, so that the earlier groups compute while the later groups' data is in flight
 		if (late) {
-			lds_wait_ge(&landed[wave - F.late_from], 1u);
+			lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
 			if (valid)
 				issue_loads(F, it, un, lane_id, pf);
 		}
 		if (wave + F.late_from < LW_FAST_WAVES) {
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			landed[wave] = 1u;
+			lds_store_u32(LW_CNT_LANDED(wave), 1u);
 		}
 	}
 	if (valid && F.dense)
@@ -1197,19 +1223,19 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 					}
 			} else {
 #ifndef LW_EXP_NOPRIO
-				__builtin_amdgcn_s_setprio(3); // finish: hand-over, overlap-add, stores
+				__builtin_amdgcn_s_setprio(LW_PRIO_FINISH); // finish: hand-over, overlap-add, stores
 #endif
 				LW_MARK("publish");
 				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
 				if (it.flags & LW_IF_NEXT_LDS) {
-					lds_wait_ge(&ackcnt[wave], n_pub_used);
+					lds_wait_ge(LW_CNT_ACK(wave), n_pub_used);
 					if (two)
 						publish<2>(pub, lane, R);
 					else
 						publish<1>(pub, lane, R);
 					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 					n_pub_used++;
-					pubcnt[wave] = n_pub_used;
+					lds_store_u32(LW_CNT_PUB(wave), n_pub_used);
 				}
 				LW_MARK("phase2");
 				// ---- the previous packet's right half: from my predecessor wave through LDS, or (chunk starts) from the
@@ -1221,7 +1247,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 					const char *src = nullptr;
 					if (it.src_kind == LW_SRC_LDS) {
 						++n_got;
-						lds_wait_ge(&pubcnt[wprev], n_got);
+						lds_wait_ge(LW_CNT_PUB(wprev), n_got);
 						src = pub0 + wprev * LW_PUB_BYTES;
 					} else if (it.src_kind == LW_SRC_STATE) {
 						const uint32_t pin = (it.flags & LW_RF_PARITY_IN) ? 1u : 0u;
@@ -1247,7 +1273,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						}
 					if (src) {
 						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						ackcnt[wprev] = n_got;
+						lds_store_u32(LW_CNT_ACK(wprev), n_got);
 					}
 				}
 				LW_MARK("state_out");
