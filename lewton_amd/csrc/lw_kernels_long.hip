@@ -942,6 +942,29 @@ __device__ __forceinline__ void prev_from_global(const float *g, uint32_t lane, 
 	h.pp[0][0] = float2_t{g1.w, g1.z}; // (c2=0: k=0 -> 511-4l, k=1 -> 510-4l)
 }
 
+// 8-byte PCM store as a write-through (sc1) store: the bytes leave the L2 while the kernel is still running instead of
+// staying dirty until the end-of-kernel write-back (16.8 MB of dirty PCM cost ~2.7 us at every kernel boundary)
+__device__ __forceinline__ void store_pcm8(void *p, uint32_t lo, uint32_t hi)
+{
+#ifdef LW_EXP_PLAIN_STORE
+	*reinterpret_cast<uint2_t *>(p) = uint2_t{lo, hi};
+#else
+	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED,
+			__HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// 16-byte write-through store (f32 PCM, stream state).  Inline asm because the builtin path offers sc1 only up to 8
+// bytes; the trailing s_nop keeps hipcc from overwriting the data registers before the store has read them.
+__device__ __forceinline__ void store16_wt(void *p, float4_t v)
+{
+#ifdef LW_EXP_PLAIN_STORE
+	*reinterpret_cast<float4_t *>(p) = v;
+#else
+	asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 // ---- window + overlap-add (audio.rs:1116-1118), sample conversion (samples.rs:92-103), stores of one channel
 template <int FMT>
 __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, uint32_t lane, int chn,
@@ -960,10 +983,10 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 	const uint32_t p0 = 4u * lane, p1 = 508u - 4u * lane, p2 = 512u + 4u * lane, p3 = 1020u - 4u * lane;
 	if (FMT == LW_OUT_F32_PLANAR) {
 		float *o = reinterpret_cast<float *>(F.out) + out_off + (uint32_t)chn * 1024u;
-		*reinterpret_cast<float4_t *>(o + p0) = float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x};
-		*reinterpret_cast<float4_t *>(o + p1) = float4_t{O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x};
-		*reinterpret_cast<float4_t *>(o + p2) = float4_t{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y};
-		*reinterpret_cast<float4_t *>(o + p3) = float4_t{O[1][2].y, O[1][3].y, O[0][2].y, O[0][3].y};
+		store16_wt(o + p0, float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x});
+		store16_wt(o + p1, float4_t{O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x});
+		store16_wt(o + p2, float4_t{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y});
+		store16_wt(o + p3, float4_t{O[1][2].y, O[1][3].y, O[0][2].y, O[0][3].y});
 	} else {
 		// samples.rs:92-103: x*32768, truncate toward zero (v_cvt_i32_f32: saturating, NaN -> 0), clamp to
 		// i16 by the saturating pack v_cvt_pk_i16_i32 -- equal to the reference's compare/clamp/`as i16`
@@ -990,16 +1013,16 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 			{
 			a.s = __builtin_amdgcn_cvt_pk_i16(iq[0][3], iq[0][2]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(iq[1][3], iq[1][2]);
-			*reinterpret_cast<uint2_t *>(o + p0) = uint2_t{a.u, b.u};
+			store_pcm8(o + p0, a.u, b.u);
 			a.s = __builtin_amdgcn_cvt_pk_i16(iq[1][1], iq[1][0]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(iq[0][1], iq[0][0]);
-			*reinterpret_cast<uint2_t *>(o + p1) = uint2_t{a.u, b.u};
+			store_pcm8(o + p1, a.u, b.u);
 			a.s = __builtin_amdgcn_cvt_pk_i16(im[0][0], im[0][1]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(im[1][0], im[1][1]);
-			*reinterpret_cast<uint2_t *>(o + p2) = uint2_t{a.u, b.u};
+			store_pcm8(o + p2, a.u, b.u);
 			a.s = __builtin_amdgcn_cvt_pk_i16(im[1][2], im[1][3]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(im[0][2], im[0][3]);
-			*reinterpret_cast<uint2_t *>(o + p3) = uint2_t{a.u, b.u};
+			store_pcm8(o + p3, a.u, b.u);
 			}
 		} else {
 			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn;
@@ -1021,10 +1044,10 @@ __device__ __forceinline__ void store_right_half(float *dst, uint32_t lane, floa
 {
 	const float4_t hi0 = float4_t{lo1.w, lo1.z, lo1.y, lo1.x}; // 1023-q for q = 511-4l .. 508-4l
 	const float4_t hi1 = float4_t{lo0.w, lo0.z, lo0.y, lo0.x};
-	*reinterpret_cast<float4_t *>(dst + 4u * lane) = lo0;
-	*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = lo1;
-	*reinterpret_cast<float4_t *>(dst + 512u + 4u * lane) = hi0;
-	*reinterpret_cast<float4_t *>(dst + 1020u - 4u * lane) = hi1;
+	store16_wt(dst + 4u * lane, lo0);
+	store16_wt(dst + 508u - 4u * lane, lo1);
+	store16_wt(dst + 512u + 4u * lane, hi0);
+	store16_wt(dst + 1020u - 4u * lane, hi1);
 }
 
 // One work item = one 32-byte scalar load (the vector-memory path would park it in eight VGPRs per item)
