@@ -16,6 +16,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wno-unused-result", "-pthread"]
 
 
+# The long-block kernel writes its packed arithmetic itself; the SLP vectoriser only adds register moves around the
+# scalar floor evaluation (-0.3 us per launch on MI355X).
+PER_FILE_FLAGS = {"lw_kernels_long.hip": ["-fno-slp-vectorize"]}
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -46,7 +51,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(LIBDIR, s + ".o")
         objs.append(obj)
-        cmd = [hipcc()] + FLAGS + os.environ.get("LW_EXTRA_FLAGS", "").split() + ["-c", src, "-o", obj]
+        cmd = [hipcc()] + FLAGS + PER_FILE_FLAGS.get(s, []) + os.environ.get("LW_EXTRA_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

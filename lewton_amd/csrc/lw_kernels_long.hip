@@ -1192,7 +1192,11 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 				issue_loads(F, it, un, lane_id, pf);
 		}
 		if (wave + F.late_from < LW_FAST_WAVES) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef LW_PACE_VMCNT
+#define LW_PACE_VMCNT 6
+#endif
+			// signal the next pacing group when all but LW_PACE_VMCNT of this wave's loads have arrived
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW_PACE_VMCNT) : "memory");
 			lds_store_u32(LW_CNT_LANDED(wave), 1u);
 		}
 	}
