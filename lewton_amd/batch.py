@@ -33,8 +33,8 @@ class Batch:
     def __del__(self):
         self.close()
 
-    def entropy(self, packets, n_threads=0):
-        """packets: list of (bytes, PreviousWindowRight).  Returns the per-packet results array."""
+    def marshal(self, packets):
+        """Build the lw_packet array for `packets` once (list of (bytes, PreviousWindowRight)); reusable with entropy_marshalled."""
         n = len(packets)
         arr = (N.Packet * n)()
         bufs = []
@@ -44,10 +44,18 @@ class Batch:
             arr[i].data = C.cast(C.c_char_p(data), C.c_void_p)
             arr[i].len = len(data)
             arr[i].pwr = pwr._bind(self.dec)
+        return (arr, bufs, n)
+
+    def entropy_marshalled(self, marshalled, n_threads=0):
+        arr, bufs, n = marshalled
         self._keep = (arr, bufs)
         rc = N.lw_batch_entropy(self._h, arr, n, n_threads)
         if rc:
             raise RuntimeError("lw_batch_entropy: %d" % rc)
+
+    def entropy(self, packets, n_threads=0):
+        """packets: list of (bytes, PreviousWindowRight).  Returns the per-packet results array."""
+        self.entropy_marshalled(self.marshal(packets), n_threads)
         return self.results()
 
     def results(self):

@@ -836,7 +836,17 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 	lds_fence();
 #endif
 #ifndef LW_EXP_NOPRIO
+#ifdef LW_EXP_GROUP_PRIO // experiment: later pacing groups (most work left) run the IMDCT at higher priority
+	{
+		const uint32_t g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+		if (g == 0) __builtin_amdgcn_s_setprio(0);
+		else if (g == 1) __builtin_amdgcn_s_setprio(LW_EXP_GROUP_PRIO >= 2 ? 1 : 0);
+		else if (g == 2) __builtin_amdgcn_s_setprio(LW_EXP_GROUP_PRIO >= 2 ? 2 : 1);
+		else __builtin_amdgcn_s_setprio(LW_EXP_GROUP_PRIO >= 2 ? 3 : 1);
+	}
+#else
 	__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT);
+#endif
 #endif
 	LW_STAMP(4);
 	if (NCH == 2) {
