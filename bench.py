@@ -36,8 +36,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # 4000 steps = ~70 ms of GPU time: the MI355X needs tens of milliseconds of sustained load to settle its clocks
+    # (200-step runs measure 20.2 us per launch, 1000-step runs 18.9, 4000-step runs 17.7; profiles/r01_steps_sweep.txt)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true", help="time the generic kernels instead of the specialised one")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -1194,8 +1194,10 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	__syncthreads();
 	LW_STAMP_NW(2);
 	if (!RIGHT_ONLY && F.late_from < LW_FAST_WAVES) {
-		// pace the HBM queue in groups of late_from waves: a group issues its loads when the data of the group before
-		// it has landed, so that the earlier groups compute while the later groups' data is in flight
+		// Order the HBM queue: wave w issues its loads when wave w - late_from has issued its own (LW_PACE_VMCNT = 63) or
+		// has all but LW_PACE_VMCNT of them back.  Requests of one CU are served in issue order, so the data arrives
+		// wave by wave instead of all at the end of the burst: the first waves compute while the later waves' data is
+		// still in flight (issue order, one wave at a time, measured best: 18.7 us vs 27 us unpaced).
 		if (late) {
 			lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
 			if (valid)
@@ -1203,9 +1205,8 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		}
 		if (wave + F.late_from < LW_FAST_WAVES) {
 #ifndef LW_PACE_VMCNT
-#define LW_PACE_VMCNT 6
+#define LW_PACE_VMCNT 63
 #endif
-			// signal the next pacing group when all but LW_PACE_VMCNT of this wave's loads have arrived
 			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW_PACE_VMCNT) : "memory");
 			lds_store_u32(LW_CNT_LANDED(wave), 1u);
 		}

@@ -104,7 +104,7 @@ struct lw_batch {
 	float *d_halo = nullptr;
 	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
-	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = LW_FAST_WAVES / 4;
+	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = 1;
 	// (debug: LW_PACE_GROUP=<waves per pacing group> overrides)
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
