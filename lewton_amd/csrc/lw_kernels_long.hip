@@ -360,13 +360,20 @@ __device__ __forceinline__ void ola_block(const float2_t (&Rc)[4], float2_t pp0,
 // ---------------------------------------------------------------------------------------------
 // Per-round register state
 // ---------------------------------------------------------------------------------------------
+// a work item in registers: every field a full dword (see load_item)
+struct ItemRegs {
+	uint32_t res_off, floor_off, out_off, src_arg;
+	int32_t state_out;
+	uint32_t halo_out, src_kind, flags;
+};
+
 struct Pref {          // what one wave loads from HBM for one item
 	float4_t r[2][4];  // residues: lane holds bins 4 (64 x + lane) + j of each channel
 	uint32_t fe[2];    // floor-1 post entry of post `lane` of each channel (lanes >= F hold 0)
 };
 
 
-__device__ __forceinline__ void issue_loads(const LwFastArgs &F, const LwFastItem &it,
+__device__ __forceinline__ void issue_loads(const LwFastArgs &F, const ItemRegs &it,
 		const LwFastUnit &un, uint32_t lane, Pref &p)
 {
 #ifdef LW_EXP_NOLOAD // experiment: no HBM reads (synthetic register contents)
@@ -990,7 +997,11 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 	}
 	// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [508-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
 	//            [512+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [1020-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
+#ifdef LW_EXP_ASCENDING_STORES // experiment (wrong sample positions): every store ascends with the lane id
+	const uint32_t p0 = 4u * lane, p1 = 256u + 4u * lane, p2 = 512u + 4u * lane, p3 = 768u + 4u * lane;
+#else
 	const uint32_t p0 = 4u * lane, p1 = 508u - 4u * lane, p2 = 512u + 4u * lane, p3 = 1020u - 4u * lane;
+#endif
 	if (FMT == LW_OUT_F32_PLANAR) {
 		float *o = reinterpret_cast<float *>(F.out) + out_off + (uint32_t)chn * 1024u;
 		store16_wt(o + p0, float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x});
@@ -1060,31 +1071,31 @@ __device__ __forceinline__ void store_right_half(float *dst, uint32_t lane, floa
 	store16_wt(dst + 1020u - 4u * lane, hi1);
 }
 
-// One work item = one 32-byte scalar load (the vector-memory path would park it in eight VGPRs per item)
+// One work item = one 32-byte scalar load (the vector-memory path would park it in eight VGPRs per item).  In registers
+// every field is a full dword: byte-sized struct members make hipcc copy the item byte by byte when it is carried from
+// one round to the next.
 typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ LwFastItem load_item(const LwFastItem *items, uint32_t idx)
+
+__device__ __forceinline__ ItemRegs load_item(const LwFastItem *items, uint32_t idx)
 {
 	const LwFastItem *p = items + __builtin_amdgcn_readfirstlane(idx);
 	u32x8_t v;
 	asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-	LwFastItem it;
+	ItemRegs it;
 	it.res_off = v[0];
 	it.floor_off = v[1];
 	it.out_off = v[2];
 	it.src_arg = v[3];
 	it.state_out = (int32_t)v[4];
 	it.halo_out = v[5];
-	it.src_kind = (uint8_t)(v[6] & 0xffu);
-	it.mode = (uint8_t)((v[6] >> 8) & 0xffu);
-	it.flags = (uint8_t)((v[6] >> 16) & 0xffu);
-	it.pad = 0;
-	it.pkt = v[7];
+	it.src_kind = v[6] & 0xffu;
+	it.flags = (v[6] >> 16) & 0xffu;
 	return it;
 }
 
 // item k of a dense list: packet k of a batch whose packets all have the same block sizes (no item load needed
 // before the HBM loads can be issued)
-__device__ __forceinline__ void dense_offsets(const LwFastArgs &F, uint32_t item, LwFastItem &it)
+__device__ __forceinline__ void dense_offsets(const LwFastArgs &F, uint32_t item, ItemRegs &it)
 {
 	it.res_off = item * F.ch * 1024u;
 	it.floor_off = item * F.ch * F.fstride;
@@ -1156,7 +1167,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	LW_STAMP_NW(13);
 
 	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
-	LwFastItem it{};
+	ItemRegs it{};
 	Pref pf{};
 	bool valid = active && item0 < F.n_items;
 #ifdef LW_EXP_ACTIVE_WAVES // experiment: only the first K waves of every workgroup work
@@ -1232,7 +1243,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb) at q_k(m' = 2 lane + c2): un-windowed left / right halves
 		const uint32_t item_n = item0 + (j + 1) * per_round;
 		const bool valid_n = active && j + 1 < rounds && item_n < F.n_items;
-		LwFastItem itn{};
+		ItemRegs itn{};
 		if (valid_n && !F.dense)
 			itn = load_item(F.items, item_n);
 		if (valid) {
