@@ -128,6 +128,14 @@ __device__ __forceinline__ void lds_fence()
 	asm volatile("" ::: "memory"); // wave-private LDS traffic is in order in hardware; stop compiler motion only
 }
 
+// LDS access by absolute byte address (the kernel has no static LDS, the dynamic segment starts at 0): saves the add of
+// the relocatable segment base that hipcc otherwise keeps in every computed address
+typedef __attribute__((address_space(3))) const float *lds_cfloat_ptr;
+__device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr)
+{
+	return *reinterpret_cast<lds_cfloat_ptr>((uintptr_t)byte_addr);
+}
+
 __device__ __forceinline__ float2_t lds2(const char *base, uint32_t byte_off)
 {
 	return *reinterpret_cast<const float2_t *>(base + byte_off);
@@ -357,6 +365,28 @@ __device__ __forceinline__ void ola_block(const float2_t (&Rc)[4], float2_t pp0,
 		    : "v"(Rc[0]), "v"(Rc[1]), "v"(Rc[2]), "v"(Rc[3]), "v"(pp0), "v"(pp1), "v"(S0), "v"(S1), "v"(S2), "v"(S3));
 }
 
+// inverse coupling (audio.rs:762-777) of four (magnitude, angle) pairs in place.  With c = (m > 0), d = (a > 0) the reference's
+//   ap = c ? a : -a;  new_m = d ? m : m + ap;  new_a = d ? m - ap : m
+// is v = m + ((c == d) ? -a : a);  (new_m, new_a) = d ? (m, v) : (v, m)   (x - y and x + (-y) are the same operation):
+// 6 VALU + 1 SALU per pair, compare masks in SGPR pairs (no VCC serialisation, no hazard pads).
+__device__ __forceinline__ void decouple4(float &m0, float &a0, float &m1, float &a1, float &m2, float &a2, float &m3, float &a3)
+{
+	float t0, t1, t2, t3;
+	unsigned long long c0, c1, c2, c3, d0, d1, d2, d3;
+	asm("v_cmp_lt_f32_e64 %12, 0, %0\n\tv_cmp_lt_f32_e64 %13, 0, %2\n\tv_cmp_lt_f32_e64 %14, 0, %4\n\tv_cmp_lt_f32_e64 %15, 0, %6\n\t"
+	    "v_cmp_lt_f32_e64 %16, 0, %1\n\tv_cmp_lt_f32_e64 %17, 0, %3\n\tv_cmp_lt_f32_e64 %18, 0, %5\n\tv_cmp_lt_f32_e64 %19, 0, %7\n\t"
+	    "s_xnor_b64 %12, %12, %16\n\ts_xnor_b64 %13, %13, %17\n\ts_xnor_b64 %14, %14, %18\n\ts_xnor_b64 %15, %15, %19\n\t"
+	    "v_cndmask_b32_e64 %8, %1, -%1, %12\n\tv_cndmask_b32_e64 %9, %3, -%3, %13\n\t"
+	    "v_cndmask_b32_e64 %10, %5, -%5, %14\n\tv_cndmask_b32_e64 %11, %7, -%7, %15\n\t"
+	    "v_add_f32_e32 %8, %0, %8\n\tv_add_f32_e32 %9, %2, %9\n\tv_add_f32_e32 %10, %4, %10\n\tv_add_f32_e32 %11, %6, %11\n\t"
+	    "v_cndmask_b32_e64 %1, %0, %8, %16\n\tv_cndmask_b32_e64 %3, %2, %9, %17\n\t"
+	    "v_cndmask_b32_e64 %5, %4, %10, %18\n\tv_cndmask_b32_e64 %7, %6, %11, %19\n\t"
+	    "v_cndmask_b32_e64 %0, %8, %0, %16\n\tv_cndmask_b32_e64 %2, %9, %2, %17\n\t"
+	    "v_cndmask_b32_e64 %4, %10, %4, %18\n\tv_cndmask_b32_e64 %6, %11, %6, %19"
+	    : "+v"(m0), "+v"(a0), "+v"(m1), "+v"(a1), "+v"(m2), "+v"(a2), "+v"(m3), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
+	      "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3), "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-round register state
 // ---------------------------------------------------------------------------------------------
@@ -450,7 +480,7 @@ __device__ __forceinline__ void spectrum(const LwFastArgs &F, const char *img, c
 			const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
 			const int q = (int)(z * ent.z);
 			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
-			fl[j] = *reinterpret_cast<const float *>(img + LWI_INV_DB + idx);
+			fl[j] = lds_abs_f32(LWI_INV_DB + idx);
 		}
 		const float2_t lo2 = pk_mul(float2_t{fl.x, fl.y}, float2_t{r[x].x, r[x].y});
 		const float2_t hi2 = pk_mul(float2_t{fl.z, fl.w}, float2_t{r[x].z, r[x].w});
@@ -489,7 +519,7 @@ __device__ __forceinline__ void spectrum_pair(const char *img, const char *sc, u
 			const float z = __builtin_fmaf(kf0 + (float)(256 * ((b) & 3) + j), e.x, e.y); /* exact: |k*dy| < 2^18 */ \
 			const int q = (int)(z * e.z);                                              \
 			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(e.w));           \
-			fl[(b) & 1][j] = *reinterpret_cast<const float *>(img + LWI_INV_DB + idx); \
+			fl[(b) & 1][j] = lds_abs_f32(LWI_INV_DB + idx); \
 		}                                                                              \
 	} while (0)
 #define LW_SP_M(b)                                                                     \
@@ -821,15 +851,11 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 	if (NCH == 2 && un.coupled) {
 #pragma unroll
 		for (int x = 0; x < 4; x++) {
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const float m = pf.r[0][x][j], a = pf.r[1][x][j];
-				const float ap = m > 0.0f ? a : -a; // (m, a) -> a>0 ? (m, m-a') : (m+a', m)
-				const float s = m + ap, d = m - ap;
-				const bool apos = a > 0.0f;
-				pf.r[0][x][j] = apos ? m : s;
-				pf.r[1][x][j] = apos ? d : m;
-			}
+			float m[4] = {pf.r[0][x].x, pf.r[0][x].y, pf.r[0][x].z, pf.r[0][x].w};
+			float a[4] = {pf.r[1][x].x, pf.r[1][x].y, pf.r[1][x].z, pf.r[1][x].w};
+			decouple4(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
+			pf.r[0][x] = float4_t{m[0], m[1], m[2], m[3]};
+			pf.r[1][x] = float4_t{a[0], a[1], a[2], a[3]};
 		}
 	}
 	LW_MARK("spectrum");
@@ -1209,6 +1235,15 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		// has all but LW_PACE_VMCNT of them back.  Requests of one CU are served in issue order, so the data arrives
 		// wave by wave instead of all at the end of the burst: the first waves compute while the later waves' data is
 		// still in flight (issue order, one wave at a time, measured best: 18.7 us vs 27 us unpaced).
+#ifdef LW_PACE_SLEEP // variant: fixed delays instead of the flag chain (wave w sleeps w * LW_PACE_SLEEP * 64 cycles)
+		if (late) {
+			for (uint32_t i = 0; i < wave; i++)
+				__builtin_amdgcn_s_sleep(LW_PACE_SLEEP);
+			if (valid)
+				issue_loads(F, it, un, lane_id, pf);
+		}
+	}
+#else
 		if (late) {
 			lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
 			if (valid)
@@ -1222,6 +1257,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 			lds_store_u32(LW_CNT_LANDED(wave), 1u);
 		}
 	}
+#endif
 	if (valid && F.dense)
 		it = load_item(F.items, item0); // the rest of the item is only needed in phase 2
 	const char *img = smem;
