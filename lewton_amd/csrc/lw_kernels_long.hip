@@ -591,6 +591,13 @@ __device__ __forceinline__ void stage_b(const LwFastArgs &F, const char *img, ui
 // ---- T2: layout B -> C.  slot(p) = p ^ ((p>>6 & 3) << 3)
 __device__ __forceinline__ void t2_write(char *sc, uint32_t lane, const float2_t (&P)[8])
 {
+#ifdef LW_EXP_DOUBLE_LDS // experiment: every transpose write twice (same data, same address)
+#pragma unroll
+	for (int x = 0; x < 8; x++) {
+		const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
+		*reinterpret_cast<volatile float2_t *>(sc + 8u * slot) = P[x];
+	}
+#endif
 #pragma unroll
 	for (int x = 0; x < 8; x++) {
 		const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
@@ -606,6 +613,51 @@ __device__ __forceinline__ void t2_read(const char *sc, uint32_t lane, float2_t 
 		const uint32_t slot = 64u * X3b + lo3 + 8u * ((uint32_t)y ^ (X3b & 3u));
 		Q[y] = lds2(sc, 8u * slot);
 	}
+}
+
+// ---- T2 without LDS: layout B -> C is an 8 x 8 transpose between the register index (pair bits 8..6) and lane bits 5..3.
+//      Three butterfly exchanges: lane bit 5 by v_permlane32_swap, bit 4 by v_permlane16_swap, bit 3 by DPP row_ror:8 with
+//      bank masks.  40 VALU per channel instead of 8 ds_write_b64 + 8 ds_read_b64: the LDS write data path (one per CU,
+//      ~7.6 cycles per ds_write_b64) is the scarcer resource (tools/exp.sh: doubling the transposes' writes costs 1.85 us).
+__device__ __forceinline__ void t2_inreg(float2_t (&P)[8])
+{
+#define LW_SWAP32(a, b)                                                                       \
+	do {                                                                                      \
+		auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false); \
+		a = __uint_as_float(r_[0]);                                                           \
+		b = __uint_as_float(r_[1]);                                                           \
+	} while (0)
+#define LW_SWAP16(a, b)                                                                       \
+	do {                                                                                      \
+		auto r_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false); \
+		a = __uint_as_float(r_[0]);                                                           \
+		b = __uint_as_float(r_[1]);                                                           \
+	} while (0)
+#define LW_SWAP8(a, b)                                                                        \
+	do {                                                                                      \
+		const int a_ = __float_as_int(a), b_ = __float_as_int(b);                             \
+		a = __int_as_float(__builtin_amdgcn_update_dpp(a_, b_, 0x128, 0xf, 0xc, false)); /* lanes 8-15 of a row <- b[l ^ 8] */ \
+		b = __int_as_float(__builtin_amdgcn_update_dpp(b_, a_, 0x128, 0xf, 0x3, false)); /* lanes 0-7  of a row <- a[l ^ 8] */ \
+	} while (0)
+#pragma unroll
+	for (int x = 0; x < 4; x++) { // register bit 2 <-> lane bit 5
+		LW_SWAP32(P[x].x, P[x + 4].x);
+		LW_SWAP32(P[x].y, P[x + 4].y);
+	}
+#pragma unroll
+	for (int i = 0; i < 4; i++) { // register bit 1 <-> lane bit 4
+		const int x = (i & 1) | ((i & 2) << 1);
+		LW_SWAP16(P[x].x, P[x + 2].x);
+		LW_SWAP16(P[x].y, P[x + 2].y);
+	}
+#pragma unroll
+	for (int x = 0; x < 8; x += 2) { // register bit 0 <-> lane bit 3
+		LW_SWAP8(P[x].x, P[x + 1].x);
+		LW_SWAP8(P[x].y, P[x + 1].y);
+	}
+#undef LW_SWAP32
+#undef LW_SWAP16
+#undef LW_SWAP8
 }
 
 // ---- stages l = 2, 3, 4 (imdct.rs:454-477)
@@ -633,6 +685,14 @@ __device__ __forceinline__ void stage_c(const LwFastArgs &F, const char *img, ui
 __device__ __forceinline__ void t3_write(char *sc, uint32_t lane, const float2_t (&Q)[8])
 {
 	const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
+#ifdef LW_EXP_DOUBLE_LDS
+#pragma unroll
+	for (int y = 0; y < 8; y++) {
+		const uint32_t nu = 8u * X3b + y;
+		const uint32_t slot = 8u * nu + (lo3 ^ ((nu >> 2) & 7u));
+		*reinterpret_cast<volatile float2_t *>(sc + 8u * slot) = Q[y];
+	}
+#endif
 #pragma unroll
 	for (int y = 0; y < 8; y++) {
 		const uint32_t nu = 8u * X3b + y;
@@ -761,6 +821,22 @@ __device__ __forceinline__ void stage_b1(const TwB &t, uint32_t lane, const floa
 
 __device__ __forceinline__ void stage_c1(const TwC &t, float2_t (&Q)[8])
 {
+#ifdef LW_EXP_DOUBLE_VALU // experiment: 120 extra packed operations per channel (results discarded through a dead select)
+	{
+		float2_t d0 = Q[0], d1 = Q[1], d2 = Q[2], d3 = Q[3];
+#pragma unroll
+		for (int i = 0; i < 10; i++) {
+			float2_t e0 = Q[4], e1 = Q[5], e2 = Q[6], e3 = Q[7];
+			bfly2x4(d0, e0, t.t4, d1, e1, t.t4, d2, e2, t.t4, d3, e3, t.t4);
+			asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+			bfly2x4(d0, e0, t.t2[0], d1, e1, t.t2[1], d2, e2, t.t2[2], d3, e3, t.t2[3]);
+			asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+			bfly2x4(d0, e0, t.t3[0], d1, e1, t.t3[1], d2, e2, t.t3[0], d3, e3, t.t3[1]);
+			asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+		}
+		asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
+	}
+#endif
 	bfly2x4(Q[4], Q[0], t.t2[0], Q[5], Q[1], t.t2[1], Q[6], Q[2], t.t2[2], Q[7], Q[3], t.t2[3]); // l = 2
 	bfly2x4(Q[2], Q[0], t.t3[0], Q[6], Q[4], t.t3[0], Q[3], Q[1], t.t3[1], Q[7], Q[5], t.t3[1]); // l = 3
 	bfly2x4(Q[1], Q[0], t.t4, Q[3], Q[2], t.t4, Q[5], Q[4], t.t4, Q[7], Q[6], t.t4);             // l = 4
@@ -787,6 +863,7 @@ __device__ __forceinline__ void imdct_pair(const char *img, char *sc, uint32_t l
 		float2_t (&R)[2][2][4])
 {
 	float2_t P0[8], P1[8];
+#ifdef LW_T2_LDS // previous variant: T2 through LDS
 	{
 		TwB tb;
 		load_tw_b(img, lane, tb);
@@ -804,6 +881,21 @@ __device__ __forceinline__ void imdct_pair(const char *img, char *sc, uint32_t l
 	t2_read(sc, lane, P1);
 	stage_c1(tc, P0);
 	__builtin_amdgcn_sched_barrier(0);
+#else
+	TwC tc;
+	{
+		TwB tb;
+		load_tw_b(img, lane, tb);
+		stage_b1(tb, lane, r[0], P0);
+		stage_b1(tb, lane, r[1], P1);
+		load_tw_c(img, lane, tc);
+		t2_inreg(P0);
+		t2_inreg(P1);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	stage_c1(tc, P0);
+	__builtin_amdgcn_sched_barrier(0);
+#endif
 	t3_write(sc, lane, P0);
 	__builtin_amdgcn_sched_barrier(0);
 	t3_read(sc, lane, P0);
@@ -894,12 +986,8 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 	LW_MARK("t2");
 #ifndef LW_EXP_NOTRANSPOSE
 #pragma unroll
-	for (int c = 0; c < NCH; c++) { // T2
-		t2_write(sc, lane, P[c]);
-		lds_fence();
-		t2_read(sc, lane, P[c]);
-		lds_fence();
-	}
+	for (int c = 0; c < NCH; c++) // T2
+		t2_inreg(P[c]);
 #endif
 	LW_MARK("stage_c");
 	stage_c<NCH>(F, img, lane, P);
