@@ -95,7 +95,8 @@ class PreviousWindowRight:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._dec is not None and getattr(self._dec, "_h", None):
+        # N is None while the interpreter shuts down; the library owns nothing that outlives the process
+        if N is not None and getattr(self, "_h", None) and self._dec is not None and getattr(self._dec, "_h", None):
             N.lw_pwr_free(self._h)
             self._h = None
 

@@ -31,7 +31,8 @@ class Batch:
             self._h = None
 
     def __del__(self):
-        self.close()
+        if N is not None and getattr(N, "lw_batch_destroy", None) is not None:  # not during interpreter shutdown
+            self.close()
 
     def marshal(self, packets):
         """Build the lw_packet array for `packets` once (list of (bytes, PreviousWindowRight)); reusable with entropy_marshalled."""

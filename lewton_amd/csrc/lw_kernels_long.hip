@@ -710,6 +710,79 @@ __device__ __forceinline__ void t3_read(const char *sc, uint32_t lane, float2_t 
 	}
 }
 
+// ---- T3 without LDS: layout C -> D is an 8 x 8 transpose between the register index (pair bits 5..3) and lane bits 2..0.
+//      Lane bit 2: v_mov_dpp row_shr/row_shl:4 with bank masks.  Lane bits 1 and 0: v_cndmask_b32_dpp quad_perm under VCC
+//      (a' = bit ? b[l^m] : a, b' = bit ? b : a[l^m]), 2 instructions per exchanged dword pair.
+#define LW_XQ_BLOCK(QP, MASK) \
+	asm volatile("s_mov_b32 vcc_lo, " MASK "\n\ts_mov_b32 vcc_hi, " MASK "\n\ts_nop 1\n\t" \
+	             "v_cndmask_b32_dpp %0, %8, %16, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %1, %9, %17, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %2, %10, %18, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %3, %11, %19, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %4, %12, %20, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %5, %13, %21, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %6, %14, %22, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %7, %15, %23, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "s_not_b64 vcc, vcc\n\t" \
+	             "v_cndmask_b32_dpp %8, %16, %8, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %9, %17, %9, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %10, %18, %10, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %11, %19, %11, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %12, %20, %12, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %13, %21, %13, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %14, %22, %14, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
+	             "v_cndmask_b32_dpp %15, %23, %15, vcc " QP " row_mask:0xf bank_mask:0xf" \
+	             : "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]), "=&v"(n[7]), \
+	               "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) \
+	             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) \
+	             : "vcc", "scc")
+
+// VCC = lanes whose bit is CLEAR: first half keeps a there and takes b[l^m] elsewhere; second half (VCC inverted) keeps b on
+// lanes whose bit is set and takes a[l^m] elsewhere.  b is updated in place, the new a comes back in n.
+__device__ __forceinline__ void xq_bit1(const float (&a)[8], float (&b)[8], float (&n)[8])
+{
+	LW_XQ_BLOCK("quad_perm:[2,3,0,1]", "0x33333333");
+}
+__device__ __forceinline__ void xq_bit0(const float (&a)[8], float (&b)[8], float (&n)[8])
+{
+	LW_XQ_BLOCK("quad_perm:[1,0,3,2]", "0x55555555");
+}
+
+__device__ __forceinline__ void t3_inreg(float2_t (&P)[8])
+{
+#define LW_X4(a, b)                                                                           \
+	do {                                                                                      \
+		const int a_ = __float_as_int(a), b_ = __float_as_int(b);                             \
+		a = __int_as_float(__builtin_amdgcn_update_dpp(a_, b_, 0x114, 0xf, 0xa, false)); /* lanes 4-7, 12-15 <- b[l - 4] */ \
+		b = __int_as_float(__builtin_amdgcn_update_dpp(b_, a_, 0x104, 0xf, 0x5, false)); /* lanes 0-3, 8-11  <- a[l + 4] */ \
+	} while (0)
+#pragma unroll
+	for (int y = 0; y < 4; y++) { // register bit 2 <-> lane bit 2
+		LW_X4(P[y].x, P[y + 4].x);
+		LW_X4(P[y].y, P[y + 4].y);
+	}
+#undef LW_X4
+	float a[8], b[8], n[8];
+#pragma unroll
+	for (int i = 0; i < 4; i++) { // register bit 1 <-> lane bit 1
+		const int y = (i & 1) | ((i & 2) << 1);
+		a[2 * i] = P[y].x, a[2 * i + 1] = P[y].y, b[2 * i] = P[y + 2].x, b[2 * i + 1] = P[y + 2].y;
+	}
+	xq_bit1(a, b, n);
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int y = (i & 1) | ((i & 2) << 1);
+		P[y] = float2_t{n[2 * i], n[2 * i + 1]}, P[y + 2] = float2_t{b[2 * i], b[2 * i + 1]};
+	}
+#pragma unroll
+	for (int i = 0; i < 4; i++) // register bit 0 <-> lane bit 0
+		a[2 * i] = P[2 * i].x, a[2 * i + 1] = P[2 * i].y, b[2 * i] = P[2 * i + 1].x, b[2 * i + 1] = P[2 * i + 1].y;
+	xq_bit0(a, b, n);
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+		P[2 * i] = float2_t{n[2 * i], n[2 * i + 1]}, P[2 * i + 1] = float2_t{b[2 * i], b[2 * i + 1]};
+}
+
 // ---- fused last three stages (imdct.rs:234-288), lane-local, 28 packed operations per channel
 __device__ __forceinline__ void stage_d(float2_t a2, float2_t (&z)[8])
 {
@@ -896,16 +969,23 @@ __device__ __forceinline__ void imdct_pair(const char *img, char *sc, uint32_t l
 	stage_c1(tc, P0);
 	__builtin_amdgcn_sched_barrier(0);
 #endif
+	const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
+	const float2_t a2 = float2_t{a2s, a2s};
+#ifdef LW_T3_LDS
 	t3_write(sc, lane, P0);
 	__builtin_amdgcn_sched_barrier(0);
 	t3_read(sc, lane, P0);
 	stage_c1(tc, P1);
 	__builtin_amdgcn_sched_barrier(0);
-	const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
-	const float2_t a2 = float2_t{a2s, a2s};
 	t3_write(sc, lane, P1);
 	__builtin_amdgcn_sched_barrier(0);
 	t3_read(sc, lane, P1);
+#else
+	t3_inreg(P0);
+	stage_c1(tc, P1);
+	__builtin_amdgcn_sched_barrier(0);
+	t3_inreg(P1);
+#endif
 	stage_d_block(a2, P0);
 	__builtin_amdgcn_sched_barrier(0);
 	t4_write(sc, lane, P0);
@@ -996,10 +1076,7 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 #ifndef LW_EXP_NOTRANSPOSE
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T3
-		t3_write(sc, lane, P[c]);
-		lds_fence();
-		t3_read(sc, lane, P[c]);
-		lds_fence();
+		t3_inreg(P[c]);
 	}
 #endif
 	LW_MARK("stage_d");
@@ -1334,8 +1411,10 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 #else
 		if (late) {
 			lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
+			LW_STAMP_NW(14);
 			if (valid)
 				issue_loads(F, it, un, lane_id, pf);
+			LW_STAMP_NW(15);
 		}
 		if (wave + F.late_from < LW_FAST_WAVES) {
 #ifndef LW_PACE_VMCNT

@@ -80,6 +80,15 @@ for rep in range(6):
             i, nm, col.min(), np.median(col), col.max(), np.median(early) if len(early) else -1, early.max() if len(early) else -1,
             np.median(lateh) if len(lateh) else -1, lateh.max() if len(lateh) else -1))
     if rep == 5:
+        # per-wave timeline (median over workgroups, cycles since WG entry)
+        cols = [c for c in (2, 14, 15, 3, 4, 8, 9, 10, 11) if full[:, :, c].max() != 0]
+        print("  per-wave medians  " + " ".join("%7s" % ("s%d" % c) for c in cols) + " | phase lengths")
+        for w in range(16):
+            if not ok[:, w].any():
+                continue
+            med = [float(np.median(absd[:, w, c][ok[:, w] & (full[:, w, c] != 0)])) if (ok[:, w] & (full[:, w, c] != 0)).any() else float("nan") for c in cols]
+            print("  wave %2d           " % w + " ".join("%7.0f" % m for m in med) + " | " + " ".join("%6.0f" % (med[i + 1] - med[i]) for i in range(len(med) - 1)))
+    if rep == 5:
         e = full[:, 0, 0]
         print("entry stamps of wave 0, blocks 0..23:", [int(x) for x in e[:24]])
         print("end stamps  of wave 0, blocks 0..23:", [int(x) for x in full[:24, 0, 59]])
