@@ -81,7 +81,7 @@ for rep in range(6):
             np.median(lateh) if len(lateh) else -1, lateh.max() if len(lateh) else -1))
     if rep == 5:
         # per-wave timeline (median over workgroups, cycles since WG entry)
-        cols = [c for c in (2, 14, 15, 3, 4, 8, 9, 10, 11) if full[:, :, c].max() != 0]
+        cols = [c for c in (2, 15, 3, 4, 8, 9, 10, 11) if full[:, :, c].max() != 0]
         print("  per-wave medians  " + " ".join("%7s" % ("s%d" % c) for c in cols) + " | phase lengths")
         for w in range(16):
             if not ok[:, w].any():
