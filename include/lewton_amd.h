@@ -168,6 +168,98 @@ void lw_batch_set_force_generic(lw_batch *b, int on);
 /* names of the kernels the last lw_batch_synth used, comma separated (introspection for tests/bench) */
 const char *lw_batch_last_kernels(const lw_batch *b);
 
+/* ---- Ogg container either side of the path ---------------------------- */
+/* lewton reads Ogg through the external crate `ogg` 0.8.0 (Cargo.lock; `PacketReader`, `Packet`) and wraps it
+ * in src/inside_ogg.rs.  The functions below replace both: a page/packet demultiplexer after RFC 3533 with the
+ * packet attributes lewton's call sites use, and `OggStreamReader` with the device decode behind it. */
+enum {
+	LW_OGG_EOF = 48,                     /* Ok(None): clean end of the physical stream */
+	/* ogg::OggReadError */
+	LW_OGG_NO_CAPTURE_PATTERN = 49,      /* NoCapturePatternFound */
+	LW_OGG_INVALID_STREAM_STRUCT_VER = 50, /* InvalidStreamStructVer(u8) */
+	LW_OGG_HASH_MISMATCH = 51,           /* HashMismatch(u32, u32) */
+	LW_OGG_READ_ERROR = 52,              /* ReadError(io::Error), incl. UnexpectedEof inside a page / read_packet_expected */
+	LW_OGG_INVALID_DATA = 53             /* InvalidData */
+};
+
+typedef struct lw_ogg_reader lw_ogg_reader; /* ogg::PacketReader<T: Read + Seek> */
+typedef struct lw_ogg_stream lw_ogg_stream; /* OggStreamReader<T>, src/inside_ogg.rs:66-77 */
+
+typedef struct {                 /* the `T: Read + Seek` of the reference as C callbacks */
+	int64_t (*read)(void *user, uint8_t *dst, size_t n);       /* bytes read (0 = end), < 0 = error */
+	int64_t (*seek)(void *user, int64_t offset, int whence);   /* whence 0/1/2 = SEEK_SET/CUR/END; new position or < 0 */
+	void *user;
+} lw_ogg_io;
+
+typedef struct {                 /* ogg::Packet */
+	const uint8_t *data;         /* owned by the reader, valid until its next call */
+	size_t len;
+	uint32_t stream_serial;      /* Packet::stream_serial() */
+	uint64_t absgp_page;         /* Packet::absgp_page(): granule position of the page the packet ended on */
+	uint8_t first_in_stream;     /* Packet::first_in_stream(): first packet of a page with the begin-of-stream flag */
+	uint8_t last_in_stream;      /* Packet::last_in_stream(): last packet of a page with the end-of-stream flag */
+	uint8_t first_in_page;       /* Packet::first_in_page() */
+	uint8_t last_in_page;        /* Packet::last_in_page() */
+} lw_ogg_packet;
+
+/* PacketReader::new(rdr).  open_memory borrows `data` unless copy != 0. */
+lw_ogg_reader *lw_ogg_reader_open_memory(const uint8_t *data, size_t len, int copy);
+lw_ogg_reader *lw_ogg_reader_open_file(const char *path, int *err);
+lw_ogg_reader *lw_ogg_reader_open_io(const lw_ogg_io *io);
+void lw_ogg_reader_close(lw_ogg_reader *r);
+/* PacketReader::read_packet: LW_OK + *out, LW_OGG_EOF, or an OggReadError code.  Streams may be multiplexed. */
+int lw_ogg_read_packet(lw_ogg_reader *r, lw_ogg_packet *out);
+/* PacketReader::read_packet_expected: end of stream is LW_OGG_READ_ERROR (UnexpectedEof) */
+int lw_ogg_read_packet_expected(lw_ogg_reader *r, lw_ogg_packet *out);
+/* PacketReader::delete_unread_packets (inside_ogg.rs:47) */
+void lw_ogg_delete_unread_packets(lw_ogg_reader *r);
+/* PacketReader::seek_absgp(stream_serial, absgp) with page granularity (inside_ogg.rs:307-313): reading resumes behind
+ * the LAST page of the stream (any stream when has_serial == 0) that completes a packet and whose granule position
+ * is <= absgp -- at the start of the physical stream if there is none -- so the position reached is <= absgp.
+ * Bisection over the byte range, then a linear scan of the last interval. */
+int lw_ogg_seek_absgp(lw_ogg_reader *r, int has_serial, uint32_t serial, uint64_t absgp);
+/* CRC of RFC 3533 (polynomial 0x04c11db7, initial 0, no reflection) -- exposed for muxers and tests */
+uint32_t lw_ogg_crc32(const uint8_t *data, size_t len, uint32_t crc);
+
+/* OggStreamReader::from_ogg_reader (inside_ogg.rs:100-113) = read_headers (:30-49) + an empty PreviousWindowRight.
+ * Takes ownership of `r` (also on failure).  The device context is created on `device` at the first decode, so
+ * opening and header access work without a GPU.  *err: HeaderReadError / OggReadError code. */
+lw_ogg_stream *lw_ogg_stream_open(lw_ogg_reader *r, int device, int *err);
+void lw_ogg_stream_close(lw_ogg_stream *s);
+/* pub fields ident_hdr / comment_hdr / setup_hdr (:72-74); owned by the stream, replaced at a chain boundary */
+const lw_ident *lw_ogg_stream_ident(const lw_ogg_stream *s);
+const lw_comment *lw_ogg_stream_comment(const lw_ogg_stream *s);
+const lw_setup *lw_ogg_stream_setup(const lw_ogg_stream *s);
+uint32_t lw_ogg_stream_serial(const lw_ogg_stream *s);                  /* stream_serial(), :288-290 */
+uint32_t lw_ogg_stream_link_index(const lw_ogg_stream *s);              /* chain boundaries crossed so far (0 = first link) */
+int lw_ogg_stream_last_absgp(const lw_ogg_stream *s, uint64_t *absgp); /* get_last_absgp(), :296-298: 1 = Some */
+/* read_dec_packet_generic<S> (:195-206; read_dec_packet :167, read_dec_packet_itl :183): decodes the next audio
+ * packet of the logical stream (chained streams re-initialise the context and prime it with their first audio
+ * packet, :120-151), truncates the last packet of the stream to the final granule position (:219-227) and tracks
+ * cur_absgp.  out: host memory for cap_elems elements, filled planar [ch][*n_samples] packed or interleaved.  LW_OK,
+ * LW_OGG_EOF (Ok(None)), or a VorbisError: AudioReadError (BadAudio), HeaderReadError (BadHeader), OggReadError
+ * (OggError) code.  LW_ERR_CAPACITY: cap_elems < channels << blocksize_1 of the CURRENT logical stream (it may just have
+ * changed at a chain boundary: re-read lw_ogg_stream_ident); the packet is kept for the next call. */
+int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t cap_elems, size_t *n_samples);
+/* Look-ahead queue (the batched form of the call above): reads up to max_packets audio
+ * packets of the current logical stream, decodes them with ONE batch (host entropy threads + one set of kernel
+ * launches) and applies the same truncation / granule bookkeeping packet by packet.  out receives the packets'
+ * blocks back to back; n_samples[i] / status[i] per packet (a packet that fails to decode has its AudioReadError in
+ * status[i] and no samples).  Stops early at the end of the stream and in front of a chain boundary.
+ * Returns LW_OK (also with *n_packets == 0 in front of a chain boundary: call lw_ogg_stream_read_dec_packet),
+ * LW_OGG_EOF when no packet is left, or an error. */
+int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out,
+		size_t cap_elems, uint32_t *n_samples, int32_t *status, size_t *n_packets);
+/* skip_samples_linear<S> (:244-283): *got_packet = 0 is (None, left); otherwise the decoded packet that contains the
+ * target is in out and *left samples of it remain to be skipped.  LW_ERR_CAPACITY as above: call again with
+ * to_skip = *left and a buffer for the current logical stream. */
+int lw_ogg_stream_skip_samples_linear(lw_ogg_stream *s, size_t to_skip, int fmt, void *out, size_t cap_elems,
+		size_t *n_samples, size_t *left, int *got_packet);
+/* seek_absgp_pg (:307-313) */
+int lw_ogg_stream_seek_absgp_pg(lw_ogg_stream *s, uint64_t absgp);
+/* into_inner (:111-113): gives the reader back and destroys the stream object */
+lw_ogg_reader *lw_ogg_stream_into_inner(lw_ogg_stream *s);
+
 /* Test hook for the host Huffman decoder (spec 3.2.1 codeword assignment; src/huffman_tree.rs:183-221):
  * returns 0 valid, 1 overspecified, 2 underpopulated, 3 invalid single entry; when valid and bits != NULL
  * decodes up to max_syms symbols. */

@@ -37,6 +37,20 @@ class PacketResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_samples", C.c_uint32), ("out_offset", C.c_uint64)]
 
 
+class OggPacket(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("stream_serial", C.c_uint32), ("absgp_page", C.c_uint64),
+                ("first_in_stream", C.c_uint8), ("last_in_stream", C.c_uint8), ("first_in_page", C.c_uint8),
+                ("last_in_page", C.c_uint8)]
+
+
+OGG_READ_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t)
+OGG_SEEK_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_int64, C.c_int)
+
+
+class OggIo(C.Structure):
+    _fields_ = [("read", OGG_READ_FN), ("seek", OGG_SEEK_FN), ("user", C.c_void_p)]
+
+
 def _sig(name, restype, argtypes):
     fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
     fn.restype = restype
@@ -90,6 +104,30 @@ SYMBOLS = {
     "lw_batch_tap": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, f32p, C.c_size_t]),
     "lw_batch_set_force_generic": (None, [C.c_void_p, C.c_int]),
     "lw_batch_last_kernels": (C.c_char_p, [C.c_void_p]),
+    "lw_ogg_reader_open_memory": (C.c_void_p, [C.c_char_p, C.c_size_t, C.c_int]),
+    "lw_ogg_reader_open_file": (C.c_void_p, [C.c_char_p, intp]),
+    "lw_ogg_reader_open_io": (C.c_void_p, [C.POINTER(OggIo)]),
+    "lw_ogg_reader_close": (None, [C.c_void_p]),
+    "lw_ogg_read_packet": (C.c_int, [C.c_void_p, C.POINTER(OggPacket)]),
+    "lw_ogg_read_packet_expected": (C.c_int, [C.c_void_p, C.POINTER(OggPacket)]),
+    "lw_ogg_delete_unread_packets": (None, [C.c_void_p]),
+    "lw_ogg_seek_absgp": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64]),
+    "lw_ogg_crc32": (C.c_uint32, [C.c_char_p, C.c_size_t, C.c_uint32]),
+    "lw_ogg_stream_open": (C.c_void_p, [C.c_void_p, C.c_int, intp]),
+    "lw_ogg_stream_close": (None, [C.c_void_p]),
+    "lw_ogg_stream_into_inner": (C.c_void_p, [C.c_void_p]),
+    "lw_ogg_stream_ident": (C.c_void_p, [C.c_void_p]),
+    "lw_ogg_stream_comment": (C.c_void_p, [C.c_void_p]),
+    "lw_ogg_stream_setup": (C.c_void_p, [C.c_void_p]),
+    "lw_ogg_stream_serial": (C.c_uint32, [C.c_void_p]),
+    "lw_ogg_stream_link_index": (C.c_uint32, [C.c_void_p]),
+    "lw_ogg_stream_last_absgp": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "lw_ogg_stream_read_dec_packet": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, szp]),
+    "lw_ogg_stream_read_dec_packets": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                                 C.POINTER(C.c_uint32), C.POINTER(C.c_int32), szp]),
+    "lw_ogg_stream_skip_samples_linear": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, szp,
+                                                    intp]),
+    "lw_ogg_stream_seek_absgp_pg": (C.c_int, [C.c_void_p, C.c_uint64]),
 }
 
 for _n, (_r, _a) in SYMBOLS.items():
@@ -100,6 +138,8 @@ AUDIO_END_OF_PACKET, AUDIO_BAD_FORMAT, AUDIO_IS_HEADER, AUDIO_BUFFER_NOT_ADDRESS
 HDR_END_OF_PACKET, HDR_NOT_VORBIS, HDR_UNSUPPORTED_VERSION, HDR_BAD_FORMAT = 16, 17, 18, 19
 HDR_BAD_TYPE, HDR_IS_AUDIO, HDR_UTF8, HDR_BUFFER_NOT_ADDRESSABLE = 20, 21, 22, 23
 ERR_NULL_ARG, ERR_DEVICE, ERR_CAPACITY, ERR_STATE_MISMATCH = 32, 33, 34, 35
+OGG_EOF, OGG_NO_CAPTURE_PATTERN, OGG_INVALID_STREAM_STRUCT_VER, OGG_HASH_MISMATCH = 48, 49, 50, 51
+OGG_READ_ERROR, OGG_INVALID_DATA = 52, 53
 FMT_I16_PLANAR, FMT_I16_INTERLEAVED, FMT_F32_PLANAR = 0, 1, 2
 TAP_RESIDUE_PRE_INVERSE, TAP_RESIDUE_POST_INVERSE, TAP_PRE_MDCT, TAP_POST_MDCT = 0, 1, 2, 3
 

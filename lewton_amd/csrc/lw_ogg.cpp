@@ -1,0 +1,924 @@
+// Ogg container either side of the hot path: the page / packet demultiplexer lewton takes from the
+// external crate `ogg` 0.8.0 (restated from RFC 3533, the crate is not part of the reference tree) and lewton's own
+// `OggStreamReader` (src/inside_ogg.rs:30-314) on top of this library's packet decoder.  Host code only; everything
+// below the packet boundary goes through the public C ABI of include/lewton_amd.h.
+#include "../../include/lewton_amd.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// byte sources (the reference's `T: Read + Seek`)
+// ---------------------------------------------------------------------------------------------
+struct Source {
+	virtual ~Source() {}
+	virtual int64_t read(uint8_t *dst, size_t n) = 0; // bytes read, 0 at the end, < 0 on error
+	virtual int64_t seek(int64_t off, int whence) = 0; // new absolute position or < 0
+};
+
+struct MemSource : Source {
+	const uint8_t *p = nullptr;
+	size_t len = 0, pos = 0;
+	std::vector<uint8_t> own;
+	int64_t read(uint8_t *dst, size_t n) override
+	{
+		const size_t k = std::min(n, len - pos);
+		std::memcpy(dst, p + pos, k);
+		pos += k;
+		return (int64_t)k;
+	}
+	int64_t seek(int64_t off, int whence) override
+	{
+		const int64_t base = whence == 0 ? 0 : whence == 1 ? (int64_t)pos : (int64_t)len;
+		const int64_t np = base + off;
+		if (np < 0)
+			return -1;
+		pos = (size_t)std::min<int64_t>(np, (int64_t)len);
+		return (int64_t)pos;
+	}
+};
+
+struct FileSource : Source {
+	FILE *f = nullptr;
+	~FileSource() override
+	{
+		if (f)
+			std::fclose(f);
+	}
+	int64_t read(uint8_t *dst, size_t n) override
+	{
+		const size_t k = std::fread(dst, 1, n, f);
+		if (k < n && std::ferror(f))
+			return -1;
+		return (int64_t)k;
+	}
+	int64_t seek(int64_t off, int whence) override
+	{
+		if (fseeko(f, (off_t)off, whence == 0 ? SEEK_SET : whence == 1 ? SEEK_CUR : SEEK_END) != 0)
+			return -1;
+		return (int64_t)ftello(f);
+	}
+};
+
+struct IoSource : Source {
+	lw_ogg_io io{};
+	int64_t read(uint8_t *dst, size_t n) override { return io.read(io.user, dst, n); }
+	int64_t seek(int64_t off, int whence) override { return io.seek(io.user, off, whence); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// CRC of RFC 3533 section 6: polynomial 0x04c11db7, initial value 0, bits not reflected, no final xor
+// ---------------------------------------------------------------------------------------------
+struct CrcTable {
+	uint32_t t[256];
+	CrcTable()
+	{
+		for (uint32_t i = 0; i < 256; i++) {
+			uint32_t r = i << 24;
+			for (int k = 0; k < 8; k++)
+				r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : (r << 1);
+			t[i] = r;
+		}
+	}
+};
+const CrcTable kCrc;
+
+uint32_t crc_update(uint32_t crc, const uint8_t *d, size_t n)
+{
+	for (size_t i = 0; i < n; i++)
+		crc = (crc << 8) ^ kCrc.t[((crc >> 24) ^ d[i]) & 0xff];
+	return crc;
+}
+
+struct Page {
+	int64_t offset = 0; // of the capture pattern
+	size_t size = 0;    // header + lacing table + body
+	bool continued = false, bos = false, eos = false;
+	uint64_t absgp = 0;
+	uint32_t serial = 0, seq = 0;
+	std::vector<uint8_t> lacing, body;
+	bool completes_packet() const
+	{
+		for (uint8_t lv : lacing)
+			if (lv < 255)
+				return true;
+		return false;
+	}
+};
+
+struct QueuedPacket {
+	std::vector<uint8_t> data;
+	uint32_t serial = 0;
+	uint64_t absgp_page = 0;
+	bool first_in_stream = false, last_in_stream = false, first_in_page = false, last_in_page = false;
+};
+
+} // namespace
+
+struct lw_ogg_reader {
+	std::unique_ptr<Source> src;
+	int64_t pos = 0; // byte offset of the next page
+	std::unordered_map<uint32_t, std::vector<uint8_t>> partial; // per logical stream: packet continued on the next page
+	std::deque<QueuedPacket> queue;
+	QueuedPacket current; // storage behind the last lw_ogg_packet handed out
+
+	// reads exactly n bytes at the current source position; 0 ok, 1 clean end before the first byte, < 0 error
+	int read_exact(uint8_t *dst, size_t n)
+	{
+		size_t got = 0;
+		while (got < n) {
+			const int64_t k = src->read(dst + got, n - got);
+			if (k < 0)
+				return -1;
+			if (k == 0)
+				return got == 0 ? 1 : -1;
+			got += (size_t)k;
+		}
+		return 0;
+	}
+
+	// the page at byte offset `at`; LW_OK, LW_OGG_EOF (no byte left) or an OggReadError code
+	int read_page_at(int64_t at, Page &pg)
+	{
+		if (src->seek(at, 0) != at)
+			return LW_OGG_READ_ERROR;
+		uint8_t h[27 + 255];
+		int rc = read_exact(h, 27);
+		if (rc == 1)
+			return LW_OGG_EOF;
+		if (rc < 0)
+			return LW_OGG_READ_ERROR;
+		if (std::memcmp(h, "OggS", 4) != 0)
+			return LW_OGG_NO_CAPTURE_PATTERN;
+		if (h[4] != 0)
+			return LW_OGG_INVALID_STREAM_STRUCT_VER;
+		const uint8_t nseg = h[26];
+		if (nseg && read_exact(h + 27, nseg) != 0)
+			return LW_OGG_READ_ERROR;
+		size_t body = 0;
+		for (int i = 0; i < nseg; i++)
+			body += h[27 + i];
+		pg.body.resize(body);
+		if (body && read_exact(pg.body.data(), body) != 0)
+			return LW_OGG_READ_ERROR;
+		uint32_t stored;
+		std::memcpy(&stored, h + 22, 4); // little endian host (x86-64, the only host of this library)
+		std::memset(h + 22, 0, 4);
+		uint32_t crc = crc_update(0, h, 27 + (size_t)nseg);
+		crc = crc_update(crc, pg.body.data(), body);
+		if (crc != stored)
+			return LW_OGG_HASH_MISMATCH;
+		pg.offset = at;
+		pg.size = 27 + (size_t)nseg + body;
+		pg.continued = (h[5] & 1) != 0;
+		pg.bos = (h[5] & 2) != 0;
+		pg.eos = (h[5] & 4) != 0;
+		std::memcpy(&pg.absgp, h + 6, 8);
+		std::memcpy(&pg.serial, h + 14, 4);
+		std::memcpy(&pg.seq, h + 18, 4);
+		pg.lacing.assign(h + 27, h + 27 + nseg);
+		return LW_OK;
+	}
+
+	// splits the next page into packets (RFC 3533 section 5: a lacing value < 255 ends a packet)
+	int pump()
+	{
+		Page pg;
+		const int rc = read_page_at(pos, pg);
+		if (rc != LW_OK)
+			return rc;
+		pos = pg.offset + (int64_t)pg.size;
+		std::vector<uint8_t> buf;
+		bool have_start = true;
+		auto it = partial.find(pg.serial);
+		if (it != partial.end()) {
+			if (pg.continued)
+				buf.swap(it->second);
+			partial.erase(it); // an unfinished packet is dropped when the next page does not continue it
+		} else if (pg.continued) {
+			have_start = false; // continuation of a packet whose beginning was not seen (after a seek)
+		}
+		size_t o = 0, n_done = 0;
+		for (uint8_t lv : pg.lacing) {
+			if (have_start)
+				buf.insert(buf.end(), pg.body.begin() + o, pg.body.begin() + o + lv);
+			o += lv;
+			if (lv < 255) {
+				if (have_start) {
+					QueuedPacket q;
+					q.data.swap(buf);
+					q.serial = pg.serial;
+					q.absgp_page = pg.absgp;
+					q.first_in_page = n_done == 0;
+					q.first_in_stream = pg.bos && n_done == 0;
+					queue.push_back(std::move(q));
+					n_done++;
+				}
+				have_start = true;
+				buf.clear();
+			}
+		}
+		if (n_done) {
+			queue.back().last_in_page = true;
+			queue.back().last_in_stream = pg.eos;
+		}
+		if (!pg.lacing.empty() && pg.lacing.back() == 255 && have_start)
+			partial[pg.serial].swap(buf);
+		return LW_OK;
+	}
+
+	int next(lw_ogg_packet *out)
+	{
+		while (queue.empty()) {
+			const int rc = pump();
+			if (rc != LW_OK)
+				return rc;
+		}
+		current = std::move(queue.front());
+		queue.pop_front();
+		out->data = current.data.data();
+		out->len = current.data.size();
+		out->stream_serial = current.serial;
+		out->absgp_page = current.absgp_page;
+		out->first_in_stream = current.first_in_stream;
+		out->last_in_stream = current.last_in_stream;
+		out->first_in_page = current.first_in_page;
+		out->last_in_page = current.last_in_page;
+		return LW_OK;
+	}
+
+	void forget()
+	{
+		queue.clear();
+		partial.clear();
+	}
+
+	// first valid page at or after byte offset `from` and before `limit`; LW_OK / LW_OGG_EOF (none) / read error
+	int find_page(int64_t from, int64_t limit, Page &pg)
+	{
+		std::vector<uint8_t> win(65536 + 3);
+		int64_t at = from;
+		while (at < limit) {
+			if (src->seek(at, 0) != at)
+				return LW_OGG_READ_ERROR;
+			const size_t want = (size_t)std::min<int64_t>((int64_t)win.size(), limit + 3 - at);
+			size_t got = 0;
+			while (got < want) {
+				const int64_t k = src->read(win.data() + got, want - got);
+				if (k < 0)
+					return LW_OGG_READ_ERROR;
+				if (k == 0)
+					break;
+				got += (size_t)k;
+			}
+			if (got < 4)
+				return LW_OGG_EOF;
+			for (size_t i = 0; i + 4 <= got; i++) {
+				if (at + (int64_t)i >= limit)
+					return LW_OGG_EOF;
+				if (win[i] == 'O' && win[i + 1] == 'g' && win[i + 2] == 'g' && win[i + 3] == 'S') {
+					const int rc = read_page_at(at + (int64_t)i, pg);
+					if (rc == LW_OK)
+						return LW_OK;
+				}
+			}
+			at += (int64_t)got - 3;
+			if (got < want)
+				return LW_OGG_EOF;
+		}
+		return LW_OGG_EOF;
+	}
+
+	int seek_absgp(bool has_serial, uint32_t serial, uint64_t goal)
+	{
+		const int64_t size = src->seek(0, 2);
+		if (size < 0)
+			return LW_OGG_READ_ERROR;
+		auto matches = [&](const Page &pg) {
+			return (!has_serial || pg.serial == serial) && pg.absgp != ~0ull && pg.completes_packet();
+		};
+		// invariant: every matching page that starts before `lo` has absgp <= goal (best_end = end of the last of them);
+		// every matching page that starts at or after `hi` has absgp > goal.  Granule positions of one logical stream
+		// never decrease, which is what makes the bisection valid.
+		int64_t lo = 0, hi = size, best_end = 0;
+		Page pg;
+		while (hi - lo > 65536) {
+			const int64_t mid = lo + (hi - lo) / 2;
+			int64_t at = mid;
+			bool found = false;
+			for (;;) {
+				const int rc = find_page(at, hi, pg);
+				if (rc == LW_OGG_EOF)
+					break;
+				if (rc != LW_OK)
+					return rc;
+				if (matches(pg)) {
+					found = true;
+					break;
+				}
+				at = pg.offset + (int64_t)pg.size;
+			}
+			if (!found) {
+				hi = mid;
+			} else if (pg.absgp <= goal) {
+				lo = pg.offset + (int64_t)pg.size;
+				best_end = lo;
+			} else {
+				hi = mid;
+			}
+		}
+		int64_t at = lo;
+		for (;;) {
+			const int rc = find_page(at, hi, pg);
+			if (rc == LW_OGG_EOF)
+				break;
+			if (rc != LW_OK)
+				return rc;
+			if (matches(pg)) {
+				if (pg.absgp > goal)
+					break;
+				best_end = pg.offset + (int64_t)pg.size;
+			}
+			at = pg.offset + (int64_t)pg.size;
+		}
+		forget();
+		pos = best_end;
+		return LW_OK;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
+// OggStreamReader
+// ---------------------------------------------------------------------------------------------
+struct lw_ogg_stream {
+	lw_ogg_reader *rdr = nullptr;
+	int device = 0;
+	lw_ident *ident = nullptr;
+	lw_comment *comment = nullptr;
+	lw_setup *setup = nullptr;
+	lw_decoder *dec = nullptr; // created at the first decode
+	lw_pwr *pwr = nullptr;
+	lw_batch *batch = nullptr; // look-ahead queue
+	size_t batch_cap = 0;
+	int batch_fmt = -1;
+	uint32_t serial = 0;
+	uint32_t link = 0; // logical streams entered so far minus one
+	bool has_absgp = false;
+	uint64_t cur_absgp = 0;
+	// a packet read ahead by the look-ahead queue that belongs to the next call (chain boundary)
+	bool has_pending = false;
+	QueuedPacket pending;
+	// an audio packet of the current logical stream handed back because the caller's buffer was too small
+	bool has_retry = false;
+	QueuedPacket retry;
+	std::vector<uint8_t> scratch;
+	std::vector<QueuedPacket> ahead;
+	int deferred = LW_OK; // container error met by the look-ahead queue behind packets it still had to deliver
+
+	void drop_context()
+	{
+		if (batch)
+			lw_batch_destroy(batch);
+		batch = nullptr;
+		if (pwr)
+			lw_pwr_free(pwr);
+		pwr = nullptr;
+		if (dec)
+			lw_decoder_destroy(dec);
+		dec = nullptr;
+		if (ident)
+			lw_ident_free(ident);
+		if (comment)
+			lw_comment_free(comment);
+		if (setup)
+			lw_setup_free(setup);
+		ident = nullptr;
+		comment = nullptr;
+		setup = nullptr;
+	}
+
+	int ensure_decoder()
+	{
+		if (!dec) {
+			int e = 0;
+			dec = lw_decoder_create(ident, setup, device, &e);
+			if (!dec)
+				return e ? e : LW_ERR_DEVICE;
+		}
+		if (!pwr) {
+			pwr = lw_pwr_new(dec);
+			if (!pwr)
+				return LW_ERR_DEVICE;
+		}
+		return LW_OK;
+	}
+
+	void reset_pwr() // `self.pwr = PreviousWindowRight::new()`
+	{
+		if (pwr)
+			lw_pwr_reset(pwr);
+	}
+
+	static void take(const lw_ogg_packet &k, QueuedPacket &q)
+	{
+		q.data.assign(k.data, k.data + k.len);
+		q.serial = k.stream_serial;
+		q.absgp_page = k.absgp_page;
+		q.first_in_stream = k.first_in_stream;
+		q.last_in_stream = k.last_in_stream;
+		q.first_in_page = k.first_in_page;
+		q.last_in_page = k.last_in_page;
+	}
+
+	// the three header packets of a logical stream whose ident packet is `first` (inside_ogg.rs:30-49, :123-131)
+	int read_header_set(const QueuedPacket &first, bool skip_foreign, lw_ident **id, lw_comment **cm, lw_setup **st,
+			uint32_t *ser)
+	{
+		int e = 0;
+		*id = lw_read_header_ident(first.data.data(), first.data.size(), &e);
+		if (!*id)
+			return e;
+		lw_ogg_packet k;
+		auto next_of_stream = [&]() {
+			for (;;) {
+				const int rc = lw_ogg_read_packet_expected(rdr, &k);
+				if (rc != LW_OK)
+					return rc;
+				if (!skip_foreign || k.stream_serial == first.serial)
+					return (int)LW_OK;
+			}
+		};
+		int rc = next_of_stream();
+		if (rc == LW_OK) {
+			*cm = lw_read_header_comment(k.data, k.len, &e);
+			if (!*cm)
+				rc = e;
+		}
+		if (rc == LW_OK)
+			rc = next_of_stream();
+		if (rc == LW_OK) {
+			lw_ident_info info;
+			lw_ident_get_info(*id, &info);
+			*st = lw_read_header_setup(k.data, k.len, info.audio_channels, info.blocksize_0, info.blocksize_1, &e);
+			if (!*st)
+				rc = e;
+			*ser = k.stream_serial;
+		}
+		if (rc != LW_OK) {
+			if (*id)
+				lw_ident_free(*id);
+			if (*cm)
+				lw_comment_free(*cm);
+			*id = nullptr;
+			*cm = nullptr;
+		}
+		return rc;
+	}
+
+	// decode one packet of the current logical stream into `out` (cap_elems elements); planar blocks are packed [ch][m].
+	// A buffer that cannot hold a full block of the CURRENT logical stream (the stream may just have changed at a
+	// chain boundary) hands the packet back: LW_ERR_CAPACITY, nothing consumed.
+	int decode(QueuedPacket &q, int fmt, void *out, size_t cap_elems, size_t *m)
+	{
+		lw_ident_info info;
+		lw_ident_get_info(ident, &info);
+		const size_t cap = cap_elems / std::max<size_t>(info.audio_channels, 1);
+		if (cap < ((size_t)1 << info.blocksize_1)) {
+			retry = std::move(q);
+			has_retry = true;
+			return LW_ERR_CAPACITY;
+		}
+		if (int rc = ensure_decoder())
+			return rc;
+		return lw_read_audio_packet(dec, q.data.data(), q.data.size(), pwr, fmt, out, cap, m);
+	}
+
+	int decode_discard(const QueuedPacket &q) // "read the first audio packet to prime the pwr and discard the packet"
+	{
+		lw_ident_info info;
+		lw_ident_get_info(ident, &info);
+		const size_t cap = (size_t)1 << info.blocksize_1;
+		scratch.resize((size_t)info.audio_channels * cap * 2);
+		size_t m = 0;
+		if (int rc = ensure_decoder())
+			return rc;
+		return lw_read_audio_packet(dec, q.data.data(), q.data.size(), pwr, LW_FMT_I16_PLANAR, scratch.data(), cap, &m);
+	}
+
+	// read_next_audio_packet, inside_ogg.rs:114-160.  LW_OK + q, LW_OGG_EOF, or an error.
+	int next_audio(QueuedPacket &q)
+	{
+		if (has_retry) {
+			q = std::move(retry);
+			has_retry = false;
+			return LW_OK;
+		}
+		if (has_pending) {
+			q = std::move(pending);
+			has_pending = false;
+			if (q.serial == serial)
+				return LW_OK;
+			return chain(q);
+		}
+		for (;;) {
+			lw_ogg_packet k;
+			const int rc = lw_ogg_read_packet(rdr, &k);
+			if (rc != LW_OK)
+				return rc;
+			if (k.stream_serial == serial) {
+				take(k, q);
+				return LW_OK;
+			}
+			if (k.first_in_stream) {
+				take(k, q);
+				return chain(q);
+			}
+			// every packet with a mismatching stream serial is ignored
+		}
+	}
+
+	// chained file: q is the ident packet of the next logical stream (inside_ogg.rs:120-151)
+	int chain(QueuedPacket &q)
+	{
+		lw_ident *id = nullptr;
+		lw_comment *cm = nullptr;
+		lw_setup *st = nullptr;
+		uint32_t ser = 0;
+		if (int rc = read_header_set(q, false, &id, &cm, &st, &ser))
+			return rc;
+		drop_context();
+		ident = id;
+		comment = cm;
+		setup = st;
+		serial = ser;
+		link++;
+		has_absgp = false;
+		lw_ogg_packet k;
+		int rc = lw_ogg_read_packet(rdr, &k);
+		if (rc != LW_OK)
+			return rc; // LW_OGG_EOF = Ok(None)
+		take(k, q);
+		if ((rc = decode_discard(q)) != LW_OK)
+			return rc;
+		has_absgp = true;
+		cur_absgp = q.absgp_page;
+		rc = lw_ogg_read_packet(rdr, &k);
+		if (rc != LW_OK)
+			return rc;
+		take(k, q); // returned as is, whatever its serial (the reference does the same)
+		return LW_OK;
+	}
+
+	static void truncate(int fmt, int ch, void *out, size_t m, size_t target)
+	{
+		if (fmt == LW_FMT_I16_INTERLEAVED || target >= m)
+			return; // interleaved: the first target * ch elements are already in place
+		const size_t es = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
+		for (int c = 1; c < ch; c++)
+			std::memmove((char *)out + (size_t)c * target * es, (char *)out + (size_t)c * m * es, target * es);
+	}
+
+	// granule bookkeeping of dec_packet_generic (inside_ogg.rs:219-230) for a packet that decoded to m samples
+	size_t account(const QueuedPacket &q, int fmt, void *out, size_t m)
+	{
+		lw_ident_info info;
+		lw_ident_get_info(ident, &info);
+		if (has_absgp && q.last_in_stream) {
+			const uint64_t target = q.absgp_page >= cur_absgp ? q.absgp_page - cur_absgp : 0; // saturating_sub
+			if (target < m) {
+				if (out)
+					truncate(fmt, info.audio_channels, out, m, (size_t)target);
+				m = (size_t)target;
+			}
+		}
+		if (q.last_in_page) {
+			has_absgp = true;
+			cur_absgp = q.absgp_page;
+		} else if (has_absgp) {
+			cur_absgp += m;
+		}
+		return m;
+	}
+};
+
+extern "C" {
+
+uint32_t lw_ogg_crc32(const uint8_t *data, size_t len, uint32_t crc)
+{
+	return data ? crc_update(crc, data, len) : crc;
+}
+
+lw_ogg_reader *lw_ogg_reader_open_memory(const uint8_t *data, size_t len, int copy)
+{
+	if (!data && len)
+		return nullptr;
+	auto m = std::make_unique<MemSource>();
+	if (copy) {
+		m->own.assign(data, data + len);
+		m->p = m->own.data();
+	} else {
+		m->p = data;
+	}
+	m->len = len;
+	auto *r = new lw_ogg_reader();
+	r->src = std::move(m);
+	return r;
+}
+
+lw_ogg_reader *lw_ogg_reader_open_file(const char *path, int *err)
+{
+	FILE *f = path ? std::fopen(path, "rb") : nullptr;
+	if (!f) {
+		if (err)
+			*err = path ? LW_OGG_READ_ERROR : LW_ERR_NULL_ARG;
+		return nullptr;
+	}
+	auto s = std::make_unique<FileSource>();
+	s->f = f;
+	auto *r = new lw_ogg_reader();
+	r->src = std::move(s);
+	return r;
+}
+
+lw_ogg_reader *lw_ogg_reader_open_io(const lw_ogg_io *io)
+{
+	if (!io || !io->read || !io->seek)
+		return nullptr;
+	auto s = std::make_unique<IoSource>();
+	s->io = *io;
+	auto *r = new lw_ogg_reader();
+	r->src = std::move(s);
+	return r;
+}
+
+void lw_ogg_reader_close(lw_ogg_reader *r)
+{
+	delete r;
+}
+
+int lw_ogg_read_packet(lw_ogg_reader *r, lw_ogg_packet *out)
+{
+	if (!r || !out)
+		return LW_ERR_NULL_ARG;
+	return r->next(out);
+}
+
+int lw_ogg_read_packet_expected(lw_ogg_reader *r, lw_ogg_packet *out)
+{
+	const int rc = lw_ogg_read_packet(r, out);
+	return rc == LW_OGG_EOF ? LW_OGG_READ_ERROR : rc;
+}
+
+void lw_ogg_delete_unread_packets(lw_ogg_reader *r)
+{
+	if (r)
+		r->forget();
+}
+
+int lw_ogg_seek_absgp(lw_ogg_reader *r, int has_serial, uint32_t serial, uint64_t absgp)
+{
+	if (!r)
+		return LW_ERR_NULL_ARG;
+	return r->seek_absgp(has_serial != 0, serial, absgp);
+}
+
+lw_ogg_stream *lw_ogg_stream_open(lw_ogg_reader *r, int device, int *err)
+{
+	int dummy;
+	if (!err)
+		err = &dummy;
+	*err = LW_OK;
+	if (!r) {
+		*err = LW_ERR_NULL_ARG;
+		return nullptr;
+	}
+	auto *s = new lw_ogg_stream();
+	s->rdr = r;
+	s->device = device;
+	lw_ogg_packet k;
+	int rc = lw_ogg_read_packet_expected(r, &k);
+	if (rc == LW_OK) {
+		QueuedPacket first;
+		lw_ogg_stream::take(k, first);
+		rc = s->read_header_set(first, true, &s->ident, &s->comment, &s->setup, &s->serial);
+	}
+	if (rc != LW_OK) {
+		*err = rc;
+		lw_ogg_stream_close(s);
+		return nullptr;
+	}
+	lw_ogg_delete_unread_packets(r);
+	return s;
+}
+
+void lw_ogg_stream_close(lw_ogg_stream *s)
+{
+	if (!s)
+		return;
+	s->drop_context();
+	lw_ogg_reader_close(s->rdr);
+	delete s;
+}
+
+lw_ogg_reader *lw_ogg_stream_into_inner(lw_ogg_stream *s)
+{
+	if (!s)
+		return nullptr;
+	lw_ogg_reader *r = s->rdr;
+	s->rdr = nullptr;
+	lw_ogg_stream_close(s);
+	return r;
+}
+
+const lw_ident *lw_ogg_stream_ident(const lw_ogg_stream *s) { return s ? s->ident : nullptr; }
+const lw_comment *lw_ogg_stream_comment(const lw_ogg_stream *s) { return s ? s->comment : nullptr; }
+const lw_setup *lw_ogg_stream_setup(const lw_ogg_stream *s) { return s ? s->setup : nullptr; }
+uint32_t lw_ogg_stream_serial(const lw_ogg_stream *s) { return s ? s->serial : 0; }
+uint32_t lw_ogg_stream_link_index(const lw_ogg_stream *s) { return s ? s->link : 0; }
+
+int lw_ogg_stream_last_absgp(const lw_ogg_stream *s, uint64_t *absgp)
+{
+	if (!s || !s->has_absgp)
+		return 0;
+	if (absgp)
+		*absgp = s->cur_absgp;
+	return 1;
+}
+
+int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t cap_elems, size_t *n_samples)
+{
+	if (!s || !out || !n_samples)
+		return LW_ERR_NULL_ARG;
+	QueuedPacket q;
+	if (int rc = s->next_audio(q))
+		return rc;
+	size_t m = 0;
+	if (int rc = s->decode(q, fmt, out, cap_elems, &m))
+		return rc;
+	*n_samples = s->account(q, fmt, out, m);
+	return LW_OK;
+}
+
+int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out,
+		size_t cap_elems, uint32_t *n_samples, int32_t *status, size_t *n_packets)
+{
+	if (!s || !out || !n_samples || !status || !n_packets || max_packets == 0)
+		return LW_ERR_NULL_ARG;
+	*n_packets = 0;
+	if (s->deferred != LW_OK) {
+		const int rc = s->deferred;
+		s->deferred = LW_OK;
+		return rc;
+	}
+	// collect: packets of the current logical stream, stopping in front of a chain boundary
+	s->ahead.clear();
+	bool eof = false;
+	while (s->ahead.size() < max_packets) {
+		QueuedPacket q;
+		if (s->has_pending) {
+			if (s->pending.serial != s->serial)
+				break;
+			q = std::move(s->pending);
+			s->has_pending = false;
+		} else {
+			lw_ogg_packet k;
+			const int rc = lw_ogg_read_packet(s->rdr, &k);
+			if (rc == LW_OGG_EOF) {
+				eof = true;
+				break;
+			}
+			if (rc != LW_OK) {
+				if (s->ahead.empty())
+					return rc;
+				s->deferred = rc; // deliver what was read, report the error on the next call
+				break;
+			}
+			if (k.stream_serial != s->serial) {
+				if (k.first_in_stream) {
+					lw_ogg_stream::take(k, s->pending);
+					s->has_pending = true;
+					break;
+				}
+				continue;
+			}
+			lw_ogg_stream::take(k, q);
+		}
+		s->ahead.push_back(std::move(q));
+	}
+	if (s->ahead.empty())
+		return eof ? LW_OGG_EOF : LW_OK;
+	if (int rc = s->ensure_decoder())
+		return rc;
+	if (!s->batch || s->batch_cap < s->ahead.size() || s->batch_fmt != fmt) {
+		if (s->batch)
+			lw_batch_destroy(s->batch);
+		int e = 0;
+		s->batch_cap = std::max(max_packets, s->ahead.size());
+		s->batch_fmt = fmt;
+		s->batch = lw_batch_create(s->dec, s->batch_cap, fmt, &e);
+		if (!s->batch)
+			return e ? e : LW_ERR_DEVICE;
+	}
+	std::vector<lw_packet> pk(s->ahead.size());
+	for (size_t i = 0; i < pk.size(); i++)
+		pk[i] = lw_packet{s->ahead[i].data.data(), s->ahead[i].data.size(), s->pwr};
+	if (int rc = lw_batch_entropy(s->batch, pk.data(), pk.size(), n_threads))
+		return rc;
+	const size_t total = lw_batch_out_elems(s->batch);
+	if (total > cap_elems)
+		return LW_ERR_CAPACITY;
+	if (int rc = lw_batch_upload(s->batch, nullptr))
+		return rc;
+	if (int rc = lw_batch_synth_to_host(s->batch, out, cap_elems, nullptr))
+		return rc;
+	// per packet: truncation of the stream's last packet and granule bookkeeping, then compact the blocks
+	const lw_packet_result *res = lw_batch_results(s->batch);
+	lw_ident_info info;
+	lw_ident_get_info(s->ident, &info);
+	const size_t es = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
+	size_t w = 0; // write cursor in elements
+	for (size_t i = 0; i < pk.size(); i++) {
+		status[i] = res[i].status;
+		size_t m = res[i].status == LW_OK ? res[i].n_samples : 0;
+		char *blk = (char *)out + res[i].out_offset * es;
+		if (res[i].status == LW_OK)
+			m = s->account(s->ahead[i], fmt, blk, res[i].n_samples);
+		n_samples[i] = (uint32_t)m;
+		const size_t elems = m * info.audio_channels;
+		if (elems && (char *)out + w * es != blk)
+			std::memmove((char *)out + w * es, blk, elems * es);
+		w += elems;
+	}
+	*n_packets = pk.size();
+	return LW_OK;
+}
+
+int lw_ogg_stream_skip_samples_linear(lw_ogg_stream *s, size_t to_skip, int fmt, void *out, size_t cap_elems,
+		size_t *n_samples, size_t *left, int *got_packet)
+{
+	if (!s || !out || !n_samples || !left || !got_packet)
+		return LW_ERR_NULL_ARG;
+	*got_packet = 0;
+	*n_samples = 0;
+	bool have_last = false;
+	QueuedPacket last, next;
+	for (;;) {
+		const int rc = s->next_audio(next);
+		if (rc == LW_OGG_EOF) {
+			*left = to_skip;
+			return LW_OK;
+		}
+		if (rc != LW_OK)
+			return rc;
+		size_t cnt = 0;
+		if (int e = lw_get_decoded_sample_count(s->ident, s->setup, next.data.data(), next.data.size(), &cnt))
+			return e;
+		if (s->has_absgp && next.last_in_stream) {
+			have_last = false;
+			const uint64_t target = next.absgp_page >= s->cur_absgp ? next.absgp_page - s->cur_absgp : 0;
+			cnt = (size_t)std::min<uint64_t>(cnt, target);
+		}
+		if (to_skip < cnt) {
+			if (have_last) {
+				s->reset_pwr();
+				if (int e = s->decode_discard(last))
+					return e;
+			}
+			size_t m = 0;
+			*left = to_skip; // on LW_ERR_CAPACITY: call again with this many samples and a larger buffer
+			if (int e = s->decode(next, fmt, out, cap_elems, &m))
+				return e;
+			*n_samples = s->account(next, fmt, out, m);
+			*got_packet = 1;
+			return LW_OK;
+		}
+		to_skip -= cnt;
+		if (s->has_absgp)
+			s->cur_absgp += cnt;
+		last = std::move(next);
+		have_last = true;
+	}
+}
+
+int lw_ogg_stream_seek_absgp_pg(lw_ogg_stream *s, uint64_t absgp)
+{
+	if (!s)
+		return LW_ERR_NULL_ARG;
+	s->has_pending = false;
+	s->has_retry = false;
+	if (int rc = lw_ogg_seek_absgp(s->rdr, 0, 0, absgp))
+		return rc;
+	s->has_absgp = false;
+	s->reset_pwr();
+	return LW_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,188 @@
+"""Ogg layer, GPU part: lewton_amd.inside_ogg.OggStreamReader (C++ host layer + HIP decode path) against the
+oracle's OggStreamReader (oracle/pyogg.py over oracle/lewton_oracle.c) -- i16 bit-exact, f32 within 1e-5 --
+on a real Ogg/Vorbis file and on synthetic / chained / trimmed streams (inside_ogg.rs:114-313)."""
+import os
+
+import numpy as np
+import pytest
+
+from common import SETUPS, sg
+from lewton_amd import inside_ogg as IO
+from lewton_amd import ogg
+from oracle import pyogg
+from oracle import pyoracle as po
+from test_ogg import GOLDEN, _vorbis_stream
+
+pytestmark = pytest.mark.gpu
+
+_OFMT = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}
+
+
+def _same(a, b, fmt):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if fmt == "f32":
+        assert np.max(np.abs(a - b), initial=0.0) <= 1e-5   # north_star tolerance for f32 output
+    else:
+        assert np.array_equal(a, b)
+
+
+def _drain(data, fmt):
+    s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data, _OFMT[fmt])
+    n = 0
+    while True:
+        a, b = s.read_dec_packet_generic(fmt), o.read_dec_packet()
+        assert (a is None) == (b is None), n
+        if a is None:
+            break
+        _same(a, b, fmt)
+        assert s.get_last_absgp() == o.get_last_absgp() and s.stream_serial() == o.stream_serial
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_real_file_matches_oracle(fmt):
+    data = open(GOLDEN, "rb").read()
+    assert _drain(data, fmt) == 26
+    # plausibility figures of SURVEY 8(c): a clean fading-in tone, 4 short then long blocks
+    s = IO.OggStreamReader(data)
+    pk = []
+    while True:
+        p = s.read_dec_packet()
+        if p is None:
+            break
+        pk.append(p)
+    assert [p.shape[1] for p in pk] == [0, 128, 128, 128, 576] + [1024] * 21
+    x = np.concatenate(pk, axis=1)
+    assert list(x[0][x[0] != 0][:12]) == [1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3]
+    assert abs(np.abs(x).max() / 32768 - 0.6178) < 1e-4
+
+
+@pytest.mark.parametrize("name,pattern,count,per_page,trim", [
+    ("stereo", "LSSL", 24, 5, 0), ("stereo", "L", 20, 3, 700), ("surround51", "LLSSSL", 18, 4, 37),
+    ("mono_small", "SL", 15, 1, 5), ("stereo", "S", 9, 2, 127)])
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_synthetic_stream_with_final_trim(name, pattern, count, per_page, trim, fmt):
+    # the last packet is truncated so that the stream ends at the final granule position (inside_ogg.rs:219-227)
+    _setup, pk, w = _vorbis_stream(name, pattern, count, per_page=per_page, trim=trim)
+    assert _drain(w.bytes(), fmt) == count
+
+
+def _chained():
+    parts = []
+    for k, (name, pattern, count, trim) in enumerate([("stereo", "LSL", 9, 11), ("surround51", "L", 6, 0),
+                                                      ("mono_small", "SLL", 7, 3)]):
+        parts.append(_vorbis_stream(name, pattern, count, seed=20 + k, serial=0x100 + k, per_page=2, trim=trim)[2].bytes())
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("fmt", ["i16", "f32"])
+def test_chained_streams_reinitialise_the_context(fmt):
+    data = _chained()
+    s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data, _OFMT[fmt])
+    serials, chans = [], []
+    while True:
+        a, b = s.read_dec_packet_generic(fmt), o.read_dec_packet()
+        assert (a is None) == (b is None)
+        if a is None:
+            break
+        _same(a, b, fmt)
+        assert s.get_last_absgp() == o.get_last_absgp()
+        if not serials or serials[-1] != s.stream_serial():
+            serials.append(s.stream_serial())
+            chans.append(s.ident_hdr.audio_channels)
+    assert serials == [0x100, 0x101, 0x102] and chans == [2, 6, 1]
+
+
+@pytest.mark.parametrize("max_packets", [1, 4, 64])
+def test_look_ahead_queue_equals_packet_by_packet(max_packets):
+    for data in (open(GOLDEN, "rb").read(), _chained(), _vorbis_stream("stereo", "LLSL", 40, per_page=7, trim=300)[2].bytes()):
+        one = IO.OggStreamReader(data)
+        ref = []
+        while True:
+            p = one.read_dec_packet()
+            if p is None:
+                break
+            ref.append(p)
+        s = IO.OggStreamReader(data)
+        got = []
+        while True:
+            r = s.read_dec_packets(max_packets)
+            if r is None:
+                break
+            if not r:                      # chain boundary: cross it with the single-packet call
+                p = s.read_dec_packet()
+                if p is None:
+                    break
+                r = [p]
+            assert len(r) <= max_packets
+            got += r
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+        assert s.get_last_absgp() == one.get_last_absgp()
+
+
+@pytest.mark.parametrize("to_skip", [0, 1, 500, 1024, 5000, 9999, 10 ** 7])
+def test_skip_samples_linear(to_skip):
+    _setup, _pk, w = _vorbis_stream("stereo", "LSSLL", 30, per_page=4, trim=100)
+    data = w.bytes()
+    s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data)
+    s.read_dec_packet(), o.read_dec_packet()
+    (a, la), (b, lb) = s.skip_samples_linear(to_skip), o.skip_samples_linear(to_skip)
+    assert la == lb and (a is None) == (b is None)
+    if a is not None:
+        assert np.array_equal(a, b)
+    assert s.get_last_absgp() == o.get_last_absgp()
+    a, b = s.read_dec_packet(), o.read_dec_packet()      # and decoding carries on identically
+    assert (a is None) == (b is None)
+    if a is not None:
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("goal", [0, 3000, 12345, 10 ** 9])
+def test_seek_absgp_pg_then_decode(goal):
+    _setup, _pk, w = _vorbis_stream("stereo", "LLSL", 40, per_page=3)
+    data = w.bytes()
+    s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data)
+    for _ in range(5):
+        s.read_dec_packet(), o.read_dec_packet()
+    s.seek_absgp_pg(goal), o.seek_absgp_pg(goal)
+    assert s.get_last_absgp() is None
+    first = True
+    while True:
+        a, b = s.read_dec_packet(), o.read_dec_packet()
+        assert (a is None) == (b is None)
+        if a is None:
+            break
+        if first and goal > 0:
+            assert a.shape[1] == 0        # the window state was reset: the first packet after a seek only primes it
+        first = False
+        assert np.array_equal(a, b)
+        assert s.get_last_absgp() == o.get_last_absgp()
+        if s.get_last_absgp() is not None and goal < 10 ** 9:
+            pass
+    # page granularity: the position reached is <= the target
+    s.seek_absgp_pg(goal)
+    s.read_dec_packet()
+    while s.get_last_absgp() is None and s.read_dec_packet() is not None:
+        pass
+
+
+def test_bad_audio_packet_surfaces_as_bad_audio():
+    setup, pk, w0 = _vorbis_stream("stereo", "L", 4)
+    idp, cmt, stp = setup.headers()
+    w = ogg.PageWriter(5)
+    w.add_packet(idp, 0, flush=True)
+    w.add_packet(cmt, 0)
+    w.add_packet(stp, 0, flush=True)
+    w.add_packet(pk[0], 0)
+    w.add_packet(idp, 1024, flush=True, eos=True)        # a header packet where audio is expected
+    s, o = IO.OggStreamReader(w.bytes()), pyogg.OggStreamReader(w.bytes())
+    assert s.read_dec_packet().shape == (2, 0)
+    o.read_dec_packet()
+    with pytest.raises(IO.VorbisError) as e:
+        s.read_dec_packet()
+    with pytest.raises(pyogg.VorbisError) as eo:
+        o.read_dec_packet()
+    assert e.value.kind == eo.value.kind == "BadAudio" and e.value.code == eo.value.inner == po.AUDIO_IS_HEADER
