@@ -117,14 +117,15 @@ int lw_read_audio_packet(lw_decoder *d, const uint8_t *packet, size_t len, lw_pw
 /* ---- host entropy stage on its own (no GPU needed) ---------------------------------------- */
 /* The bit-serial half of read_audio_packet_generic (audio.rs:921-986 + floor-1 amplitude unwrap
  * :391-435): decodes one packet into the GPU-stage record.  floor_out: [ch][lw_setup_floor_stride()] u16
- * (ascending-x order; bits 0-7 = final_y*multiplier, bit 15 = active, entry 0 == 0xFFFF = unused floor);
- * residue_out: [ch][n/2] f32 before inverse coupling.  *blocksize_log2, *mode and *flags (bit 0 long, bit 1
+ * (ascending-x order; bits 0-7 = final_y*multiplier, bit 15 = active, entry 0 == 0xFFFF = unused floor, entry 0 ==
+ * 0xFFFE = floor 0: the curve of audio.rs:160-212 is in floor_curve_out [ch][n/2] f32, which may be NULL for setups
+ * without a floor of type 0); residue_out: [ch][n/2] f32 before inverse coupling.  *blocksize_log2, *mode and *flags (bit 0 long, bit 1
  * prev window flag, bit 2 next window flag) describe the packet; *bits_consumed = position of the bit
  * cursor afterwards. */
 uint32_t lw_setup_floor_stride(const lw_setup *s);
 int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len,
 		uint16_t *floor_out, float *residue_out, size_t residue_cap_floats, uint8_t *blocksize_log2, uint8_t *mode,
-		uint8_t *flags, uint64_t *bits_consumed);
+		uint8_t *flags, uint64_t *bits_consumed, float *floor_curve_out);
 
 /* ---- batches ------------------------------------------------------------------------------ */
 typedef struct {

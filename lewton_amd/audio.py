@@ -135,19 +135,22 @@ def read_audio_packet(ident, setup, packet, pwr):
 
 
 def entropy_decode_host(ident, setup, packet):
-    """Host entropy stage only (no GPU): returns dict(floor=[ch][stride] u16, residue=[ch][n/2] f32, bs, mode, flags, bits)."""
+    """Host entropy stage only (no GPU): returns dict(floor=[ch][stride] u16, residue=[ch][n/2] f32, floor_curve=[ch][n/2] f32
+    (rows of floor-0 channels, record entry 0 == 0xFFFE), bs, mode, flags, bits)."""
     ch = ident.audio_channels
     stride = N.lw_setup_floor_stride(setup._h)
     floor = np.zeros((ch, stride), np.uint16)
     cap = ch * (1 << ident.blocksize_1) // 2
     res = np.zeros(cap, np.float32)
     bs, mode, flags, bits = C.c_uint8(0), C.c_uint8(0), C.c_uint8(0), C.c_uint64(0)
+    curve = np.zeros(cap, np.float32)
     pkt = bytes(packet)
     rc = N.lw_entropy_decode_host(ident._h, setup._h, pkt, len(pkt), floor.ctypes.data_as(N.u16p),
                                   res.ctypes.data_as(N.f32p), cap, C.byref(bs), C.byref(mode), C.byref(flags),
-                                  C.byref(bits))
+                                  C.byref(bits), curve.ctypes.data_as(N.f32p))
     if rc:
         raise AudioReadError(rc)
     half = (1 << bs.value) // 2
-    return dict(floor=floor, residue=res[: ch * half].reshape(ch, half).copy(), bs=bs.value, mode=mode.value,
+    return dict(floor=floor, residue=res[: ch * half].reshape(ch, half).copy(),
+                floor_curve=curve[: ch * half].reshape(ch, half).copy(), bs=bs.value, mode=mode.value,
                 flags=flags.value, bits=bits.value)

@@ -2,6 +2,7 @@
 #include "lw_entropy.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace lw {
@@ -79,6 +80,76 @@ FloorResult floor_one_decode(BitReader &r, const Setup &s, const Floor1 &fl, uin
 		}
 	}
 	return FL_OK;
+}
+
+// floor_zero_decode, audio.rs:109-158: cosines of the LSP coefficients + amplitude.  Any bit-reader underrun is
+// "unused" (From<()> for FloorSpecialCase), a book number outside the list or a codebook without a VQ lookup is
+// "undecodable".
+FloorResult floor_zero_decode(BitReader &r, const Setup &s, const Floor0 &fl, float *coeff, uint64_t &amplitude)
+{
+	if (!r.read64(fl.amp_bits, amplitude) || amplitude == 0)
+		return FL_UNUSED;
+	uint32_t booknumber;
+	if (!r.read(ilog(fl.n_books), booknumber))
+		return FL_UNUSED;
+	if (booknumber >= fl.n_books)
+		return FL_UNDECODABLE;
+	const Codebook &cb = s.codebooks[fl.book_list[booknumber]];
+	size_t n = 0;
+	float last = 0.0f;
+	for (;;) {
+		float last_new = last;
+		uint32_t idx;
+		if (!cb.huff.decode(r, idx))
+			return FL_UNUSED;
+		if (!cb.has_vq)
+			return FL_UNDECODABLE;
+		for (size_t d = 0; d < cb.dims; d++) {
+			const float e = cb.vq[(size_t)idx * cb.dims + d];
+			coeff[n++] = cosf(last + e);
+			last_new = e;
+			if (n == fl.order)
+				return FL_OK;
+		}
+		last += last_new;
+		if (n >= fl.order)
+			return FL_OK;
+	}
+}
+
+// floor_zero_compute_curve, audio.rs:160-212: one value per run of equal bark-map entries
+void floor_zero_curve(const float *cosc, uint64_t amplitude, const Floor0 &fl, bool blockflag, size_t n, float *out)
+{
+	const float *bark_cos = fl.bark_cos_omega[blockflag ? 1 : 0].data();
+	const float common = (float)amplitude * (float)fl.amp_offset / (float)((((uint64_t)1) << fl.amp_bits) - 1);
+	size_t i = 0;
+	while (i < n) {
+		const float cos_omega = bark_cos[i];
+		size_t p_ub, q_ub;
+		float p, q;
+		if (fl.order & 1) {
+			p_ub = ((size_t)fl.order - 3) / 2;
+			q_ub = ((size_t)fl.order - 1) / 2;
+			p = 1.0f - cos_omega * cos_omega;
+			q = 0.25f;
+		} else {
+			p_ub = q_ub = ((size_t)fl.order - 2) / 2;
+			p = (1.0f - cos_omega) / 2.0f;
+			q = (1.0f + cos_omega) / 2.0f;
+		}
+		for (size_t j = 0; j < p_ub + 1; j++) {
+			const float pm = cosc[2 * j + 1] - cos_omega;
+			p *= 4.0f * pm * pm;
+		}
+		for (size_t j = 0; j < q_ub + 1; j++) {
+			const float qm = cosc[2 * j] - cos_omega;
+			q *= 4.0f * qm * qm;
+		}
+		const float lfv = expf(0.11512925f * (common / sqrtf(p + q) - (float)fl.amp_offset));
+		do {
+			out[i++] = lfv;
+		} while (i < n && bark_cos[i] == cos_omega);
+	}
 }
 
 // audio.rs:354-367 with wrapping u32 arithmetic (release-mode Rust)
@@ -252,7 +323,7 @@ bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, c
 } // namespace
 
 int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t len, Prologue &p, uint16_t *floor_out,
-		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed)
+		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed, float *fcurve_out)
 {
 	BitReader r(pkt, len);
 	int rc = read_prologue(id, s, r, p);
@@ -266,8 +337,24 @@ int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t l
 	for (size_t c = 0; c < ch; c++) {
 		const Floor &fl = s.floors[map.submap_floor[map.mux[c]]];
 		uint16_t *rec = floor_out + c * fstride;
-		if (fl.type != 1)
-			return AUDIO_BAD_FORMAT; // floor 0 streams are rejected at decoder creation; defensive
+		if (fl.type == 0) {
+			if (!fcurve_out)
+				return AUDIO_BAD_FORMAT; // the caller did not provide room for explicit floor curves
+			float coeff[256 + 8];
+			uint64_t amplitude = 0;
+			const FloorResult fr = floor_zero_decode(r, s, fl.f0, coeff, amplitude);
+			if (fr == FL_UNDECODABLE)
+				return AUDIO_END_OF_PACKET;
+			if (fr == FL_UNUSED) {
+				rec[0] = LW_FLOOR_UNUSED;
+				no_residue[c] = true;
+			} else {
+				floor_zero_curve(coeff, amplitude, fl.f0, p.blockflag, half, fcurve_out + c * half);
+				rec[0] = LW_FLOOR_EXPLICIT;
+				no_residue[c] = false;
+			}
+			continue;
+		}
 		uint32_t y[LW_MAX_POSTS];
 		const FloorResult fr = floor_one_decode(r, s, fl.f1, y);
 		if (fr == FL_UNDECODABLE)

@@ -32,8 +32,11 @@ struct EntropyScratch {
 // Decodes floors and residues of one packet.
 //   floor_out   [ch][fstride] u16 records (see lw_records.h)
 //   residue_out [ch][n/2] f32, pre-decoupling
+//   fcurve_out  [ch][n/2] f32: floor-0 channels get their curve here (audio.rs:109-212; host libm); may be nullptr
+//               when the setup has no floor of type 0
 // Returns OK or an AudioReadError code (on error the outputs are unspecified).
 int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t len, Prologue &p, uint16_t *floor_out,
-		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed = nullptr);
+		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed = nullptr,
+		float *fcurve_out = nullptr);
 
 } // namespace lw

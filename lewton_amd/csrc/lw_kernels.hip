@@ -115,9 +115,10 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
 	const uint32_t fl = T.mode_floor[rec.mode * T.ch + c];
 	const bool unused = frec[0] == LW_FLOOR_UNUSED;
+	const bool explicit_curve = frec[0] == LW_FLOOR_EXPLICIT; // floor 0: curve evaluated by the host stage
 	if (tid == 0) {
 		int K = 0;
-		if (!unused) {
+		if (!unused && !explicit_curve) {
 			const uint32_t F = T.floor_F[fl];
 			for (uint32_t s = 0; s < F; s++) {
 				const uint16_t e = frec[s];
@@ -139,6 +140,8 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 		float f;
 		if (unused) {
 			f = 0.0f;
+		} else if (explicit_curve) {
+			f = B.fcurve[rec.res_off + c * n2 + k];
 		} else {
 			int lo = 0, hi = K - 1; // largest i with px[i] <= k
 			while (lo < hi) {

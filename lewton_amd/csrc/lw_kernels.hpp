@@ -35,6 +35,7 @@ struct LwBatchDev {
 	const LwPacketRec *recs;
 	const uint16_t *floors;
 	const float *residue;
+	const float *fcurve; // explicit floor curves (floor 0), layout of residue; nullptr when the setup has none
 	float *decoupled; // scratch [same layout as residue]
 	float *td;        // scratch: per packet [ch][n] time-domain blocks at float offset 2 * res_off
 	float *state;     // state pool [slots][2][ch][n1/2]

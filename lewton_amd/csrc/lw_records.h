@@ -5,7 +5,10 @@
 //   recs    [n_packets]                 LwPacketRec, 32 B each
 //   floor   [n_packets][ch][fstride]    u16 per floor-1 post in ascending-x order:
 //                                       bits 0-7 = final_y * multiplier (<= 255), bit 15 = post is active
-//                                       (step2 flag); entry 0 == 0xFFFF marks an unused floor (audio.rs:66-70)
+//                                       (step2 flag); entry 0 == 0xFFFF marks an unused floor (audio.rs:66-70);
+//                                       entry 0 == 0xFFFE: floor 0 -- the curve (audio.rs:160-212, transcendental,
+//                                       evaluated on the host) is given explicitly in `fcurve`
+//   fcurve  [same layout as residue]    f32 floor curve of floor-0 channels (allocated only for setups with a floor 0)
 //   residue [sum over packets ch*n/2]   f32, per packet [ch][n/2], BEFORE inverse coupling
 //                                       (the vectors of audio.rs:957-986, type-2 already de-interleaved)
 // Algorithmic bytes per packet: ch*(n/2)*4 + ch*F*2 + 16 in, ch*m*2 out.
@@ -15,6 +18,7 @@
 
 #define LW_MAX_POSTS 65       // header.rs:873
 #define LW_FLOOR_UNUSED 0xFFFFu
+#define LW_FLOOR_EXPLICIT 0xFFFEu
 #define LW_POST_ACTIVE 0x8000u
 
 // rec.flags

@@ -64,6 +64,7 @@ struct lw_decoder {
 	LwDevTables T{};
 	void *d_blob = nullptr; // one allocation holding every table
 	bool any_coupling = false;
+	bool any_floor0 = false; // some floor is of type 0: batches carry explicit floor curves
 	uint32_t max_posts = 2;
 	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
 	std::mutex mu;
@@ -93,6 +94,7 @@ struct lw_batch {
 	LwPacketRec *h_recs = nullptr;
 	uint16_t *h_floor = nullptr;
 	float *h_res = nullptr;
+	float *h_fcurve = nullptr, *d_fcurve = nullptr; // explicit floor curves (floor 0), layout of the residues
 	LwPacketRec *d_recs = nullptr;
 	uint16_t *d_floor = nullptr;
 	float *d_res = nullptr;
@@ -298,7 +300,7 @@ uint32_t lw_setup_floor_stride(const lw_setup *s)
 
 int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len, uint16_t *floor_out,
 		float *residue_out, size_t residue_cap_floats, uint8_t *blocksize_log2, uint8_t *mode, uint8_t *flags,
-		uint64_t *bits_consumed)
+		uint64_t *bits_consumed, float *floor_curve_out)
 {
 	if (!id || !s || !packet || !floor_out || !residue_out)
 		return LW_ERR_NULL_ARG;
@@ -311,7 +313,7 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 		return LW_ERR_CAPACITY;
 	lw::EntropyScratch scr;
 	rc = lw::entropy_decode(*id->p, *s->p, packet, len, p, floor_out, floor_stride_of(*s->p), residue_out, scr,
-			bits_consumed);
+			bits_consumed, floor_curve_out);
 	if (blocksize_log2)
 		*blocksize_log2 = p.bs;
 	if (mode)
@@ -379,14 +381,6 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	}
 	const lw::Ident &id = *idh->p;
 	const lw::Setup &s = *sh->p;
-	for (const auto &fl : s.floors) {
-		if (fl.type != 1) {
-			// floor 0 is "next" row f4 of the scope table; refuse loudly instead of decoding wrongly
-			*err = LW_ERR_UNSUPPORTED_STREAM;
-			g_dev_err = "floor type 0 streams are not supported by the device path yet";
-			return nullptr;
-		}
-	}
 	for (const auto &m : s.mappings)
 		if (m.mux.size() != id.channels) {
 			*err = LW_ERR_STATE_MISMATCH;
@@ -429,6 +423,8 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	std::vector<uint16_t> fx(nfl * LW_XSTRIDE, 0);
 	std::vector<uint8_t> fF(nfl, 0);
 	for (size_t f = 0; f < nfl; f++) {
+		if (s.floors[f].type == 0)
+			d->any_floor0 = true;
 		const lw::Floor1 &f1 = s.floors[f].f1;
 		fF[f] = (uint8_t)f1.sorted_x.size();
 		d->max_posts = std::max<uint32_t>(d->max_posts, (uint32_t)f1.sorted_x.size());
@@ -646,6 +642,9 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		hip_ok(hipHostMalloc((void **)&b->h_halo_items, max_packets * sizeof(LwFastItem)), "hipHostMalloc(halo items)") &&
 		hip_ok(hipMalloc((void **)&b->d_items, max_packets * sizeof(LwFastItem)), "hipMalloc(items)") &&
 		hip_ok(hipMalloc((void **)&b->d_halo_items, max_packets * sizeof(LwFastItem)), "hipMalloc(halo items)");
+	if (ok && d->any_floor0)
+		ok = hip_ok(hipHostMalloc((void **)&b->h_fcurve, res_b), "hipHostMalloc(floor curves)") &&
+			hip_ok(hipMalloc((void **)&b->d_fcurve, res_b), "hipMalloc(floor curves)");
 	if (!ok) {
 		*err = LW_ERR_DEVICE;
 		lw_batch_destroy(b.release());
@@ -667,13 +666,15 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_recs);
 	if (b->h_floor)
 		(void)hipHostFree(b->h_floor);
+	if (b->h_fcurve)
+		(void)hipHostFree(b->h_fcurve);
 	if (b->h_res)
 		(void)hipHostFree(b->h_res);
 	if (b->h_items)
 		(void)hipHostFree(b->h_items);
 	if (b->h_halo_items)
 		(void)hipHostFree(b->h_halo_items);
-	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
+	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_fcurve, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -766,7 +767,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 					continue;
 				LwPacketRec &r = b->h_recs[i];
 				b->status[i] = lw::entropy_decode(id, s, pkts[i].data, pkts[i].len, b->prologues[i],
-						b->h_floor + r.floor_off, (unsigned)fstride, b->h_res + r.res_off, scr);
+						b->h_floor + r.floor_off, (unsigned)fstride, b->h_res + r.res_off, scr, nullptr,
+						b->h_fcurve ? b->h_fcurve + r.res_off : nullptr);
 			}
 		}
 	};
@@ -857,7 +859,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		alg += (uint64_t)ch * (p.n / 2) * 4 + 16 + (uint64_t)res.n_samples * ch * esz;
 		for (size_t c = 0; c < ch; c++) {
 			const lw::Mapping &mp = s.mappings[s.modes[p.mode].mapping];
-			alg += (uint64_t)s.floors[mp.submap_floor[mp.mux[c]]].f1.x_list.size() * 2;
+			const lw::Floor &fl = s.floors[mp.submap_floor[mp.mux[c]]];
+			alg += fl.type == 0 ? (uint64_t)(p.n / 2) * 4 + 2 : (uint64_t)fl.f1.x_list.size() * 2; // explicit curve | posts
 		}
 		if (!(r.flags & LW_RF_FAST))
 			b->has_generic = true;
@@ -966,6 +969,8 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 				hipMemcpyHostToDevice, st));
 	if (b->res_floats)
 		HIP_TRY(hipMemcpyAsync(b->d_res, b->h_res, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
+	if (b->res_floats && b->d_fcurve)
+		HIP_TRY(hipMemcpyAsync(b->d_fcurve, b->h_fcurve, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
@@ -1001,6 +1006,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.recs = b->d_recs;
 	B.floors = b->d_floor;
 	B.residue = b->d_res;
+	B.fcurve = b->d_fcurve;
 	B.decoupled = b->d_decoupled;
 	B.td = b->d_td;
 	B.state = d->d_state;

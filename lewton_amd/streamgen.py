@@ -201,6 +201,7 @@ class Floor0:
     amplitude_bits: int
     amplitude_offset: int
     book_list: List[int]
+    amp_max: int = 0   # generator only: largest amplitude drawn (0 = the full range of amplitude_bits)
 
 
 @dataclass
@@ -577,6 +578,32 @@ def mono_setup(bs0: int = 6, bs1: int = 9, sample_rate: int = 8000) -> StreamSet
     return StreamSetup(1, sample_rate, bs0, bs1, books, [fl_short, fl_long], rs, maps, [Mode(0, 0), Mode(1, 1)])
 
 
+def floor0_setup(bs0: int = 7, bs1: int = 10, sample_rate: int = 22050, mixed: bool = False) -> StreamSetup:
+    """2 ch with floor type 0 (LSP, src/audio.rs:109-212): even order for short blocks, odd order and a two-book list for
+    long blocks.  `mixed`: short blocks use a floor 1 instead, so both floor kinds occur in one stream."""
+    books, ix = _std_books()
+    rng = np.random.default_rng(77)
+    # LSP angles: ascending within a vector, the last element advances the running offset (audio.rs:131-147), so the
+    # angles spread over (0, pi) for the orders used below and p + q stays away from zero
+    ix["lsp2"] = len(books)
+    books.append(vq_table_book(2, np.round(np.sort(rng.uniform(0.3, 0.8, (32, 2)), axis=1) * 64) / 64, delta=1 / 64))
+    ix["lsp3"] = len(books)
+    books.append(vq_table_book(3, np.round(np.sort(rng.uniform(0.3, 1.0, (64, 3)), axis=1) * 64) / 64, delta=1 / 64))
+    n0h, n1h = (1 << bs0) // 2, (1 << bs1) // 2
+    if mixed:
+        fl_short = _floor1([n0h // 2, n0h // 4, 3 * n0h // 4], bs0 - 1, 2, ix["y16"], ix["master8"], ix["y16"])
+    else:
+        fl_short = Floor0(order=8, rate=sample_rate, bark_map_size=n0h // 2, amplitude_bits=4, amplitude_offset=12,
+                          book_list=[ix["lsp2"]], amp_max=2)
+    fl_long = Floor0(order=9, rate=sample_rate, bark_map_size=n1h // 4, amplitude_bits=5, amplitude_offset=15,
+                     book_list=[ix["lsp3"], ix["lsp2"]], amp_max=2)
+    rs_short = Residue(2, 0, 2 * (n0h * 13 // 16), 16, 4, ix["class16"], _res_books(ix))
+    rs_long = Residue(1, 0, 800 * n1h // 1024, 32, 4, ix["class16"], _res_books(ix))
+    maps = [Mapping([(0, 1)], [0, 0], [0], [0]), Mapping([(0, 1)], [0, 0], [1], [1])]
+    return StreamSetup(2, sample_rate, bs0, bs1, books, [fl_short, fl_long], [rs_short, rs_long], maps,
+                       [Mode(0, 0), Mode(1, 1)])
+
+
 # --------------------------------------------------------------------------------------------
 # audio packet writer -- emits symbols in decode order (src/audio.rs:921-986; SURVEY 9.2)
 # --------------------------------------------------------------------------------------------
@@ -645,7 +672,8 @@ class PacketWriter:
         if self.rng.random() < self.p_unused:
             w.write(0, fl.amplitude_bits)
             return False
-        w.write(int(self.rng.integers(1, 1 << min(fl.amplitude_bits, 30))), fl.amplitude_bits)
+        hi = 1 << min(fl.amplitude_bits, 30)
+        w.write(int(self.rng.integers(1, min(hi, fl.amp_max + 1) if fl.amp_max else hi)), fl.amplitude_bits)
         bn = int(self.rng.integers(0, len(fl.book_list)))
         w.write(bn, ilog(len(fl.book_list)))
         cb_i = fl.book_list[bn]

@@ -20,6 +20,12 @@ SETUPS = {
     "stereo_6_13": lambda: sg.stereo_setup(bs0=6, bs1=13),
     "stereo_7_7": lambda: sg.stereo_setup(bs0=7, bs1=7),
 }
+# floor type 0: curve evaluated by the host stage, multiplied on the GPU
+FLOOR0_SETUPS = {
+    "floor0": lambda: sg.floor0_setup(),
+    "floor0_mixed": lambda: sg.floor0_setup(mixed=True),
+    "floor0_8_11": lambda: sg.floor0_setup(bs0=8, bs1=11, sample_rate=44100),
+}
 
 
 def oracle_headers(setup):

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from common import SETUPS, oracle_headers, po, sg
+from common import FLOOR0_SETUPS, SETUPS, oracle_headers, po, sg
 
 pytestmark = pytest.mark.gpu
 
@@ -64,14 +64,16 @@ def test_device_imdct_random_all_sizes(name):
 
 
 PATTERNS = {"stereo": "LLSSSSSSSSL", "stereo_t1": "LSLLS", "surround51": "LLSSL", "mono_small": "LSSLLSL",
-            "stereo_9_12": "LLSL", "stereo_6_13": "LSSL", "stereo_7_7": "LSLL"}
+            "stereo_9_12": "LLSL", "stereo_6_13": "LSSL", "stereo_7_7": "LSLL",
+            "floor0": "LLSSL", "floor0_mixed": "LSLLS", "floor0_8_11": "LLLSL"}
+ALL_SETUPS = dict(SETUPS, **FLOOR0_SETUPS)   # floor-0 streams: curve from the host stage, multiply + IMDCT on the GPU
 
 
-@pytest.mark.parametrize("name", sorted(SETUPS))
+@pytest.mark.parametrize("name", sorted(ALL_SETUPS))
 @pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
 def test_read_audio_packet_matches_oracle(name, fmt):
     """Drop-in call (audio.rs:919/1170), packet by packet with state carry, incl. unused floors and truncated packets."""
-    setup = SETUPS[name]()
+    setup = ALL_SETUPS[name]()
     audio, ident, st = _product(setup)
     o_id, o_st = oracle_headers(setup)
     pkts = sg.make_stream(setup, PATTERNS[name], 30, seed=21, p_floor_unused=0.1)
@@ -149,12 +151,12 @@ def test_pwr_clone_and_reset():
     assert audio.read_audio_packet(ident, st, pkts[5], pwr).shape[1] == 1024
 
 
-@pytest.mark.parametrize("name", ["stereo", "surround51", "mono_small"])
+@pytest.mark.parametrize("name", ["stereo", "surround51", "mono_small", "floor0", "floor0_mixed"])
 def test_batch_many_streams_matches_oracle(name):
     """Batched decode, several interleaved streams, state carried across two batches, taps at the record_*! points."""
     from lewton_amd import _native as N
     from lewton_amd.batch import Batch
-    setup = SETUPS[name]()
+    setup = ALL_SETUPS[name]()
     audio, ident, st = _product(setup)
     o_id, o_st = oracle_headers(setup)
     dec = audio.decoder_for(ident, st)

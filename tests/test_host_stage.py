@@ -188,3 +188,71 @@ def test_entropy_stage_corrupted_packets():
             n_ok += 1
             assert np.array_equal(rec["residue"].view(np.uint32), taps["residue_pre_inverse"].view(np.uint32))
     assert n_ok > 50
+
+
+# ---- floor type 0: the host stage evaluates the LSP curve (audio.rs:109-212) ---------------------
+from common import FLOOR0_SETUPS  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(FLOOR0_SETUPS))
+def test_floor0_host_curve_matches_oracle(name):
+    """spectrum = explicit floor curve x inverse-coupled residue must equal the oracle's pre-IMDCT tap bit for bit
+    (same libm calls in the same order on the same host)."""
+    setup = FLOOR0_SETUPS[name]()
+    idp, _cmt, stp = setup.headers()
+    ident, st = oracle_headers(setup)
+    hid = header.read_header_ident(idp)
+    hst = header.read_header_setup(stp, hid.audio_channels, (hid.blocksize_0, hid.blocksize_1))
+    pk = sg.make_stream(setup, "LSSLL", 30, seed=9, p_floor_unused=0.2)
+    pwr = po.Pwr()
+    n_explicit = n_unused = 0
+    for p in pk:
+        _out, taps = po.read_audio_packet(ident, st, p, pwr, "f32", taps=True)
+        e = audio.entropy_decode_host(hid, hst, p)
+        half = (1 << e["bs"]) // 2
+        assert np.array_equal(e["residue"], taps["residue_pre_inverse"])
+        mode = e["mode"]
+        for c in range(2):
+            kind = int(e["floor"][c, 0])
+            fl = setup.floors[setup.mappings[setup.modes[mode].mapping].submap_floor[0]]
+            if kind == 0xFFFF:
+                n_unused += 1
+                assert not taps["pre_mdct"][c].any()
+            elif isinstance(fl, sg.Floor0):
+                assert kind == 0xFFFE
+                n_explicit += 1
+                curve = e["floor_curve"][c]
+                assert np.all(np.isfinite(curve)) and np.all(curve > 0)
+                want = taps["pre_mdct"][c][:half]
+                got = (curve * taps["residue_post_inverse"][c][:half]).astype(np.float32)
+                assert np.array_equal(got, want)
+            else:
+                assert kind not in (0xFFFE, 0xFFFF)     # floor 1 record
+    assert n_explicit > 10 and n_unused > 0
+
+
+def test_floor0_undecodable_and_unused_semantics():
+    setup = FLOOR0_SETUPS["floor0"]()
+    idp, _cmt, stp = setup.headers()
+    ident, st = oracle_headers(setup)
+    hid = header.read_header_ident(idp)
+    hst = header.read_header_setup(stp, 2, (hid.blocksize_0, hid.blocksize_1))
+    # long block: mode 1, flags (1,1); amplitude 0 => unused (audio.rs:115-119); truncated after the amplitude => unused
+    for bits, want_kind in (([(0, 1), (1, 1), (1, 1), (1, 1), (0, 5), (0, 5)], 0xFFFF),):
+        w = sg.BitWriter()
+        for v, n in bits:
+            w.write(v, n)
+        pkt = w.bytes()
+        e = audio.entropy_decode_host(hid, hst, pkt)
+        assert int(e["floor"][0, 0]) == want_kind and int(e["floor"][1, 0]) == want_kind
+        assert po.read_audio_packet(ident, st, pkt, po.Pwr(), "f32").shape == (2, 0)
+    # book number outside the list (2 books -> ilog(2) = 2 bits, value 3): undecodable => EndOfPacket (audio.rs:122-124, :571)
+    w = sg.BitWriter()
+    for v, n in [(0, 1), (1, 1), (1, 1), (1, 1), (1, 5), (3, 2)]:
+        w.write(v, n)
+    pkt = w.bytes()
+    with pytest.raises(audio.AudioReadError) as e:
+        audio.entropy_decode_host(hid, hst, pkt)
+    with pytest.raises(po.OracleError) as eo:
+        po.read_audio_packet(ident, st, pkt, po.Pwr(), "f32")
+    assert e.value.code == eo.value.code == po.AUDIO_END_OF_PACKET
