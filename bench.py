@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--force-generic", action="store_true", help="time the generic kernels instead of the specialised one")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of hipGraph replay")
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed graph replays after the W warmup steps until the device clocks have settled")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group also for one process (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--streams", type=int, default=256,
                     help="logical streams per 4096-packet batch (each contributes 4096/streams consecutive packets)")
     args = ap.parse_args()
@@ -56,8 +60,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or args.force_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from lewton_amd import _native as N
     from lewton_amd import audio, header, streamgen as sg
@@ -112,15 +119,29 @@ def main():
     torch.cuda.synchronize()
     # One hipGraph holding N_BATCHES consecutive steps (launch-bound inner loop -> graph replay); the Python
     # interpreter would otherwise be the bottleneck at ~25 us per launch.
-    graph = None
+    graph = tail_graph = None
+    n_tail = args.steps % N_BATCHES
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for k in range(N_BATCHES):
                 step(args.warmup + k, cs)
+        if n_tail:  # K is not a multiple of the graph length: the remainder is its own graph, not eager launches
+            tail_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tail_graph):
+                cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for k in range(n_tail):
+                    step(args.warmup + k, cs)
         torch.cuda.synchronize()
-    if world > 1:
+        # untimed: let the device clocks settle (DVFS reaches its steady state only after tens of ms of load, far
+        # longer than W steps of 18 us); the timed region below is still exactly K steps
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(16):
+                graph.replay()
+            torch.cuda.synchronize()
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -131,18 +152,25 @@ def main():
         while k + N_BATCHES <= args.steps:
             graph.replay()
             k += N_BATCHES
+        if tail_graph is not None:
+            tail_graph.replay()
+            k += n_tail
     while k < args.steps:
         step(args.warmup + k, sptr)
         k += 1
     ev1.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     from lewton_amd import shard
-    elapsed = shard.max_elapsed(elapsed, dist if world > 1 else None, "cuda")
+    if args.force_dist and world == 1:  # run the collective of the N > 1 path once
+        chk = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+        assert float(chk.item()) == elapsed
+    elapsed = shard.max_elapsed(elapsed, dist if dist.is_initialized() else None, "cuda")
     # device time of the K steps on the launch stream (HIP events), per step
     launch_ms = ev0.elapsed_time(ev1) / args.steps
 
@@ -218,7 +246,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batches of 4096 synthetic 44.1 kHz stereo long-block (n=2048) "
                                    "packets per GPU = %d streams x %d consecutive packets, 8 batches rotated, records "
                                    "resident in HBM" % (S, per_stream),
-                       "streams_per_batch": S,
+                       "streams_per_batch": S, "untimed_clock_settle_ms": 0.0 if args.no_graph else args.settle_ms,
                        "packets_per_step": PACKETS_PER_BATCH, "channels": 2, "blocksize": 2048,
                        "output": "i16 planar", "kernels": kernels, "parity": parity,
                        "parallelism": "streams sharded across GPUs, no collectives"},
@@ -229,7 +257,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
