@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--force-generic", action="store_true", help="time the generic kernels instead of the specialised one")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of hipGraph replay")
+    ap.add_argument("--format", choices=["i16", "i16_interleaved", "f32"], default="i16",
+                    help="output sample format (the BASELINE metric is quoted on planar i16 = Vec<Vec<i16>>)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed graph replays after the W warmup steps until the device clocks have settled")
     ap.add_argument("--force-dist", action="store_true",
@@ -88,12 +90,12 @@ def main():
     for b in range(N_BATCHES):
         # prime every stream with one packet so that all 4096 packets of the batch yield samples
         spw = [audio.PreviousWindowRight() for _ in range(S)]
-        prime = Batch(dec, S, "i16")
+        prime = Batch(dec, S, args.format)
         prime.entropy([(pool[int(rng.integers(0, UNIQUE_PACKETS))], pw) for pw in spw])
         prime.upload(sptr)
         prime.synth_to_host(sptr)
         prime.close()
-        bt = Batch(dec, PACKETS_PER_BATCH, "i16")
+        bt = Batch(dec, PACKETS_PER_BATCH, args.format)
         if args.force_generic:
             bt.set_force_generic(True)
         order = rng.integers(0, UNIQUE_PACKETS, PACKETS_PER_BATCH)
@@ -102,13 +104,13 @@ def main():
         assert all(r[0] == 0 and r[1] == 1024 for r in res)
         pwr = spw
         bt.upload(sptr)
-        out = torch.empty(bt.out_elems, dtype=torch.int16, device="cuda")
+        out = torch.empty(bt.out_elems, dtype=torch.float32 if args.format == "f32" else torch.int16, device="cuda")
         batches.append(bt)
         outs.append(out)
         pwrs.append(pwr)
     torch.cuda.synchronize()
     alg_bytes = batches[0].algorithmic_bytes  # 12 420 B per stereo long packet
-    assert alg_bytes == PACKETS_PER_BATCH * 12420, alg_bytes
+    assert alg_bytes == PACKETS_PER_BATCH * (12420 + (4096 if args.format == "f32" else 0)), alg_bytes
 
     def step(k, sp):
         b = k % N_BATCHES
@@ -185,16 +187,18 @@ def main():
             # without the priming packet; instead check a fresh short stream end-to-end
             chk = [pool[i] for i in range(33)]
             pw, opw = audio.PreviousWindowRight(), po.Pwr()
-            bt = Batch(dec, 33, "i16")
+            bt = Batch(dec, 33, args.format)
             if args.force_generic:
                 bt.set_force_generic(True)
             bt.entropy([(p, pw) for p in chk])
             bt.upload(sptr)
             got = bt.split(bt.synth_to_host(sptr), 2)
             ok = True
+            ofmt = {"i16": "i16", "i16_interleaved": "i16_itl", "f32": "f32"}[args.format]
             for p, g in zip(chk, got):
-                ok &= bool(np.array_equal(g, po.read_audio_packet(o_id, o_st, p, opw, "i16")))
-            parity = "i16 bit-exact vs oracle (33 packets)" if ok else "MISMATCH"
+                w = po.read_audio_packet(o_id, o_st, p, opw, ofmt)
+                ok &= bool(np.array_equal(np.asarray(g).reshape(-1), np.asarray(w).reshape(-1)))
+            parity = "%s bit-exact vs oracle (33 packets)" % args.format if ok else "MISMATCH"
             kernels = bt.last_kernels
         except Exception as e:  # the oracle is only a checker here
             parity = "unchecked: %r" % (e,)
@@ -248,7 +252,7 @@ def main():
                                    "resident in HBM" % (S, per_stream),
                        "streams_per_batch": S, "untimed_clock_settle_ms": 0.0 if args.no_graph else args.settle_ms,
                        "packets_per_step": PACKETS_PER_BATCH, "channels": 2, "blocksize": 2048,
-                       "output": "i16 planar", "kernels": kernels, "parity": parity,
+                       "output": {"i16": "i16 planar", "i16_interleaved": "i16 interleaved", "f32": "f32 planar"}[args.format], "kernels": kernels, "parity": parity,
                        "parallelism": "streams sharded across GPUs, no collectives"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

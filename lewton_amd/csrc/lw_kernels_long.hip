@@ -1173,6 +1173,55 @@ __device__ __forceinline__ void store16_wt(void *p, float4_t v)
 #endif
 }
 
+// kernel-internal output format: LW_OUT_I16_INTERLEAVED of a 2-channel stream whose channels form ONE unit (a coupled pair)
+#define LW_OUT_I16_ITL_STEREO 3
+
+// ---- interleaved stereo (InterleavedSamples<i16>, samples.rs:48-78; `read_dec_packet_itl`): one channel's window +
+//      overlap-add + conversion, packed two samples per dword: D[g][h] = positions (p_g + 2h, p_g + 2h + 1), with
+//      p_0 = 4l, p_1 = 508 - 4l, p_2 = 512 + 4l, p_3 = 1020 - 4l
+__device__ __forceinline__ void ola_pack_i16(const char *img, uint32_t lane, const float2_t (&Rc)[2][4], const PrevHalf &h,
+		uint32_t (&D)[4][2])
+{
+	float2_t O[2][4];
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) {
+		const float4_t w0 = lds4(img + LWI_WIN, 32u * (64u * c2 + lane));
+		const float4_t w1 = lds4(img + LWI_WIN, 32u * (64u * c2 + lane) + 16u);
+		ola_block<true>(Rc[c2], h.pp[c2][0], h.pp[c2][1], w0, w1, O[c2]);
+	}
+	typedef short short2_t __attribute__((ext_vector_type(2)));
+	union {
+		short2_t s;
+		uint32_t u;
+	} a;
+#define LW_PKI(d, v0, v1) a.s = __builtin_amdgcn_cvt_pk_i16((int)(v0), (int)(v1)), d = a.u
+	LW_PKI(D[0][0], O[0][3].x, O[0][2].x);
+	LW_PKI(D[0][1], O[1][3].x, O[1][2].x);
+	LW_PKI(D[1][0], O[1][1].x, O[1][0].x);
+	LW_PKI(D[1][1], O[0][1].x, O[0][0].x);
+	LW_PKI(D[2][0], O[0][0].y, O[0][1].y);
+	LW_PKI(D[2][1], O[1][0].y, O[1][1].y);
+	LW_PKI(D[3][0], O[1][2].y, O[1][3].y);
+	LW_PKI(D[3][1], O[0][2].y, O[0][3].y);
+#undef LW_PKI
+}
+
+// (L, R) pairs of four consecutive positions = 16 contiguous bytes per group: 2 v_perm_b32 per dword pair, 4 stores
+__device__ __forceinline__ void store_interleaved2(const LwFastArgs &F, uint32_t lane, uint32_t out_off,
+		const uint32_t (&L)[4][2], const uint32_t (&R)[4][2])
+{
+	int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off;
+	const uint32_t pos[4] = {4u * lane, 508u - 4u * lane, 512u + 4u * lane, 1020u - 4u * lane};
+#pragma unroll
+	for (int g = 0; g < 4; g++) {
+		const uint32_t d0 = __builtin_amdgcn_perm(R[g][0], L[g][0], 0x05040100u); // (L[p], R[p])
+		const uint32_t d1 = __builtin_amdgcn_perm(R[g][0], L[g][0], 0x07060302u); // (L[p+1], R[p+1])
+		const uint32_t d2 = __builtin_amdgcn_perm(R[g][1], L[g][1], 0x05040100u);
+		const uint32_t d3 = __builtin_amdgcn_perm(R[g][1], L[g][1], 0x07060302u);
+		store16_wt(o + 2u * pos[g], float4_t{__uint_as_float(d0), __uint_as_float(d1), __uint_as_float(d2), __uint_as_float(d3)});
+	}
+}
+
 // ---- window + overlap-add (audio.rs:1116-1118), sample conversion (samples.rs:92-103), stores of one channel
 template <int FMT>
 __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, uint32_t lane, int chn,
@@ -1237,15 +1286,24 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 			store_pcm8(o + p3, a.u, b.u);
 			}
 		} else {
+			// any channel count: 2-byte stores at stride ch (the stereo case never gets here, see store_interleaved2)
+			typedef short short2_t __attribute__((ext_vector_type(2)));
 			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn;
-			const int g0[4] = {iq[0][3], iq[0][2], iq[1][3], iq[1][2]}, g1[4] = {iq[1][1], iq[1][0], iq[0][1], iq[0][0]};
-			const int g2[4] = {im[0][0], im[0][1], im[1][0], im[1][1]}, g3[4] = {im[1][2], im[1][3], im[0][2], im[0][3]};
+			const uint32_t pos[4] = {p0, p1, p2, p3};
+			const int lo[4][2] = {{iq[0][3], iq[1][3]}, {iq[1][1], iq[0][1]}, {im[0][0], im[1][0]}, {im[1][2], im[0][2]}};
+			const int hi[4][2] = {{iq[0][2], iq[1][2]}, {iq[1][0], iq[0][0]}, {im[0][1], im[1][1]}, {im[1][3], im[0][3]}};
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				o[(p0 + i) * F.ch] = (int16_t)min(max(g0[i], -32768), 32767);
-				o[(p1 + i) * F.ch] = (int16_t)min(max(g1[i], -32768), 32767);
-				o[(p2 + i) * F.ch] = (int16_t)min(max(g2[i], -32768), 32767);
-				o[(p3 + i) * F.ch] = (int16_t)min(max(g3[i], -32768), 32767);
+			for (int g = 0; g < 4; g++) {
+				uint32_t off = pos[g] * F.ch; // one running offset per group keeps the address registers few
+				asm volatile("" : "+v"(off));
+#pragma unroll
+				for (int h2 = 0; h2 < 2; h2++) {
+					const short2_t pk = __builtin_amdgcn_cvt_pk_i16(lo[g][h2], hi[g][h2]); // saturating = the reference's clamp
+					o[off] = pk.x;
+					off += F.ch;
+					o[off] = pk.y;
+					off += F.ch;
+				}
 			}
 		}
 	}
@@ -1513,16 +1571,34 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						cstride = 2048u;
 					}
 					LW_STAMP_NW(9);
+					if (FMT == LW_OUT_I16_ITL_STEREO) {
+						// 2-channel stream decoded as one channel pair: both channels of a sample position leave in one 16-byte store
+						uint32_t D[2][4][2];
 #pragma unroll
-					for (int c = 0; c < 2; c++)
-						if (c == 0 || two) {
+						for (int c = 0; c < 2; c++) {
 							PrevHalf ph;
 							if (src)
 								prev_from_lds(src + 2048 * c, lane, ph);
 							else
 								prev_from_global(g + (uint32_t)chn[c] * cstride, lane, ph);
-							ola_store<FMT>(F, img, lane, chn[c], it.out_off, R[c], ph);
+							ola_pack_i16(img, lane, R[c], ph, D[c]);
 						}
+						if (chn[0] == 0)
+							store_interleaved2(F, lane, it.out_off, D[0], D[1]);
+						else
+							store_interleaved2(F, lane, it.out_off, D[1], D[0]);
+					} else {
+#pragma unroll
+						for (int c = 0; c < 2; c++)
+							if (c == 0 || two) {
+								PrevHalf ph;
+								if (src)
+									prev_from_lds(src + 2048 * c, lane, ph);
+								else
+									prev_from_global(g + (uint32_t)chn[c] * cstride, lane, ph);
+								ola_store<FMT>(F, img, lane, chn[c], it.out_off, R[c], ph);
+							}
+					}
 					if (src) {
 						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 						lds_store_u32(LW_CNT_ACK(wprev), n_got);
@@ -1598,6 +1674,7 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_INTERLEAVED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_ITL_STEREO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_F32_PLANAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_done = true;
@@ -1620,6 +1697,8 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 		F.late_from = L.late_from;
 		if (fmt == LW_OUT_I16_PLANAR)
 			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, F);
+		else if (fmt == LW_OUT_I16_INTERLEAVED && F.ch == 2 && L.n_units == 1 && L.units[0].ch_b >= 0)
+			hipLaunchKernelGGL((k_long<LW_OUT_I16_ITL_STEREO, false>), dim3(grid), dim3(LW_WG), lds, st, F);
 		else if (fmt == LW_OUT_I16_INTERLEAVED)
 			hipLaunchKernelGGL((k_long<LW_OUT_I16_INTERLEAVED, false>), dim3(grid), dim3(LW_WG), lds, st, F);
 		else
