@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of hipGraph replay")
     ap.add_argument("--format", choices=["i16", "i16_interleaved", "f32"], default="i16",
                     help="output sample format (the BASELINE metric is quoted on planar i16 = Vec<Vec<i16>>)")
+    ap.add_argument("--device-vq", action="store_true",
+                    help="Tier B records: codeword symbols in HBM, inverse VQ in k_residue_vq before the synthesis kernel "
+                         "(not the BASELINE metric's record format; reported for the k_residue_vq kernel time)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed graph replays after the W warmup steps until the device clocks have settled")
     ap.add_argument("--force-dist", action="store_true",
@@ -96,6 +99,8 @@ def main():
         prime.synth_to_host(sptr)
         prime.close()
         bt = Batch(dec, PACKETS_PER_BATCH, args.format)
+        if args.device_vq:
+            assert bt.set_residue_on_device(True)
         if args.force_generic:
             bt.set_force_generic(True)
         order = rng.integers(0, UNIQUE_PACKETS, PACKETS_PER_BATCH)
@@ -188,6 +193,8 @@ def main():
             chk = [pool[i] for i in range(33)]
             pw, opw = audio.PreviousWindowRight(), po.Pwr()
             bt = Batch(dec, 33, args.format)
+            if args.device_vq:
+                bt.set_residue_on_device(True)
             if args.force_generic:
                 bt.set_force_generic(True)
             bt.entropy([(p, pw) for p in chk])

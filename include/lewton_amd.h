@@ -47,7 +47,8 @@ enum {
 	LW_ERR_NULL_ARG = 32,      /* like capi.rs:106-108 returning 1 */
 	LW_ERR_DEVICE = 33,        /* HIP error / no GPU; lw_last_device_error() has the text */
 	LW_ERR_CAPACITY = 34,      /* caller-provided buffer or batch too small */
-	LW_ERR_STATE_MISMATCH = 35 /* pwr belongs to another decoder (the reference panics, audio.rs:1086) */
+	LW_ERR_STATE_MISMATCH = 35, /* pwr belongs to another decoder (the reference panics, audio.rs:1086) */
+	LW_ERR_UNSUPPORTED = 36     /* an optional mode is not available for this stream (see the function's comment) */
 };
 
 /* Output sample formats = the `Samples` implementations of src/samples.rs */
@@ -166,6 +167,15 @@ uint64_t lw_batch_algorithmic_bytes(const lw_batch *b);
 int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats);
 /* Force the generic (any block size / window shape) kernels even where a specialised one applies. */
 void lw_batch_set_force_generic(lw_batch *b, int on);
+/* Where the residue inverse VQ runs.  Default (off): the host entropy stage adds the VQ vectors
+ * (audio.rs:587-618) and ships f32 residue vectors ([ch][n/2] per packet, 8 KiB for a stereo long block).  On: the host
+ * only decodes the codewords and ships one 8-byte symbol per codeword (2.5-5x fewer bytes over PCIe at usual bit rates);
+ * the additions and the type-2 de-interleave (:748-754) run in the k_residue_vq kernel, pass by pass in the
+ * reference's order, so the residue vectors are bit-identical.  Needs every residue book's dimension to divide its
+ * partition size (then no codeword crosses a partition end); otherwise LW_ERR_UNSUPPORTED and the batch stays in host
+ * mode -- lw_decoder_supports_device_vq says which (and why not). */
+int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why);
+int lw_batch_set_residue_on_device(lw_batch *b, int on);
 /* names of the kernels the last lw_batch_synth used, comma separated (introspection for tests/bench) */
 const char *lw_batch_last_kernels(const lw_batch *b);
 

@@ -104,6 +104,8 @@ SYMBOLS = {
     "lw_batch_tap": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, f32p, C.c_size_t]),
     "lw_batch_set_force_generic": (None, [C.c_void_p, C.c_int]),
     "lw_batch_last_kernels": (C.c_char_p, [C.c_void_p]),
+    "lw_decoder_supports_device_vq": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
+    "lw_batch_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_ogg_reader_open_memory": (C.c_void_p, [C.c_char_p, C.c_size_t, C.c_int]),
     "lw_ogg_reader_open_file": (C.c_void_p, [C.c_char_p, intp]),
     "lw_ogg_reader_open_io": (C.c_void_p, [C.POINTER(OggIo)]),
@@ -137,7 +139,7 @@ OK = 0
 AUDIO_END_OF_PACKET, AUDIO_BAD_FORMAT, AUDIO_IS_HEADER, AUDIO_BUFFER_NOT_ADDRESSABLE = 1, 2, 3, 4
 HDR_END_OF_PACKET, HDR_NOT_VORBIS, HDR_UNSUPPORTED_VERSION, HDR_BAD_FORMAT = 16, 17, 18, 19
 HDR_BAD_TYPE, HDR_IS_AUDIO, HDR_UTF8, HDR_BUFFER_NOT_ADDRESSABLE = 20, 21, 22, 23
-ERR_NULL_ARG, ERR_DEVICE, ERR_CAPACITY, ERR_STATE_MISMATCH = 32, 33, 34, 35
+ERR_NULL_ARG, ERR_DEVICE, ERR_CAPACITY, ERR_STATE_MISMATCH, ERR_UNSUPPORTED = 32, 33, 34, 35, 36
 OGG_EOF, OGG_NO_CAPTURE_PATTERN, OGG_INVALID_STREAM_STRUCT_VER, OGG_HASH_MISMATCH = 48, 49, 50, 51
 OGG_READ_ERROR, OGG_INVALID_DATA = 52, 53
 FMT_I16_PLANAR, FMT_I16_INTERLEAVED, FMT_F32_PLANAR = 0, 1, 2

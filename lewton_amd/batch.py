@@ -105,6 +105,16 @@ class Batch:
             raise RuntimeError("lw_batch_tap: %d %s" % (rc, N.device_error()))
         return out.reshape(ch, -1)
 
+    def set_residue_on_device(self, on=True):
+        """Tier B (lw_batch_set_residue_on_device): ship codeword symbols, run the inverse VQ in k_residue_vq.
+        Returns False (and stays in host mode) when the stream is not eligible."""
+        rc = N.lw_batch_set_residue_on_device(self._h, 1 if on else 0)
+        if rc == N.ERR_UNSUPPORTED:
+            return False
+        if rc:
+            raise RuntimeError("lw_batch_set_residue_on_device: %d %s" % (rc, N.device_error()))
+        return True
+
     def split(self, flat, channels):
         """Split the flat output of synth_to_host into per-packet arrays ([ch][m], or [m*ch] interleaved)."""
         out = []

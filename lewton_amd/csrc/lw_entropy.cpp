@@ -203,8 +203,9 @@ void floor_one_record(const uint32_t *y, const Floor1 &fl, uint16_t *rec)
 	}
 }
 
-// audio.rs:587-618
-inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len)
+// audio.rs:587-618.  With a sink the additions are recorded (coordinate `coord` of v[0]) instead of performed.
+inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len,
+		SymbolSink *sink, uint32_t coord, uint32_t book, unsigned pass)
 {
 	const unsigned dims = cb.dims;
 	uint32_t idx;
@@ -213,6 +214,10 @@ inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, uns
 		for (unsigned i = 0; i < step; i++) {
 			if (!cb.huff.decode(r, idx))
 				return false;
+			if (sink) {
+				sink->push(coord + i, book, idx, pass);
+				continue;
+			}
 			const float *e = &cb.vq[(size_t)idx * dims];
 			for (unsigned j = 0; j < dims; j++)
 				v[i + j * step] += e[j];
@@ -224,9 +229,13 @@ inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, uns
 				return false;
 			if ((size_t)i + dims > vec_len)
 				break;
-			const float *e = &cb.vq[(size_t)idx * dims];
-			for (unsigned j = 0; j < dims; j++)
-				v[i + j] += e[j];
+			if (sink) {
+				sink->push(coord + i, book, idx, pass);
+			} else {
+				const float *e = &cb.vq[(size_t)idx * dims];
+				for (unsigned j = 0; j < dims; j++)
+					v[i + j] += e[j];
+			}
 			i += dims;
 		}
 	}
@@ -235,7 +244,7 @@ inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, uns
 
 // audio.rs:620-717; `vectors` = ch * (cur_blocksize/2) zeros.  false = Err(()) (packet undecodable)
 bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_blocksize, const bool *dnd, size_t ch,
-		float *vectors, EntropyScratch &scr)
+		float *vectors, EntropyScratch &scr, SymbolSink *sink)
 {
 	const size_t actual = cur_blocksize / 2;
 	const size_t begin = std::min<size_t>(rs.begin, actual), end = std::min<size_t>(rs.end, actual);
@@ -276,7 +285,7 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 						continue;
 					const size_t offs = begin + pc * rs.partition_size;
 					if (!read_partition(r, s.codebooks[rb.val_i[pass]], rs.type, rs.partition_size,
-								vectors + j * actual + offs, actual - offs))
+								vectors + j * actual + offs, actual - offs, sink, (uint32_t)(j * actual + offs), rb.val_i[pass], pass))
 						return true;
 				}
 			}
@@ -287,12 +296,13 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 
 // audio.rs:722-760
 bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, const bool *dnd, size_t ch, float *out,
-		EntropyScratch &scr)
+		EntropyScratch &scr, SymbolSink *sink)
 {
 	const size_t half = n / 2;
-	std::memset(out, 0, sizeof(float) * ch * half);
+	if (!sink)
+		std::memset(out, 0, sizeof(float) * ch * half);
 	if (rs.type != 2)
-		return residue_inner(r, s, rs, n, dnd, ch, out, scr);
+		return residue_inner(r, s, rs, n, dnd, ch, out, scr, sink);
 	bool any = false;
 	for (size_t j = 0; j < ch; j++)
 		any |= !dnd[j];
@@ -301,9 +311,11 @@ bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, c
 	const size_t bs2 = (size_t)(uint16_t)((uint16_t)n * (uint16_t)ch); // `cur_blocksize * ch as u16` wraps (:745)
 	if (bs2 / 2 < ch * half)
 		return false; // wrapped: the reference panics slicing the short vector; report the packet as bad
-	scr.interleaved.assign(ch * half, 0.0f);
 	const bool one_dnd[1] = {false};
-	if (!residue_inner(r, s, rs, bs2, one_dnd, 1, scr.interleaved.data(), scr))
+	if (sink)
+		return residue_inner(r, s, rs, bs2, one_dnd, 1, nullptr, scr, sink); // de-interleaved by k_residue_vq
+	scr.interleaved.assign(ch * half, 0.0f);
+	if (!residue_inner(r, s, rs, bs2, one_dnd, 1, scr.interleaved.data(), scr, nullptr))
 		return false;
 	const float *v = scr.interleaved.data();
 	if (ch == 2) {
@@ -323,7 +335,8 @@ bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, c
 } // namespace
 
 int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t len, Prologue &p, uint16_t *floor_out,
-		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed, float *fcurve_out)
+		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed, float *fcurve_out,
+		SymbolSink *sink)
 {
 	BitReader r(pkt, len);
 	int rc = read_prologue(id, s, r, p);
@@ -386,16 +399,22 @@ int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t l
 			}
 		}
 		const Residue &rs = s.residues[map.submap_residue[sm]];
+		if (sink) { // Tier B: record the codewords; coordinates are relative to this submap's vector space
+			sink->submap = (uint32_t)sm;
+			if (sub_ch && !residue_decode(r, s, rs, p.n, dnd, sub_ch, nullptr, scr, sink))
+				return AUDIO_BAD_FORMAT;
+			continue;
+		}
 		// channels of a submap are usually contiguous and in order: decode straight into the output block
 		bool contiguous = sub_ch > 0;
 		for (size_t k = 1; k < sub_ch; k++)
 			contiguous &= chans[k] == chans[0] + k;
 		if (contiguous) {
-			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, residue_out + chans[0] * half, scr))
+			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, residue_out + chans[0] * half, scr, nullptr))
 				return AUDIO_BAD_FORMAT;
 		} else {
 			scr.sub.assign(sub_ch * half + 1, 0.0f);
-			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, scr.sub.data(), scr))
+			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, scr.sub.data(), scr, nullptr))
 				return AUDIO_BAD_FORMAT;
 			for (size_t k = 0; k < sub_ch; k++)
 				std::memcpy(residue_out + chans[k] * half, scr.sub.data() + k * half, sizeof(float) * half);
@@ -404,6 +423,69 @@ int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t l
 	if (bits_consumed)
 		*bits_consumed = r.pos;
 	return OK;
+}
+
+void SymbolSink::sort_by_pass(std::vector<uint64_t> &tmp)
+{
+	uint32_t cnt[9] = {0};
+	for (uint64_t o : ops)
+		cnt[((o >> 60) & 7u) + 1]++;
+	for (int p = 0; p < 8; p++)
+		cnt[p + 1] += cnt[p];
+	for (int p = 0; p < 9; p++)
+		pass_off[p] = cnt[p];
+	if (in_order)
+		return;
+	tmp.resize(ops.size());
+	uint32_t at[8];
+	for (int p = 0; p < 8; p++)
+		at[p] = cnt[p];
+	for (uint64_t o : ops)
+		tmp[at[(o >> 60) & 7u]++] = o; // stable: decode order is kept inside a pass
+	ops.swap(tmp);
+}
+
+bool symbols_supported(const Ident &id, const Setup &s, const char **why)
+{
+	const char *dummy;
+	if (!why)
+		why = &dummy;
+	*why = "";
+	if (s.codebooks.size() > 256) {
+		*why = "more than 256 codebooks";
+		return false;
+	}
+	for (const Mapping &mp : s.mappings)
+		if (mp.submap_floor.size() > 16) {
+			*why = "more than 16 submaps";
+			return false;
+		}
+	if ((size_t)id.channels * ((size_t)1 << id.bs1) / 2 * sizeof(float) > 64 * 1024) {
+		*why = "channels x blocksize_1 / 2 floats exceed the 64 KB accumulation buffer";
+		return false;
+	}
+	for (const Residue &rs : s.residues)
+		for (const ResidueBook &rb : rs.books)
+			for (unsigned pass = 0; pass < 8; pass++)
+				if (rb.vals_used & (1u << pass)) {
+					const Codebook &cb = s.codebooks[rb.val_i[pass]];
+					if (!cb.has_vq || cb.dims == 0 || rs.partition_size % cb.dims != 0) {
+						*why = "a residue book's dimension does not divide the partition size (or it has no VQ table)";
+						return false;
+					}
+					if (cb.dims != 1 && cb.dims != 2 && cb.dims != 4 && cb.dims != 8) {
+						*why = "a residue book's dimension is not 1, 2, 4 or 8";
+						return false;
+					}
+					// the device adds with LDS float atomics, which need not honour subnormals: with every table value 0 or
+					// >= 2^-100 in magnitude no operand and no partial sum of <= 8 passes can be subnormal
+					for (float v : cb.vq)
+						if (v != 0.0f && std::fabs(v) < 7.8886090522101181e-31f) {
+							*why = "a residue book has values below 2^-100";
+							return false;
+						}
+				}
+	return true;
 }
 
 } // namespace lw

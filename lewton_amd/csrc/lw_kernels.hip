@@ -19,6 +19,153 @@
 #define LW_BLOCK 256
 
 // ---------------------------------------------------------------------------------------------
+// Tier B: residue vectors from codeword symbols (audio.rs:587-618 additions, :748-754 de-interleave)
+// ---------------------------------------------------------------------------------------------
+// One WAVE per packet (like the long-block kernel), up to 16 packets per workgroup.  A packet's vectors are accumulated
+// in the wave's own LDS slice IN THE COORDINATES THE BITSTREAM USES (per submap: [sub_ch][n/2], or the interleaved
+// type-2 vector), so the elements of a codeword are consecutive words and need no address arithmetic; the mapping to
+// [channel][bin] (for type 2 the de-interleave of audio.rs:748-754) happens once, in the coalesced write-out.
+// A position receives at most one vector element per cascade pass (partitions are disjoint and, for eligible streams,
+// no codeword crosses a partition end), so inside a pass the lanes work on different symbols without conflicts, and the
+// passes follow each other in program order -- LDS operations of one wave execute in order, no barrier is needed --
+// so every bin sees exactly the reference's sequence 0.0 + e(pass 0) + e(pass 1) + ...
+// Bound: latency and instruction issue, not bandwidth.  Lane = symbol (coalesced 8-byte symbol loads, a whole chunk of
+// 1024 symbols in flight at once); rows of window u+1 are in flight while window u is added; the tables of the small books are copied to LDS (8..32-byte gathers out of 128-byte L2 lines
+// otherwise); all reads of a window go before its writes (element-by-element `acc[i] += v` serialises on possible
+// aliasing, LDS float atomics run at about a lane per clock: 48 / 61 us per 4096-packet batch).
+// A window may straddle pass boundaries: its lanes are then added pass by pass (symbols are sorted by pass).
+#define LW_VQ_DIMS 8 // codebook dimensions the device path accepts: 1, 2, 4, 8 (lw::symbols_supported)
+#define LW_VQ_WIN 16 // windows of 64 symbols per chunk (a stereo long block at 128 kbit/s has well under 1024 symbols)
+struct LwVqRow {
+	float2 v[LW_VQ_DIMS / 2];
+};
+
+// rows of the first `staged` floats of the pool come from the LDS copy, the others from L2
+__device__ __forceinline__ void vq_gather(const float *vq, const float *s_vq, uint32_t staged, const uint32_t *s_boff,
+		const uint16_t *s_bdims, bool valid, unsigned long long op, LwVqRow &row, uint32_t &dims)
+{
+	dims = 0;
+	if (!valid)
+		return;
+	const uint32_t book = ((uint32_t)op >> 24) & 0xffu, entry = (uint32_t)(op >> 32) & 0xffffffu;
+	dims = s_bdims[book];
+	const uint32_t at = s_boff[book] + entry * dims;
+	const bool in_lds = at + dims <= staged;
+	if (dims == 1) {
+		row.v[0].x = in_lds ? s_vq[at] : vq[at];
+		return;
+	}
+	// two explicit address spaces (ds_read / global_load under exec masks), not one generic pointer: flat loads wait on
+	// both memory counters and take the slow path to LDS
+	if (in_lds) {
+#pragma unroll
+		for (int q = 0; q < LW_VQ_DIMS / 2; q++)
+			if (2u * (uint32_t)q < dims)
+				row.v[q] = *reinterpret_cast<const float2 *>(s_vq + at + 2 * q);
+	} else {
+#pragma unroll
+		for (int q = 0; q < LW_VQ_DIMS / 2; q++)
+			if (2u * (uint32_t)q < dims)
+				row.v[q] = *reinterpret_cast<const float2 *>(vq + at + 2 * q);
+	}
+}
+
+__global__ void __launch_bounds__(1024) k_residue_vq(LwDevTables T, LwVqTables V, LwBatchDev B, uint32_t slice_floats,
+		uint32_t staged)
+{
+	extern __shared__ __attribute__((aligned(16))) float acc_all[];
+	__shared__ uint32_t s_boff[256];
+	__shared__ uint16_t s_bdims[256];
+	__shared__ LwSubmapDesc s_desc_all[16][16]; // [wave][submap] of the wave's packet mode
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
+	if (tid < 256) {
+		s_boff[tid] = V.book_off[tid];
+		s_bdims[tid] = V.book_dims[tid];
+	}
+	float *s_vq = acc_all + (size_t)waves * slice_floats; // LDS copy of the small VQ tables, behind the accumulation slices
+	for (uint32_t i = tid; i < staged / 4u; i += blockDim.x)
+		reinterpret_cast<float4 *>(s_vq)[i] = reinterpret_cast<const float4 *>(V.vq)[i];
+	const uint32_t pkt = blockIdx.x * waves + wave;
+	const bool have = pkt < B.n_packets;
+	LwPacketRec rec{};
+	if (have)
+		rec = B.recs[pkt];
+	const bool work = have && !(rec.flags & LW_RF_SKIP);
+	if (work && lane < 16)
+		s_desc_all[wave][lane] = V.submap[(uint32_t)rec.mode * 16u + lane];
+	__syncthreads();
+	if (!work)
+		return;
+	const LwSubmapDesc *s_desc = s_desc_all[wave];
+	float *acc = acc_all + (size_t)wave * slice_floats;
+	const uint32_t hshift = rec.bs - 1u, half = 1u << hshift, total = T.ch * half;
+	for (uint32_t i = lane; i < total; i += 64)
+		acc[i] = 0.0f;
+	const uint32_t *blk = B.sym + B.sym_off[pkt];
+	const unsigned long long *ops = reinterpret_cast<const unsigned long long *>(blk + 10);
+	const uint32_t n_ops = blk[8];
+	// A chunk = LW_VQ_WIN windows of 64 symbols: all its symbol loads are issued back to back (one HBM round trip per
+	// chunk -- s_waitcnt vmcnt counts in order, so a rolling prefetch of symbols would be waited for anyway whenever a
+	// younger row gather is), then the windows are processed from registers, the rows of window u+1 in flight while
+	// window u is added.
+	for (uint32_t base = 0; base < n_ops; base += 64u * LW_VQ_WIN) {
+		unsigned long long opq[LW_VQ_WIN];
+#pragma unroll
+		for (int u = 0; u < LW_VQ_WIN; u++) {
+			const uint32_t i = base + 64u * (uint32_t)u + lane;
+			opq[u] = i < n_ops ? ops[i] : 0ull;
+		}
+		LwVqRow row0, row1;
+		uint32_t dims0 = 0, dims1 = 0;
+		vq_gather(V.vq, s_vq, staged, s_boff, s_bdims, base + lane < n_ops, opq[0], row0, dims0);
+#pragma unroll
+		for (int u = 0; u < LW_VQ_WIN; u++) {
+			const uint32_t w0 = base + 64u * (uint32_t)u; // first symbol of this window
+			if (w0 >= n_ops)
+				break;
+			const unsigned long long op0 = opq[u];
+			if (u + 1 < LW_VQ_WIN)
+				vq_gather(V.vq, s_vq, staged, s_boff, s_bdims, w0 + 64u + lane < n_ops, opq[u + 1 < LW_VQ_WIN ? u + 1 : u], row1, dims1);
+			// ---- add this window, pass by pass
+			const uint32_t my_pass = (uint32_t)(op0 >> 60) & 7u;
+			const uint32_t last_lane = min(63u, n_ops - 1u - w0);
+			const uint32_t pmin = __builtin_amdgcn_readfirstlane(my_pass), pmax = __builtin_amdgcn_readlane(my_pass, last_lane);
+			const LwSubmapDesc d = s_desc[(uint32_t)(op0 >> 56) & 0xfu];
+			const uint32_t at = ((uint32_t)d.vbase_ch << hshift) + ((uint32_t)op0 & 0xffffffu);
+			uint32_t step = 1u;
+			if (__builtin_amdgcn_ballot_w64(d.type == 0 && dims0 != 0) != 0) // residue type 0 (strided vectors) is rare: keep
+				step = d.type == 0 && dims0 ? d.psize / dims0 : 1u;          // the division off the usual path
+			const float rv[LW_VQ_DIMS] = {row0.v[0].x, row0.v[0].y, row0.v[1].x, row0.v[1].y, row0.v[2].x, row0.v[2].y,
+				row0.v[3].x, row0.v[3].y};
+			for (uint32_t p = pmin; p <= pmax; p++) {
+				const bool mine = dims0 && my_pass == p;
+				float cur[LW_VQ_DIMS];
+#pragma unroll
+				for (int j = 0; j < LW_VQ_DIMS; j++)
+					cur[j] = mine && (uint32_t)j < dims0 ? acc[at + (uint32_t)j * step] : 0.0f;
+#pragma unroll
+				for (int j = 0; j < LW_VQ_DIMS; j++)
+					if (mine && (uint32_t)j < dims0)
+						acc[at + (uint32_t)j * step] = cur[j] + rv[j];
+			}
+			row0 = row1;
+			dims0 = dims1;
+		}
+	}
+	// ---- write-out: [channel][bin] <- accumulation coordinates
+	float *out = const_cast<float *>(B.residue) + rec.res_off;
+	const LwChanMap *chmap = V.chmap + (size_t)rec.mode * T.ch;
+	for (uint32_t c = 0; c < T.ch; c++) {
+		const LwChanMap m = chmap[c]; // uniform
+		const uint32_t vb = (uint32_t)m.vbase_ch << hshift;
+		for (uint32_t k = lane; k < half; k += 64) {
+			const uint32_t src = m.type == 2 ? vb + k * m.sub_ch + m.pos : vb + ((uint32_t)m.pos << hshift) + k;
+			out[c * half + k] = acc[src];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // inverse coupling
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(LW_BLOCK) k_decouple(LwDevTables T, LwBatchDev B, uint32_t skip_mask)
@@ -370,6 +517,30 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 	const size_t lds = (size_t)max_n * sizeof(float) + LW_XSTRIDE * 3 + 16;
 	hipLaunchKernelGGL(k_imdct_generic, dim3(B.n_packets * T.ch), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
 			any_coupling ? 1 : 0, skip_mask);
+}
+
+void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBatchDev &B, hipStream_t st, uint32_t max_n,
+		const uint32_t *book_ends, size_t n_book_ends)
+{
+	if (B.n_packets == 0)
+		return;
+	static bool once = false;
+	if (!once) {
+		once = true;
+		(void)hipFuncSetAttribute((const void *)k_residue_vq, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
+	}
+	const uint32_t budget = 36u * 1024u; // floats of dynamic LDS (144 KB; 8 KB of static tables beside it)
+	const uint32_t slice = ((T.ch * (max_n / 2)) + 3u) & ~3u; // floats per packet (<= 16384, lw::symbols_supported)
+	// at least 4 K floats are kept for VQ tables when the slices allow 8 or more waves anyway
+	uint32_t waves = std::max(1u, std::min(16u, budget / slice));
+	if (waves >= 8 && waves * slice + 4096u > budget)
+		waves = std::max(8u, (budget - 4096u) / slice);
+	uint32_t staged = 0; // whole book tables only, smallest first
+	for (size_t i = 0; i < n_book_ends && waves * slice + book_ends[i] <= budget; i++)
+		staged = book_ends[i];
+	staged &= ~3u;
+	const uint32_t grid = (B.n_packets + waves - 1) / waves;
+	hipLaunchKernelGGL(k_residue_vq, dim3(grid), dim3(64 * waves), (size_t)(waves * slice + staged) * 4, st, T, V, B, slice, staged);
 }
 
 void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast)

@@ -29,6 +29,31 @@ struct LwDevTables {
 	uint32_t state_chan_stride;   // n1 / 2
 };
 
+// Tier B: residue inverse VQ on the device
+struct LwSubmapDesc {
+	uint8_t type;      // residue type 0/1/2 of the submap
+	uint8_t sub_ch;    // channels in the submap
+	uint16_t psize;    // partition size
+	uint16_t vbase_ch; // channels in the submaps before this one: the submap's vector space starts at vbase_ch * n/2
+	uint16_t pad;
+};
+
+// where channel c of a mode finds its residue in the accumulation space of k_residue_vq
+struct LwChanMap {
+	uint8_t vbase_ch; // of the channel's submap
+	uint8_t sub_ch;   // channels in that submap
+	uint8_t pos;      // position of the channel inside the submap (mapping_mux order)
+	uint8_t type;     // residue type: 2 = interleaved vector (audio.rs:748-754), else [sub_ch][n/2]
+};
+
+struct LwVqTables {
+	const float *vq;            // dense VQ tables of all codebooks (header.rs:495-531), concatenated
+	const uint32_t *book_off;   // [256] float offset of a book's table in vq
+	const uint16_t *book_dims;  // [256]
+	const LwSubmapDesc *submap; // [n_modes][16]
+	const LwChanMap *chmap;     // [n_modes][ch]
+};
+
 enum LwOutFmt { LW_OUT_I16_PLANAR = 0, LW_OUT_I16_INTERLEAVED = 1, LW_OUT_F32_PLANAR = 2 };
 
 struct LwBatchDev {
@@ -36,6 +61,8 @@ struct LwBatchDev {
 	const uint16_t *floors;
 	const float *residue;
 	const float *fcurve; // explicit floor curves (floor 0), layout of residue; nullptr when the setup has none
+	const uint32_t *sym;     // Tier B: per packet 10 header words (9 pass offsets, pad) + 64-bit ops; nullptr for Tier A
+	const uint32_t *sym_off; // [n_packets] word offset of a packet's block in sym
 	float *decoupled; // scratch [same layout as residue]
 	float *td;        // scratch: per packet [ch][n] time-domain blocks at float offset 2 * res_off
 	float *state;     // state pool [slots][2][ch][n1/2]
@@ -47,6 +74,9 @@ struct LwBatchDev {
 // right halves for generic successors).
 void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
 		bool any_coupling, bool include_fast);
+// Tier B pre-pass: residue vectors from codeword symbols (writes B.residue)
+void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBatchDev &B, hipStream_t st, uint32_t max_n,
+		const uint32_t *book_ends, size_t n_book_ends);
 void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast);
 
 // Specialised long-block path (lw_kernels_long.hip): optional halo pre-pass + main pass.

@@ -65,6 +65,11 @@ struct lw_decoder {
 	void *d_blob = nullptr; // one allocation holding every table
 	bool any_coupling = false;
 	bool any_floor0 = false; // some floor is of type 0: batches carry explicit floor curves
+	bool symbols_ok = false; // Tier B (device-side inverse VQ) is possible for this stream
+	std::string symbols_why;
+	LwVqTables V{};
+	void *d_vq_blob = nullptr;
+	std::vector<uint32_t> vq_book_ends; // cumulative float offsets of the book tables in V.vq (ascending table size)
 	uint32_t max_posts = 2;
 	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
 	std::mutex mu;
@@ -95,6 +100,10 @@ struct lw_batch {
 	uint16_t *h_floor = nullptr;
 	float *h_res = nullptr;
 	float *h_fcurve = nullptr, *d_fcurve = nullptr; // explicit floor curves (floor 0), layout of the residues
+	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
+	bool symbols = false;
+	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
+	size_t sym_cap_words = 0, sym_words = 0;
 	LwPacketRec *d_recs = nullptr;
 	uint16_t *d_floor = nullptr;
 	float *d_res = nullptr;
@@ -485,6 +494,89 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	d->T.n_floors = (uint32_t)nfl;
 	d->T.state_chan_stride = (1u << id.bs1) / 2;
 	d->T.state_stride = d->T.ch * d->T.state_chan_stride;
+	// ---- Tier B tables: dense VQ tables, per-mode submap descriptors
+	{
+		const char *why = "";
+		d->symbols_ok = lw::symbols_supported(id, s, &why);
+		d->symbols_why = why;
+		if (d->symbols_ok) {
+			std::vector<uint8_t> vb;
+			auto putv = [&](const void *p, size_t bytes) {
+				const size_t off = (vb.size() + 255) & ~(size_t)255;
+				vb.resize(off + bytes);
+				std::memcpy(vb.data() + off, p, bytes);
+				return off;
+			};
+			// the tables of the books used by residues, smallest first: k_residue_vq stages a prefix of the pool in LDS (the
+			// gathers of 8..32 bytes out of 128-byte L2 lines are what bounds that kernel otherwise)
+			std::vector<float> pool;
+			std::vector<uint32_t> boff(256, 0);
+			std::vector<uint16_t> bdims(256, 0);
+			std::vector<bool> in_residue(s.codebooks.size(), false);
+			for (const lw::Residue &rs : s.residues)
+				for (const lw::ResidueBook &rb : rs.books)
+					for (unsigned pass = 0; pass < 8; pass++)
+						if (rb.vals_used & (1u << pass))
+							in_residue[rb.val_i[pass]] = true;
+			std::vector<size_t> order;
+			for (size_t k = 0; k < s.codebooks.size(); k++) {
+				bdims[k] = s.codebooks[k].dims;
+				if (s.codebooks[k].has_vq && in_residue[k])
+					order.push_back(k);
+			}
+			std::stable_sort(order.begin(), order.end(),
+					[&](size_t a, size_t b) { return s.codebooks[a].vq.size() < s.codebooks[b].vq.size(); });
+			d->vq_book_ends.clear();
+			for (size_t k : order) {
+				const lw::Codebook &cb = s.codebooks[k];
+				pool.resize((pool.size() + 3) & ~(size_t)3); // rows of 2 / 4 / 8 floats stay 8 / 16 / 32-byte aligned
+				boff[k] = (uint32_t)pool.size();
+				pool.insert(pool.end(), cb.vq.begin(), cb.vq.end());
+				d->vq_book_ends.push_back((uint32_t)pool.size());
+			}
+			if (pool.empty())
+				pool.push_back(0.0f);
+			std::vector<LwSubmapDesc> sd(nmodes * 16);
+			std::vector<LwChanMap> cm(nmodes * ch);
+			for (size_t m = 0; m < nmodes; m++) {
+				const lw::Mapping &mp = s.mappings[s.modes[m].mapping];
+				unsigned before = 0;
+				for (size_t sm = 0; sm < mp.submap_residue.size(); sm++) {
+					const lw::Residue &rs = s.residues[mp.submap_residue[sm]];
+					LwSubmapDesc &e = sd[m * 16 + sm];
+					e.type = rs.type;
+					e.psize = (uint16_t)rs.partition_size;
+					e.vbase_ch = (uint16_t)before;
+					e.pad = 0;
+					uint8_t n = 0;
+					for (size_t c = 0; c < ch; c++)
+						if (mp.mux[c] == sm)
+							n++;
+					e.sub_ch = n;
+					uint8_t pos = 0;
+					for (size_t c = 0; c < ch; c++)
+						if (mp.mux[c] == sm)
+							cm[m * ch + c] = LwChanMap{(uint8_t)before, n, pos++, rs.type};
+					before += n;
+				}
+			}
+			const size_t o_vq = putv(pool.data(), pool.size() * 4), o_bo = putv(boff.data(), boff.size() * 4);
+			const size_t o_bd = putv(bdims.data(), bdims.size() * 2), o_sd = putv(sd.data(), sd.size() * sizeof(LwSubmapDesc));
+			const size_t o_ch = putv(cm.data(), cm.size() * sizeof(LwChanMap));
+			if (!hip_ok(hipMalloc(&d->d_vq_blob, vb.size()), "hipMalloc(vq tables)") ||
+					!hip_ok(hipMemcpy(d->d_vq_blob, vb.data(), vb.size(), hipMemcpyHostToDevice), "hipMemcpy(vq tables)")) {
+				*err = LW_ERR_DEVICE;
+				(void)hipFree(d->d_blob);
+				return nullptr;
+			}
+			const uint8_t *vbase = (const uint8_t *)d->d_vq_blob;
+			d->V.vq = (const float *)(vbase + o_vq);
+			d->V.book_off = (const uint32_t *)(vbase + o_bo);
+			d->V.book_dims = (const uint16_t *)(vbase + o_bd);
+			d->V.submap = (const LwSubmapDesc *)(vbase + o_sd);
+			d->V.chmap = (const LwChanMap *)(vbase + o_ch);
+		}
+	}
 	lw::build_fast_plan(id, s, d->fast);
 	if (d->fast.eligible) {
 		std::memcpy(d->fast.image.data() + d->fast.off.inv_db, kInverseDbTable, sizeof(float) * 256);
@@ -516,6 +608,8 @@ void lw_decoder_destroy(lw_decoder *d)
 		(void)hipFree(d->d_state);
 	if (d->d_blob)
 		(void)hipFree(d->d_blob);
+	if (d->d_vq_blob)
+		(void)hipFree(d->d_vq_blob);
 	if (d->d_fast_image)
 		(void)hipFree(d->d_fast_image);
 	if (d->d_fast_units)
@@ -668,13 +762,17 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_floor);
 	if (b->h_fcurve)
 		(void)hipHostFree(b->h_fcurve);
+	if (b->h_sym)
+		(void)hipHostFree(b->h_sym);
+	if (b->h_sym_off)
+		(void)hipHostFree(b->h_sym_off);
 	if (b->h_res)
 		(void)hipHostFree(b->h_res);
 	if (b->h_items)
 		(void)hipHostFree(b->h_items);
 	if (b->h_halo_items)
 		(void)hipHostFree(b->h_halo_items);
-	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_fcurve, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
+	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_fcurve, b->d_sym, b->d_sym_off, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -685,6 +783,34 @@ void lw_batch_set_force_generic(lw_batch *b, int on)
 {
 	if (b)
 		b->force_generic = on != 0;
+}
+
+int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why)
+{
+	if (why)
+		*why = d ? d->symbols_why.c_str() : "";
+	return d && d->symbols_ok ? 1 : 0;
+}
+
+int lw_batch_set_residue_on_device(lw_batch *b, int on)
+{
+	if (!b)
+		return LW_ERR_NULL_ARG;
+	if (!on) {
+		b->symbols = false;
+		return LW_OK;
+	}
+	if (!b->dec->symbols_ok)
+		return LW_ERR_UNSUPPORTED;
+	if (int rc = decoder_set_device(b->dec))
+		return rc;
+	if (!b->h_sym_off) {
+		if (!hip_ok(hipHostMalloc((void **)&b->h_sym_off, b->max_packets * sizeof(uint32_t)), "hipHostMalloc(symbol offsets)") ||
+				!hip_ok(hipMalloc((void **)&b->d_sym_off, b->max_packets * sizeof(uint32_t)), "hipMalloc(symbol offsets)"))
+			return LW_ERR_DEVICE;
+	}
+	b->symbols = true;
+	return LW_OK;
 }
 
 size_t lw_batch_size(const lw_batch *b)
@@ -756,8 +882,23 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
 	nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n / 8));
 	std::atomic<size_t> next{0};
+	// Tier B: a worker reserves room for a packet's symbol block in the pinned pool with one atomic add once the packet
+	// is decoded (block sizes are not known before).  Blocks that no longer fit are parked in the worker's own arena and
+	// gathered after the pool has been enlarged (first batches only).
+	struct SymRef {
+		int32_t arena = -1; // -1: already in the pool at h_sym_off[i]
+		uint32_t off = 0, words = 0;
+	};
+	std::vector<SymRef> sym_ref(b->symbols ? n : 0);
+	std::vector<std::vector<uint32_t>> arenas(b->symbols ? std::max(1u, nt) : 0);
+	std::atomic<unsigned> next_arena{0};
+	std::atomic<size_t> pool_used{0};
+	std::atomic<bool> overflow{false};
 	auto worker = [&]() {
 		lw::EntropyScratch scr;
+		lw::SymbolSink sink;
+		std::vector<uint64_t> tmp;
+		const unsigned my = b->symbols ? next_arena.fetch_add(1) : 0;
 		for (;;) {
 			const size_t i0 = next.fetch_add(16);
 			if (i0 >= n)
@@ -766,9 +907,34 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				if (b->status[i] != LW_OK)
 					continue;
 				LwPacketRec &r = b->h_recs[i];
+				if (b->symbols)
+					sink.clear();
 				b->status[i] = lw::entropy_decode(id, s, pkts[i].data, pkts[i].len, b->prologues[i],
 						b->h_floor + r.floor_off, (unsigned)fstride, b->h_res + r.res_off, scr, nullptr,
-						b->h_fcurve ? b->h_fcurve + r.res_off : nullptr);
+						b->h_fcurve ? b->h_fcurve + r.res_off : nullptr, b->symbols ? &sink : nullptr);
+				if (b->symbols && b->status[i] == LW_OK) {
+					sink.sort_by_pass(tmp);
+					SymRef &ref = sym_ref[i];
+					ref.words = 10 + 2 * (uint32_t)sink.ops.size();
+					const size_t at = pool_used.fetch_add(ref.words);
+					uint32_t *w;
+					if (at + ref.words <= b->sym_cap_words) {
+						b->h_sym_off[i] = (uint32_t)at;
+						w = b->h_sym + at;
+					} else {
+						overflow = true;
+						std::vector<uint32_t> &a = arenas[my];
+						ref.arena = (int32_t)my;
+						ref.off = (uint32_t)a.size();
+						a.resize(a.size() + ref.words);
+						w = a.data() + ref.off;
+					}
+					for (int q = 0; q < 9; q++)
+						w[q] = sink.pass_off[q];
+					w[9] = 0;
+					if (!sink.ops.empty())
+						std::memcpy(w + 10, sink.ops.data(), sink.ops.size() * 8);
+				}
 			}
 		}
 	};
@@ -780,6 +946,39 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			th.emplace_back(worker);
 		for (auto &t : th)
 			t.join();
+	}
+	if (b->symbols) {
+		const size_t total = pool_used.load();
+		if (overflow) {
+			// enlarge the pool, keep what is already in it, append the parked blocks
+			uint32_t *nh = nullptr, *nd = nullptr;
+			const size_t cap = total + total / 2 + 1024;
+			if (!hip_ok(hipHostMalloc((void **)&nh, cap * 4), "hipHostMalloc(symbols)") ||
+					!hip_ok(hipMalloc((void **)&nd, cap * 4), "hipMalloc(symbols)"))
+				return LW_ERR_DEVICE;
+			size_t at = 0;
+			for (size_t i = 0; i < n; i++) {
+				const SymRef &ref = sym_ref[i];
+				if (!ref.words)
+					continue;
+				const uint32_t *src = ref.arena < 0 ? b->h_sym + b->h_sym_off[i] : arenas[ref.arena].data() + ref.off;
+				std::memcpy(nh + at, src, (size_t)ref.words * 4);
+				b->h_sym_off[i] = (uint32_t)at;
+				at += ref.words;
+			}
+			if (b->h_sym)
+				(void)hipHostFree(b->h_sym);
+			if (b->d_sym) {
+				(void)hipDeviceSynchronize();
+				(void)hipFree(b->d_sym);
+			}
+			b->h_sym = nh;
+			b->d_sym = nd;
+			b->sym_cap_words = cap;
+			b->sym_words = at;
+		} else {
+			b->sym_words = total;
+		}
 	}
 
 	// pass 3 (sequential): window geometry, state hand-over, output offsets, error semantics
@@ -967,8 +1166,13 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	HIP_TRY(hipMemcpyAsync(b->d_recs, b->h_recs, b->n * sizeof(LwPacketRec), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(b->d_floor, b->h_floor, b->n * ch * b->dec->T.fstride * sizeof(uint16_t),
 				hipMemcpyHostToDevice, st));
-	if (b->res_floats)
+	if (b->res_floats && !b->symbols)
 		HIP_TRY(hipMemcpyAsync(b->d_res, b->h_res, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
+	if (b->symbols) {
+		HIP_TRY(hipMemcpyAsync(b->d_sym_off, b->h_sym_off, b->n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+		if (b->sym_words)
+			HIP_TRY(hipMemcpyAsync(b->d_sym, b->h_sym, b->sym_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	}
 	if (b->res_floats && b->d_fcurve)
 		HIP_TRY(hipMemcpyAsync(b->d_fcurve, b->h_fcurve, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
 	if (b->n_items)
@@ -1011,10 +1215,16 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.td = b->d_td;
 	B.state = d->d_state;
 	B.n_packets = (uint32_t)b->n;
+	B.sym = b->symbols ? b->d_sym : nullptr;
+	B.sym_off = b->d_sym_off;
 	b->last_kernels.clear();
+	if (b->symbols) {
+		lw_launch_residue_vq(d->T, d->V, B, st, b->max_n, d->vq_book_ends.data(), d->vq_book_ends.size());
+		b->last_kernels = "k_residue_vq,";
+	}
 	if (run_generic) {
 		lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic);
-		b->last_kernels = d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
+		b->last_kernels += d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 	}
 	if (run_fast) {
 		LwFastLaunch L{};
@@ -1104,7 +1314,7 @@ int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats
 	const size_t want = tap == LW_TAP_POST_MDCT ? ch * n : ch * n / 2;
 	if (cap_floats < want)
 		return LW_ERR_CAPACITY;
-	if (tap == LW_TAP_RESIDUE_PRE_INVERSE) {
+	if (tap == LW_TAP_RESIDUE_PRE_INVERSE && !b->symbols) {
 		std::memcpy(dst, b->h_res + r.res_off, want * sizeof(float));
 		return LW_OK;
 	}
@@ -1116,7 +1326,9 @@ int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats
 		return rc;
 	HIP_TRY(hipDeviceSynchronize());
 	const float *src;
-	if (tap == LW_TAP_RESIDUE_POST_INVERSE)
+	if (tap == LW_TAP_RESIDUE_PRE_INVERSE)
+		src = b->d_res + r.res_off; // Tier B: the vectors k_residue_vq built on the device
+	else if (tap == LW_TAP_RESIDUE_POST_INVERSE)
 		src = (d->any_coupling ? b->d_decoupled : b->d_res) + r.res_off;
 	else if (tap == LW_TAP_PRE_MDCT)
 		src = b->d_tap + r.res_off;

@@ -297,3 +297,69 @@ def test_full_size_batch_properties():
     again = bf.synth_to_host()
     assert np.array_equal(again, fa)
     assert bf.algorithmic_bytes == 4096 * (8192 + 132) + 4095 * 4096
+
+
+# ---- Tier B: residue inverse VQ on the device ---------------------------------------------------
+@pytest.mark.parametrize("name", sorted(ALL_SETUPS))
+def test_device_inverse_vq_matches_oracle(name):
+    """Codeword symbols from the host, additions + de-interleave in k_residue_vq: the residue vectors (tap), the PCM and
+    the stream state must equal the oracle's bit for bit, incl. packets that end in the middle of the residue."""
+    from lewton_amd import _native as N
+    from lewton_amd.batch import Batch
+    setup = ALL_SETUPS[name]()
+    audio, ident, st = _product(setup)
+    o_id, o_st = oracle_headers(setup)
+    dec = audio.decoder_for(ident, st)
+    ch = setup.channels
+    why = C.c_char_p()
+    ok = bool(N.lw_decoder_supports_device_vq(dec._h, C.byref(why)))
+    batch = Batch(dec, 64, "i16")
+    assert batch.set_residue_on_device(True) == ok
+    if not ok:
+        assert name == "mono_small" and b"partition size" in why.value   # dims 2/4/8 vs partition sizes 8 and 24
+        return
+    n_streams, per = 4, 10
+    rng = np.random.default_rng(3)
+    streams = [sg.make_stream(setup, PATTERNS[name], per, seed=300 + s, p_floor_unused=0.1) for s in range(n_streams)]
+    for s in range(n_streams):                                   # end-of-packet inside the residue (audio.rs:655-660)
+        k = int(rng.integers(2, per))
+        streams[s][k] = streams[s][k][: max(8, len(streams[s][k]) * 2 // 3)]
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    o_pwrs = [po.Pwr() for _ in range(n_streams)]
+    items, want = [], []
+    for t in range(per):
+        for s in range(n_streams):
+            items.append((streams[s][t], pwrs[s]))
+            try:
+                want.append(po.read_audio_packet(o_id, o_st, streams[s][t], o_pwrs[s], "f32", taps=True))
+            except po.OracleError as e:
+                want.append(e.code)
+    res = batch.entropy(items, n_threads=3)
+    batch.upload()
+    got = batch.split(batch.synth_to_host(), ch)
+    assert batch.last_kernels.startswith("k_residue_vq,")
+    for i, (w, g, r) in enumerate(zip(want, got, res)):
+        if isinstance(w, int):
+            assert r[0] == w
+            continue
+        out, taps = w
+        assert r[0] == 0 and r[1] == out.shape[1]
+        wi = np.vectorize(po.lib().lwo_sample_i16, otypes=[np.int16])(out) if out.size else out.astype(np.int16)
+        assert np.array_equal(g, wi), i
+    for i in range(0, len(items), 7):
+        if isinstance(want[i], int):
+            continue
+        n = want[i][1]["n"]
+        t = batch.tap(i, N.TAP_RESIDUE_PRE_INVERSE, ch, n)
+        assert np.array_equal(t.view(np.uint32), want[i][1]["residue_pre_inverse"].view(np.uint32)), i
+    for s in range(n_streams):
+        assert np.array_equal(pwrs[s].data().view(np.uint32), o_pwrs[s].data(ch).view(np.uint32))
+    # the same batch object back in host mode gives the same PCM
+    assert batch.set_residue_on_device(False)
+    pw2 = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    batch.entropy([(p, pw2[i % n_streams]) for i, (p, _) in enumerate(items)], n_threads=2)
+    batch.upload()
+    again = batch.split(batch.synth_to_host(), ch)
+    assert "k_residue_vq" not in batch.last_kernels
+    for a, g in zip(again, got):
+        assert (a is None) == (g is None) and (a is None or np.array_equal(a, g))

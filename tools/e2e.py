@@ -24,6 +24,7 @@ ap.add_argument("--batches", type=int, default=24)
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--packets", type=int, default=4096)
 ap.add_argument("--streams", type=int, default=256)
+ap.add_argument("--device-vq", action="store_true", help="Tier B: ship codeword symbols, inverse VQ in k_residue_vq")
 args = ap.parse_args()
 
 setup = sg.stereo_setup(44100, 8, 11)
@@ -46,6 +47,8 @@ slots = []
 for i in range(2):
     stream = torch.cuda.Stream()
     bt = Batch(dec, NP, "i16")
+    if args.device_vq:
+        assert bt.set_residue_on_device(True)
     d_out = torch.empty(NP * 2 * 1024, dtype=torch.int16, device="cuda")
     h_out = torch.empty(NP * 2 * 1024, dtype=torch.int16).pin_memory()
     slots.append((stream, bt, d_out, h_out, torch.cuda.Event()))
@@ -74,6 +77,13 @@ t0 = time.perf_counter()
 t_ent = run(args.batches)
 dt = time.perf_counter() - t0
 npk = args.batches * NP
+h2d = None
+try:
+    from lewton_amd import _native as N
+    h2d = "symbols" if args.device_vq else "f32 residues"
+except Exception:
+    pass
+print("mode: %s; kernels: %s" % (h2d, slots[0][1].last_kernels))
 print("end-to-end: %d packets in %.3f s -> %.2f M packets/s (%.1f MB/s of Vorbis payload, %.2f GB/s of H2D records, "
       "%.2f GB/s of D2H PCM); host entropy stage alone %.2f M packets/s on %s threads" % (
           npk, dt, npk / dt / 1e6, payload * args.batches / dt / 1e6, npk * 8324 / dt / 1e9, npk * 4096 / dt / 1e9,
