@@ -168,9 +168,27 @@ __global__ void __launch_bounds__(1024) k_residue_vq(LwDevTables T, LwVqTables V
 // ---------------------------------------------------------------------------------------------
 // inverse coupling
 // ---------------------------------------------------------------------------------------------
+// packet of generic task `t` (dense lists of the batch) or t itself when every packet is generic
+__device__ __forceinline__ bool generic_packet(const LwBatchDev &B, uint32_t t, uint32_t &pkt)
+{
+	if (!B.gen_small) {
+		pkt = t;
+		return t < B.n_packets;
+	}
+	if (t < B.n_gen_small)
+		pkt = B.gen_small[t];
+	else if (t - B.n_gen_small < B.n_gen_large)
+		pkt = B.gen_large[t - B.n_gen_small];
+	else
+		return false;
+	return true;
+}
+
 __global__ void __launch_bounds__(LW_BLOCK) k_decouple(LwDevTables T, LwBatchDev B, uint32_t skip_mask)
 {
-	const uint32_t pkt = blockIdx.x;
+	uint32_t pkt;
+	if (!generic_packet(B, blockIdx.x, pkt))
+		return;
 	const LwPacketRec rec = B.recs[pkt];
 	if (rec.flags & skip_mask)
 		return;
@@ -242,48 +260,102 @@ __device__ __forceinline__ void iter54(float *w)
 	w[0] = k11 + k22;
 }
 
-__global__ void __launch_bounds__(LW_BLOCK)
-k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled, uint32_t skip_mask)
+// TPB threads work on one (packet, channel) block: TPB = LW_BLOCK (one block per workgroup, barriers between the stages) for
+// the large block sizes, TPB = 64 (four blocks per workgroup, each on its own wave; the stages are ordered by the wave's
+// own LDS ordering, no barrier) for block sizes up to 2^LW_SMALL_BS -- a 256-point short block has 32 butterflies per
+// stage, a 256-thread workgroup and its barriers were 4x the work of the transform itself.
+#define LW_SMALL_BS 9
+template <int TPB>
+__device__ __forceinline__ void stage_sync()
 {
-	extern __shared__ __attribute__((aligned(16))) float smem[];
-	const uint32_t pkt = blockIdx.x / T.ch, c = blockIdx.x % T.ch;
+	if (TPB == LW_BLOCK)
+		__syncthreads();
+	else
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wave: its LDS operations complete in order
+}
+
+template <int TPB>
+__global__ void __launch_bounds__(LW_BLOCK)
+k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled, uint32_t skip_mask, uint32_t task_floats)
+{
+	extern __shared__ __attribute__((aligned(16))) float smem_all[];
+	const uint32_t task = TPB == LW_BLOCK ? blockIdx.x : blockIdx.x * (LW_BLOCK / TPB) + threadIdx.x / TPB;
+	const uint32_t *list = TPB == LW_BLOCK ? B.gen_large : B.gen_small;
+	const uint32_t n_list = TPB == LW_BLOCK ? B.n_gen_large : B.n_gen_small;
+	if (task >= (list ? n_list : B.n_packets) * T.ch)
+		return;
+	const uint32_t pkt = list ? list[task / T.ch] : task / T.ch, c = task % T.ch;
 	const LwPacketRec rec = B.recs[pkt];
 	if (rec.flags & skip_mask)
 		return;
-	const uint32_t tid = threadIdx.x;
+	if ((rec.bs <= LW_SMALL_BS) != (TPB != LW_BLOCK))
+		return; // the other instantiation handles this block size
+	const uint32_t tid = threadIdx.x % TPB;
+	float *smem = smem_all + (TPB == LW_BLOCK ? 0u : (threadIdx.x / TPB) * task_floats);
 	const LwDevBs tb = T.bs[(rec.flags & LW_RF_LONG) ? 1 : 0];
 	const uint32_t bs = rec.bs, n = 1u << bs, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
 	float *u = smem, *v = smem + n2;
 	uint16_t *px = (uint16_t *)(smem + 2 * n2);
 	uint8_t *py = (uint8_t *)(px + LW_XSTRIDE);
-	__shared__ int s_K;
+	int *s_Kp = (int *)(py + LW_XSTRIDE + 2); // 4-byte aligned: 2 * n2 floats + 66 * 2 + 68 bytes
 
 	// ---- active floor posts, ascending x (audio.rs:536-545 walks exactly these)
 	const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
 	const uint32_t fl = T.mode_floor[rec.mode * T.ch + c];
 	const bool unused = frec[0] == LW_FLOOR_UNUSED;
 	const bool explicit_curve = frec[0] == LW_FLOOR_EXPLICIT; // floor 0: curve evaluated by the host stage
-	if (tid == 0) {
-		int K = 0;
-		if (!unused && !explicit_curve) {
-			const uint32_t F = T.floor_F[fl];
-			for (uint32_t s = 0; s < F; s++) {
-				const uint16_t e = frec[s];
-				if (e & LW_POST_ACTIVE) {
-					px[K] = T.floor_x[fl * LW_XSTRIDE + s];
-					py[K] = (uint8_t)(e & 0xff);
-					K++;
-				}
-			}
-		}
-		s_K = K;
+	// one thread per post (F <= 65): a serial walk by thread 0 is a chain of ~2 F dependent global loads, tens of
+	// microseconds -- it used to be most of this kernel's run time
+	uint8_t *act = (uint8_t *)(s_Kp + 1);
+	// the block size's twiddle tables in LDS (A n/2, B n/2, C n/4 floats, bitrev n/8 words): read from HBM/L2 they cost a
+	// round trip in every one of the ~20 barrier-separated stages, which is what a block's latency consisted of
+	float *sA = smem + 2 * n2 + (LW_XSTRIDE * 4 + 24 + 3) / 4, *sB = sA + n2, *sC = sB + n2;
+	uint32_t *sR = (uint32_t *)(sC + n4);
+	for (uint32_t i = tid; i < n2; i += TPB) {
+		sA[i] = tb.A[i];
+		sB[i] = tb.B[i];
+		if (i < n4)
+			sC[i] = tb.C[i];
+		if (i < n8)
+			sR[i] = tb.bitrev[i];
 	}
-	__syncthreads();
-	const int K = s_K;
+	const uint32_t F = (unused || explicit_curve) ? 0u : T.floor_F[fl];
+	uint16_t my_e = 0, my_x = 0;
+	for (uint32_t s0 = 0; s0 < F; s0 += TPB) { // one iteration unless TPB = 64 and F = 65
+		const uint32_t sidx = s0 + tid;
+		if (sidx < F) {
+			my_e = frec[sidx];
+			my_x = T.floor_x[fl * LW_XSTRIDE + sidx];
+			act[sidx] = (my_e & LW_POST_ACTIVE) ? 1 : 0;
+		}
+	}
+	stage_sync<TPB>();
+	for (uint32_t s0 = 0; s0 < F; s0 += TPB) {
+		const uint32_t sidx = s0 + tid;
+		if (sidx < F) {
+			int rank = 0;
+			for (uint32_t t = 0; t < sidx; t++)
+				rank += act[t];
+			// my_e / my_x hold the LAST round's post: reload in the (TPB = 64, F = 65) case for the earlier round
+			const bool last_round = s0 + TPB >= F;
+			const uint16_t e = last_round ? my_e : frec[sidx];
+			const uint16_t x = last_round ? my_x : T.floor_x[fl * LW_XSTRIDE + sidx];
+			if (e & LW_POST_ACTIVE) {
+				px[rank] = x;
+				py[rank] = (uint8_t)(e & 0xff);
+			}
+			if (sidx == F - 1)
+				*s_Kp = rank + ((e & LW_POST_ACTIVE) ? 1 : 0);
+		}
+	}
+	if (F == 0 && tid == 0)
+		*s_Kp = 0;
+	stage_sync<TPB>();
+	const int K = *s_Kp;
 
 	// ---- spectrum = floor * residue (audio.rs:1035-1037); zero floor for an unused channel (:1021-1024)
 	const float *src = (use_decoupled ? B.decoupled : B.residue) + rec.res_off + c * n2;
-	for (uint32_t k = tid; k < n2; k += LW_BLOCK) {
+	for (uint32_t k = tid; k < n2; k += TPB) {
 		float f;
 		if (unused) {
 			f = 0.0f;
@@ -315,11 +387,11 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 		if (tap_spec)
 			tap_spec[rec.res_off + c * n2 + k] = x;
 	}
-	__syncthreads();
+	stage_sync<TPB>();
 
-	const float *A = tb.A, *Bt = tb.B, *C = tb.C;
+	const float *A = sA, *Bt = sB, *C = sC;
 	// ---- imdct.rs:337-371: X = u -> v
-	for (uint32_t j = tid; j < n8; j += LW_BLOCK) {
+	for (uint32_t j = tid; j < n8; j += TPB) {
 		const float x0 = u[4 * j], x2 = u[4 * j + 2];
 		v[n2 - 1 - 2 * j] = x0 * A[2 * j] - x2 * A[2 * j + 1];
 		v[n2 - 2 - 2 * j] = x0 * A[2 * j + 1] + x2 * A[2 * j];
@@ -328,9 +400,9 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 		v[d + 1] = me2 * A[a] - me0 * A[a + 1];
 		v[d] = me2 * A[a + 1] + me0 * A[a];
 	}
-	__syncthreads();
+	stage_sync<TPB>();
 	// ---- imdct.rs:385-430 (step 2): v -> u
-	for (uint32_t i = tid; i < (n >> 4); i += LW_BLOCK) {
+	for (uint32_t i = tid; i < (n >> 4); i += TPB) {
 		const uint32_t a = n2 - 8 - 8 * i, lo = 4 * i, hi = n4 + 4 * i;
 		{
 			const float p = v[hi + 1] - v[lo + 1], q = v[hi] - v[lo];
@@ -347,7 +419,7 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 			u[lo + 2] = q * A[a] + p * A[a + 1];
 		}
 	}
-	__syncthreads();
+	stage_sync<TPB>();
 	// ---- imdct.rs:445-477 (step 3): stages 0 and 1 always run, then up to ld-7 (for bs 6/7 this is the
 	//      literal behaviour of the reference: see DESIGN.md "small block sizes")
 	const int last_stage = (int)bs - 7 > 1 ? (int)bs - 7 : 1;
@@ -356,17 +428,17 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 		if (l == 1 && per_s < 4) // imdct_step3_inner_r_loop runs lim>>2 groups of four (imdct.rs:93)
 			break;
 		const uint32_t k0 = n >> (l + 2), k1 = 1u << (l + 3);
-		for (uint32_t b = tid; b < n8; b += LW_BLOCK) {
+		for (uint32_t b = tid; b < n8; b += TPB) {
 			const uint32_t s = b / per_s, r = b - s * per_s;
 			const uint32_t hi = n2 - 1 - k0 * s - 2 * r;
 			bfly(u, hi, hi - (k0 >> 1), A[r * k1], A[r * k1 + 1]);
 		}
-		__syncthreads();
+		stage_sync<TPB>();
 	}
 	// ---- imdct.rs:234-288 fused last three stages, one 16-float group per thread
 	{
 		const float a2 = A[n8];
-		for (uint32_t g = tid; g < (n >> 5); g += LW_BLOCK) {
+		for (uint32_t g = tid; g < (n >> 5); g += TPB) {
 			float *z = u + (n2 - 16 - 16 * g); // z[15 - k] is the reference's z![-k]
 			float k00, k11;
 			k00 = z[15] - z[7];
@@ -397,24 +469,24 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 			iter54(z);
 		}
 	}
-	__syncthreads();
+	stage_sync<TPB>();
 	// ---- imdct.rs:490-528 bit-reverse: u -> v
-	for (uint32_t t = tid; t < (n >> 4); t += LW_BLOCK) {
-		uint32_t k = tb.bitrev[2 * t];
+	for (uint32_t t = tid; t < (n >> 4); t += TPB) {
+		uint32_t k = sR[2 * t];
 		const uint32_t d1 = n2 - 4 - 4 * t, d0 = n4 - 4 - 4 * t;
 		v[d1 + 3] = u[k];
 		v[d1 + 2] = u[k + 1];
 		v[d0 + 3] = u[k + 2];
 		v[d0 + 2] = u[k + 3];
-		k = tb.bitrev[2 * t + 1];
+		k = sR[2 * t + 1];
 		v[d1 + 1] = u[k];
 		v[d1] = u[k + 1];
 		v[d0 + 1] = u[k + 2];
 		v[d0] = u[k + 3];
 	}
-	__syncthreads();
+	stage_sync<TPB>();
 	// ---- imdct.rs:533-580 step 7, in place on v
-	for (uint32_t m = tid; m < (n >> 4); m += LW_BLOCK) {
+	for (uint32_t m = tid; m < (n >> 4); m += TPB) {
 		const uint32_t d = 4 * m, e = n2 - 4 - 4 * m;
 		{
 			const float a02 = v[d] - v[e + 2], a11 = v[d + 1] + v[e + 3];
@@ -435,10 +507,10 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 			v[e + 1] = b1 - b3;
 		}
 	}
-	__syncthreads();
+	stage_sync<TPB>();
 	// ---- imdct.rs:589-658 step 8 + output mapping -> time-domain block in HBM
 	float *out = B.td + 2u * rec.res_off + c * n;
-	for (uint32_t p = tid; p < n4; p += LW_BLOCK) {
+	for (uint32_t p = tid; p < n4; p += TPB) {
 		const float w0 = v[2 * p], w1 = v[2 * p + 1];
 		const float pa = w0 * Bt[2 * p + 1] - w1 * Bt[2 * p];
 		const float pb = (-w0) * Bt[2 * p] - w1 * Bt[2 * p + 1];
@@ -467,7 +539,10 @@ __device__ __forceinline__ int16_t to_i16(float x)
 template <int FMT>
 __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatchDev B, void *out_v, uint32_t skip_mask)
 {
-	const uint32_t pkt = blockIdx.x / T.ch, c = blockIdx.x % T.ch;
+	uint32_t pkt;
+	if (!generic_packet(B, blockIdx.x / T.ch, pkt))
+		return;
+	const uint32_t c = blockIdx.x % T.ch;
 	const LwPacketRec rec = B.recs[pkt];
 	if (rec.flags & skip_mask)
 		return;
@@ -513,10 +588,29 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 		return;
 	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
 	if (any_coupling)
-		hipLaunchKernelGGL(k_decouple, dim3(B.n_packets), dim3(LW_BLOCK), 0, st, T, B, skip_mask);
-	const size_t lds = (size_t)max_n * sizeof(float) + LW_XSTRIDE * 3 + 16;
-	hipLaunchKernelGGL(k_imdct_generic, dim3(B.n_packets * T.ch), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
-			any_coupling ? 1 : 0, skip_mask);
+		hipLaunchKernelGGL(k_decouple, dim3(B.gen_small ? B.n_gen_small + B.n_gen_large : B.n_packets), dim3(LW_BLOCK), 0, st, T, B,
+				skip_mask);
+	static bool once = false;
+	if (!once) {
+		once = true;
+		(void)hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_imdct_generic<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+	}
+	// large block sizes: one (packet, channel) block per workgroup; small ones: four per workgroup, one per wave
+	const uint32_t n_large = (B.gen_large ? B.n_gen_large : B.n_packets) * T.ch;
+	const uint32_t n_small = (B.gen_small ? B.n_gen_small : B.n_packets) * T.ch;
+	if (max_n > (1u << LW_SMALL_BS) && n_large) {
+		const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + max_n + max_n / 4 + max_n / 8 + 4) * sizeof(float);
+		hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(n_large), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
+				any_coupling ? 1 : 0, skip_mask, 0u);
+	}
+	if (T.bs[0].bs <= LW_SMALL_BS && n_small) {
+		const uint32_t small_n = std::min(max_n, 1u << LW_SMALL_BS);
+		const uint32_t task_floats = (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + small_n + small_n / 4 + small_n / 8 + 7u) & ~3u;
+		const uint32_t per_wg = LW_BLOCK / 64;
+		hipLaunchKernelGGL(k_imdct_generic<64>, dim3((n_small + per_wg - 1) / per_wg), dim3(LW_BLOCK),
+				(size_t)per_wg * task_floats * sizeof(float), st, T, B, tap_spec, any_coupling ? 1 : 0, skip_mask, task_floats);
+	}
 }
 
 void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBatchDev &B, hipStream_t st, uint32_t max_n,
@@ -548,7 +642,7 @@ void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out,
 	if (B.n_packets == 0)
 		return;
 	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
-	const dim3 g(B.n_packets * T.ch), b(LW_BLOCK);
+	const dim3 g((B.gen_small ? B.n_gen_small + B.n_gen_large : B.n_packets) * T.ch), b(LW_BLOCK);
 	if (fmt == LW_OUT_I16_PLANAR)
 		hipLaunchKernelGGL(k_ola_generic<LW_OUT_I16_PLANAR>, g, b, 0, st, T, B, out, skip_mask);
 	else if (fmt == LW_OUT_I16_INTERLEAVED)

@@ -67,6 +67,9 @@ struct LwBatchDev {
 	float *td;        // scratch: per packet [ch][n] time-domain blocks at float offset 2 * res_off
 	float *state;     // state pool [slots][2][ch][n1/2]
 	uint32_t n_packets;
+	// packets the generic kernels work on, by block-size class; nullptr = every packet (filters inside the kernels)
+	const uint32_t *gen_small, *gen_large;
+	uint32_t n_gen_small, n_gen_large;
 };
 
 // Generic path (any block size 64..8192, any window shape, any channel count / coupling list), two phases so

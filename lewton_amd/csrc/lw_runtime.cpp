@@ -100,6 +100,10 @@ struct lw_batch {
 	uint16_t *h_floor = nullptr;
 	float *h_res = nullptr;
 	float *h_fcurve = nullptr, *d_fcurve = nullptr; // explicit floor curves (floor 0), layout of the residues
+	// packets of the generic kernels, by size class (block size <= / > 2^9): dense launch grids instead of 8192
+	// workgroups that mostly find out they have nothing to do
+	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [2][max_packets]
+	uint32_t n_gen_small = 0, n_gen_large = 0;
 	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
 	bool symbols = false;
 	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
@@ -735,7 +739,9 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		hip_ok(hipHostMalloc((void **)&b->h_items, max_packets * sizeof(LwFastItem)), "hipHostMalloc(items)") &&
 		hip_ok(hipHostMalloc((void **)&b->h_halo_items, max_packets * sizeof(LwFastItem)), "hipHostMalloc(halo items)") &&
 		hip_ok(hipMalloc((void **)&b->d_items, max_packets * sizeof(LwFastItem)), "hipMalloc(items)") &&
-		hip_ok(hipMalloc((void **)&b->d_halo_items, max_packets * sizeof(LwFastItem)), "hipMalloc(halo items)");
+		hip_ok(hipMalloc((void **)&b->d_halo_items, max_packets * sizeof(LwFastItem)), "hipMalloc(halo items)") &&
+		hip_ok(hipHostMalloc((void **)&b->h_gen, 2 * max_packets * sizeof(uint32_t)), "hipHostMalloc(generic lists)") &&
+		hip_ok(hipMalloc((void **)&b->d_gen, 2 * max_packets * sizeof(uint32_t)), "hipMalloc(generic lists)");
 	if (ok && d->any_floor0)
 		ok = hip_ok(hipHostMalloc((void **)&b->h_fcurve, res_b), "hipHostMalloc(floor curves)") &&
 			hip_ok(hipMalloc((void **)&b->d_fcurve, res_b), "hipMalloc(floor curves)");
@@ -762,6 +768,8 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_floor);
 	if (b->h_fcurve)
 		(void)hipHostFree(b->h_fcurve);
+	if (b->h_gen)
+		(void)hipHostFree(b->h_gen);
 	if (b->h_sym)
 		(void)hipHostFree(b->h_sym);
 	if (b->h_sym_off)
@@ -772,7 +780,7 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_items);
 	if (b->h_halo_items)
 		(void)hipHostFree(b->h_halo_items);
-	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_fcurve, b->d_sym, b->d_sym_off, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
+	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_fcurve, b->d_sym, b->d_sym_off, b->d_gen, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -994,6 +1002,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	uint64_t alg = 0;
 	const size_t esz = elem_size(b->fmt);
 	b->has_generic = b->has_fast = false;
+	b->n_gen_small = b->n_gen_large = 0;
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
 	for (size_t i = 0; i < n; i++) {
 		LwPacketRec &r = b->h_recs[i];
@@ -1061,8 +1070,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			const lw::Floor &fl = s.floors[mp.submap_floor[mp.mux[c]]];
 			alg += fl.type == 0 ? (uint64_t)(p.n / 2) * 4 + 2 : (uint64_t)fl.f1.x_list.size() * 2; // explicit curve | posts
 		}
-		if (!(r.flags & LW_RF_FAST))
+		if (!(r.flags & LW_RF_FAST)) {
 			b->has_generic = true;
+			if (p.bs <= 9)
+				b->h_gen[b->n_gen_small++] = (uint32_t)i;
+			else
+				b->h_gen[b->max_packets + b->n_gen_large++] = (uint32_t)i;
+		}
 	}
 	// the last ok packet of every stream hands its right part to the stream's state slot
 	for (lw_pwr *pw : b->touched) {
@@ -1175,6 +1189,11 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	}
 	if (b->res_floats && b->d_fcurve)
 		HIP_TRY(hipMemcpyAsync(b->d_fcurve, b->h_fcurve, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
+	if (b->n_gen_small)
+		HIP_TRY(hipMemcpyAsync(b->d_gen, b->h_gen, b->n_gen_small * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+	if (b->n_gen_large)
+		HIP_TRY(hipMemcpyAsync(b->d_gen + b->max_packets, b->h_gen + b->max_packets, b->n_gen_large * sizeof(uint32_t),
+					hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
@@ -1215,6 +1234,11 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.td = b->d_td;
 	B.state = d->d_state;
 	B.n_packets = (uint32_t)b->n;
+	// dense lists of the generic packets (not used when every packet goes through the generic kernels)
+	B.gen_small = all_generic ? nullptr : b->d_gen;
+	B.gen_large = all_generic ? nullptr : b->d_gen + b->max_packets;
+	B.n_gen_small = b->n_gen_small;
+	B.n_gen_large = b->n_gen_large;
 	B.sym = b->symbols ? b->d_sym : nullptr;
 	B.sym_off = b->d_sym_off;
 	b->last_kernels.clear();
