@@ -307,18 +307,6 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	// one thread per post (F <= 65): a serial walk by thread 0 is a chain of ~2 F dependent global loads, tens of
 	// microseconds -- it used to be most of this kernel's run time
 	uint8_t *act = (uint8_t *)(s_Kp + 1);
-	// the block size's twiddle tables in LDS (A n/2, B n/2, C n/4 floats, bitrev n/8 words): read from HBM/L2 they cost a
-	// round trip in every one of the ~20 barrier-separated stages, which is what a block's latency consisted of
-	float *sA = smem + 2 * n2 + (LW_XSTRIDE * 4 + 24 + 3) / 4, *sB = sA + n2, *sC = sB + n2;
-	uint32_t *sR = (uint32_t *)(sC + n4);
-	for (uint32_t i = tid; i < n2; i += TPB) {
-		sA[i] = tb.A[i];
-		sB[i] = tb.B[i];
-		if (i < n4)
-			sC[i] = tb.C[i];
-		if (i < n8)
-			sR[i] = tb.bitrev[i];
-	}
 	const uint32_t F = (unused || explicit_curve) ? 0u : T.floor_F[fl];
 	uint16_t my_e = 0, my_x = 0;
 	for (uint32_t s0 = 0; s0 < F; s0 += TPB) { // one iteration unless TPB = 64 and F = 65
@@ -389,7 +377,8 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	}
 	stage_sync<TPB>();
 
-	const float *A = sA, *Bt = sB, *C = sC;
+	// twiddles stay in L2 (copies in LDS were measured slower: fewer resident workgroups, no gain per stage)
+	const float *A = tb.A, *Bt = tb.B, *C = tb.C;
 	// ---- imdct.rs:337-371: X = u -> v
 	for (uint32_t j = tid; j < n8; j += TPB) {
 		const float x0 = u[4 * j], x2 = u[4 * j + 2];
@@ -472,13 +461,13 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	stage_sync<TPB>();
 	// ---- imdct.rs:490-528 bit-reverse: u -> v
 	for (uint32_t t = tid; t < (n >> 4); t += TPB) {
-		uint32_t k = sR[2 * t];
+		uint32_t k = tb.bitrev[2 * t];
 		const uint32_t d1 = n2 - 4 - 4 * t, d0 = n4 - 4 - 4 * t;
 		v[d1 + 3] = u[k];
 		v[d1 + 2] = u[k + 1];
 		v[d0 + 3] = u[k + 2];
 		v[d0 + 2] = u[k + 3];
-		k = sR[2 * t + 1];
+		k = tb.bitrev[2 * t + 1];
 		v[d1 + 1] = u[k];
 		v[d1] = u[k + 1];
 		v[d0 + 1] = u[k + 2];
@@ -600,13 +589,13 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 	const uint32_t n_large = (B.gen_large ? B.n_gen_large : B.n_packets) * T.ch;
 	const uint32_t n_small = (B.gen_small ? B.n_gen_small : B.n_packets) * T.ch;
 	if (max_n > (1u << LW_SMALL_BS) && n_large) {
-		const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + max_n + max_n / 4 + max_n / 8 + 4) * sizeof(float);
+		const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 4) * sizeof(float);
 		hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(n_large), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
 				any_coupling ? 1 : 0, skip_mask, 0u);
 	}
 	if (T.bs[0].bs <= LW_SMALL_BS && n_small) {
 		const uint32_t small_n = std::min(max_n, 1u << LW_SMALL_BS);
-		const uint32_t task_floats = (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + small_n + small_n / 4 + small_n / 8 + 7u) & ~3u;
+		const uint32_t task_floats = (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 7u) & ~3u;
 		const uint32_t per_wg = LW_BLOCK / 64;
 		hipLaunchKernelGGL(k_imdct_generic<64>, dim3((n_small + per_wg - 1) / per_wg), dim3(LW_BLOCK),
 				(size_t)per_wg * task_floats * sizeof(float), st, T, B, tap_spec, any_coupling ? 1 : 0, skip_mask, task_floats);
