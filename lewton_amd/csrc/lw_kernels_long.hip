@@ -1412,7 +1412,12 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	const bool two = un.ch_b >= 0;
 #endif
 	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
-	const bool late = !RIGHT_ONLY && wave >= F.late_from;
+#ifndef LW_PRE_WAVES
+#define LW_PRE_WAVES 2 // waves that queue their HBM loads before the barrier (waves 0-3 can: the others stage the image);
+                       // measured: 1 -> 17.33, 2 -> 17.0-17.16, 4 -> 17.73 us; releasing the next wave of the chain before
+                       // (18.0) or half-way through (17.17) the own loads is slower than after them
+#endif
+	const bool late = !RIGHT_ONLY && wave >= (F.late_from > LW_PRE_WAVES ? F.late_from : (uint32_t)LW_PRE_WAVES);
 	LW_STAMP_NW(13);
 
 	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
