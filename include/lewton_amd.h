@@ -128,6 +128,24 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 		uint16_t *floor_out, float *residue_out, size_t residue_cap_floats, uint8_t *blocksize_log2, uint8_t *mode,
 		uint8_t *flags, uint64_t *bits_consumed, float *floor_curve_out);
 
+/* The same stage producing codeword symbols instead of residue vectors (the record format of
+ * lw_batch_set_residue_on_device; no GPU needed): one 64-bit symbol per decoded codeword,
+ *   bits 0-23 start coordinate in the submap's vector space ([sub_ch][n/2], or the interleaved type-2 vector of
+ *   audio.rs:745-754), bits 24-31 codebook, bits 32-55 codebook entry, bits 56-59 submap, bits 60-62 cascade pass,
+ * sorted by pass (decode order inside a pass); pass_off[p] .. pass_off[p+1] are the symbols of pass p.
+ * floor_out / floor_curve_out / blocksize_log2 / mode / flags as above.  LW_ERR_CAPACITY if cap_symbols is too small,
+ * LW_ERR_UNSUPPORTED if the stream is not eligible (lw_setup_supports_device_vq). */
+int lw_entropy_symbols_host(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len,
+		uint16_t *floor_out, uint64_t *symbols, size_t cap_symbols, size_t *n_symbols, uint32_t pass_off[9],
+		uint8_t *blocksize_log2, uint8_t *mode, uint8_t *flags, float *floor_curve_out);
+int lw_setup_supports_device_vq(const lw_ident *id, const lw_setup *s, const char **why);
+/* Introspection for tests and tools: the dense VQ table of a codebook (header.rs:495-531; entries x dims floats,
+ * dst may be NULL to query the sizes; returns LW_ERR_UNSUPPORTED for a book without a lookup table) and the residue
+ * layout of a submap of a mode (type, partition size, channels in mapping_mux order). */
+int lw_setup_codebook_vq(const lw_setup *s, unsigned book, float *dst, size_t cap_floats, uint32_t *dims, uint32_t *entries);
+int lw_setup_submap_info(const lw_setup *s, unsigned mode, unsigned submap, uint8_t *residue_type, uint32_t *partition_size,
+		uint8_t *channels, size_t cap_channels, size_t *n_channels);
+
 /* ---- batches ------------------------------------------------------------------------------ */
 typedef struct {
 	const uint8_t *data;

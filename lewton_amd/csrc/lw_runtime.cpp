@@ -336,6 +336,95 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 	return rc;
 }
 
+int lw_setup_supports_device_vq(const lw_ident *id, const lw_setup *s, const char **why)
+{
+	static thread_local std::string msg;
+	const char *w = "";
+	const bool ok = id && s && lw::symbols_supported(*id->p, *s->p, &w);
+	msg = w;
+	if (why)
+		*why = msg.c_str();
+	return ok ? 1 : 0;
+}
+
+int lw_entropy_symbols_host(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len, uint16_t *floor_out,
+		uint64_t *symbols, size_t cap_symbols, size_t *n_symbols, uint32_t pass_off[9], uint8_t *blocksize_log2,
+		uint8_t *mode, uint8_t *flags, float *floor_curve_out)
+{
+	if (!id || !s || !packet || !floor_out || !symbols || !n_symbols || !pass_off)
+		return LW_ERR_NULL_ARG;
+	if (!lw::symbols_supported(*id->p, *s->p, nullptr))
+		return LW_ERR_UNSUPPORTED;
+	lw::Prologue p;
+	lw::EntropyScratch scr;
+	lw::SymbolSink sink;
+	std::vector<uint64_t> tmp;
+	sink.clear();
+	const int rc = lw::entropy_decode(*id->p, *s->p, packet, len, p, floor_out, floor_stride_of(*s->p), nullptr, scr, nullptr,
+			floor_curve_out, &sink);
+	if (blocksize_log2)
+		*blocksize_log2 = p.bs;
+	if (mode)
+		*mode = p.mode;
+	if (flags)
+		*flags = (uint8_t)((p.blockflag ? 1 : 0) | (p.prev_flag ? 2 : 0) | (p.next_flag ? 4 : 0));
+	if (rc)
+		return rc;
+	sink.sort_by_pass(tmp);
+	*n_symbols = sink.ops.size();
+	for (int q = 0; q < 9; q++)
+		pass_off[q] = sink.pass_off[q];
+	if (sink.ops.size() > cap_symbols)
+		return LW_ERR_CAPACITY;
+	if (!sink.ops.empty())
+		std::memcpy(symbols, sink.ops.data(), sink.ops.size() * 8);
+	return LW_OK;
+}
+
+int lw_setup_codebook_vq(const lw_setup *s, unsigned book, float *dst, size_t cap_floats, uint32_t *dims, uint32_t *entries)
+{
+	if (!s || book >= s->p->codebooks.size())
+		return LW_ERR_NULL_ARG;
+	const lw::Codebook &cb = s->p->codebooks[book];
+	if (dims)
+		*dims = cb.dims;
+	if (entries)
+		*entries = cb.entries;
+	if (!cb.has_vq)
+		return LW_ERR_UNSUPPORTED;
+	if (dst) {
+		if (cap_floats < cb.vq.size())
+			return LW_ERR_CAPACITY;
+		std::memcpy(dst, cb.vq.data(), cb.vq.size() * sizeof(float));
+	}
+	return LW_OK;
+}
+
+int lw_setup_submap_info(const lw_setup *s, unsigned mode, unsigned submap, uint8_t *residue_type, uint32_t *partition_size,
+		uint8_t *channels, size_t cap_channels, size_t *n_channels)
+{
+	if (!s || mode >= s->p->modes.size())
+		return LW_ERR_NULL_ARG;
+	const lw::Mapping &mp = s->p->mappings[s->p->modes[mode].mapping];
+	if (submap >= mp.submap_residue.size())
+		return LW_ERR_NULL_ARG;
+	const lw::Residue &rs = s->p->residues[mp.submap_residue[submap]];
+	if (residue_type)
+		*residue_type = rs.type;
+	if (partition_size)
+		*partition_size = rs.partition_size;
+	size_t n = 0;
+	for (size_t c = 0; c < mp.mux.size(); c++)
+		if (mp.mux[c] == submap) {
+			if (channels && n < cap_channels)
+				channels[n] = (uint8_t)c;
+			n++;
+		}
+	if (n_channels)
+		*n_channels = n;
+	return channels && n > cap_channels ? LW_ERR_CAPACITY : LW_OK;
+}
+
 size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint32_t *offsets16)
 {
 	if (!id || !s)
