@@ -14,7 +14,7 @@ P3="FETCH_SIZE"
 P4="WRITE_SIZE"
 i=1
 for P in "$P1" "$P2" "$P3" "$P4"; do
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --settle-ms 5 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python3 - <<PY

@@ -10,7 +10,7 @@ PB="SQ_WAVES SQC_ICACHE_MISSES SQC_ICACHE_HITS SQC_ICACHE_REQ SQ_WAIT_INST_LDS S
 PC="SQ_WAVES SQ_IFETCH SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL"
 i=1
 for P in "$PA" "$PB" "$PC"; do
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --settle-ms 5 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python3 - <<PY
