@@ -96,6 +96,8 @@ struct lw_batch {
 	lw_decoder *dec = nullptr;
 	size_t max_packets = 0;
 	int fmt = 0;
+	uint8_t *h_slab = nullptr, *d_slab = nullptr; // all host->device buffers below are slices of these
+	size_t slab_bytes = 0;
 	LwPacketRec *h_recs = nullptr;
 	uint16_t *h_floor = nullptr;
 	float *h_res = nullptr;
@@ -819,21 +821,33 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	const size_t rec_b = max_packets * sizeof(LwPacketRec);
 	const size_t fl_b = max_packets * ch * d->T.fstride * sizeof(uint16_t);
 	const size_t res_b = max_packets * ch * half1 * sizeof(float);
-	bool ok = hip_ok(hipHostMalloc((void **)&b->h_recs, rec_b), "hipHostMalloc(recs)") &&
-		hip_ok(hipHostMalloc((void **)&b->h_floor, fl_b), "hipHostMalloc(floor)") &&
-		hip_ok(hipHostMalloc((void **)&b->h_res, res_b), "hipHostMalloc(residue)") &&
-		hip_ok(hipMalloc((void **)&b->d_recs, rec_b), "hipMalloc(recs)") &&
-		hip_ok(hipMalloc((void **)&b->d_floor, fl_b), "hipMalloc(floor)") &&
-		hip_ok(hipMalloc((void **)&b->d_res, res_b), "hipMalloc(residue)") &&
-		hip_ok(hipHostMalloc((void **)&b->h_items, max_packets * sizeof(LwFastItem)), "hipHostMalloc(items)") &&
-		hip_ok(hipHostMalloc((void **)&b->h_halo_items, max_packets * sizeof(LwFastItem)), "hipHostMalloc(halo items)") &&
-		hip_ok(hipMalloc((void **)&b->d_items, max_packets * sizeof(LwFastItem)), "hipMalloc(items)") &&
-		hip_ok(hipMalloc((void **)&b->d_halo_items, max_packets * sizeof(LwFastItem)), "hipMalloc(halo items)") &&
-		hip_ok(hipHostMalloc((void **)&b->h_gen, 2 * max_packets * sizeof(uint32_t)), "hipHostMalloc(generic lists)") &&
-		hip_ok(hipMalloc((void **)&b->d_gen, 2 * max_packets * sizeof(uint32_t)), "hipMalloc(generic lists)");
-	if (ok && d->any_floor0)
-		ok = hip_ok(hipHostMalloc((void **)&b->h_fcurve, res_b), "hipHostMalloc(floor curves)") &&
-			hip_ok(hipMalloc((void **)&b->d_fcurve, res_b), "hipMalloc(floor curves)");
+	// every host->device buffer of the batch is a slice of ONE pinned slab mirrored by ONE device slab at the same
+	// offsets: a small batch (the single-packet path of lw_read_audio_packet above all) goes up with one hipMemcpyAsync
+	// instead of five
+	size_t off = 0;
+	auto slice = [&](size_t bytes) {
+		const size_t at = off;
+		off = (off + bytes + 255) & ~(size_t)255;
+		return at;
+	};
+	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
+	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(2 * max_packets * sizeof(uint32_t));
+	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
+	b->slab_bytes = off;
+	bool ok = hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
+		hip_ok(hipMalloc((void **)&b->d_slab, off), "hipMalloc(batch records)");
+	if (ok) {
+		auto H = [&](size_t o) { return b->h_slab + o; };
+		auto D = [&](size_t o) { return b->d_slab + o; };
+		b->h_recs = (LwPacketRec *)H(o_recs), b->d_recs = (LwPacketRec *)D(o_recs);
+		b->h_floor = (uint16_t *)H(o_floor), b->d_floor = (uint16_t *)D(o_floor);
+		b->h_items = (LwFastItem *)H(o_items), b->d_items = (LwFastItem *)D(o_items);
+		b->h_halo_items = (LwFastItem *)H(o_halo), b->d_halo_items = (LwFastItem *)D(o_halo);
+		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
+		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
+		if (d->any_floor0)
+			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
+	}
 	if (!ok) {
 		*err = LW_ERR_DEVICE;
 		lw_batch_destroy(b.release());
@@ -851,25 +865,13 @@ void lw_batch_destroy(lw_batch *b)
 		return;
 	(void)hipSetDevice(b->dec->device);
 	(void)hipDeviceSynchronize();
-	if (b->h_recs)
-		(void)hipHostFree(b->h_recs);
-	if (b->h_floor)
-		(void)hipHostFree(b->h_floor);
-	if (b->h_fcurve)
-		(void)hipHostFree(b->h_fcurve);
-	if (b->h_gen)
-		(void)hipHostFree(b->h_gen);
+	if (b->h_slab)
+		(void)hipHostFree(b->h_slab);
 	if (b->h_sym)
 		(void)hipHostFree(b->h_sym);
 	if (b->h_sym_off)
 		(void)hipHostFree(b->h_sym_off);
-	if (b->h_res)
-		(void)hipHostFree(b->h_res);
-	if (b->h_items)
-		(void)hipHostFree(b->h_items);
-	if (b->h_halo_items)
-		(void)hipHostFree(b->h_halo_items);
-	void *dev[] = {b->d_recs, b->d_floor, b->d_res, b->d_fcurve, b->d_sym, b->d_sym_off, b->d_gen, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_items, b->d_halo_items, b->d_halo};
+	void *dev[] = {b->d_slab, b->d_sym, b->d_sym_off, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -1266,6 +1268,10 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	const size_t ch = b->dec->T.ch;
 	if (b->n == 0)
 		return LW_OK;
+	if (b->slab_bytes <= 64 * 1024 && !b->symbols) { // small batch: the whole slab in one copy
+		HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_slab, b->slab_bytes, hipMemcpyHostToDevice, st));
+		return LW_OK;
+	}
 	HIP_TRY(hipMemcpyAsync(b->d_recs, b->h_recs, b->n * sizeof(LwPacketRec), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(b->d_floor, b->h_floor, b->n * ch * b->dec->T.fstride * sizeof(uint16_t),
 				hipMemcpyHostToDevice, st));
@@ -1546,8 +1552,10 @@ int lw_read_audio_packet(lw_decoder *d, const uint8_t *packet, size_t len, lw_pw
 		HIP_TRY(hipHostMalloc(&d->one_out, std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4)));
 		d->one_out_bytes = std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4);
 	}
-	if (int rc = lw_batch_synth_to_host(b, d->one_out, b->out_elems, nullptr))
+	// the kernels write the PCM straight into the pinned host buffer (device-visible): launch + synchronise, no D2H copy
+	if (int rc = lw_batch_synth(b, d->one_out, b->out_elems, nullptr)) // (a first packet yields no samples, only the state)
 		return rc;
+	HIP_TRY(hipStreamSynchronize(nullptr));
 	std::memcpy(out, d->one_out, b->out_elems * elem_size(fmt));
 	*n_samples = res.n_samples;
 	return LW_OK;
