@@ -9,6 +9,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <utility>
@@ -56,9 +57,13 @@ struct BitReader {
 	uint64_t window() const
 	{
 		const uint64_t byte = pos >> 3;
-		const uint64_t total = (nbits + 7) >> 3;
+		const uint64_t total = nbits >> 3; // nbits is a whole number of bytes
 		uint64_t w = 0;
-		const unsigned navail = (unsigned)((total - byte) < 8 ? (total - byte) : 8);
+		if (byte + 8 <= total) { // everywhere but in the last 7 bytes of the packet: one unaligned load (little-endian host)
+			std::memcpy(&w, d + byte, 8);
+			return w >> (pos & 7);
+		}
+		const unsigned navail = (unsigned)(total > byte ? total - byte : 0);
 		for (unsigned i = 0; i < navail; i++)
 			w |= (uint64_t)d[byte + i] << (8 * i);
 		return w >> (pos & 7);
