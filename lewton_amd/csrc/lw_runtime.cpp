@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -43,6 +45,70 @@ bool hip_ok(hipError_t e, const char *what)
 	} while (0)
 
 extern const float kInverseDbTable[256];
+
+// ---- persistent worker threads of the host entropy stage ----------------------------------------
+// lw_batch_entropy runs a few milliseconds per 4096-packet batch; creating and joining 32-64 threads for every batch
+// cost a fifth of that.  The pool grows on demand and its threads live until the process exits.
+class EntropyPool {
+public:
+	// runs fn() on `n` threads in total (the caller is one of them) and returns when all have finished
+	void run(unsigned n, const std::function<void()> &fn)
+	{
+		if (n <= 1) {
+			fn();
+			return;
+		}
+		std::unique_lock<std::mutex> serial(serial_); // one parallel region at a time
+		{
+			std::unique_lock<std::mutex> g(mu_);
+			while (threads_.size() < n - 1)
+				threads_.emplace_back([this, id = threads_.size()]() { loop(id); });
+			fn_ = &fn;
+			want_ = n - 1;
+			pending_ = n - 1;
+			epoch_++;
+		}
+		cv_.notify_all();
+		fn();
+		std::unique_lock<std::mutex> g(mu_);
+		done_.wait(g, [this]() { return pending_ == 0; });
+		fn_ = nullptr;
+	}
+
+private:
+	void loop(size_t id)
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			const std::function<void()> *fn = nullptr;
+			{
+				std::unique_lock<std::mutex> g(mu_);
+				cv_.wait(g, [&]() { return epoch_ != seen; });
+				seen = epoch_;
+				if (id < want_)
+					fn = fn_;
+			}
+			if (fn) {
+				(*fn)();
+				std::unique_lock<std::mutex> g(mu_);
+				if (--pending_ == 0)
+					done_.notify_one();
+			}
+		}
+	}
+	std::mutex mu_, serial_;
+	std::condition_variable cv_, done_;
+	std::vector<std::thread> threads_;
+	const std::function<void()> *fn_ = nullptr;
+	size_t want_ = 0, pending_ = 0;
+	uint64_t epoch_ = 0;
+};
+
+EntropyPool &entropy_pool()
+{
+	static EntropyPool *p = new EntropyPool(); // never destroyed: its threads are detached from process teardown
+	return *p;
+}
 
 } // namespace
 
@@ -1037,15 +1103,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			}
 		}
 	};
-	if (nt <= 1) {
-		worker();
-	} else {
-		std::vector<std::thread> th;
-		for (unsigned t = 0; t < nt; t++)
-			th.emplace_back(worker);
-		for (auto &t : th)
-			t.join();
-	}
+	entropy_pool().run(nt, worker);
 	if (b->symbols) {
 		const size_t total = pool_used.load();
 		if (overflow) {
