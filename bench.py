@@ -71,6 +71,8 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    # host threads for the (untimed) entropy stage that prepares the records: an equal share of the cores per rank
+    host_threads = max(4, (os.cpu_count() or 8) // max(1, world))
     from lewton_amd import _native as N
     from lewton_amd import audio, header, streamgen as sg
     from lewton_amd.batch import Batch
@@ -105,7 +107,7 @@ def main():
             bt.set_force_generic(True)
         order = rng.integers(0, UNIQUE_PACKETS, PACKETS_PER_BATCH)
         # stream-major order: stream s contributes packets [s*per_stream, (s+1)*per_stream) of the batch
-        res = bt.entropy([(pool[int(i)], spw[k // per_stream]) for k, i in enumerate(order)], n_threads=0)
+        res = bt.entropy([(pool[int(i)], spw[k // per_stream]) for k, i in enumerate(order)], n_threads=host_threads)
         assert all(r[0] == 0 and r[1] == 1024 for r in res)
         pwr = spw
         bt.upload(sptr)
