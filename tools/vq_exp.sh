@@ -1,8 +1,7 @@
 #!/bin/bash
-# (GPU box) k_residue_vq ablations: tools/vq_exp.sh "<flags>" ...
-mkdir -p gpurun_out/vqexp
-for F in "$@"; do
-  LW_EXTRA_FLAGS="$F" python lewton_amd/build.py --force > gpurun_out/vqexp/build.log 2>&1 || tail -3 gpurun_out/vqexp/build.log
+# (GPU box) time k_residue_vq in the bench workload: tools/vq_exp.sh ["<extra hipcc flags>" ...]
+for F in "${@:-}"; do
+  if [ -n "$F" ]; then LW_EXTRA_FLAGS="$F" python lewton_amd/build.py --force > /dev/null 2>&1; fi
   tools/prof.sh vqx --device-vq --steps 160 --warmup 16 --settle-ms 20 > /dev/null 2>&1
   python3 - "$F" <<'PY'
 import csv, sys
