@@ -1,0 +1,132 @@
+"""Robustness of the host stage on malformed input (the reference's counterpart: dev/cmp/tests/fuzzed.rs, and its
+`forbid(unsafe_code)`): (1) the product's C++ header parser and entropy stage under AddressSanitizer + UBSan on mutated
+headers and packets; (2) the same mutations through the shipped library vs the oracle: same error kind, same records."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import FLOOR0_SETUPS, ROOT, SETUPS, oracle_headers, po, sg
+from lewton_amd import audio, header
+
+ALL = dict(SETUPS, **FLOOR0_SETUPS)
+
+
+def _mutate(rng, b, kind):
+    b = bytearray(b)
+    if kind == 0 and len(b) > 1:                       # truncate
+        return bytes(b[: int(rng.integers(1, len(b)))])
+    if kind == 1:                                      # flip 1..4 bits
+        for _ in range(int(rng.integers(1, 5))):
+            i = int(rng.integers(0, len(b)))
+            b[i] ^= 1 << int(rng.integers(0, 8))
+        return bytes(b)
+    if kind == 2:                                      # overwrite a run with random bytes
+        i = int(rng.integers(0, len(b)))
+        n = int(rng.integers(1, 9))
+        b[i:i + n] = rng.integers(0, 256, len(b[i:i + n]), dtype=np.uint8).tobytes()
+        return bytes(b)
+    return bytes(b) + rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tobytes()   # append junk
+
+
+def _cases(seed, n_setup_mut, n_packet_mut):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for name in sorted(ALL):
+        setup = ALL[name]()
+        idp, _cmt, stp = setup.headers()
+        pk = sg.make_stream(setup, "LSSL", 6, seed=seed)
+        muts = [_mutate(rng, p, int(rng.integers(0, 4))) for p in pk for _ in range(n_packet_mut)]
+        cases.append((idp, stp, pk + muts))
+        for _ in range(n_setup_mut):                   # damaged setup headers (most are rejected, some parse)
+            cases.append((idp, _mutate(rng, stp, int(rng.integers(0, 3))), pk[:2]))
+        cases.append((_mutate(rng, idp, 1), stp, pk[:1]))
+    return cases
+
+
+def test_host_stage_under_sanitizers(tmp_path):
+    exe = tmp_path / "host_fuzz"
+    src = os.path.join(ROOT, "tests", "san", "host_fuzz.cpp")
+    csrc = os.path.join(ROOT, "lewton_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+           src, os.path.join(csrc, "lw_headers.cpp"), os.path.join(csrc, "lw_entropy.cpp"), "-o", str(exe)]
+    subprocess.check_call(cmd)
+    cases = _cases(5, n_setup_mut=12, n_packet_mut=6)
+    blob = bytearray(struct.pack("<I", len(cases)))
+    for idp, stp, pks in cases:
+        blob += struct.pack("<I", len(idp)) + idp + struct.pack("<I", len(stp)) + stp + struct.pack("<I", len(pks))
+        for p in pks:
+            blob += struct.pack("<I", len(p)) + p
+    f = tmp_path / "cases.bin"
+    f.write_bytes(bytes(blob))
+    r = subprocess.run([str(exe), str(f)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "packets decoded" in r.stdout
+    decoded = int(r.stdout.split("packets decoded ")[1].split(",")[0])
+    assert decoded > 100
+
+
+@pytest.mark.parametrize("name", sorted(ALL))
+def test_mutated_packets_product_equals_oracle(name):
+    setup = ALL[name]()
+    idp, _cmt, stp = setup.headers()
+    o_id, o_st = oracle_headers(setup)
+    hid = header.read_header_ident(idp)
+    hst = header.read_header_setup(stp, hid.audio_channels, (hid.blocksize_0, hid.blocksize_1))
+    rng = np.random.default_rng(17)
+    pk = sg.make_stream(setup, "LSLLS", 10, seed=4, p_floor_unused=0.1)
+    n_err = n_ok = 0
+    for p in pk:
+        for kind in (0, 1, 1, 2, 3):
+            m = _mutate(rng, p, kind)
+            try:
+                _out, taps = po.read_audio_packet(o_id, o_st, m, po.Pwr(), "f32", taps=True)
+                want_rc = 0
+            except po.OracleError as e:
+                want_rc = e.code
+            try:
+                got = audio.entropy_decode_host(hid, hst, m)
+                rc = 0
+            except audio.AudioReadError as e:
+                rc = e.code
+            assert rc == want_rc, (name, kind, rc, want_rc)
+            if rc:
+                n_err += 1
+                continue
+            n_ok += 1
+            assert np.array_equal(got["residue"].view(np.uint32), taps["residue_pre_inverse"].view(np.uint32))
+            try:
+                assert audio.get_decoded_sample_count(hid, hst, m) == po.get_decoded_sample_count(o_id, o_st, m)
+            except (audio.AudioReadError, po.OracleError):
+                pass
+    assert n_ok > 10
+
+
+def test_mutated_setup_headers_product_equals_oracle():
+    rng = np.random.default_rng(23)
+    agree = rejected = 0
+    for name in sorted(ALL):
+        setup = ALL[name]()
+        idp, _cmt, stp = setup.headers()
+        o_id = po.Ident(idp)
+        hid = header.read_header_ident(idp)
+        for _ in range(40):
+            m = _mutate(rng, stp, int(rng.integers(0, 3)))
+            try:
+                po.Setup(m, o_id)
+                want = 0
+            except po.OracleError as e:
+                want = e.code
+            try:
+                header.read_header_setup(m, hid.audio_channels, (hid.blocksize_0, hid.blocksize_1))
+                got = 0
+            except header.HeaderReadError as e:
+                got = e.code
+            assert got == want, (name, got, want)
+            agree += 1
+            rejected += got != 0
+    assert agree > 200 and rejected > 50

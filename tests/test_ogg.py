@@ -227,3 +227,52 @@ def test_stream_reader_header_bootstrap_without_gpu():
     assert e.value.kind == "OggError" and e.value.inner.kind == "ReadError"
     real = IO.OggStreamReader(GOLDEN)
     assert real.comment_hdr.vendor.startswith("Xiph.Org libVorbis") and real.stream_serial() == 0x54C6F544
+
+
+def test_mutated_containers_product_equals_oracle():
+    """Random damage to a physical stream: the C++ demultiplexer and the oracle deliver the same packets and stop with
+    the same error kind (nothing may crash or hang; sanitizer coverage of the packet layer is in test_fuzz_host.py)."""
+    rng = np.random.default_rng(29)
+    a, b = ogg.PageWriter(10, 7), ogg.PageWriter(11, 3)
+    for w, n in ((a, 30), (b, 20)):
+        for i, p in enumerate(_rand_packets(rng, n, sizes=(0, 5, 100, 255, 300, 900))):
+            w.add_packet(p, 7 * (i + 1), flush=(i % 4 == 3), eos=(i == n - 1))
+    good = ogg.interleave_pages(a, b)
+    kinds = set()
+    for trial in range(120):
+        m = bytearray(good)
+        k = trial % 4
+        if k == 0:
+            m = m[: int(rng.integers(1, len(m)))]
+        elif k == 1:
+            m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 2:
+            i = int(rng.integers(0, len(m)))
+            del m[i:i + int(rng.integers(1, 40))]
+        else:
+            i = int(rng.integers(0, len(m)))
+            m[i:i] = rng.integers(0, 256, int(rng.integers(1, 20)), dtype=np.uint8).tobytes()
+        m = bytes(m)
+        r, o = ogg.PacketReader(m), pyogg.PacketReader(m)
+        n = 0
+        while True:
+            ea = eb = None
+            pa = pb = None
+            try:
+                pa = r.read_packet()
+            except ogg.OggReadError as e:
+                ea = e.kind
+            try:
+                pb = o.read_packet()
+            except pyogg.OggError as e:
+                eb = e.kind
+            assert ea == eb, (trial, n, ea, eb)
+            if ea is not None:
+                kinds.add(ea)
+                break
+            assert (pa is None) == (pb is None), (trial, n)
+            if pa is None:
+                break
+            assert _attrs(pa) == _oattrs(pb), (trial, n)
+            n += 1
+    assert {"HashMismatch", "ReadError", "NoCapturePatternFound"} <= kinds
