@@ -269,7 +269,6 @@ __device__ __forceinline__ void iter54(float *w)
 // the large block sizes, TPB = 64 (four blocks per workgroup, each on its own wave; the stages are ordered by the wave's
 // own LDS ordering, no barrier) for block sizes up to 2^LW_SMALL_BS -- a 256-point short block has 32 butterflies per
 // stage, a 256-thread workgroup and its barriers were 4x the work of the transform itself.
-#define LW_SMALL_BS 9
 template <int TPB>
 __device__ __forceinline__ void stage_sync()
 {
@@ -598,7 +597,7 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 		hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(n_large), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
 				any_coupling ? 1 : 0, skip_mask, 0u);
 	}
-	if (T.bs[0].bs <= LW_SMALL_BS && n_small) {
+	if (n_small) {
 		const uint32_t small_n = std::min(max_n, 1u << LW_SMALL_BS);
 		const uint32_t task_floats = (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 7u) & ~3u;
 		const uint32_t per_wg = LW_BLOCK / 64;

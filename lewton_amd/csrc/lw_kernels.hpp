@@ -29,6 +29,12 @@ struct LwDevTables {
 	uint32_t state_chan_stride;   // n1 / 2
 };
 
+// generic kernels: blocks up to 2^LW_SMALL_BS points are transformed by ONE wave each (four per workgroup), larger ones by
+// a 256-thread workgroup (host: lw_runtime.cpp builds one task list per class)
+#ifndef LW_SMALL_BS
+#define LW_SMALL_BS 9
+#endif
+
 // Tier B: residue inverse VQ on the device
 struct LwSubmapDesc {
 	uint8_t type;      // residue type 0/1/2 of the submap

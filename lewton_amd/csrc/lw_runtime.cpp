@@ -1221,7 +1221,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		}
 		if (!(r.flags & LW_RF_FAST)) {
 			b->has_generic = true;
-			if (p.bs <= 9)
+			if (p.bs <= LW_SMALL_BS)
 				b->h_gen[b->n_gen_small++] = (uint32_t)i;
 			else
 				b->h_gen[b->max_packets + b->n_gen_large++] = (uint32_t)i;
