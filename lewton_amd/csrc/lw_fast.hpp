@@ -82,6 +82,7 @@ struct LwFastPlan {
 #define LW_SRC_TD 4u     // time-domain block at float offset src_arg of B.td (generic-kernel predecessor)
 
 #define LW_IF_NEXT_LDS 1u // the next item of the list takes this packet's right half through LDS
+#define LW_IF_TDONLY 32u  // = LW_RF_TDONLY: no overlap-add here, the whole time-domain block goes to td
 
 // One work item of the specialised kernel = one packet; everything the kernel needs, in one 32-byte scalar load.
 struct LwFastItem {

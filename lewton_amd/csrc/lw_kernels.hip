@@ -532,11 +532,18 @@ __device__ __forceinline__ int16_t to_i16(float x)
 template <int FMT>
 __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatchDev B, void *out_v, uint32_t skip_mask)
 {
-	uint32_t pkt;
-	if (!generic_packet(B, blockIdx.x / T.ch, pkt))
+	uint32_t pkt = blockIdx.x / T.ch;
+	if (B.gen_ola) {
+		if (pkt >= B.n_gen_ola)
+			return;
+		pkt = B.gen_ola[pkt];
+	} else if (pkt >= B.n_packets) {
 		return;
+	}
 	const uint32_t c = blockIdx.x % T.ch;
-	const LwPacketRec rec = B.recs[pkt];
+	LwPacketRec rec = B.recs[pkt];
+	if (rec.flags & LW_RF_TDONLY)
+		rec.flags &= (uint8_t)~LW_RF_FAST; // its time-domain block comes from the specialised kernel, the rest happens here
 	if (rec.flags & skip_mask)
 		return;
 	const uint32_t n = 1u << rec.bs;
@@ -580,7 +587,7 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 	if (B.n_packets == 0)
 		return;
 	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
-	if (any_coupling)
+	if (any_coupling && (!B.gen_small || B.n_gen_small + B.n_gen_large))
 		hipLaunchKernelGGL(k_decouple, dim3(B.gen_small ? B.n_gen_small + B.n_gen_large : B.n_packets), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T,
 				B, skip_mask);
 	static bool once = false;
@@ -635,7 +642,9 @@ void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out,
 	if (B.n_packets == 0)
 		return;
 	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
-	const dim3 g((B.gen_small ? B.n_gen_small + B.n_gen_large : B.n_packets) * T.ch), b(LW_ELEMENTWISE_BLOCK);
+	const dim3 g((B.gen_ola ? B.n_gen_ola : B.n_packets) * T.ch), b(LW_ELEMENTWISE_BLOCK);
+	if (g.x == 0)
+		return;
 	if (fmt == LW_OUT_I16_PLANAR)
 		hipLaunchKernelGGL(k_ola_generic<LW_OUT_I16_PLANAR>, g, b, 0, st, T, B, out, skip_mask);
 	else if (fmt == LW_OUT_I16_INTERLEAVED)

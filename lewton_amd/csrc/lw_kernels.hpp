@@ -76,6 +76,8 @@ struct LwBatchDev {
 	// packets the generic kernels work on, by block-size class; nullptr = every packet (filters inside the kernels)
 	const uint32_t *gen_small, *gen_large;
 	uint32_t n_gen_small, n_gen_large;
+	const uint32_t *gen_ola; // packets of k_ola_generic: the two lists above plus the LW_RF_TDONLY packets
+	uint32_t n_gen_ola;
 };
 
 // Generic path (any block size 64..8192, any window shape, any channel count / coupling list), two phases so

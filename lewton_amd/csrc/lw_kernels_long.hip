@@ -1309,6 +1309,20 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 	}
 }
 
+// ---- raw left half of one channel to a td block: q ascending, then mirrored with the sign flipped (imdct.rs:589-658)
+#define LW_PA_LO0(c) float4_t{R[c][0][3].x, R[c][0][2].x, R[c][1][3].x, R[c][1][2].x}
+#define LW_PA_LO1(c) float4_t{R[c][1][1].x, R[c][1][0].x, R[c][0][1].x, R[c][0][0].x}
+__device__ __forceinline__ void store16_wt(void *p, float4_t v);
+__device__ __forceinline__ void store_left_half(float *dst, uint32_t lane, float4_t lo0, float4_t lo1)
+{
+	const float4_t hi0 = float4_t{-lo1.w, -lo1.z, -lo1.y, -lo1.x}; // 1023-q for q = 511-4l .. 508-4l
+	const float4_t hi1 = float4_t{-lo0.w, -lo0.z, -lo0.y, -lo0.x};
+	store16_wt(dst + 4u * lane, lo0);
+	store16_wt(dst + 508u - 4u * lane, lo1);
+	store16_wt(dst + 512u + 4u * lane, hi0);
+	store16_wt(dst + 1020u - 4u * lane, hi1);
+}
+
 // ---- raw right half of one channel to a [1024]-float block (state slot / td block): q ascending, then mirrored
 __device__ __forceinline__ void store_right_half(float *dst, uint32_t lane, float4_t lo0, float4_t lo1)
 {
@@ -1624,6 +1638,8 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 							}
 							if (to_td)
 								store_right_half(F.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u + 1024u, lane, lo0, lo1);
+							if (it.flags & LW_IF_TDONLY) // the un-windowed left half too: cur[q] = pa(q), cur[1023 - q] = -pa(q)
+								store_left_half(F.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u, lane, LW_PA_LO0(c), LW_PA_LO1(c));
 						}
 				}
 			}

@@ -27,6 +27,9 @@
 #define LW_RF_SKIP 4u          // packet failed in the entropy stage: no device work, no output
 #define LW_RF_FAST 8u          // handled by the specialised long-block kernel
 #define LW_RF_WRITE_TD 16u     // fast packet must also store its raw right half into its td block (generic successor)
+#define LW_RF_TDONLY 32u       // (with LW_RF_FAST) long block whose window shape or stored state is not the (1,1) / full-half case:
+                               // the specialised kernel does floor, decoupling and IMDCT and writes the whole time-domain
+                               // block; window / overlap-add / state are done by k_ola_generic
 
 struct LwPacketRec {
 	uint32_t res_off;   // float offset of this packet's [ch][n/2] residue block

@@ -170,8 +170,8 @@ struct lw_batch {
 	float *h_fcurve = nullptr, *d_fcurve = nullptr; // explicit floor curves (floor 0), layout of the residues
 	// packets of the generic kernels, by size class (block size <= / > 2^9): dense launch grids instead of 8192
 	// workgroups that mostly find out they have nothing to do
-	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [2][max_packets]
-	uint32_t n_gen_small = 0, n_gen_large = 0;
+	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
+	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
 	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
 	bool symbols = false;
 	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
@@ -897,7 +897,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		return at;
 	};
 	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
-	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(2 * max_packets * sizeof(uint32_t));
+	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
 	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
 	b->slab_bytes = off;
 	bool ok = hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
@@ -1151,7 +1151,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	uint64_t alg = 0;
 	const size_t esz = elem_size(b->fmt);
 	b->has_generic = b->has_fast = false;
-	b->n_gen_small = b->n_gen_large = 0;
+	b->n_gen_small = b->n_gen_large = b->n_gen_ola = 0;
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
 	for (size_t i = 0; i < n; i++) {
 		LwPacketRec &r = b->h_recs[i];
@@ -1203,9 +1203,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			r.plen = 0;
 		}
 		// specialised kernel: long block, both neighbours long, stored right part (if any) is a full long half
-		if (d->fast.eligible && !b->force_generic && p.blockflag && p.prev_flag && p.next_flag &&
-				(d->fast.long_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) && (r.prev == -1 || r.plen == n1h)) {
+		// Other long blocks of an eligible stream (window shapes next to short blocks, a stored right part of another
+		// length) still get floor, decoupling and IMDCT from the specialised kernel, which writes their whole time-domain
+		// block; k_ola_generic does their window / overlap-add / state (LW_RF_TDONLY).
+		if (d->fast.eligible && !b->force_generic && p.blockflag && (d->fast.long_mode_mask[p.mode >> 3] & (1u << (p.mode & 7)))) {
 			r.flags |= LW_RF_FAST;
+			if (!(p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h)))
+				r.flags |= LW_RF_TDONLY;
 			b->fast_idx.push_back((uint32_t)i);
 			b->fast_slot.push_back((uint32_t)pw->slot);
 		}
@@ -1225,6 +1229,10 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				b->h_gen[b->n_gen_small++] = (uint32_t)i;
 			else
 				b->h_gen[b->max_packets + b->n_gen_large++] = (uint32_t)i;
+		}
+		if (!(r.flags & LW_RF_FAST) || (r.flags & LW_RF_TDONLY)) {
+			b->has_generic = true; // k_ola_generic has work
+			b->h_gen[2 * b->max_packets + b->n_gen_ola++] = (uint32_t)i;
 		}
 	}
 	// the last ok packet of every stream hands its right part to the stream's state slot
@@ -1252,7 +1260,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		const size_t nf = b->fast_idx.size();
 		for (size_t i = 0; i < n; i++) { // generic successors of fast packets read the td block
 			const LwPacketRec &r = b->h_recs[i];
-			if (!(r.flags & (LW_RF_SKIP | LW_RF_FAST)) && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
+			const bool ola_generic = !(r.flags & LW_RF_FAST) || (r.flags & LW_RF_TDONLY);
+			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
 				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
 		}
 		b->fast_order.resize(nf);
@@ -1279,7 +1288,11 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			it.out_off = r.out_off;
 			it.state_out = r.state_out;
 			it.mode = r.mode;
-			it.flags = (uint8_t)(r.flags & (LW_RF_PARITY_IN | LW_RF_PARITY_OUT | LW_RF_WRITE_TD));
+			it.flags = (uint8_t)(r.flags & (LW_RF_PARITY_IN | LW_RF_PARITY_OUT | LW_RF_WRITE_TD | LW_RF_TDONLY));
+			if (r.flags & LW_RF_TDONLY) {
+				it.flags |= LW_RF_WRITE_TD; // left AND right half go to the td block
+				it.state_out = -1;          // the state slot is written by k_ola_generic
+			}
 			it.pkt = idx;
 		};
 		for (size_t k = 0; k < nf; k++) {
@@ -1289,8 +1302,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			fill(it, idx);
 			if (it.res_off != (uint32_t)(k * ch * n1h) || it.floor_off != (uint32_t)(k * ch * fstride))
 				b->fast_dense = 0;
-			if (r.prev == -1) {
-				it.src_kind = LW_SRC_NONE;
+			if (r.prev == -1 || (r.flags & LW_RF_TDONLY)) {
+				it.src_kind = LW_SRC_NONE; // (a TD-only packet is overlapped later, by k_ola_generic)
 			} else if (r.prev <= -2) {
 				it.src_kind = LW_SRC_STATE;
 				it.src_arg = (uint32_t)(-(r.prev + 2));
@@ -1347,6 +1360,9 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	if (b->n_gen_large)
 		HIP_TRY(hipMemcpyAsync(b->d_gen + b->max_packets, b->h_gen + b->max_packets, b->n_gen_large * sizeof(uint32_t),
 					hipMemcpyHostToDevice, st));
+	if (b->n_gen_ola)
+		HIP_TRY(hipMemcpyAsync(b->d_gen + 2 * b->max_packets, b->h_gen + 2 * b->max_packets, b->n_gen_ola * sizeof(uint32_t),
+					hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
@@ -1392,6 +1408,8 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.gen_large = all_generic ? nullptr : b->d_gen + b->max_packets;
 	B.n_gen_small = b->n_gen_small;
 	B.n_gen_large = b->n_gen_large;
+	B.gen_ola = all_generic ? nullptr : b->d_gen + 2 * b->max_packets;
+	B.n_gen_ola = b->n_gen_ola;
 	B.sym = b->symbols ? b->d_sym : nullptr;
 	B.sym_off = b->d_sym_off;
 	b->last_kernels.clear();
