@@ -363,3 +363,32 @@ def test_device_inverse_vq_matches_oracle(name):
     assert "k_residue_vq" not in batch.last_kernels
     for a, g in zip(again, got):
         assert (a is None) == (g is None) and (a is None or np.array_equal(a, g))
+
+
+@pytest.mark.parametrize("name,pattern", [("stereo", "LLLLLLSSLLLSLLLLLLLLLLLLLLLLLLLLLLLLLSSSSL"), ("surround51", "LLLSLLLLLLLLLLLLLLLLSSL")])
+@pytest.mark.parametrize("fmt", ["i16", "f32"])
+def test_long_mixed_single_stream_in_one_batch(name, pattern, fmt):
+    """ONE stream, 700 packets in one batch: chunks of the specialised kernel joined by the halo pre-pass, LDS hand-over
+    inside the chunks, long blocks next to short ones split between the specialised kernel (IMDCT) and the generic
+    overlap-add, short blocks on the generic path -- against the oracle, packet by packet."""
+    from lewton_amd.batch import Batch
+    setup = ALL_SETUPS[name]()
+    audio, ident, st = _product(setup)
+    o_id, o_st = oracle_headers(setup)
+    dec = audio.decoder_for(ident, st)
+    ch = setup.channels
+    pk = sg.make_stream(setup, pattern, 700, seed=77, p_floor_unused=0.02)
+    pwr, o_pwr = audio.PreviousWindowRight(), po.Pwr()
+    b = Batch(dec, len(pk), fmt)
+    res = b.entropy([(p, pwr) for p in pk], n_threads=4)
+    b.upload()
+    got = b.split(b.synth_to_host(), ch)
+    assert "k_long" in b.last_kernels and "k_ola_generic" in b.last_kernels
+    for i, p in enumerate(pk):
+        want = po.read_audio_packet(o_id, o_st, p, o_pwr, fmt)
+        assert res[i][0] == 0 and got[i].shape == want.shape, i
+        if fmt == "f32":
+            assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), i
+        else:
+            assert np.array_equal(got[i], want), i
+    assert np.array_equal(pwr.data().view(np.uint32), o_pwr.data(ch).view(np.uint32))
