@@ -303,3 +303,14 @@ def test_symbol_capacity_and_null_arguments():
     rc2, _ = vq_model.symbols(hid, hst, p, cap=4)
     assert rc2 == N.ERR_CAPACITY
     assert N.lw_entropy_symbols_host(None, hst._h, p, len(p), None, None, 0, None, None, None, None, None, None) == N.ERR_NULL_ARG
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both public headers must compile as C99 (no C++-isms), and examples/perf.c against them."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "lewton_amd.h"\n#include "lewton.h"\nint main(void) { return (int)sizeof(lw_packet_result) + LW_OGG_EOF; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
+                           os.path.join(ROOT, "examples", "perf.c")])
