@@ -532,7 +532,9 @@ __device__ __forceinline__ int16_t to_i16(float x)
 template <int FMT>
 __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatchDev B, void *out_v, uint32_t skip_mask)
 {
-	uint32_t pkt = blockIdx.x / T.ch;
+	// one workgroup per PACKET, all channels: the chain of dependent loads (list -> record -> predecessor's record ->
+	// data) is paid once per packet, and a stereo short block (2 x 128 samples) fills the 256 threads exactly
+	uint32_t pkt = blockIdx.x;
 	if (B.gen_ola) {
 		if (pkt >= B.n_gen_ola)
 			return;
@@ -540,31 +542,34 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 	} else if (pkt >= B.n_packets) {
 		return;
 	}
-	const uint32_t c = blockIdx.x % T.ch;
 	LwPacketRec rec = B.recs[pkt];
 	if (rec.flags & LW_RF_TDONLY)
 		rec.flags &= (uint8_t)~LW_RF_FAST; // its time-domain block comes from the specialised kernel, the rest happens here
 	if (rec.flags & skip_mask)
 		return;
 	const uint32_t n = 1u << rec.bs;
-	const float *cur = B.td + 2u * rec.res_off + c * n;
+	const float *cur0 = B.td + 2u * rec.res_off;
 	const uint32_t ls = rec.ls, rs = rec.rs, re = rec.re, plen = rec.plen;
-	if (rec.prev != -1) {
+	if (rec.prev != -1 && rs > ls) {
 		const uint32_t m = rs - ls;
 		const float *slope = T.bs[(rec.flags & LW_RF_SLOPE_BS1) ? 1 : 0].window;
-		const float *prev;
+		const float *prev0;
+		uint32_t prev_stride;
 		if (rec.prev >= 0) {
 			const LwPacketRec pr = B.recs[rec.prev];
-			prev = B.td + 2u * pr.res_off + c * (1u << pr.bs) + pr.rs;
+			prev0 = B.td + 2u * pr.res_off + pr.rs;
+			prev_stride = 1u << pr.bs;
 		} else {
 			const uint32_t slot = (uint32_t)(-(rec.prev + 2));
 			const uint32_t par = (rec.flags & LW_RF_PARITY_IN) ? 1u : 0u;
-			prev = B.state + ((size_t)slot * 2 + par) * T.state_stride + c * T.state_chan_stride;
+			prev0 = B.state + ((size_t)slot * 2 + par) * T.state_stride;
+			prev_stride = T.state_chan_stride;
 		}
-		for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
-			float x = cur[ls + i];
+		for (uint32_t e = threadIdx.x; e < m * T.ch; e += blockDim.x) {
+			const uint32_t c = e / m, i = e - c * m;
+			float x = cur0[c * n + ls + i];
 			if (i < plen)
-				x = (x * slope[i]) + (prev[i] * slope[plen - 1 - i]); // audio.rs:1116-1118
+				x = (x * slope[i]) + (prev0[c * prev_stride + i] * slope[plen - 1 - i]); // audio.rs:1116-1118
 			if (FMT == LW_OUT_I16_PLANAR)
 				((int16_t *)out_v)[rec.out_off + c * m + i] = to_i16(x);
 			else if (FMT == LW_OUT_I16_INTERLEAVED)
@@ -573,11 +578,13 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 				((float *)out_v)[rec.out_off + c * m + i] = x;
 		}
 	}
-	if (rec.state_out >= 0) { // audio.rs:1121, :1142-1147: the raw (un-windowed) right part
-		const uint32_t par = (rec.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
-		float *st = B.state + ((size_t)rec.state_out * 2 + par) * T.state_stride + c * T.state_chan_stride;
-		for (uint32_t i = threadIdx.x; i < re - rs; i += blockDim.x)
-			st[i] = cur[rs + i];
+	if (rec.state_out >= 0 && re > rs) { // audio.rs:1121, :1142-1147: the raw (un-windowed) right part
+		const uint32_t par = (rec.flags & LW_RF_PARITY_OUT) ? 1u : 0u, len = re - rs;
+		float *st = B.state + ((size_t)rec.state_out * 2 + par) * T.state_stride;
+		for (uint32_t e = threadIdx.x; e < len * T.ch; e += blockDim.x) {
+			const uint32_t c = e / len, i = e - c * len;
+			st[c * T.state_chan_stride + i] = cur0[c * n + rs + i];
+		}
 	}
 }
 
@@ -642,7 +649,7 @@ void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out,
 	if (B.n_packets == 0)
 		return;
 	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
-	const dim3 g((B.gen_ola ? B.n_gen_ola : B.n_packets) * T.ch), b(LW_ELEMENTWISE_BLOCK);
+	const dim3 g(B.gen_ola ? B.n_gen_ola : B.n_packets), b(LW_ELEMENTWISE_BLOCK);
 	if (g.x == 0)
 		return;
 	if (fmt == LW_OUT_I16_PLANAR)
