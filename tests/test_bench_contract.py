@@ -1,0 +1,30 @@
+"""The bench line the driver consumes: the committed profiles/r01_bench.json (output of bench.py on an MI355X) must carry
+every field of the contract, with consistent numbers."""
+import json
+import os
+
+from common import ROOT
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    line = open(os.path.join(ROOT, "profiles", "r01_bench.json")).readline()
+    d = json.loads(line)
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"].split(" (")[0] == base["metric"].split(" (")[0] and d["unit"] == "packets/s"
+    for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # achieved = algorithmic bytes per launch / launch duration (12 420 B per stereo long packet)
+    assert r["algorithmic_bytes_per_launch"] == 4096 * 12420
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    # value = packets of all ranks / wall time per step
+    assert abs(d["value"] - 4096 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "packets/s" and c["value"] > 0 and "sample" in c
+    assert "bit-exact" in d["config"]["parity"]
