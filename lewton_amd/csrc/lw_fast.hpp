@@ -112,6 +112,7 @@ struct LwFastLaunch {
 	uint32_t rounds;    // rounds per workgroup
 	uint32_t dense;     // item k == packet k with uniform block sizes
 	uint32_t late_from; // first wave of a workgroup that issues its first HBM loads late
+	uint32_t has_tdonly; // some item is LW_IF_TDONLY
 	LwFastUnit units[LW_FAST_WAVES];
 	float *d_halo;
 };

@@ -1390,7 +1390,9 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t byte_addr, uint32_t need)
 		__builtin_amdgcn_s_sleep(1);
 }
 
-template <int FMT, bool RIGHT_ONLY>
+// TD: the batch contains LW_IF_TDONLY items (long blocks next to short ones): a separate instantiation, so that the
+// all-(1,1) batches keep the kernel without that branch (its presence alone cost 2 % of the headline launch time)
+template <int FMT, bool RIGHT_ONLY, bool TD = false>
 __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1638,7 +1640,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 							}
 							if (to_td)
 								store_right_half(F.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u + 1024u, lane, lo0, lo1);
-							if (it.flags & LW_IF_TDONLY) // the un-windowed left half too: cur[q] = pa(q), cur[1023 - q] = -pa(q)
+							if (TD && (it.flags & LW_IF_TDONLY)) // the un-windowed left half too: cur[q] = pa(q), cur[1023 - q] = -pa(q)
 								store_left_half(F.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u, lane, LW_PA_LO0(c), LW_PA_LO1(c));
 						}
 				}
@@ -1698,6 +1700,10 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_ITL_STEREO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_F32_PLANAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_INTERLEAVED, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_ITL_STEREO, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_F32_PLANAR, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_done = true;
 	}
 	if (L.n_halo_items) {
@@ -1716,13 +1722,22 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 		const uint32_t chunk = L.per_round * L.rounds;
 		const uint32_t grid = (L.n_items + chunk - 1) / chunk;
 		F.late_from = L.late_from;
+#define LW_LAUNCH_MAIN(F_)                                                                                     \
+	do {                                                                                                      \
+		if (L.has_tdonly) {                                                                                   \
+			hipLaunchKernelGGL((k_long<F_, false, true>), dim3(grid), dim3(LW_WG), lds, st, F);                \
+		} else {                                                                                              \
+			hipLaunchKernelGGL((k_long<F_, false, false>), dim3(grid), dim3(LW_WG), lds, st, F);               \
+		}                                                                                                     \
+	} while (0)
 		if (fmt == LW_OUT_I16_PLANAR)
-			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, F);
+			LW_LAUNCH_MAIN(LW_OUT_I16_PLANAR);
 		else if (fmt == LW_OUT_I16_INTERLEAVED && F.ch == 2 && L.n_units == 1 && L.units[0].ch_b >= 0)
-			hipLaunchKernelGGL((k_long<LW_OUT_I16_ITL_STEREO, false>), dim3(grid), dim3(LW_WG), lds, st, F);
+			LW_LAUNCH_MAIN(LW_OUT_I16_ITL_STEREO);
 		else if (fmt == LW_OUT_I16_INTERLEAVED)
-			hipLaunchKernelGGL((k_long<LW_OUT_I16_INTERLEAVED, false>), dim3(grid), dim3(LW_WG), lds, st, F);
+			LW_LAUNCH_MAIN(LW_OUT_I16_INTERLEAVED);
 		else
-			hipLaunchKernelGGL((k_long<LW_OUT_F32_PLANAR, false>), dim3(grid), dim3(LW_WG), lds, st, F);
+			LW_LAUNCH_MAIN(LW_OUT_F32_PLANAR);
+#undef LW_LAUNCH_MAIN
 	}
 }

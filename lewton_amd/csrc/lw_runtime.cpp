@@ -172,6 +172,7 @@ struct lw_batch {
 	// workgroups that mostly find out they have nothing to do
 	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
 	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
+	bool has_tdonly = false; // the specialised kernel's work list contains LW_RF_TDONLY packets
 	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
 	bool symbols = false;
 	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
@@ -1152,6 +1153,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	const size_t esz = elem_size(b->fmt);
 	b->has_generic = b->has_fast = false;
 	b->n_gen_small = b->n_gen_large = b->n_gen_ola = 0;
+	b->has_tdonly = false;
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
 	for (size_t i = 0; i < n; i++) {
 		LwPacketRec &r = b->h_recs[i];
@@ -1208,8 +1210,10 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		// block; k_ola_generic does their window / overlap-add / state (LW_RF_TDONLY).
 		if (d->fast.eligible && !b->force_generic && p.blockflag && (d->fast.long_mode_mask[p.mode >> 3] & (1u << (p.mode & 7)))) {
 			r.flags |= LW_RF_FAST;
-			if (!(p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h)))
+			if (!(p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h))) {
 				r.flags |= LW_RF_TDONLY;
+				b->has_tdonly = true;
+			}
 			b->fast_idx.push_back((uint32_t)i);
 			b->fast_slot.push_back((uint32_t)pw->slot);
 		}
@@ -1434,6 +1438,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.rounds = b->fast_rounds;
 		L.dense = b->fast_dense;
 		L.late_from = b->fast_late_from;
+		L.has_tdonly = b->has_tdonly ? 1u : 0u;
 		if (const char *e = getenv("LW_PACE_GROUP"))
 			L.late_from = (uint32_t)atoi(e);
 		for (size_t i = 0; i < d->fast.units.size() && i < LW_FAST_WAVES; i++)
