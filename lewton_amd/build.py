@@ -12,7 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblewton_amd.so")
 SOURCES = ["lw_headers.cpp", "lw_entropy.cpp", "lw_runtime.cpp", "lw_fast.cpp", "lw_ogg.cpp", "lw_capi.cpp", "lw_kernels.hip", "lw_kernels_long.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall",
+ARCH = os.environ.get("LW_OFFLOAD_ARCH", "gfx950")  # e.g. gfx950:xnack- for an experiment
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall",
          "-Wno-unused-result", "-pthread"]
 
 
@@ -62,7 +63,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on " + s)
         if verbose and out:
             print(out.decode())
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-pthread"]
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-pthread"]
     subprocess.check_call(cmd)
     return LIB
 
