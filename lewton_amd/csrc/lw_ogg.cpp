@@ -31,7 +31,8 @@ struct MemSource : Source {
 	int64_t read(uint8_t *dst, size_t n) override
 	{
 		const size_t k = std::min(n, len - pos);
-		std::memcpy(dst, p + pos, k);
+		if (k)
+			std::memcpy(dst, p + pos, k);
 		pos += k;
 		return (int64_t)k;
 	}
@@ -638,7 +639,7 @@ lw_ogg_reader *lw_ogg_reader_open_file(const char *path, int *err)
 	FILE *f = path ? std::fopen(path, "rb") : nullptr;
 	if (!f) {
 		if (err)
-			*err = path ? LW_OGG_READ_ERROR : LW_ERR_NULL_ARG;
+			*err = path ? (int)LW_OGG_READ_ERROR : (int)LW_ERR_NULL_ARG;
 		return nullptr;
 	}
 	auto s = std::make_unique<FileSource>();
@@ -814,7 +815,7 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 		s->ahead.push_back(std::move(q));
 	}
 	if (s->ahead.empty())
-		return eof ? LW_OGG_EOF : LW_OK;
+		return eof ? (int)LW_OGG_EOF : (int)LW_OK;
 	if (int rc = s->ensure_decoder())
 		return rc;
 	if (!s->batch || s->batch_cap < s->ahead.size() || s->batch_fmt != fmt) {

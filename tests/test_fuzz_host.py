@@ -130,3 +130,50 @@ def test_mutated_setup_headers_product_equals_oracle():
             agree += 1
             rejected += got != 0
     assert agree > 200 and rejected > 50
+
+
+def test_ogg_demultiplexer_under_sanitizers(tmp_path):
+    from lewton_amd import ogg
+    exe = tmp_path / "ogg_fuzz"
+    src = os.path.join(ROOT, "tests", "san", "ogg_fuzz.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", src,
+                           "-o", str(exe)])
+    rng = np.random.default_rng(31)
+    a, b = ogg.PageWriter(21, 9), ogg.PageWriter(22, 2)
+    for w, n in ((a, 60), (b, 25)):
+        for i in range(n):
+            p = rng.integers(0, 256, int(rng.choice([0, 1, 40, 255, 256, 700, 5000, 70000])), dtype=np.uint8).tobytes()
+            w.add_packet(p, 11 * (i + 1), flush=(i % 5 == 4), eos=(i == n - 1))
+    good = ogg.interleave_pages(a, b)
+    real = open(os.path.join(ROOT, "tests", "golden", "invalid_keypress.ogg"), "rb").read()
+    cases = [good, real, b"", b"OggS", good[:27], good[:28]]
+    for base in (good, real):
+        for _ in range(150):
+            m = bytearray(base)
+            k = int(rng.integers(0, 5))
+            if k == 0:
+                m = m[: int(rng.integers(0, len(m)))]
+            elif k == 1:
+                for _ in range(int(rng.integers(1, 6))):
+                    m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 2:
+                i = int(rng.integers(0, len(m)))
+                del m[i:i + int(rng.integers(1, 300))]
+            elif k == 3:
+                i = int(rng.integers(0, len(m)))
+                m[i:i] = rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8).tobytes()
+            else:                                        # a valid-looking header with an absurd lacing table / size
+                i = int(rng.integers(0, max(1, len(m) - 30)))
+                m[i:i + 4] = b"OggS"
+                m[i + 4] = 0
+                m[min(len(m) - 1, i + 26)] = 255
+            cases.append(bytes(m))
+    blob = bytearray(struct.pack("<I", len(cases)))
+    for c in cases:
+        blob += struct.pack("<I", len(c)) + c
+    f = tmp_path / "ogg_cases.bin"
+    f.write_bytes(bytes(blob))
+    r = subprocess.run([str(exe), str(f)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "packets" in r.stdout and int(r.stdout.split("packets ")[1].split(",")[0]) > 500
