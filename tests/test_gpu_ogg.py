@@ -186,3 +186,30 @@ def test_bad_audio_packet_surfaces_as_bad_audio():
     with pytest.raises(pyogg.VorbisError) as eo:
         o.read_dec_packet()
     assert e.value.kind == eo.value.kind == "BadAudio" and e.value.code == eo.value.inner == po.AUDIO_IS_HEADER
+
+
+@pytest.mark.parametrize("lookahead", [1, 7, 1024])
+def test_ogg2wav_example_matches_oracle(tmp_path, lookahead):
+    """examples/ogg2wav.c (C ABI only): the WAV payload is the oracle's interleaved decode of the same file."""
+    import subprocess
+    from common import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples"), "ogg2wav"])
+    setup, pk, w = _vorbis_stream("stereo", "LLSSLLL", 60, per_page=6, trim=333)
+    src = tmp_path / "in.ogg"
+    src.write_bytes(w.bytes())
+    for path in (str(src), GOLDEN):
+        dst = tmp_path / "out.wav"
+        subprocess.check_call([os.path.join(ROOT, "examples", "ogg2wav"), path, str(dst), str(lookahead)])
+        raw = dst.read_bytes()
+        assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and raw[36:40] == b"data"
+        n_bytes = int.from_bytes(raw[40:44], "little")
+        got = np.frombuffer(raw[44:44 + n_bytes], np.int16)
+        o = pyogg.OggStreamReader(open(path, "rb").read(), "i16_itl")
+        want = []
+        while True:
+            p = o.read_dec_packet()
+            if p is None:
+                break
+            want.append(p)
+        want = np.concatenate(want)
+        assert len(raw) == 44 + n_bytes and np.array_equal(got, want)

@@ -314,3 +314,4 @@ def test_headers_are_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
     subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
                            os.path.join(ROOT, "examples", "perf.c")])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, os.path.join(ROOT, "examples", "ogg2wav.c")])
