@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true", help="time the generic kernels instead of the specialised one")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-all-cores-seconds", type=float, default=4.0,
+                    help="also time the CPU port on every host core at once (one worker process per core); 0 = skip")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of hipGraph replay")
     ap.add_argument("--format", choices=["i16", "i16_interleaved", "f32"], default="i16",
                     help="output sample format (the BASELINE metric is quoted on planar i16 = Vec<Vec<i16>>)")
@@ -229,6 +231,24 @@ def main():
         cpu = {"value": npk / secs, "unit": "packets/s", "cores": 1, "kind": "port",
                "sample": "%d stereo long packets (same generator as the GPU workload), oracle/lewton_oracle.c "
                          "(C restatement of lewton incl. entropy decode), 1 thread, %.1f s" % (npk, secs)}
+        # all host cores, one independent stream per core (separate worker processes; informational)
+        if args.cpu_all_cores_seconds > 0:
+            try:
+                import subprocess
+                import sys
+                ncore = os.cpu_count() or 1
+                procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", str(2000 + i), str(args.cpu_all_cores_seconds)],
+                                          cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(ncore)]
+                tot = 0.0
+                for p in procs:
+                    out, _ = p.communicate(timeout=120 + 10 * args.cpu_all_cores_seconds)
+                    n_, s_ = out.split()
+                    tot += float(n_) / float(s_)
+                cpu["all_cores"] = {"value": tot, "unit": "packets/s", "cores": ncore, "kind": "port",
+                                    "sample": "%d worker processes, one synthetic stream each, %.0f s each" % (
+                                        ncore, args.cpu_all_cores_seconds)}
+            except Exception as e:  # informational only
+                cpu["all_cores"] = {"error": repr(e)}
 
     # HBM traffic of one launch from the PMC passes (tools/pmc.sh -> profiles/): measured in separate rocprofv3 runs of
     # this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; null if no profile is committed
