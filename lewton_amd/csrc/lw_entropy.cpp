@@ -61,17 +61,18 @@ FloorResult floor_one_decode(BitReader &r, const Setup &s, const Floor1 &fl, uin
 	if (!r.read(b, y[k]))
 		return FL_UNUSED;
 	k++;
+	CodeReader cr(r); // only codewords from here on; a failed read leaves r at the end of the packet like BitReader would
 	for (uint8_t c : fl.partition_class) {
 		const unsigned cdim = fl.class_dim[c], cbits = fl.class_sub[c];
 		const uint32_t csub = (1u << cbits) - 1;
 		uint32_t cval = 0;
-		if (cbits && !s.codebooks[fl.class_master[c]].huff.decode(r, cval))
+		if (cbits && !cr.next(s.codebooks[fl.class_master[c]].huff, cval))
 			return FL_UNUSED;
 		for (unsigned d = 0; d < cdim; d++) {
 			const int book = fl.sub_books[c][cval & csub];
 			cval >>= cbits;
 			if (book >= 0) {
-				if (!s.codebooks[book].huff.decode(r, y[k]))
+				if (!cr.next(s.codebooks[book].huff, y[k]))
 					return FL_UNUSED;
 			} else {
 				y[k] = 0;
@@ -79,6 +80,7 @@ FloorResult floor_one_decode(BitReader &r, const Setup &s, const Floor1 &fl, uin
 			k++;
 		}
 	}
+	cr.sync();
 	return FL_OK;
 }
 
@@ -152,13 +154,14 @@ void floor_zero_curve(const float *cosc, uint64_t amplitude, const Floor0 &fl, b
 	}
 }
 
-// audio.rs:354-367 with wrapping u32 arithmetic (release-mode Rust)
-inline uint32_t render_point(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x)
+// audio.rs:354-367 with wrapping u32 arithmetic (release-mode Rust).  x - x0 and the divisor adx = x1 - x0 are
+// header constants of the post: the division is a multiplication by the post's precomputed 2^64 / adx + 1, exact for
+// every 32-bit dividend (the divisor is below 2^16).
+inline uint32_t render_point(uint32_t y0, uint32_t y1, uint32_t dx, uint64_t adx_magic)
 {
 	const int32_t dy = (int32_t)(y1 - y0);
-	const uint32_t adx = x1 - x0;
 	const uint32_t ady = dy < 0 ? 0u - (uint32_t)dy : (uint32_t)dy;
-	const uint32_t off = (ady * (x - x0)) / adx;
+	const uint32_t off = (uint32_t)(((unsigned __int128)(uint32_t)(ady * dx) * adx_magic) >> 64);
 	return dy < 0 ? y0 - off : y0 + off;
 }
 
@@ -174,8 +177,7 @@ void floor_one_record(const uint32_t *y, const Floor1 &fl, uint16_t *rec)
 	step2[0] = step2[1] = true;
 	for (size_t i = 2; i < F; i++) {
 		const unsigned lo = fl.lo_idx[i], hi = fl.hi_idx[i];
-		const int32_t predicted =
-			(int32_t)render_point(fl.x_list[lo], final_y[lo], fl.x_list[hi], final_y[hi], fl.x_list[i]);
+		const int32_t predicted = (int32_t)render_point(final_y[lo], final_y[hi], fl.dx[i], fl.adx_magic[i]);
 		const int32_t val = (int32_t)y[i];
 		const int32_t highroom = (int32_t)(range - (uint32_t)predicted);
 		const int32_t lowroom = predicted;
@@ -203,16 +205,24 @@ void floor_one_record(const uint32_t *y, const Floor1 &fl, uint16_t *rec)
 	}
 }
 
+// v[0..DIMS) += e[0..DIMS): the same f32 additions in the same order for every DIMS (lanes are independent)
+template <unsigned DIMS> inline void add_entry(float *v, const float *e)
+{
+	for (unsigned j = 0; j < DIMS; j++)
+		v[j] += e[j];
+}
+
 // audio.rs:587-618.  With a sink the additions are recorded (coordinate `coord` of v[0]) instead of performed.
-inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len,
+inline bool read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len,
 		SymbolSink *sink, uint32_t coord, uint32_t book, unsigned pass)
 {
 	const unsigned dims = cb.dims;
+	const Huffman &h = cb.huff;
 	uint32_t idx;
 	if (rtype == 0) {
 		const unsigned step = psize / dims;
 		for (unsigned i = 0; i < step; i++) {
-			if (!cb.huff.decode(r, idx))
+			if (!cr.next(h, idx))
 				return false;
 			if (sink) {
 				sink->push(coord + i, book, idx, pass);
@@ -222,22 +232,42 @@ inline bool read_partition(BitReader &r, const Codebook &cb, unsigned rtype, uns
 			for (unsigned j = 0; j < dims; j++)
 				v[i + j * step] += e[j];
 		}
-	} else {
-		unsigned i = 0;
-		while (i < psize) {
-			if (!cb.huff.decode(r, idx))
-				return false;
-			if ((size_t)i + dims > vec_len)
-				break;
-			if (sink) {
-				sink->push(coord + i, book, idx, pass);
-			} else {
-				const float *e = &cb.vq[(size_t)idx * dims];
-				for (unsigned j = 0; j < dims; j++)
-					v[i + j] += e[j];
-			}
-			i += dims;
+		return true;
+	}
+	const float *vq = cb.vq.data();
+	if (!sink && (size_t)psize <= vec_len && psize % dims == 0) { // the whole partition is inside the vector
+		switch (dims) {
+#define LW_PART_LOOP(D)                               \
+	case D:                                           \
+		for (unsigned i = 0; i < psize; i += D) {     \
+			if (!cr.next(h, idx))                     \
+				return false;                         \
+			add_entry<D>(v + i, vq + (size_t)idx * D); \
+		}                                             \
+		return true;
+			LW_PART_LOOP(1)
+			LW_PART_LOOP(2)
+			LW_PART_LOOP(4)
+			LW_PART_LOOP(8)
+#undef LW_PART_LOOP
+		default:
+			break;
 		}
+	}
+	unsigned i = 0;
+	while (i < psize) {
+		if (!cr.next(h, idx))
+			return false;
+		if ((size_t)i + dims > vec_len)
+			break;
+		if (sink) {
+			sink->push(coord + i, book, idx, pass);
+		} else {
+			const float *e = vq + (size_t)idx * dims;
+			for (unsigned j = 0; j < dims; j++)
+				v[i + j] += e[j];
+		}
+		i += dims;
 	}
 	return true;
 }
@@ -260,6 +290,10 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 	scr.cls.assign(ch * stride, 0);
 	uint32_t *cls = scr.cls.data();
 	const uint32_t ncls = rs.classifications;
+	const uint8_t *digits = rs.class_digits.empty() ? nullptr : rs.class_digits.data();
+	CodeReader cr(r);
+	// every exit leaves r.pos where the reference's reader stands: a failed read went through Huffman::decode (which moved
+	// r.pos to the end of the packet), a completed loop syncs below
 	for (unsigned pass = 0; pass < 8; pass++) {
 		size_t pc = 0;
 		while (pc < parts) {
@@ -268,11 +302,18 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 					if (dnd[j])
 						continue;
 					uint32_t t;
-					if (!classbook.huff.decode(r, t))
+					if (!cr.next(classbook.huff, t))
 						return true; // end of packet is normal (audio.rs:655-660)
-					for (size_t i = cpc; i-- > 0;) {
-						cls[j * stride + pc + i] = t % ncls;
-						t /= ncls;
+					uint32_t *c = cls + j * stride + pc;
+					if (digits) {
+						const uint8_t *dg = digits + (size_t)t * cpc;
+						for (size_t i = 0; i < cpc; i++)
+							c[i] = dg[i];
+					} else {
+						for (size_t i = cpc; i-- > 0;) {
+							c[i] = t % ncls;
+							t /= ncls;
+						}
 					}
 				}
 			}
@@ -284,13 +325,14 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 					if (!(rb.vals_used & (1u << pass)))
 						continue;
 					const size_t offs = begin + pc * rs.partition_size;
-					if (!read_partition(r, s.codebooks[rb.val_i[pass]], rs.type, rs.partition_size,
+					if (!read_partition(cr, s.codebooks[rb.val_i[pass]], rs.type, rs.partition_size,
 								vectors + j * actual + offs, actual - offs, sink, (uint32_t)(j * actual + offs), rb.val_i[pass], pass))
 						return true;
 				}
 			}
 		}
 	}
+	cr.sync();
 	return true;
 }
 
@@ -299,13 +341,13 @@ bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, c
 		EntropyScratch &scr, SymbolSink *sink)
 {
 	const size_t half = n / 2;
-	if (!sink)
-		std::memset(out, 0, sizeof(float) * ch * half);
-	if (rs.type != 2)
-		return residue_inner(r, s, rs, n, dnd, ch, out, scr, sink);
 	bool any = false;
 	for (size_t j = 0; j < ch; j++)
 		any |= !dnd[j];
+	if (!sink && (rs.type != 2 || !any)) // (the type-2 path below writes every element of `out`)
+		std::memset(out, 0, sizeof(float) * ch * half);
+	if (rs.type != 2)
+		return residue_inner(r, s, rs, n, dnd, ch, out, scr, sink);
 	if (!any)
 		return true;
 	const size_t bs2 = (size_t)(uint16_t)((uint16_t)n * (uint16_t)ch); // `cur_blocksize * ch as u16` wraps (:745)

@@ -28,6 +28,7 @@ Huffman::BuildResult Huffman::build(const uint8_t *lengths, size_t n)
 	nodes.clear();
 	single = -1;
 	used = 0;
+	has_lut = false;
 	uint32_t avail[33];
 	std::memset(avail, 0, sizeof(avail));
 	std::vector<uint32_t> code(n, 0); // left-aligned path bits
@@ -105,6 +106,39 @@ Huffman::BuildResult Huffman::build(const uint8_t *lengths, size_t n)
 			}
 		}
 	}
+	// second level: one sub-table per LUT_BITS-bit prefix that only long codes share, indexed by the following
+	// min(longest code - LUT_BITS, SUB_BITS) bits; codes longer than that keep a zero entry (tree walk)
+	std::vector<uint8_t> sub_bits((size_t)1 << LUT_BITS, 0);
+	auto stream_bits = [&](size_t i) { // bit k of the result = k-th bit of entry i's code in stream order
+		uint32_t v = 0;
+		for (unsigned k = 0; k < lengths[i]; k++)
+			v |= ((code[i] >> (31 - k)) & 1u) << k;
+		return v;
+	};
+	for (size_t i = 0; i < n; i++)
+		if (lengths[i] > LUT_BITS) {
+			uint8_t &sb = sub_bits[stream_bits(i) & ((1u << LUT_BITS) - 1)];
+			sb = std::max<uint8_t>(sb, (uint8_t)std::min<unsigned>(lengths[i] - LUT_BITS, SUB_BITS));
+		}
+	for (size_t p = 0; p < ((size_t)1 << LUT_BITS); p++)
+		if (sub_bits[p] && lut.size() + ((size_t)1 << sub_bits[p]) <= (1u << 24)) {
+			lut[p] = LINK | ((uint32_t)sub_bits[p] << 24) | (uint32_t)lut.size();
+			lut.resize(lut.size() + ((size_t)1 << sub_bits[p]), 0);
+		}
+	for (size_t i = 0; i < n && i < (1u << 24); i++) {
+		const unsigned len = lengths[i];
+		if (len <= LUT_BITS)
+			continue;
+		const uint32_t bits = stream_bits(i);
+		const uint32_t link = lut[bits & ((1u << LUT_BITS) - 1)];
+		const unsigned sb = (link >> 24) & 0x7fu;
+		if (!(link & LINK) || len - LUT_BITS > sb)
+			continue;
+		const unsigned own = len - LUT_BITS;
+		for (uint32_t hi = 0; hi < (1u << (sb - own)); hi++)
+			lut[(link & 0xffffffu) + ((bits >> LUT_BITS) | (hi << own))] = ((uint32_t)len << 24) | (uint32_t)i;
+	}
+	has_lut = true;
 	return VALID;
 }
 
@@ -436,6 +470,8 @@ void read_floor(Rd &rd, Floor &fl, uint16_t codebook_cnt, uint8_t bs0, uint8_t b
 	// neighbours of every post among the earlier posts (audio.rs:253-292): header-only, so done once here
 	f.lo_idx.assign(F, 0);
 	f.hi_idx.assign(F, 0);
+	f.dx.assign(F, 0);
+	f.adx_magic.assign(F, 0);
 	for (size_t i = 2; i < F; i++) {
 		int lo = -1, hi = -1;
 		for (size_t j = 0; j < i; j++) {
@@ -448,6 +484,8 @@ void read_floor(Rd &rd, Floor &fl, uint16_t codebook_cnt, uint8_t bs0, uint8_t b
 			bad(); // unreachable after the duplicate check (posts 0 and 1 bracket every x < 2^rangebits)
 		f.lo_idx[i] = (uint16_t)lo;
 		f.hi_idx[i] = (uint16_t)hi;
+		f.dx[i] = f.x_list[i] - f.x_list[lo];
+		f.adx_magic[i] = UINT64_MAX / (uint64_t)(f.x_list[hi] - f.x_list[lo]) + 1; // adx >= 2: lo < i < hi are distinct integers
 	}
 }
 
@@ -487,6 +525,17 @@ void read_residue(Rd &rd, Residue &rs, const std::vector<Codebook> &cbs)
 	}
 	if (rs.classbook >= cbs.size())
 		bad();
+	const Codebook &cb = cbs[rs.classbook];
+	if (cb.dims && (uint64_t)cb.entries * cb.dims <= (1u << 16)) {
+		rs.class_digits.resize((size_t)cb.entries * cb.dims);
+		for (uint32_t e = 0; e < cb.entries; e++) {
+			uint32_t t = e;
+			for (size_t i = cb.dims; i-- > 0;) {
+				rs.class_digits[(size_t)e * cb.dims + i] = (uint8_t)(t % rs.classifications);
+				t /= rs.classifications;
+			}
+		}
+	}
 }
 
 // header.rs:985-1057

@@ -112,17 +112,31 @@ struct BitReader {
 
 // Huffman decoder for one codebook.  Codewords follow the Vorbis assignment rule (each entry, in
 // entry order, takes the lowest free codeword of its length); decoding uses a LUT on the next
-// LUT_BITS bits with a binary-tree walk for longer codes.  Results are identical to a bit-by-bit
-// walk, including at the end of a packet (a code that runs past the end consumes the rest and fails).
+// LUT_BITS bits, a second-level table on up to SUB_BITS more for prefixes shared by longer codes, and a
+// binary-tree walk for what is longer still.  Results are identical to a bit-by-bit walk, including at
+// the end of a packet (a code that runs past the end consumes the rest and fails).
 struct Huffman {
-	static constexpr unsigned LUT_BITS = 10;
-	std::vector<uint32_t> lut;  // (len << 24) | symbol; len == 0 -> walk the tree
+	static constexpr unsigned LUT_BITS = 10, SUB_BITS = 8;
+	static constexpr uint32_t LINK = 0x80000000u;
+	// first 2^LUT_BITS entries: (len << 24) | symbol, or LINK | (sub_bits << 24) | offset of the prefix's sub-table in
+	// this vector (entries of the same form, len = whole code length); len == 0 -> walk the tree
+	std::vector<uint32_t> lut;
 	std::vector<int32_t> nodes; // 2 ints per node: child for bit 0 / bit 1; >= 0 node index, < 0 = ~symbol, INT32_MIN = none
 	int32_t single = -1;        // single-entry book: any one bit decodes this entry (huffman_tree.rs:202-217)
 	uint32_t used = 0;
+	bool has_lut = false;       // lut is populated and the book has more than one entry (CodeReader's fast path)
 
 	enum BuildResult { VALID = 0, OVERSPECIFIED = 1, UNDERPOPULATED = 2, INVALID_SINGLE = 3 };
 	BuildResult build(const uint8_t *lengths, size_t n);
+
+	// table entry for the code at the start of window `w` (>= LUT_BITS + SUB_BITS bits, zero padded); len 0 = not in the tables
+	inline uint32_t lookup(uint64_t w) const
+	{
+		uint32_t e = lut[w & ((1u << LUT_BITS) - 1)];
+		if (e & LINK)
+			e = lut[(e & 0xffffffu) + ((w >> LUT_BITS) & ((1u << ((e >> 24) & 0x7fu)) - 1))];
+		return e;
+	}
 
 	inline bool decode(BitReader &r, uint32_t &sym) const
 	{
@@ -136,7 +150,7 @@ struct Huffman {
 		const uint64_t w = r.window();
 		const uint64_t rem = r.remaining();
 		if (!lut.empty()) {
-			const uint32_t e = lut[w & ((1u << LUT_BITS) - 1)];
+			const uint32_t e = lookup(w);
 			const unsigned len = e >> 24;
 			if (len) {
 				if (len > rem) {
@@ -193,6 +207,8 @@ struct Floor1 {
 	std::vector<uint32_t> x_list;
 	// derived, header-only (audio.rs:253-292 evaluated once instead of per packet)
 	std::vector<uint16_t> lo_idx, hi_idx; // per post (header order), valid for i >= 2
+	std::vector<uint32_t> dx;             // x_list[i] - x_list[lo_idx[i]]
+	std::vector<uint64_t> adx_magic;      // 2^64 / (x_list[hi] - x_list[lo]) + 1: n / adx == (n * magic) >> 64 for every u32 n
 	std::vector<uint16_t> sorted_idx;     // floor1_x_list_sorted[i].0 (header.rs:887-889)
 	std::vector<uint32_t> sorted_x;       // floor1_x_list_sorted[i].1
 	uint32_t range() const
@@ -214,6 +230,62 @@ struct Floor {
 	Floor1 f1;
 };
 
+// Codeword reader of the residue loops: the bit window lives in registers across codewords and is topped up without
+// a branch (w |= next 8 bytes << avail; the bytes already covered are OR-ed again with themselves).  The fast path runs
+// while the 8 bytes at `byte` are inside the packet, where a table hit (<= LUT_BITS + SUB_BITS bits) cannot run into
+// the end; everything else (longer codes, the tail of the packet, single-entry books) goes through Huffman::decode,
+// whose results this reader reproduces exactly.
+struct CodeReader {
+	BitReader &r;
+	const uint64_t total; // bytes in the packet
+	uint64_t w = 0, byte = 0; // window (bit 0 = next unread bit) and the offset of the first byte not yet counted in avail
+	unsigned avail = 0;       // bits of w accounted for: the read position is 8 * byte - avail
+	bool live = false;        // w / byte / avail are valid (else r.pos is the read position)
+	explicit CodeReader(BitReader &r_) : r(r_), total(r_.nbits >> 3) {}
+	inline bool next(const Huffman &h, uint32_t &sym)
+	{
+		if (h.has_lut) {
+			if (!live) {
+				const uint64_t b = r.pos >> 3;
+				if (b + 16 <= total) {
+					const unsigned drop = (unsigned)(r.pos & 7);
+					uint64_t x;
+					std::memcpy(&x, r.d + b, 8);
+					w = x >> drop;
+					avail = 56 - drop;
+					byte = b + 7;
+					live = true;
+				}
+			}
+			if (live) {
+				if (byte + 8 <= total) {
+					uint64_t x;
+					std::memcpy(&x, r.d + byte, 8);
+					w |= x << avail;
+					byte += (63 - avail) >> 3;
+					avail |= 56;
+					const uint32_t e = h.lookup(w);
+					const unsigned len = e >> 24;
+					if (len) {
+						w >>= len;
+						avail -= len;
+						sym = e & 0xffffffu;
+						return true;
+					}
+				}
+			}
+		}
+		sync();
+		return h.decode(r, sym);
+	}
+	void sync()
+	{
+		if (live)
+			r.pos = byte * 8 - avail;
+		live = false;
+	}
+};
+
 struct ResidueBook {
 	uint8_t vals_used = 0;
 	uint8_t val_i[8] = {0};
@@ -224,6 +296,9 @@ struct Residue {
 	uint32_t begin = 0, end = 0, partition_size = 1;
 	uint8_t classifications = 1, classbook = 0;
 	std::vector<ResidueBook> books;
+	// derived: the classification digits of every classbook entry ([entry][classbook.dims], audio.rs:662-668 evaluated at
+	// setup time); empty when the table would be large, then the digits are computed per codeword
+	std::vector<uint8_t> class_digits;
 };
 
 struct Mapping {

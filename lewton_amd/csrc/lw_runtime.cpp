@@ -518,11 +518,13 @@ int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bi
 	if (rc)
 		return rc;
 	if (bits && syms && n_syms) {
+		// through the residue loops' reader: table path while 8 bytes lie ahead, Huffman::decode for the rest
 		lw::BitReader r(bits, bits_len);
+		lw::CodeReader cr(r);
 		size_t k = 0;
 		while (k < max_syms) {
 			uint32_t sym;
-			if (!h.decode(r, sym))
+			if (!cr.next(h, sym))
 				break;
 			syms[k++] = sym;
 		}

@@ -531,9 +531,15 @@ def _res_books(ix):
     ]
 
 
-def stereo_setup(sample_rate: int = 44100, bs0: int = 8, bs1: int = 11, residue_type: int = 2) -> StreamSetup:
-    """2 ch, bs 8/11 (the sizes of lewton's ident-header test, src/header.rs:264-276)."""
+def stereo_setup(sample_rate: int = 44100, bs0: int = 8, bs1: int = 11, residue_type: int = 2,
+                 single_entry_book: bool = False) -> StreamSetup:
+    """2 ch, bs 8/11 (the sizes of lewton's ident-header test, src/header.rs:264-276).
+    single_entry_book: the second pass of class 2 uses a one-entry codebook (one bit per codeword, either value,
+    src/huffman_tree.rs:202-217)."""
     books, ix = _std_books()
+    if single_entry_book:
+        ix["vq2fine"] = len(books)
+        books.append(vq_lattice_book(2, [0.5], 1.0, delta=0.5))
     n0h, n1h = (1 << bs0) // 2, (1 << bs1) // 2
     fl_short = _floor1(_scale_x(SHORT_X, 128, n0h), bs0 - 1, 4, ix["y16"], ix["master8"], ix["y16"])
     fl_long = _floor1(_scale_x(LONG_X, 1024, n1h), bs1 - 1, 2, ix["y16"], ix["master8"], ix["y32"])

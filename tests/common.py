@@ -20,6 +20,8 @@ SETUPS = {
     "stereo_6_13": lambda: sg.stereo_setup(bs0=6, bs1=13),
     "stereo_7_7": lambda: sg.stereo_setup(bs0=7, bs1=7),
 }
+# host-stage tests only (no GPU test iterates these): a residue pass through a one-entry codebook
+HOST_SETUPS = dict(SETUPS, stereo_single_entry=lambda: sg.stereo_setup(single_entry_book=True))
 # floor type 0: curve evaluated by the host stage, multiplied on the GPU
 FLOOR0_SETUPS = {
     "floor0": lambda: sg.floor0_setup(),

@@ -9,10 +9,10 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import FLOOR0_SETUPS, ROOT, SETUPS, oracle_headers, po, sg
+from common import FLOOR0_SETUPS, HOST_SETUPS, ROOT, oracle_headers, po, sg
 from lewton_amd import audio, header
 
-ALL = dict(SETUPS, **FLOOR0_SETUPS)
+ALL = dict(HOST_SETUPS, **FLOOR0_SETUPS)
 
 
 def _mutate(rng, b, kind):

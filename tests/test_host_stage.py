@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from common import ROOT, SETUPS, floor_from_record, floor_x_sorted, oracle_headers, po, sg
+from common import HOST_SETUPS, ROOT, SETUPS, floor_from_record, floor_x_sorted, oracle_headers, po, sg
 from lewton_amd import _native as N
 from lewton_amd import audio, header
 
@@ -61,18 +61,26 @@ def test_huffman_golden():
 
 
 def test_huffman_product_vs_oracle_random():
+    # the product decodes with a two-level table + tree walk behind a register bit window (lw_host.hpp CodeReader); the
+    # oracle walks bit by bit.  Trials cover short books, books with codes beyond both table levels (> 18 bits), and
+    # inputs of every length class (shorter than the window, ending inside a code)
     rng = np.random.default_rng(5)
     L = po.lib()
-    for trial in range(300):
-        n = int(rng.integers(1, 40))
-        if trial % 3 == 0:
+    for trial in range(420):
+        n = int(rng.integers(1, 40)) if trial < 300 else int(rng.integers(200, 3000))
+        if trial >= 300:
+            lens = np.array(sg.huffman_lengths(np.exp(-rng.random(n) * (8 + 3 * (trial % 7))) + 1e-12, 32), np.uint8)
+        elif trial % 3 == 0:
             lens = np.array(sg.huffman_lengths(rng.random(n) ** 3 + 1e-3, 32), np.uint8)
             if trial % 6 == 0 and n > 2:
                 lens[rng.integers(0, n)] = int(rng.integers(0, 6))  # usually breaks completeness
         else:
             lens = rng.integers(0, 7, n).astype(np.uint8)
         arr = (C.c_uint8 * n)(*lens.tolist())
-        bits = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+        nbytes = 64 if trial % 4 else int(rng.integers(1, 200))
+        bits = rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes()
+        if trial >= 300 and trial % 2:  # bias towards 1-bits: long codes live at the all-ones end of the Vorbis assignment
+            bits = bytes(b | int(m) for b, m in zip(bits, rng.integers(0, 256, nbytes)))
         s1, s2 = (C.c_uint32 * 600)(), (C.c_uint32 * 600)()
         n1, n2 = C.c_size_t(0), C.c_size_t(0)
         r1 = L.lwo_huffman_check(arr, n, bits, len(bits), s1, 600, C.byref(n1))
@@ -82,9 +90,36 @@ def test_huffman_product_vs_oracle_random():
             assert n1.value == n2.value and list(s1[: n1.value]) == list(s2[: n2.value]), lens
 
 
-@pytest.mark.parametrize("name", sorted(SETUPS))
+def test_huffman_long_codes_and_truncation():
+    # entries drawn uniformly, so codes beyond the first table level (10 bits) and beyond both levels (18 bits) occur all
+    # the time; every stream is also cut inside its last bytes: a code running past the end must fail the same way
+    rng = np.random.default_rng(11)
+    L = po.lib()
+    for trial in range(24):
+        n = int(rng.integers(300, 2500))
+        lens = sg.huffman_lengths(np.exp(-rng.random(n) * (6 + 3 * (trial % 8))) + 1e-12, 32)
+        cws = sg.assign_codewords(lens)
+        assert max(lens) > 18 or trial % 8 < 2
+        arr = (C.c_uint8 * n)(*lens)
+        want = rng.integers(0, n, 400).tolist()
+        w = sg.BitWriter()
+        for e in want:
+            w.write(*cws[e])
+        data = w.bytes()
+        for cut in (0, 1, 2, 3, 5, 9, 17):
+            d = data[: len(data) - cut]
+            s1, s2 = (C.c_uint32 * 500)(), (C.c_uint32 * 500)()
+            n1, n2 = C.c_size_t(0), C.c_size_t(0)
+            assert L.lwo_huffman_check(arr, n, d, len(d), s1, 500, C.byref(n1)) == 0
+            assert N.lw_huffman_check(arr, n, d, len(d), s2, 500, C.byref(n2)) == 0
+            assert n1.value == n2.value and list(s1[: n1.value]) == list(s2[: n2.value])
+            if cut == 0:
+                assert list(s2[:400]) == want
+
+
+@pytest.mark.parametrize("name", sorted(HOST_SETUPS))
 def test_headers_parse_like_oracle(name):
-    setup = SETUPS[name]()
+    setup = HOST_SETUPS[name]()
     idp, cmt, stp = setup.headers()
     ident = header.read_header_ident(idp)
     assert (ident.audio_channels, ident.audio_sample_rate, ident.blocksize_0, ident.blocksize_1) == \
@@ -118,14 +153,14 @@ PATTERNS = {"stereo": "LLSSSSSSSSL", "stereo_t1": "LSLLS", "surround51": "LLSSL"
             "stereo_9_12": "LLSL", "stereo_6_13": "LSSL", "stereo_7_7": "LSLL"}
 
 
-@pytest.mark.parametrize("name", sorted(SETUPS))
+@pytest.mark.parametrize("name", sorted(HOST_SETUPS))
 def test_entropy_stage_matches_oracle(name):
-    setup = SETUPS[name]()
+    setup = HOST_SETUPS[name]()
     idp, _, stp = setup.headers()
     o_id, o_st = oracle_headers(setup)
     ident = header.read_header_ident(idp)
     st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
-    pkts = sg.make_stream(setup, PATTERNS[name], 24, seed=11, p_floor_unused=0.15)
+    pkts = sg.make_stream(setup, PATTERNS.get(name, "LLSLS"), 24, seed=11, p_floor_unused=0.15)
     inv_db = po.inverse_db_table()
     L = po.lib()
     L.lwo_debug_bits_consumed.restype = C.c_size_t
@@ -263,11 +298,11 @@ from common import SETUPS  # noqa: E402
 import vq_model  # noqa: E402
 
 
-@pytest.mark.parametrize("name", sorted(set(SETUPS) | set(FLOOR0_SETUPS)))
+@pytest.mark.parametrize("name", sorted(set(HOST_SETUPS) | set(FLOOR0_SETUPS)))
 def test_symbols_rebuild_the_residue_vectors(name):
     """The symbol records, replayed by a numpy model of k_residue_vq, give exactly the vectors the host path adds up
     (audio.rs:587-618, :748-754) -- also for packets that end inside the residue."""
-    setup = dict(SETUPS, **FLOOR0_SETUPS)[name]()
+    setup = dict(HOST_SETUPS, **FLOOR0_SETUPS)[name]()
     idp, _cmt, stp = setup.headers()
     hid = header.read_header_ident(idp)
     hst = header.read_header_setup(stp, hid.audio_channels, (hid.blocksize_0, hid.blocksize_1))
