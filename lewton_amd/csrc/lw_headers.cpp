@@ -75,6 +75,13 @@ Huffman::BuildResult Huffman::build(const uint8_t *lengths, size_t n)
 		return VALID; // decodes nothing; reading from it is a stream error
 
 	// decode structures
+	{
+		unsigned maxlen = 0;
+		for (size_t i = 0; i < n; i++)
+			maxlen = std::max<unsigned>(maxlen, lengths[i]);
+		lut_bits = std::min(maxlen, used >= 2048 ? 12u : used >= 512 ? 11u : 10u);
+	}
+	const unsigned LUT_BITS = lut_bits;
 	lut.assign((size_t)1 << LUT_BITS, 0);
 	nodes.assign(2, INT32_MIN);
 	for (size_t i = 0; i < n; i++) {

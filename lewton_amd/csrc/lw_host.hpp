@@ -112,13 +112,16 @@ struct BitReader {
 
 // Huffman decoder for one codebook.  Codewords follow the Vorbis assignment rule (each entry, in
 // entry order, takes the lowest free codeword of its length); decoding uses a LUT on the next
-// LUT_BITS bits, a second-level table on up to SUB_BITS more for prefixes shared by longer codes, and a
+// lut_bits bits, a second-level table on up to SUB_BITS more for prefixes shared by longer codes, and a
 // binary-tree walk for what is longer still.  Results are identical to a bit-by-bit walk, including at
 // the end of a packet (a code that runs past the end consumes the rest and fails).
 struct Huffman {
-	static constexpr unsigned LUT_BITS = 10, SUB_BITS = 8;
+	static constexpr unsigned SUB_BITS = 8;
 	static constexpr uint32_t LINK = 0x80000000u;
-	// first 2^LUT_BITS entries: (len << 24) | symbol, or LINK | (sub_bits << 24) | offset of the prefix's sub-table in
+	// width of the first table level: the longest code, capped at 10 bits (12 for books with >= 2048 used entries, 11 from
+	// 512): small books stay small in L1, large ones resolve most codes without the second, dependent load
+	unsigned lut_bits = 10;
+	// first 2^lut_bits entries: (len << 24) | symbol, or LINK | (sub_bits << 24) | offset of the prefix's sub-table in
 	// this vector (entries of the same form, len = whole code length); len == 0 -> walk the tree
 	std::vector<uint32_t> lut;
 	std::vector<int32_t> nodes; // 2 ints per node: child for bit 0 / bit 1; >= 0 node index, < 0 = ~symbol, INT32_MIN = none
@@ -129,12 +132,12 @@ struct Huffman {
 	enum BuildResult { VALID = 0, OVERSPECIFIED = 1, UNDERPOPULATED = 2, INVALID_SINGLE = 3 };
 	BuildResult build(const uint8_t *lengths, size_t n);
 
-	// table entry for the code at the start of window `w` (>= LUT_BITS + SUB_BITS bits, zero padded); len 0 = not in the tables
+	// table entry for the code at the start of window `w` (>= lut_bits + SUB_BITS bits, zero padded); len 0 = not in the tables
 	inline uint32_t lookup(uint64_t w) const
 	{
-		uint32_t e = lut[w & ((1u << LUT_BITS) - 1)];
+		uint32_t e = lut[w & ((1u << lut_bits) - 1)];
 		if (e & LINK)
-			e = lut[(e & 0xffffffu) + ((w >> LUT_BITS) & ((1u << ((e >> 24) & 0x7fu)) - 1))];
+			e = lut[(e & 0xffffffu) + ((w >> lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1))];
 		return e;
 	}
 
@@ -232,7 +235,7 @@ struct Floor {
 
 // Codeword reader of the residue loops: the bit window lives in registers across codewords and is topped up without
 // a branch (w |= next 8 bytes << avail; the bytes already covered are OR-ed again with themselves).  The fast path runs
-// while the 8 bytes at `byte` are inside the packet, where a table hit (<= LUT_BITS + SUB_BITS bits) cannot run into
+// while the 8 bytes at `byte` are inside the packet, where a table hit (<= 12 + SUB_BITS bits) cannot run into
 // the end; everything else (longer codes, the tail of the packet, single-entry books) goes through Huffman::decode,
 // whose results this reader reproduces exactly.
 struct CodeReader {

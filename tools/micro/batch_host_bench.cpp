@@ -1,0 +1,120 @@
+// Host side of the batch path without a GPU: the product's lw_runtime.cpp / lw_entropy.cpp / lw_headers.cpp / lw_fast.cpp
+// linked against the stand-ins below (device memory = malloc, copies = memcpy, kernel launchers = no-ops), to time
+// lw_batch_entropy -- prologue pass, threaded entropy decode into the staging slab, planning pass -- on this machine's
+// cores.  A profiling tool only (tools/batch_host_bench.py builds and runs it); nothing here is shipped or tested against.
+//   usage: batch_host_bench case.bin [packets 4096] [streams 256] [reps 20] [symbols 0/1] [threads...]
+#include "../../include/lewton_amd.h"
+#include "../../lewton_amd/csrc/lw_fast.hpp"
+#include "../../lewton_amd/csrc/lw_kernels.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+// ---- stand-ins for the HIP runtime (C linkage like the real ones) ---------------------------------------------
+extern "C" {
+hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 160 * 1024; return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char *hipGetErrorString(hipError_t) { return "stub"; }
+hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind)
+{
+	for (size_t i = 0; i < h; i++)
+		memcpy((char *)d + i * dp, (const char *)s + i * sp, w);
+	return hipSuccess;
+}
+}
+void lw_launch_generic_imdct(const LwDevTables &, const LwBatchDev &, float *, hipStream_t, uint32_t, bool, bool) {}
+void lw_launch_residue_vq(const LwDevTables &, const LwVqTables &, const LwBatchDev &, hipStream_t, uint32_t, const uint32_t *, size_t) {}
+void lw_launch_generic_ola(const LwDevTables &, const LwBatchDev &, void *, int, hipStream_t, bool) {}
+void lw_launch_long(const LwDevTables &, const LwBatchDev &, const LwFastLaunch &, void *, int, hipStream_t) {}
+
+static bool rd(FILE *f, uint32_t &v) { return fread(&v, 4, 1, f) == 1; }
+static bool rdv(FILE *f, std::vector<uint8_t> &b)
+{
+	uint32_t n;
+	if (!rd(f, n))
+		return false;
+	b.resize(n);
+	return n == 0 || fread(b.data(), 1, n, f) == n;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2)
+		return 2;
+	FILE *f = fopen(argv[1], "rb");
+	if (!f)
+		return 2;
+	const size_t NP = argc > 2 ? atoi(argv[2]) : 4096, S = argc > 3 ? atoi(argv[3]) : 256;
+	const int reps = argc > 4 ? atoi(argv[4]) : 20, sym = argc > 5 ? atoi(argv[5]) : 0;
+	uint32_t nc, npk;
+	std::vector<uint8_t> idp, stp;
+	if (!rd(f, nc) || !rdv(f, idp) || !rdv(f, stp) || !rd(f, npk))
+		return 2;
+	std::vector<std::vector<uint8_t>> pool(npk);
+	for (auto &p : pool)
+		if (!rdv(f, p))
+			return 2;
+	int err = 0;
+	lw_ident *id = lw_read_header_ident(idp.data(), idp.size(), &err);
+	lw_ident_info info;
+	lw_ident_get_info(id, &info);
+	lw_setup *st = lw_read_header_setup(stp.data(), stp.size(), info.audio_channels, info.blocksize_0, info.blocksize_1, &err);
+	lw_decoder *dec = lw_decoder_create(id, st, 0, &err);
+	if (!dec) {
+		printf("decoder: %d\n", err);
+		return 1;
+	}
+	lw_batch *b = lw_batch_create(dec, NP, LW_FMT_I16_PLANAR, &err);
+	if (sym && lw_batch_set_residue_on_device(b, 1)) {
+		printf("symbols mode not available\n");
+		return 1;
+	}
+	std::vector<lw_pwr *> pwr(S);
+	for (auto &p : pwr)
+		p = lw_pwr_new(dec);
+	std::vector<lw_packet> pk(NP);
+	unsigned x = 12345;
+	for (size_t k = 0; k < NP; k++) {
+		x = x * 1664525u + 1013904223u;
+		const auto &p = pool[(x >> 8) % npk];
+		pk[k] = {p.data(), p.size(), pwr[k / (NP / S)]};
+	}
+	std::vector<int> threads;
+	for (int a = 6; a < argc; a++)
+		threads.push_back(atoi(argv[a]));
+	if (threads.empty())
+		threads = {1, 2, 4, 8};
+	// this also wakes the machine's other cores up (VMs hand out idle vCPUs lazily: the first second of a multi-threaded
+	// run can be serialised on one core)
+	for (auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2);)
+		lw_batch_entropy(b, pk.data(), NP, 0);
+	for (int nt : threads) {
+		double best = 1e9;
+		for (int r = 0; r < reps; r++) {
+			auto t0 = std::chrono::steady_clock::now();
+			int rc = lw_batch_entropy(b, pk.data(), NP, nt);
+			double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			if (rc) {
+				printf("rc %d\n", rc);
+				return 1;
+			}
+			best = std::min(best, dt);
+		}
+		printf("threads %2d: %.3f ms per batch of %zu  -> %.3f M packets/s  (%.2f us per packet-thread)\n", nt, best * 1e3, NP,
+				NP / best * 1e-6, best * nt / NP * 1e6);
+	}
+	return 0;
+}
