@@ -137,6 +137,7 @@ struct lw_decoder {
 	void *d_vq_blob = nullptr;
 	std::vector<uint32_t> vq_book_ends; // cumulative float offsets of the book tables in V.vq (ascending table size)
 	uint32_t max_posts = 2;
+	std::vector<uint64_t> mode_floor_bytes; // per mode: bytes of floor input over all channels (SURVEY 8(d) accounting)
 	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
 	std::mutex mu;
 	float *d_state = nullptr;
@@ -593,6 +594,15 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	}
 	const size_t off_db = put(kInverseDbTable, sizeof(float) * 256);
 	const size_t nfl = s.floors.size(), nmodes = s.modes.size(), ch = id.channels;
+	d->mode_floor_bytes.assign(nmodes, 0);
+	for (size_t m = 0; m < nmodes; m++) {
+		const lw::Mapping &mp = s.mappings[s.modes[m].mapping];
+		const uint64_t half = ((uint64_t)1 << (s.modes[m].blockflag ? id.bs1 : id.bs0)) / 2;
+		for (size_t c = 0; c < ch; c++) {
+			const lw::Floor &fl = s.floors[mp.submap_floor[mp.mux[c]]];
+			d->mode_floor_bytes[m] += fl.type == 0 ? half * 4 + 2 : (uint64_t)fl.f1.x_list.size() * 2; // explicit curve | posts
+		}
+	}
 	std::vector<uint16_t> fx(nfl * LW_XSTRIDE, 0);
 	std::vector<uint8_t> fF(nfl, 0);
 	for (size_t f = 0; f < nfl; f++) {
@@ -1223,12 +1233,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		pw->len = w.right_end - w.right_start;
 		b->slot_last[pw->slot] = (int32_t)i;
 		out_off += (size_t)res.n_samples * ch;
-		alg += (uint64_t)ch * (p.n / 2) * 4 + 16 + (uint64_t)res.n_samples * ch * esz;
-		for (size_t c = 0; c < ch; c++) {
-			const lw::Mapping &mp = s.mappings[s.modes[p.mode].mapping];
-			const lw::Floor &fl = s.floors[mp.submap_floor[mp.mux[c]]];
-			alg += fl.type == 0 ? (uint64_t)(p.n / 2) * 4 + 2 : (uint64_t)fl.f1.x_list.size() * 2; // explicit curve | posts
-		}
+		alg += (uint64_t)ch * (p.n / 2) * 4 + 16 + (uint64_t)res.n_samples * ch * esz + d->mode_floor_bytes[p.mode];
 		if (!(r.flags & LW_RF_FAST)) {
 			b->has_generic = true;
 			if (p.bs <= LW_SMALL_BS)
@@ -1273,8 +1278,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		b->fast_order.resize(nf);
 		for (size_t k = 0; k < nf; k++)
 			b->fast_order[k] = (uint32_t)k;
-		std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
-				[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
+		if (!std::is_sorted(b->fast_slot.begin(), b->fast_slot.end())) // (callers usually list their streams one after the other)
+			std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
+					[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
 		const uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
 		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
