@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <cstdlib>
@@ -47,61 +48,96 @@ bool hip_ok(hipError_t e, const char *what)
 extern const float kInverseDbTable[256];
 
 // ---- persistent worker threads of the host entropy stage ----------------------------------------
-// lw_batch_entropy runs a few milliseconds per 4096-packet batch; creating and joining 32-64 threads for every batch
-// cost a fifth of that.  The pool grows on demand and its threads live until the process exits.
+// lw_batch_entropy runs a fraction of a millisecond per 4096-packet batch on a many-core host; creating and joining
+// 32-64 threads for every batch cost a fifth of that, and waking 63 sleepers through one condition variable (each
+// re-acquiring the mutex in turn) is of the same order.  The pool grows on demand, its threads live until the process
+// exits, and between regions they spin on the region counter for a short while (batches arrive back to back) before
+// they go to sleep on the condition variable.
+// packets a worker claims at a time: small enough that 64 threads share a 4096-packet batch evenly to the end
+#define LW_ENTROPY_CHUNK 4
+
 class EntropyPool {
 public:
+	static constexpr unsigned MAX_THREADS = 1024;
 	// runs fn() on `n` threads in total (the caller is one of them) and returns when all have finished
 	void run(unsigned n, const std::function<void()> &fn)
 	{
+		n = std::min(n, MAX_THREADS);
 		if (n <= 1) {
 			fn();
 			return;
 		}
 		std::unique_lock<std::mutex> serial(serial_); // one parallel region at a time
+		const uint64_t epoch = (state_.load() >> 16) + 1;
 		{
 			std::unique_lock<std::mutex> g(mu_);
 			while (threads_.size() < n - 1)
-				threads_.emplace_back([this, id = threads_.size()]() { loop(id); });
-			fn_ = &fn;
-			want_ = n - 1;
-			pending_ = n - 1;
-			epoch_++;
+				threads_.emplace_back([this, id = threads_.size(), epoch]() { loop(id, epoch - 1); });
 		}
-		cv_.notify_all();
+		fn_ = &fn;
+		pending_.store(n - 1);
+		state_.store((epoch << 16) | (n - 1)); // region number and its helper count in one word (seq_cst, see loop())
+		if (sleepers_.load() > 0) {
+			{ std::unique_lock<std::mutex> g(mu_); } // a worker between its predicate check and its wait holds mu_
+			cv_.notify_all();
+		}
 		fn();
-		std::unique_lock<std::mutex> g(mu_);
-		done_.wait(g, [this]() { return pending_ == 0; });
-		fn_ = nullptr;
+		for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) {
+			if (spins < 4096)
+				cpu_relax();
+			else
+				std::this_thread::yield();
+		}
 	}
 
 private:
-	void loop(size_t id)
+	static void cpu_relax()
 	{
-		uint64_t seen = 0;
+#if defined(__x86_64__) || defined(__i386__)
+		__builtin_ia32_pause();
+#else
+		std::this_thread::yield();
+#endif
+	}
+	void loop(size_t id, uint64_t seen)
+	{
 		for (;;) {
-			const std::function<void()> *fn = nullptr;
-			{
-				std::unique_lock<std::mutex> g(mu_);
-				cv_.wait(g, [&]() { return epoch_ != seen; });
-				seen = epoch_;
-				if (id < want_)
-					fn = fn_;
+			// wait for the next region: spin for ~100 us (batches arrive back to back), then sleep
+			uint64_t st = 0;
+			bool got = false;
+			const auto t0 = std::chrono::steady_clock::now();
+			for (unsigned spins = 0;; spins++) {
+				st = state_.load(std::memory_order_acquire);
+				if ((st >> 16) != seen) {
+					got = true;
+					break;
+				}
+				if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100))
+					break;
+				cpu_relax();
 			}
-			if (fn) {
-				(*fn)();
+			if (!got) {
 				std::unique_lock<std::mutex> g(mu_);
-				if (--pending_ == 0)
-					done_.notify_one();
+				sleepers_.fetch_add(1);
+				cv_.wait(g, [&]() { return ((st = state_.load()) >> 16) != seen; });
+				sleepers_.fetch_sub(1);
+			}
+			seen = st >> 16;
+			// helpers of region `seen` are the threads with id < (st & 0xffff): run() keeps fn_ unchanged until all of them
+			// have counted down; any other thread must not look at fn_ (the region may be over already)
+			if (id < (st & 0xffffu)) {
+				(*fn_)();
+				pending_.fetch_sub(1, std::memory_order_acq_rel);
 			}
 		}
 	}
 	std::mutex mu_, serial_;
-	std::condition_variable cv_, done_;
+	std::condition_variable cv_;
 	std::vector<std::thread> threads_;
 	const std::function<void()> *fn_ = nullptr;
-	size_t want_ = 0, pending_ = 0;
-	uint64_t epoch_ = 0;
+	std::atomic<size_t> pending_{0};
+	std::atomic<uint64_t> state_{0}; // (region number << 16) | helpers of that region
+	std::atomic<unsigned> sleepers_{0};
 };
 
 EntropyPool &entropy_pool()
@@ -1073,15 +1109,16 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	std::atomic<size_t> pool_used{0};
 	std::atomic<bool> overflow{false};
 	auto worker = [&]() {
-		lw::EntropyScratch scr;
-		lw::SymbolSink sink;
-		std::vector<uint64_t> tmp;
+		// scratch vectors keep their capacity from batch to batch (pool threads are persistent)
+		static thread_local lw::EntropyScratch scr;
+		static thread_local lw::SymbolSink sink;
+		static thread_local std::vector<uint64_t> tmp;
 		const unsigned my = b->symbols ? next_arena.fetch_add(1) : 0;
 		for (;;) {
-			const size_t i0 = next.fetch_add(16);
+			const size_t i0 = next.fetch_add(LW_ENTROPY_CHUNK);
 			if (i0 >= n)
 				break;
-			for (size_t i = i0; i < std::min(n, i0 + 16); i++) {
+			for (size_t i = i0; i < std::min(n, i0 + LW_ENTROPY_CHUNK); i++) {
 				if (b->status[i] != LW_OK)
 					continue;
 				LwPacketRec &r = b->h_recs[i];

@@ -3,6 +3,9 @@
 // lw_batch_entropy -- prologue pass, threaded entropy decode into the staging slab, planning pass -- on this machine's
 // cores.  A profiling tool only (tools/batch_host_bench.py builds and runs it); nothing here is shipped or tested against.
 //   usage: batch_host_bench case.bin [packets 4096] [streams 256] [reps 20] [symbols 0/1] [threads...]
+// With LW_HOST_BENCH_CHECK=1 in the environment it does not time anything: it runs the batch on one thread and on every
+// listed thread count and compares statuses, sample counts, output offsets and the staged residue vectors (against each
+// other and against lw_entropy_decode_host packet by packet); tests/test_host_batch.py runs that under ThreadSanitizer.
 #include "../../include/lewton_amd.h"
 #include "../../lewton_amd/csrc/lw_fast.hpp"
 #include "../../lewton_amd/csrc/lw_kernels.hpp"
@@ -97,6 +100,66 @@ int main(int argc, char **argv)
 		threads.push_back(atoi(argv[a]));
 	if (threads.empty())
 		threads = {1, 2, 4, 8};
+	if (getenv("LW_HOST_BENCH_CHECK")) {
+		const size_t ch = info.audio_channels, cap = ch * ((size_t)1 << info.blocksize_1) / 2;
+		struct Snap {
+			std::vector<lw_packet_result> res;
+			std::vector<float> vec;
+		};
+		auto snap = [&](int nt, Snap &o) {
+			for (auto *p : pwr)
+				lw_pwr_reset(p);
+			if (int rc = lw_batch_entropy(b, pk.data(), NP, nt)) {
+				printf("lw_batch_entropy(%d threads): %d\n", nt, rc);
+				exit(1);
+			}
+			o.res.assign(lw_batch_results(b), lw_batch_results(b) + NP);
+			o.vec.assign(NP * cap, 0.0f);
+			if (!sym)
+				for (size_t k = 0; k < NP; k++)
+					if (o.res[k].status == LW_OK && lw_batch_tap(b, k, LW_TAP_RESIDUE_PRE_INVERSE, &o.vec[k * cap], cap)) {
+						printf("tap %zu failed\n", k);
+						exit(1);
+					}
+		};
+		Snap ref;
+		snap(1, ref);
+		size_t ok = 0;
+		std::vector<uint16_t> fo(ch * lw_setup_floor_stride(st));
+		std::vector<float> one(cap), curve(cap);
+		for (size_t k = 0; k < NP && !sym; k++) { // the batch path against the one-packet host hook
+			uint8_t bs = 0, mode = 0, flags = 0;
+			uint64_t bits = 0;
+			const int rc = lw_entropy_decode_host(id, st, pk[k].data, pk[k].len, fo.data(), one.data(), cap, &bs, &mode, &flags, &bits,
+					curve.data());
+			// (a packet can decode here and still fail in the batch: window / state checks of audio.rs:1107-1111)
+			if (ref.res[k].status == LW_OK) {
+				ok++;
+				if (rc != LW_OK || memcmp(one.data(), &ref.vec[k * cap], sizeof(float) * ch * ((size_t)1 << bs) / 2)) {
+					printf("packet %zu: batch and single-packet host stage differ\n", k);
+					return 1;
+				}
+			}
+		}
+		for (int nt : threads) {
+			for (int rep = 0; rep < std::max(1, reps); rep++) {
+				Snap got;
+				snap(nt, got);
+				for (size_t k = 0; k < NP; k++)
+					if (got.res[k].status != ref.res[k].status || got.res[k].n_samples != ref.res[k].n_samples ||
+							got.res[k].out_offset != ref.res[k].out_offset) {
+						printf("packet %zu: result differs on %d threads\n", k, nt);
+						return 1;
+					}
+				if (got.vec != ref.vec) {
+					printf("staged residue differs on %d threads\n", nt);
+					return 1;
+				}
+			}
+		}
+		printf("check ok: %zu packets (%zu decodable vs single-packet hook)\n", NP, ok);
+		return 0;
+	}
 	// this also wakes the machine's other cores up (VMs hand out idle vCPUs lazily: the first second of a multi-threaded
 	// run can be serialised on one core)
 	for (auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2);)
