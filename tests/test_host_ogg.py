@@ -1,0 +1,181 @@
+"""Stream layer (lw_ogg.cpp = OggStreamReader of inside_ogg.rs:66-313) in the CPU suite: tests/san/ogg_stream_host.cpp links
+the PRODUCT sources against stand-ins for the HIP runtime (tests/san/hip_standins.inc; sample values are zero, everything the
+host decides is real) and prints a trace of sample counts, serials, chain links and granule positions.  The trace is compared
+with the oracle's OggStreamReader (oracle/pyogg.py); the harness is built with ASan + UBSan, and mutated files are run
+through it as well.  The sample VALUES of the same calls are checked on the GPU (tests/test_gpu_ogg.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import ROOT
+from oracle import pyogg
+from test_ogg import GOLDEN, _vorbis_stream
+
+CS = os.path.join(ROOT, "lewton_amd", "csrc")
+SRC = [os.path.join(ROOT, "tests", "san", "ogg_stream_host.cpp")] + [
+    os.path.join(CS, n) for n in ("lw_ogg.cpp", "lw_runtime.cpp", "lw_entropy.cpp", "lw_headers.cpp", "lw_fast.cpp")]
+HIP_INC = "/opt/rocm/include"
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    if not os.path.isdir(os.path.join(HIP_INC, "hip")):
+        pytest.skip("HIP headers not installed")
+    exe = str(tmp_path_factory.mktemp("hostogg") / "ogg_stream_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + HIP_INC] + SRC + ["-lpthread", "-o", exe])
+    return exe
+
+
+def _chained():
+    parts = []
+    for k, (name, pattern, count, trim) in enumerate([("stereo", "LSL", 9, 11), ("surround51", "L", 6, 0),
+                                                      ("mono_small", "SLL", 7, 3)]):
+        parts.append(_vorbis_stream(name, pattern, count, seed=20 + k, serial=0x100 + k, per_page=2, trim=trim)[2].bytes())
+    return b"".join(parts)
+
+
+def _files():
+    return {
+        "golden": open(GOLDEN, "rb").read(),
+        "trim": _vorbis_stream("stereo", "LSSL", 24, per_page=5, trim=700)[2].bytes(),
+        "surround": _vorbis_stream("surround51", "LLSSSL", 18, per_page=4, trim=37)[2].bytes(),
+        "mono_pages": _vorbis_stream("mono_small", "SL", 15, per_page=1, trim=5)[2].bytes(),
+        "chained": _chained(),
+    }
+
+
+def _run(exe, tmp_path, data, *mode):
+    path = str(tmp_path / "in.ogg")
+    with open(path, "wb") as f:
+        f.write(data)
+    out = subprocess.run([exe, path] + [str(m) for m in mode], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-4000:]
+    return [l.split() for l in out.stdout.splitlines()]
+
+
+def _gp(v):
+    return "-" if v is None else str(v)
+
+
+def _oracle_trace(o):
+    """P lines of a drain of the oracle reader + the terminating line."""
+    rows, link, last_serial = [], 0, o.stream_serial
+    while True:
+        try:
+            d = o.read_dec_packet()
+        except pyogg.VorbisError as e:
+            rows.append(["E", e])
+            return rows
+        if d is None:
+            rows.append(["EOF"])
+            return rows
+        if o.stream_serial != last_serial:
+            link, last_serial = link + 1, o.stream_serial
+        rows.append(["P", str(d.shape[1]), "0", str(o.stream_serial), str(link), _gp(o.get_last_absgp())])
+
+
+@pytest.mark.parametrize("name", ["golden", "trim", "surround", "mono_pages", "chained"])
+def test_packet_by_packet_trace_matches_oracle(harness, tmp_path, name):
+    data = _files()[name]
+    got = _run(harness, tmp_path, data, "seq")
+    want = _oracle_trace(pyogg.OggStreamReader(data))
+    assert want[-1] == ["EOF"] and got == want
+    if name == "chained":
+        assert [r[4] for r in got if r[0] == "P"][-1] == "2"
+
+
+@pytest.mark.parametrize("k", [1, 4, 64])
+@pytest.mark.parametrize("name", ["golden", "trim", "chained"])
+def test_look_ahead_queue_trace(harness, tmp_path, name, k):
+    """read_dec_packets: the same sample counts in the same order, stops in front of a chain boundary, the granule
+    position after every batch equals the packet-by-packet one at that point."""
+    data = _files()[name]
+    got = _run(harness, tmp_path, data, "ahead", k)
+    want = [r for r in _oracle_trace(pyogg.OggStreamReader(data)) if r[0] == "P"]
+    counts, at = [], []
+    i = 0
+    while i < len(got):
+        r = got[i]
+        if r[0] == "B":
+            n = int(r[1])
+            assert n <= k
+            qs = got[i + 1:i + 1 + n]
+            assert all(q[0] == "Q" and q[2] == "0" for q in qs)
+            counts += [q[1] for q in qs]
+            pos = got[i + 1 + n]
+            if n == 0:                      # the single-packet call that crossed the chain boundary
+                counts.append(pos[1])
+            at.append((len(counts), pos[3], pos[5]))
+            i += n + 2
+        else:
+            assert r == ["EOF"] and i == len(got) - 1
+            i += 1
+    assert counts == [w[1] for w in want]
+    for n_done, serial, gp in at:
+        assert (serial, gp) == (want[n_done - 1][3], want[n_done - 1][5])
+
+
+@pytest.mark.parametrize("to_skip", [0, 1, 127, 128, 1500, 9000, 10 ** 7])
+def test_skip_samples_linear_trace(harness, tmp_path, to_skip):
+    data = _vorbis_stream("stereo", "LSSLL", 30, per_page=4, trim=100)[2].bytes()
+    got = _run(harness, tmp_path, data, "skip", to_skip)
+    o = pyogg.OggStreamReader(data)
+    dec, left = o.skip_samples_linear(to_skip)
+    want = [["S", "0" if dec is None else "1", "0" if dec is None else str(dec.shape[1]), str(left)]]
+    if dec is not None:
+        want.append(["P", str(dec.shape[1]), "0", str(o.stream_serial), "0", _gp(o.get_last_absgp())])
+    assert got == want + _oracle_trace(o)
+
+
+@pytest.mark.parametrize("goal", [0, 3000, 12345, 10 ** 9])
+def test_seek_absgp_pg_trace(harness, tmp_path, goal):
+    data = _vorbis_stream("stereo", "LLSL", 40, per_page=3)[2].bytes()
+    got = _run(harness, tmp_path, data, "seek", goal)
+    o = pyogg.OggStreamReader(data)
+    o.seek_absgp_pg(goal)
+    assert got == [["K", "0"]] + _oracle_trace(o)
+
+
+def test_mutated_files_under_sanitizers(harness, tmp_path):
+    """Bit flips, truncations and duplicated pages of real and synthetic files: the stream layer may fail in any documented
+    way, it may not trip ASan/UBSan; where the oracle reads the stream to a clean end the product must do so too, packet
+    for packet."""
+    rng = np.random.default_rng(8)
+    files = _files()
+    ran = agree = 0
+    for name in ("golden", "trim", "chained"):
+        base = files[name]
+        for trial in range(14):
+            d = bytearray(base)
+            kind = trial % 4
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 4))):
+                    d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                d = d[: int(rng.integers(28, len(d)))]
+            elif kind == 2:
+                a = int(rng.integers(0, len(d) - 64))
+                d[a:a + int(rng.integers(1, 64))] = b""
+            else:
+                a = bytes(d).find(b"OggS", int(rng.integers(0, len(d) // 2)))
+                b = bytes(d).find(b"OggS", a + 4)
+                if a >= 0 and b > a:
+                    d[a:a] = d[a:b]          # a page twice
+            for mode in (("seq",), ("ahead", 5)):
+                got = _run(harness, tmp_path, bytes(d), *mode)
+                ran += 1
+                if mode == ("seq",):
+                    try:
+                        want = _oracle_trace(pyogg.OggStreamReader(bytes(d)))
+                    except pyogg.VorbisError:
+                        assert got and got[0][0] == "E"
+                        continue
+                    if want[-1] == ["EOF"]:
+                        assert got == want
+                        agree += 1
+                    else:
+                        assert got[: len(want) - 1] == want[:-1] and got[len(want) - 1][0] == "E"
+    assert ran == 84 and agree >= 5

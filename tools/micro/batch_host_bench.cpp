@@ -1,5 +1,5 @@
 // Host side of the batch path without a GPU: the product's lw_runtime.cpp / lw_entropy.cpp / lw_headers.cpp / lw_fast.cpp
-// linked against the stand-ins below (device memory = malloc, copies = memcpy, kernel launchers = no-ops), to time
+// linked against tests/san/hip_standins.inc (device memory = malloc, copies = memcpy, kernel launchers = no-ops), to time
 // lw_batch_entropy -- prologue pass, threaded entropy decode into the staging slab, planning pass -- on this machine's
 // cores.  A profiling tool only (tools/batch_host_bench.py builds and runs it); nothing here is shipped or tested against.
 //   usage: batch_host_bench case.bin [packets 4096] [streams 256] [reps 20] [symbols 0/1] [threads...]
@@ -7,41 +7,13 @@
 // listed thread count and compares statuses, sample counts, output offsets and the staged residue vectors (against each
 // other and against lw_entropy_decode_host packet by packet); tests/test_host_batch.py runs that under ThreadSanitizer.
 #include "../../include/lewton_amd.h"
-#include "../../lewton_amd/csrc/lw_fast.hpp"
-#include "../../lewton_amd/csrc/lw_kernels.hpp"
-
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
-// ---- stand-ins for the HIP runtime (C linkage like the real ones) ---------------------------------------------
-extern "C" {
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 160 * 1024; return hipSuccess; }
-hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipGetLastError(void) { return hipSuccess; }
-const char *hipGetErrorString(hipError_t) { return "stub"; }
-hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return hipSuccess; }
-hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind)
-{
-	for (size_t i = 0; i < h; i++)
-		memcpy((char *)d + i * dp, (const char *)s + i * sp, w);
-	return hipSuccess;
-}
-}
-void lw_launch_generic_imdct(const LwDevTables &, const LwBatchDev &, float *, hipStream_t, uint32_t, bool, bool) {}
-void lw_launch_residue_vq(const LwDevTables &, const LwVqTables &, const LwBatchDev &, hipStream_t, uint32_t, const uint32_t *, size_t) {}
-void lw_launch_generic_ola(const LwDevTables &, const LwBatchDev &, void *, int, hipStream_t, bool) {}
-void lw_launch_long(const LwDevTables &, const LwBatchDev &, const LwFastLaunch &, void *, int, hipStream_t) {}
+#include "../../tests/san/hip_standins.inc"
 
 static bool rd(FILE *f, uint32_t &v) { return fread(&v, 4, 1, f) == 1; }
 static bool rdv(FILE *f, std::vector<uint8_t> &b)
