@@ -44,7 +44,7 @@ enum {
 	LW_HDR_UTF8 = 22,
 	LW_HDR_BUFFER_NOT_ADDRESSABLE = 23,
 	/* errors of this library (no counterpart in the reference) */
-	LW_ERR_NULL_ARG = 32,      /* like capi.rs:106-108 returning 1 */
+	LW_ERR_NULL_ARG = 32,      /* like capi.rs:106-108 returning 1; a packet given as (NULL, 0) is not an error but an empty packet */
 	LW_ERR_DEVICE = 33,        /* HIP error / no GPU; lw_last_device_error() has the text */
 	LW_ERR_CAPACITY = 34,      /* caller-provided buffer or batch too small */
 	LW_ERR_STATE_MISMATCH = 35, /* pwr belongs to another decoder (the reference panics, audio.rs:1086) */

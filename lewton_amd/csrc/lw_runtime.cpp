@@ -293,7 +293,7 @@ const char *lw_last_device_error(void)
 lw_ident *lw_read_header_ident(const uint8_t *packet, size_t len, int *err)
 {
 	int e = 0;
-	if (!packet) {
+	if (!packet && len) { // (NULL, 0) is an empty packet: the reader fails on its first bit like the reference's
 		if (err)
 			*err = LW_ERR_NULL_ARG;
 		return nullptr;
@@ -330,7 +330,7 @@ void lw_ident_free(lw_ident *id)
 lw_setup *lw_read_header_setup(const uint8_t *packet, size_t len, uint8_t ch, uint8_t bs0, uint8_t bs1, int *err)
 {
 	int e = 0;
-	if (!packet) {
+	if (!packet && len) { // (NULL, 0) is an empty packet: the reader fails on its first bit like the reference's
 		if (err)
 			*err = LW_ERR_NULL_ARG;
 		return nullptr;
@@ -353,7 +353,7 @@ void lw_setup_free(lw_setup *s)
 lw_comment *lw_read_header_comment(const uint8_t *packet, size_t len, int *err)
 {
 	int e = 0;
-	if (!packet) {
+	if (!packet && len) { // (NULL, 0) is an empty packet: the reader fails on its first bit like the reference's
 		if (err)
 			*err = LW_ERR_NULL_ARG;
 		return nullptr;
@@ -398,7 +398,7 @@ void lw_comment_free(lw_comment *c)
 
 int lw_get_decoded_sample_count(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len, size_t *count)
 {
-	if (!id || !s || !packet || !count)
+	if (!id || !s || (!packet && len) || !count)
 		return LW_ERR_NULL_ARG;
 	return lw::decoded_sample_count(*id->p, *s->p, packet, len, *count);
 }
@@ -421,7 +421,7 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 		float *residue_out, size_t residue_cap_floats, uint8_t *blocksize_log2, uint8_t *mode, uint8_t *flags,
 		uint64_t *bits_consumed, float *floor_curve_out)
 {
-	if (!id || !s || !packet || !floor_out || !residue_out)
+	if (!id || !s || (!packet && len) || !floor_out || !residue_out)
 		return LW_ERR_NULL_ARG;
 	lw::BitReader br(packet, len);
 	lw::Prologue p;
@@ -457,7 +457,7 @@ int lw_entropy_symbols_host(const lw_ident *id, const lw_setup *s, const uint8_t
 		uint64_t *symbols, size_t cap_symbols, size_t *n_symbols, uint32_t pass_off[9], uint8_t *blocksize_log2,
 		uint8_t *mode, uint8_t *flags, float *floor_curve_out)
 {
-	if (!id || !s || !packet || !floor_out || !symbols || !n_symbols || !pass_off)
+	if (!id || !s || (!packet && len) || !floor_out || !symbols || !n_symbols || !pass_off)
 		return LW_ERR_NULL_ARG;
 	if (!lw::symbols_supported(*id->p, *s->p, nullptr))
 		return LW_ERR_UNSUPPORTED;
@@ -1074,7 +1074,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		r.state_out = -1;
 		r.floor_off = (uint32_t)(i * ch * fstride);
 		r.res_off = (uint32_t)res_off;
-		if (!pkts[i].data || !pkts[i].pwr) {
+		if ((!pkts[i].data && pkts[i].len) || !pkts[i].pwr) {
 			b->status[i] = LW_ERR_NULL_ARG;
 			continue;
 		}
@@ -1643,7 +1643,7 @@ int lw_debug_imdct(lw_decoder *d, int blockflag, const float *spectrum, float *o
 int lw_read_audio_packet(lw_decoder *d, const uint8_t *packet, size_t len, lw_pwr *pwr, int fmt, void *out,
 		size_t cap_per_channel, size_t *n_samples)
 {
-	if (!d || !packet || !pwr || !out || !n_samples)
+	if (!d || (!packet && len) || !pwr || !out || !n_samples)
 		return LW_ERR_NULL_ARG;
 	if (pwr->dec != d)
 		return LW_ERR_STATE_MISMATCH;

@@ -48,3 +48,59 @@ def test_batch_entropy_threads_agree_under_tsan(harness, tmp_path, name, pattern
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "check ok: 384 packets" in out.stdout
+
+
+@pytest.mark.parametrize("name,pattern", [("stereo", "LLSSLSL"), ("surround51", "LSSLL"), ("mono_small", "SLLSL"),
+                                          ("stereo_7_7", "LSL")])
+def test_batch_statuses_and_sample_counts_equal_the_oracle(harness, tmp_path, name, pattern):
+    """What lw_batch_entropy decides on the host -- AudioReadError codes, samples per packet (audio.rs:1140-1152), output
+    offsets, and how an error leaves the stream's previous-window state (:1107-1111) -- against the oracle decoding the same
+    streams packet by packet.  Packets are damaged on purpose (cut short, bits flipped, a header packet in between)."""
+    import numpy as np
+    from common import SETUPS, oracle_headers, po
+    setup = SETUPS[name]()
+    n_streams, per = 8, 24
+    rng = np.random.default_rng(4)
+    streams = []
+    for k in range(n_streams):
+        pk = [bytearray(p) for p in sg.make_stream(setup, pattern, per, seed=40 + k, p_floor_unused=0.1)]
+        for i in range(per):
+            r = rng.random()
+            if r < 0.08:
+                pk[i] = pk[i][: int(rng.integers(0, max(1, len(pk[i]))))]
+            elif r < 0.16 and len(pk[i]):
+                pk[i][int(rng.integers(0, len(pk[i])))] ^= 1 << int(rng.integers(0, 8))
+            elif r < 0.21:
+                pk[i] = bytearray(b"\x01vorbis")
+        streams.append([bytes(p) for p in pk])
+    idp, _, stp = setup.headers()
+    case = str(tmp_path / "case.bin")
+    with open(case, "wb") as f:
+        f.write(struct.pack("<I", 1))
+        for b in (idp, stp):
+            f.write(struct.pack("<I", len(b)) + bytes(b))
+        f.write(struct.pack("<I", n_streams * per))
+        for st in streams:
+            for p in st:
+                f.write(struct.pack("<I", len(p)) + p)
+    env = dict(os.environ, LW_HOST_BENCH_CHECK="1", LW_HOST_BENCH_DUMP="1", LW_HOST_BENCH_FILE_ORDER="1",
+               TSAN_OPTIONS="halt_on_error=1")
+    out = subprocess.run([harness, case, str(n_streams * per), str(n_streams), "1", "0", "3"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    got = [tuple(int(v) for v in l.split()[1:]) for l in out.stdout.splitlines() if l.startswith("R ")]
+    o_id, o_st = oracle_headers(setup)
+    ch = o_id.audio_channels
+    want, off = [], 0
+    for st in streams:
+        pwr = po.Pwr()
+        for p in st:
+            try:
+                n = po.read_audio_packet(o_id, o_st, p, pwr, "i16").shape[1]
+                want.append((0, n, off))
+                off += n * ch
+            except po.OracleError as e:
+                want.append((e.code, 0, off))
+    assert len(got) == len(want)
+    assert got == want
+    assert sum(1 for w in want if w[0]) >= 3          # the damage took (a cut packet usually still decodes: audio.rs:655-660)

@@ -179,3 +179,39 @@ def test_mutated_files_under_sanitizers(harness, tmp_path):
                     else:
                         assert got[: len(want) - 1] == want[:-1] and got[len(want) - 1][0] == "E"
     assert ran == 84 and agree >= 5
+
+
+def test_zero_length_packets_are_empty_packets_not_null_arguments(harness, tmp_path):
+    """A zero-length Ogg packet (lacing value 0) is legal; lewton's reader fails on its first bit: BadAudio(EndOfPacket)
+    for an audio packet (audio.rs:921), EndOfPacket for a header.  (The C ABI takes such a packet as (NULL, 0).)"""
+    from common import SETUPS, sg
+    from lewton_amd import ogg
+    from oracle import pyoracle as po
+    setup = SETUPS["stereo"]()
+    idp, cmt, stp = setup.headers()
+    pk = sg.make_stream(setup, "LSL", 9, seed=5)
+    pk[4] = b""
+    w = ogg.PageWriter(0x51)
+    w.add_packet(idp, 0, flush=True)
+    w.add_packet(cmt, 0)
+    w.add_packet(stp, 0, flush=True)
+    for i, p in enumerate(pk):
+        w.add_packet(p, 1000 * i, flush=(i % 3 == 2), eos=(i == len(pk) - 1))
+    data = w.bytes()
+    want = _oracle_trace(pyogg.OggStreamReader(data))
+    assert want[-1][0] == "E" and want[-1][1].kind == "BadAudio" and want[-1][1].inner == po.AUDIO_END_OF_PACKET and len(want) == 5
+    got = _run(harness, tmp_path, data, "seq")
+    assert got[:-1] == want[:-1] and got[-1] == ["E", str(po.AUDIO_END_OF_PACKET)]
+    # the look-ahead queue reports it per packet
+    got = _run(harness, tmp_path, data, "ahead", 16)
+    qs = [r for r in got if r[0] == "Q"]
+    assert [q[2] for q in qs][:5] == ["0"] * 4 + [str(po.AUDIO_END_OF_PACKET)]
+    # an empty comment header: read_header_comment fails on its first byte (header.rs:309-313; the oracle does not
+    # parse comment headers, so this half is pinned on the reference's text alone)
+    w = ogg.PageWriter(0x52)
+    w.add_packet(idp, 0, flush=True)
+    w.add_packet(b"", 0)
+    w.add_packet(stp, 0, flush=True)
+    data = w.bytes()
+    got = _run(harness, tmp_path, data, "seq")
+    assert got == [["E", str(po.HDR_END_OF_PACKET)]]

@@ -350,3 +350,25 @@ def test_headers_are_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
                            os.path.join(ROOT, "examples", "perf.c")])
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, os.path.join(ROOT, "examples", "ogg2wav.c")])
+
+
+def test_null_pointer_with_zero_length_is_an_empty_packet():
+    """(NULL, 0) = what C++ callers get from an empty std::vector: the readers fail on the first bit like the reference's
+    (EndOfPacket), they do not report a null argument; (NULL, n > 0) still does."""
+    setup = SETUPS["stereo"]()
+    idp, _cmt, stp = setup.headers()
+    hid = header.read_header_ident(idp)
+    hst = header.read_header_setup(stp, 2, (8, 11))
+    err = C.c_int(0)
+    assert not N.lib.lw_read_header_ident(None, 0, C.byref(err)) and err.value == po.HDR_END_OF_PACKET
+    assert not N.lib.lw_read_header_ident(None, 5, C.byref(err)) and err.value == 32
+    assert not N.lib.lw_read_header_comment(None, 0, C.byref(err)) and err.value == po.HDR_END_OF_PACKET
+    assert not N.lib.lw_read_header_setup(None, 0, 2, 8, 11, C.byref(err)) and err.value == po.HDR_END_OF_PACKET
+    cnt = C.c_size_t(0)
+    assert N.lib.lw_get_decoded_sample_count(hid._h, hst._h, None, 0, C.byref(cnt)) == po.AUDIO_END_OF_PACKET
+    assert N.lib.lw_get_decoded_sample_count(hid._h, hst._h, None, 3, C.byref(cnt)) == 32
+    floor = (C.c_uint16 * (2 * N.lw_setup_floor_stride(hst._h)))()
+    res = (C.c_float * 2048)()
+    bs, mode, flags, bits = C.c_uint8(0), C.c_uint8(0), C.c_uint8(0), C.c_uint64(0)
+    assert N.lib.lw_entropy_decode_host(hid._h, hst._h, None, 0, floor, res, 2048, C.byref(bs), C.byref(mode), C.byref(flags),
+                                        C.byref(bits), None) == po.AUDIO_END_OF_PACKET

@@ -5,7 +5,8 @@
 //   usage: batch_host_bench case.bin [packets 4096] [streams 256] [reps 20] [symbols 0/1] [threads...]
 // With LW_HOST_BENCH_CHECK=1 in the environment it does not time anything: it runs the batch on one thread and on every
 // listed thread count and compares statuses, sample counts, output offsets and the staged residue vectors (against each
-// other and against lw_entropy_decode_host packet by packet); tests/test_host_batch.py runs that under ThreadSanitizer.
+// other and against lw_entropy_decode_host packet by packet); tests/test_host_batch.py runs that under ThreadSanitizer
+// (LW_HOST_BENCH_FILE_ORDER=1: packets in file order; LW_HOST_BENCH_DUMP=1: print status / sample count / offset per packet).
 #include "../../include/lewton_amd.h"
 #include <chrono>
 #include <cstdio>
@@ -62,9 +63,10 @@ int main(int argc, char **argv)
 		p = lw_pwr_new(dec);
 	std::vector<lw_packet> pk(NP);
 	unsigned x = 12345;
+	const bool file_order = getenv("LW_HOST_BENCH_FILE_ORDER") != nullptr; // packet k = k-th packet of the file (tests)
 	for (size_t k = 0; k < NP; k++) {
 		x = x * 1664525u + 1013904223u;
-		const auto &p = pool[(x >> 8) % npk];
+		const auto &p = pool[file_order ? k % npk : (x >> 8) % npk];
 		pk[k] = {p.data(), p.size(), pwr[k / (NP / S)]};
 	}
 	std::vector<int> threads;
@@ -96,6 +98,9 @@ int main(int argc, char **argv)
 		};
 		Snap ref;
 		snap(1, ref);
+		if (getenv("LW_HOST_BENCH_DUMP"))
+			for (size_t k = 0; k < NP; k++)
+				printf("R %d %u %llu\n", ref.res[k].status, ref.res[k].n_samples, (unsigned long long)ref.res[k].out_offset);
 		size_t ok = 0;
 		std::vector<uint16_t> fo(ch * lw_setup_floor_stride(st));
 		std::vector<float> one(cap), curve(cap);
