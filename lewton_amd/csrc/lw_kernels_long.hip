@@ -958,14 +958,20 @@ __device__ __forceinline__ void imdct_pair(const char *img, char *sc, uint32_t l
 	TwC tc;
 	{
 		TwB tb;
+		LW_MARK("ip_stage_b");
 		load_tw_b(img, lane, tb);
 		stage_b1(tb, lane, r[0], P0);
 		stage_b1(tb, lane, r[1], P1);
 		load_tw_c(img, lane, tc);
+#ifdef LW_MARKS // (region boundaries of tools/isa_regions.py only: the production schedule is free to mix B and T2)
+		__builtin_amdgcn_sched_barrier(0);
+#endif
+		LW_MARK("ip_t2");
 		t2_inreg(P0);
 		t2_inreg(P1);
 		__builtin_amdgcn_sched_barrier(0);
 	}
+	LW_MARK("ip_stage_c");
 	stage_c1(tc, P0);
 	__builtin_amdgcn_sched_barrier(0);
 #endif
@@ -981,22 +987,33 @@ __device__ __forceinline__ void imdct_pair(const char *img, char *sc, uint32_t l
 	__builtin_amdgcn_sched_barrier(0);
 	t3_read(sc, lane, P1);
 #else
+	LW_MARK("ip_t3_0+c1");
 	t3_inreg(P0);
 	stage_c1(tc, P1);
 	__builtin_amdgcn_sched_barrier(0);
+	LW_MARK("ip_t3_1");
 	t3_inreg(P1);
 #endif
+#ifdef LW_MARKS
+	__builtin_amdgcn_sched_barrier(0);
+#endif
+	LW_MARK("ip_stage_d0");
 	stage_d_block(a2, P0);
 	__builtin_amdgcn_sched_barrier(0);
+	LW_MARK("ip_t4w_0");
 	t4_write(sc, lane, P0);
 	__builtin_amdgcn_sched_barrier(0);
+	LW_MARK("ip_e0+d1");
 	stage_e1(img, sc, lane, R[0]);
 	stage_d_block(a2, P1);
 	__builtin_amdgcn_sched_barrier(0);
+	LW_MARK("ip_t4w_1");
 	t4_write(sc, lane, P1);
 	__builtin_amdgcn_sched_barrier(0);
+	LW_MARK("ip_stage_e1");
 	stage_e1(img, sc, lane, R[1]);
 	__builtin_amdgcn_sched_barrier(0);
+	LW_MARK("ip_end");
 }
 
 // ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private).

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction counts per marked region of k_long<0,false> (stereo-only build with -DLW_MARKS)."""
+"""Static instruction counts per marked region of k_long<0,false,false> (stereo-only build with -DLW_MARKS)."""
 import collections, re, subprocess, sys, os, glob
 os.makedirs("/tmp/kl", exist_ok=True)
 os.chdir("/tmp/kl")
@@ -8,7 +8,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
                 "-DLW_EXP_STEREO_ONLY", "-DLW_MARKS", "-save-temps", "-c", "/root/repo/lewton_amd/csrc/lw_kernels_long.hip", "-o", "/tmp/kl/m.o"] + flags,
                check=True, stderr=subprocess.DEVNULL)
 src = open(glob.glob("lw_kernels_long-hip-amdgcn*.s")[0]).read()
-body = src[src.index("_Z6k_longILi0ELb0EEv"):]
+body = src[src.index("_Z6k_longILi0ELb0ELb0EEv"):]
 body = body[:body.index("s_endpgm")]
 region, order, cnt = "prologue", ["prologue"], collections.defaultdict(collections.Counter)
 for line in body.splitlines():
