@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../tests/san/hip_standins.inc"
@@ -133,6 +134,39 @@ int main(int argc, char **argv)
 					return 1;
 				}
 			}
+		}
+		{ // two callers, each with its own batch and streams, share the decoder and the worker pool
+			lw_batch *b2 = lw_batch_create(dec, NP, LW_FMT_I16_PLANAR, &err);
+			if (sym)
+				lw_batch_set_residue_on_device(b2, 1);
+			std::vector<lw_pwr *> pwr2(S);
+			for (auto &p : pwr2)
+				p = lw_pwr_new(dec);
+			std::vector<lw_packet> pk2 = pk;
+			for (size_t k = 0; k < NP; k++)
+				pk2[k].pwr = pwr2[k / (NP / S)];
+			std::vector<lw_packet_result> r1, r2;
+			bool bad = false;
+			auto drive = [&](lw_batch *bb, std::vector<lw_packet> &pp, std::vector<lw_pwr *> &pw, std::vector<lw_packet_result> &out) {
+				for (int rep = 0; rep < 4; rep++) {
+					for (auto *p : pw)
+						lw_pwr_reset(p);
+					if (lw_batch_entropy(bb, pp.data(), NP, threads.empty() ? 4 : threads.back()))
+						bad = true;
+					out.assign(lw_batch_results(bb), lw_batch_results(bb) + NP);
+				}
+			};
+			std::thread t1([&]() { drive(b, pk, pwr, r1); }), t2([&]() { drive(b2, pk2, pwr2, r2); });
+			t1.join();
+			t2.join();
+			for (size_t k = 0; k < NP && !bad; k++)
+				bad = r1[k].status != ref.res[k].status || r2[k].status != ref.res[k].status ||
+						r1[k].n_samples != ref.res[k].n_samples || r2[k].n_samples != ref.res[k].n_samples;
+			if (bad) {
+				printf("two concurrent callers: results differ\n");
+				return 1;
+			}
+			lw_batch_destroy(b2);
 		}
 		printf("check ok: %zu packets (%zu decodable vs single-packet hook)\n", NP, ok);
 		return 0;
