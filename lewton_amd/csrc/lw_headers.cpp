@@ -127,8 +127,11 @@ Huffman::BuildResult Huffman::build(const uint8_t *lengths, size_t n)
 			uint8_t &sb = sub_bits[stream_bits(i) & ((1u << LUT_BITS) - 1)];
 			sb = std::max<uint8_t>(sb, (uint8_t)std::min<unsigned>(lengths[i] - LUT_BITS, SUB_BITS));
 		}
+	// table memory stays proportional to the book (a setup header must not buy megabytes of tables per codebook with a few
+	// kilobytes of code lengths); prefixes that no longer fit are left to the tree walk
+	const size_t cap = std::min<size_t>((size_t)1 << 24, ((size_t)1 << LUT_BITS) + 8 * (size_t)used);
 	for (size_t p = 0; p < ((size_t)1 << LUT_BITS); p++)
-		if (sub_bits[p] && lut.size() + ((size_t)1 << sub_bits[p]) <= (1u << 24)) {
+		if (sub_bits[p] && lut.size() + ((size_t)1 << sub_bits[p]) <= cap) {
 			lut[p] = LINK | ((uint32_t)sub_bits[p] << 24) | (uint32_t)lut.size();
 			lut.resize(lut.size() + ((size_t)1 << sub_bits[p]), 0);
 		}
