@@ -231,6 +231,11 @@ def main():
         cpu = {"value": npk / secs, "unit": "packets/s", "cores": 1, "kind": "port",
                "sample": "%d stereo long packets (same generator as the GPU workload), oracle/lewton_oracle.c "
                          "(C restatement of lewton incl. entropy decode), 1 thread, %.1f s" % (npk, secs)}
+        try:  # per-stage split of the baseline: bit-serial entropy stage vs synthesis; informational
+            e_s, t_s = po.stage_split(o_id, o_st, pool)
+            cpu["entropy_share"] = round(e_s / t_s, 4)
+        except Exception as e:
+            cpu["entropy_share"] = None
         # all host cores, one independent stream per core (separate worker processes; informational)
         if args.cpu_all_cores_seconds > 0:
             try:

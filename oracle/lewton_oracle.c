@@ -2138,6 +2138,27 @@ int lwo_get_decoded_sample_count(const lwo_ident *id, const lwo_setup *s, const 
 	return LWO_OK;
 }
 
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* bench hook (SURVEY 8(d) asks for the baseline's entropy / synthesis split): with lwo_stage_timing(1) every packet adds
+ * the time from its first bit to the end of residue decode to a counter; the arithmetic is untouched. */
+static int g_stage_timing;
+static double g_entropy_seconds;
+void lwo_stage_timing(int on)
+{
+	g_stage_timing = on;
+	g_entropy_seconds = 0.0;
+}
+double lwo_stage_entropy_seconds(void)
+{
+	return g_entropy_seconds;
+}
+
 static size_t g_debug_bits_consumed; /* test hook: bit cursor after the entropy stage of the last packet */
 size_t lwo_debug_bits_consumed(void)
 {
@@ -2161,6 +2182,7 @@ static int read_audio_packet_core(const lwo_ident *id, const lwo_setup *s, const
 	int flag, pf = 0, nf = 0;
 	uint32_t mode_number, n, n2;
 	const mode_cfg *mode;
+	const double packet_t0 = g_stage_timing ? now_s() : 0.0;
 	const mapping_cfg *map;
 	size_t ch = id->channels, i, j, k;
 	decoded_floor *fls;
@@ -2243,6 +2265,8 @@ static int read_audio_packet_core(const lwo_ident *id, const lwo_setup *s, const
 		free(vecs);
 	}
 	g_debug_bits_consumed = (size_t)r.pos;
+	if (g_stage_timing) /* the bit-serial stage (rows A2-A5) ends here, synthesis (A7-A14) follows */
+		g_entropy_seconds += now_s() - packet_t0;
 	if (taps && taps->residue_pre_inverse)
 		memcpy(taps->residue_pre_inverse, residue, sizeof(float) * ch * n2);
 	/* inverse coupling, audio.rs:990-1002 (reverse step order) */
@@ -2400,13 +2424,6 @@ int lwo_read_audio_packet_i16_itl(const lwo_ident *id, const lwo_setup *s, const
 	*n_samples = m;
 	free(work);
 	return LWO_OK;
-}
-
-static double now_s(void)
-{
-	struct timespec ts;
-	clock_gettime(CLOCK_MONOTONIC, &ts);
-	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
 int lwo_decode_stream_i16(const lwo_ident *id, const lwo_setup *s, const uint8_t *data,

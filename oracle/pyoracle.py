@@ -212,6 +212,19 @@ def read_audio_packet(ident, setup, packet, pwr, fmt="i16", taps=False):
     return out[: ch * m.value].copy()
 
 
+def stage_split(ident, setup, packets):
+    """(seconds in the bit-serial stage A2-A5, total seconds) of one perf.rs-shaped pass over `packets`."""
+    L = lib()
+    L.lwo_stage_timing.argtypes = [C.c_int]
+    L.lwo_stage_entropy_seconds.restype = C.c_double
+    L.lwo_stage_timing(1)
+    try:
+        _, _, total = decode_stream_i16(ident, setup, packets, keep=False)
+        return L.lwo_stage_entropy_seconds(), total
+    finally:
+        L.lwo_stage_timing(0)
+
+
 def decode_stream_i16(ident, setup, packets, pwr=None, keep=True):
     """perf.rs-shaped loop over a list of packets; returns (list-concatenated planar-per-packet i16, total, seconds)."""
     pwr = pwr or Pwr()
