@@ -111,6 +111,9 @@ int lwo_decode_stream_i16(const lwo_ident *id, const lwo_setup *s,
 
 /* test hook: bits consumed by the entropy stage of the most recent packet (not thread safe) */
 size_t lwo_debug_bits_consumed(void);
+/* bench hook: accumulate the time of the bit-serial stage (audio.rs:921-986) of every packet decoded while on */
+void lwo_stage_timing(int on);
+double lwo_stage_entropy_seconds(void);
 
 /* ---- unit-level entry points for known-answer tests ---- */
 /* header_cached.rs:34-110 -- tables for one blocksize; arrays sized n/2,n/2,n/4,n/2,n/8 */
