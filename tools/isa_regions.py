@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Static instruction counts per marked region of k_long<0,false,false> (stereo-only build with -DLW_MARKS)."""
+"""Static instruction counts per marked region of k_long<0,false,false> (stereo-only build with -DLW_MARKS).
+
+Caveat: the marks are `asm volatile` statements and the build is not the shipped one -- it spills, and it carries ~60 16-bit
+byte-shuffle operations per item (v_bitop3_b16 / v_lshlrev_b16 / v_or_b32_sdwa) that the production kernel does not have
+(4 in total there; count them in the shipped code object with llvm-objdump before chasing them).  Use the region table for
+the packed-arithmetic / LDS split, not for plain-VALU overhead."""
 import collections, re, subprocess, sys, os, glob
 os.makedirs("/tmp/kl", exist_ok=True)
 os.chdir("/tmp/kl")
