@@ -217,7 +217,7 @@ def main():
     kernels = batches[0].last_kernels
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (the contract: rank 0 at N=1 only; null in the N>1 lines)
         from oracle import pyoracle as po
         o_id = po.Ident(idp)
         o_st = po.Setup(stp, o_id)
