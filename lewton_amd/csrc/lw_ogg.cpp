@@ -78,24 +78,39 @@ struct IoSource : Source {
 // ---------------------------------------------------------------------------------------------
 // CRC of RFC 3533 section 6: polynomial 0x04c11db7, initial value 0, bits not reflected, no final xor
 // ---------------------------------------------------------------------------------------------
+// Slicing by 8: t[k][b] is the CRC of byte b followed by k zero bytes, so eight input bytes are folded with eight
+// independent table reads per step instead of eight dependent ones (the demultiplexer is the sequential stage of the
+// single-stream path; bytewise it ran at ~0.3 GB/s).
 struct CrcTable {
-	uint32_t t[256];
+	uint32_t t[8][256];
 	CrcTable()
 	{
 		for (uint32_t i = 0; i < 256; i++) {
 			uint32_t r = i << 24;
 			for (int k = 0; k < 8; k++)
 				r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : (r << 1);
-			t[i] = r;
+			t[0][i] = r;
 		}
+		for (int k = 1; k < 8; k++)
+			for (uint32_t i = 0; i < 256; i++)
+				t[k][i] = (t[k - 1][i] << 8) ^ t[0][t[k - 1][i] >> 24];
 	}
 };
 const CrcTable kCrc;
 
 uint32_t crc_update(uint32_t crc, const uint8_t *d, size_t n)
 {
-	for (size_t i = 0; i < n; i++)
-		crc = (crc << 8) ^ kCrc.t[((crc >> 24) ^ d[i]) & 0xff];
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) {
+		uint32_t a, b;
+		std::memcpy(&a, d + i, 4);
+		std::memcpy(&b, d + i + 4, 4);
+		const uint32_t hi = crc ^ __builtin_bswap32(a), lo = __builtin_bswap32(b); // the CRC shifts the first byte in first
+		crc = kCrc.t[7][hi >> 24] ^ kCrc.t[6][(hi >> 16) & 0xff] ^ kCrc.t[5][(hi >> 8) & 0xff] ^ kCrc.t[4][hi & 0xff] ^
+		      kCrc.t[3][lo >> 24] ^ kCrc.t[2][(lo >> 16) & 0xff] ^ kCrc.t[1][(lo >> 8) & 0xff] ^ kCrc.t[0][lo & 0xff];
+	}
+	for (; i < n; i++)
+		crc = (crc << 8) ^ kCrc.t[0][((crc >> 24) ^ d[i]) & 0xff];
 	return crc;
 }
 
@@ -233,6 +248,19 @@ struct lw_ogg_reader {
 		}
 		if (!pg.lacing.empty() && pg.lacing.back() == 255 && have_start)
 			partial[pg.serial].swap(buf);
+		return LW_OK;
+	}
+
+	// the next packet with its storage (the stream layer keeps packets in its look-ahead queue: no second copy)
+	int next_owned(QueuedPacket &q)
+	{
+		while (queue.empty()) {
+			const int rc = pump();
+			if (rc != LW_OK)
+				return rc;
+		}
+		q = std::move(queue.front());
+		queue.pop_front();
 		return LW_OK;
 	}
 
@@ -790,8 +818,7 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 			q = std::move(s->pending);
 			s->has_pending = false;
 		} else {
-			lw_ogg_packet k;
-			const int rc = lw_ogg_read_packet(s->rdr, &k);
+			const int rc = s->rdr->next_owned(q);
 			if (rc == LW_OGG_EOF) {
 				eof = true;
 				break;
@@ -802,15 +829,14 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 				s->deferred = rc; // deliver what was read, report the error on the next call
 				break;
 			}
-			if (k.stream_serial != s->serial) {
-				if (k.first_in_stream) {
-					lw_ogg_stream::take(k, s->pending);
+			if (q.serial != s->serial) {
+				if (q.first_in_stream) {
+					s->pending = std::move(q);
 					s->has_pending = true;
 					break;
 				}
 				continue;
 			}
-			lw_ogg_stream::take(k, q);
 		}
 		s->ahead.push_back(std::move(q));
 	}

@@ -77,12 +77,13 @@ int main(int argc, char **argv)
 		drain();
 	} else if (mode == "ahead") {
 		const size_t K = (size_t)std::max<unsigned long long>(1, arg);
+		const int n_threads = getenv("LW_OSH_THREADS") ? atoi(getenv("LW_OSH_THREADS")) : 2; // (profiling runs: more entropy threads)
 		std::vector<uint32_t> ns(K);
 		std::vector<int32_t> st(K);
 		for (;;) {
 			size_t np = 0;
 			out.resize(std::max(out.size(), cap_for(s) * K));
-			const int rc = lw_ogg_stream_read_dec_packets(s, LW_FMT_I16_PLANAR, K, 2, out.data(), out.size(), ns.data(), st.data(), &np);
+			const int rc = lw_ogg_stream_read_dec_packets(s, LW_FMT_I16_PLANAR, K, n_threads, out.data(), out.size(), ns.data(), st.data(), &np);
 			if (rc == LW_OGG_EOF) {
 				printf("EOF\n");
 				break;
