@@ -145,6 +145,7 @@ struct lw_ogg_reader {
 	std::unordered_map<uint32_t, std::vector<uint8_t>> partial; // per logical stream: packet continued on the next page
 	std::deque<QueuedPacket> queue;
 	QueuedPacket current; // storage behind the last lw_ogg_packet handed out
+	Page pump_page;       // scratch of pump()
 
 	// reads exactly n bytes at the current source position; 0 ok, 1 clean end before the first byte, < 0 error
 	int read_exact(uint8_t *dst, size_t n)
@@ -207,7 +208,7 @@ struct lw_ogg_reader {
 	// splits the next page into packets (RFC 3533 section 5: a lacing value < 255 ends a packet)
 	int pump()
 	{
-		Page pg;
+		Page &pg = pump_page; // (its vectors keep their capacity from page to page)
 		const int rc = read_page_at(pos, pg);
 		if (rc != LW_OK)
 			return rc;
@@ -223,9 +224,20 @@ struct lw_ogg_reader {
 			have_start = false; // continuation of a packet whose beginning was not seen (after a seek)
 		}
 		size_t o = 0, n_done = 0;
-		for (uint8_t lv : pg.lacing) {
-			if (have_start)
+		for (size_t li = 0; li < pg.lacing.size(); li++) {
+			const uint8_t lv = pg.lacing[li];
+			if (have_start) {
+				if (buf.empty()) { // one allocation per packet: the segments of the packet that lie on this page
+					size_t len = 0;
+					for (size_t k = li; k < pg.lacing.size(); k++) {
+						len += pg.lacing[k];
+						if (pg.lacing[k] < 255)
+							break;
+					}
+					buf.reserve(len);
+				}
 				buf.insert(buf.end(), pg.body.begin() + o, pg.body.begin() + o + lv);
+			}
 			o += lv;
 			if (lv < 255) {
 				if (have_start) {
