@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY (like the rest of oracle/): nothing under lewton_amd/ imports this module.
 
-Two parts:
+Three parts:
 
 * Ogg page / packet demultiplexing.  lewton delegates this to the external crate `ogg 0.8.0`
   (Cargo.lock; not vendored under /root/reference), so the restatement follows the published
@@ -10,6 +10,7 @@ Two parts:
   no reflection, no final xor, CRC field zeroed while summing), and the packet attributes lewton's call
   sites consume: `stream_serial()`, `first_in_stream()`, `last_in_stream()`, `last_in_page()`,
   `absgp_page()` (inside_ogg.rs:32-49, 116-151, 219-227).
+* `read_header_comment` (header.rs:309-355), which the C oracle does not have.
 * `OggStreamReader` (inside_ogg.rs:66-314): header bootstrap, chained streams, truncation of the last
   packet to the final granule position, `skip_samples_linear`, `seek_absgp_pg`, over the oracle's
   packet decoder (oracle/pyoracle.py).
@@ -206,8 +207,50 @@ def _hdr(fn, *a):
         raise VorbisError("BadHeader", e.code)
 
 
+def read_header_comment(packet):
+    """header.rs:309-355 (+ read_header_begin_body :131-153): (vendor, [(key, value)]) or OracleError(HeaderReadError code).
+    Comments that are not UTF-8 or have no '=' are skipped, the key is everything before the FIRST '='; the framing byte
+    must be exactly 1.  Every short read is EndOfPacket (From<io::Error>, :80-87)."""
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        if len(packet) - pos < n:
+            raise po.OracleError(po.HDR_END_OF_PACKET)
+        b = bytes(packet[pos:pos + n])
+        pos += n
+        return b
+
+    hd_id = take(1)[0]
+    if hd_id & 1 == 0:
+        raise po.OracleError(po.HDR_IS_AUDIO)
+    for want in b"vorbis":          # `&&` chain: reading stops at the first mismatch
+        if take(1)[0] != want:
+            raise po.OracleError(po.HDR_NOT_VORBIS)
+    if hd_id != 3:
+        raise po.OracleError(po.HDR_BAD_TYPE)
+    try:
+        vendor = take(struct.unpack("<I", take(4))[0]).decode("utf-8")
+    except UnicodeDecodeError:
+        raise po.OracleError(po.HDR_UTF8)
+    comments = []
+    for _ in range(struct.unpack("<I", take(4))[0]):
+        raw = take(struct.unpack("<I", take(4))[0])
+        try:
+            text = raw.decode("utf-8")
+        except UnicodeDecodeError:
+            continue
+        if "=" not in text:
+            continue
+        key, val = text.split("=", 1)
+        comments.append((key, val))
+    if take(1)[0] != 1:
+        raise po.OracleError(po.HDR_BAD_FORMAT)
+    return vendor, comments
+
+
 def read_headers(rdr):
-    """inside_ogg.rs:30-49 (the comment header is skipped: the oracle has no parser for it and the path does not use it)."""
+    """inside_ogg.rs:30-49"""
     try:
         pck = rdr.read_packet_expected()
         ident = _hdr(po.Ident, pck.data)
@@ -216,6 +259,7 @@ def read_headers(rdr):
         while pck.serial != serial:
             pck = rdr.read_packet_expected()
         comment_packet = pck.data
+        _hdr(read_header_comment, comment_packet)
         pck = rdr.read_packet_expected()
         while pck.serial != serial:
             pck = rdr.read_packet_expected()
@@ -257,6 +301,7 @@ class OggStreamReader:
                 ident = _hdr(po.Ident, pck.data)
                 pck = self._read_packet(True)
                 self.comment_packet = pck.data
+                _hdr(read_header_comment, pck.data)
                 pck = self._read_packet(True)
                 setup = _hdr(po.Setup, pck.data, ident)
                 self.pwr = po.Pwr()

@@ -206,12 +206,14 @@ def test_zero_length_packets_are_empty_packets_not_null_arguments(harness, tmp_p
     got = _run(harness, tmp_path, data, "ahead", 16)
     qs = [r for r in got if r[0] == "Q"]
     assert [q[2] for q in qs][:5] == ["0"] * 4 + [str(po.AUDIO_END_OF_PACKET)]
-    # an empty comment header: read_header_comment fails on its first byte (header.rs:309-313; the oracle does not
-    # parse comment headers, so this half is pinned on the reference's text alone)
+    # an empty comment header: read_header_comment fails on its first byte (header.rs:309-313)
     w = ogg.PageWriter(0x52)
     w.add_packet(idp, 0, flush=True)
     w.add_packet(b"", 0)
     w.add_packet(stp, 0, flush=True)
     data = w.bytes()
+    with pytest.raises(pyogg.VorbisError) as e:
+        pyogg.OggStreamReader(data)
+    assert (e.value.kind, e.value.inner) == ("BadHeader", po.HDR_END_OF_PACKET)
     got = _run(harness, tmp_path, data, "seq")
     assert got == [["E", str(po.HDR_END_OF_PACKET)]]

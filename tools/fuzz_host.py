@@ -87,7 +87,7 @@ with tempfile.TemporaryDirectory() as tmp:
                            "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + HIP_INC] + SRC + ["-lpthread", "-o", exe])
     files = _files()
     names = sorted(files)
-    agree = opened = 0
+    agree = opened = comment_rejects = 0
     for t in range(args.stream_cases):
         d = bytearray(files[names[t % len(names)]])
         kind = int(rng.integers(0, 5))
@@ -116,17 +116,34 @@ with tempfile.TemporaryDirectory() as tmp:
             if mode == ["seq"]:
                 got = [l.split() for l in r.stdout.splitlines()]
                 try:
-                    want = _oracle_trace(pyogg.OggStreamReader(data))
-                except pyogg.VorbisError:
-                    assert got and got[0][0] == "E", (t, got[:2])
-                    continue
-                opened += 1
-                if want[-1] == ["EOF"]:
-                    assert got == want, (t, want[-2:], got[-2:])
-                    agree += 1
-                else:
-                    e, k = want[-1][1], len(want) - 1
-                    assert got[:k] == want[:k] and got[k][0] == "E", (t, want[-2:], got[k - 1:k + 1])
-                    assert e.kind != "BadAudio" or got[k][1] == str(e.inner), (t, e, got[k])
+                    try:
+                        want = _oracle_trace(pyogg.OggStreamReader(data))
+                    except pyogg.VorbisError:
+                        assert got and got[0][0] == "E", (t, got[:2])
+                        continue
+                    if got and got[0][0] == "E":
+                        # the oracle does not parse comment headers (oracle/pyogg.py read_headers); the product and the
+                        # reference do (inside_ogg.rs:38-41): a damaged comment packet is a header error there
+                        try:
+                            header.read_header_comment(pyogg.OggStreamReader(data).comment_packet)
+                        except header.HeaderReadError as e:
+                            assert int(got[0][1]) == e.code, (t, got[0], e.code)
+                            comment_rejects += 1
+                            continue
+                    opened += 1
+                    if want[-1] == ["EOF"]:
+                        assert got == want, (t, want[-2:], got[-2:])
+                        agree += 1
+                    else:
+                        e, k = want[-1][1], len(want) - 1
+                        assert got[:k] == want[:k] and got[k][0] == "E", (t, want[-2:], got[k - 1:k + 1])
+                        assert e.kind != "BadAudio" or got[k][1] == str(e.inner), (t, e, got[k])
+                except AssertionError:
+                    keep = os.path.join(ROOT, "gpurun_out", "fuzz_diff_%d.ogg" % t)
+                    os.makedirs(os.path.dirname(keep), exist_ok=True)
+                    open(keep, "wb").write(data)
+                    print("trace differs from the oracle's; input kept as", keep)
+                    raise
     print("stream layer: %d mutated files x 4 modes without a sanitizer report; %d opened, %d read to a clean end, all traces equal "
-          "to the oracle" % (args.stream_cases, opened, agree))
+          "to the oracle (%d damaged comment headers rejected by the product's parser only: the oracle has none)" % (
+              args.stream_cases, opened, agree, comment_rejects))
