@@ -65,6 +65,7 @@ for c in range(args.callers):
 
 def run_caller(c, n, t_ent):
     slots, marshalled, _ = callers[c]
+    kernels_done = None                       # consecutive batches carry the streams' window state on the device
     for k in range(n):
         stream, bt, d_out, h_out, ev = slots[k % len(slots)]
         ev.synchronize()                      # the slot's previous batch has left the staging buffers
@@ -73,7 +74,11 @@ def run_caller(c, n, t_ent):
         t_ent[c] += time.perf_counter() - t0
         sp = C.c_void_p(stream.cuda_stream)
         bt.upload(sp)
+        if kernels_done is not None:
+            stream.wait_event(kernels_done)   # kernels of batch k read the state batch k-1's kernels wrote (other HIP stream)
         bt.synth(C.c_void_p(d_out.data_ptr()), d_out.numel(), sp)
+        kernels_done = torch.cuda.Event()
+        kernels_done.record(stream)
         with torch.cuda.stream(stream):
             h_out[: bt.out_elems].copy_(d_out[: bt.out_elems], non_blocking=True)
             ev.record(stream)
