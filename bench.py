@@ -91,6 +91,7 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     batches, outs, pwrs = [], [], []
+    prime_idx, orders = [], []   # what every batch was built from (the parity check below re-decodes batch 0 on the CPU)
     S = args.streams
     assert PACKETS_PER_BATCH % S == 0
     per_stream = PACKETS_PER_BATCH // S
@@ -98,7 +99,8 @@ def main():
         # prime every stream with one packet so that all 4096 packets of the batch yield samples
         spw = [audio.PreviousWindowRight() for _ in range(S)]
         prime = Batch(dec, S, args.format)
-        prime.entropy([(pool[int(rng.integers(0, UNIQUE_PACKETS))], pw) for pw in spw])
+        pidx = rng.integers(0, UNIQUE_PACKETS, S)
+        prime.entropy([(pool[int(i)], pw) for i, pw in zip(pidx, spw)])
         prime.upload(sptr)
         prime.synth_to_host(sptr)
         prime.close()
@@ -117,6 +119,8 @@ def main():
         batches.append(bt)
         outs.append(out)
         pwrs.append(pwr)
+        prime_idx.append(pidx)
+        orders.append(order)
     torch.cuda.synchronize()
     alg_bytes = batches[0].algorithmic_bytes  # 12 420 B per stereo long packet
     assert alg_bytes == PACKETS_PER_BATCH * (12420 + (4096 if args.format == "f32" else 0)), alg_bytes
@@ -185,36 +189,33 @@ def main():
     # device time of the K steps on the launch stream (HIP events), per step
     launch_ms = ev0.elapsed_time(ev1) / args.steps
 
-    # ---- spot-check parity of what was just timed (rank 0, first batch, first 64 packets) against the oracle
+    # ---- parity of the bytes that were just timed: outs[0] as the last timed replay of batch 0 left it, against the
+    #      oracle (rank 0): streams 0, S/2 - 1 and S - 1 of that batch, every packet of each, starting from the
+    #      primed state (the oracle decodes the priming packet first, exactly as the GPU stream did)
     parity = None
+    kernels = batches[0].last_kernels
     if rank == 0:
         try:
             from oracle import pyoracle as po
             o_id = po.Ident(idp)
             o_st = po.Setup(stp, o_id)
-            # re-decode batch 0's first packets on the CPU starting from the same primed state is not possible
-            # without the priming packet; instead check a fresh short stream end-to-end
-            chk = [pool[i] for i in range(33)]
-            pw, opw = audio.PreviousWindowRight(), po.Pwr()
-            bt = Batch(dec, 33, args.format)
-            if args.device_vq:
-                bt.set_residue_on_device(True)
-            if args.force_generic:
-                bt.set_force_generic(True)
-            bt.entropy([(p, pw) for p in chk])
-            bt.upload(sptr)
-            got = bt.split(bt.synth_to_host(sptr), 2)
-            ok = True
             ofmt = {"i16": "i16", "i16_interleaved": "i16_itl", "f32": "f32"}[args.format]
-            for p, g in zip(chk, got):
-                w = po.read_audio_packet(o_id, o_st, p, opw, ofmt)
-                ok &= bool(np.array_equal(np.asarray(g).reshape(-1), np.asarray(w).reshape(-1)))
-            parity = "%s bit-exact vs oracle (33 packets)" % args.format if ok else "MISMATCH"
-            kernels = bt.last_kernels
+            host = outs[0].cpu().numpy()
+            per_pkt = 2 * 1024                     # elements per packet block (every timed packet yields 1024 x 2)
+            chk_streams = list(range(S))      # all of them: 4096 packets cost the oracle ~0.2 s
+            ok, n_chk = True, 0
+            for sidx in chk_streams:
+                opw = po.Pwr()
+                po.read_audio_packet(o_id, o_st, pool[int(prime_idx[0][sidx])], opw, ofmt)
+                for k in range(sidx * per_stream, (sidx + 1) * per_stream):
+                    w = po.read_audio_packet(o_id, o_st, pool[int(orders[0][k])], opw, ofmt)
+                    g = host[k * per_pkt:(k + 1) * per_pkt]
+                    ok &= bool(np.array_equal(g.reshape(-1), np.asarray(w).reshape(-1)))
+                    n_chk += 1
+            parity = ("timed batch 0: all %d streams x %d packets = %d packets %s bit-exact vs oracle" % (
+                len(chk_streams), per_stream, n_chk, args.format)) if ok else "MISMATCH in timed batch 0"
         except Exception as e:  # the oracle is only a checker here
             parity = "unchecked: %r" % (e,)
-            kernels = batches[0].last_kernels
-    kernels = batches[0].last_kernels
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (the contract: rank 0 at N=1 only; null in the N>1 lines)
@@ -257,9 +258,11 @@ def main():
 
     # HBM traffic of one launch from the PMC passes (tools/pmc.sh -> profiles/): measured in separate rocprofv3 runs of
     # this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; null if no profile is committed
-    traffic = None
+    traffic, pmc_file = None, "none"
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        import glob
+        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]   # newest round
+        pm = json.load(open(pmc_file))
         traffic = pm.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -290,7 +293,7 @@ def main():
                        "parallelism": "streams sharded across GPUs, no collectives"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_summary.json)",
+                         "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/%s)" % os.path.basename(pmc_file),
                          "kernel": kernels, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }

@@ -114,7 +114,12 @@ _FMT = {"i16": N.FMT_I16_PLANAR, "i16_interleaved": N.FMT_I16_INTERLEAVED, "f32"
 
 def read_audio_packet_generic(ident, setup, packet, pwr, samples="i16", device=0):
     """`samples`: 'i16' (Vec<Vec<i16>>), 'i16_interleaved' (InterleavedSamples<i16>), 'f32' (Vec<Vec<f32>>)."""
-    dec = decoder_for(ident, setup, device)
+    return read_audio_packet_on(decoder_for(ident, setup, device), packet, pwr, samples)
+
+
+def read_audio_packet_on(dec, packet, pwr, samples="i16"):
+    """The same call on an explicit Decoder (one per GPU / per logical shard of a multi-device process)."""
+    ident = dec.ident
     h = pwr._bind(dec)
     ch = ident.audio_channels
     cap = (1 << ident.blocksize_1)

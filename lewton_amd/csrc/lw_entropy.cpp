@@ -45,7 +45,9 @@ int decoded_sample_count(const Ident &id, const Setup &s, const uint8_t *pkt, si
 
 namespace {
 
-enum FloorResult { FL_OK, FL_UNUSED, FL_UNDECODABLE };
+// FL_REF_PANICS: a state in which the reference indexes out of bounds / divides by zero (a Rust panic, i.e. no defined
+// result); the packet is reported as AUDIO_BAD_FORMAT instead of touching memory the setup does not describe
+enum FloorResult { FL_OK, FL_UNUSED, FL_UNDECODABLE, FL_REF_PANICS };
 
 // audio.rs:215-251
 FloorResult floor_one_decode(BitReader &r, const Setup &s, const Floor1 &fl, uint32_t *y)
@@ -96,6 +98,10 @@ FloorResult floor_zero_decode(BitReader &r, const Setup &s, const Floor0 &fl, fl
 		return FL_UNUSED;
 	if (booknumber >= fl.n_books)
 		return FL_UNDECODABLE;
+	// header.rs:793 accepts a book number equal to the codebook count (`>` instead of `>=`); the reference then panics on
+	// `codebooks[idx]` here (:127)
+	if (fl.book_list[booknumber] >= s.codebooks.size())
+		return FL_REF_PANICS;
 	const Codebook &cb = s.codebooks[fl.book_list[booknumber]];
 	size_t n = 0;
 	float last = 0.0f;
@@ -106,6 +112,11 @@ FloorResult floor_zero_decode(BitReader &r, const Setup &s, const Floor0 &fl, fl
 			return FL_UNUSED;
 		if (!cb.has_vq)
 			return FL_UNDECODABLE;
+		// floor0_order 0 or 1: the reference collects the first vector (order 0: all of it, whatever its length) and
+		// returns Ok; floor_zero_compute_curve then evaluates `(order - 2) / 2` resp. `(order - 3) / 2` in usize, which
+		// wraps, and panics indexing the coefficients (:176-191).  Nothing is written to coeff[] for such a floor.
+		if (fl.order < 2 && cb.dims != 0)
+			return FL_REF_PANICS;
 		for (size_t d = 0; d < cb.dims; d++) {
 			const float e = cb.vq[(size_t)idx * cb.dims + d];
 			coeff[n++] = cosf(last + e);
@@ -115,7 +126,7 @@ FloorResult floor_zero_decode(BitReader &r, const Setup &s, const Floor0 &fl, fl
 		}
 		last += last_new;
 		if (n >= fl.order)
-			return FL_OK;
+			return fl.order < 2 ? FL_REF_PANICS : FL_OK; // (order 0 with a zero-dimensional book: Ok, then the curve panics)
 	}
 }
 
@@ -123,7 +134,10 @@ FloorResult floor_zero_decode(BitReader &r, const Setup &s, const Floor0 &fl, fl
 void floor_zero_curve(const float *cosc, uint64_t amplitude, const Floor0 &fl, bool blockflag, size_t n, float *out)
 {
 	const float *bark_cos = fl.bark_cos_omega[blockflag ? 1 : 0].data();
-	const float common = (float)amplitude * (float)fl.amp_offset / (float)((((uint64_t)1) << fl.amp_bits) - 1);
+	// `((1 << bits) - 1) as f32` (:167) is i32 arithmetic: in a release build the shift count is taken mod 32 and the
+	// subtraction wraps (bits = 31 gives i32::MAX, bits = 32 gives 0 and an infinite / NaN curve)
+	const int32_t denom = (int32_t)((1u << (fl.amp_bits & 31u)) - 1u);
+	const float common = (float)amplitude * (float)fl.amp_offset / (float)denom;
 	size_t i = 0;
 	while (i < n) {
 		const float cos_omega = bark_cos[i];
@@ -213,17 +227,28 @@ template <unsigned DIMS> inline void add_entry(float *v, const float *e)
 }
 
 // audio.rs:587-618.  With a sink the additions are recorded (coordinate `coord` of v[0]) instead of performed.
-inline bool read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len,
+// 1 = partition done, 0 = end of packet, -1 = the reference panics (residue type 0 divides by a zero book dimension)
+inline int read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len,
 		SymbolSink *sink, uint32_t coord, uint32_t book, unsigned pass)
 {
 	const unsigned dims = cb.dims;
 	const Huffman &h = cb.huff;
 	uint32_t idx;
+	if (dims == 0) {
+		// a lookup-type-2 book may have zero dimensions (header.rs:548-560 accepts it).  Type 0: `partition_size / 0`
+		// panics (:592).  Types 1/2: every vector is empty, `i` never advances (:600-612) and codewords are consumed
+		// until the packet ends.
+		if (rtype == 0)
+			return -1;
+		while (cr.next(h, idx)) {
+		}
+		return 0;
+	}
 	if (rtype == 0) {
 		const unsigned step = psize / dims;
 		for (unsigned i = 0; i < step; i++) {
 			if (!cr.next(h, idx))
-				return false;
+				return 0;
 			if (sink) {
 				sink->push(coord + i, book, idx, pass);
 				continue;
@@ -232,7 +257,7 @@ inline bool read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, u
 			for (unsigned j = 0; j < dims; j++)
 				v[i + j * step] += e[j];
 		}
-		return true;
+		return 1;
 	}
 	const float *vq = cb.vq.data();
 	if (!sink && (size_t)psize <= vec_len && psize % dims == 0) { // the whole partition is inside the vector
@@ -241,10 +266,10 @@ inline bool read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, u
 	case D:                                           \
 		for (unsigned i = 0; i < psize; i += D) {     \
 			if (!cr.next(h, idx))                     \
-				return false;                         \
+				return 0;                             \
 			add_entry<D>(v + i, vq + (size_t)idx * D); \
 		}                                             \
-		return true;
+		return 1;
 			LW_PART_LOOP(1)
 			LW_PART_LOOP(2)
 			LW_PART_LOOP(4)
@@ -257,7 +282,7 @@ inline bool read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, u
 	unsigned i = 0;
 	while (i < psize) {
 		if (!cr.next(h, idx))
-			return false;
+			return 0;
 		if ((size_t)i + dims > vec_len)
 			break;
 		if (sink) {
@@ -269,7 +294,7 @@ inline bool read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, u
 		}
 		i += dims;
 	}
-	return true;
+	return 1;
 }
 
 // audio.rs:620-717; `vectors` = ch * (cur_blocksize/2) zeros.  false = Err(()) (packet undecodable)
@@ -325,8 +350,11 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 					if (!(rb.vals_used & (1u << pass)))
 						continue;
 					const size_t offs = begin + pc * rs.partition_size;
-					if (!read_partition(cr, s.codebooks[rb.val_i[pass]], rs.type, rs.partition_size,
-								vectors + j * actual + offs, actual - offs, sink, (uint32_t)(j * actual + offs), rb.val_i[pass], pass))
+					const int pr = read_partition(cr, s.codebooks[rb.val_i[pass]], rs.type, rs.partition_size,
+							vectors + j * actual + offs, actual - offs, sink, (uint32_t)(j * actual + offs), rb.val_i[pass], pass);
+					if (pr < 0)
+						return false;
+					if (pr == 0)
 						return true;
 				}
 			}
@@ -398,6 +426,8 @@ int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t l
 			float coeff[256 + 8];
 			uint64_t amplitude = 0;
 			const FloorResult fr = floor_zero_decode(r, s, fl.f0, coeff, amplitude);
+			if (fr == FL_REF_PANICS)
+				return AUDIO_BAD_FORMAT;
 			if (fr == FL_UNDECODABLE)
 				return AUDIO_END_OF_PACKET;
 			if (fr == FL_UNUSED) {

@@ -597,9 +597,8 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 	if (any_coupling && (!B.gen_small || B.n_gen_small + B.n_gen_large))
 		hipLaunchKernelGGL(k_decouple, dim3(B.gen_small ? B.n_gen_small + B.n_gen_large : B.n_packets), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T,
 				B, skip_mask);
-	static bool once = false;
-	if (!once) {
-		once = true;
+	static LwPerDeviceOnce once;
+	if (once.first_launch_on_device()) {
 		(void)hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_imdct_generic<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 	}
@@ -625,9 +624,8 @@ void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBat
 {
 	if (B.n_packets == 0)
 		return;
-	static bool once = false;
-	if (!once) {
-		once = true;
+	static LwPerDeviceOnce once;
+	if (once.first_launch_on_device()) {
 		(void)hipFuncSetAttribute((const void *)k_residue_vq, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
 	}
 	const uint32_t budget = 36u * 1024u; // floats of dynamic LDS (144 KB; 8 KB of static tables beside it)

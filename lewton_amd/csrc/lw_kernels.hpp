@@ -6,6 +6,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
+// hipFuncSetAttribute is per DEVICE, and launchers are entered from several host threads (one decoder per GPU in one
+// process): `first_launch_on_device(flags)` is true exactly once per (flag set, current device).
+struct LwPerDeviceOnce {
+	std::mutex mu;
+	uint64_t done[4] = {0, 0, 0, 0}; // one bit per device ordinal
+	bool first_launch_on_device()
+	{
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256)
+			return true; // unknown ordinal: set the attributes every time (cheap, idempotent)
+		std::lock_guard<std::mutex> g(mu);
+		const bool first = !(done[dev >> 6] & (1ull << (dev & 63)));
+		done[dev >> 6] |= 1ull << (dev & 63);
+		return first;
+	}
+};
+
 // CachedBlocksizeDerived (header_cached.rs:19-110) in HBM; computed on the host, never on the device.
 struct LwDevBs {
 	const float *A, *B, *C, *window;

@@ -1710,18 +1710,16 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 		F.waves[w].slot = (uint8_t)(w / L.n_units);
 	}
 	F.late_from = 0xFFFFFFFFu;
-	static bool attr_done = false;
-	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_INTERLEAVED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_ITL_STEREO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_F32_PLANAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_PLANAR, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_INTERLEAVED, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_I16_ITL_STEREO, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_long<LW_OUT_F32_PLANAR, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_done = true;
+	// k_long needs its 152 KB of dynamic LDS opted in once per device (LwPerDeviceOnce, lw_kernels.hpp)
+	static LwPerDeviceOnce once;
+	if (once.first_launch_on_device()) {
+		const void *fns[] = {(const void *)k_long<LW_OUT_I16_PLANAR, false>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false>,
+			(const void *)k_long<LW_OUT_I16_ITL_STEREO, false>, (const void *)k_long<LW_OUT_F32_PLANAR, false>,
+			(const void *)k_long<LW_OUT_I16_PLANAR, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, true>,
+			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, true>, (const void *)k_long<LW_OUT_I16_ITL_STEREO, false, true>,
+			(const void *)k_long<LW_OUT_F32_PLANAR, false, true>};
+		for (const void *f : fns)
+			(void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	}
 	if (L.n_halo_items) {
 		F.items = L.d_halo_items;

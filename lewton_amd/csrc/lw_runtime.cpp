@@ -396,10 +396,22 @@ void lw_comment_free(lw_comment *c)
 	delete c;
 }
 
+// a setup header is parsed for a channel count (header.rs:1029: the mux lists have one entry per channel); pairing it with
+// another stream's ident header would index those lists out of range
+static bool setup_matches_ident(const lw::Ident &id, const lw::Setup &s)
+{
+	for (const auto &m : s.mappings)
+		if (m.mux.size() != id.channels)
+			return false;
+	return true;
+}
+
 int lw_get_decoded_sample_count(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len, size_t *count)
 {
 	if (!id || !s || (!packet && len) || !count)
 		return LW_ERR_NULL_ARG;
+	if (!setup_matches_ident(*id->p, *s->p))
+		return LW_ERR_STATE_MISMATCH;
 	return lw::decoded_sample_count(*id->p, *s->p, packet, len, *count);
 }
 
@@ -423,6 +435,8 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 {
 	if (!id || !s || (!packet && len) || !floor_out || !residue_out)
 		return LW_ERR_NULL_ARG;
+	if (!setup_matches_ident(*id->p, *s->p))
+		return LW_ERR_STATE_MISMATCH;
 	lw::BitReader br(packet, len);
 	lw::Prologue p;
 	int rc = lw::read_prologue(*id->p, *s->p, br, p);
@@ -459,6 +473,8 @@ int lw_entropy_symbols_host(const lw_ident *id, const lw_setup *s, const uint8_t
 {
 	if (!id || !s || (!packet && len) || !floor_out || !symbols || !n_symbols || !pass_off)
 		return LW_ERR_NULL_ARG;
+	if (!setup_matches_ident(*id->p, *s->p))
+		return LW_ERR_STATE_MISMATCH;
 	if (!lw::symbols_supported(*id->p, *s->p, nullptr))
 		return LW_ERR_UNSUPPORTED;
 	lw::Prologue p;
@@ -591,11 +607,10 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	}
 	const lw::Ident &id = *idh->p;
 	const lw::Setup &s = *sh->p;
-	for (const auto &m : s.mappings)
-		if (m.mux.size() != id.channels) {
-			*err = LW_ERR_STATE_MISMATCH;
-			return nullptr;
-		}
+	if (!setup_matches_ident(id, s)) {
+		*err = LW_ERR_STATE_MISMATCH;
+		return nullptr;
+	}
 	int ndev = 0;
 	if (!hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || device < 0 || device >= ndev ||
 			!hip_ok(hipSetDevice(device), "hipSetDevice")) {
@@ -1661,27 +1676,43 @@ int lw_read_audio_packet(lw_decoder *d, const uint8_t *packet, size_t len, lw_pw
 	}
 	lw_batch *b = d->one;
 	lw_packet pk{packet, len, pwr};
-	if (int rc = lw_batch_entropy(b, &pk, 1, 1))
+	// lw_batch_entropy commits the host half of the PreviousWindowRight (present, len, parity) when it plans the batch; the
+	// device half follows when the kernels run.  Any failure in between must leave `pwr` as the reference leaves it on an
+	// error: untouched (the one error that consumes the state, audio.rs:1107-1111, is reported through res.status).
+	const lw_pwr saved = *pwr;
+	if (int rc = lw_batch_entropy(b, &pk, 1, 1)) {
+		*pwr = saved;
 		return rc;
+	}
 	const lw_packet_result &res = b->results[0];
 	if (res.status != LW_OK)
 		return res.status;
+	int rc = LW_OK;
 	if (res.n_samples > cap_per_channel)
-		return LW_AUDIO_BUFFER_NOT_ADDRESSABLE;
-	if (int rc = lw_batch_upload(b, nullptr))
-		return rc;
+		rc = LW_AUDIO_BUFFER_NOT_ADDRESSABLE;
+	if (!rc)
+		rc = lw_batch_upload(b, nullptr);
 	const size_t need = std::max<size_t>(b->out_elems, 1) * elem_size(fmt);
-	if (d->one_out_bytes < need) {
+	if (!rc && d->one_out_bytes < need) {
 		if (d->one_out)
 			(void)hipHostFree(d->one_out);
 		d->one_out = nullptr;
-		HIP_TRY(hipHostMalloc(&d->one_out, std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4)));
-		d->one_out_bytes = std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4);
+		d->one_out_bytes = 0;
+		const size_t bytes = std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4);
+		if (hip_ok(hipHostMalloc(&d->one_out, bytes), "hipHostMalloc(packet output)"))
+			d->one_out_bytes = bytes;
+		else
+			rc = LW_ERR_DEVICE;
 	}
 	// the kernels write the PCM straight into the pinned host buffer (device-visible): launch + synchronise, no D2H copy
-	if (int rc = lw_batch_synth(b, d->one_out, b->out_elems, nullptr)) // (a first packet yields no samples, only the state)
+	if (!rc)
+		rc = lw_batch_synth(b, d->one_out, b->out_elems, nullptr); // (a first packet yields no samples, only the state)
+	if (!rc && !hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize"))
+		rc = LW_ERR_DEVICE;
+	if (rc) {
+		*pwr = saved; // the packet was not decoded: the next call overlaps against the state this one found
 		return rc;
-	HIP_TRY(hipStreamSynchronize(nullptr));
+	}
 	std::memcpy(out, d->one_out, b->out_elems * elem_size(fmt));
 	*n_samples = res.n_samples;
 	return LW_OK;

@@ -1827,8 +1827,9 @@ int lwo_floor1_curve(const lwo_setup *s, int floor_idx, const uint32_t *y, uint3
 /* ------------------------------------------------------------------------------------------
  * Floor 0 -- src/audio.rs:109-212
  * ------------------------------------------------------------------------------------------ */
-/* returns 0 ok, 1 unused, 2 undecodable */
-static int floor_zero_decode(bitrd *r, const codebook *cbs, const floor0 *fl, float *coeff, uint64_t *amp)
+/* returns 0 ok, 1 unused, 2 undecodable, 3 the reference panics (see below) */
+static int floor_zero_decode(bitrd *r, const codebook *cbs, size_t n_codebooks, const floor0 *fl, float *coeff,
+		uint64_t *amp)
 {
 	uint64_t amplitude;
 	uint32_t booknumber;
@@ -1843,6 +1844,9 @@ static int floor_zero_decode(bitrd *r, const codebook *cbs, const floor0 *fl, fl
 		return 1;
 	if (booknumber >= fl->n_books)
 		return 2;
+	/* header.rs:793 lets a book number EQUAL to the codebook count through (`>`), `codebooks[idx]` (:127) then panics */
+	if (fl->book_list[booknumber] >= n_codebooks)
+		return 3;
 	cb = &cbs[fl->book_list[booknumber]];
 	for (;;) {
 		float last_new = last;
@@ -1852,6 +1856,11 @@ static int floor_zero_decode(bitrd *r, const codebook *cbs, const floor0 *fl, fl
 			return 1;
 		if (!cb->vq)
 			return 2;
+		/* floor0_order 0 or 1: the first vector is collected (all of it for order 0: the `== order` test of :143 never
+		 * fires) and Ok is returned; floor_zero_compute_curve then wraps `(order - 2) / 2` / `(order - 3) / 2` in usize
+		 * and panics on `cos_coefficients[..]` (:176-191) */
+		if (fl->order < 2 && cb->dims != 0)
+			return 3;
 		for (d = 0; d < cb->dims; d++) {
 			float e = cb->vq[(size_t)idx * cb->dims + d];
 			coeff[ncoef++] = cosf(last + e);
@@ -1864,7 +1873,7 @@ static int floor_zero_decode(bitrd *r, const codebook *cbs, const floor0 *fl, fl
 		last += last_new;
 		if (ncoef >= fl->order) {
 			*amp = amplitude;
-			return 0;
+			return fl->order < 2 ? 3 : 0;
 		}
 	}
 }
@@ -1875,8 +1884,10 @@ static void floor_zero_curve(const float *cosc, uint64_t amplitude, const floor0
 {
 	const float *bark_cos = fl->bark_cos_omega[blockflag];
 	uint32_t i = 0;
-	float lfv_common_term = (float)amplitude * (float)fl->amp_offset /
-		(float)(((uint64_t)1 << fl->amp_bits) - 1);
+	/* `((1 << bits) - 1) as f32` (:167): the literal is an i32, so a release build takes the shift count mod 32 and
+	 * wraps the subtraction (bits 31 -> i32::MAX, bits 32 -> 0: an infinite / NaN curve, no panic) */
+	int32_t denom = (int32_t)((1u << (fl->amp_bits & 31u)) - 1u);
+	float lfv_common_term = (float)amplitude * (float)fl->amp_offset / (float)denom;
 	while (i < n) {
 		float cos_omega = bark_cos[i];
 		size_t p_ub, q_ub, j;
@@ -1913,12 +1924,21 @@ static void floor_zero_curve(const float *cosc, uint64_t amplitude, const floor0
  * Residue -- src/audio.rs:587-760
  * ------------------------------------------------------------------------------------------ */
 /* audio.rs:587-618. vec_len = floats available from vec_v to the end of this channel's vector.
- * returns 0 ok, 1 end of packet */
+ * returns 0 ok, 1 end of packet, 2 the reference panics */
 static int residue_read_partition(bitrd *r, const codebook *cb, const residue_cfg *rs, float *vec_v,
 		size_t vec_len)
 {
 	size_t dims = cb->dims;
 	uint32_t idx;
+	if (dims == 0) {
+		/* zero-dimensional book (lookup type 2 accepts it): type 0 divides by it (:592, panic = 2 here); types 1/2 read
+		 * empty vectors for ever, i.e. until the packet ends (:600-612) */
+		if (rs->type == 0)
+			return 2;
+		while (!ht_read(&cb->tree, r, &idx)) {
+		}
+		return 1;
+	}
 	if (rs->type == 0) {
 		size_t step = rs->partition_size / dims, i, j;
 		for (i = 0; i < step; i++) {
@@ -1942,7 +1962,7 @@ static int residue_read_partition(bitrd *r, const codebook *cb, const residue_cf
 	return 0;
 }
 
-/* audio.rs:620-717. `vectors` must hold ch*actual_size zeros. returns 0 or -1 (Err(())) */
+/* audio.rs:620-717. `vectors` must hold ch*actual_size zeros. returns 0, -1 (Err(())) or -2 (the reference panics) */
 static int residue_decode_inner(bitrd *r, size_t cur_blocksize, const uint8_t *dnd, size_t ch,
 		const residue_cfg *rs, const codebook *cbs, float *vectors)
 {
@@ -1993,8 +2013,13 @@ static int residue_decode_inner(bitrd *r, size_t cur_blocksize, const uint8_t *d
 					rb = &rs->books[vqclass];
 					if (rb->vals_used & (1u << pass)) {
 						const codebook *cb = &cbs[rb->val_i[pass]];
-						if (residue_read_partition(r, cb, rs, vectors + j * actual_size + offs,
-									actual_size - offs))
+						int pr = residue_read_partition(r, cb, rs, vectors + j * actual_size + offs,
+								actual_size - offs);
+						if (pr == 2) {
+							free(cls);
+							return -2;
+						}
+						if (pr)
 							goto done;
 					}
 				}
@@ -2030,7 +2055,7 @@ static int residue_packet_decode(bitrd *r, size_t cur_blocksize, const uint8_t *
 		rc = residue_decode_inner(r, bs2, c_dnd, 1, rs, cbs, tmp);
 		if (rc) {
 			free(tmp);
-			return -1;
+			return rc;
 		}
 		/* vectors.chunks(ch).map(|c| c[j]) over the bs2/2 decoded values (:748-754) */
 		for (j = 0; j < ch; j++)
@@ -2218,8 +2243,12 @@ static int read_audio_packet_core(const lwo_ident *id, const lwo_setup *s, const
 		int fr;
 		fls[i].cfg = fc;
 		if (fc->type == 0) {
-			fr = floor_zero_decode(&r, s->codebooks, &fc->f0, fls[i].coeff, &fls[i].amp);
+			fr = floor_zero_decode(&r, s->codebooks, (size_t)s->n_codebooks, &fc->f0, fls[i].coeff, &fls[i].amp);
 			fls[i].kind = (fr == 0) ? 2 : 0;
+			if (fr == 3) {
+				free(fls);
+				return LWO_REF_PANIC;
+			}
 		} else {
 			uint32_t ny = 0;
 			fr = floor_one_decode(&r, s->codebooks, &fc->f1, fls[i].y, &ny);
@@ -2250,11 +2279,14 @@ static int read_audio_packet_core(const lwo_ident *id, const lwo_setup *s, const
 			if (map->mux[j] == i)
 				dnd[sub_ch++] = no_residue[j];
 		vecs = (float *)malloc(sizeof(float) * (sub_ch * n2 + 1));
-		if (residue_packet_decode(&r, n, dnd, sub_ch, rs, s->codebooks, vecs)) {
-			free(vecs);
-			free(residue);
-			free(fls);
-			return LWO_AUDIO_BAD_FORMAT;
+		{
+			int rrc = residue_packet_decode(&r, n, dnd, sub_ch, rs, s->codebooks, vecs);
+			if (rrc) {
+				free(vecs);
+				free(residue);
+				free(fls);
+				return rrc == -2 ? LWO_REF_PANIC : LWO_AUDIO_BAD_FORMAT;
+			}
 		}
 		for (j = 0; j < ch; j++) {
 			if (map->mux[j] == i) {

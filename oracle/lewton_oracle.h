@@ -44,7 +44,10 @@ enum {
 	LWO_HDR_BAD_TYPE = 20,
 	LWO_HDR_IS_AUDIO = 21,
 	LWO_HDR_UTF8 = 22,
-	LWO_HDR_BUFFER_NOT_ADDRESSABLE = 23
+	LWO_HDR_BUFFER_NOT_ADDRESSABLE = 23,
+	/* not a lewton result: the reference PANICS on this input (out-of-range index, division by zero).  A decoder behind a C
+	 * ABI must report an error instead of unwinding or touching memory; tests accept any non-OK status for it. */
+	LWO_REF_PANIC = 64
 };
 
 typedef struct lwo_ident lwo_ident;

@@ -97,6 +97,9 @@ def _f32p(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+REF_PANIC = 64   # LWO_REF_PANIC: the reference panics on this input (no defined result)
+
+
 class OracleError(Exception):
     def __init__(self, code):
         super().__init__("oracle error %d" % code)

@@ -177,3 +177,109 @@ def test_ogg_demultiplexer_under_sanitizers(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "packets" in r.stdout and int(r.stdout.split("packets ")[1].split(",")[0]) > 500
+
+
+# ---- setups the reference's header parser accepts but on which its audio path PANICS (order-0/1 floor 0,
+#      a floor-0 book number equal to the codebook count, zero-dimensional residue books), plus floor-0 amplitude widths
+#      >= 32 where `1 << bits` is an i32 shift.  The oracle reports LWO_REF_PANIC for the panics; the product must return
+#      an error without touching memory outside its buffers (sanitizer run below).
+def _degenerate_setups():
+    out = {}
+    for order in (0, 1):
+        s = sg.floor0_setup()
+        s.floors[0].order = order
+        s.floors[1].order = order
+        out["floor0_order%d" % order] = s
+    s = sg.floor0_setup()
+    s.floors[1].book_list = [s.floors[1].book_list[0], len(s.codebooks)]     # header.rs:793 `>` lets this through
+    out["floor0_book_eq_count"] = s
+    for rtype in (0, 1, 2):
+        s = sg.stereo_setup(residue_type=rtype)
+        zero = sg.Codebook(dims=0, lengths=[2, 2, 2, 2], lookup_type=2, minimum=0.0, delta=1.0, value_bits=4, multiplicands=[])
+        s.codebooks.append(zero)
+        for rs in s.residues:
+            for cls in rs.books:
+                for p in range(len(cls)):
+                    if cls[p] >= 0:
+                        cls[p] = len(s.codebooks) - 1
+                        break
+        out["zero_dim_book_t%d" % rtype] = s
+    for bits in (31, 32, 33, 40, 63):
+        s = sg.floor0_setup()
+        s.floors[1].amplitude_bits = bits
+        out["floor0_ampbits%d" % bits] = s
+    return out
+
+
+def _degenerate_packets(name, setup):
+    """packets of the sane sibling setup (same mode layout) + damaged copies: whatever bits arrive, nothing may crash"""
+    rng = np.random.default_rng(len(name))
+    base = sg.floor0_setup() if name.startswith("floor0") else sg.stereo_setup(residue_type=int(name[-1]))
+    src = setup if "ampbits" in name else base
+    pk = sg.make_stream(src, "LSLLSL", 12, seed=3)
+    return pk + [_mutate(rng, p, int(rng.integers(0, 4))) for p in pk for _ in range(3)]
+
+
+@pytest.mark.parametrize("name", sorted(_degenerate_setups()))
+def test_degenerate_setups_product_vs_oracle(name):
+    setup = _degenerate_setups()[name]
+    idp, _cmt, stp = setup.headers()
+    o_id, o_st = oracle_headers(setup)        # both parsers accept these headers, as the reference does
+    hid = header.read_header_ident(idp)
+    hst = header.read_header_setup(stp, hid.audio_channels, (hid.blocksize_0, hid.blocksize_1))
+    n_panic = n_ok = 0
+    for m in _degenerate_packets(name, setup):
+        try:
+            _out, taps = po.read_audio_packet(o_id, o_st, m, po.Pwr(), "f32", taps=True)
+            want_rc = 0
+        except po.OracleError as e:
+            want_rc = e.code
+        try:
+            got = audio.entropy_decode_host(hid, hst, m)
+            rc = 0
+        except audio.AudioReadError as e:
+            rc = e.code
+        if want_rc == po.REF_PANIC:
+            n_panic += 1
+            assert rc != 0, name
+            continue
+        assert rc == want_rc, (name, rc, want_rc)
+        if rc == 0:
+            n_ok += 1
+            assert np.array_equal(got["residue"].view(np.uint32), taps["residue_pre_inverse"].view(np.uint32))
+            if "ampbits" in name:
+                # host curve x decoupled residue = the oracle's pre-IMDCT spectrum, bit for bit (inf / NaN included)
+                half = (1 << got["bs"]) // 2
+                for c in range(2):
+                    if int(got["floor"][c, 0]) == 0xFFFE:
+                        with np.errstate(all="ignore"):
+                            mine = (got["floor_curve"][c] * taps["residue_post_inverse"][c][:half]).astype(np.float32)
+                        assert np.array_equal(mine.view(np.uint32), taps["pre_mdct"][c][:half].view(np.uint32)), name
+    if "ampbits" in name:
+        assert n_ok > 5 and n_panic == 0
+    elif name.endswith("t0") or "order" in name or "eq_count" in name:
+        assert n_panic > 0, "the case never reached the panicking state"
+
+
+def test_degenerate_setups_under_sanitizers(tmp_path):
+    exe = tmp_path / "host_fuzz"
+    src = os.path.join(ROOT, "tests", "san", "host_fuzz.cpp")
+    csrc = os.path.join(ROOT, "lewton_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", src, os.path.join(csrc, "lw_headers.cpp"), os.path.join(csrc, "lw_entropy.cpp"),
+                           "-o", str(exe)])
+    cases = []
+    for name, setup in sorted(_degenerate_setups().items()):
+        idp, _cmt, stp = setup.headers()
+        cases.append((idp, stp, _degenerate_packets(name, setup)))
+    blob = bytearray(struct.pack("<I", len(cases)))
+    for idp, stp, pks in cases:
+        blob += struct.pack("<I", len(idp)) + idp + struct.pack("<I", len(stp)) + stp + struct.pack("<I", len(pks))
+        for p in pks:
+            blob += struct.pack("<I", len(p)) + p
+    f = tmp_path / "cases.bin"
+    f.write_bytes(bytes(blob))
+    r = subprocess.run([str(exe), str(f)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "setups parsed %d" % len(cases) in r.stdout, r.stdout
