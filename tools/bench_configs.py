@@ -22,7 +22,9 @@ from lewton_amd.batch import Batch  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=400)
 ap.add_argument("--packets", type=int, default=4096)
+ap.add_argument("--only", default="", help="comma-separated config numbers (default: 3,4,5)")
 args = ap.parse_args()
+ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
 NB = 4
 
 
@@ -85,10 +87,38 @@ def run(name, setup, pattern, n_streams, per_stream, note):
     for bt, _ in batches:
         bt.close()
 
+def uncoupled_stereo():
+    """the bench stream without its coupling step: two single-channel units per packet instead of one coupled pair"""
+    st = sg.stereo_setup(44100, 8, 11, residue_type=1)
+    for m in st.mappings:
+        m.coupling = []
+    return st
 
-run("3 mixed short/long", sg.stereo_setup(44100, 8, 11), "LLSSSSSSSSL", 256, args.packets // 256,
-    "256 streams x 16 consecutive packets of the pattern; state carried inside the launch")
-run("4 5.1 @ 48 kHz long blocks", sg.surround51_setup(48000, 8, 11), "L", 256, args.packets // 256,
-    "6 channels = 4 units per packet (2 coupled pairs + 2 single channels)")
-run("5 independent streams, 1 packet per stream per launch", sg.stereo_setup(44100, 8, 11), "L", args.packets, 1,
-    "state read from and written to the HBM state pool by every packet")
+
+def mono():
+    st = sg.stereo_setup(44100, 8, 11, residue_type=1)
+    st.channels = 1
+    st.mappings = [sg.Mapping([], [0], [0], [0]), sg.Mapping([], [0], [1], [1])]
+    return st
+
+
+if "3" in ONLY:
+    run("3 mixed short/long", sg.stereo_setup(44100, 8, 11), "LLSSSSSSSSL", 256, args.packets // 256,
+        "256 streams x 16 consecutive packets of the pattern; state carried inside the launch")
+if "4" in ONLY:
+    run("4 5.1 @ 48 kHz long blocks", sg.surround51_setup(48000, 8, 11), "L", 256, args.packets // 256,
+        "6 channels = 4 units per packet (2 coupled pairs + 2 single channels)")
+if "5" in ONLY:
+    run("5 independent streams, 1 packet per stream per launch", sg.stereo_setup(44100, 8, 11), "L", args.packets, 1,
+        "state read from and written to the HBM state pool by every packet")
+# design probes for k_long (not BASELINE configs): what single-channel waves cost
+if "6" in ONLY:
+    run("6 stereo long blocks WITHOUT coupling", uncoupled_stereo(), "L", 256, args.packets // 256,
+        "two single-channel units per packet: 8 packets per round, 2 rounds per workgroup")
+if "7" in ONLY:
+    run("7 mono long blocks", mono(), "L", 256, args.packets // 256, "one single-channel unit per packet, 1 round")
+if "8" in ONLY:
+    run("8 mono long blocks, 2 x packets", mono(), "L", 256, 2 * args.packets // 256, "single-channel units, 2 rounds")
+if "9" in ONLY:
+    run("9 stereo long blocks, 2 x packets", sg.stereo_setup(44100, 8, 11), "L", 256, 2 * args.packets // 256,
+        "coupled pairs, 2 rounds per workgroup")
