@@ -53,6 +53,8 @@ def main():
                          "(not the BASELINE metric's record format; reported for the k_residue_vq kernel time)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed graph replays after the W warmup steps until the device clocks have settled")
+    ap.add_argument("--gate-us", type=float, default=0.0,
+                    help="length of the spin kernel in front of the timed region (see the comment at ev0); 0 = none")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group also for one process (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--streams", type=int, default=256,
@@ -135,12 +137,15 @@ def main():
     # One hipGraph holding N_BATCHES consecutive steps (launch-bound inner loop -> graph replay); the Python
     # interpreter would otherwise be the bottleneck at ~25 us per launch.
     graph = tail_graph = None
-    n_tail = args.steps % N_BATCHES
+    # K <= 512: ONE graph holds all K steps (one submission for the whole timed region); larger K: a graph of N_BATCHES steps
+    # replayed K // N_BATCHES times plus a tail graph (the submissions after the first hide behind queued work)
+    per_graph = args.steps if args.steps <= 512 else N_BATCHES
+    n_tail = args.steps % per_graph
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for k in range(N_BATCHES):
+            for k in range(per_graph):
                 step(args.warmup + k, cs)
         if n_tail:  # K is not a multiple of the graph length: the remainder is its own graph, not eager launches
             tail_graph = torch.cuda.CUDAGraph()
@@ -156,17 +161,34 @@ def main():
             for _ in range(16):
                 graph.replay()
             torch.cuda.synchronize()
+    # spin kernel in front of the timed region (see below): calibrate torch.cuda._sleep's tick once, aim at --gate-us
+    gate_ticks = 0
+    if graph is not None and hasattr(torch.cuda, "_sleep") and args.gate_us > 0:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        c0.record(stream)
+        torch.cuda._sleep(20000)
+        c1.record(stream)
+        torch.cuda.synchronize()
+        us_per_tick = max(c0.elapsed_time(c1) * 1e3 / 20000, 1e-5)
+        gate_ticks = max(1, int(args.gate_us / us_per_tick))
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    # The HIP-event span below is device time of the K steps: a short spin kernel (~17 us) goes first so that the first graph
+    # is already queued when the first event is reached (otherwise the ~10 us the host needs to submit it sit between ev0
+    # and the first kernel: +0.5 us per step at K = 20).  The wall clock t0..t1 includes the spin instead of that wait.
+    if gate_ticks:
+        torch.cuda._sleep(gate_ticks)
     ev0.record(stream)
     k = 0
     if graph is not None:
-        while k + N_BATCHES <= args.steps:
+        while k + per_graph <= args.steps:
             graph.replay()
-            k += N_BATCHES
+            k += per_graph
         if tail_graph is not None:
             tail_graph.replay()
             k += n_tail

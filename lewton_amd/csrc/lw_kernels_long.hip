@@ -43,9 +43,23 @@
 #ifndef LW_PRIO_FINISH
 #define LW_PRIO_FINISH 3
 #endif
+#ifndef LW_FLOOR_FIRST_FROM
+#define LW_FLOOR_FIRST_FROM 7 // first wave of a workgroup that builds its floor curve before it requests its residues (>= 4)
+#endif
+#ifndef LW_IMDCT_PRIO_LATE
+#define LW_IMDCT_PRIO_LATE 12
+#endif
+#ifndef LW_PRIO_PACE
+#define LW_PRIO_PACE 0 // while a wave waits for its turn in the load queue and requests its residues
+#endif
+#ifndef LW_PRIO_READY
+#define LW_PRIO_READY 3 // inverse coupling + floor multiply of a wave whose floor curve was built ahead
+#endif
 #define LW_SCR_BYTES 4096u // per wave: transposes of one channel at a time / 2 x 1 KB floor segment tables
 #define LW_PUB_BYTES 4096u // per wave: published right half [2 channels][2][64] float4
 #define LW_LDS_BYTES (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES) + 3 * LW_FAST_WAVES * 4)
+
+#include "lw_stamps.inc" // experiment hooks: empty macros unless built with -DLW_STAMPS
 
 struct LwFastArgs {
 	// hot scalars first: everything the first HBM loads depend on sits in the first kernel-argument cache lines
@@ -68,56 +82,6 @@ struct LwFastArgs {
 	uint32_t state_stride, state_chan_stride;
 };
 static_assert(offsetof(LwFastArgs, waves) == 48, "kernel reads waves[] through the kernarg segment pointer");
-
-#ifdef LW_STAMPS
-// Debug build: s_memtime stamps collected in two VGPRs (lane i = stamp i) and stored once at the end of the kernel,
-// so that the instrumentation adds no memory traffic or waits of its own (LW_STAMP_W also drains the wave's loads).
-__device__ unsigned long long *g_lw_stamps = nullptr;
-extern "C" int lw_debug_set_stamp_buffer(void *dptr)
-{
-	return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lw_stamps), &dptr, sizeof(dptr));
-}
-#define LW_STAMP_DECL uint32_t st_lo_ = 0, st_hi_ = 0; unsigned long long *st_buf_ = g_lw_stamps
-#define LW_STAMP_ARGS , uint32_t &st_lo_, uint32_t &st_hi_
-#define LW_STAMP_PASS , st_lo_, st_hi_
-#define LW_STAMP_AT(i, waitstr)                                                                               \
-	do {                                                                                                      \
-		unsigned long long t_;                                                                                \
-		asm volatile(waitstr "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-		if (sj == 0)                                                                                          \
-			asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                 \
-					: "+v"(st_lo_), "+v"(st_hi_) : "s"((uint32_t)t_), "s"((uint32_t)(t_ >> 32)), "n"(i));    \
-		else if (sj == 1)                                                                                     \
-			asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                 \
-					: "+v"(st_lo_), "+v"(st_hi_) : "s"((uint32_t)t_), "s"((uint32_t)(t_ >> 32)), "n"((i) + 16)); \
-		else if (sj == 3)                                                                                     \
-			asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                 \
-					: "+v"(st_lo_), "+v"(st_hi_) : "s"((uint32_t)t_), "s"((uint32_t)(t_ >> 32)), "n"((i) + 48)); \
-	} while (0)
-#define LW_STAMP(i) LW_STAMP_AT(i, "")
-#define LW_STAMP_NW(i) LW_STAMP_AT(i, "")
-#define LW_STAMP_W(i) LW_STAMP_AT(i, "s_waitcnt vmcnt(0)\n\t")
-#define LW_STAMP_FLUSH                                                                                        \
-	do {                                                                                                      \
-		if (st_buf_)                                                                                          \
-			st_buf_[((size_t)blockIdx.x * LW_FAST_WAVES + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63u)] =   \
-				((unsigned long long)st_hi_ << 32) | st_lo_;                                                  \
-	} while (0)
-#else
-#define LW_STAMP_DECL
-#define LW_STAMP_ARGS
-#define LW_STAMP_PASS
-#define LW_STAMP(i)
-#define LW_STAMP_NW(i)
-#define LW_STAMP_W(i)
-#define LW_STAMP_FLUSH
-#endif
-
-#ifdef LW_MARKS
-#define LW_MARK(name) asm volatile("; LWMARK " name)
-#else
-#define LW_MARK(name)
-#endif
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -403,31 +367,42 @@ struct Pref {          // what one wave loads from HBM for one item
 };
 
 
-__device__ __forceinline__ void issue_loads(const LwFastArgs &F, const ItemRegs &it,
-		const LwFastUnit &un, uint32_t lane, Pref &p)
+// The floor posts (58 bytes per channel) are requested BEFORE the residues: loads return in order, so a wave can wait for
+// its floor record alone (s_waitcnt vmcnt(#residue loads)) and build the whole floor curve while the residues are in flight.
+__device__ __forceinline__ void issue_floor_loads(const LwFastArgs &F, const ItemRegs &it, const LwFastUnit &un, uint32_t lane,
+		Pref &p)
 {
-#ifdef LW_EXP_NOLOAD // experiment: no HBM reads (synthetic register contents)
-	for (int c = 0; c < 2; c++)
-		for (int x = 0; x < 4; x++)
-			p.r[c][x] = float4_t{(float)lane, 1.0f, (float)x, 2.0f};
-	p.fe[0] = p.fe[1] = lane == 0 ? (0x8000u | 100u) : (lane == (uint32_t)un.F_a - 1 ? (0x8000u | 90u) : 0u);
-	return;
-#endif
-	const float4_t *s0 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
-#pragma unroll
-	for (int x = 0; x < 4; x++)
-		p.r[0][x] = s0[64 * x + lane];
 	const uint16_t *f0 = F.floors + it.floor_off + (uint32_t)un.ch_a * F.fstride;
 	p.fe[0] = lane < un.F_a ? (uint32_t)f0[lane] : 0u;
 	p.fe[1] = 0u;
 	if (un.ch_b >= 0) {
+		const uint16_t *f1 = F.floors + it.floor_off + (uint32_t)un.ch_b * F.fstride;
+		p.fe[1] = lane < un.F_b ? (uint32_t)f1[lane] : 0u;
+	}
+}
+
+// PAIR: the caller knows that the unit has two channels (every residue register is written: none stays live before the call)
+template <bool PAIR = false>
+__device__ __forceinline__ void issue_residue_loads(const LwFastArgs &F, const ItemRegs &it, const LwFastUnit &un,
+		uint32_t lane, Pref &p)
+{
+	const float4_t *s0 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
+#pragma unroll
+	for (int x = 0; x < 4; x++)
+		p.r[0][x] = s0[64 * x + lane];
+	if (PAIR || un.ch_b >= 0) {
 		const float4_t *s1 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_b * 1024u);
 #pragma unroll
 		for (int x = 0; x < 4; x++)
 			p.r[1][x] = s1[64 * x + lane];
-		const uint16_t *f1 = F.floors + it.floor_off + (uint32_t)un.ch_b * F.fstride;
-		p.fe[1] = lane < un.F_b ? (uint32_t)f1[lane] : 0u;
 	}
+}
+
+// the ordinary order: residues first, the floor records behind them
+__device__ __forceinline__ void issue_loads(const LwFastArgs &F, const ItemRegs &it, const LwFastUnit &un, uint32_t lane, Pref &p)
+{
+	issue_residue_loads(F, it, un, lane, p);
+	issue_floor_loads(F, it, un, lane, p);
 }
 
 // ---- floor segment table of one channel (one 16-byte entry per static interval), built by lanes = posts:
@@ -547,6 +522,53 @@ __device__ __forceinline__ void spectrum_pair(const char *img, const char *sc, u
 #undef LW_SP_M
 }
 
+// ---- floor value per bin (audio.rs:552-554) of one channel: fl[x][j] = floor of bin 4 (64 x + lane) + j
+__device__ __forceinline__ void floor_values(const char *img, const char *sc, uint32_t lane, uint32_t fslot, bool unused,
+		float4_t (&fl)[4])
+{
+	if (unused) {
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+			fl[x] = float4_t{0.0f, 0.0f, 0.0f, 0.0f}; // zero floor (audio.rs:1021-1024)
+		return;
+	}
+	const float kf0 = (float)(4 * (int)lane);
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		const uint2_t sw = *reinterpret_cast<const uint2_t *>(img + LWI_SID16 + 8u * ((fslot * 4 + x) * 64u + lane));
+		const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const float4_t ent = lds4(sc, s16[j]);
+			const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
+			const int q = (int)(z * ent.z);
+			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
+			fl[x][j] = lds_abs_f32(LWI_INV_DB + idx);
+		}
+	}
+}
+
+// ---- the whole floor stage of one unit: segment tables (1 KB each in the wave's scratch) + floor value of every bin this
+//      lane holds.  Needs only the 58-byte floor records, so it runs while the unit's residues are still on their way.
+template <int NCH>
+__device__ __forceinline__ void floor_phase(const LwFastArgs &F, const char *img, char *sc, uint32_t lane, const LwFastUnit &un,
+		const uint32_t (&fe)[2], float4_t (&fl)[2][4])
+{
+	__builtin_amdgcn_s_setprio(LW_PRIO_FLOOR); // latency-bound phase (LDS round trips, few VALU): issue ahead of waves in the IMDCT
+	const bool unused0 = floor_table(F, img, sc, lane, fe[0], un.floor_a, un.F_a);
+	bool unused1 = false;
+	if (NCH == 2)
+		unused1 = floor_table(F, img, sc + 1024, lane, fe[1], un.floor_b, un.F_b);
+	lds_fence();
+	// (no software pipeline across the channels as in spectrum_pair: this runs while the wave would otherwise idle, and the
+	// plain form needs half the registers)
+	floor_values(img, sc, lane, un.floor_a, unused0, fl[0]);
+	if (NCH == 2)
+		floor_values(img, sc + 1024, lane, un.floor_b, unused1, fl[1]);
+	lds_fence();
+	__builtin_amdgcn_s_setprio(0);
+}
+
 // ---- IMDCT step 1 (imdct.rs:337-371) in the load layout, exchange with the mirror lane -> layout B;
 //      step 2 (imdct.rs:385-430) and stages l = 0, 1 (imdct.rs:445-452); twiddles shared by the channels
 template <int NCH>
@@ -588,36 +610,57 @@ __device__ __forceinline__ void stage_b(const LwFastArgs &F, const char *img, ui
 	}
 }
 
-// ---- T2: layout B -> C.  slot(p) = p ^ ((p>>6 & 3) << 3)
-__device__ __forceinline__ void t2_write(char *sc, uint32_t lane, const float2_t (&P)[8])
+// Exchange of one lane bit with one register-index bit for eight (a, b) dword pairs: a' = bit ? b[partner lane] : a,
+// b' = bit ? b : a[partner lane], as v_cndmask_b32_dpp under VCC (2 instructions per pair, every lane of the results written:
+// no copy of the old value as a tied DPP move would need).  VCC = lanes whose bit is CLEAR: the first half keeps a there and
+// takes b from the partner lane elsewhere; the second half (VCC inverted) keeps b on lanes whose bit is set and takes a from
+// the partner lane elsewhere.  b is updated in place, the new a comes back in n.  DA / DB: the DPP controls that fetch from
+// the partner lane for lanes with the bit set / clear.
+#define LW_XCHG_BLOCK(DA, DB, MASK, BC) \
+	asm volatile("s_mov_b32 vcc_lo, " MASK "\n\ts_mov_b32 vcc_hi, " MASK "\n\ts_nop 1\n\t" \
+	             "v_cndmask_b32_dpp %0, %8, %16, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %1, %9, %17, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %2, %10, %18, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %3, %11, %19, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %4, %12, %20, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %5, %13, %21, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %6, %14, %22, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %7, %15, %23, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "s_not_b64 vcc, vcc\n\t" \
+	             "v_cndmask_b32_dpp %8, %16, %8, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %9, %17, %9, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %10, %18, %10, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %11, %19, %11, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %12, %20, %12, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %13, %21, %13, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %14, %22, %14, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
+	             "v_cndmask_b32_dpp %15, %23, %15, vcc " DB " row_mask:0xf bank_mask:0xf" BC \
+	             : "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]), "=&v"(n[7]), \
+	               "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) \
+	             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) \
+	             : "vcc", "scc")
+
+__device__ __forceinline__ void xq_bit3(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 8
 {
-#ifdef LW_EXP_DOUBLE_LDS // experiment: every transpose write twice (same data, same address)
-#pragma unroll
-	for (int x = 0; x < 8; x++) {
-		const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
-		*reinterpret_cast<volatile float2_t *>(sc + 8u * slot) = P[x];
-	}
-#endif
-#pragma unroll
-	for (int x = 0; x < 8; x++) {
-		const uint32_t slot = 64u * x + (lane ^ ((x & 3u) << 3));
-		*reinterpret_cast<float2_t *>(sc + 8u * slot) = P[x];
-	}
+	LW_XCHG_BLOCK("row_ror:8", "row_ror:8", "0x00ff00ff", "");
+}
+// (a lane without a source lane under row_shr / row_shl is one that keeps its own value anyway: bound_ctrl keeps it enabled)
+__device__ __forceinline__ void xq_bit2(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 4
+{
+	LW_XCHG_BLOCK("row_shr:4", "row_shl:4", "0x0f0f0f0f", " bound_ctrl:1");
+}
+__device__ __forceinline__ void xq_bit1(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 2
+{
+	LW_XCHG_BLOCK("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]", "0x33333333", "");
+}
+__device__ __forceinline__ void xq_bit0(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 1
+{
+	LW_XCHG_BLOCK("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]", "0x55555555", "");
 }
 
-__device__ __forceinline__ void t2_read(const char *sc, uint32_t lane, float2_t (&Q)[8])
-{
-	const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
-#pragma unroll
-	for (int y = 0; y < 8; y++) {
-		const uint32_t slot = 64u * X3b + lo3 + 8u * ((uint32_t)y ^ (X3b & 3u));
-		Q[y] = lds2(sc, 8u * slot);
-	}
-}
-
-// ---- T2 without LDS: layout B -> C is an 8 x 8 transpose between the register index (pair bits 8..6) and lane bits 5..3.
-//      Three butterfly exchanges: lane bit 5 by v_permlane32_swap, bit 4 by v_permlane16_swap, bit 3 by DPP row_ror:8 with
-//      bank masks.  40 VALU per channel instead of 8 ds_write_b64 + 8 ds_read_b64: the LDS write data path (one per CU,
+// ---- T2: layout B -> C is an 8 x 8 transpose between the register index (pair bits 8..6) and lane bits 5..3.
+//      Three butterfly exchanges: lane bit 5 by v_permlane32_swap, bit 4 by v_permlane16_swap, bit 3 by v_cndmask_b32_dpp
+//      row_ror:8 under VCC.  32 VALU per channel instead of 8 ds_write_b64 + 8 ds_read_b64: the LDS write data path (one per CU,
 //      ~7.6 cycles per ds_write_b64) is the scarcer resource (tools/exp.sh: doubling the transposes' writes costs 1.85 us).
 __device__ __forceinline__ void t2_inreg(float2_t (&P)[8])
 {
@@ -633,12 +676,6 @@ __device__ __forceinline__ void t2_inreg(float2_t (&P)[8])
 		a = __uint_as_float(r_[0]);                                                           \
 		b = __uint_as_float(r_[1]);                                                           \
 	} while (0)
-#define LW_SWAP8(a, b)                                                                        \
-	do {                                                                                      \
-		const int a_ = __float_as_int(a), b_ = __float_as_int(b);                             \
-		a = __int_as_float(__builtin_amdgcn_update_dpp(a_, b_, 0x128, 0xf, 0xc, false)); /* lanes 8-15 of a row <- b[l ^ 8] */ \
-		b = __int_as_float(__builtin_amdgcn_update_dpp(b_, a_, 0x128, 0xf, 0x3, false)); /* lanes 0-7  of a row <- a[l ^ 8] */ \
-	} while (0)
 #pragma unroll
 	for (int x = 0; x < 4; x++) { // register bit 2 <-> lane bit 5
 		LW_SWAP32(P[x].x, P[x + 4].x);
@@ -650,14 +687,16 @@ __device__ __forceinline__ void t2_inreg(float2_t (&P)[8])
 		LW_SWAP16(P[x].x, P[x + 2].x);
 		LW_SWAP16(P[x].y, P[x + 2].y);
 	}
+	float a[8], b[8], n[8];
 #pragma unroll
-	for (int x = 0; x < 8; x += 2) { // register bit 0 <-> lane bit 3
-		LW_SWAP8(P[x].x, P[x + 1].x);
-		LW_SWAP8(P[x].y, P[x + 1].y);
-	}
+	for (int i = 0; i < 4; i++) // register bit 0 <-> lane bit 3
+		a[2 * i] = P[2 * i].x, a[2 * i + 1] = P[2 * i].y, b[2 * i] = P[2 * i + 1].x, b[2 * i + 1] = P[2 * i + 1].y;
+	xq_bit3(a, b, n);
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+		P[2 * i] = float2_t{n[2 * i], n[2 * i + 1]}, P[2 * i + 1] = float2_t{b[2 * i], b[2 * i + 1]};
 #undef LW_SWAP32
 #undef LW_SWAP16
-#undef LW_SWAP8
 }
 
 // ---- stages l = 2, 3, 4 (imdct.rs:454-477)
@@ -681,88 +720,19 @@ __device__ __forceinline__ void stage_c(const LwFastArgs &F, const char *img, ui
 	}
 }
 
-// ---- T3: layout C -> D.  slot(p) = 8 nu + (z ^ (nu>>2 & 7)), nu = p>>3, z = p&7
-__device__ __forceinline__ void t3_write(char *sc, uint32_t lane, const float2_t (&Q)[8])
-{
-	const uint32_t X3b = lane >> 3, lo3 = lane & 7u;
-#ifdef LW_EXP_DOUBLE_LDS
-#pragma unroll
-	for (int y = 0; y < 8; y++) {
-		const uint32_t nu = 8u * X3b + y;
-		const uint32_t slot = 8u * nu + (lo3 ^ ((nu >> 2) & 7u));
-		*reinterpret_cast<volatile float2_t *>(sc + 8u * slot) = Q[y];
-	}
-#endif
-#pragma unroll
-	for (int y = 0; y < 8; y++) {
-		const uint32_t nu = 8u * X3b + y;
-		const uint32_t slot = 8u * nu + (lo3 ^ ((nu >> 2) & 7u));
-		*reinterpret_cast<float2_t *>(sc + 8u * slot) = Q[y];
-	}
-}
-
-__device__ __forceinline__ void t3_read(const char *sc, uint32_t lane, float2_t (&Z)[8])
-{
-#pragma unroll
-	for (int zz = 0; zz < 8; zz++) { // Z[j] = (u[16 lane + 2j], u[16 lane + 2j + 1])
-		const uint32_t slot = 8u * lane + ((uint32_t)zz ^ ((lane >> 2) & 7u));
-		Z[zz] = lds2(sc, 8u * slot);
-	}
-}
-
-// ---- T3 without LDS: layout C -> D is an 8 x 8 transpose between the register index (pair bits 5..3) and lane bits 2..0.
-//      Lane bit 2: v_mov_dpp row_shr/row_shl:4 with bank masks.  Lane bits 1 and 0: v_cndmask_b32_dpp quad_perm under VCC
-//      (a' = bit ? b[l^m] : a, b' = bit ? b : a[l^m]), 2 instructions per exchanged dword pair.
-#define LW_XQ_BLOCK(QP, MASK) \
-	asm volatile("s_mov_b32 vcc_lo, " MASK "\n\ts_mov_b32 vcc_hi, " MASK "\n\ts_nop 1\n\t" \
-	             "v_cndmask_b32_dpp %0, %8, %16, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %1, %9, %17, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %2, %10, %18, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %3, %11, %19, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %4, %12, %20, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %5, %13, %21, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %6, %14, %22, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %7, %15, %23, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "s_not_b64 vcc, vcc\n\t" \
-	             "v_cndmask_b32_dpp %8, %16, %8, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %9, %17, %9, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %10, %18, %10, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %11, %19, %11, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %12, %20, %12, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %13, %21, %13, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %14, %22, %14, vcc " QP " row_mask:0xf bank_mask:0xf\n\t" \
-	             "v_cndmask_b32_dpp %15, %23, %15, vcc " QP " row_mask:0xf bank_mask:0xf" \
-	             : "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]), "=&v"(n[7]), \
-	               "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) \
-	             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) \
-	             : "vcc", "scc")
-
-// VCC = lanes whose bit is CLEAR: first half keeps a there and takes b[l^m] elsewhere; second half (VCC inverted) keeps b on
-// lanes whose bit is set and takes a[l^m] elsewhere.  b is updated in place, the new a comes back in n.
-__device__ __forceinline__ void xq_bit1(const float (&a)[8], float (&b)[8], float (&n)[8])
-{
-	LW_XQ_BLOCK("quad_perm:[2,3,0,1]", "0x33333333");
-}
-__device__ __forceinline__ void xq_bit0(const float (&a)[8], float (&b)[8], float (&n)[8])
-{
-	LW_XQ_BLOCK("quad_perm:[1,0,3,2]", "0x55555555");
-}
-
+// ---- T3: layout C -> D is an 8 x 8 transpose between the register index (pair bits 5..3) and lane bits 2..0.
+//      Three exchanges by v_cndmask_b32_dpp under VCC (LW_XCHG_BLOCK): lane bit 2 with row_shr / row_shl:4, lane bits 1 and 0
+//      with quad_perm; 2 instructions per exchanged dword pair, 48 VALU per channel.
 __device__ __forceinline__ void t3_inreg(float2_t (&P)[8])
 {
-#define LW_X4(a, b)                                                                           \
-	do {                                                                                      \
-		const int a_ = __float_as_int(a), b_ = __float_as_int(b);                             \
-		a = __int_as_float(__builtin_amdgcn_update_dpp(a_, b_, 0x114, 0xf, 0xa, false)); /* lanes 4-7, 12-15 <- b[l - 4] */ \
-		b = __int_as_float(__builtin_amdgcn_update_dpp(b_, a_, 0x104, 0xf, 0x5, false)); /* lanes 0-3, 8-11  <- a[l + 4] */ \
-	} while (0)
-#pragma unroll
-	for (int y = 0; y < 4; y++) { // register bit 2 <-> lane bit 2
-		LW_X4(P[y].x, P[y + 4].x);
-		LW_X4(P[y].y, P[y + 4].y);
-	}
-#undef LW_X4
 	float a[8], b[8], n[8];
+#pragma unroll
+	for (int y = 0; y < 4; y++) // register bit 2 <-> lane bit 2
+		a[2 * y] = P[y].x, a[2 * y + 1] = P[y].y, b[2 * y] = P[y + 4].x, b[2 * y + 1] = P[y + 4].y;
+	xq_bit2(a, b, n);
+#pragma unroll
+	for (int y = 0; y < 4; y++)
+		P[y] = float2_t{n[2 * y], n[2 * y + 1]}, P[y + 4] = float2_t{b[2 * y], b[2 * y + 1]};
 #pragma unroll
 	for (int i = 0; i < 4; i++) { // register bit 1 <-> lane bit 1
 		const int y = (i & 1) | ((i & 2) << 1);
@@ -781,37 +751,6 @@ __device__ __forceinline__ void t3_inreg(float2_t (&P)[8])
 #pragma unroll
 	for (int i = 0; i < 4; i++)
 		P[2 * i] = float2_t{n[2 * i], n[2 * i + 1]}, P[2 * i + 1] = float2_t{b[2 * i], b[2 * i + 1]};
-}
-
-// ---- fused last three stages (imdct.rs:234-288), lane-local, 28 packed operations per channel
-__device__ __forceinline__ void stage_d(float2_t a2, float2_t (&z)[8])
-{
-	float2_t t0, t1;
-	t0 = pk_add(z[7], z[3]);
-	z[3] = pk_sub(z[7], z[3]);
-	z[7] = t0;
-	t0 = pk_add(z[6], z[2]);
-	t1 = pk_sub(z[6], z[2]);                    // (k11, k00)
-	z[2] = pk_mul(pk_add_A2(t1, t1), a2);       // ((k11-k00) a2, (k00+k11) a2)
-	z[6] = t0;
-	t0 = pk_add(z[5], z[1]);
-	z[1] = pk_add_A3(z[1], z[5]);               // (z3 - z11, z10 - z2)
-	z[5] = t0;
-	t0 = pk_add(z[4], z[0]);
-	t1 = pk_add_A4(z[0], z[4]);                 // (k11, k00)
-	z[0] = pk_mul(pk_add_A5(t1, t1), a2);       // ((k00-k11) a2, (k00+k11) a2)
-	z[4] = t0;
-#pragma unroll
-	for (int b = 4; b >= 0; b -= 4) { // imdct.rs:202-232 on w[0..8) = z[b..b+4)
-		const float2_t A = pk_add(z[b + 3], z[b + 1]);  // (y1, y0)
-		const float2_t Bm = pk_sub(z[b + 3], z[b + 1]); // (k11, k00)
-		const float2_t Cc = pk_add(z[b + 2], z[b]);     // (y3, y2)
-		const float2_t Dm = pk_sub(z[b + 2], z[b]);     // (k33, k22)
-		z[b + 3] = pk_add(A, Cc);
-		z[b + 2] = pk_sub(A, Cc);
-		z[b + 1] = pk_add_A2(Bm, Dm);                   // (k11 - k22, k00 + k33)
-		z[b] = pk_add_A6(Bm, Dm);                       // (k11 + k22, k00 - k33)
-	}
 }
 
 // ---- T4: layout D -> bit-reverse gather.  slot(p) = (p & ~127) | ((p & 3) << 5) | ((p >> 2) & 31)
@@ -894,22 +833,6 @@ __device__ __forceinline__ void stage_b1(const TwB &t, uint32_t lane, const floa
 
 __device__ __forceinline__ void stage_c1(const TwC &t, float2_t (&Q)[8])
 {
-#ifdef LW_EXP_DOUBLE_VALU // experiment: 120 extra packed operations per channel (results discarded through a dead select)
-	{
-		float2_t d0 = Q[0], d1 = Q[1], d2 = Q[2], d3 = Q[3];
-#pragma unroll
-		for (int i = 0; i < 10; i++) {
-			float2_t e0 = Q[4], e1 = Q[5], e2 = Q[6], e3 = Q[7];
-			bfly2x4(d0, e0, t.t4, d1, e1, t.t4, d2, e2, t.t4, d3, e3, t.t4);
-			asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
-			bfly2x4(d0, e0, t.t2[0], d1, e1, t.t2[1], d2, e2, t.t2[2], d3, e3, t.t2[3]);
-			asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
-			bfly2x4(d0, e0, t.t3[0], d1, e1, t.t3[1], d2, e2, t.t3[0], d3, e3, t.t3[1]);
-			asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
-		}
-		asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
-	}
-#endif
 	bfly2x4(Q[4], Q[0], t.t2[0], Q[5], Q[1], t.t2[1], Q[6], Q[2], t.t2[2], Q[7], Q[3], t.t2[3]); // l = 2
 	bfly2x4(Q[2], Q[0], t.t3[0], Q[6], Q[4], t.t3[0], Q[3], Q[1], t.t3[1], Q[7], Q[5], t.t3[1]); // l = 3
 	bfly2x4(Q[1], Q[0], t.t4, Q[3], Q[2], t.t4, Q[5], Q[4], t.t4, Q[7], Q[6], t.t4);             // l = 4
@@ -936,118 +859,65 @@ __device__ __forceinline__ void imdct_pair(const char *img, char *sc, uint32_t l
 		float2_t (&R)[2][2][4])
 {
 	float2_t P0[8], P1[8];
-#ifdef LW_T2_LDS // previous variant: T2 through LDS
-	{
-		TwB tb;
-		load_tw_b(img, lane, tb);
-		stage_b1(tb, lane, r[0], P0);
-		t2_write(sc, lane, P0);
-		__builtin_amdgcn_sched_barrier(0);
-		t2_read(sc, lane, P0);
-		stage_b1(tb, lane, r[1], P1);
-		__builtin_amdgcn_sched_barrier(0);
-	}
-	TwC tc;
-	load_tw_c(img, lane, tc);
-	t2_write(sc, lane, P1);
-	__builtin_amdgcn_sched_barrier(0);
-	t2_read(sc, lane, P1);
-	stage_c1(tc, P0);
-	__builtin_amdgcn_sched_barrier(0);
-#else
 	TwC tc;
 	{
 		TwB tb;
-		LW_MARK("ip_stage_b");
 		load_tw_b(img, lane, tb);
 		stage_b1(tb, lane, r[0], P0);
 		stage_b1(tb, lane, r[1], P1);
 		load_tw_c(img, lane, tc);
-#ifdef LW_MARKS // (region boundaries of tools/isa_regions.py only: the production schedule is free to mix B and T2)
-		__builtin_amdgcn_sched_barrier(0);
-#endif
-		LW_MARK("ip_t2");
 		t2_inreg(P0);
 		t2_inreg(P1);
 		__builtin_amdgcn_sched_barrier(0);
 	}
-	LW_MARK("ip_stage_c");
 	stage_c1(tc, P0);
 	__builtin_amdgcn_sched_barrier(0);
-#endif
 	const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
 	const float2_t a2 = float2_t{a2s, a2s};
-#ifdef LW_T3_LDS
-	t3_write(sc, lane, P0);
-	__builtin_amdgcn_sched_barrier(0);
-	t3_read(sc, lane, P0);
-	stage_c1(tc, P1);
-	__builtin_amdgcn_sched_barrier(0);
-	t3_write(sc, lane, P1);
-	__builtin_amdgcn_sched_barrier(0);
-	t3_read(sc, lane, P1);
-#else
-	LW_MARK("ip_t3_0+c1");
 	t3_inreg(P0);
 	stage_c1(tc, P1);
 	__builtin_amdgcn_sched_barrier(0);
-	LW_MARK("ip_t3_1");
 	t3_inreg(P1);
-#endif
-#ifdef LW_MARKS
-	__builtin_amdgcn_sched_barrier(0);
-#endif
-	LW_MARK("ip_stage_d0");
 	stage_d_block(a2, P0);
 	__builtin_amdgcn_sched_barrier(0);
-	LW_MARK("ip_t4w_0");
 	t4_write(sc, lane, P0);
 	__builtin_amdgcn_sched_barrier(0);
-	LW_MARK("ip_e0+d1");
 	stage_e1(img, sc, lane, R[0]);
 	stage_d_block(a2, P1);
 	__builtin_amdgcn_sched_barrier(0);
-	LW_MARK("ip_t4w_1");
 	t4_write(sc, lane, P1);
 	__builtin_amdgcn_sched_barrier(0);
-	LW_MARK("ip_stage_e1");
 	stage_e1(img, sc, lane, R[1]);
 	__builtin_amdgcn_sched_barrier(0);
-	LW_MARK("ip_end");
 }
 
-// ---- phase 1: everything up to the un-windowed halves (pa, pb) of this packet-unit (wave-private).
-// Both channels of a pair advance through the stages together (shared twiddles); their transposes go through
-// ONE 4 KB buffer one after the other (LDS operations of a wave execute in order).
-template <int NCH>
-__device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img, char *sc, uint32_t lane,
-		const LwFastUnit &un, Pref &pf, float2_t (&R)[2][2][4], uint32_t sj LW_STAMP_ARGS)
+// ---- inverse coupling (audio.rs:762-777, :990-1002) of a coupled pair on the raw residues
+__device__ __forceinline__ void decouple_pair(Pref &pf)
 {
-	(void)sj;
-#ifndef LW_EXP_NOFLOOR
-#ifndef LW_EXP_NOPRIO
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		float m[4] = {pf.r[0][x].x, pf.r[0][x].y, pf.r[0][x].z, pf.r[0][x].w};
+		float a[4] = {pf.r[1][x].x, pf.r[1][x].y, pf.r[1][x].z, pf.r[1][x].w};
+		decouple4(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
+		pf.r[0][x] = float4_t{m[0], m[1], m[2], m[3]};
+		pf.r[1][x] = float4_t{a[0], a[1], a[2], a[3]};
+	}
+}
+
+// ---- from the landed residues to the spectrum, floor stage included (the path of a wave whose residues were requested
+//      before it had time for the floor stage): segment tables, inverse coupling, floor x residue fused into the gathers
+template <int NCH>
+__device__ __forceinline__ void spectrum_fused(const LwFastArgs &F, const char *img, char *sc, uint32_t lane,
+		const LwFastUnit &un, Pref &pf)
+{
 	__builtin_amdgcn_s_setprio(LW_PRIO_FLOOR); // latency-bound phase (LDS round trips, few VALU): issue ahead of waves in the IMDCT
-#endif
-	LW_MARK("floor_table");
-	// ---- floor segment tables (1 KB each)
 	const bool unused0 = floor_table(F, img, sc, lane, pf.fe[0], un.floor_a, un.F_a);
 	bool unused1 = false;
 	if (NCH == 2)
 		unused1 = floor_table(F, img, sc + 1024, lane, pf.fe[1], un.floor_b, un.F_b);
 	lds_fence();
-	LW_MARK("decouple");
-	// ---- inverse coupling (audio.rs:762-777, :990-1002) on the raw residues
-	if (NCH == 2 && un.coupled) {
-#pragma unroll
-		for (int x = 0; x < 4; x++) {
-			float m[4] = {pf.r[0][x].x, pf.r[0][x].y, pf.r[0][x].z, pf.r[0][x].w};
-			float a[4] = {pf.r[1][x].x, pf.r[1][x].y, pf.r[1][x].z, pf.r[1][x].w};
-			decouple4(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
-			pf.r[0][x] = float4_t{m[0], m[1], m[2], m[3]};
-			pf.r[1][x] = float4_t{a[0], a[1], a[2], a[3]};
-		}
-	}
-	LW_MARK("spectrum");
+	if (NCH == 2 && un.coupled)
+		decouple_pair(pf);
 	if (NCH == 2 && !unused0 && !unused1) {
 		spectrum_pair(img, sc, lane, un.floor_a, un.floor_b, pf.r);
 	} else {
@@ -1056,47 +926,50 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 			spectrum(F, img, sc + 1024, lane, un.floor_b, unused1, pf.r[1]);
 	}
 	lds_fence();
-#endif
-#ifndef LW_EXP_NOPRIO
-#ifdef LW_EXP_GROUP_PRIO // experiment: later pacing groups (most work left) run the IMDCT at higher priority
-	{
-		const uint32_t g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-		if (g == 0) __builtin_amdgcn_s_setprio(0);
-		else if (g == 1) __builtin_amdgcn_s_setprio(LW_EXP_GROUP_PRIO >= 2 ? 1 : 0);
-		else if (g == 2) __builtin_amdgcn_s_setprio(LW_EXP_GROUP_PRIO >= 2 ? 2 : 1);
-		else __builtin_amdgcn_s_setprio(LW_EXP_GROUP_PRIO >= 2 ? 3 : 1);
-	}
-#else
-	__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT);
-#endif
-#endif
-	LW_STAMP(4);
+}
+
+// ---- the same with the floor values already in registers (floor_phase ran while the residues were in flight):
+//      inverse coupling and one multiply per bin (audio.rs:1035-1037)
+__device__ __forceinline__ void spectrum_ready(const LwFastUnit &un, Pref &pf, const float4_t (&fl)[2][4])
+{
+	if (un.coupled)
+		decouple_pair(pf);
+#pragma unroll
+	for (int c = 0; c < 2; c++)
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+			const float2_t lo2 = pk_mul(float2_t{fl[c][x].x, fl[c][x].y}, float2_t{pf.r[c][x].x, pf.r[c][x].y});
+			const float2_t hi2 = pk_mul(float2_t{fl[c][x].z, fl[c][x].w}, float2_t{pf.r[c][x].z, pf.r[c][x].w});
+			pf.r[c][x] = float4_t{lo2.x, lo2.y, hi2.x, hi2.y};
+		}
+}
+
+// ---- IMDCT of the unit's spectrum up to the un-windowed halves (pa, pb) (wave-private).  Both channels of a pair advance
+// through the stages together (shared twiddles); their transposes go through ONE 4 KB buffer one after the other (LDS
+// operations of a wave execute in order).
+template <int NCH>
+__device__ __forceinline__ void long_imdct(const LwFastArgs &F, const char *img, char *sc, uint32_t lane, Pref &pf,
+		float2_t (&R)[2][2][4])
+{
+	// the last waves to get their data (the launch ends when they do) run the IMDCT one priority level up
+	if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= LW_IMDCT_PRIO_LATE)
+		__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT + 1);
+	else
+		__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT);
 	if (NCH == 2) {
 		imdct_pair(img, sc, lane, pf.r, R);
-		LW_STAMP(8);
 		return;
 	}
-	LW_MARK("stage_b");
 	float2_t P[2][8];
 	stage_b<NCH>(F, img, lane, pf.r, P);
-	LW_STAMP(5);
-	LW_MARK("t2");
-#ifndef LW_EXP_NOTRANSPOSE
 #pragma unroll
 	for (int c = 0; c < NCH; c++) // T2
 		t2_inreg(P[c]);
-#endif
-	LW_MARK("stage_c");
 	stage_c<NCH>(F, img, lane, P);
-	LW_STAMP(6);
-	LW_MARK("t3");
-#ifndef LW_EXP_NOTRANSPOSE
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T3
 		t3_inreg(P[c]);
 	}
-#endif
-	LW_MARK("stage_d");
 	{
 		const float a2s = *reinterpret_cast<const float *>(img + LWI_A2);
 		const float2_t a2 = float2_t{a2s, a2s};
@@ -1104,8 +977,6 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		for (int c = 0; c < NCH; c++)
 			stage_d_block(a2, P[c]);
 	}
-	LW_STAMP(7);
-	LW_MARK("t4_stage_e");
 #pragma unroll
 	for (int c = 0; c < NCH; c++) { // T4 + layout E
 		t4_write(sc, lane, P[c]);
@@ -1120,8 +991,6 @@ __device__ __forceinline__ void long_phase1(const LwFastArgs &F, const char *img
 		}
 		lds_fence();
 	}
-	LW_STAMP(8);
-	LW_MARK("phase1_end");
 }
 
 // ---- publish the un-windowed right half for the successor ([channel][c2][lane] float4)
@@ -1171,23 +1040,15 @@ __device__ __forceinline__ void prev_from_global(const float *g, uint32_t lane, 
 // staying dirty until the end-of-kernel write-back (16.8 MB of dirty PCM cost ~2.7 us at every kernel boundary)
 __device__ __forceinline__ void store_pcm8(void *p, uint32_t lo, uint32_t hi)
 {
-#ifdef LW_EXP_PLAIN_STORE
-	*reinterpret_cast<uint2_t *>(p) = uint2_t{lo, hi};
-#else
 	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED,
 			__HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 
 // 16-byte write-through store (f32 PCM, stream state).  Inline asm because the builtin path offers sc1 only up to 8
 // bytes; the trailing s_nop keeps hipcc from overwriting the data registers before the store has read them.
 __device__ __forceinline__ void store16_wt(void *p, float4_t v)
 {
-#ifdef LW_EXP_PLAIN_STORE
-	*reinterpret_cast<float4_t *>(p) = v;
-#else
 	asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#endif
 }
 
 // kernel-internal output format: LW_OUT_I16_INTERLEAVED of a 2-channel stream whose channels form ONE unit (a coupled pair)
@@ -1254,11 +1115,7 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 	}
 	// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [508-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
 	//            [512+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [1020-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
-#ifdef LW_EXP_ASCENDING_STORES // experiment (wrong sample positions): every store ascends with the lane id
-	const uint32_t p0 = 4u * lane, p1 = 256u + 4u * lane, p2 = 512u + 4u * lane, p3 = 768u + 4u * lane;
-#else
 	const uint32_t p0 = 4u * lane, p1 = 508u - 4u * lane, p2 = 512u + 4u * lane, p3 = 1020u - 4u * lane;
-#endif
 	if (FMT == LW_OUT_F32_PLANAR) {
 		float *o = reinterpret_cast<float *>(F.out) + out_off + (uint32_t)chn * 1024u;
 		store16_wt(o + p0, float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x});
@@ -1283,11 +1140,6 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 				uint32_t u;
 			} a, b;
 			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn * 1024u;
-#ifdef LW_EXP_NOSTORE // experiment: keep the conversion, drop the HBM writes (never-true runtime condition)
-			if (F.n_items != 0xFFFFFFFFu)
-				o = nullptr;
-			if (o)
-#endif
 			{
 			a.s = __builtin_amdgcn_cvt_pk_i16(iq[0][3], iq[0][2]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(iq[1][3], iq[1][2]);
@@ -1415,35 +1267,26 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const uint32_t lane_id = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint32_t sj = 0;
-	(void)sj;
 	LW_STAMP_DECL;
-	LW_STAMP_NW(0);
+	LW_STAMP(0);
 	const uint32_t n_units = F.n_units, per_round = F.per_round, rounds = F.rounds;
-	// pull every scalar the first HBM loads depend on into SGPRs with ONE batch of kernel-argument loads (the compiler
-	// would otherwise load them one by one, each behind its own s_waitcnt, on the critical path to the first load)
-	asm volatile("" ::"s"(F.residue), "s"(F.floors), "s"(F.n_items), "s"(n_units), "s"(per_round), "s"(rounds), "s"(F.dense),
-			"s"(F.late_from), "s"(F.ch), "s"(F.fstride), "s"(F.image));
-	LW_STAMP_NW(12);
-	// this wave's unit and packet slot: one 8-byte scalar load from the kernel-argument segment
+	// this wave's unit and packet slot: one 8-byte scalar load from the kernel-argument segment, requested together with ...
 	LwFastUnit un;
 #if defined(__HIP_DEVICE_COMPILE__)
-	{
-		typedef const unsigned long long __attribute__((address_space(4))) *ka_ptr;
-		const unsigned long long w = ((ka_ptr)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(LwFastArgs, waves) / 8 + wave];
-		__builtin_memcpy(&un, &w, 8);
-	}
+	typedef const unsigned long long __attribute__((address_space(4))) *ka_ptr;
+	const unsigned long long unit_word = ((ka_ptr)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(LwFastArgs, waves) / 8 + wave];
 #else
-	un = F.waves[0];
+	const unsigned long long unit_word = 0;
 #endif
+	// ... every scalar the first HBM loads depend on: ONE batch of kernel-argument loads behind one wait (the compiler
+	// would otherwise load them one by one, each behind its own s_waitcnt, on the critical path to the first load)
+	asm volatile("" ::"s"(F.residue), "s"(F.floors), "s"(F.n_items), "s"(n_units), "s"(per_round), "s"(rounds), "s"(F.dense),
+			"s"(F.late_from), "s"(F.ch), "s"(F.fstride), "s"(F.image), "s"(unit_word));
+	__builtin_memcpy(&un, &unit_word, 8);
 	const uint32_t slot = un.slot, uidx = wave - slot * n_units; // packet slot of the round, unit of the packet
 	const bool active = slot < per_round;
 	const uint32_t item0 = blockIdx.x * per_round * rounds + slot;      // item of round j = item0 + j * per_round
-#ifdef LW_EXP_STEREO_ONLY // instruction-count experiments: only the two-channel path is compiled
-	const bool two = true;
-#else
 	const bool two = un.ch_b >= 0;
-#endif
 	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
 #ifndef LW_PRE_WAVES
 #define LW_PRE_WAVES 2 // waves that queue their HBM loads before the barrier (waves 0-3 can: the others stage the image);
@@ -1451,15 +1294,11 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
                        // (18.0) or half-way through (17.17) the own loads is slower than after them
 #endif
 	const bool late = !RIGHT_ONLY && wave >= (F.late_from > LW_PRE_WAVES ? F.late_from : (uint32_t)LW_PRE_WAVES);
-	LW_STAMP_NW(13);
 
 	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
 	ItemRegs it{};
 	Pref pf{};
 	bool valid = active && item0 < F.n_items;
-#ifdef LW_EXP_ACTIVE_WAVES // experiment: only the first K waves of every workgroup work
-	valid = valid && wave < LW_EXP_ACTIVE_WAVES;
-#endif
 	if (valid) {
 		if (F.dense)
 			dense_offsets(F, item0, it);
@@ -1470,11 +1309,11 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	// 2 per thread, no tail) and clear the hand-over counters.  A wave that waits for image data therefore never has
 	// residue loads in flight (s_waitcnt vmcnt counts in order), and the first group's loads are issued ~1 us after launch.
 	static_assert(LWI_TOTAL / 16 == 2 * (LW_WG - 256), "image staging: 12 waves x 2 x 16 bytes per thread");
+	static_assert(LW_FLOOR_FIRST_FROM >= 4, "floor-first waves request their floor records after staging the image");
+	const bool floor_first = late && two && F.late_from < LW_FAST_WAVES && wave >= LW_FLOOR_FIRST_FROM;
 	if (wave < 4) {
-		LW_STAMP_NW(14);
 		if (valid && !late)
 			issue_loads(F, it, un, lane_id, pf);
-		LW_STAMP_NW(15);
 	} else {
 		const uint32_t t = threadIdx.x - 256u;
 		const uint4 *src = reinterpret_cast<const uint4 *>(F.image) + t;
@@ -1484,57 +1323,89 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 			lds_store_u32(LW_CNT_BASE + 4u * t, 0u);
 		dst[0] = v0;
 		dst[LW_WG - 256] = v1;
-		LW_STAMP_NW(1);
 		lds_fence();
 		if (valid && !late)
 			issue_loads(F, it, un, lane_id, pf);
+		// a floor-first wave (below) asks for its floor records now, 58 bytes per channel: behind the image data it just
+		// waited for (loads return in order), ahead of every residue it will request
+		if (valid && floor_first)
+			issue_floor_loads(F, it, un, lane_id, pf);
 	}
 	__syncthreads();
-	LW_STAMP_NW(2);
-	if (!RIGHT_ONLY && F.late_from < LW_FAST_WAVES) {
-		// Order the HBM queue: wave w issues its loads when wave w - late_from has issued its own (LW_PACE_VMCNT = 63) or
-		// has all but LW_PACE_VMCNT of them back.  Requests of one CU are served in issue order, so the data arrives
-		// wave by wave instead of all at the end of the burst: the first waves compute while the later waves' data is
-		// still in flight (issue order, one wave at a time, measured best: 18.7 us vs 27 us unpaced).
-#ifdef LW_PACE_SLEEP // variant: fixed delays instead of the flag chain (wave w sleeps w * LW_PACE_SLEEP * 64 cycles)
-		if (late) {
-			for (uint32_t i = 0; i < wave; i++)
-				__builtin_amdgcn_s_sleep(LW_PACE_SLEEP);
-			if (valid)
-				issue_loads(F, it, un, lane_id, pf);
-		}
-	}
-#else
-		if (late) {
-			lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
-			LW_STAMP_NW(14);
-			if (valid)
-				issue_loads(F, it, un, lane_id, pf);
-			LW_STAMP_NW(15);
-		}
-		if (wave + F.late_from < LW_FAST_WAVES) {
-#ifndef LW_PACE_VMCNT
-#define LW_PACE_VMCNT 63
-#endif
-			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW_PACE_VMCNT) : "memory");
-			lds_store_u32(LW_CNT_LANDED(wave), 1u);
-		}
-	}
-#endif
-	if (valid && F.dense)
-		it = load_item(F.items, item0); // the rest of the item is only needed in phase 2
 	const char *img = smem;
+	LW_STAMP(2);
 	char *sc = smem + LWI_TOTAL + wave * LW_SCR_BYTES;
 	char *pub0 = smem + LWI_TOTAL + LW_FAST_WAVES * LW_SCR_BYTES; // [wave][LW_PUB_BYTES]
 	char *pub = pub0 + wave * LW_PUB_BYTES;
+	// A wave far enough back in the load queue builds its floor curve NOW, before its turn to request residues comes (the
+	// queue advances by one wave per ~0.6 us; the floor stage is ~1.8 us of LDS round trips with the VALU mostly idle):
+	// when its residues land, only inverse coupling, one multiply per bin and the IMDCT are left.  The first waves of the
+	// queue request their residues first (the queue must not wait for them) and build the curve afterwards.
+#ifndef LW_PACE_VMCNT
+#define LW_PACE_VMCNT 63
+#endif
+	// Order the HBM queue: wave w issues its loads when wave w - late_from has issued its own (LW_PACE_VMCNT = 63) or
+	// has all but LW_PACE_VMCNT of them back.  Requests of one CU are served in issue order, so the data arrives
+	// wave by wave instead of all at the end of the burst: the first waves compute while the later waves' data is
+	// still in flight (issue order, one wave at a time, measured best: 18.7 us vs 27 us unpaced).
+	const bool paced = !RIGHT_ONLY && F.late_from < LW_FAST_WAVES;
+	// ---- round 0 up to the spectrum (floor x residue) in the residue registers
+	// (the lane id is laundered, as in the loop below: with its known bits visible hipcc turns every `4 lane + const` of the
+	// floor stage into an integer OR plus a conversion, two instructions per bin instead of one addition)
+	uint32_t lane0 = lane_id;
+	asm volatile("" : "+v"(lane0));
+	if (valid && floor_first) {
+		// (one block, so that no residue register is live during the floor stage and no floor register after it)
+		float4_t fl[2][4]; // floor value of every bin this lane holds
+		floor_phase<2>(F, img, sc, lane0, un, pf.fe, fl);
+		LW_STAMP(1);
+		__builtin_amdgcn_s_setprio(LW_PRIO_PACE);
+		lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
+		issue_residue_loads<true>(F, it, un, lane_id, pf);
+		LW_STAMP(15);
+		if (wave + F.late_from < LW_FAST_WAVES) {
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW_PACE_VMCNT) : "memory");
+			lds_store_u32(LW_CNT_LANDED(wave), 1u);
+		}
+		if (F.dense)
+			it = load_item(F.items, item0); // the rest of the item (phase 2); its latency hides behind the residues'
+		__builtin_amdgcn_s_setprio(LW_PRIO_READY);
+		LW_STAMP_W(3);
+		spectrum_ready(un, pf, fl);
+		__builtin_amdgcn_s_setprio(0);
+		LW_STAMP(4);
+	} else {
+		if (paced) {
+			__builtin_amdgcn_s_setprio(LW_PRIO_PACE);
+			if (late) {
+				lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
+				if (valid)
+					issue_loads(F, it, un, lane_id, pf);
+			}
+			LW_STAMP(15);
+			if (wave + F.late_from < LW_FAST_WAVES) {
+				asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW_PACE_VMCNT) : "memory");
+				lds_store_u32(LW_CNT_LANDED(wave), 1u);
+			}
+			__builtin_amdgcn_s_setprio(0);
+		}
+		if (valid && F.dense)
+			it = load_item(F.items, item0); // the rest of the item (phase 2); its latency hides behind the residues'
+		LW_STAMP_W(3);
+		if (valid) {
+			if (two)
+				spectrum_fused<2>(F, img, sc, lane0, un, pf);
+			else
+				spectrum_fused<1>(F, img, sc, lane0, un, pf);
+		}
+		LW_STAMP(4);
+	}
 	uint32_t n_pub_used = 0; // hand-overs published by this wave (only those a successor reads are published)
 	uint32_t n_got = 0;      // hand-overs consumed from the predecessor wave
 	// predecessor waves: same round (slot > 0) / previous round (slot == 0)
 	const uint32_t wprev = slot != 0 ? wave - n_units : (per_round - 1) * n_units + uidx;
 
-	LW_MARK("loop");
 	for (uint32_t j = 0; j < rounds; j++) {
-		sj = j;
 		// launder the lane id once per round: everything derived from it (LDS addresses, bin numbers as floats) is
 		// recomputed where it is used instead of being hoisted out of the loop and kept in registers
 		uint32_t lane = lane_id;
@@ -1546,19 +1417,12 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 		if (valid_n && !F.dense)
 			itn = load_item(F.items, item_n);
 		if (valid) {
-			LW_STAMP_W(3);
-#ifdef LW_EXP_NOCOMPUTE // experiment: no arithmetic, only the HBM traffic
-			for (int c = 0; c < 2; c++)
-				for (int c2 = 0; c2 < 2; c2++)
-					for (int k = 0; k < 4; k++)
-						R[c][c2][k] = float2_t{pf.r[c][2 * c2 + (k >> 1)][2 * (k & 1)], pf.r[c][2 * c2 + (k >> 1)][2 * (k & 1) + 1]} *
-							__uint_as_float(pf.fe[c] + 0x3f800000u);
-#else
 			if (two)
-				long_phase1<2>(F, img, sc, lane, un, pf, R, j LW_STAMP_PASS);
+				long_imdct<2>(F, img, sc, lane, pf, R);
 			else
-				long_phase1<1>(F, img, sc, lane, un, pf, R, j LW_STAMP_PASS);
-#endif
+				long_imdct<1>(F, img, sc, lane, pf, R);
+			if (j == 0)
+				LW_STAMP(8);
 		}
 		if (valid) {
 			if (RIGHT_ONLY) {
@@ -1570,10 +1434,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
 					}
 			} else {
-#ifndef LW_EXP_NOPRIO
 				__builtin_amdgcn_s_setprio(LW_PRIO_FINISH); // finish: hand-over, overlap-add, stores
-#endif
-				LW_MARK("publish");
 				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
 				if (it.flags & LW_IF_NEXT_LDS) {
 					lds_wait_ge(LW_CNT_ACK(wave), n_pub_used);
@@ -1585,7 +1446,6 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 					n_pub_used++;
 					lds_store_u32(LW_CNT_PUB(wave), n_pub_used);
 				}
-				LW_MARK("phase2");
 				// ---- the previous packet's right half: from my predecessor wave through LDS, or (chunk starts) from the
 				//      stream's state slot / the halo buffer / a generic predecessor's time-domain block; then window,
 				//      overlap-add, conversion and stores, one channel at a time (register pressure)
@@ -1608,7 +1468,8 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						g = F.td + (size_t)it.src_arg + 1024u;
 						cstride = 2048u;
 					}
-					LW_STAMP_NW(9);
+					if (j == 0)
+						LW_STAMP(9);
 					if (FMT == LW_OUT_I16_ITL_STEREO) {
 						// 2-channel stream decoded as one channel pair: both channels of a sample position leave in one 16-byte store
 						uint32_t D[2][4][2];
@@ -1642,7 +1503,6 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						lds_store_u32(LW_CNT_ACK(wprev), n_got);
 					}
 				}
-				LW_MARK("state_out");
 				// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
 				const bool to_state = it.state_out >= 0, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
 				if (to_state || to_td) {
@@ -1663,11 +1523,9 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 				}
 			}
 		}
-#ifndef LW_EXP_NOPRIO
+		if (j == 0)
+			LW_STAMP(10);
 		__builtin_amdgcn_s_setprio(0);
-#endif
-		LW_MARK("round_end");
-		LW_STAMP_NW(10);
 		// ---- HBM loads of the next round
 		if (valid_n) {
 			if (F.dense) {
@@ -1677,11 +1535,16 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 			} else {
 				issue_loads(F, itn, un, lane, pf);
 			}
+			// ... and its spectrum (waits for them; the stage sits here, not at the top of the loop, so that round 0 can
+			// enter the loop with its spectrum already built on either of the two paths above)
+			if (two)
+				spectrum_fused<2>(F, img, sc, lane, un, pf);
+			else
+				spectrum_fused<1>(F, img, sc, lane, un, pf);
 		}
 		it = itn;
 		valid = valid_n;
 	}
-	sj = 3;
 	LW_STAMP_W(11);
 	LW_STAMP_FLUSH;
 }
@@ -1704,7 +1567,7 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 	F.n_units = L.n_units;
 	F.halo = L.d_halo;
 	F.out = out;
-	const size_t lds = LW_LDS_BYTES;
+	const size_t lds = LW_LDS_BYTES + LW_STAMP_LDS_EXTRA;
 	for (uint32_t w = 0; w < LW_FAST_WAVES; w++) {
 		F.waves[w] = L.units[w % L.n_units];
 		F.waves[w].slot = (uint8_t)(w / L.n_units);

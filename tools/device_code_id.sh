@@ -1,7 +1,7 @@
 #!/bin/bash
 # Identity of the device code in lewton_amd/_lib/*.hip.o: sha256 of the gfx950 disassembly of each translation unit
 # (the code objects themselves also embed source paths).  Host-side changes must leave these unchanged; compare with
-# profiles/r01_device_code.sha256, the build the round's GPU tests, bench line and rocprof summaries were taken on.
+# profiles/r02_device_code.sha256, the build the round's GPU tests, bench line and rocprof summaries were taken on.
 #   usage: tools/device_code_id.sh [objdir]
 D=${1:-lewton_amd/_lib}
 B=/opt/rocm/lib/llvm/bin

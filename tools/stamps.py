@@ -16,7 +16,7 @@ from lewton_amd.batch import Batch  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 NP = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-NSTAMP = 64
+NSTAMP = 16
 setup = sg.stereo_setup(44100, 8, 11)
 idp, _, stp = setup.headers()
 ident = header.read_header_ident(idp)
@@ -59,36 +59,25 @@ for rep in range(6):
     if rep < 2:
         continue
     print("rep %d: kernel(event) %.1f us, waves stamped %d" % (rep, ms * 1e3, len(a)))
-    names = [(0, "entry"), (12, "kernargs in SGPRs"), (13, "unit loaded"), (14, "before issue_loads"), (15, "after issue_loads"), (1, "image loads issued"), (2, "image+sync"), (3, "r0 residue landed"), (4, "r0 floor+spec"),
-             (5, "r0 stage B"), (6, "r0 stage C"), (7, "r0 stage D"), (8, "r0 stage E"), (9, "r0 handover done"), (10, "r0 phase2 issued"),
-             (19, "r1 residue landed"), (20, "r1 floor+spec"), (21, "r1 stage B"), (22, "r1 stage C"), (23, "r1 stage D"),
-             (24, "r1 stage E"), (25, "r1 handover"), (26, "r1 phase2 issued"), (59, "all stores done")]
+    names = [(0, "entry"), (2, "image+sync"), (1, "floor-first: floor done"), (15, "residue loads issued"), (3, "residue landed"),
+             (4, "spectrum done"), (8, "IMDCT done"), (9, "hand-over done"), (10, "finish issued"), (11, "all stores done")]
     # s_memtime counters are not synchronised across the chip: reference every wave to the earliest entry of its
     # own workgroup (all its waves run on one CU)
     full = buf.cpu().numpy().reshape(-1, 16, NSTAMP)   # [block][wave][stamp]
     ent = np.where(full[:, :, 0] != 0, full[:, :, 0], np.iinfo(np.int64).max).min(axis=1)
     absd = full - ent[:, None, None]
     ok = full[:, :, 0] != 0
-    for i, nm in names:
-        if full[:, :, i].max() == 0:
-            continue
-        m = ok & (full[:, :, i] != 0)
-        col = absd[:, :, i][m]
-        early = absd[:, :8, i][m[:, :8]]
-        lateh = absd[:, 8:, i][m[:, 8:]]
-        print("  %2d %-20s since WG entry min/med/max %7d %7d %7d | waves0-7 med %7d max %7d | waves8-15 med %7d max %7d" % (
-            i, nm, col.min(), np.median(col), col.max(), np.median(early) if len(early) else -1, early.max() if len(early) else -1,
-            np.median(lateh) if len(lateh) else -1, lateh.max() if len(lateh) else -1))
     if rep == 5:
-        # per-wave timeline (median over workgroups, cycles since WG entry)
-        cols = [c for c in (2, 15, 3, 4, 8, 9, 10, 11) if full[:, :, c].max() != 0]
-        print("  per-wave medians  " + " ".join("%7s" % ("s%d" % c) for c in cols) + " | phase lengths")
+        cols = [i for i, _ in names if full[:, :, i].max() != 0]
+        print("  per-wave medians (cycles since workgroup entry)")
+        print("  wave " + " ".join("%8s" % ("s%d" % c) for c in cols) + " | landed->done")
         for w in range(16):
             if not ok[:, w].any():
                 continue
-            med = [float(np.median(absd[:, w, c][ok[:, w] & (full[:, w, c] != 0)])) if (ok[:, w] & (full[:, w, c] != 0)).any() else float("nan") for c in cols]
-            print("  wave %2d           " % w + " ".join("%7.0f" % m for m in med) + " | " + " ".join("%6.0f" % (med[i + 1] - med[i]) for i in range(len(med) - 1)))
-    if rep == 5:
-        e = full[:, 0, 0]
-        print("entry stamps of wave 0, blocks 0..23:", [int(x) for x in e[:24]])
-        print("end stamps  of wave 0, blocks 0..23:", [int(x) for x in full[:24, 0, 59]])
+            med = {}
+            for c in cols:
+                m = ok[:, w] & (full[:, w, c] != 0)
+                med[c] = float(np.median(absd[:, w, c][m])) if m.any() else float("nan")
+            print("  %4d " % w + " ".join("%8.0f" % med[c] for c in cols) + " | %8.0f" % (med.get(11, float("nan")) - med.get(3, float("nan"))))
+        for i, nm in names:
+            print("  s%-2d = %s" % (i, nm))
