@@ -610,57 +610,53 @@ __device__ __forceinline__ void stage_b(const LwFastArgs &F, const char *img, ui
 	}
 }
 
-// Exchange of one lane bit with one register-index bit for eight (a, b) dword pairs: a' = bit ? b[partner lane] : a,
-// b' = bit ? b : a[partner lane], as v_cndmask_b32_dpp under VCC (2 instructions per pair, every lane of the results written:
-// no copy of the old value as a tied DPP move would need).  VCC = lanes whose bit is CLEAR: the first half keeps a there and
-// takes b from the partner lane elsewhere; the second half (VCC inverted) keeps b on lanes whose bit is set and takes a from
-// the partner lane elsewhere.  b is updated in place, the new a comes back in n.  DA / DB: the DPP controls that fetch from
-// the partner lane for lanes with the bit set / clear.
-#define LW_XCHG_BLOCK(DA, DB, MASK, BC) \
-	asm volatile("s_mov_b32 vcc_lo, " MASK "\n\ts_mov_b32 vcc_hi, " MASK "\n\ts_nop 1\n\t" \
-	             "v_cndmask_b32_dpp %0, %8, %16, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %1, %9, %17, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %2, %10, %18, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %3, %11, %19, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %4, %12, %20, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %5, %13, %21, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %6, %14, %22, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %7, %15, %23, vcc " DA " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "s_not_b64 vcc, vcc\n\t" \
-	             "v_cndmask_b32_dpp %8, %16, %8, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %9, %17, %9, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %10, %18, %10, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %11, %19, %11, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %12, %20, %12, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %13, %21, %13, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %14, %22, %14, vcc " DB " row_mask:0xf bank_mask:0xf" BC "\n\t" \
-	             "v_cndmask_b32_dpp %15, %23, %15, vcc " DB " row_mask:0xf bank_mask:0xf" BC \
-	             : "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]), "=&v"(n[7]), \
-	               "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) \
-	             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) \
-	             : "vcc", "scc")
+// Exchange of one lane bit (1 or 0, i.e. inside a quad) with one register-index bit for eight (a, b) dword pairs:
+// a' = bit ? b[partner lane] : a, b' = bit ? b : a[partner lane].  Per pair: two full-width v_mov_b32_dpp quad_perm into
+// temporaries and two v_cndmask_b32_e64 under an SGPR-pair lane mask (4 x 4.3 cycles per SIMD).  NOT v_cndmask_b32_dpp: a
+// VALU select whose mask is VCC -- the only form the DPP encoding has -- costs 16-23 cycles per instruction on gfx950,
+// against 4.3 for the same select with the mask in an SGPR pair (tools/micro/op_cost.hip, profiles/r02_micro_op_cost.txt).
+// The block works on four pairs at a time (eight temporaries); M = lanes whose bit is SET.
+#define LW_XCHG4(QP, i0)                                                                                      \
+	asm volatile("s_nop 1\n\t"                                                                                \
+	             "v_mov_b32_dpp %8, %4 " QP " row_mask:0xf bank_mask:0xf\n\t"                                  \
+	             "v_mov_b32_dpp %9, %5 " QP " row_mask:0xf bank_mask:0xf\n\t"                                  \
+	             "v_mov_b32_dpp %10, %6 " QP " row_mask:0xf bank_mask:0xf\n\t"                                 \
+	             "v_mov_b32_dpp %11, %7 " QP " row_mask:0xf bank_mask:0xf\n\t"                                 \
+	             "v_mov_b32_dpp %12, %0 " QP " row_mask:0xf bank_mask:0xf\n\t"                                 \
+	             "v_mov_b32_dpp %13, %1 " QP " row_mask:0xf bank_mask:0xf\n\t"                                 \
+	             "v_mov_b32_dpp %14, %2 " QP " row_mask:0xf bank_mask:0xf\n\t"                                 \
+	             "v_mov_b32_dpp %15, %3 " QP " row_mask:0xf bank_mask:0xf\n\t"                                 \
+	             "v_cndmask_b32_e64 %0, %0, %8, %16\n\t"                                                       \
+	             "v_cndmask_b32_e64 %1, %1, %9, %16\n\t"                                                       \
+	             "v_cndmask_b32_e64 %2, %2, %10, %16\n\t"                                                      \
+	             "v_cndmask_b32_e64 %3, %3, %11, %16\n\t"                                                      \
+	             "v_cndmask_b32_e64 %4, %12, %4, %16\n\t"                                                      \
+	             "v_cndmask_b32_e64 %5, %13, %5, %16\n\t"                                                      \
+	             "v_cndmask_b32_e64 %6, %14, %6, %16\n\t"                                                      \
+	             "v_cndmask_b32_e64 %7, %15, %7, %16"                                                           \
+	             : "+v"(a[i0]), "+v"(a[i0 + 1]), "+v"(a[i0 + 2]), "+v"(a[i0 + 3]), "+v"(b[i0]), "+v"(b[i0 + 1]),   \
+	               "+v"(b[i0 + 2]), "+v"(b[i0 + 3]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), \
+	               "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])                                                        \
+	             : "s"(M))
 
-__device__ __forceinline__ void xq_bit3(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 8
+__device__ __forceinline__ void xq_bit1(float (&a)[8], float (&b)[8]) // partner = lane ^ 2
 {
-	LW_XCHG_BLOCK("row_ror:8", "row_ror:8", "0x00ff00ff", "");
+	const unsigned long long M = 0xccccccccccccccccull;
+	float t[8];
+	LW_XCHG4("quad_perm:[2,3,0,1]", 0);
+	LW_XCHG4("quad_perm:[2,3,0,1]", 4);
 }
-// (a lane without a source lane under row_shr / row_shl is one that keeps its own value anyway: bound_ctrl keeps it enabled)
-__device__ __forceinline__ void xq_bit2(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 4
+__device__ __forceinline__ void xq_bit0(float (&a)[8], float (&b)[8]) // partner = lane ^ 1
 {
-	LW_XCHG_BLOCK("row_shr:4", "row_shl:4", "0x0f0f0f0f", " bound_ctrl:1");
-}
-__device__ __forceinline__ void xq_bit1(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 2
-{
-	LW_XCHG_BLOCK("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]", "0x33333333", "");
-}
-__device__ __forceinline__ void xq_bit0(const float (&a)[8], float (&b)[8], float (&n)[8]) // partner = lane ^ 1
-{
-	LW_XCHG_BLOCK("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]", "0x55555555", "");
+	const unsigned long long M = 0xaaaaaaaaaaaaaaaaull;
+	float t[8];
+	LW_XCHG4("quad_perm:[1,0,3,2]", 0);
+	LW_XCHG4("quad_perm:[1,0,3,2]", 4);
 }
 
 // ---- T2: layout B -> C is an 8 x 8 transpose between the register index (pair bits 8..6) and lane bits 5..3.
-//      Three butterfly exchanges: lane bit 5 by v_permlane32_swap, bit 4 by v_permlane16_swap, bit 3 by v_cndmask_b32_dpp
-//      row_ror:8 under VCC.  32 VALU per channel instead of 8 ds_write_b64 + 8 ds_read_b64: the LDS write data path (one per CU,
+//      Three butterfly exchanges: lane bit 5 by v_permlane32_swap, bit 4 by v_permlane16_swap, bit 3 by DPP row_ror:8 with
+//      bank masks.  40 VALU per channel instead of 8 ds_write_b64 + 8 ds_read_b64: the LDS write data path (one per CU,
 //      ~7.6 cycles per ds_write_b64) is the scarcer resource (tools/exp.sh: doubling the transposes' writes costs 1.85 us).
 __device__ __forceinline__ void t2_inreg(float2_t (&P)[8])
 {
@@ -676,6 +672,12 @@ __device__ __forceinline__ void t2_inreg(float2_t (&P)[8])
 		a = __uint_as_float(r_[0]);                                                           \
 		b = __uint_as_float(r_[1]);                                                           \
 	} while (0)
+#define LW_SWAP8(a, b)                                                                        \
+	do {                                                                                      \
+		const int a_ = __float_as_int(a), b_ = __float_as_int(b);                             \
+		a = __int_as_float(__builtin_amdgcn_update_dpp(a_, b_, 0x128, 0xf, 0xc, false)); /* lanes 8-15 of a row <- b[l ^ 8] */ \
+		b = __int_as_float(__builtin_amdgcn_update_dpp(b_, a_, 0x128, 0xf, 0x3, false)); /* lanes 0-7  of a row <- a[l ^ 8] */ \
+	} while (0)
 #pragma unroll
 	for (int x = 0; x < 4; x++) { // register bit 2 <-> lane bit 5
 		LW_SWAP32(P[x].x, P[x + 4].x);
@@ -687,16 +689,14 @@ __device__ __forceinline__ void t2_inreg(float2_t (&P)[8])
 		LW_SWAP16(P[x].x, P[x + 2].x);
 		LW_SWAP16(P[x].y, P[x + 2].y);
 	}
-	float a[8], b[8], n[8];
 #pragma unroll
-	for (int i = 0; i < 4; i++) // register bit 0 <-> lane bit 3
-		a[2 * i] = P[2 * i].x, a[2 * i + 1] = P[2 * i].y, b[2 * i] = P[2 * i + 1].x, b[2 * i + 1] = P[2 * i + 1].y;
-	xq_bit3(a, b, n);
-#pragma unroll
-	for (int i = 0; i < 4; i++)
-		P[2 * i] = float2_t{n[2 * i], n[2 * i + 1]}, P[2 * i + 1] = float2_t{b[2 * i], b[2 * i + 1]};
+	for (int x = 0; x < 8; x += 2) { // register bit 0 <-> lane bit 3 (tied DPP moves under bank masks + one copy per pair)
+		LW_SWAP8(P[x].x, P[x + 1].x);
+		LW_SWAP8(P[x].y, P[x + 1].y);
+	}
 #undef LW_SWAP32
 #undef LW_SWAP16
+#undef LW_SWAP8
 }
 
 // ---- stages l = 2, 3, 4 (imdct.rs:454-477)
@@ -721,36 +721,41 @@ __device__ __forceinline__ void stage_c(const LwFastArgs &F, const char *img, ui
 }
 
 // ---- T3: layout C -> D is an 8 x 8 transpose between the register index (pair bits 5..3) and lane bits 2..0.
-//      Three exchanges by v_cndmask_b32_dpp under VCC (LW_XCHG_BLOCK): lane bit 2 with row_shr / row_shl:4, lane bits 1 and 0
-//      with quad_perm; 2 instructions per exchanged dword pair, 48 VALU per channel.
+//      Lane bit 2: v_mov_b32_dpp row_shr / row_shl:4 with bank masks (tied: one copy per pair).  Lane bits 1 and 0 (inside a
+//      quad, where bank masks cannot select): LW_XCHG4, 4 instructions per exchanged dword pair.
 __device__ __forceinline__ void t3_inreg(float2_t (&P)[8])
 {
-	float a[8], b[8], n[8];
+#define LW_X4(a, b)                                                                           \
+	do {                                                                                      \
+		const int a_ = __float_as_int(a), b_ = __float_as_int(b);                             \
+		a = __int_as_float(__builtin_amdgcn_update_dpp(a_, b_, 0x114, 0xf, 0xa, false)); /* lanes 4-7, 12-15 <- b[l - 4] */ \
+		b = __int_as_float(__builtin_amdgcn_update_dpp(b_, a_, 0x104, 0xf, 0x5, false)); /* lanes 0-3, 8-11  <- a[l + 4] */ \
+	} while (0)
 #pragma unroll
-	for (int y = 0; y < 4; y++) // register bit 2 <-> lane bit 2
-		a[2 * y] = P[y].x, a[2 * y + 1] = P[y].y, b[2 * y] = P[y + 4].x, b[2 * y + 1] = P[y + 4].y;
-	xq_bit2(a, b, n);
-#pragma unroll
-	for (int y = 0; y < 4; y++)
-		P[y] = float2_t{n[2 * y], n[2 * y + 1]}, P[y + 4] = float2_t{b[2 * y], b[2 * y + 1]};
+	for (int y = 0; y < 4; y++) { // register bit 2 <-> lane bit 2
+		LW_X4(P[y].x, P[y + 4].x);
+		LW_X4(P[y].y, P[y + 4].y);
+	}
+#undef LW_X4
+	float a[8], b[8];
 #pragma unroll
 	for (int i = 0; i < 4; i++) { // register bit 1 <-> lane bit 1
 		const int y = (i & 1) | ((i & 2) << 1);
 		a[2 * i] = P[y].x, a[2 * i + 1] = P[y].y, b[2 * i] = P[y + 2].x, b[2 * i + 1] = P[y + 2].y;
 	}
-	xq_bit1(a, b, n);
+	xq_bit1(a, b);
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
 		const int y = (i & 1) | ((i & 2) << 1);
-		P[y] = float2_t{n[2 * i], n[2 * i + 1]}, P[y + 2] = float2_t{b[2 * i], b[2 * i + 1]};
+		P[y] = float2_t{a[2 * i], a[2 * i + 1]}, P[y + 2] = float2_t{b[2 * i], b[2 * i + 1]};
 	}
 #pragma unroll
 	for (int i = 0; i < 4; i++) // register bit 0 <-> lane bit 0
 		a[2 * i] = P[2 * i].x, a[2 * i + 1] = P[2 * i].y, b[2 * i] = P[2 * i + 1].x, b[2 * i + 1] = P[2 * i + 1].y;
-	xq_bit0(a, b, n);
+	xq_bit0(a, b);
 #pragma unroll
 	for (int i = 0; i < 4; i++)
-		P[2 * i] = float2_t{n[2 * i], n[2 * i + 1]}, P[2 * i + 1] = float2_t{b[2 * i], b[2 * i + 1]};
+		P[2 * i] = float2_t{a[2 * i], a[2 * i + 1]}, P[2 * i + 1] = float2_t{b[2 * i], b[2 * i + 1]};
 }
 
 // ---- T4: layout D -> bit-reverse gather.  slot(p) = (p & ~127) | ((p & 3) << 5) | ((p >> 2) & 31)
