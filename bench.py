@@ -53,6 +53,10 @@ def main():
                          "(not the BASELINE metric's record format; reported for the k_residue_vq kernel time)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed graph replays after the W warmup steps until the device clocks have settled")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end object (staging-ring rate incl. PCIe)")
+    ap.add_argument("--e2e-batches", type=int, default=32)
+    ap.add_argument("--e2e-threads", type=int, nargs="+", default=[32, 64],
+                    help="host thread counts tried for the end-to-end rate (the best is reported)")
     ap.add_argument("--gate-us", type=float, default=0.0,
                     help="length of the spin kernel in front of the timed region (see the comment at ev0); 0 = none")
     ap.add_argument("--force-dist", action="store_true",
@@ -278,6 +282,28 @@ def main():
             except Exception as e:  # informational only
                 cpu["all_cores"] = {"error": repr(e)}
 
+    # ---- end-to-end rate through the library's staging ring (informational; never `value`): host entropy stage on this
+    #      box's cores -> pinned staging -> H2D -> kernels -> D2H, entropy decode of batch N+1 overlapping the GPU work of N
+    e2e_obj = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        try:
+            from lewton_amd import e2e as e2e_mod
+            best = None
+            for thr in args.e2e_threads:
+                r_ = e2e_mod.measure(dec, pool, n_batches=args.e2e_batches, packets=PACKETS_PER_BATCH, streams=S, threads=thr,
+                                     slots=3, device_vq=False, callers=1, samples=args.format)
+                if best is None or r_["value"] > best["value"]:
+                    best = r_
+            e2e_obj = best
+            try:   # the same with Tier B records (codeword symbols over PCIe, inverse VQ on the device)
+                r_ = e2e_mod.measure(dec, pool, n_batches=args.e2e_batches, packets=PACKETS_PER_BATCH, streams=S,
+                                     threads=best["host_threads"], slots=3, device_vq=True, callers=1, samples=args.format)
+                e2e_obj["tier_b"] = {k: r_[k] for k in ("value", "unit", "records", "d2h_GBps", "host_entropy_stage_alone", "kernels")}
+            except Exception as e:
+                e2e_obj["tier_b"] = {"error": repr(e)}
+        except Exception as e:
+            e2e_obj = {"error": repr(e)}
+
     # HBM traffic of one launch from the PMC passes (tools/pmc.sh -> profiles/): measured in separate rocprofv3 runs of
     # this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; null if no profile is committed
     traffic, pmc_file = None, "none"
@@ -318,6 +344,7 @@ def main():
                          "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/%s)" % os.path.basename(pmc_file),
                          "kernel": kernels, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
+            "end_to_end": e2e_obj,
         }
         print(json.dumps(line))
     if dist.is_initialized():

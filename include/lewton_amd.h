@@ -197,6 +197,47 @@ int lw_batch_set_residue_on_device(lw_batch *b, int on);
 /* names of the kernels the last lw_batch_synth used, comma separated (introspection for tests/bench) */
 const char *lw_batch_last_kernels(const lw_batch *b);
 
+/* ---- staging ring (BASELINE north_star: "pinned hipMemcpyAsync staging ring so entropy decode of packet N+1 overlaps
+ * GPU synthesis of packet N") ------------------------------------------------------------------------------------------
+ * A ring of `slots` staging slots on the decoder's device; a slot = one batch object (pinned records + device mirror), a device
+ * PCM buffer, a pinned host PCM buffer, a HIP stream.  Slots are used first-in first-out:
+ *   lw_ring_stage    host entropy stage of `n` packets into the next free slot (what lw_batch_entropy does);
+ *                    LW_ERR_CAPACITY when every slot is in flight (collect + release first) or n > max_packets
+ *   lw_ring_launch   queues, for the oldest staged slot and without waiting: H2D of its records, the synthesis kernels
+ *                    (ordered behind the previous launch's kernels: consecutive batches may carry the same streams'
+ *                    window state) and D2H of the PCM into the slot's pinned buffer
+ *   lw_ring_submit   = stage + launch: returns while the GPU works, so the next submit's entropy decode overlaps it
+ *   lw_ring_collect  waits for the oldest launched slot; results / PCM stay valid until lw_ring_release
+ *   lw_ring_release  frees that slot
+ *   lw_ring_drain    waits for everything in flight and frees all slots (their results are dropped)
+ * stage may run on another thread than launch / collect / release (one thread each).  Every PreviousWindowRight sees its
+ * packets in submission order.  The reference has no counterpart (it decodes one packet per call, audio.rs:919); callers
+ * that want its call-by-call semantics use lw_read_audio_packet or the Ogg stream layer below, which runs on this ring. */
+typedef struct lw_ring lw_ring;
+lw_ring *lw_ring_create(lw_decoder *d, size_t slots, size_t max_packets, int fmt, int *err);
+void lw_ring_destroy(lw_ring *r);
+int lw_ring_stage(lw_ring *r, const lw_packet *pkts, size_t n, int n_threads);
+int lw_ring_launch(lw_ring *r);
+int lw_ring_submit(lw_ring *r, const lw_packet *pkts, size_t n, int n_threads);
+int lw_ring_collect(lw_ring *r, const lw_packet_result **results, size_t *n, const void **pcm, size_t *pcm_elems);
+int lw_ring_release(lw_ring *r);
+int lw_ring_drain(lw_ring *r);
+size_t lw_ring_slots(const lw_ring *r);
+size_t lw_ring_in_flight(lw_ring *r); /* slots staged, launched or collected and not yet released */
+int lw_ring_set_residue_on_device(lw_ring *r, int on); /* lw_batch_set_residue_on_device for every slot (ring must be idle) */
+const char *lw_ring_last_kernels(const lw_ring *r);
+/* The host half of a PreviousWindowRight (whether a right part is stored, its length, which of the two device buffers
+ * holds it).  lw_batch_entropy / lw_ring_stage advance it when they plan a batch; a caller that drops a staged batch (or
+ * one launched batch: a launch writes the OTHER device buffer) restores the state it saved before staging. */
+typedef struct {
+	uint8_t present, parity;
+	uint32_t len;
+} lw_pwr_state;
+void lw_pwr_get_state(const lw_pwr *p, lw_pwr_state *out);
+void lw_pwr_set_state(lw_pwr *p, const lw_pwr_state *in);
+int lw_decoder_device(const lw_decoder *d);
+size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * blocksize_1 / 2: the largest block a packet yields */
+
 /* ---- Ogg container either side of the path ---------------------------- */
 /* lewton reads Ogg through the external crate `ogg` 0.8.0 (Cargo.lock; `PacketReader`, `Packet`) and wraps it
  * in src/inside_ogg.rs.  The functions below replace both: a page/packet demultiplexer after RFC 3533 with the

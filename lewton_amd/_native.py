@@ -37,6 +37,10 @@ class PacketResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_samples", C.c_uint32), ("out_offset", C.c_uint64)]
 
 
+class PwrState(C.Structure):
+    _fields_ = [("present", C.c_uint8), ("parity", C.c_uint8), ("len", C.c_uint32)]
+
+
 class OggPacket(C.Structure):
     _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("stream_serial", C.c_uint32), ("absgp_page", C.c_uint64),
                 ("first_in_stream", C.c_uint8), ("last_in_stream", C.c_uint8), ("first_in_page", C.c_uint8),
@@ -111,6 +115,22 @@ SYMBOLS = {
     "lw_batch_last_kernels": (C.c_char_p, [C.c_void_p]),
     "lw_decoder_supports_device_vq": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
     "lw_batch_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "lw_ring_create": (C.c_void_p, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, intp]),
+    "lw_ring_destroy": (None, [C.c_void_p]),
+    "lw_ring_stage": (C.c_int, [C.c_void_p, C.POINTER(Packet), C.c_size_t, C.c_int]),
+    "lw_ring_launch": (C.c_int, [C.c_void_p]),
+    "lw_ring_submit": (C.c_int, [C.c_void_p, C.POINTER(Packet), C.c_size_t, C.c_int]),
+    "lw_ring_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(PacketResult)), szp, C.POINTER(C.c_void_p), szp]),
+    "lw_ring_release": (C.c_int, [C.c_void_p]),
+    "lw_ring_drain": (C.c_int, [C.c_void_p]),
+    "lw_ring_slots": (C.c_size_t, [C.c_void_p]),
+    "lw_ring_in_flight": (C.c_size_t, [C.c_void_p]),
+    "lw_ring_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "lw_ring_last_kernels": (C.c_char_p, [C.c_void_p]),
+    "lw_pwr_get_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
+    "lw_pwr_set_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
+    "lw_decoder_device": (C.c_int, [C.c_void_p]),
+    "lw_decoder_max_block_elems": (C.c_size_t, [C.c_void_p]),
     "lw_ogg_reader_open_memory": (C.c_void_p, [C.c_char_p, C.c_size_t, C.c_int]),
     "lw_ogg_reader_open_file": (C.c_void_p, [C.c_char_p, intp]),
     "lw_ogg_reader_open_io": (C.c_void_p, [C.POINTER(OggIo)]),

@@ -10,6 +10,7 @@
 #include "lw_fast.hpp"
 #include "lw_host.hpp"
 #include "lw_kernels.hpp"
+#include "lw_pool.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -25,6 +26,8 @@
 #include <vector>
 
 #define LW_ERR_UNSUPPORTED_STREAM LW_AUDIO_BAD_FORMAT
+// packets a worker claims at a time: small enough that 64 threads share a 4096-packet batch evenly to the end
+#define LW_ENTROPY_CHUNK 4
 
 namespace {
 
@@ -46,105 +49,6 @@ bool hip_ok(hipError_t e, const char *what)
 	} while (0)
 
 extern const float kInverseDbTable[256];
-
-// ---- persistent worker threads of the host entropy stage ----------------------------------------
-// lw_batch_entropy runs a fraction of a millisecond per 4096-packet batch on a many-core host; creating and joining
-// 32-64 threads for every batch cost a fifth of that, and waking 63 sleepers through one condition variable (each
-// re-acquiring the mutex in turn) is of the same order.  The pool grows on demand, its threads live until the process
-// exits, and between regions they spin on the region counter for a short while (batches arrive back to back) before
-// they go to sleep on the condition variable.
-// packets a worker claims at a time: small enough that 64 threads share a 4096-packet batch evenly to the end
-#define LW_ENTROPY_CHUNK 4
-
-class EntropyPool {
-public:
-	static constexpr unsigned MAX_THREADS = 1024;
-	// runs fn() on `n` threads in total (the caller is one of them) and returns when all have finished
-	void run(unsigned n, const std::function<void()> &fn)
-	{
-		n = std::min(n, MAX_THREADS);
-		if (n <= 1) {
-			fn();
-			return;
-		}
-		std::unique_lock<std::mutex> serial(serial_); // one parallel region at a time
-		const uint64_t epoch = (state_.load() >> 16) + 1;
-		{
-			std::unique_lock<std::mutex> g(mu_);
-			while (threads_.size() < n - 1)
-				threads_.emplace_back([this, id = threads_.size(), epoch]() { loop(id, epoch - 1); });
-		}
-		fn_ = &fn;
-		pending_.store(n - 1);
-		state_.store((epoch << 16) | (n - 1)); // region number and its helper count in one word (seq_cst, see loop())
-		if (sleepers_.load() > 0) {
-			{ std::unique_lock<std::mutex> g(mu_); } // a worker between its predicate check and its wait holds mu_
-			cv_.notify_all();
-		}
-		fn();
-		for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) {
-			if (spins < 4096)
-				cpu_relax();
-			else
-				std::this_thread::yield();
-		}
-	}
-
-private:
-	static void cpu_relax()
-	{
-#if defined(__x86_64__) || defined(__i386__)
-		__builtin_ia32_pause();
-#else
-		std::this_thread::yield();
-#endif
-	}
-	void loop(size_t id, uint64_t seen)
-	{
-		for (;;) {
-			// wait for the next region: spin for ~100 us (batches arrive back to back), then sleep
-			uint64_t st = 0;
-			bool got = false;
-			const auto t0 = std::chrono::steady_clock::now();
-			for (unsigned spins = 0;; spins++) {
-				st = state_.load(std::memory_order_acquire);
-				if ((st >> 16) != seen) {
-					got = true;
-					break;
-				}
-				if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100))
-					break;
-				cpu_relax();
-			}
-			if (!got) {
-				std::unique_lock<std::mutex> g(mu_);
-				sleepers_.fetch_add(1);
-				cv_.wait(g, [&]() { return ((st = state_.load()) >> 16) != seen; });
-				sleepers_.fetch_sub(1);
-			}
-			seen = st >> 16;
-			// helpers of region `seen` are the threads with id < (st & 0xffff): run() keeps fn_ unchanged until all of them
-			// have counted down; any other thread must not look at fn_ (the region may be over already)
-			if (id < (st & 0xffffu)) {
-				(*fn_)();
-				pending_.fetch_sub(1, std::memory_order_acq_rel);
-			}
-		}
-	}
-	std::mutex mu_, serial_;
-	std::condition_variable cv_;
-	std::vector<std::thread> threads_;
-	const std::function<void()> *fn_ = nullptr;
-	std::atomic<size_t> pending_{0};
-	std::atomic<uint64_t> state_{0}; // (region number << 16) | helpers of that region
-	std::atomic<unsigned> sleepers_{0};
-};
-
-EntropyPool &entropy_pool()
-{
-	static EntropyPool *p = new EntropyPool(); // never destroyed: its threads are detached from process teardown
-	return *p;
-}
 
 } // namespace
 
@@ -842,6 +746,16 @@ void lw_decoder_destroy(lw_decoder *d)
 	delete d;
 }
 
+int lw_decoder_device(const lw_decoder *d)
+{
+	return d ? d->device : -1;
+}
+
+size_t lw_decoder_max_block_elems(const lw_decoder *d)
+{
+	return d ? (size_t)d->T.ch * d->T.state_chan_stride : 0;
+}
+
 // ---- PreviousWindowRight ----------------------------------------------------------------------
 lw_pwr *lw_pwr_new(lw_decoder *d)
 {
@@ -875,6 +789,24 @@ void lw_pwr_reset(lw_pwr *p)
 size_t lw_pwr_len(const lw_pwr *p)
 {
 	return (p && p->present) ? p->len : 0;
+}
+
+void lw_pwr_get_state(const lw_pwr *p, lw_pwr_state *out)
+{
+	if (!p || !out)
+		return;
+	out->present = p->present ? 1 : 0;
+	out->parity = p->parity;
+	out->len = p->len;
+}
+
+void lw_pwr_set_state(lw_pwr *p, const lw_pwr_state *in)
+{
+	if (!p || !in)
+		return;
+	p->present = in->present != 0;
+	p->parity = in->parity & 1;
+	p->len = in->len;
 }
 
 lw_pwr *lw_pwr_clone(const lw_pwr *p)
@@ -1168,7 +1100,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			}
 		}
 	};
-	entropy_pool().run(nt, worker);
+	lw::entropy_pool().run(nt, worker);
 	if (b->symbols) {
 		const size_t total = pool_used.load();
 		if (overflow) {
