@@ -236,7 +236,7 @@ typedef struct {
 void lw_pwr_get_state(const lw_pwr *p, lw_pwr_state *out);
 void lw_pwr_set_state(lw_pwr *p, const lw_pwr_state *in);
 int lw_decoder_device(const lw_decoder *d);
-size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * blocksize_1 / 2: the largest block a packet yields */
+size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0) / 4: the largest block a packet yields */
 
 /* ---- Ogg container either side of the path ---------------------------- */
 /* lewton reads Ogg through the external crate `ogg` 0.8.0 (Cargo.lock; `PacketReader`, `Packet`) and wraps it

@@ -5,11 +5,14 @@
 #include "../../include/lewton_amd.h"
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -407,9 +410,34 @@ struct lw_ogg_stream {
 	lw_setup *setup = nullptr;
 	lw_decoder *dec = nullptr; // created at the first decode
 	lw_pwr *pwr = nullptr;
-	lw_batch *batch = nullptr; // look-ahead queue
-	size_t batch_cap = 0;
-	int batch_fmt = -1;
+	// look-ahead pipeline (lw_ogg_stream_read_dec_packets): a producer thread demultiplexes and entropy-decodes up to
+	// pipe_k packets at a time into the staging ring while the caller's thread launches, collects and delivers earlier
+	// batches; see "look-ahead pipeline" below
+	lw_ring *ring = nullptr;
+	size_t ring_cap = 0;
+	int ring_fmt = -1;
+	bool pipe_active = false;
+	int pipe_fmt = -1, pipe_threads = 0;
+	size_t pipe_k = 0;
+	struct PipeSlot {
+		std::vector<QueuedPacket> ahead;
+		lw_pwr_state saved{};   // host half of the PreviousWindowRight before this batch was staged
+		bool launched = false;
+	};
+	enum { TERM_NONE = 0, TERM_CHAIN, TERM_EOF, TERM_ERROR };
+	std::deque<PipeSlot> staged;  // FIFO image of the ring's busy slots (guarded by pmu)
+	int terminal = TERM_NONE, terminal_rc = LW_OK; // why the producer stopped reading (guarded by pmu)
+	bool p_stop = false, p_done = false;
+	std::thread producer;
+	std::mutex pmu;
+	std::condition_variable pcv;
+	// packets (and one-shot container errors) that were read ahead and handed back by a roll-back: consumed before the
+	// demultiplexer is asked again
+	struct Requeued {
+		QueuedPacket q;
+		int rc = LW_OK; // != LW_OK: this container error occurs at this point of the sequence
+	};
+	std::deque<Requeued> requeue;
 	uint32_t serial = 0;
 	uint32_t link = 0; // logical streams entered so far minus one
 	bool has_absgp = false;
@@ -421,14 +449,14 @@ struct lw_ogg_stream {
 	bool has_retry = false;
 	QueuedPacket retry;
 	std::vector<uint8_t> scratch;
-	std::vector<QueuedPacket> ahead;
-	int deferred = LW_OK; // container error met by the look-ahead queue behind packets it still had to deliver
 
 	void drop_context()
 	{
-		if (batch)
-			lw_batch_destroy(batch);
-		batch = nullptr;
+		rollback();
+		if (ring)
+			lw_ring_destroy(ring);
+		ring = nullptr;
+		ring_cap = 0;
 		if (pwr)
 			lw_pwr_free(pwr);
 		pwr = nullptr;
@@ -554,6 +582,21 @@ struct lw_ogg_stream {
 		return lw_read_audio_packet(dec, q.data.data(), q.data.size(), pwr, LW_FMT_I16_PLANAR, scratch.data(), cap, &m);
 	}
 
+	// next packet of the physical stream: what a roll-back of the look-ahead pipeline handed back first, then the
+	// demultiplexer.  LW_OK + q, LW_OGG_EOF, or an OggReadError code.
+	int next_raw(QueuedPacket &q)
+	{
+		if (!requeue.empty()) {
+			Requeued r = std::move(requeue.front());
+			requeue.pop_front();
+			if (r.rc != LW_OK)
+				return r.rc;
+			q = std::move(r.q);
+			return LW_OK;
+		}
+		return rdr->next_owned(q);
+	}
+
 	// read_next_audio_packet, inside_ogg.rs:114-160.  LW_OK + q, LW_OGG_EOF, or an error.
 	int next_audio(QueuedPacket &q)
 	{
@@ -562,26 +605,21 @@ struct lw_ogg_stream {
 			has_retry = false;
 			return LW_OK;
 		}
-		if (has_pending) {
-			q = std::move(pending);
-			has_pending = false;
-			if (q.serial == serial)
-				return LW_OK;
-			return chain(q);
-		}
 		for (;;) {
-			lw_ogg_packet k;
-			const int rc = lw_ogg_read_packet(rdr, &k);
-			if (rc != LW_OK)
-				return rc;
-			if (k.stream_serial == serial) {
-				take(k, q);
-				return LW_OK;
-			}
-			if (k.first_in_stream) {
-				take(k, q);
+			if (has_pending && requeue.empty()) { // (what was handed back by a roll-back precedes the pending packet)
+				q = std::move(pending);
+				has_pending = false;
+				if (q.serial == serial)
+					return LW_OK;
 				return chain(q);
 			}
+			const int rc = next_raw(q);
+			if (rc != LW_OK)
+				return rc;
+			if (q.serial == serial)
+				return LW_OK;
+			if (q.first_in_stream)
+				return chain(q);
 			// every packet with a mismatching stream serial is ignored
 		}
 	}
@@ -616,6 +654,157 @@ struct lw_ogg_stream {
 			return rc;
 		take(k, q); // returned as is, whatever its serial (the reference does the same)
 		return LW_OK;
+	}
+
+	// ---- look-ahead pipeline ----------------------------------------------------------------------------------
+	// Three batches are in the pipeline at a time (ring of three slots): the producer thread demultiplexes and
+	// entropy-decodes batch k+2 (lw_ring_stage) while the GPU works on batch k+1 (launched by the caller's thread as soon
+	// as batch k has come back) and the caller's thread copies batch k out of pinned memory.  The producer only reads
+	// packets of the current logical stream and stops in front of a chain boundary, at the end of the file and at a
+	// container error, exactly where the sequential code stopped.  Everything lewton's API can do between two batched
+	// calls (read_dec_packet, skip_samples_linear, seek_absgp_pg, into_inner) first ROLLS the pipeline BACK: the producer
+	// is stopped, GPU work in flight is waited for and dropped, every packet that was read ahead but not delivered goes
+	// back in front of the demultiplexer, and the PreviousWindowRight returns to its state after the last delivered packet
+	// (its host half was saved before each batch was staged; of the undelivered batches at most ONE was launched, and a
+	// launch writes the other of the state's two device buffers, so the device half is still there).
+	void producer_main()
+	{
+		std::vector<lw_packet> pk;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> g(pmu);
+				pcv.wait(g, [&]() { return p_stop || staged.size() < 3; });
+				if (p_stop)
+					break;
+			}
+			// collect: packets of the current logical stream, stopping in front of a chain boundary (this thread owns the
+			// demultiplexer, `requeue` and `pending` while the pipeline is active)
+			PipeSlot ps;
+			int term = TERM_NONE, term_rc = LW_OK;
+			while (ps.ahead.size() < pipe_k) {
+				QueuedPacket q;
+				if (has_pending && requeue.empty()) {
+					if (pending.serial != serial) {
+						term = TERM_CHAIN;
+						break;
+					}
+					q = std::move(pending);
+					has_pending = false;
+				} else {
+					const int rc = next_raw(q);
+					if (rc == LW_OGG_EOF) {
+						term = TERM_EOF;
+						break;
+					}
+					if (rc != LW_OK) {
+						term = TERM_ERROR;
+						term_rc = rc;
+						break;
+					}
+					if (q.serial != serial) {
+						if (q.first_in_stream) {
+							pending = std::move(q);
+							has_pending = true;
+							term = TERM_CHAIN;
+							break;
+						}
+						continue; // every packet with a mismatching stream serial is ignored
+					}
+				}
+				ps.ahead.push_back(std::move(q));
+			}
+			if (!ps.ahead.empty()) {
+				lw_pwr_get_state(pwr, &ps.saved);
+				pk.resize(ps.ahead.size());
+				for (size_t i = 0; i < pk.size(); i++)
+					pk[i] = lw_packet{ps.ahead[i].data.data(), ps.ahead[i].data.size(), pwr};
+				const int rc = lw_ring_stage(ring, pk.data(), pk.size(), pipe_threads);
+				if (rc != LW_OK) { // (cannot happen for a well-formed call: hand the packets back, report the error)
+					lw_pwr_set_state(pwr, &ps.saved);
+					for (size_t i = ps.ahead.size(); i-- > 0;) {
+						Requeued r;
+						r.q = std::move(ps.ahead[i]);
+						requeue.push_front(std::move(r));
+					}
+					ps.ahead.clear();
+					term = TERM_ERROR;
+					term_rc = rc;
+				}
+			}
+			std::unique_lock<std::mutex> g(pmu);
+			if (!ps.ahead.empty())
+				staged.push_back(std::move(ps));
+			if (term != TERM_NONE) {
+				terminal = term;
+				terminal_rc = term_rc;
+			}
+			pcv.notify_all();
+			if (term != TERM_NONE)
+				break;
+		}
+		std::unique_lock<std::mutex> g(pmu);
+		p_done = true;
+		pcv.notify_all();
+	}
+
+	int pipeline_start(int fmt, size_t k, int n_threads)
+	{
+		if (int rc = ensure_decoder())
+			return rc;
+		if (!ring || ring_cap < k || ring_fmt != fmt) {
+			if (ring)
+				lw_ring_destroy(ring);
+			int e = 0;
+			ring = lw_ring_create(dec, 3, k, fmt, &e);
+			if (!ring)
+				return e ? e : LW_ERR_DEVICE;
+			ring_cap = k;
+			ring_fmt = fmt;
+		}
+		pipe_fmt = fmt;
+		pipe_k = k;
+		pipe_threads = n_threads;
+		terminal = TERM_NONE;
+		terminal_rc = LW_OK;
+		p_stop = p_done = false;
+		pipe_active = true;
+		producer = std::thread([this]() { producer_main(); });
+		return LW_OK;
+	}
+
+	// stop reading ahead and give back everything that was not delivered (see above); no-op when the pipeline is idle
+	void rollback()
+	{
+		if (!pipe_active)
+			return;
+		{
+			std::unique_lock<std::mutex> g(pmu);
+			p_stop = true;
+			pcv.notify_all();
+		}
+		if (producer.joinable())
+			producer.join();
+		(void)lw_ring_drain(ring);
+		if (!staged.empty())
+			lw_pwr_set_state(pwr, &staged.front().saved);
+		std::deque<Requeued> back;
+		for (PipeSlot &ps : staged)
+			for (QueuedPacket &q : ps.ahead) {
+				Requeued r;
+				r.q = std::move(q);
+				back.push_back(std::move(r));
+			}
+		if (terminal == TERM_ERROR) { // met behind the packets above (the demultiplexer is only asked once `requeue` is empty)
+			Requeued r;
+			r.rc = terminal_rc;
+			back.push_back(std::move(r));
+		}
+		for (Requeued &r : requeue)
+			back.push_back(std::move(r));
+		requeue.swap(back);
+		staged.clear();
+		terminal = TERM_NONE;
+		pipe_active = false;
 	}
 
 	static void truncate(int fmt, int ch, void *out, size_t m, size_t target)
@@ -773,7 +962,8 @@ lw_ogg_reader *lw_ogg_stream_into_inner(lw_ogg_stream *s)
 {
 	if (!s)
 		return nullptr;
-	lw_ogg_reader *r = s->rdr;
+	s->rollback();
+	lw_ogg_reader *r = s->rdr; // (packets read ahead are dropped with the stream object, like the reference's queue)
 	s->rdr = nullptr;
 	lw_ogg_stream_close(s);
 	return r;
@@ -798,6 +988,7 @@ int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t c
 {
 	if (!s || !out || !n_samples)
 		return LW_ERR_NULL_ARG;
+	s->rollback();
 	QueuedPacket q;
 	if (int rc = s->next_audio(q))
 		return rc;
@@ -811,92 +1002,81 @@ int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t c
 int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out,
 		size_t cap_elems, uint32_t *n_samples, int32_t *status, size_t *n_packets)
 {
-	if (!s || !out || !n_samples || !status || !n_packets || max_packets == 0)
+	if (!s || !out || !n_samples || !status || !n_packets || max_packets == 0 || fmt < 0 || fmt > 2)
 		return LW_ERR_NULL_ARG;
 	*n_packets = 0;
-	if (s->deferred != LW_OK) {
-		const int rc = s->deferred;
-		s->deferred = LW_OK;
-		return rc;
+	if (s->pipe_active && (s->pipe_fmt != fmt || s->pipe_k != max_packets || s->pipe_threads != n_threads))
+		s->rollback(); // other batch geometry: what was read ahead is staged again under the new one
+	if (!s->pipe_active)
+		if (int rc = s->pipeline_start(fmt, max_packets, n_threads))
+			return rc;
+	// the oldest batch in the pipeline, or the reason why there is none
+	lw_ogg_stream::PipeSlot *ps = nullptr;
+	{
+		std::unique_lock<std::mutex> g(s->pmu);
+		s->pcv.wait(g, [&]() { return !s->staged.empty() || s->p_done; });
+		if (!s->staged.empty())
+			ps = &s->staged.front(); // (deque: stays valid while the producer appends at the back)
 	}
-	// collect: packets of the current logical stream, stopping in front of a chain boundary
-	s->ahead.clear();
-	bool eof = false;
-	while (s->ahead.size() < max_packets) {
-		QueuedPacket q;
-		if (s->has_pending) {
-			if (s->pending.serial != s->serial)
-				break;
-			q = std::move(s->pending);
-			s->has_pending = false;
-		} else {
-			const int rc = s->rdr->next_owned(q);
-			if (rc == LW_OGG_EOF) {
-				eof = true;
-				break;
-			}
-			if (rc != LW_OK) {
-				if (s->ahead.empty())
-					return rc;
-				s->deferred = rc; // deliver what was read, report the error on the next call
-				break;
-			}
-			if (q.serial != s->serial) {
-				if (q.first_in_stream) {
-					s->pending = std::move(q);
-					s->has_pending = true;
-					break;
-				}
-				continue;
-			}
-		}
-		s->ahead.push_back(std::move(q));
+	if (!ps) {
+		const int term = s->terminal, rc = s->terminal_rc;
+		if (s->producer.joinable())
+			s->producer.join();
+		s->terminal = lw_ogg_stream::TERM_NONE;
+		s->pipe_active = false;
+		if (term == lw_ogg_stream::TERM_ERROR)
+			return rc;
+		if (term == lw_ogg_stream::TERM_EOF)
+			return LW_OGG_EOF;
+		return LW_OK; // in front of a chain boundary: *n_packets == 0, lw_ogg_stream_read_dec_packet crosses it
 	}
-	if (s->ahead.empty())
-		return eof ? (int)LW_OGG_EOF : (int)LW_OK;
-	if (int rc = s->ensure_decoder())
-		return rc;
-	if (!s->batch || s->batch_cap < s->ahead.size() || s->batch_fmt != fmt) {
-		if (s->batch)
-			lw_batch_destroy(s->batch);
-		int e = 0;
-		s->batch_cap = std::max(max_packets, s->ahead.size());
-		s->batch_fmt = fmt;
-		s->batch = lw_batch_create(s->dec, s->batch_cap, fmt, &e);
-		if (!s->batch)
-			return e ? e : LW_ERR_DEVICE;
+	if (!ps->launched) {
+		if (int rc = lw_ring_launch(s->ring))
+			return rc;
+		ps->launched = true;
 	}
-	std::vector<lw_packet> pk(s->ahead.size());
-	for (size_t i = 0; i < pk.size(); i++)
-		pk[i] = lw_packet{s->ahead[i].data.data(), s->ahead[i].data.size(), s->pwr};
-	if (int rc = lw_batch_entropy(s->batch, pk.data(), pk.size(), n_threads))
+	const lw_packet_result *res = nullptr;
+	const void *pcm = nullptr;
+	size_t n = 0, total = 0;
+	if (int rc = lw_ring_collect(s->ring, &res, &n, &pcm, &total))
 		return rc;
-	const size_t total = lw_batch_out_elems(s->batch);
 	if (total > cap_elems)
-		return LW_ERR_CAPACITY;
-	if (int rc = lw_batch_upload(s->batch, nullptr))
-		return rc;
-	if (int rc = lw_batch_synth_to_host(s->batch, out, cap_elems, nullptr))
-		return rc;
-	// per packet: truncation of the stream's last packet and granule bookkeeping, then compact the blocks
-	const lw_packet_result *res = lw_batch_results(s->batch);
+		return LW_ERR_CAPACITY; // nothing consumed: the batch stays at the head of the pipeline for a larger buffer
+	// the next batch goes to the GPU now, while this one is copied out (at most one launched batch is ever undelivered)
+	{
+		lw_ogg_stream::PipeSlot *next = nullptr;
+		{
+			std::unique_lock<std::mutex> g(s->pmu);
+			if (s->staged.size() >= 2 && !s->staged[1].launched)
+				next = &s->staged[1];
+		}
+		if (next && lw_ring_launch(s->ring) == LW_OK)
+			next->launched = true;
+	}
+	// per packet: truncation of the stream's last packet and granule bookkeeping, blocks packed back to back
 	lw_ident_info info;
 	lw_ident_get_info(s->ident, &info);
 	const size_t es = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
 	size_t w = 0; // write cursor in elements
-	for (size_t i = 0; i < pk.size(); i++) {
+	for (size_t i = 0; i < n; i++) {
 		status[i] = res[i].status;
-		size_t m = res[i].status == LW_OK ? res[i].n_samples : 0;
-		char *blk = (char *)out + res[i].out_offset * es;
+		size_t m = 0;
+		const size_t full = res[i].status == LW_OK ? (size_t)res[i].n_samples * info.audio_channels : 0;
+		char *dst = (char *)out + w * es;
+		if (full)
+			std::memcpy(dst, (const char *)pcm + res[i].out_offset * es, full * es);
 		if (res[i].status == LW_OK)
-			m = s->account(s->ahead[i], fmt, blk, res[i].n_samples);
+			m = s->account(ps->ahead[i], fmt, dst, res[i].n_samples);
 		n_samples[i] = (uint32_t)m;
-		const size_t elems = m * info.audio_channels;
-		if (elems && (char *)out + w * es != blk)
-			std::memmove((char *)out + w * es, blk, elems * es);
-		w += elems;
+		w += m * info.audio_channels;
 	}
-	*n_packets = pk.size();
+	*n_packets = n;
+	(void)lw_ring_release(s->ring);
+	{
+		std::unique_lock<std::mutex> g(s->pmu);
+		s->staged.pop_front();
+		s->pcv.notify_all();
+	}
 	return LW_OK;
 }
 
@@ -907,6 +1087,7 @@ int lw_ogg_stream_skip_samples_linear(lw_ogg_stream *s, size_t to_skip, int fmt,
 		return LW_ERR_NULL_ARG;
 	*got_packet = 0;
 	*n_samples = 0;
+	s->rollback();
 	bool have_last = false;
 	QueuedPacket last, next;
 	for (;;) {
@@ -951,6 +1132,8 @@ int lw_ogg_stream_seek_absgp_pg(lw_ogg_stream *s, uint64_t absgp)
 {
 	if (!s)
 		return LW_ERR_NULL_ARG;
+	s->rollback();
+	s->requeue.clear(); // everything read ahead is void after a seek
 	s->has_pending = false;
 	s->has_retry = false;
 	if (int rc = lw_ogg_seek_absgp(s->rdr, 0, 0, absgp))

@@ -753,7 +753,12 @@ int lw_decoder_device(const lw_decoder *d)
 
 size_t lw_decoder_max_block_elems(const lw_decoder *d)
 {
-	return d ? (size_t)d->T.ch * d->T.state_chan_stride : 0;
+	// a long block with a long predecessor and a short successor yields the most samples: right_start - left_start =
+	// (3 n1 - n0) / 4 (audio.rs:1056-1073)
+	if (!d)
+		return 0;
+	const size_t n0 = (size_t)1 << d->id->bs0, n1 = (size_t)1 << d->id->bs1;
+	return (size_t)d->T.ch * ((3 * n1 - n0) / 4);
 }
 
 // ---- PreviousWindowRight ----------------------------------------------------------------------

@@ -127,6 +127,78 @@ int main(int argc, char **argv)
 				show(s, n, 0);
 			drain();
 		}
+	} else if (mode == "mix") {
+		// the roll-back paths of the look-ahead pipeline: one batched call of K packets, then `singles` packet-by-packet
+		// calls, a batched call, a skip of `skip` samples, a batched call, optionally a seek, then drain packet by packet.
+		//   argv: K singles skip seek_goal(or -1)
+		const size_t K = (size_t)std::max<unsigned long long>(1, arg);
+		const size_t singles = argc > 4 ? strtoull(argv[4], nullptr, 10) : 2;
+		const size_t skip = argc > 5 ? strtoull(argv[5], nullptr, 10) : 0;
+		const long long goal = argc > 6 ? atoll(argv[6]) : -1;
+		std::vector<uint32_t> ns(K);
+		std::vector<int32_t> st(K);
+		bool stop = false;
+		auto batch = [&]() {
+			size_t np = 0;
+			out.resize(std::max(out.size(), cap_for(s) * K));
+			const int rc = lw_ogg_stream_read_dec_packets(s, LW_FMT_I16_PLANAR, K, 2, out.data(), out.size(), ns.data(), st.data(), &np);
+			if (rc == LW_OGG_EOF) {
+				printf("EOF\n");
+				stop = true;
+				return;
+			}
+			if (rc != LW_OK) {
+				printf("E %d\n", rc);
+				stop = true;
+				return;
+			}
+			for (size_t i = 0; i < np; i++)
+				printf("Q %u %d\n", ns[i], st[i]);
+			show(s, 0, 0);
+		};
+		batch();
+		for (size_t i = 0; i < singles && !stop; i++) {
+			size_t n = 0;
+			int r1;
+			while ((r1 = lw_ogg_stream_read_dec_packet(s, LW_FMT_I16_PLANAR, out.data(), out.size(), &n)) == LW_ERR_CAPACITY)
+				out.resize(cap_for(s) * K);
+			if (r1 == LW_OGG_EOF) {
+				printf("EOF\n");
+				stop = true;
+			} else if (r1 != LW_OK) {
+				printf("E %d\n", r1);
+				stop = true;
+			} else {
+				show(s, n, 0);
+			}
+		}
+		if (!stop)
+			batch();
+		if (!stop && skip) {
+			size_t left = skip, n = 0;
+			int got = 0, rc;
+			while ((rc = lw_ogg_stream_skip_samples_linear(s, left, LW_FMT_I16_PLANAR, out.data(), out.size(), &n, &left, &got)) ==
+					LW_ERR_CAPACITY)
+				out.resize(cap_for(s) * K);
+			if (rc != LW_OK) {
+				printf("E %d\n", rc);
+				stop = true;
+			} else {
+				printf("S %d %zu %zu\n", got, got ? n : 0, left);
+				if (got)
+					show(s, n, 0);
+			}
+		}
+		if (!stop)
+			batch();
+		if (!stop && goal >= 0) {
+			const int rc = lw_ogg_stream_seek_absgp_pg(s, (uint64_t)goal);
+			printf("K %d\n", rc);
+			if (rc == LW_OK)
+				batch();
+		}
+		if (!stop)
+			drain();
 	} else if (mode == "seek") {
 		const int rc = lw_ogg_stream_seek_absgp_pg(s, arg);
 		printf("K %d\n", rc);

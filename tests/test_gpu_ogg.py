@@ -213,3 +213,55 @@ def test_ogg2wav_example_matches_oracle(tmp_path, lookahead):
             want.append(p)
         want = np.concatenate(want)
         assert len(raw) == 44 + n_bytes and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k,singles,skip,goal", [(4, 2, 900, None), (9, 0, 1, 5000), (3, 4, 3000, 0), (64, 1, 128, 20000)])
+def test_single_skip_seek_between_batched_calls_sample_values(k, singles, skip, goal):
+    """The look-ahead pipeline (three batches staged / in flight behind read_dec_packets) rolled back by read_dec_packet,
+    skip_samples_linear and seek_absgp_pg (inside_ogg.rs:167-313): every sample delivered afterwards equals the oracle's
+    OggStreamReader driven with the same calls packet by packet -- i.e. the PreviousWindowRight really is back at the state
+    after the last DELIVERED packet, on the device too."""
+    data = _vorbis_stream("stereo", "LLSLLLSSL", 80, per_page=4, trim=123)[2].bytes()
+    s = IO.OggStreamReader(data)
+    o = pyogg.OggStreamReader(data)
+
+    def same(a, b):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.shape == b.shape and np.array_equal(a, b)
+
+    def batch():
+        r = s.read_dec_packets(k)
+        want = []
+        for _ in range(k):
+            d = o.read_dec_packet()
+            if d is None:
+                break
+            want.append(d)
+        if r is None:
+            assert not want
+            return False
+        assert len(r) == len(want)
+        for a, b in zip(r, want):
+            same(a, b)
+        assert s.get_last_absgp() == o.get_last_absgp()
+        return True
+
+    alive = batch()
+    for _ in range(singles):
+        if alive:
+            a, b = s.read_dec_packet(), o.read_dec_packet()
+            same(a, b)
+            alive = a is not None
+    alive = alive and batch()
+    if alive and skip:
+        (a, la), (b, lb) = s.skip_samples_linear(skip), o.skip_samples_linear(skip)
+        same(a, b)
+        assert la == lb
+    alive = alive and batch()
+    if alive and goal is not None:
+        s.seek_absgp_pg(goal)
+        o.seek_absgp_pg(goal)
+        alive = batch()
+    while alive:
+        alive = batch()

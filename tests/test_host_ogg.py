@@ -130,6 +130,62 @@ def test_skip_samples_linear_trace(harness, tmp_path, to_skip):
     assert got == want + _oracle_trace(o)
 
 
+@pytest.mark.parametrize("k,singles,skip,goal", [(4, 2, 900, -1), (7, 0, 1, 5000), (3, 5, 3000, 0), (64, 1, 128, 20000),
+                                                  (1, 1, 0, -1), (16, 3, 10 ** 7, -1)])
+def test_calls_between_batched_calls_roll_the_pipeline_back(harness, tmp_path, k, singles, skip, goal):
+    """read_dec_packet, skip_samples_linear and seek_absgp_pg between read_dec_packets calls (inside_ogg.rs:167-313): the
+    look-ahead pipeline has read and entropy-decoded up to three batches ahead by then; every call must see the stream
+    exactly where the packet-by-packet reader stands after the same calls (sample counts, granule positions, EOF)."""
+    data = _vorbis_stream("stereo", "LLSLLLSSL", 70, per_page=4, trim=123)[2].bytes()
+    got = _run(harness, tmp_path, data, "mix", k, singles, skip, goal)
+    o = pyogg.OggStreamReader(data)
+    want, stop = [], [False]
+
+    def pos():
+        return ["P", "0", "0", str(o.stream_serial), "0", _gp(o.get_last_absgp())]
+
+    def batch():
+        rows = []
+        for _ in range(k):
+            d = o.read_dec_packet()
+            if d is None:
+                break
+            rows.append(["Q", str(d.shape[1]), "0"])
+        if not rows:
+            want.append(["EOF"])
+            stop[0] = True
+            return
+        want.extend(rows)
+        want.append(pos())
+
+    batch()
+    for _ in range(singles):
+        if stop[0]:
+            break
+        d = o.read_dec_packet()
+        if d is None:
+            want.append(["EOF"])
+            stop[0] = True
+        else:
+            want.append(["P", str(d.shape[1]), "0", str(o.stream_serial), "0", _gp(o.get_last_absgp())])
+    if not stop[0]:
+        batch()
+    if not stop[0] and skip:
+        dec, left = o.skip_samples_linear(skip)
+        want.append(["S", "0" if dec is None else "1", "0" if dec is None else str(dec.shape[1]), str(left)])
+        if dec is not None:
+            want.append(["P", str(dec.shape[1]), "0", str(o.stream_serial), "0", _gp(o.get_last_absgp())])
+    if not stop[0]:
+        batch()
+    if not stop[0] and goal >= 0:
+        o.seek_absgp_pg(goal)
+        want.append(["K", "0"])
+        batch()
+    if not stop[0]:
+        want += _oracle_trace(o)
+    assert got == want
+
+
 @pytest.mark.parametrize("goal", [0, 3000, 12345, 10 ** 9])
 def test_seek_absgp_pg_trace(harness, tmp_path, goal):
     data = _vorbis_stream("stereo", "LLSL", 40, per_page=3)[2].bytes()
