@@ -425,6 +425,14 @@ struct lw_ogg_stream {
 		bool launched = false;
 	};
 	enum { TERM_NONE = 0, TERM_CHAIN, TERM_EOF, TERM_ERROR };
+	struct Collected {          // a batch the demultiplexer thread has read, not yet entropy-decoded
+		std::vector<QueuedPacket> ahead;
+		int term = 0, term_rc = 0; // why no further batch follows this one (TERM_*)
+	};
+	std::deque<Collected> collected; // guarded by pmu
+	Collected *in_stage = nullptr;   // the batch the staging thread is working on (its packets have left `collected`)
+	std::vector<QueuedPacket> stage_failed;
+	std::thread demuxer;
 	std::deque<PipeSlot> staged;  // FIFO image of the ring's busy slots (guarded by pmu)
 	int terminal = TERM_NONE, terminal_rc = LW_OK; // why the producer stopped reading (guarded by pmu)
 	bool p_stop = false, p_done = false;
@@ -667,25 +675,23 @@ struct lw_ogg_stream {
 	// back in front of the demultiplexer, and the PreviousWindowRight returns to its state after the last delivered packet
 	// (its host half was saved before each batch was staged; of the undelivered batches at most ONE was launched, and a
 	// launch writes the other of the state's two device buffers, so the device half is still there).
-	void producer_main()
+	// demultiplexer thread: batches of up to pipe_k packets of the current logical stream, stopping in front of a chain
+	// boundary (this thread owns the demultiplexer, `requeue` and `pending` while the pipeline is active)
+	void demux_main()
 	{
-		std::vector<lw_packet> pk;
 		for (;;) {
 			{
 				std::unique_lock<std::mutex> g(pmu);
-				pcv.wait(g, [&]() { return p_stop || staged.size() < 3; });
+				pcv.wait(g, [&]() { return p_stop || collected.size() < 2; });
 				if (p_stop)
-					break;
+					return;
 			}
-			// collect: packets of the current logical stream, stopping in front of a chain boundary (this thread owns the
-			// demultiplexer, `requeue` and `pending` while the pipeline is active)
-			PipeSlot ps;
-			int term = TERM_NONE, term_rc = LW_OK;
-			while (ps.ahead.size() < pipe_k) {
+			Collected c;
+			while (c.ahead.size() < pipe_k) {
 				QueuedPacket q;
 				if (has_pending && requeue.empty()) {
 					if (pending.serial != serial) {
-						term = TERM_CHAIN;
+						c.term = TERM_CHAIN;
 						break;
 					}
 					q = std::move(pending);
@@ -693,45 +699,72 @@ struct lw_ogg_stream {
 				} else {
 					const int rc = next_raw(q);
 					if (rc == LW_OGG_EOF) {
-						term = TERM_EOF;
+						c.term = TERM_EOF;
 						break;
 					}
 					if (rc != LW_OK) {
-						term = TERM_ERROR;
-						term_rc = rc;
+						c.term = TERM_ERROR;
+						c.term_rc = rc;
 						break;
 					}
 					if (q.serial != serial) {
 						if (q.first_in_stream) {
 							pending = std::move(q);
 							has_pending = true;
-							term = TERM_CHAIN;
+							c.term = TERM_CHAIN;
 							break;
 						}
 						continue; // every packet with a mismatching stream serial is ignored
 					}
 				}
-				ps.ahead.push_back(std::move(q));
+				c.ahead.push_back(std::move(q));
 			}
+			const bool last = c.term != TERM_NONE;
+			std::unique_lock<std::mutex> g(pmu);
+			collected.push_back(std::move(c));
+			pcv.notify_all();
+			if (last)
+				return;
+		}
+	}
+
+	// staging thread: host entropy stage of the collected batches into the ring (lw_ring_stage runs the bit-serial decode
+	// on pipe_threads host threads, this one included), in order
+	void producer_main()
+	{
+		std::vector<lw_packet> pk;
+		for (;;) {
+			Collected c;
+			{
+				std::unique_lock<std::mutex> g(pmu);
+				pcv.wait(g, [&]() { return p_stop || (!collected.empty() && staged.size() < 3); });
+				if (p_stop)
+					break;
+				c = std::move(collected.front());
+				// (the entry stays at the head of `collected`, emptied, until its packets sit in `staged`: a roll-back that
+				// comes in between finds every packet in exactly one of the two queues or in `in_stage`)
+				in_stage = &c;
+			}
+			PipeSlot ps;
+			ps.ahead = std::move(c.ahead);
+			int term = c.term, term_rc = c.term_rc;
 			if (!ps.ahead.empty()) {
 				lw_pwr_get_state(pwr, &ps.saved);
 				pk.resize(ps.ahead.size());
 				for (size_t i = 0; i < pk.size(); i++)
 					pk[i] = lw_packet{ps.ahead[i].data.data(), ps.ahead[i].data.size(), pwr};
 				const int rc = lw_ring_stage(ring, pk.data(), pk.size(), pipe_threads);
-				if (rc != LW_OK) { // (cannot happen for a well-formed call: hand the packets back, report the error)
+				if (rc != LW_OK) { // (cannot happen for a well-formed call: the packets go back, the error is reported)
 					lw_pwr_set_state(pwr, &ps.saved);
-					for (size_t i = ps.ahead.size(); i-- > 0;) {
-						Requeued r;
-						r.q = std::move(ps.ahead[i]);
-						requeue.push_front(std::move(r));
-					}
+					stage_failed = std::move(ps.ahead);
 					ps.ahead.clear();
 					term = TERM_ERROR;
 					term_rc = rc;
 				}
 			}
 			std::unique_lock<std::mutex> g(pmu);
+			in_stage = nullptr;
+			collected.pop_front();
 			if (!ps.ahead.empty())
 				staged.push_back(std::move(ps));
 			if (term != TERM_NONE) {
@@ -768,6 +801,7 @@ struct lw_ogg_stream {
 		terminal_rc = LW_OK;
 		p_stop = p_done = false;
 		pipe_active = true;
+		demuxer = std::thread([this]() { demux_main(); });
 		producer = std::thread([this]() { producer_main(); });
 		return LW_OK;
 	}
@@ -784,17 +818,36 @@ struct lw_ogg_stream {
 		}
 		if (producer.joinable())
 			producer.join();
+		if (demuxer.joinable())
+			demuxer.join();
 		(void)lw_ring_drain(ring);
 		if (!staged.empty())
 			lw_pwr_set_state(pwr, &staged.front().saved);
+		// everything read ahead, in stream order: delivered-next batches first, then what was only demultiplexed; a container
+		// error sits behind the packets it followed (the demultiplexer is only asked once `requeue` is empty)
 		std::deque<Requeued> back;
-		for (PipeSlot &ps : staged)
-			for (QueuedPacket &q : ps.ahead) {
+		auto give_back = [&](std::vector<QueuedPacket> &v) {
+			for (QueuedPacket &q : v) {
 				Requeued r;
 				r.q = std::move(q);
 				back.push_back(std::move(r));
 			}
-		if (terminal == TERM_ERROR) { // met behind the packets above (the demultiplexer is only asked once `requeue` is empty)
+		};
+		for (PipeSlot &ps : staged)
+			give_back(ps.ahead);
+		give_back(stage_failed);
+		stage_failed.clear();
+		bool error_queued = false;
+		for (Collected &c : collected) {
+			give_back(c.ahead);
+			if (c.term == TERM_ERROR) {
+				Requeued r;
+				r.rc = c.term_rc;
+				back.push_back(std::move(r));
+				error_queued = true;
+			}
+		}
+		if (terminal == TERM_ERROR && !error_queued) {
 			Requeued r;
 			r.rc = terminal_rc;
 			back.push_back(std::move(r));
@@ -803,6 +856,7 @@ struct lw_ogg_stream {
 			back.push_back(std::move(r));
 		requeue.swap(back);
 		staged.clear();
+		collected.clear();
 		terminal = TERM_NONE;
 		pipe_active = false;
 	}
@@ -1020,10 +1074,8 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 	}
 	if (!ps) {
 		const int term = s->terminal, rc = s->terminal_rc;
-		if (s->producer.joinable())
-			s->producer.join();
-		s->terminal = lw_ogg_stream::TERM_NONE;
-		s->pipe_active = false;
+		s->terminal = lw_ogg_stream::TERM_NONE; // reported by this call
+		s->rollback(); // both threads have stopped or stop now; nothing is staged; what the demultiplexer still holds goes back
 		if (term == lw_ogg_stream::TERM_ERROR)
 			return rc;
 		if (term == lw_ogg_stream::TERM_EOF)
