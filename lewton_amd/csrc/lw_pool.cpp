@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -27,10 +28,22 @@ struct EntropyPool::Impl {
 	std::condition_variable cv, cv_deep;
 	std::vector<std::thread> threads;
 	const std::function<void()> *fn = nullptr;
-	std::atomic<size_t> pending{0};
-	std::atomic<uint64_t> state{0}; // (region number << 16) | helpers of that region
-	std::atomic<unsigned> sleepers{0};
+	// each on a cache line of its own: the helpers spin on `state` while finished helpers count `pending` down (on one
+	// line every count-down would invalidate every spinner's copy, across both sockets of a 2 x 64-core host)
+	alignas(128) std::atomic<size_t> pending{0};
+	alignas(128) std::atomic<uint64_t> state{0}; // (region number << 16) | helpers of that region
+	alignas(128) std::atomic<unsigned> sleepers{0};
+	alignas(128) char pad_[8] = {0};
 	unsigned awake_upto = 0; // threads with id >= awake_upto may be in deep sleep (written under `serial`)
+	// how long a helper spins for the next region before it sleeps (LW_POOL_SPIN_US overrides).  Longer spins were measured
+	// on the GPU box (2 x EPYC 9575F shared with other jobs, load average 20+): 3 ms instead of 100 us made every
+	// configuration slower -- the spinning helpers take the cores the box's other work needs, and then their own.
+	long spin_us = 100;
+	Impl()
+	{
+		if (const char *e = getenv("LW_POOL_SPIN_US"))
+			spin_us = std::max(0L, atol(e));
+	}
 
 	void loop(size_t id, uint64_t seen)
 	{
@@ -45,7 +58,7 @@ struct EntropyPool::Impl {
 					return (st >> 16) != seen && id < (st & 0xffffu);
 				});
 			} else {
-				// wait for the next region: spin for ~100 us (batches arrive back to back), then sleep
+				// wait for the next region: spin for spin_us (batches arrive back to back), then sleep
 				bool got = false;
 				const auto t0 = std::chrono::steady_clock::now();
 				for (unsigned spins = 0;; spins++) {
@@ -54,7 +67,7 @@ struct EntropyPool::Impl {
 						got = true;
 						break;
 					}
-					if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100))
+					if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us))
 						break;
 					cpu_relax();
 				}

@@ -1047,7 +1047,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	// pass 2 (parallel): entropy decode straight into the pinned staging buffers
 	unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
 	nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n / 8));
-	std::atomic<size_t> next{0};
+	alignas(128) std::atomic<size_t> next{0}; // (its own cache line: every worker adds to it once per LW_ENTROPY_CHUNK packets)
+	alignas(128) char next_pad[8] = {0};
+	(void)next_pad;
 	// Tier B: a worker reserves room for a packet's symbol block in the pinned pool with one atomic add once the packet
 	// is decoded (block sizes are not known before).  Blocks that no longer fit are parked in the worker's own arena and
 	// gathered after the pool has been enlarged (first batches only).
