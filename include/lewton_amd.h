@@ -238,6 +238,35 @@ void lw_pwr_set_state(lw_pwr *p, const lw_pwr_state *in);
 int lw_decoder_device(const lw_decoder *d);
 size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0) / 4: the largest block a packet yields */
 
+/* ---- independent streams sharded over the GPUs of a node, one process (BASELINE configs[4]) ----------------
+ * Streams never exchange data (audio.rs:919 touches only its own pwr): shard g owns the streams with stream_id mod G == g.
+ * A shard = one lw_decoder on devices[g] (tables + the state pool of its streams in that GPU's HBM), one batch with pinned
+ * staging, one HIP stream, one worker thread.  devices[] may name a device several times (logical shards).
+ * lw_sharder_decode takes packets of any streams (those of one stream in stream order), runs every shard's host entropy
+ * stage, H2D, kernels and D2H on the shard's own thread and device, all shards at once, and returns when the last one is
+ * done: no collective, nothing crosses xGMI.  out = host memory for cap_elems elements; results[i] (status, n_samples,
+ * out_offset = element offset of packet i's block in out) come back in the order of pkts; blocks are laid out shard by
+ * shard.  LW_ERR_CAPACITY: more than max_packets_per_shard packets for one shard, or out too small.
+ * The process-per-GPU form of the same rule is lewton_amd/shard.py + bench.py under torch.distributed.run. */
+typedef struct lw_sharder lw_sharder;
+typedef struct lw_shard_stream lw_shard_stream; /* one logical stream: its PreviousWindowRight lives on the owning shard */
+typedef struct {
+	lw_shard_stream *stream;
+	const uint8_t *data;
+	size_t len;
+} lw_shard_packet;
+lw_sharder *lw_sharder_create(const lw_ident *id, const lw_setup *setup, const int *devices, size_t n_shards,
+		size_t max_packets_per_shard, int fmt, int *err);
+void lw_sharder_destroy(lw_sharder *sh); /* close the streams first */
+size_t lw_sharder_shards(const lw_sharder *sh);
+size_t lw_sharder_shard_of(const lw_sharder *sh, uint64_t stream_id);
+int lw_sharder_device_of(const lw_sharder *sh, size_t shard);
+lw_shard_stream *lw_sharder_stream_open(lw_sharder *sh, uint64_t stream_id);
+void lw_sharder_stream_close(lw_shard_stream *st);
+void lw_sharder_stream_reset(lw_shard_stream *st); /* `pwr = PreviousWindowRight::new()` */
+int lw_sharder_decode(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int n_threads_per_shard, void *out,
+		size_t cap_elems, lw_packet_result *results);
+
 /* ---- Ogg container either side of the path ---------------------------- */
 /* lewton reads Ogg through the external crate `ogg` 0.8.0 (Cargo.lock; `PacketReader`, `Packet`) and wraps it
  * in src/inside_ogg.rs.  The functions below replace both: a page/packet demultiplexer after RFC 3533 with the

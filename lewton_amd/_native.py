@@ -37,6 +37,10 @@ class PacketResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_samples", C.c_uint32), ("out_offset", C.c_uint64)]
 
 
+class ShardPacket(C.Structure):
+    _fields_ = [("stream", C.c_void_p), ("data", C.c_void_p), ("len", C.c_size_t)]
+
+
 class PwrState(C.Structure):
     _fields_ = [("present", C.c_uint8), ("parity", C.c_uint8), ("len", C.c_uint32)]
 
@@ -127,6 +131,16 @@ SYMBOLS = {
     "lw_ring_in_flight": (C.c_size_t, [C.c_void_p]),
     "lw_ring_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_ring_last_kernels": (C.c_char_p, [C.c_void_p]),
+    "lw_sharder_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_size_t, C.c_size_t, C.c_int, intp]),
+    "lw_sharder_destroy": (None, [C.c_void_p]),
+    "lw_sharder_shards": (C.c_size_t, [C.c_void_p]),
+    "lw_sharder_shard_of": (C.c_size_t, [C.c_void_p, C.c_uint64]),
+    "lw_sharder_device_of": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "lw_sharder_stream_open": (C.c_void_p, [C.c_void_p, C.c_uint64]),
+    "lw_sharder_stream_close": (None, [C.c_void_p]),
+    "lw_sharder_stream_reset": (None, [C.c_void_p]),
+    "lw_sharder_decode": (C.c_int, [C.c_void_p, C.POINTER(ShardPacket), C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                    C.POINTER(PacketResult)]),
     "lw_pwr_get_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
     "lw_pwr_set_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
     "lw_decoder_device": (C.c_int, [C.c_void_p]),

@@ -31,3 +31,79 @@ def job_throughput(units_per_rank, elapsed_seconds, dist=None, device=None):
     """Weak scaling: every rank processed `units_per_rank` units; value = all units / slowest rank's time."""
     world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
     return units_per_rank * world / max_elapsed(elapsed_seconds, dist, device)
+
+
+class Sharder:
+    """Single-process form (lw_sharder_*): one decoder, batch, HIP stream and worker thread per entry of `devices`; streams
+    are opened through the sharder and live on shard stream_id mod G."""
+
+    def __init__(self, ident, setup, devices, max_packets_per_shard, samples="i16"):
+        import ctypes as C
+        from . import _native as N
+        from .audio import _FMT
+        self._N, self._C = N, C
+        self.ident, self.fmt = ident, _FMT[samples]
+        arr = (C.c_int * len(devices))(*devices)
+        err = C.c_int(0)
+        self._h = N.lw_sharder_create(ident._h, setup._h, arr, len(devices), max_packets_per_shard, self.fmt, C.byref(err))
+        if not self._h:
+            raise RuntimeError("lw_sharder_create failed (%d): %s" % (err.value, N.device_error()))
+        self._streams = {}
+
+    @property
+    def shards(self):
+        return self._N.lw_sharder_shards(self._h)
+
+    def shard_of(self, stream_id):
+        return self._N.lw_sharder_shard_of(self._h, stream_id)
+
+    def stream(self, stream_id):
+        if stream_id not in self._streams:
+            h = self._N.lw_sharder_stream_open(self._h, stream_id)
+            if not h:
+                raise RuntimeError("lw_sharder_stream_open failed: " + self._N.device_error())
+            self._streams[stream_id] = h
+        return self._streams[stream_id]
+
+    def decode(self, packets, n_threads=0):
+        """packets: list of (stream_id, bytes).  Returns a list of per-packet arrays ([ch][m], None for a failed packet) and
+        the list of (status, n_samples, out_offset)."""
+        import numpy as np
+        N, C = self._N, self._C
+        n = len(packets)
+        arr = (N.ShardPacket * n)()
+        keep = []
+        for i, (sid, data) in enumerate(packets):
+            data = bytes(data)
+            keep.append(data)
+            arr[i].stream = self.stream(sid)
+            arr[i].data = C.cast(C.c_char_p(data), C.c_void_p)
+            arr[i].len = len(data)
+        ch = self.ident.audio_channels
+        cap = n * ch * (1 << self.ident.blocksize_1)
+        out = np.zeros(cap, np.float32 if self.fmt == N.FMT_F32_PLANAR else np.int16)
+        res = (N.PacketResult * n)()
+        rc = N.lw_sharder_decode(self._h, arr, n, n_threads, out.ctypes.data_as(C.c_void_p), cap, res)
+        if rc:
+            raise RuntimeError("lw_sharder_decode: %d %s" % (rc, N.device_error()))
+        blocks = []
+        for i in range(n):
+            if res[i].status != 0:
+                blocks.append(None)
+            elif self.fmt == N.FMT_I16_INTERLEAVED:
+                blocks.append(out[res[i].out_offset: res[i].out_offset + res[i].n_samples * ch])
+            else:
+                blocks.append(out[res[i].out_offset: res[i].out_offset + res[i].n_samples * ch].reshape(ch, res[i].n_samples))
+        return blocks, [(res[i].status, res[i].n_samples, res[i].out_offset) for i in range(n)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for h in self._streams.values():
+                self._N.lw_sharder_stream_close(h)
+            self._streams = {}
+            self._N.lw_sharder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        if getattr(self, "_N", None) is not None and getattr(self._N, "lw_sharder_destroy", None) is not None:
+            self.close()

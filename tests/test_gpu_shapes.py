@@ -168,3 +168,30 @@ def test_two_decoders_in_one_process_interleaved():
             a = audio.read_audio_packet_on(decs[i], q, pwrs[i])
             w = po.read_audio_packet(o_id, o_st, q, opws[i], "i16")
             assert a.shape == w.shape and np.array_equal(a, w)
+
+
+def test_sharder_ten_thousand_streams_one_process():
+    """The same 10 000 streams through the C-level sharder (lw_sharder_*): eight logical shards, one worker thread, decoder,
+    batch and HIP stream each (every visible device in turn, so on a one-GPU box all on device 0), two calls of two packets
+    per stream with the state carried on each shard between the calls; every packet against the oracle."""
+    from lewton_amd import _native as N
+    from lewton_amd import shard
+    setup = SETUPS["stereo"]()
+    audio, ident, st = _product(setup)
+    o_id, o_st = oracle_headers(setup)
+    G, n_streams = 8, 10000
+    ndev = max(1, N.lw_device_count())
+    sh = shard.Sharder(ident, st, [g % ndev for g in range(G)], max_packets_per_shard=2 * (n_streams // G + 1), samples="i16")
+    assert sh.shards == G and sh.shard_of(12345) == 12345 % G
+    pool = sg.make_stream(setup, "L", 128, seed=17)
+    rng = np.random.default_rng(4)
+    pick = rng.integers(0, len(pool), (n_streams, 4))
+    opws = [po.Pwr() for _ in range(n_streams)]
+    for half in range(2):
+        # round-robin over the streams inside a call: the sharder sorts out who owns what, stream order is kept
+        items = [(s, pool[int(pick[s, 2 * half + t])]) for t in range(2) for s in range(n_streams)]
+        blocks, res = sh.decode(items, n_threads=8)
+        for (s, pkt), b, r in zip(items, blocks, res):
+            want = po.read_audio_packet(o_id, o_st, pkt, opws[s], "i16")
+            assert r[0] == 0 and b.shape == want.shape and np.array_equal(b, want), (half, s)
+    sh.close()
