@@ -265,10 +265,6 @@ __device__ __forceinline__ void iter54(float *w)
 	w[0] = k11 + k22;
 }
 
-// TPB threads work on one (packet, channel) block: TPB = LW_BLOCK (one block per workgroup, barriers between the stages) for
-// the large block sizes, TPB = 64 (four blocks per workgroup, each on its own wave; the stages are ordered by the wave's
-// own LDS ordering, no barrier) for block sizes up to 2^LW_SMALL_BS -- a 256-point short block has 32 butterflies per
-// stage, a 256-thread workgroup and its barriers were 4x the work of the transform itself.
 template <int TPB>
 __device__ __forceinline__ void stage_sync()
 {
@@ -278,25 +274,27 @@ __device__ __forceinline__ void stage_sync()
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wave: its LDS operations complete in order
 }
 
-template <int TPB>
-__global__ void __launch_bounds__(LW_BLOCK)
-k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled, uint32_t skip_mask, uint32_t task_floats)
+// One (packet, channel) block: floor curve, floor x residue, IMDCT (imdct.rs:291-659) by TPB threads in `smem`; the n
+// time-domain values go to `out` (HBM, or LDS for the fused small-block kernel).
+// TPB threads work on one (packet, channel) block: TPB = LW_BLOCK (one block per workgroup, barriers between the stages) for
+// the large block sizes, TPB = 64 (one wave per block; the stages are ordered by the wave's own LDS ordering, no barrier)
+// for block sizes up to 2^LW_SMALL_BS -- a 256-point short block has 32 butterflies per stage, a 256-thread workgroup and
+// its barriers were 4x the work of the transform itself.
+struct LwBlockTables { // tables of one block size + the inverse-dB table: in HBM / L2, or copies in LDS
+	const float *A, *Bt, *C, *inv_db;
+	const uint32_t *bitrev;
+};
+
+__device__ __forceinline__ LwBlockTables global_tables(const LwDevTables &T, const LwPacketRec &rec)
 {
-	extern __shared__ __attribute__((aligned(16))) float smem_all[];
-	const uint32_t task = TPB == LW_BLOCK ? blockIdx.x : blockIdx.x * (LW_BLOCK / TPB) + threadIdx.x / TPB;
-	const uint32_t *list = TPB == LW_BLOCK ? B.gen_large : B.gen_small;
-	const uint32_t n_list = TPB == LW_BLOCK ? B.n_gen_large : B.n_gen_small;
-	if (task >= (list ? n_list : B.n_packets) * T.ch)
-		return;
-	const uint32_t pkt = list ? list[task / T.ch] : task / T.ch, c = task % T.ch;
-	const LwPacketRec rec = B.recs[pkt];
-	if (rec.flags & skip_mask)
-		return;
-	if ((rec.bs <= LW_SMALL_BS) != (TPB != LW_BLOCK))
-		return; // the other instantiation handles this block size
-	const uint32_t tid = threadIdx.x % TPB;
-	float *smem = smem_all + (TPB == LW_BLOCK ? 0u : (threadIdx.x / TPB) * task_floats);
-	const LwDevBs tb = T.bs[(rec.flags & LW_RF_LONG) ? 1 : 0];
+	const LwDevBs &tb = T.bs[(rec.flags & LW_RF_LONG) ? 1 : 0];
+	return LwBlockTables{tb.A, tb.B, tb.C, T.inv_db, tb.bitrev};
+}
+
+template <int TPB>
+__device__ __forceinline__ void imdct_block(const LwDevTables &T, const LwBatchDev &B, const LwPacketRec &rec, uint32_t c, uint32_t tid,
+		float *smem, float *out, float *tap_spec, int use_decoupled, int partner, int role, const LwBlockTables tabs)
+{
 	const uint32_t bs = rec.bs, n = 1u << bs, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
 	float *u = smem, *v = smem + n2;
 	uint16_t *px = (uint16_t *)(smem + 2 * n2);
@@ -346,7 +344,11 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	const int K = *s_Kp;
 
 	// ---- spectrum = floor * residue (audio.rs:1035-1037); zero floor for an unused channel (:1021-1024)
+	// residue of this channel after inverse coupling: from k_decouple's buffer, or -- `partner` >= 0: this channel takes part
+	// in exactly one coupling step of the mode with that channel (role 1 = magnitude, 2 = angle) -- computed here from the two
+	// raw vectors (audio.rs:762-777), or the raw vector itself
 	const float *src = (use_decoupled ? B.decoupled : B.residue) + rec.res_off + c * n2;
+	const float *psrc = partner >= 0 ? B.residue + rec.res_off + (uint32_t)partner * n2 : nullptr;
 	for (uint32_t k = tid; k < n2; k += TPB) {
 		float f;
 		if (unused) {
@@ -372,9 +374,32 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 				const int off = (ady * ((int)k - x0)) / adx; // closed form of render_line
 				y = dy < 0 ? y0 - off : y0 + off;
 			}
-			f = T.inv_db[y];
+			f = tabs.inv_db[y];
 		}
-		const float x = f * src[k];
+		float r = src[k];
+		if (psrc) {
+			const float m = role == 1 ? r : psrc[k], a = role == 1 ? psrc[k] : r;
+			float nm, na;
+			if (m > 0.0f) {
+				if (a > 0.0f) {
+					nm = m;
+					na = m - a;
+				} else {
+					nm = m + a;
+					na = m;
+				}
+			} else {
+				if (a > 0.0f) {
+					nm = m;
+					na = m + a;
+				} else {
+					nm = m - a;
+					na = m;
+				}
+			}
+			r = role == 1 ? nm : na;
+		}
+		const float x = f * r;
 		u[k] = x;
 		if (tap_spec)
 			tap_spec[rec.res_off + c * n2 + k] = x;
@@ -382,7 +407,7 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	stage_sync<TPB>();
 
 	// twiddles stay in L2 (copies in LDS were measured slower: fewer resident workgroups, no gain per stage)
-	const float *A = tb.A, *Bt = tb.B, *C = tb.C;
+	const float *A = tabs.A, *Bt = tabs.Bt, *C = tabs.C;
 	// ---- imdct.rs:337-371: X = u -> v
 	for (uint32_t j = tid; j < n8; j += TPB) {
 		const float x0 = u[4 * j], x2 = u[4 * j + 2];
@@ -465,13 +490,13 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	stage_sync<TPB>();
 	// ---- imdct.rs:490-528 bit-reverse: u -> v
 	for (uint32_t t = tid; t < (n >> 4); t += TPB) {
-		uint32_t k = tb.bitrev[2 * t];
+		uint32_t k = tabs.bitrev[2 * t];
 		const uint32_t d1 = n2 - 4 - 4 * t, d0 = n4 - 4 - 4 * t;
 		v[d1 + 3] = u[k];
 		v[d1 + 2] = u[k + 1];
 		v[d0 + 3] = u[k + 2];
 		v[d0 + 2] = u[k + 3];
-		k = tb.bitrev[2 * t + 1];
+		k = tabs.bitrev[2 * t + 1];
 		v[d1 + 1] = u[k];
 		v[d1] = u[k + 1];
 		v[d0 + 1] = u[k + 2];
@@ -502,7 +527,6 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	}
 	stage_sync<TPB>();
 	// ---- imdct.rs:589-658 step 8 + output mapping -> time-domain block in HBM
-	float *out = B.td + 2u * rec.res_off + c * n;
 	for (uint32_t p = tid; p < n4; p += TPB) {
 		const float w0 = v[2 * p], w1 = v[2 * p + 1];
 		const float pa = w0 * Bt[2 * p + 1] - w1 * Bt[2 * p];
@@ -513,6 +537,27 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 		out[n2 + q] = pb;
 		out[n - 1 - q] = pb;
 	}
+}
+
+template <int TPB>
+__global__ void __launch_bounds__(LW_BLOCK)
+k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled, uint32_t skip_mask, uint32_t task_floats)
+{
+	extern __shared__ __attribute__((aligned(16))) float smem_all[];
+	const uint32_t task = TPB == LW_BLOCK ? blockIdx.x : blockIdx.x * (LW_BLOCK / TPB) + threadIdx.x / TPB;
+	const uint32_t *list = TPB == LW_BLOCK ? B.gen_large : B.gen_small;
+	const uint32_t n_list = TPB == LW_BLOCK ? B.n_gen_large : B.n_gen_small;
+	if (task >= (list ? n_list : B.n_packets) * T.ch)
+		return;
+	const uint32_t pkt = list ? list[task / T.ch] : task / T.ch, c = task % T.ch;
+	const LwPacketRec rec = B.recs[pkt];
+	if (rec.flags & skip_mask)
+		return;
+	if ((rec.bs <= LW_SMALL_BS) != (TPB != LW_BLOCK))
+		return; // the other instantiation handles this block size
+	float *smem = smem_all + (TPB == LW_BLOCK ? 0u : (threadIdx.x / TPB) * task_floats);
+	imdct_block<TPB>(T, B, rec, c, threadIdx.x % TPB, smem, B.td + 2u * rec.res_off + c * (1u << rec.bs), tap_spec, use_decoupled, -1, 0,
+			global_tables(T, rec));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,6 +631,205 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 			st[c * T.state_chan_stride + i] = cur0[c * n + rs + i];
 		}
 	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused small-block path
+// ---------------------------------------------------------------------------------------------
+// One workgroup = one LwSegment: up to 16 / ch consecutive packets of ONE stream out of the batch's overlap-add list, one
+// wave per (packet, channel).  Phase A: every wave whose packet is a small generic block (<= 2^LW_SMALL_BS points) does
+// inverse coupling (its own side of the one coupling step it is in), floor curve, floor x residue and the IMDCT in its
+// LDS slice and leaves the time-domain block in LDS.  One barrier.  Phase B: window / overlap-add / conversion / state of
+// every member (audio.rs:1056-1154) -- the previous packet's raw right part comes from the neighbouring wave's LDS block,
+// from the block the segment recomputed for that purpose (`halo`: the predecessor is a small block of another segment; its
+// IMDCT costs less than a round trip through HBM and a second launch would), from B.td (predecessor transformed by the
+// specialised kernel or the large generic IMDCT, which ran before) or from the stream's state slot.  Members that are not
+// small blocks (long blocks next to short ones, LW_RF_TDONLY; large generic blocks) take their own block from B.td.
+// An alternative to k_decouple + k_imdct_generic<64> + k_ola_generic (three launches, two round trips of every block
+// through HBM) for the mixed short/long streams of BASELINE configs[2]; bit-identical to them (tests).  MEASURED SLOWER on
+// MI355X as it stands (35 us against 30 us for the three kernels on 2 979 short + 745 adjacent long packets; without
+// either phase the workgroups' skeleton alone -- descriptor, records, table staging, five barriers -- takes 8.6 us, phase
+// A 16 us, phase B 12 us: every part is a chain of dependent L2 / HBM round trips, as in the kernels it replaces), so the
+// runtime only takes this path when LW_SMALL_FUSED=1 is set (profiles/r02_small_fused.txt).
+template <int FMT>
+__global__ void __launch_bounds__(1024) k_small_fused(LwDevTables T, LwBatchDev B, void *out_v, uint32_t task_floats, uint32_t td_floats)
+{
+	extern __shared__ __attribute__((aligned(16))) float smem_all[];
+	__shared__ LwPacketRec s_rec[17]; // the members' records, [16] = the halo packet's
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+	const LwSegment seg = B.seg[blockIdx.x];
+	const uint32_t ch = T.ch, m = wave / ch, c = wave - m * ch;
+	float *work = smem_all + (size_t)wave * task_floats;                       // IMDCT scratch of this wave
+	float *td_all = smem_all + (size_t)n_waves * task_floats;                  // [wave][td_floats] time-domain blocks
+	float *halo_all = td_all + (size_t)n_waves * td_floats;                    // [ch][td_floats] recomputed predecessor
+	float *tab = halo_all + (size_t)ch * td_floats;                            // table copies (below)
+	// ---- tables of the small block sizes and the inverse-dB table: L2 -> LDS once per workgroup.  Every stage of the
+	// transform reads its twiddles; from L2 that is one ~0.5 us round trip per stage and block, ~10 us per 256-point block.
+	float *s_inv_db = tab;
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+		s_inv_db[i] = T.inv_db[i];
+	// (two named structs selected by value, not an array indexed at run time: that would live in scratch memory)
+	float *p0 = tab + 256;
+	const uint32_t n0 = T.bs[0].n, n1 = T.bs[1].n;
+	const bool small0 = T.bs[0].bs <= LW_SMALL_BS, small1 = T.bs[1].bs <= LW_SMALL_BS;
+	float *p1 = p0 + (small0 ? n0 + n0 / 4 + n0 / 8 : 0u);
+#define LW_STAGE_TABLES(P, N, TB)                                                     \
+	do {                                                                              \
+		for (uint32_t i = threadIdx.x; i < (N) / 2; i += blockDim.x) {                \
+			(P)[i] = (TB).A[i];                                                       \
+			(P)[(N) / 2 + i] = (TB).B[i];                                             \
+		}                                                                             \
+		for (uint32_t i = threadIdx.x; i < (N) / 4; i += blockDim.x)                  \
+			(P)[(N) + i] = (TB).C[i];                                                 \
+		for (uint32_t i = threadIdx.x; i < (N) / 8; i += blockDim.x)                  \
+			(P)[(N) + (N) / 4 + i] = __uint_as_float((TB).bitrev[i]);                 \
+	} while (0)
+	if (small0)
+		LW_STAGE_TABLES(p0, n0, T.bs[0]);
+	if (small1)
+		LW_STAGE_TABLES(p1, n1, T.bs[1]);
+#undef LW_STAGE_TABLES
+	// (only small blocks are transformed here: a larger size gets LDS pointers too, never followed -- with nothing but LDS
+	// pointers in these structs hipcc addresses the tables with ds_read instead of flat loads)
+	const LwBlockTables lt0{p0, p0 + n0 / 2, p0 + n0, s_inv_db, reinterpret_cast<const uint32_t *>(p0 + n0 + n0 / 4)};
+	const LwBlockTables lt1{p1, p1 + n1 / 2, p1 + n1, s_inv_db, reinterpret_cast<const uint32_t *>(p1 + n1 + n1 / 4)};
+	if (threadIdx.x < seg.count)
+		s_rec[threadIdx.x] = B.recs[B.gen_ola[seg.first + threadIdx.x]];
+	__syncthreads();
+	if (seg.halo && threadIdx.x == 0)
+		s_rec[16] = B.recs[s_rec[0].prev];
+	__syncthreads();
+	// ---- phase A: one wave per (member, channel); the halo block on the waves of the first unused member slot (the host
+	// keeps one free in a segment that needs a halo)
+	const bool member = m < seg.count, halo_wave = seg.halo && m == seg.count;
+	if (member || halo_wave) {
+		const LwPacketRec rec = s_rec[halo_wave ? 16 : m];
+		if (halo_wave || (!(rec.flags & LW_RF_FAST) && rec.bs <= LW_SMALL_BS))
+			imdct_block<64>(T, B, rec, c, lane, work, halo_wave ? halo_all + (size_t)c * td_floats : td_all + (size_t)wave * td_floats,
+					nullptr, 0, T.pair_coupling ? T.mode_partner[rec.mode * ch + c] : -1,
+					T.pair_coupling ? T.mode_role[rec.mode * ch + c] : 0, (rec.flags & LW_RF_LONG) ? lt1 : lt0);
+	}
+	__syncthreads();
+	// ---- phase B: window / overlap-add / conversion / state of every member (audio.rs:1056-1154).  All (member, channel,
+	// sample) triples of the segment form ONE index space that the workgroup's threads stride through: every load of a pass is
+	// independent of every other (a loop over members would pay one HBM / L2 round trip per member and channel: a long block
+	// next to short ones has 1472 samples per channel, a short block 128).
+	__shared__ uint32_t s_out_end[17], s_st_end[17]; // running totals of output samples / state samples per (member, channel)
+	__shared__ const float *s_prev[16 * 8], *s_cur[16 * 8];
+	const uint32_t n_mc = seg.count * ch;
+	if (threadIdx.x < n_mc) {
+		const uint32_t mi = threadIdx.x / ch, cc = threadIdx.x - mi * ch;
+		const LwPacketRec rec = s_rec[mi];
+		const bool small = !(rec.flags & LW_RF_FAST) && rec.bs <= LW_SMALL_BS;
+		const uint32_t n = 1u << rec.bs;
+		s_cur[threadIdx.x] = small ? td_all + (size_t)(mi * ch + cc) * td_floats : B.td + 2u * rec.res_off + cc * n;
+		const float *prev = nullptr;
+		if (rec.prev >= 0) {
+			const LwPacketRec prg = mi > 0 ? s_rec[mi - 1] : (seg.halo ? s_rec[16] : B.recs[rec.prev]);
+			const bool pr_small = !(prg.flags & LW_RF_FAST) && prg.bs <= LW_SMALL_BS;
+			if (pr_small && mi > 0)         // (the host links a small predecessor either into this segment ...
+				prev = td_all + (size_t)((mi - 1) * ch + cc) * td_floats + prg.rs;
+			else if (pr_small)              // ... or marks the segment `halo`)
+				prev = halo_all + (size_t)cc * td_floats + prg.rs;
+			else
+				prev = B.td + 2u * prg.res_off + cc * (1u << prg.bs) + prg.rs;
+		} else if (rec.prev <= -2) {
+			const uint32_t slot = (uint32_t)(-(rec.prev + 2));
+			const uint32_t par = (rec.flags & LW_RF_PARITY_IN) ? 1u : 0u;
+			prev = B.state + ((size_t)slot * 2 + par) * T.state_stride + cc * T.state_chan_stride;
+		}
+		s_prev[threadIdx.x] = prev;
+	}
+	if (threadIdx.x == 0) {
+		uint32_t a = 0, st = 0;
+		for (uint32_t j = 0; j < n_mc; j++) {
+			const LwPacketRec &rec = s_rec[j / ch];
+			a += (rec.prev != -1 && rec.rs > rec.ls) ? (uint32_t)(rec.rs - rec.ls) : 0u;
+			st += (rec.state_out >= 0 && rec.re > rec.rs) ? (uint32_t)(rec.re - rec.rs) : 0u;
+			s_out_end[j] = a;
+			s_st_end[j] = st;
+		}
+	}
+	__syncthreads();
+	const uint32_t total_out = n_mc ? s_out_end[n_mc - 1] : 0, total_st = n_mc ? s_st_end[n_mc - 1] : 0;
+	for (uint32_t idx = threadIdx.x; idx < total_out; idx += blockDim.x) {
+		uint32_t j = 0;
+		while (s_out_end[j] <= idx)
+			j++;
+		const uint32_t i = idx - (j ? s_out_end[j - 1] : 0u), mi = j / ch, cc = j - mi * ch;
+		const LwPacketRec &rec = s_rec[mi];
+		const uint32_t ls = rec.ls, mm = rec.rs - ls, plen = rec.plen;
+		float x = s_cur[j][ls + i];
+		if (i < plen) {
+			const float *slope = T.bs[(rec.flags & LW_RF_SLOPE_BS1) ? 1 : 0].window;
+			x = (x * slope[i]) + (s_prev[j][i] * slope[plen - 1 - i]); // audio.rs:1116-1118
+		}
+		if (FMT == LW_OUT_I16_PLANAR)
+			((int16_t *)out_v)[rec.out_off + cc * mm + i] = to_i16(x);
+		else if (FMT == LW_OUT_I16_INTERLEAVED)
+			((int16_t *)out_v)[rec.out_off + i * ch + cc] = to_i16(x);
+		else
+			((float *)out_v)[rec.out_off + cc * mm + i] = x;
+	}
+	for (uint32_t idx = threadIdx.x; idx < total_st; idx += blockDim.x) { // audio.rs:1121, :1142-1147: the raw right part
+		uint32_t j = 0;
+		while (s_st_end[j] <= idx)
+			j++;
+		const uint32_t i = idx - (j ? s_st_end[j - 1] : 0u), mi = j / ch, cc = j - mi * ch;
+		const LwPacketRec &rec = s_rec[mi];
+		const uint32_t par = (rec.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
+		B.state[((size_t)rec.state_out * 2 + par) * T.state_stride + cc * T.state_chan_stride + i] = s_cur[j][rec.rs + i];
+	}
+}
+
+static uint32_t small_task_floats(uint32_t max_n)
+{
+	const uint32_t small_n = std::min(max_n, 1u << LW_SMALL_BS);
+	return (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 7u) & ~3u;
+}
+
+void lw_launch_small_fused(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, uint32_t max_n)
+{
+	if (!B.seg || B.n_seg == 0)
+		return;
+	const uint32_t ppw = lw_small_fused_members(T.ch), waves = ppw * T.ch;
+	const uint32_t task_floats = small_task_floats(max_n), td_floats = std::min(max_n, 1u << LW_SMALL_BS);
+	size_t tab_floats = 256; // inverse-dB table + A, B, C, bitrev of every block size the kernel transforms
+	for (int q = 0; q < 2; q++)
+		if (T.bs[q].bs <= LW_SMALL_BS)
+			tab_floats += T.bs[q].n + T.bs[q].n / 4 + T.bs[q].n / 8;
+	const size_t lds = ((size_t)waves * (task_floats + td_floats) + (size_t)T.ch * td_floats + tab_floats) * sizeof(float);
+	static LwPerDeviceOnce once;
+	if (once.first_launch_on_device()) {
+		(void)hipFuncSetAttribute((const void *)k_small_fused<LW_OUT_I16_PLANAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_small_fused<LW_OUT_I16_INTERLEAVED>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_small_fused<LW_OUT_F32_PLANAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+	}
+	const dim3 g(B.n_seg), b(64 * waves);
+	if (fmt == LW_OUT_I16_PLANAR)
+		hipLaunchKernelGGL(k_small_fused<LW_OUT_I16_PLANAR>, g, b, lds, st, T, B, out, task_floats, td_floats);
+	else if (fmt == LW_OUT_I16_INTERLEAVED)
+		hipLaunchKernelGGL(k_small_fused<LW_OUT_I16_INTERLEAVED>, g, b, lds, st, T, B, out, task_floats, td_floats);
+	else
+		hipLaunchKernelGGL(k_small_fused<LW_OUT_F32_PLANAR>, g, b, lds, st, T, B, out, task_floats, td_floats);
+}
+
+// the large generic blocks only (their small siblings go through k_small_fused): inverse coupling + IMDCT into B.td
+void lw_launch_generic_imdct_large(const LwDevTables &T, const LwBatchDev &B, hipStream_t st, uint32_t max_n, bool any_coupling)
+{
+	if (!B.gen_large || B.n_gen_large == 0)
+		return;
+	LwBatchDev L = B;
+	L.gen_small = B.gen_large; // k_decouple walks gen_small then gen_large: give it the large list alone
+	L.n_gen_small = 0;
+	if (any_coupling)
+		hipLaunchKernelGGL(k_decouple, dim3(B.n_gen_large), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T, L, (uint32_t)(LW_RF_SKIP | LW_RF_FAST));
+	static LwPerDeviceOnce once;
+	if (once.first_launch_on_device())
+		(void)hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+	const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 4) * sizeof(float);
+	hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(B.n_gen_large * T.ch), dim3(LW_BLOCK), lds, st, T, B, (float *)nullptr,
+			any_coupling ? 1 : 0, (uint32_t)(LW_RF_SKIP | LW_RF_FAST), 0u);
 }
 
 void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,

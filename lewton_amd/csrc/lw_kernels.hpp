@@ -43,6 +43,9 @@ struct LwDevTables {
 	const uint16_t *couple_off;   // [n_modes + 1] offsets (in steps) into `couple`
 	const uint8_t *couple;        // (magnitude, angle) channel pairs in header order (audio.rs:990-1002 walks them reversed)
 	const uint8_t *sid;           // fast path: [n_floors][2][n_max/2] static interval index per bin (may be null)
+	const int8_t *mode_partner;   // [n_modes][ch] the other channel of the ONE coupling step this channel is in, or -1
+	const uint8_t *mode_role;     // [n_modes][ch] 1 = magnitude, 2 = angle of that step
+	uint32_t pair_coupling;       // 1: in every mode a channel takes part in at most one coupling step (the two tables are valid)
 	uint32_t ch, fstride, n_modes, n_floors;
 	uint32_t state_stride;        // floats per (slot, parity): ch * (n1 / 2)
 	uint32_t state_chan_stride;   // n1 / 2
@@ -97,6 +100,8 @@ struct LwBatchDev {
 	uint32_t n_gen_small, n_gen_large;
 	const uint32_t *gen_ola; // packets of k_ola_generic: the two lists above plus the LW_RF_TDONLY packets
 	uint32_t n_gen_ola;
+	const LwSegment *seg;    // workgroups of k_small_fused over gen_ola (null: the three-kernel generic path)
+	uint32_t n_seg;
 };
 
 // Generic path (any block size 64..8192, any window shape, any channel count / coupling list), two phases so
@@ -108,6 +113,18 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBatchDev &B, hipStream_t st, uint32_t max_n,
 		const uint32_t *book_ends, size_t n_book_ends);
 void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast);
+// Fused path of the small blocks (<= 2^LW_SMALL_BS points): inverse coupling, floor, IMDCT, window / overlap-add, conversion
+// in ONE launch over B.seg; also does window / overlap-add of the other packets of the overlap-add list (their time-domain
+// blocks must be in B.td: specialised kernel / large generic IMDCT run before).  `large_only` variant of the generic IMDCT:
+void lw_launch_generic_imdct_large(const LwDevTables &T, const LwBatchDev &B, hipStream_t st, uint32_t max_n, bool any_coupling);
+// members (packets) per workgroup of k_small_fused: 8 waves per workgroup where the channel count allows, at least 2 members
+// (a segment that recomputes its predecessor block keeps one member slot free for it); channels <= 8
+static inline uint32_t lw_small_fused_members(uint32_t ch)
+{
+	const uint32_t m = 8u / (ch ? ch : 1u);
+	return m < 2u ? 2u : m;
+}
+void lw_launch_small_fused(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, uint32_t max_n);
 
 // Specialised long-block path (lw_kernels_long.hip): optional halo pre-pass + main pass.
 struct LwFastLaunch;

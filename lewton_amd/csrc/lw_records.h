@@ -52,3 +52,11 @@ static_assert(sizeof(LwPacketRec) == 32, "LwPacketRec must stay 32 bytes");
 
 #define LW_RF_PARITY_OUT 64u
 #define LW_RF_PARITY_IN 128u
+
+// One workgroup of the fused small-block kernel (k_small_fused): `count` consecutive entries of the batch's overlap-add list,
+// starting at `first`, that are consecutive packets of ONE stream (entry i+1's predecessor is entry i).
+struct LwSegment {
+	uint32_t first;
+	uint16_t count;
+	uint16_t halo; // 1: the first member's predecessor is a small generic block of ANOTHER segment: its IMDCT is recomputed here
+};

@@ -113,6 +113,8 @@ struct lw_batch {
 	// workgroups that mostly find out they have nothing to do
 	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
 	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
+	LwSegment *h_seg = nullptr, *d_seg = nullptr; // workgroups of the fused small-block kernel over the overlap-add list
+	uint32_t n_seg = 0;
 	bool has_tdonly = false; // the specialised kernel's work list contains LW_RF_TDONLY packets
 	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
 	bool symbols = false;
@@ -587,11 +589,32 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	couple_off[nmodes] = (uint16_t)(couple.size() / 2);
 	if (couple.empty())
 		couple.push_back(0);
+	// per mode and channel: the other channel of the one coupling step it takes part in (fused small-block kernel: a wave
+	// decouples its own channel on the fly); pair_coupling = no channel of any mode is in more than one step
+	std::vector<int8_t> mode_partner(nmodes * ch, -1);
+	std::vector<uint8_t> mode_role(nmodes * ch, 0);
+	bool pair_coupling = ch <= 127;
+	for (size_t m = 0; m < nmodes && pair_coupling; m++) {
+		const lw::Mapping &mp = s.mappings[s.modes[m].mapping];
+		for (size_t k = 0; k < mp.mag.size(); k++) {
+			const size_t mg = mp.mag[k], an = mp.ang[k];
+			if (mg == an || mode_partner[m * ch + mg] >= 0 || mode_partner[m * ch + an] >= 0) {
+				pair_coupling = false;
+				break;
+			}
+			mode_partner[m * ch + mg] = (int8_t)an;
+			mode_role[m * ch + mg] = 1;
+			mode_partner[m * ch + an] = (int8_t)mg;
+			mode_role[m * ch + an] = 2;
+		}
+	}
 	const size_t off_fx = put(fx.data(), fx.size() * 2);
 	const size_t off_fF = put(fF.data(), fF.size());
 	const size_t off_mf = put(mode_floor.data(), mode_floor.size());
 	const size_t off_co = put(couple_off.data(), couple_off.size() * 2);
 	const size_t off_cp = put(couple.data(), couple.size());
+	const size_t off_mp = put(mode_partner.data(), mode_partner.size());
+	const size_t off_mr = put(mode_role.data(), mode_role.size());
 
 	if (!hip_ok(hipMalloc(&d->d_blob, blob.size()), "hipMalloc(tables)") ||
 			!hip_ok(hipMemcpy(d->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(tables)")) {
@@ -616,6 +639,9 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	d->T.mode_floor = base + off_mf;
 	d->T.couple_off = (const uint16_t *)(base + off_co);
 	d->T.couple = base + off_cp;
+	d->T.mode_partner = (const int8_t *)(base + off_mp);
+	d->T.mode_role = base + off_mr;
+	d->T.pair_coupling = pair_coupling ? 1u : 0u;
 	d->T.sid = nullptr;
 	d->T.ch = (uint32_t)ch;
 	d->T.fstride = floor_stride_of(s);
@@ -899,6 +925,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	};
 	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
 	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
+	const size_t o_seg = slice(max_packets * sizeof(LwSegment));
 	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
 	b->slab_bytes = off;
 	bool ok = hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
@@ -911,6 +938,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		b->h_items = (LwFastItem *)H(o_items), b->d_items = (LwFastItem *)D(o_items);
 		b->h_halo_items = (LwFastItem *)H(o_halo), b->d_halo_items = (LwFastItem *)D(o_halo);
 		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
+		b->h_seg = (LwSegment *)H(o_seg), b->d_seg = (LwSegment *)D(o_seg);
 		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
 		if (d->any_floor0)
 			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
@@ -1253,6 +1281,43 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->out_elems = out_off;
 	b->alg_bytes = alg;
 
+	// ---- workgroups of the fused small-block kernel: runs of consecutive entries of the overlap-add list that are consecutive
+	// packets of one stream, cut at 16 / ch members (one wave per member and channel).  Used when the batch has small generic
+	// blocks, every coupling step is a disjoint pair and a packet's channels fit one workgroup -- and only on request
+	// (LW_SMALL_FUSED=1): measured slower than the three generic kernels so far (lw_kernels.hip); otherwise those run as
+	// before (b->n_seg == 0).
+	b->n_seg = 0;
+	if (b->n_gen_small && d->T.pair_coupling && ch <= 8 && !b->force_generic && getenv("LW_SMALL_FUSED")) {
+		const uint32_t *e = b->h_gen + 2 * b->max_packets;
+		const uint32_t ppw = lw_small_fused_members((uint32_t)ch);
+		auto small_generic = [&](const LwPacketRec &r) { return !(r.flags & LW_RF_FAST) && r.bs <= LW_SMALL_BS; };
+		uint32_t start = 0;
+		auto close = [&](uint32_t end) {
+			if (end == start)
+				return;
+			LwSegment &sg = b->h_seg[b->n_seg++];
+			sg.first = start;
+			sg.count = (uint16_t)(end - start);
+			const int32_t p = b->h_recs[e[start]].prev;
+			sg.halo = (p >= 0 && small_generic(b->h_recs[p])) ? 1 : 0;
+			start = end;
+		};
+		// (a segment whose first member's predecessor is a small block of another segment recomputes that block on the
+		// waves of one member slot: such a segment holds ppw - 1 members, and at least one)
+		auto cap_of = [&](uint32_t first) {
+			const int32_t p = b->h_recs[e[first]].prev;
+			const bool halo = p >= 0 && small_generic(b->h_recs[p]);
+			return halo ? std::max(1u, ppw - 1) : ppw;
+		};
+		uint32_t cap = b->n_gen_ola ? cap_of(0) : ppw;
+		for (uint32_t i = 1; i < b->n_gen_ola; i++)
+			if (b->h_recs[e[i]].prev != (int32_t)e[i - 1] || i - start == cap) {
+				close(i);
+				cap = cap_of(i);
+			}
+		close(b->n_gen_ola);
+	}
+
 	// ---- work plan of the specialised kernel: items sorted by stream so that consecutive packets of a
 	// stream sit in consecutive items; a workgroup works through a chunk of rounds * per_round consecutive
 	// items and hands right halves over in LDS; a predecessor outside the chunk is recomputed by the halo pre-pass
@@ -1272,13 +1337,18 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		if (!std::is_sorted(b->fast_slot.begin(), b->fast_slot.end())) // (callers usually list their streams one after the other)
 			std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
 					[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
-		const uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
+		uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
 		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
 		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
 		uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
-		if (const char *e = getenv("LW_FAST_ROUNDS")) // test hook: force the number of rounds per workgroup
+		if (const char *e = getenv("LW_FAST_ROUNDS")) { // test hook: force the number of rounds per workgroup
 			rounds = (uint32_t)std::min(LW_FAST_MAX_ROUNDS, std::max(1, atoi(e)));
+		} else if (rounds == 1) {
+			// fewer packets than one full round per CU (the long blocks of a mixed short/long batch, a small batch): fewer
+			// packets per workgroup, so that every CU gets some (1 117 long packets in chunks of 16 kept 186 of 256 CUs idle)
+			per_round = (uint32_t)std::min<size_t>(per_round, std::max<size_t>(1, (nf + d->n_cus - 1) / std::max(1, d->n_cus)));
+		}
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
 		b->fast_rounds = rounds;
@@ -1366,6 +1436,8 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	if (b->n_gen_ola)
 		HIP_TRY(hipMemcpyAsync(b->d_gen + 2 * b->max_packets, b->h_gen + 2 * b->max_packets, b->n_gen_ola * sizeof(uint32_t),
 					hipMemcpyHostToDevice, st));
+	if (b->n_seg)
+		HIP_TRY(hipMemcpyAsync(b->d_seg, b->h_seg, b->n_seg * sizeof(LwSegment), hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
@@ -1420,7 +1492,15 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		lw_launch_residue_vq(d->T, d->V, B, st, b->max_n, d->vq_book_ends.data(), d->vq_book_ends.size());
 		b->last_kernels = "k_residue_vq,";
 	}
-	if (run_generic) {
+	const bool fused_small = run_generic && !all_generic && !tap && b->n_seg > 0;
+	B.seg = fused_small ? b->d_seg : nullptr;
+	B.n_seg = fused_small ? b->n_seg : 0;
+	if (fused_small) {
+		if (b->n_gen_large) { // large generic blocks still go through k_decouple / k_imdct_generic into B.td
+			lw_launch_generic_imdct_large(d->T, B, st, b->max_n, d->any_coupling);
+			b->last_kernels += d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
+		}
+	} else if (run_generic) {
 		lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic);
 		b->last_kernels += d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 	}
@@ -1446,7 +1526,10 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		lw_launch_long(d->T, B, L, d_out, b->fmt, st);
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
 	}
-	if (run_generic) {
+	if (fused_small) {
+		lw_launch_small_fused(d->T, B, d_out, b->fmt, st, b->max_n);
+		b->last_kernels += "k_small_fused,";
+	} else if (run_generic) {
 		lw_launch_generic_ola(d->T, B, d_out, b->fmt, st, all_generic);
 		b->last_kernels += "k_ola_generic,";
 	}

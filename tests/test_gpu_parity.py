@@ -191,7 +191,7 @@ def test_batch_many_streams_matches_oracle(name):
                 assert np.array_equal(t.view(np.uint32), ref.view(np.uint32)), key
         for s in range(n_streams):
             assert np.array_equal(pwrs[s].data().view(np.uint32), o_pwrs[s].data(ch).view(np.uint32))
-    assert "k_imdct_generic" in batch.last_kernels or "k_long" in batch.last_kernels
+    assert any(k in batch.last_kernels for k in ("k_imdct_generic", "k_long", "k_small_fused"))
 
 
 def _decode_batch(setup, items_streams, fmt="i16", force_generic=False, batch=None):
@@ -392,3 +392,62 @@ def test_long_mixed_single_stream_in_one_batch(name, pattern, fmt):
         else:
             assert np.array_equal(got[i], want), i
     assert np.array_equal(pwr.data().view(np.uint32), o_pwr.data(ch).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", sorted(ALL_SETUPS))
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_fused_small_block_kernel_equals_three_kernel_path(name, fmt, monkeypatch):
+    """k_small_fused (inverse coupling, floor, IMDCT, window / overlap-add of short blocks and of the long blocks next to them
+    in one launch; segments of consecutive packets with LDS hand-over, halo recomputation at segment starts) against the
+    oracle AND against the three generic kernels it replaces, on streams interleaved round-robin (every segment then starts
+    with a halo) and stream-major (long segments), with unused floors and packets cut short."""
+    from lewton_amd.batch import Batch
+    setup = ALL_SETUPS[name]()
+    audio, ident, st = _product(setup)
+    o_id, o_st = oracle_headers(setup)
+    dec = audio.decoder_for(ident, st)
+    ch = setup.channels
+    n_streams, per = 6, 26
+    streams = [sg.make_stream(setup, "LSSSSSSSSSSLLSSL", per, seed=40 + s, p_floor_unused=0.06) for s in range(n_streams)]
+    for s in range(n_streams):
+        streams[s][7 + s] = streams[s][7 + s][: max(4, len(streams[s][7 + s]) // 2)]
+    ofmt = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}[fmt]
+    for order in ("stream_major", "round_robin"):
+        if order == "stream_major":
+            items = [(streams[s][t], s) for s in range(n_streams) for t in range(per)]
+        else:
+            items = [(streams[s][t], s) for t in range(per) for s in range(n_streams)]
+        outs = {}
+        for fused in (True, False):
+            if fused:
+                monkeypatch.setenv("LW_SMALL_FUSED", "1")
+            else:
+                monkeypatch.delenv("LW_SMALL_FUSED", raising=False)
+            pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+            b = Batch(dec, len(items), fmt)
+            res = b.entropy([(p, pwrs[s]) for p, s in items], n_threads=2)
+            b.upload()
+            outs[fused] = (b.split(b.synth_to_host(), ch), res, b.last_kernels, pwrs)
+        got, res, kernels, pwrs = outs[True]
+        ref, _res2, kernels2, pwrs2 = outs[False]
+        if setup.channels <= 8:
+            assert "k_small_fused" in kernels and "k_ola_generic" not in kernels, kernels
+        assert "k_small_fused" not in kernels2 and "k_ola_generic" in kernels2, kernels2
+        opws = [po.Pwr() for _ in range(n_streams)]
+        for i, (p, s) in enumerate(items):
+            try:
+                want = po.read_audio_packet(o_id, o_st, p, opws[s], ofmt)
+                rc = 0
+            except po.OracleError as e:
+                rc = e.code
+            assert res[i][0] == rc, (order, i)
+            if rc:
+                continue
+            for g in (got[i], ref[i]):
+                assert g.size == want.size, (order, i)
+                if fmt == "f32":
+                    assert np.array_equal(g.reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32)), (order, i)
+                else:
+                    assert np.array_equal(g.reshape(-1), want.reshape(-1)), (order, i)
+        for s in range(n_streams):
+            assert np.array_equal(pwrs[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32))

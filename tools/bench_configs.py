@@ -122,3 +122,8 @@ if "8" in ONLY:
 if "9" in ONLY:
     run("9 stereo long blocks, 2 x packets", sg.stereo_setup(44100, 8, 11), "L", 256, 2 * args.packets // 256,
         "coupled pairs, 2 rounds per workgroup")
+if "10" in ONLY:
+    # BASELINE configs[4] on ONE GPU (the share of an 8-GPU job is 1250 streams; here all 10 000): 4 consecutive packets of
+    # every stream per launch = 40 000 packets per launch, state through the HBM state pool between launches
+    run("5b 10 000 independent streams x 4 packets per launch", sg.stereo_setup(44100, 8, 11), "L", 10000, 4,
+        "configs[4] stepping: 16 launches of this shape = 10 000 streams x 64 packets")
