@@ -1,0 +1,129 @@
+// Internals shared by the translation units of the runtime (lw_runtime.cpp: headers, device context, PreviousWindowRight;
+// lw_batch.cpp: batches -- host entropy stage, work plan, upload, launches; lw_packet.cpp: the drop-in single-packet call).
+// Product code, not part of the C ABI.
+#pragma once
+
+#include "../../include/lewton_amd.h"
+
+#include "lw_entropy.hpp"
+#include "lw_fast.hpp"
+#include "lw_host.hpp"
+#include "lw_kernels.hpp"
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// thread-local text of the last HIP error (lw_last_device_error)
+bool lw_hip_ok(hipError_t e, const char *what);
+void lw_set_device_error(const std::string &msg);
+#define HIP_TRY(expr)                        \
+	do {                                     \
+		if (!lw_hip_ok((expr), #expr))       \
+			return LW_ERR_DEVICE;            \
+	} while (0)
+
+struct lw_ident {
+	std::shared_ptr<lw::Ident> p;
+};
+struct lw_setup {
+	std::shared_ptr<lw::Setup> p;
+};
+struct lw_comment {
+	std::unique_ptr<lw::Comment> p;
+};
+
+struct lw_decoder {
+	std::shared_ptr<lw::Ident> id;
+	std::shared_ptr<lw::Setup> setup;
+	int device = 0;
+	int n_cus = 256;
+	LwDevTables T{};
+	void *d_blob = nullptr; // one allocation holding every table
+	bool any_coupling = false;
+	bool any_floor0 = false; // some floor is of type 0: batches carry explicit floor curves
+	bool symbols_ok = false; // Tier B (device-side inverse VQ) is possible for this stream
+	std::string symbols_why;
+	LwVqTables V{};
+	void *d_vq_blob = nullptr;
+	std::vector<uint32_t> vq_book_ends; // cumulative float offsets of the book tables in V.vq (ascending table size)
+	uint32_t max_posts = 2;
+	std::vector<uint64_t> mode_floor_bytes; // per mode: bytes of floor input over all channels (SURVEY 8(d) accounting)
+	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
+	std::mutex mu;
+	float *d_state = nullptr;
+	size_t state_cap = 0;
+	std::vector<int> free_slots;
+	LwFastPlan fast;               // specialised long-block kernel: eligibility, units, LDS image
+	uint8_t *d_fast_image = nullptr;
+	LwFastUnit *d_fast_units = nullptr;
+	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
+	void *one_out = nullptr; // pinned host output for the single-packet path
+	size_t one_out_bytes = 0;
+};
+
+struct lw_pwr {
+	lw_decoder *dec = nullptr;
+	int slot = -1;
+	bool present = false;
+	uint32_t len = 0;   // per-channel length
+	uint8_t parity = 0; // which of the two buffers holds the valid state
+};
+
+struct lw_batch {
+	lw_decoder *dec = nullptr;
+	size_t max_packets = 0;
+	int fmt = 0;
+	uint8_t *h_slab = nullptr, *d_slab = nullptr; // all host->device buffers below are slices of these
+	size_t slab_bytes = 0;
+	LwPacketRec *h_recs = nullptr;
+	uint16_t *h_floor = nullptr;
+	float *h_res = nullptr;
+	float *h_fcurve = nullptr, *d_fcurve = nullptr; // explicit floor curves (floor 0), layout of the residues
+	// packets of the generic kernels, by size class (block size <= / > 2^9): dense launch grids instead of 8192
+	// workgroups that mostly find out they have nothing to do
+	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
+	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
+	LwSegment *h_seg = nullptr, *d_seg = nullptr; // workgroups of the fused small-block kernel over the overlap-add list
+	uint32_t n_seg = 0;
+	bool has_tdonly = false; // the specialised kernel's work list contains LW_RF_TDONLY packets
+	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
+	bool symbols = false;
+	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
+	size_t sym_cap_words = 0, sym_words = 0;
+	LwPacketRec *d_recs = nullptr;
+	uint16_t *d_floor = nullptr;
+	float *d_res = nullptr;
+	float *d_decoupled = nullptr, *d_td = nullptr, *d_tap = nullptr;
+	void *d_out = nullptr;
+	size_t d_out_elems = 0;
+	LwFastItem *h_items = nullptr, *d_items = nullptr;           // [max_packets] main pass
+	LwFastItem *h_halo_items = nullptr, *d_halo_items = nullptr; // [max_packets] halo pre-pass
+	float *d_halo = nullptr;
+	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
+	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
+	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = 1;
+	// (debug: LW_PACE_GROUP=<waves per pacing group> overrides)
+	size_t n = 0, res_floats = 0, out_elems = 0;
+	uint32_t max_n = 0;
+	bool has_generic = false, has_fast = false, force_generic = false;
+	std::vector<lw_packet_result> results;
+	uint64_t alg_bytes = 0;
+	std::string last_kernels;
+	std::vector<lw::Prologue> prologues;
+	std::vector<int> status;
+	std::vector<int32_t> slot_last; // per state slot: last ok packet index in this batch (-1 none)
+	std::vector<uint32_t> slot_seen; // per state slot: epoch of the batch that last touched it
+	uint32_t epoch = 0;
+	std::vector<lw_pwr *> touched;
+};
+
+
+inline size_t lw_elem_size(int fmt)
+{
+	return fmt == LW_FMT_F32_PLANAR ? 4 : 2;
+}
+int lw_decoder_set_device(const lw_decoder *d);
+// grow the state pool to at least `slots` (caller holds d->mu)
+int lw_grow_state(lw_decoder *d, size_t slots);

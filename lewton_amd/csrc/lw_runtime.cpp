@@ -1,16 +1,12 @@
 // Runtime + C ABI of the MI355X audio-packet decode path (product code, compiled with hipcc).
 //
-// Implements include/lewton_amd.h: header objects, the device context (tables in HBM), the
-// device-resident PreviousWindowRight pool, batches with pinned staging, and the drop-in
-// single-packet call.  There is no CPU fallback for the synthesis stage: without a usable GPU every
+// Implements include/lewton_amd.h: header objects, the device context (tables in HBM) and the device-resident
+// PreviousWindowRight pool.  Batches live in lw_batch.cpp, the drop-in single-packet call in lw_packet.cpp, the staging
+// ring in lw_ring.cpp, the stream sharder in lw_shard.cpp, the worker pool in lw_pool.cpp.  There is no CPU fallback for the synthesis stage: without a usable GPU every
 // device call returns LW_ERR_DEVICE.
 #include "../../include/lewton_amd.h"
 
-#include "lw_entropy.hpp"
-#include "lw_fast.hpp"
-#include "lw_host.hpp"
-#include "lw_kernels.hpp"
-#include "lw_pool.hpp"
+#include "lw_internal.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -26,14 +22,13 @@
 #include <vector>
 
 #define LW_ERR_UNSUPPORTED_STREAM LW_AUDIO_BAD_FORMAT
-// packets a worker claims at a time: small enough that 64 threads share a 4096-packet batch evenly to the end
-#define LW_ENTROPY_CHUNK 4
 
 namespace {
-
 thread_local std::string g_dev_err;
+extern const float kInverseDbTable[256];
+} // namespace
 
-bool hip_ok(hipError_t e, const char *what)
+bool lw_hip_ok(hipError_t e, const char *what)
 {
 	if (e == hipSuccess)
 		return true;
@@ -42,126 +37,18 @@ bool hip_ok(hipError_t e, const char *what)
 	return false;
 }
 
-#define HIP_TRY(expr)                        \
-	do {                                     \
-		if (!hip_ok((expr), #expr))          \
-			return LW_ERR_DEVICE;            \
-	} while (0)
-
-extern const float kInverseDbTable[256];
-
-} // namespace
-
-struct lw_ident {
-	std::shared_ptr<lw::Ident> p;
-};
-struct lw_setup {
-	std::shared_ptr<lw::Setup> p;
-};
-struct lw_comment {
-	std::unique_ptr<lw::Comment> p;
-};
-
-struct lw_decoder {
-	std::shared_ptr<lw::Ident> id;
-	std::shared_ptr<lw::Setup> setup;
-	int device = 0;
-	int n_cus = 256;
-	LwDevTables T{};
-	void *d_blob = nullptr; // one allocation holding every table
-	bool any_coupling = false;
-	bool any_floor0 = false; // some floor is of type 0: batches carry explicit floor curves
-	bool symbols_ok = false; // Tier B (device-side inverse VQ) is possible for this stream
-	std::string symbols_why;
-	LwVqTables V{};
-	void *d_vq_blob = nullptr;
-	std::vector<uint32_t> vq_book_ends; // cumulative float offsets of the book tables in V.vq (ascending table size)
-	uint32_t max_posts = 2;
-	std::vector<uint64_t> mode_floor_bytes; // per mode: bytes of floor input over all channels (SURVEY 8(d) accounting)
-	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
-	std::mutex mu;
-	float *d_state = nullptr;
-	size_t state_cap = 0;
-	std::vector<int> free_slots;
-	LwFastPlan fast;               // specialised long-block kernel: eligibility, units, LDS image
-	uint8_t *d_fast_image = nullptr;
-	LwFastUnit *d_fast_units = nullptr;
-	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
-	void *one_out = nullptr; // pinned host output for the single-packet path
-	size_t one_out_bytes = 0;
-};
-
-struct lw_pwr {
-	lw_decoder *dec = nullptr;
-	int slot = -1;
-	bool present = false;
-	uint32_t len = 0;   // per-channel length
-	uint8_t parity = 0; // which of the two buffers holds the valid state
-};
-
-struct lw_batch {
-	lw_decoder *dec = nullptr;
-	size_t max_packets = 0;
-	int fmt = 0;
-	uint8_t *h_slab = nullptr, *d_slab = nullptr; // all host->device buffers below are slices of these
-	size_t slab_bytes = 0;
-	LwPacketRec *h_recs = nullptr;
-	uint16_t *h_floor = nullptr;
-	float *h_res = nullptr;
-	float *h_fcurve = nullptr, *d_fcurve = nullptr; // explicit floor curves (floor 0), layout of the residues
-	// packets of the generic kernels, by size class (block size <= / > 2^9): dense launch grids instead of 8192
-	// workgroups that mostly find out they have nothing to do
-	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
-	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
-	LwSegment *h_seg = nullptr, *d_seg = nullptr; // workgroups of the fused small-block kernel over the overlap-add list
-	uint32_t n_seg = 0;
-	bool has_tdonly = false; // the specialised kernel's work list contains LW_RF_TDONLY packets
-	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
-	bool symbols = false;
-	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
-	size_t sym_cap_words = 0, sym_words = 0;
-	LwPacketRec *d_recs = nullptr;
-	uint16_t *d_floor = nullptr;
-	float *d_res = nullptr;
-	float *d_decoupled = nullptr, *d_td = nullptr, *d_tap = nullptr;
-	void *d_out = nullptr;
-	size_t d_out_elems = 0;
-	LwFastItem *h_items = nullptr, *d_items = nullptr;           // [max_packets] main pass
-	LwFastItem *h_halo_items = nullptr, *d_halo_items = nullptr; // [max_packets] halo pre-pass
-	float *d_halo = nullptr;
-	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
-	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
-	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = 1;
-	// (debug: LW_PACE_GROUP=<waves per pacing group> overrides)
-	size_t n = 0, res_floats = 0, out_elems = 0;
-	uint32_t max_n = 0;
-	bool has_generic = false, has_fast = false, force_generic = false;
-	std::vector<lw_packet_result> results;
-	uint64_t alg_bytes = 0;
-	std::string last_kernels;
-	std::vector<lw::Prologue> prologues;
-	std::vector<int> status;
-	std::vector<int32_t> slot_last; // per state slot: last ok packet index in this batch (-1 none)
-	std::vector<uint32_t> slot_seen; // per state slot: epoch of the batch that last touched it
-	uint32_t epoch = 0;
-	std::vector<lw_pwr *> touched;
-};
-
-namespace {
-
-size_t elem_size(int fmt)
+void lw_set_device_error(const std::string &msg)
 {
-	return fmt == LW_FMT_F32_PLANAR ? 4 : 2;
+	g_dev_err = msg;
 }
 
-int decoder_set_device(const lw_decoder *d)
+int lw_decoder_set_device(const lw_decoder *d)
 {
 	HIP_TRY(hipSetDevice(d->device));
 	return LW_OK;
 }
 
-// grow the state pool to at least `slots` (caller holds d->mu)
-int grow_state(lw_decoder *d, size_t slots)
+int lw_grow_state(lw_decoder *d, size_t slots)
 {
 	if (slots <= d->state_cap)
 		return LW_OK;
@@ -181,7 +68,6 @@ int grow_state(lw_decoder *d, size_t slots)
 	return LW_OK;
 }
 
-} // namespace
 
 extern "C" {
 
@@ -496,7 +382,7 @@ int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bi
 int lw_device_count(void)
 {
 	int n = 0;
-	if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount"))
+	if (!lw_hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount"))
 		return 0;
 	return n;
 }
@@ -518,8 +404,8 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 		return nullptr;
 	}
 	int ndev = 0;
-	if (!hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || device < 0 || device >= ndev ||
-			!hip_ok(hipSetDevice(device), "hipSetDevice")) {
+	if (!lw_hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || device < 0 || device >= ndev ||
+			!lw_hip_ok(hipSetDevice(device), "hipSetDevice")) {
 		if (g_dev_err.empty())
 			g_dev_err = "no such HIP device";
 		*err = LW_ERR_DEVICE;
@@ -616,8 +502,8 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	const size_t off_mp = put(mode_partner.data(), mode_partner.size());
 	const size_t off_mr = put(mode_role.data(), mode_role.size());
 
-	if (!hip_ok(hipMalloc(&d->d_blob, blob.size()), "hipMalloc(tables)") ||
-			!hip_ok(hipMemcpy(d->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(tables)")) {
+	if (!lw_hip_ok(hipMalloc(&d->d_blob, blob.size()), "hipMalloc(tables)") ||
+			!lw_hip_ok(hipMemcpy(d->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(tables)")) {
 		*err = LW_ERR_DEVICE;
 		if (d->d_blob)
 			(void)hipFree(d->d_blob);
@@ -718,8 +604,8 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			const size_t o_vq = putv(pool.data(), pool.size() * 4), o_bo = putv(boff.data(), boff.size() * 4);
 			const size_t o_bd = putv(bdims.data(), bdims.size() * 2), o_sd = putv(sd.data(), sd.size() * sizeof(LwSubmapDesc));
 			const size_t o_ch = putv(cm.data(), cm.size() * sizeof(LwChanMap));
-			if (!hip_ok(hipMalloc(&d->d_vq_blob, vb.size()), "hipMalloc(vq tables)") ||
-					!hip_ok(hipMemcpy(d->d_vq_blob, vb.data(), vb.size(), hipMemcpyHostToDevice), "hipMemcpy(vq tables)")) {
+			if (!lw_hip_ok(hipMalloc(&d->d_vq_blob, vb.size()), "hipMalloc(vq tables)") ||
+					!lw_hip_ok(hipMemcpy(d->d_vq_blob, vb.data(), vb.size(), hipMemcpyHostToDevice), "hipMemcpy(vq tables)")) {
 				*err = LW_ERR_DEVICE;
 				(void)hipFree(d->d_blob);
 				return nullptr;
@@ -736,11 +622,11 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	if (d->fast.eligible) {
 		std::memcpy(d->fast.image.data() + d->fast.off.inv_db, kInverseDbTable, sizeof(float) * 256);
 		const size_t ub = d->fast.units.size() * sizeof(LwFastUnit);
-		if (!hip_ok(hipMalloc((void **)&d->d_fast_image, d->fast.image.size()), "hipMalloc(fast image)") ||
-				!hip_ok(hipMemcpy(d->d_fast_image, d->fast.image.data(), d->fast.image.size(), hipMemcpyHostToDevice),
+		if (!lw_hip_ok(hipMalloc((void **)&d->d_fast_image, d->fast.image.size()), "hipMalloc(fast image)") ||
+				!lw_hip_ok(hipMemcpy(d->d_fast_image, d->fast.image.data(), d->fast.image.size(), hipMemcpyHostToDevice),
 					"hipMemcpy(fast image)") ||
-				!hip_ok(hipMalloc((void **)&d->d_fast_units, ub), "hipMalloc(fast units)") ||
-				!hip_ok(hipMemcpy(d->d_fast_units, d->fast.units.data(), ub, hipMemcpyHostToDevice), "hipMemcpy(fast units)")) {
+				!lw_hip_ok(hipMalloc((void **)&d->d_fast_units, ub), "hipMalloc(fast units)") ||
+				!lw_hip_ok(hipMemcpy(d->d_fast_units, d->fast.units.data(), ub, hipMemcpyHostToDevice), "hipMemcpy(fast units)")) {
 			*err = LW_ERR_DEVICE;
 			(void)hipFree(d->d_blob);
 			return nullptr;
@@ -795,7 +681,7 @@ lw_pwr *lw_pwr_new(lw_decoder *d)
 	std::lock_guard<std::mutex> g(d->mu);
 	if (hipSetDevice(d->device) != hipSuccess)
 		return nullptr;
-	if (d->free_slots.empty() && grow_state(d, d->state_cap + 1) != LW_OK)
+	if (d->free_slots.empty() && lw_grow_state(d, d->state_cap + 1) != LW_OK)
 		return nullptr;
 	auto *p = new lw_pwr;
 	p->dec = d;
@@ -854,8 +740,8 @@ lw_pwr *lw_pwr_clone(const lw_pwr *p)
 		lw_decoder *d = p->dec;
 		std::lock_guard<std::mutex> g(d->mu);
 		const size_t per = (size_t)2 * d->T.state_stride;
-		if (!hip_ok(hipDeviceSynchronize(), "sync") ||
-				!hip_ok(hipMemcpy(d->d_state + (size_t)q->slot * per, d->d_state + (size_t)p->slot * per,
+		if (!lw_hip_ok(hipDeviceSynchronize(), "sync") ||
+				!lw_hip_ok(hipMemcpy(d->d_state + (size_t)q->slot * per, d->d_state + (size_t)p->slot * per,
 							per * sizeof(float), hipMemcpyDeviceToDevice),
 					"hipMemcpy(state clone)")) {
 			q->present = false;
@@ -882,101 +768,13 @@ int lw_pwr_copy_to_host(const lw_pwr *p, float *dst)
 	if (!p->present)
 		return LW_ERR_CAPACITY;
 	lw_decoder *d = p->dec;
-	if (int rc = decoder_set_device(d))
+	if (int rc = lw_decoder_set_device(d))
 		return rc;
 	HIP_TRY(hipDeviceSynchronize());
 	const float *src = d->d_state + ((size_t)p->slot * 2 + p->parity) * d->T.state_stride;
 	HIP_TRY(hipMemcpy2D(dst, p->len * sizeof(float), src, d->T.state_chan_stride * sizeof(float), p->len * sizeof(float),
 				d->T.ch, hipMemcpyDeviceToHost));
 	return LW_OK;
-}
-
-// ---- batches ----------------------------------------------------------------------------------
-lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
-{
-	int dummy;
-	if (!err)
-		err = &dummy;
-	*err = LW_OK;
-	if (!d || max_packets == 0 || fmt < 0 || fmt > 2) {
-		*err = LW_ERR_NULL_ARG;
-		return nullptr;
-	}
-	if (decoder_set_device(d)) {
-		*err = LW_ERR_DEVICE;
-		return nullptr;
-	}
-	auto b = std::make_unique<lw_batch>();
-	b->dec = d;
-	b->max_packets = max_packets;
-	b->fmt = fmt;
-	const size_t ch = d->T.ch, half1 = d->T.state_chan_stride;
-	const size_t rec_b = max_packets * sizeof(LwPacketRec);
-	const size_t fl_b = max_packets * ch * d->T.fstride * sizeof(uint16_t);
-	const size_t res_b = max_packets * ch * half1 * sizeof(float);
-	// every host->device buffer of the batch is a slice of ONE pinned slab mirrored by ONE device slab at the same
-	// offsets: a small batch (the single-packet path of lw_read_audio_packet above all) goes up with one hipMemcpyAsync
-	// instead of five
-	size_t off = 0;
-	auto slice = [&](size_t bytes) {
-		const size_t at = off;
-		off = (off + bytes + 255) & ~(size_t)255;
-		return at;
-	};
-	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
-	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
-	const size_t o_seg = slice(max_packets * sizeof(LwSegment));
-	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
-	b->slab_bytes = off;
-	bool ok = hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
-		hip_ok(hipMalloc((void **)&b->d_slab, off), "hipMalloc(batch records)");
-	if (ok) {
-		auto H = [&](size_t o) { return b->h_slab + o; };
-		auto D = [&](size_t o) { return b->d_slab + o; };
-		b->h_recs = (LwPacketRec *)H(o_recs), b->d_recs = (LwPacketRec *)D(o_recs);
-		b->h_floor = (uint16_t *)H(o_floor), b->d_floor = (uint16_t *)D(o_floor);
-		b->h_items = (LwFastItem *)H(o_items), b->d_items = (LwFastItem *)D(o_items);
-		b->h_halo_items = (LwFastItem *)H(o_halo), b->d_halo_items = (LwFastItem *)D(o_halo);
-		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
-		b->h_seg = (LwSegment *)H(o_seg), b->d_seg = (LwSegment *)D(o_seg);
-		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
-		if (d->any_floor0)
-			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
-	}
-	if (!ok) {
-		*err = LW_ERR_DEVICE;
-		lw_batch_destroy(b.release());
-		return nullptr;
-	}
-	b->results.resize(max_packets);
-	b->prologues.resize(max_packets);
-	b->status.resize(max_packets);
-	return b.release();
-}
-
-void lw_batch_destroy(lw_batch *b)
-{
-	if (!b)
-		return;
-	(void)hipSetDevice(b->dec->device);
-	(void)hipDeviceSynchronize();
-	if (b->h_slab)
-		(void)hipHostFree(b->h_slab);
-	if (b->h_sym)
-		(void)hipHostFree(b->h_sym);
-	if (b->h_sym_off)
-		(void)hipHostFree(b->h_sym_off);
-	void *dev[] = {b->d_slab, b->d_sym, b->d_sym_off, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
-	for (void *p : dev)
-		if (p)
-			(void)hipFree(p);
-	delete b;
-}
-
-void lw_batch_set_force_generic(lw_batch *b, int on)
-{
-	if (b)
-		b->force_generic = on != 0;
 }
 
 int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why)
@@ -986,759 +784,6 @@ int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why)
 	return d && d->symbols_ok ? 1 : 0;
 }
 
-int lw_batch_set_residue_on_device(lw_batch *b, int on)
-{
-	if (!b)
-		return LW_ERR_NULL_ARG;
-	if (!on) {
-		b->symbols = false;
-		return LW_OK;
-	}
-	if (!b->dec->symbols_ok)
-		return LW_ERR_UNSUPPORTED;
-	if (int rc = decoder_set_device(b->dec))
-		return rc;
-	if (!b->h_sym_off) {
-		if (!hip_ok(hipHostMalloc((void **)&b->h_sym_off, b->max_packets * sizeof(uint32_t)), "hipHostMalloc(symbol offsets)") ||
-				!hip_ok(hipMalloc((void **)&b->d_sym_off, b->max_packets * sizeof(uint32_t)), "hipMalloc(symbol offsets)"))
-			return LW_ERR_DEVICE;
-	}
-	b->symbols = true;
-	return LW_OK;
-}
-
-size_t lw_batch_size(const lw_batch *b)
-{
-	return b ? b->n : 0;
-}
-
-size_t lw_batch_out_elems(const lw_batch *b)
-{
-	return b ? b->out_elems : 0;
-}
-
-const lw_packet_result *lw_batch_results(const lw_batch *b)
-{
-	return b ? b->results.data() : nullptr;
-}
-
-uint64_t lw_batch_algorithmic_bytes(const lw_batch *b)
-{
-	return b ? b->alg_bytes : 0;
-}
-
-const char *lw_batch_last_kernels(const lw_batch *b)
-{
-	return b ? b->last_kernels.c_str() : "";
-}
-
-int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads)
-{
-	if (!b || (!pkts && n))
-		return LW_ERR_NULL_ARG;
-	if (n > b->max_packets)
-		return LW_ERR_CAPACITY;
-	lw_decoder *d = b->dec;
-	const lw::Ident &id = *d->id;
-	const lw::Setup &s = *d->setup;
-	const size_t ch = d->T.ch, fstride = d->T.fstride;
-	b->n = n;
-
-	// pass 1 (sequential, cheap): prologues -> block sizes -> residue offsets
-	size_t res_off = 0;
-	uint32_t max_n = 0;
-	for (size_t i = 0; i < n; i++) {
-		LwPacketRec &r = b->h_recs[i];
-		std::memset(&r, 0, sizeof(r));
-		r.prev = -1;
-		r.state_out = -1;
-		r.floor_off = (uint32_t)(i * ch * fstride);
-		r.res_off = (uint32_t)res_off;
-		if ((!pkts[i].data && pkts[i].len) || !pkts[i].pwr) {
-			b->status[i] = LW_ERR_NULL_ARG;
-			continue;
-		}
-		if (pkts[i].pwr->dec != d) {
-			b->status[i] = LW_ERR_STATE_MISMATCH;
-			continue;
-		}
-		lw::BitReader br(pkts[i].data, pkts[i].len);
-		b->status[i] = lw::read_prologue(id, s, br, b->prologues[i]);
-		if (b->status[i] == LW_OK) {
-			res_off += ch * (b->prologues[i].n / 2);
-			max_n = std::max(max_n, b->prologues[i].n);
-		}
-	}
-	b->res_floats = res_off;
-	b->max_n = max_n;
-
-	// pass 2 (parallel): entropy decode straight into the pinned staging buffers
-	unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
-	nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n / 8));
-	alignas(128) std::atomic<size_t> next{0}; // (its own cache line: every worker adds to it once per LW_ENTROPY_CHUNK packets)
-	alignas(128) char next_pad[8] = {0};
-	(void)next_pad;
-	// Tier B: a worker reserves room for a packet's symbol block in the pinned pool with one atomic add once the packet
-	// is decoded (block sizes are not known before).  Blocks that no longer fit are parked in the worker's own arena and
-	// gathered after the pool has been enlarged (first batches only).
-	struct SymRef {
-		int32_t arena = -1; // -1: already in the pool at h_sym_off[i]
-		uint32_t off = 0, words = 0;
-	};
-	std::vector<SymRef> sym_ref(b->symbols ? n : 0);
-	std::vector<std::vector<uint32_t>> arenas(b->symbols ? std::max(1u, nt) : 0);
-	std::atomic<unsigned> next_arena{0};
-	std::atomic<size_t> pool_used{0};
-	std::atomic<bool> overflow{false};
-	auto worker = [&]() {
-		// scratch vectors keep their capacity from batch to batch (pool threads are persistent)
-		static thread_local lw::EntropyScratch scr;
-		static thread_local lw::SymbolSink sink;
-		static thread_local std::vector<uint64_t> tmp;
-		const unsigned my = b->symbols ? next_arena.fetch_add(1) : 0;
-		for (;;) {
-			const size_t i0 = next.fetch_add(LW_ENTROPY_CHUNK);
-			if (i0 >= n)
-				break;
-			for (size_t i = i0; i < std::min(n, i0 + LW_ENTROPY_CHUNK); i++) {
-				if (b->status[i] != LW_OK)
-					continue;
-				LwPacketRec &r = b->h_recs[i];
-				if (b->symbols)
-					sink.clear();
-				b->status[i] = lw::entropy_decode(id, s, pkts[i].data, pkts[i].len, b->prologues[i],
-						b->h_floor + r.floor_off, (unsigned)fstride, b->h_res + r.res_off, scr, nullptr,
-						b->h_fcurve ? b->h_fcurve + r.res_off : nullptr, b->symbols ? &sink : nullptr);
-				if (b->symbols && b->status[i] == LW_OK) {
-					sink.sort_by_pass(tmp);
-					SymRef &ref = sym_ref[i];
-					ref.words = 10 + 2 * (uint32_t)sink.ops.size();
-					const size_t at = pool_used.fetch_add(ref.words);
-					uint32_t *w;
-					if (at + ref.words <= b->sym_cap_words) {
-						b->h_sym_off[i] = (uint32_t)at;
-						w = b->h_sym + at;
-					} else {
-						overflow = true;
-						std::vector<uint32_t> &a = arenas[my];
-						ref.arena = (int32_t)my;
-						ref.off = (uint32_t)a.size();
-						a.resize(a.size() + ref.words);
-						w = a.data() + ref.off;
-					}
-					for (int q = 0; q < 9; q++)
-						w[q] = sink.pass_off[q];
-					w[9] = 0;
-					if (!sink.ops.empty())
-						std::memcpy(w + 10, sink.ops.data(), sink.ops.size() * 8);
-				}
-			}
-		}
-	};
-	lw::entropy_pool().run(nt, worker);
-	if (b->symbols) {
-		const size_t total = pool_used.load();
-		if (overflow) {
-			// enlarge the pool, keep what is already in it, append the parked blocks
-			uint32_t *nh = nullptr, *nd = nullptr;
-			const size_t cap = total + total / 2 + 1024;
-			if (!hip_ok(hipHostMalloc((void **)&nh, cap * 4), "hipHostMalloc(symbols)") ||
-					!hip_ok(hipMalloc((void **)&nd, cap * 4), "hipMalloc(symbols)"))
-				return LW_ERR_DEVICE;
-			size_t at = 0;
-			for (size_t i = 0; i < n; i++) {
-				const SymRef &ref = sym_ref[i];
-				if (!ref.words)
-					continue;
-				const uint32_t *src = ref.arena < 0 ? b->h_sym + b->h_sym_off[i] : arenas[ref.arena].data() + ref.off;
-				std::memcpy(nh + at, src, (size_t)ref.words * 4);
-				b->h_sym_off[i] = (uint32_t)at;
-				at += ref.words;
-			}
-			if (b->h_sym)
-				(void)hipHostFree(b->h_sym);
-			if (b->d_sym) {
-				(void)hipDeviceSynchronize();
-				(void)hipFree(b->d_sym);
-			}
-			b->h_sym = nh;
-			b->d_sym = nd;
-			b->sym_cap_words = cap;
-			b->sym_words = at;
-		} else {
-			b->sym_words = total;
-		}
-	}
-
-	// pass 3 (sequential): window geometry, state hand-over, output offsets, error semantics
-	if (b->slot_last.size() < d->state_cap) {
-		b->slot_last.assign(d->state_cap, -1);
-		b->slot_seen.assign(d->state_cap, 0);
-	}
-	b->epoch++;
-	b->touched.clear();
-	b->fast_idx.clear();
-	b->fast_slot.clear();
-	size_t out_off = 0;
-	uint64_t alg = 0;
-	const size_t esz = elem_size(b->fmt);
-	b->has_generic = b->has_fast = false;
-	b->n_gen_small = b->n_gen_large = b->n_gen_ola = 0;
-	b->has_tdonly = false;
-	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
-	for (size_t i = 0; i < n; i++) {
-		LwPacketRec &r = b->h_recs[i];
-		lw_packet_result &res = b->results[i];
-		res.status = b->status[i];
-		res.n_samples = 0;
-		res.out_offset = out_off;
-		r.out_off = (uint32_t)out_off;
-		if (b->status[i] != LW_OK) {
-			r.flags = LW_RF_SKIP;
-			continue;
-		}
-		lw_pwr *pw = pkts[i].pwr;
-		const lw::Prologue &p = b->prologues[i];
-		const lw::WindowInfo w = lw::window_info(id, p.blockflag, p.prev_flag, p.next_flag);
-		r.bs = p.bs;
-		r.mode = p.mode;
-		r.ls = (uint16_t)w.left_start;
-		r.rs = (uint16_t)w.right_start;
-		r.re = (uint16_t)w.right_end;
-		r.flags = (p.blockflag ? LW_RF_LONG : 0) | (w.left_use_bs1 ? LW_RF_SLOPE_BS1 : 0);
-		if (b->slot_seen[pw->slot] != b->epoch) {
-			b->slot_seen[pw->slot] = b->epoch;
-			b->touched.push_back(pw);
-		}
-		if (pw->present) {
-			const uint32_t slope_len = w.left_use_bs1 ? n1h : n0h;
-			if (slope_len < pw->len) {
-				// audio.rs:1107-1111: error after pwr.data.take() -> the state is gone
-				pw->present = false;
-				pw->len = 0;
-				b->slot_last[pw->slot] = -1;
-				res.status = b->status[i] = LW_AUDIO_BAD_FORMAT;
-				r.flags = LW_RF_SKIP;
-				continue;
-			}
-			r.plen = (uint16_t)pw->len;
-			const int32_t last = b->slot_last[pw->slot];
-			if (last >= 0) {
-				r.prev = last;
-			} else {
-				r.prev = -(pw->slot + 2);
-				if (pw->parity)
-					r.flags |= LW_RF_PARITY_IN;
-			}
-			res.n_samples = w.right_start - w.left_start;
-		} else {
-			r.prev = -1; // audio.rs:1140-1152: no previous window -> zero samples
-			r.plen = 0;
-		}
-		// specialised kernel: long block, both neighbours long, stored right part (if any) is a full long half
-		// Other long blocks of an eligible stream (window shapes next to short blocks, a stored right part of another
-		// length) still get floor, decoupling and IMDCT from the specialised kernel, which writes their whole time-domain
-		// block; k_ola_generic does their window / overlap-add / state (LW_RF_TDONLY).
-		if (d->fast.eligible && !b->force_generic && p.blockflag && (d->fast.long_mode_mask[p.mode >> 3] & (1u << (p.mode & 7)))) {
-			r.flags |= LW_RF_FAST;
-			if (!(p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h))) {
-				r.flags |= LW_RF_TDONLY;
-				b->has_tdonly = true;
-			}
-			b->fast_idx.push_back((uint32_t)i);
-			b->fast_slot.push_back((uint32_t)pw->slot);
-		}
-		pw->present = true;
-		pw->len = w.right_end - w.right_start;
-		b->slot_last[pw->slot] = (int32_t)i;
-		out_off += (size_t)res.n_samples * ch;
-		alg += (uint64_t)ch * (p.n / 2) * 4 + 16 + (uint64_t)res.n_samples * ch * esz + d->mode_floor_bytes[p.mode];
-		if (!(r.flags & LW_RF_FAST)) {
-			b->has_generic = true;
-			if (p.bs <= LW_SMALL_BS)
-				b->h_gen[b->n_gen_small++] = (uint32_t)i;
-			else
-				b->h_gen[b->max_packets + b->n_gen_large++] = (uint32_t)i;
-		}
-		if (!(r.flags & LW_RF_FAST) || (r.flags & LW_RF_TDONLY)) {
-			b->has_generic = true; // k_ola_generic has work
-			b->h_gen[2 * b->max_packets + b->n_gen_ola++] = (uint32_t)i;
-		}
-	}
-	// the last ok packet of every stream hands its right part to the stream's state slot
-	for (lw_pwr *pw : b->touched) {
-		const int32_t last = b->slot_last[pw->slot];
-		if (last >= 0) {
-			LwPacketRec &r = b->h_recs[last];
-			r.state_out = pw->slot;
-			const uint8_t outp = pw->parity ^ 1;
-			if (outp)
-				r.flags |= LW_RF_PARITY_OUT;
-			pw->parity = outp;
-		}
-		b->slot_last[pw->slot] = -1;
-	}
-	b->out_elems = out_off;
-	b->alg_bytes = alg;
-
-	// ---- workgroups of the fused small-block kernel: runs of consecutive entries of the overlap-add list that are consecutive
-	// packets of one stream, cut at 16 / ch members (one wave per member and channel).  Used when the batch has small generic
-	// blocks, every coupling step is a disjoint pair and a packet's channels fit one workgroup -- and only on request
-	// (LW_SMALL_FUSED=1): measured slower than the three generic kernels so far (lw_kernels.hip); otherwise those run as
-	// before (b->n_seg == 0).
-	b->n_seg = 0;
-	if (b->n_gen_small && d->T.pair_coupling && ch <= 8 && !b->force_generic && getenv("LW_SMALL_FUSED")) {
-		const uint32_t *e = b->h_gen + 2 * b->max_packets;
-		const uint32_t ppw = lw_small_fused_members((uint32_t)ch);
-		auto small_generic = [&](const LwPacketRec &r) { return !(r.flags & LW_RF_FAST) && r.bs <= LW_SMALL_BS; };
-		uint32_t start = 0;
-		auto close = [&](uint32_t end) {
-			if (end == start)
-				return;
-			LwSegment &sg = b->h_seg[b->n_seg++];
-			sg.first = start;
-			sg.count = (uint16_t)(end - start);
-			const int32_t p = b->h_recs[e[start]].prev;
-			sg.halo = (p >= 0 && small_generic(b->h_recs[p])) ? 1 : 0;
-			start = end;
-		};
-		// (a segment whose first member's predecessor is a small block of another segment recomputes that block on the
-		// waves of one member slot: such a segment holds ppw - 1 members, and at least one)
-		auto cap_of = [&](uint32_t first) {
-			const int32_t p = b->h_recs[e[first]].prev;
-			const bool halo = p >= 0 && small_generic(b->h_recs[p]);
-			return halo ? std::max(1u, ppw - 1) : ppw;
-		};
-		uint32_t cap = b->n_gen_ola ? cap_of(0) : ppw;
-		for (uint32_t i = 1; i < b->n_gen_ola; i++)
-			if (b->h_recs[e[i]].prev != (int32_t)e[i - 1] || i - start == cap) {
-				close(i);
-				cap = cap_of(i);
-			}
-		close(b->n_gen_ola);
-	}
-
-	// ---- work plan of the specialised kernel: items sorted by stream so that consecutive packets of a
-	// stream sit in consecutive items; a workgroup works through a chunk of rounds * per_round consecutive
-	// items and hands right halves over in LDS; a predecessor outside the chunk is recomputed by the halo pre-pass
-	b->n_items = b->n_halo_items = 0;
-	b->has_fast = !b->fast_idx.empty();
-	if (b->has_fast) {
-		const size_t nf = b->fast_idx.size();
-		for (size_t i = 0; i < n; i++) { // generic successors of fast packets read the td block
-			const LwPacketRec &r = b->h_recs[i];
-			const bool ola_generic = !(r.flags & LW_RF_FAST) || (r.flags & LW_RF_TDONLY);
-			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
-				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
-		}
-		b->fast_order.resize(nf);
-		for (size_t k = 0; k < nf; k++)
-			b->fast_order[k] = (uint32_t)k;
-		if (!std::is_sorted(b->fast_slot.begin(), b->fast_slot.end())) // (callers usually list their streams one after the other)
-			std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
-					[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
-		uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
-		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
-		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
-		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
-		uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
-		if (const char *e = getenv("LW_FAST_ROUNDS")) { // test hook: force the number of rounds per workgroup
-			rounds = (uint32_t)std::min(LW_FAST_MAX_ROUNDS, std::max(1, atoi(e)));
-		} else if (rounds == 1) {
-			// fewer packets than one full round per CU (the long blocks of a mixed short/long batch, a small batch): fewer
-			// packets per workgroup, so that every CU gets some (1 117 long packets in chunks of 16 kept 186 of 256 CUs idle)
-			per_round = (uint32_t)std::min<size_t>(per_round, std::max<size_t>(1, (nf + d->n_cus - 1) / std::max(1, d->n_cus)));
-		}
-		const uint32_t chunk = per_round * rounds;
-		b->fast_per_round = per_round;
-		b->fast_rounds = rounds;
-		b->fast_dense = 1;
-		auto fill = [&](LwFastItem &it, uint32_t idx) {
-			const LwPacketRec &r = b->h_recs[idx];
-			std::memset(&it, 0, sizeof(it));
-			it.res_off = r.res_off;
-			it.floor_off = r.floor_off;
-			it.out_off = r.out_off;
-			it.state_out = r.state_out;
-			it.mode = r.mode;
-			it.flags = (uint8_t)(r.flags & (LW_RF_PARITY_IN | LW_RF_PARITY_OUT | LW_RF_WRITE_TD | LW_RF_TDONLY));
-			if (r.flags & LW_RF_TDONLY) {
-				it.flags |= LW_RF_WRITE_TD; // left AND right half go to the td block
-				it.state_out = -1;          // the state slot is written by k_ola_generic
-			}
-			it.pkt = idx;
-		};
-		for (size_t k = 0; k < nf; k++) {
-			const uint32_t idx = b->fast_idx[b->fast_order[k]];
-			const LwPacketRec &r = b->h_recs[idx];
-			LwFastItem &it = b->h_items[k];
-			fill(it, idx);
-			if (it.res_off != (uint32_t)(k * ch * n1h) || it.floor_off != (uint32_t)(k * ch * fstride))
-				b->fast_dense = 0;
-			if (r.prev == -1 || (r.flags & LW_RF_TDONLY)) {
-				it.src_kind = LW_SRC_NONE; // (a TD-only packet is overlapped later, by k_ola_generic)
-			} else if (r.prev <= -2) {
-				it.src_kind = LW_SRC_STATE;
-				it.src_arg = (uint32_t)(-(r.prev + 2));
-			} else if (b->h_recs[r.prev].flags & LW_RF_FAST) {
-				if ((k % chunk) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev) {
-					it.src_kind = LW_SRC_LDS;
-					b->h_items[k - 1].flags |= LW_IF_NEXT_LDS;
-				} else {
-					it.src_kind = LW_SRC_HALO;
-					it.src_arg = (uint32_t)b->n_halo_items;
-					LwFastItem &h = b->h_halo_items[b->n_halo_items];
-					fill(h, (uint32_t)r.prev);
-					h.state_out = -1;
-					h.halo_out = (uint32_t)b->n_halo_items++;
-				}
-			} else {
-				it.src_kind = LW_SRC_TD;
-				it.src_arg = 2u * b->h_recs[r.prev].res_off;
-			}
-		}
-		b->n_items = nf;
-	}
-	return LW_OK;
-}
-
-int lw_batch_upload(lw_batch *b, void *hip_stream)
-{
-	if (!b)
-		return LW_ERR_NULL_ARG;
-	if (int rc = decoder_set_device(b->dec))
-		return rc;
-	hipStream_t st = (hipStream_t)hip_stream;
-	const size_t ch = b->dec->T.ch;
-	if (b->n == 0)
-		return LW_OK;
-	if (b->slab_bytes <= 64 * 1024 && !b->symbols) { // small batch: the whole slab in one copy
-		HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_slab, b->slab_bytes, hipMemcpyHostToDevice, st));
-		return LW_OK;
-	}
-	HIP_TRY(hipMemcpyAsync(b->d_recs, b->h_recs, b->n * sizeof(LwPacketRec), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(b->d_floor, b->h_floor, b->n * ch * b->dec->T.fstride * sizeof(uint16_t),
-				hipMemcpyHostToDevice, st));
-	if (b->res_floats && !b->symbols)
-		HIP_TRY(hipMemcpyAsync(b->d_res, b->h_res, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
-	if (b->symbols) {
-		HIP_TRY(hipMemcpyAsync(b->d_sym_off, b->h_sym_off, b->n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-		if (b->sym_words)
-			HIP_TRY(hipMemcpyAsync(b->d_sym, b->h_sym, b->sym_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-	}
-	if (b->res_floats && b->d_fcurve)
-		HIP_TRY(hipMemcpyAsync(b->d_fcurve, b->h_fcurve, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
-	if (b->n_gen_small)
-		HIP_TRY(hipMemcpyAsync(b->d_gen, b->h_gen, b->n_gen_small * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-	if (b->n_gen_large)
-		HIP_TRY(hipMemcpyAsync(b->d_gen + b->max_packets, b->h_gen + b->max_packets, b->n_gen_large * sizeof(uint32_t),
-					hipMemcpyHostToDevice, st));
-	if (b->n_gen_ola)
-		HIP_TRY(hipMemcpyAsync(b->d_gen + 2 * b->max_packets, b->h_gen + 2 * b->max_packets, b->n_gen_ola * sizeof(uint32_t),
-					hipMemcpyHostToDevice, st));
-	if (b->n_seg)
-		HIP_TRY(hipMemcpyAsync(b->d_seg, b->h_seg, b->n_seg * sizeof(LwSegment), hipMemcpyHostToDevice, st));
-	if (b->n_items)
-		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
-	if (b->n_halo_items)
-		HIP_TRY(hipMemcpyAsync(b->d_halo_items, b->h_halo_items, b->n_halo_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
-	return LW_OK;
-}
-
-static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_generic, float *tap)
-{
-	lw_decoder *d = b->dec;
-	if (b->n == 0)
-		return LW_OK;
-	const bool run_generic = b->has_generic || all_generic;
-	const bool run_fast = b->has_fast && !all_generic;
-	if (run_generic) {
-		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
-		if (d->any_coupling && !b->d_decoupled)
-			HIP_TRY(hipMalloc((void **)&b->d_decoupled, maxres * sizeof(float)));
-		if (!b->d_td)
-			HIP_TRY(hipMalloc((void **)&b->d_td, 2 * maxres * sizeof(float)));
-	}
-	if (run_fast && b->n_halo_items > b->halo_cap) {
-		if (b->d_halo) {
-			HIP_TRY(hipStreamSynchronize(st));
-			(void)hipFree(b->d_halo);
-			b->d_halo = nullptr;
-		}
-		const size_t cap = std::max<size_t>(b->n_halo_items, 64);
-		HIP_TRY(hipMalloc((void **)&b->d_halo, cap * d->T.ch * 512 * sizeof(float)));
-		b->halo_cap = cap;
-	}
-	LwBatchDev B{};
-	B.recs = b->d_recs;
-	B.floors = b->d_floor;
-	B.residue = b->d_res;
-	B.fcurve = b->d_fcurve;
-	B.decoupled = b->d_decoupled;
-	B.td = b->d_td;
-	B.state = d->d_state;
-	B.n_packets = (uint32_t)b->n;
-	// dense lists of the generic packets (not used when every packet goes through the generic kernels)
-	B.gen_small = all_generic ? nullptr : b->d_gen;
-	B.gen_large = all_generic ? nullptr : b->d_gen + b->max_packets;
-	B.n_gen_small = b->n_gen_small;
-	B.n_gen_large = b->n_gen_large;
-	B.gen_ola = all_generic ? nullptr : b->d_gen + 2 * b->max_packets;
-	B.n_gen_ola = b->n_gen_ola;
-	B.sym = b->symbols ? b->d_sym : nullptr;
-	B.sym_off = b->d_sym_off;
-	b->last_kernels.clear();
-	if (b->symbols) {
-		lw_launch_residue_vq(d->T, d->V, B, st, b->max_n, d->vq_book_ends.data(), d->vq_book_ends.size());
-		b->last_kernels = "k_residue_vq,";
-	}
-	const bool fused_small = run_generic && !all_generic && !tap && b->n_seg > 0;
-	B.seg = fused_small ? b->d_seg : nullptr;
-	B.n_seg = fused_small ? b->n_seg : 0;
-	if (fused_small) {
-		if (b->n_gen_large) { // large generic blocks still go through k_decouple / k_imdct_generic into B.td
-			lw_launch_generic_imdct_large(d->T, B, st, b->max_n, d->any_coupling);
-			b->last_kernels += d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
-		}
-	} else if (run_generic) {
-		lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic);
-		b->last_kernels += d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
-	}
-	if (run_fast) {
-		LwFastLaunch L{};
-		L.off = d->fast.off;
-		L.d_image = d->d_fast_image;
-		L.d_items = b->d_items;
-		L.n_items = (uint32_t)b->n_items;
-		L.d_halo_items = b->d_halo_items;
-		L.n_halo_items = (uint32_t)b->n_halo_items;
-		L.n_units = (uint32_t)d->fast.units.size();
-		L.per_round = b->fast_per_round;
-		L.rounds = b->fast_rounds;
-		L.dense = b->fast_dense;
-		L.late_from = b->fast_late_from;
-		L.has_tdonly = b->has_tdonly ? 1u : 0u;
-		if (const char *e = getenv("LW_PACE_GROUP"))
-			L.late_from = (uint32_t)atoi(e);
-		for (size_t i = 0; i < d->fast.units.size() && i < LW_FAST_WAVES; i++)
-			L.units[i] = d->fast.units[i];
-		L.d_halo = b->d_halo;
-		lw_launch_long(d->T, B, L, d_out, b->fmt, st);
-		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
-	}
-	if (fused_small) {
-		lw_launch_small_fused(d->T, B, d_out, b->fmt, st, b->max_n);
-		b->last_kernels += "k_small_fused,";
-	} else if (run_generic) {
-		lw_launch_generic_ola(d->T, B, d_out, b->fmt, st, all_generic);
-		b->last_kernels += "k_ola_generic,";
-	}
-	if (!b->last_kernels.empty())
-		b->last_kernels.pop_back();
-	HIP_TRY(hipGetLastError());
-	return LW_OK;
-}
-
-int lw_batch_synth(lw_batch *b, void *d_out, size_t out_capacity_elems, void *hip_stream)
-{
-	if (!b || (!d_out && b->out_elems))
-		return LW_ERR_NULL_ARG;
-	if (out_capacity_elems < b->out_elems)
-		return LW_ERR_CAPACITY;
-	if (int rc = decoder_set_device(b->dec))
-		return rc;
-	return batch_launch(b, d_out, (hipStream_t)hip_stream, b->force_generic, nullptr);
-}
-
-static int ensure_internal_out(lw_batch *b)
-{
-	if (b->d_out_elems >= b->out_elems && b->d_out)
-		return LW_OK;
-	if (b->d_out)
-		(void)hipFree(b->d_out);
-	b->d_out = nullptr;
-	const size_t cap = std::max<size_t>(b->out_elems, b->max_packets * b->dec->T.ch * b->dec->T.state_chan_stride);
-	HIP_TRY(hipMalloc(&b->d_out, cap * elem_size(b->fmt)));
-	b->d_out_elems = cap;
-	return LW_OK;
-}
-
-int lw_batch_synth_to_host(lw_batch *b, void *h_out, size_t out_capacity_elems, void *hip_stream)
-{
-	if (!b || (!h_out && b->out_elems))
-		return LW_ERR_NULL_ARG;
-	if (out_capacity_elems < b->out_elems)
-		return LW_ERR_CAPACITY;
-	if (int rc = decoder_set_device(b->dec))
-		return rc;
-	if (int rc = ensure_internal_out(b))
-		return rc;
-	hipStream_t st = (hipStream_t)hip_stream;
-	if (int rc = batch_launch(b, b->d_out, st, b->force_generic, nullptr))
-		return rc;
-	if (b->out_elems)
-		HIP_TRY(hipMemcpyAsync(h_out, b->d_out, b->out_elems * elem_size(b->fmt), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	return LW_OK;
-}
-
-int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats)
-{
-	if (!b || !dst)
-		return LW_ERR_NULL_ARG;
-	if (idx >= b->n || b->status[idx] != LW_OK)
-		return LW_ERR_CAPACITY;
-	lw_decoder *d = b->dec;
-	if (int rc = decoder_set_device(d))
-		return rc;
-	const LwPacketRec &r = b->h_recs[idx];
-	const size_t n = (size_t)1 << r.bs, ch = d->T.ch;
-	const size_t want = tap == LW_TAP_POST_MDCT ? ch * n : ch * n / 2;
-	if (cap_floats < want)
-		return LW_ERR_CAPACITY;
-	if (tap == LW_TAP_RESIDUE_PRE_INVERSE && !b->symbols) {
-		std::memcpy(dst, b->h_res + r.res_off, want * sizeof(float));
-		return LW_OK;
-	}
-	if (int rc = ensure_internal_out(b))
-		return rc;
-	if (!b->d_tap)
-		HIP_TRY(hipMalloc((void **)&b->d_tap, b->max_packets * ch * d->T.state_chan_stride * sizeof(float)));
-	if (int rc = batch_launch(b, b->d_out, nullptr, true, b->d_tap))
-		return rc;
-	HIP_TRY(hipDeviceSynchronize());
-	const float *src;
-	if (tap == LW_TAP_RESIDUE_PRE_INVERSE)
-		src = b->d_res + r.res_off; // Tier B: the vectors k_residue_vq built on the device
-	else if (tap == LW_TAP_RESIDUE_POST_INVERSE)
-		src = (d->any_coupling ? b->d_decoupled : b->d_res) + r.res_off;
-	else if (tap == LW_TAP_PRE_MDCT)
-		src = b->d_tap + r.res_off;
-	else
-		src = b->d_td + 2 * (size_t)r.res_off;
-	HIP_TRY(hipMemcpy(dst, src, want * sizeof(float), hipMemcpyDeviceToHost));
-	return LW_OK;
-}
-
-int lw_debug_imdct(lw_decoder *d, int blockflag, const float *spectrum, float *out)
-{
-	if (!d || !spectrum || !out)
-		return LW_ERR_NULL_ARG;
-	if (int rc = decoder_set_device(d))
-		return rc;
-	const lw::Setup &s = *d->setup;
-	int mode = -1;
-	for (size_t m = 0; m < s.modes.size(); m++)
-		if ((int)s.modes[m].blockflag == (blockflag ? 1 : 0))
-			mode = (int)m;
-	if (mode < 0)
-		return LW_ERR_CAPACITY;
-	int e = 0;
-	lw_batch *b = lw_batch_create(d, 1, LW_FMT_F32_PLANAR, &e);
-	if (!b)
-		return e ? e : LW_ERR_DEVICE;
-	const uint32_t bs = blockflag ? d->id->bs1 : d->id->bs0, n = 1u << bs, ch = d->T.ch;
-	LwPacketRec &r = b->h_recs[0];
-	std::memset(&r, 0, sizeof(r));
-	r.prev = -1;
-	r.state_out = -1;
-	r.bs = (uint8_t)bs;
-	r.mode = (uint8_t)mode;
-	r.flags = blockflag ? LW_RF_LONG : 0;
-	r.rs = (uint16_t)(n / 2);
-	r.re = (uint16_t)(n / 2); // nothing to hand over
-	std::memset(b->h_res, 0, sizeof(float) * ch * n / 2);
-	std::memcpy(b->h_res, spectrum, sizeof(float) * n / 2);
-	const lw::Mapping &mp = s.mappings[s.modes[mode].mapping];
-	for (uint32_t c = 0; c < ch; c++) {
-		uint16_t *rec = b->h_floor + c * d->T.fstride;
-		const size_t F = s.floors[mp.submap_floor[mp.mux[c]]].f1.x_list.size();
-		for (size_t i = 0; i < F; i++)
-			rec[i] = 0;
-		rec[0] = LW_POST_ACTIVE | 255u;     // x = 0
-		rec[F - 1] = LW_POST_ACTIVE | 255u; // largest x; beyond it the curve stays flat
-	}
-	b->n = 1;
-	b->res_floats = (size_t)ch * n / 2;
-	b->max_n = n;
-	b->out_elems = 0;
-	b->status[0] = LW_OK;
-	int rc = lw_batch_upload(b, nullptr);
-	if (!rc)
-		rc = ensure_internal_out(b);
-	if (!rc)
-		rc = batch_launch(b, b->d_out, nullptr, true, nullptr);
-	if (!rc && !hip_ok(hipDeviceSynchronize(), "sync"))
-		rc = LW_ERR_DEVICE;
-	if (!rc && !hip_ok(hipMemcpy(out, b->d_td, sizeof(float) * n, hipMemcpyDeviceToHost), "memcpy td"))
-		rc = LW_ERR_DEVICE;
-	lw_batch_destroy(b);
-	return rc;
-}
-
-// ---- one packet ---------------------------------------------------------------------------------
-int lw_read_audio_packet(lw_decoder *d, const uint8_t *packet, size_t len, lw_pwr *pwr, int fmt, void *out,
-		size_t cap_per_channel, size_t *n_samples)
-{
-	if (!d || (!packet && len) || !pwr || !out || !n_samples)
-		return LW_ERR_NULL_ARG;
-	if (pwr->dec != d)
-		return LW_ERR_STATE_MISMATCH;
-	if (fmt < 0 || fmt > 2)
-		return LW_ERR_NULL_ARG;
-	if (int rc = decoder_set_device(d))
-		return rc;
-	if (!d->one || d->one->fmt != fmt) {
-		if (d->one)
-			lw_batch_destroy(d->one);
-		int e = 0;
-		d->one = lw_batch_create(d, 1, fmt, &e);
-		if (!d->one)
-			return e ? e : LW_ERR_DEVICE;
-	}
-	lw_batch *b = d->one;
-	lw_packet pk{packet, len, pwr};
-	// lw_batch_entropy commits the host half of the PreviousWindowRight (present, len, parity) when it plans the batch; the
-	// device half follows when the kernels run.  Any failure in between must leave `pwr` as the reference leaves it on an
-	// error: untouched (the one error that consumes the state, audio.rs:1107-1111, is reported through res.status).
-	const lw_pwr saved = *pwr;
-	if (int rc = lw_batch_entropy(b, &pk, 1, 1)) {
-		*pwr = saved;
-		return rc;
-	}
-	const lw_packet_result &res = b->results[0];
-	if (res.status != LW_OK)
-		return res.status;
-	int rc = LW_OK;
-	if (res.n_samples > cap_per_channel)
-		rc = LW_AUDIO_BUFFER_NOT_ADDRESSABLE;
-	if (!rc)
-		rc = lw_batch_upload(b, nullptr);
-	const size_t need = std::max<size_t>(b->out_elems, 1) * elem_size(fmt);
-	if (!rc && d->one_out_bytes < need) {
-		if (d->one_out)
-			(void)hipHostFree(d->one_out);
-		d->one_out = nullptr;
-		d->one_out_bytes = 0;
-		const size_t bytes = std::max<size_t>(need, (size_t)d->T.state_stride * 2 * 4);
-		if (hip_ok(hipHostMalloc(&d->one_out, bytes), "hipHostMalloc(packet output)"))
-			d->one_out_bytes = bytes;
-		else
-			rc = LW_ERR_DEVICE;
-	}
-	// the kernels write the PCM straight into the pinned host buffer (device-visible): launch + synchronise, no D2H copy
-	if (!rc)
-		rc = lw_batch_synth(b, d->one_out, b->out_elems, nullptr); // (a first packet yields no samples, only the state)
-	if (!rc && !hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize"))
-		rc = LW_ERR_DEVICE;
-	if (rc) {
-		*pwr = saved; // the packet was not decoded: the next call overlaps against the state this one found
-		return rc;
-	}
-	std::memcpy(out, d->one_out, b->out_elems * elem_size(fmt));
-	*n_samples = res.n_samples;
-	return LW_OK;
-}
 
 } // extern "C"
 
@@ -1750,3 +795,4 @@ const float kInverseDbTable[256] = {
 #include "lw_inverse_db.inc"
 };
 } // namespace
+

@@ -23,6 +23,15 @@ void lw_pwr_reset(lw_pwr *) {}
 void lw_pwr_free(lw_pwr *) {}
 int lw_get_decoded_sample_count(const lw_ident *, const lw_setup *, const uint8_t *, size_t, size_t *) { return LW_ERR_NULL_ARG; }
 int lw_read_audio_packet(lw_decoder *, const uint8_t *, size_t, lw_pwr *, int, void *, size_t, size_t *) { return LW_ERR_DEVICE; }
+lw_ring *lw_ring_create(lw_decoder *, size_t, size_t, int, int *err) { if (err) *err = LW_ERR_DEVICE; return nullptr; }
+void lw_ring_destroy(lw_ring *) {}
+int lw_ring_stage(lw_ring *, const lw_packet *, size_t, int) { return LW_ERR_DEVICE; }
+int lw_ring_launch(lw_ring *) { return LW_ERR_DEVICE; }
+int lw_ring_collect(lw_ring *, const lw_packet_result **, size_t *, const void **, size_t *) { return LW_ERR_DEVICE; }
+int lw_ring_release(lw_ring *) { return LW_ERR_DEVICE; }
+int lw_ring_drain(lw_ring *) { return LW_OK; }
+void lw_pwr_get_state(const lw_pwr *, lw_pwr_state *) {}
+void lw_pwr_set_state(lw_pwr *, const lw_pwr_state *) {}
 lw_batch *lw_batch_create(lw_decoder *, size_t, int, int *) { return nullptr; }
 void lw_batch_destroy(lw_batch *) {}
 int lw_batch_entropy(lw_batch *, const lw_packet *, size_t, int) { return LW_ERR_DEVICE; }
