@@ -164,7 +164,7 @@ enum { LW_TAP_RESIDUE_PRE_INVERSE = 0, LW_TAP_RESIDUE_POST_INVERSE = 1, LW_TAP_P
 
 lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err);
 void lw_batch_destroy(lw_batch *b);
-/* Host entropy stage for `n` packets on `n_threads` host threads (0 = hardware concurrency): fills the
+/* Host entropy stage for `n` packets on `n_threads` host threads (0 = lw_default_host_threads()): fills the
  * pinned staging buffers with GPU-stage records and decides sample counts, window geometry and error
  * statuses (all host-decidable).  Advances the host-side bookkeeping of every pwr. */
 int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads);
@@ -377,6 +377,9 @@ size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, 
 
 /* Library/version introspection */
 const char *lw_version(void);
+/* Host threads the entropy stage uses when a call passes n_threads <= 0: the CPUs this process may run on (hardware
+ * threads, cut to the affinity mask and to the container's CFS quota, cgroup cpu.max); LW_HOST_THREADS overrides. */
+int lw_default_host_threads(void);
 
 #ifdef __cplusplus
 }

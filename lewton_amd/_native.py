@@ -69,6 +69,7 @@ def _sig(name, restype, argtypes):
 # every symbol include/lewton_amd.h declares
 SYMBOLS = {
     "lw_version": (C.c_char_p, []),
+    "lw_default_host_threads": (C.c_int, []),
     "lw_last_device_error": (C.c_char_p, []),
     "lw_read_header_ident": (C.c_void_p, [C.c_char_p, C.c_size_t, intp]),
     "lw_ident_get_info": (C.c_int, [C.c_void_p, C.POINTER(IdentInfo)]),

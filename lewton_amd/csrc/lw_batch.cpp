@@ -190,7 +190,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->max_n = max_n;
 
 	// pass 2 (parallel): entropy decode straight into the pinned staging buffers
-	unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+	unsigned nt = n_threads > 0 ? (unsigned)n_threads : lw::default_host_threads();
 	nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n / 8));
 	alignas(128) std::atomic<size_t> next{0}; // (its own cache line: every worker adds to it once per LW_ENTROPY_CHUNK packets)
 	alignas(128) char next_pad[8] = {0};
@@ -615,11 +615,11 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	if (fused_small) {
 		if (b->n_gen_large) { // large generic blocks still go through k_decouple / k_imdct_generic into B.td
 			lw_launch_generic_imdct_large(d->T, B, st, b->max_n, d->any_coupling);
-			b->last_kernels += d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
+			b->last_kernels += d->any_coupling && !d->T.pair_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 		}
 	} else if (run_generic) {
 		lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic);
-		b->last_kernels += d->any_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
+		b->last_kernels += d->any_coupling && (!d->T.pair_coupling || tap) ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 	}
 	if (run_fast) {
 		LwFastLaunch L{};

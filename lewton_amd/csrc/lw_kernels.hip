@@ -543,6 +543,9 @@ template <int TPB>
 __global__ void __launch_bounds__(LW_BLOCK)
 k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled, uint32_t skip_mask, uint32_t task_floats)
 {
+	// use_decoupled: 0 = raw residues (no coupling in the stream), 1 = k_decouple's buffer, 2 = inverse coupling done here,
+	// each channel from its own and its partner's raw vector (T.pair_coupling streams: one launch and one round trip of
+	// the residues through HBM less)
 	extern __shared__ __attribute__((aligned(16))) float smem_all[];
 	const uint32_t task = TPB == LW_BLOCK ? blockIdx.x : blockIdx.x * (LW_BLOCK / TPB) + threadIdx.x / TPB;
 	const uint32_t *list = TPB == LW_BLOCK ? B.gen_large : B.gen_small;
@@ -556,7 +559,9 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	if ((rec.bs <= LW_SMALL_BS) != (TPB != LW_BLOCK))
 		return; // the other instantiation handles this block size
 	float *smem = smem_all + (TPB == LW_BLOCK ? 0u : (threadIdx.x / TPB) * task_floats);
-	imdct_block<TPB>(T, B, rec, c, threadIdx.x % TPB, smem, B.td + 2u * rec.res_off + c * (1u << rec.bs), tap_spec, use_decoupled, -1, 0,
+	const bool inl = use_decoupled == 2;
+	imdct_block<TPB>(T, B, rec, c, threadIdx.x % TPB, smem, B.td + 2u * rec.res_off + c * (1u << rec.bs), tap_spec,
+			use_decoupled == 1, inl ? T.mode_partner[rec.mode * T.ch + c] : -1, inl ? T.mode_role[rec.mode * T.ch + c] : 0,
 			global_tables(T, rec));
 }
 
@@ -822,14 +827,15 @@ void lw_launch_generic_imdct_large(const LwDevTables &T, const LwBatchDev &B, hi
 	LwBatchDev L = B;
 	L.gen_small = B.gen_large; // k_decouple walks gen_small then gen_large: give it the large list alone
 	L.n_gen_small = 0;
-	if (any_coupling)
+	const int coupling = !any_coupling ? 0 : T.pair_coupling ? 2 : 1;
+	if (coupling == 1)
 		hipLaunchKernelGGL(k_decouple, dim3(B.n_gen_large), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T, L, (uint32_t)(LW_RF_SKIP | LW_RF_FAST));
 	static LwPerDeviceOnce once;
 	if (once.first_launch_on_device())
 		(void)hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 	const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 4) * sizeof(float);
 	hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(B.n_gen_large * T.ch), dim3(LW_BLOCK), lds, st, T, B, (float *)nullptr,
-			any_coupling ? 1 : 0, (uint32_t)(LW_RF_SKIP | LW_RF_FAST), 0u);
+			coupling, (uint32_t)(LW_RF_SKIP | LW_RF_FAST), 0u);
 }
 
 void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
@@ -838,7 +844,10 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 	if (B.n_packets == 0)
 		return;
 	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
-	if (any_coupling && (!B.gen_small || B.n_gen_small + B.n_gen_large))
+	// inverse coupling: inside the transform kernel when every channel is in at most one step (and nobody taps the
+	// intermediate vectors), otherwise by k_decouple into B.decoupled first
+	const int coupling = !any_coupling ? 0 : (T.pair_coupling && !tap_spec) ? 2 : 1;
+	if (coupling == 1 && (!B.gen_small || B.n_gen_small + B.n_gen_large))
 		hipLaunchKernelGGL(k_decouple, dim3(B.gen_small ? B.n_gen_small + B.n_gen_large : B.n_packets), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T,
 				B, skip_mask);
 	static LwPerDeviceOnce once;
@@ -851,15 +860,14 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 	const uint32_t n_small = (B.gen_small ? B.n_gen_small : B.n_packets) * T.ch;
 	if (max_n > (1u << LW_SMALL_BS) && n_large) {
 		const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 4) * sizeof(float);
-		hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(n_large), dim3(LW_BLOCK), lds, st, T, B, tap_spec,
-				any_coupling ? 1 : 0, skip_mask, 0u);
+		hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(n_large), dim3(LW_BLOCK), lds, st, T, B, tap_spec, coupling, skip_mask, 0u);
 	}
 	if (n_small) {
 		const uint32_t small_n = std::min(max_n, 1u << LW_SMALL_BS);
 		const uint32_t task_floats = (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 7u) & ~3u;
 		const uint32_t per_wg = LW_BLOCK / 64;
 		hipLaunchKernelGGL(k_imdct_generic<64>, dim3((n_small + per_wg - 1) / per_wg), dim3(LW_BLOCK),
-				(size_t)per_wg * task_floats * sizeof(float), st, T, B, tap_spec, any_coupling ? 1 : 0, skip_mask, task_floats);
+				(size_t)per_wg * task_floats * sizeof(float), st, T, B, tap_spec, coupling, skip_mask, task_floats);
 	}
 }
 

@@ -7,6 +7,7 @@
 #include "../../include/lewton_amd.h"
 
 #include "lw_internal.hpp"
+#include "lw_pool.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -74,6 +75,11 @@ extern "C" {
 const char *lw_version(void)
 {
 	return "lewton_amd 0.1 (gfx950)";
+}
+
+int lw_default_host_threads(void)
+{
+	return (int)lw::default_host_threads();
 }
 
 const char *lw_last_device_error(void)

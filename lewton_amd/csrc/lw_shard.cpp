@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -240,7 +241,10 @@ int lw_sharder_decode(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int
 		s.idx.push_back(i);
 		s.pk.push_back(lw_packet{pkts[i].data, pkts[i].len, st->pwr});
 	}
-	sh->n_threads = n_threads_per_shard;
+	// all shards run their host entropy stage at once (the worker pool serves their parallel regions side by side): by
+	// default they share the CPUs this process may use
+	sh->n_threads = n_threads_per_shard > 0 ? n_threads_per_shard
+			: std::max(1, lw_default_host_threads() / (int)sh->shards.size());
 	sh->out = out;
 	const uint64_t base_phase = 2 * (++sh->call_no);
 	sh->all_workers(base_phase + 1); // phase 1: host entropy stage of every shard (sample counts, offsets inside the shard)

@@ -11,6 +11,7 @@ import time
 import numpy as np
 
 from . import audio
+from . import _native as _N
 from .ring import Ring
 
 
@@ -79,7 +80,7 @@ def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots
         "h2d_GBps": (npk * rec_bytes / dt / 1e9) if rec_bytes else None,
         "d2h_GBps": npk * ch * half * esz / dt / 1e9,
         "vorbis_payload_MBps": payload / packets * npk / dt / 1e6,
-        "host_threads": threads or os.cpu_count(), "callers": callers, "ring_slots": slots,
+        "host_threads": threads or _N.lw_default_host_threads(), "callers": callers, "ring_slots": slots,
         "host_entropy_stage_alone": npk / max(t_host) if callers == 1 else npk / (sum(t_host) / callers),
         "kernels": rings[0].last_kernels,
         "path": "lw_ring_stage (host entropy decode into pinned staging) -> lw_ring_launch (hipMemcpyAsync H2D, kernels, "
