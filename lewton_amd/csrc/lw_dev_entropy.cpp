@@ -1,0 +1,293 @@
+// Flattened setup header for the device entropy stage: see lw_dev_entropy.hpp / lw_dev_entropy.h.  Product code.
+#include "lw_dev_entropy.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace lw {
+
+namespace {
+
+// every bit pattern resolves inside the two table levels (no tree walk on the device)
+bool tables_complete(const Huffman &h)
+{
+	if (h.single >= 0)
+		return true;
+	if (!h.has_lut || h.lut.empty())
+		return false;
+	const size_t first = (size_t)1 << h.lut_bits;
+	if (h.lut.size() < first)
+		return false;
+	for (size_t i = 0; i < first; i++) {
+		const uint32_t e = h.lut[i];
+		if (e & Huffman::LINK) {
+			const size_t base = e & 0xffffffu, cnt = (size_t)1 << ((e >> 24) & 0x7fu);
+			if (base + cnt > h.lut.size())
+				return false;
+			for (size_t k = 0; k < cnt; k++) {
+				const uint32_t f = h.lut[base + k];
+				if ((f & Huffman::LINK) || (f >> 24) == 0)
+					return false;
+			}
+		} else if ((e >> 24) == 0) {
+			return false;
+		}
+	}
+	return true;
+}
+
+template <class T> size_t put(std::vector<uint8_t> &blob, const T *p, size_t n)
+{
+	const size_t at = (blob.size() + 15) & ~(size_t)15;
+	blob.resize(at + n * sizeof(T));
+	if (n)
+		std::memcpy(blob.data() + at, p, n * sizeof(T));
+	return at;
+}
+
+} // namespace
+
+bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEntropyImage &img, const char **why)
+{
+	const char *dummy;
+	if (!why)
+		why = &dummy;
+	*why = "";
+	const size_t ch = id.channels;
+	const size_t n1 = (size_t)1 << id.bs1;
+	if (ch == 0 || ch > LW_ENT_MAX_CH) {
+		*why = "more than 8 channels";
+		return false;
+	}
+	if (n1 * ch >= 65536) {
+		*why = "blocksize_1 * channels does not fit the reference's u16 product (audio.rs:745)";
+		return false;
+	}
+	if (s.codebooks.size() > 256 || s.floors.size() > 64 || s.residues.size() > 64 || s.modes.size() > 64) {
+		*why = "setup too large";
+		return false;
+	}
+	std::vector<bool> book_used(s.codebooks.size(), false), floor_used(s.floors.size(), false), res_used(s.residues.size(), false);
+	std::vector<LwEntMode> modes(s.modes.size());
+	for (size_t mi = 0; mi < s.modes.size(); mi++) {
+		const Mapping &map = s.mappings[s.modes[mi].mapping];
+		LwEntMode &m = modes[mi];
+		std::memset(&m, 0, sizeof(m));
+		m.blockflag = s.modes[mi].blockflag ? 1 : 0;
+		if (map.submap_floor.size() != 1 || map.submap_residue.size() != 1) {
+			*why = "a mapping with more than one submap";
+			return false;
+		}
+		if (map.mag.size() > LW_ENT_MAX_COUPLING) {
+			*why = "more than 16 coupling steps";
+			return false;
+		}
+		m.n_coupling = (uint8_t)map.mag.size();
+		for (size_t i = 0; i < map.mag.size(); i++) {
+			m.mag[i] = map.mag[i];
+			m.ang[i] = map.ang[i];
+		}
+		for (size_t c = 0; c < ch; c++)
+			m.floor_of_ch[c] = map.submap_floor[0];
+		m.residue = map.submap_residue[0];
+		floor_used[map.submap_floor[0]] = true;
+		res_used[map.submap_residue[0]] = true;
+	}
+	std::vector<LwEntFloor> floors(s.floors.size());
+	for (size_t fi = 0; fi < s.floors.size(); fi++) {
+		LwEntFloor &f = floors[fi];
+		std::memset(&f, 0, sizeof(f));
+		if (!floor_used[fi])
+			continue;
+		if (s.floors[fi].type != 1) {
+			*why = "floor type 0";
+			return false;
+		}
+		const Floor1 &fl = s.floors[fi].f1;
+		const size_t F = fl.x_list.size();
+		if (fl.partition_class.size() > 32 || F > LW_MAX_POSTS || F < 2) {
+			*why = "floor 1 shape";
+			return false;
+		}
+		f.multiplier = fl.multiplier;
+		f.range = fl.range();
+		f.range_bits = (uint8_t)ilog(fl.range() - 1);
+		f.n_part = (uint8_t)fl.partition_class.size();
+		f.F = (uint8_t)F;
+		size_t posts = 2;
+		for (size_t p = 0; p < fl.partition_class.size(); p++) {
+			const unsigned c = fl.partition_class[p];
+			if (c >= 16) {
+				*why = "floor 1 class number";
+				return false;
+			}
+			f.partition_class[p] = (uint8_t)c;
+			posts += fl.class_dim[c];
+			if (fl.class_sub[c]) {
+				if (fl.class_master[c] >= s.codebooks.size()) {
+					*why = "floor 1 master book out of range";
+					return false;
+				}
+				book_used[fl.class_master[c]] = true;
+			}
+			if (fl.class_sub[c] > 3) {
+				*why = "floor 1 subclass bits";
+				return false;
+			}
+			for (unsigned k = 0; k < (1u << fl.class_sub[c]); k++) {
+				const int b = fl.sub_books[c][k];
+				if (b >= 0) {
+					if ((size_t)b >= s.codebooks.size()) {
+						*why = "floor 1 sub book out of range";
+						return false;
+					}
+					book_used[b] = true;
+				}
+			}
+		}
+		if (posts != F) {
+			*why = "floor 1 post count";
+			return false;
+		}
+		for (int c = 0; c < 16; c++) {
+			f.class_dim[c] = fl.class_dim[c];
+			f.class_sub[c] = fl.class_sub[c];
+			f.class_master[c] = fl.class_master[c];
+			for (int k = 0; k < 8; k++)
+				f.sub_books[c][k] = fl.sub_books[c][k];
+		}
+		for (size_t i = 0; i < F; i++) {
+			f.sorted_idx[i] = (uint8_t)fl.sorted_idx[i];
+			if (i >= 2) {
+				f.lo_idx[i] = (uint8_t)fl.lo_idx[i];
+				f.hi_idx[i] = (uint8_t)fl.hi_idx[i];
+				f.dx[i] = fl.dx[i];
+				f.adx_magic[i] = fl.adx_magic[i];
+			}
+		}
+	}
+	std::vector<LwEntResidue> residues(s.residues.size());
+	std::vector<uint8_t> bytes;
+	size_t cls_bytes = 0;
+	for (size_t ri = 0; ri < s.residues.size(); ri++) {
+		LwEntResidue &r = residues[ri];
+		std::memset(&r, 0, sizeof(r));
+		r.digits_off = 0xFFFFFFFFu;
+		if (!res_used[ri])
+			continue;
+		const Residue &rs = s.residues[ri];
+		if (rs.type > 2 || rs.classifications == 0 || rs.classifications > LW_ENT_MAX_CLASSES || rs.books.size() < rs.classifications ||
+				rs.partition_size == 0 || rs.classbook >= s.codebooks.size()) {
+			*why = "residue shape";
+			return false;
+		}
+		const Codebook &cbk = s.codebooks[rs.classbook];
+		if (cbk.dims == 0 || cbk.dims > 255) {
+			*why = "classbook dimensions";
+			return false;
+		}
+		book_used[rs.classbook] = true;
+		r.type = rs.type;
+		r.classifications = rs.classifications;
+		r.classbook = rs.classbook;
+		r.cpc = (uint8_t)cbk.dims;
+		r.begin = rs.begin;
+		r.end = rs.end;
+		r.psize = rs.partition_size;
+		for (unsigned c = 0; c < rs.classifications; c++) {
+			r.vals_used[c] = rs.books[c].vals_used;
+			for (unsigned p = 0; p < 8; p++) {
+				r.val_i[c][p] = rs.books[c].val_i[p];
+				if (!(rs.books[c].vals_used & (1u << p)))
+					continue;
+				const unsigned bi = rs.books[c].val_i[p];
+				if (bi >= s.codebooks.size()) {
+					*why = "residue book out of range";
+					return false;
+				}
+				const Codebook &cb = s.codebooks[bi];
+				if (cb.dims == 0 || cb.dims > 255 || !cb.has_vq || cb.vq.size() < (size_t)cb.entries * cb.dims) {
+					*why = "a residue book without a vector lookup";
+					return false;
+				}
+				if (rs.type != 0 && rs.partition_size % cb.dims != 0) {
+					*why = "a residue book whose dimension does not divide the partition size";
+					return false;
+				}
+				book_used[bi] = true;
+			}
+		}
+		if (!rs.class_digits.empty()) {
+			r.digits_off = (uint32_t)bytes.size();
+			bytes.insert(bytes.end(), rs.class_digits.begin(), rs.class_digits.end());
+		}
+		const size_t nch = rs.type == 2 ? 1 : ch, actual = rs.type == 2 ? ch * (n1 / 2) : n1 / 2;
+		cls_bytes = std::max(cls_bytes, nch * (actual / rs.partition_size + cbk.dims));
+	}
+	std::vector<LwEntBook> books(s.codebooks.size());
+	std::vector<uint32_t> lut;
+	std::vector<float> vq;
+	for (size_t bi = 0; bi < s.codebooks.size(); bi++) {
+		LwEntBook &b = books[bi];
+		std::memset(&b, 0, sizeof(b));
+		b.single = -1;
+		if (!book_used[bi])
+			continue;
+		const Codebook &cb = s.codebooks[bi];
+		if (!tables_complete(cb.huff)) {
+			*why = "a Huffman code longer than the two table levels (or an empty book)";
+			return false;
+		}
+		if (cb.huff.single >= 0) {
+			if (cb.huff.single > 32767) {
+				*why = "single-entry book with a large entry number";
+				return false;
+			}
+			b.single = (int16_t)cb.huff.single;
+		} else {
+			b.lut_off = (uint32_t)lut.size();
+			b.lut_bits = (uint8_t)cb.huff.lut_bits;
+			lut.insert(lut.end(), cb.huff.lut.begin(), cb.huff.lut.end());
+		}
+		b.dims = (uint8_t)std::min<unsigned>(cb.dims, 255);
+		if (cb.has_vq && !cb.vq.empty()) {
+			while (vq.size() % 8)
+				vq.push_back(0.0f);
+			b.vq_off = (uint32_t)vq.size();
+			vq.insert(vq.end(), cb.vq.begin(), cb.vq.end());
+		}
+	}
+	lut.push_back(0);
+	vq.push_back(0.0f);
+	bytes.push_back(0);
+	img.blob.clear();
+	img.off_books = put(img.blob, books.data(), books.size());
+	img.off_floors = put(img.blob, floors.data(), floors.size());
+	img.off_residues = put(img.blob, residues.data(), residues.size());
+	img.off_modes = put(img.blob, modes.data(), modes.size());
+	img.off_lut = put(img.blob, lut.data(), lut.size());
+	img.off_vq = put(img.blob, vq.data(), vq.size());
+	img.off_bytes = put(img.blob, bytes.data(), bytes.size());
+	img.ch = (uint32_t)ch;
+	img.fstride = fstride;
+	img.ws_bytes = (uint32_t)((LW_ENT_POSTS_BYTES + cls_bytes + 15) & ~(size_t)15);
+	return true;
+}
+
+LwEntTables dev_entropy_view(const DevEntropyImage &img, const uint8_t *base)
+{
+	LwEntTables T;
+	T.books = (const LwEntBook *)(base + img.off_books);
+	T.floors = (const LwEntFloor *)(base + img.off_floors);
+	T.residues = (const LwEntResidue *)(base + img.off_residues);
+	T.modes = (const LwEntMode *)(base + img.off_modes);
+	T.lut = (const uint32_t *)(base + img.off_lut);
+	T.vq = (const float *)(base + img.off_vq);
+	T.bytes = base + img.off_bytes;
+	T.ch = img.ch;
+	T.fstride = img.fstride;
+	T.ws_bytes = img.ws_bytes;
+	return T;
+}
+
+} // namespace lw

@@ -1,0 +1,375 @@
+// Entropy stage ON THE DEVICE (product code): the bit-serial half of read_audio_packet_generic (audio.rs:921-986 --
+// floor-1 decode :215-251 with the amplitude unwrap :391-435, residue decode :587-760) restated so that it compiles for the
+// GPU (lw_kernels_entropy.hip: one LANE per packet, 64 packets per wave) and, unchanged, for the host, where the CPU
+// suite runs it packet by packet against the host entropy stage (lw_entropy.cpp) on intact, truncated and mutated packets.
+//
+// Why: the host stage costs 5.4-6 us per stereo long-block packet and core; a GPU box grants its container 16 CPUs, so the
+// staging ring tops out at 2.7-2.8 M packets/s while the synthesis kernels take 16.5 us per 4096 packets.
+// Huffman decoding is serial inside a packet but packets are independent: 4096 lanes decode 4096 packets side by side,
+// and only the packets themselves (~0.5 KB instead of 8.3 KB of records) cross PCIe.
+//
+// Everything here is plain data and pointers: the setup header is flattened once into one image (lw_dev_entropy.cpp,
+// LwEntImage) that lives in HBM.  The function writes exactly what the host stage writes into a batch's staging -- floor
+// records [ch][fstride] u16 and residue vectors [ch][n/2] f32 before inverse coupling -- so the synthesis kernels run
+// unchanged behind it.  Eligible setups only (lw::dev_entropy_build says why not): floor type 1, one submap per mapping,
+// residue books of 1/2/4/8 dimensions dividing the partition size, every Huffman code inside the two table levels.
+// For those the packet status is decided by the prologue alone (the host reads it: mode number, window flags), so the
+// host's planning pass needs nothing back from the device.
+#pragma once
+
+#include "lw_records.h"
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LW_HD __host__ __device__ __forceinline__
+#else
+#define LW_HD inline
+#endif
+
+#define LW_ENT_MAX_CH 8
+#define LW_ENT_MAX_CLASSES 64
+#define LW_ENT_MAX_COUPLING 16
+#define LW_ENT_LINK 0x80000000u
+
+struct LwEntBook { // 16 bytes
+	uint32_t lut_off;  // first-level table (2^lut_bits entries) in the image's u32 pool; sub-tables follow at offsets relative to it
+	uint32_t vq_off;   // entries * dims floats in the image's f32 pool
+	uint8_t lut_bits, dims;
+	int16_t single;    // >= 0: single-entry book, any one bit decodes this entry (huffman_tree.rs:202-217)
+	uint32_t pad;
+};
+
+struct LwEntFloor {
+	uint8_t multiplier, range_bits, n_part, F;
+	uint32_t range;
+	uint8_t partition_class[32];
+	uint8_t class_dim[16], class_sub[16], class_master[16];
+	int16_t sub_books[16][8];
+	uint8_t lo_idx[LW_MAX_POSTS], hi_idx[LW_MAX_POSTS], sorted_idx[LW_MAX_POSTS];
+	uint8_t pad0;
+	uint32_t dx[LW_MAX_POSTS];
+	uint32_t pad1;
+	uint64_t adx_magic[LW_MAX_POSTS];
+};
+
+struct LwEntResidue {
+	uint8_t type, classifications, classbook, cpc;
+	uint32_t begin, end, psize;
+	uint32_t digits_off; // u8 [classbook entries][cpc] in the image's byte pool, or 0xFFFFFFFF: digits by division
+	uint8_t vals_used[LW_ENT_MAX_CLASSES];
+	uint8_t val_i[LW_ENT_MAX_CLASSES][8];
+};
+
+struct LwEntMode {
+	uint8_t blockflag, n_coupling, residue, pad;
+	uint8_t floor_of_ch[LW_ENT_MAX_CH];
+	uint8_t mag[LW_ENT_MAX_COUPLING], ang[LW_ENT_MAX_COUPLING];
+};
+
+// Resolved view of the image (device pointers on the GPU, host pointers in the CPU harness)
+struct LwEntTables {
+	const LwEntBook *books;
+	const LwEntFloor *floors;
+	const LwEntResidue *residues;
+	const LwEntMode *modes;
+	const uint32_t *lut;
+	const float *vq;
+	const uint8_t *bytes;
+	uint32_t ch, fstride;
+	uint32_t ws_bytes; // per-packet scratch: posts (4 * LW_MAX_POSTS rounded up) + classification digits
+};
+
+// One packet of a device-entropy batch
+struct LwEntPacket { // 16 bytes
+	uint32_t word_off; // packet bytes in the batch's packet pool (u32 words; padded with >= 8 zero bytes)
+	uint32_t len;      // bytes
+	uint8_t start_bit; // first bit after the prologue (audio.rs:921-938, read by the host)
+	uint8_t pad[3];
+	uint32_t pad1;
+};
+
+#define LW_ENT_POSTS_BYTES ((4u * LW_MAX_POSTS + 15u) & ~15u)
+
+struct LwEntReader {
+	const uint32_t *w;
+	uint32_t nbits, pos;
+
+	// the next 32 bits (at least), zero past the end of the packet (the pool is zero padded)
+	LW_HD uint32_t peek() const
+	{
+		const uint32_t i = pos >> 5, s = pos & 31u;
+		const uint64_t x = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
+		return (uint32_t)(x >> s);
+	}
+	// bitpacking.rs:291-297: a fixed-width read that does not fit fails without consuming anything; n <= 32
+	LW_HD bool read(uint32_t n, uint32_t &v)
+	{
+		if (n == 0) {
+			v = 0;
+			return true;
+		}
+		if (pos + n > nbits)
+			return false;
+		const uint32_t x = peek();
+		v = n >= 32 ? x : (x & ((1u << n) - 1u));
+		pos += n;
+		return true;
+	}
+	// huffman_tree.rs:362-381 through the two table levels: a code that runs past the end consumes the rest and fails
+	LW_HD bool code(const LwEntTables &T, const LwEntBook &b, uint32_t &sym)
+	{
+		if (b.single >= 0) {
+			if (pos + 1 > nbits)
+				return false;
+			pos += 1;
+			sym = (uint32_t)b.single;
+			return true;
+		}
+		const uint32_t x = peek();
+		const uint32_t *lut = T.lut + b.lut_off;
+		uint32_t e = lut[x & ((1u << b.lut_bits) - 1u)];
+		if (e & LW_ENT_LINK)
+			e = lut[(e & 0xffffffu) + ((x >> b.lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
+		const uint32_t len = e >> 24;
+		if (len > nbits - pos) {
+			pos = nbits;
+			return false;
+		}
+		pos += len;
+		sym = e & 0xffffffu;
+		return true;
+	}
+};
+
+// audio.rs:215-251; y = the packet's scratch.  false = unused floor (FloorSpecialCase::Unused)
+LW_HD bool lw_ent_floor_decode(const LwEntTables &T, const LwEntFloor &fl, LwEntReader &r, uint32_t *y)
+{
+	uint32_t nonzero;
+	if (!r.read(1, nonzero) || !nonzero)
+		return false;
+	uint32_t k = 0;
+	if (!r.read(fl.range_bits, y[k]))
+		return false;
+	k++;
+	if (!r.read(fl.range_bits, y[k]))
+		return false;
+	k++;
+	for (uint32_t p = 0; p < fl.n_part; p++) {
+		const uint32_t c = fl.partition_class[p];
+		const uint32_t cdim = fl.class_dim[c], cbits = fl.class_sub[c];
+		const uint32_t csub = (1u << cbits) - 1u;
+		uint32_t cval = 0;
+		if (cbits && !r.code(T, T.books[fl.class_master[c]], cval))
+			return false;
+		for (uint32_t d = 0; d < cdim; d++) {
+			const int book = fl.sub_books[c][cval & csub];
+			cval >>= cbits;
+			if (book >= 0) {
+				if (!r.code(T, T.books[book], y[k]))
+					return false;
+			} else {
+				y[k] = 0;
+			}
+			k++;
+		}
+	}
+	return true;
+}
+
+// audio.rs:354-367 with wrapping u32 arithmetic; the division by the header constant adx is a multiplication by its
+// precomputed 2^64 / adx + 1 (exact for every 32-bit dividend)
+LW_HD uint32_t lw_ent_render_point(uint32_t y0, uint32_t y1, uint32_t dx, uint64_t adx_magic)
+{
+	const int32_t dy = (int32_t)(y1 - y0);
+	const uint32_t ady = dy < 0 ? 0u - (uint32_t)dy : (uint32_t)dy;
+	const uint32_t num = ady * dx;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t off = (uint32_t)__umul64hi((uint64_t)num, adx_magic);
+#else
+	const uint32_t off = (uint32_t)(((unsigned __int128)num * adx_magic) >> 64);
+#endif
+	return dy < 0 ? y0 - off : y0 + off;
+}
+
+// audio.rs:391-435 -> device record: per post in ascending-x order, (final_y * multiplier) | active flag.  y is updated in
+// place (a post's neighbours precede it in header order).
+LW_HD void lw_ent_floor_record(const LwEntFloor &fl, uint32_t *y, uint16_t *rec)
+{
+	const uint32_t F = fl.F, range = fl.range;
+	uint32_t act0 = 3u, act1 = 0u, act2 = 0u; // step2 flags of posts 0-31, 32-63, 64
+	for (uint32_t i = 2; i < F; i++) {
+		const uint32_t lo = fl.lo_idx[i], hi = fl.hi_idx[i];
+		const int32_t predicted = (int32_t)lw_ent_render_point(y[lo], y[hi], fl.dx[i], fl.adx_magic[i]);
+		const int32_t val = (int32_t)y[i];
+		const int32_t highroom = (int32_t)(range - (uint32_t)predicted);
+		const int32_t lowroom = predicted;
+		const int32_t room = (int32_t)((uint32_t)(highroom < lowroom ? highroom : lowroom) * 2u);
+		if (val > 0) {
+			const uint32_t idx[3] = {lo, hi, i};
+			for (int q = 0; q < 3; q++) {
+				const uint32_t j = idx[q];
+				if (j < 32)
+					act0 |= 1u << j;
+				else if (j < 64)
+					act1 |= 1u << (j - 32);
+				else
+					act2 |= 1u;
+			}
+			uint32_t fy;
+			if (val >= room) {
+				fy = highroom > lowroom ? (uint32_t)predicted + (uint32_t)val - (uint32_t)lowroom
+				                        : (uint32_t)predicted - (uint32_t)val + (uint32_t)highroom - 1u;
+			} else {
+				const int32_t t = (val % 2 == 1) ? (int32_t)(0u - (uint32_t)val - 1u) : val;
+				fy = (uint32_t)predicted + (uint32_t)(t >> 1);
+			}
+			y[i] = fy;
+		} else {
+			y[i] = (uint32_t)predicted;
+		}
+	}
+	for (uint32_t sidx = 0; sidx < F; sidx++) {
+		const uint32_t i = fl.sorted_idx[sidx];
+		const uint32_t fy = y[i] < range - 1u ? y[i] : range - 1u; // :431-433
+		const uint32_t on = i < 32 ? (act0 >> i) & 1u : i < 64 ? (act1 >> (i - 32)) & 1u : act2 & 1u;
+		rec[sidx] = (uint16_t)(((fy * fl.multiplier) & 0xffu) | (on ? LW_POST_ACTIVE : 0u));
+	}
+}
+
+// audio.rs:620-717 for `nch` vectors of `actual` elements.  Element e of vector j is out[map(j, e)]: for residue type 2 the
+// ONE interleaved vector of ch * n/2 elements is written straight to its channel-major place (audio.rs:748-754: element i
+// belongs to channel i % ch, bin i / ch) -- every element receives the same additions in the same order as in the
+// reference's interleaved buffer.  `out` holds zeros on entry.  `cls` = scratch for nch * (parts + cpc) digits.
+LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntReader &r, uint32_t nch, uint32_t actual,
+		const bool *dnd, float *out, uint32_t half, uint32_t deint_ch, uint8_t *cls)
+{
+	const uint32_t begin = rs.begin < actual ? rs.begin : actual, end = rs.end < actual ? rs.end : actual;
+	const uint32_t cpc = rs.cpc;
+	const uint32_t n_to_read = end - begin;
+	const uint32_t parts = n_to_read / rs.psize;
+	if (n_to_read == 0)
+		return;
+	const uint32_t stride = parts + cpc;
+	const LwEntBook &classbook = T.books[rs.classbook];
+	const uint32_t ncls = rs.classifications;
+	for (uint32_t pass = 0; pass < 8; pass++) {
+		uint32_t pc = 0;
+		while (pc < parts) {
+			if (pass == 0) {
+				for (uint32_t j = 0; j < nch; j++) {
+					if (dnd[j])
+						continue;
+					uint32_t t;
+					if (!r.code(T, classbook, t))
+						return; // end of packet is normal (audio.rs:655-660)
+					uint8_t *c = cls + j * stride + pc;
+					if (rs.digits_off != 0xFFFFFFFFu) {
+						const uint8_t *dg = T.bytes + rs.digits_off + t * cpc;
+						for (uint32_t i = 0; i < cpc; i++)
+							c[i] = dg[i];
+					} else {
+						for (uint32_t i = cpc; i-- > 0;) {
+							c[i] = (uint8_t)(t % ncls);
+							t /= ncls;
+						}
+					}
+				}
+			}
+			for (uint32_t k = 0; k < cpc && pc < parts; k++, pc++) {
+				for (uint32_t j = 0; j < nch; j++) {
+					if (dnd[j])
+						continue;
+					const uint32_t cl = cls[j * stride + pc];
+					if (!(rs.vals_used[cl] & (1u << pass)))
+						continue;
+					const LwEntBook &cb = T.books[rs.val_i[cl][pass]];
+					const uint32_t dims = cb.dims;
+					const uint32_t offs = begin + pc * rs.psize;
+					const float *vq = T.vq + cb.vq_off;
+					// audio.rs:587-618 (the whole partition lies inside the vector; dims divides the partition size)
+					if (rs.type == 0) {
+						const uint32_t step = rs.psize / dims;
+						for (uint32_t i = 0; i < step; i++) {
+							uint32_t idx;
+							if (!r.code(T, cb, idx))
+								return;
+							const float *e = vq + idx * dims;
+							for (uint32_t d = 0; d < dims; d++)
+								out[j * half + offs + i + d * step] += e[d];
+						}
+					} else if (deint_ch == 0) {
+						float *v = out + j * half + offs;
+						for (uint32_t i = 0; i < rs.psize; i += dims) {
+							uint32_t idx;
+							if (!r.code(T, cb, idx))
+								return;
+							const float *e = vq + idx * dims;
+							for (uint32_t d = 0; d < dims; d++)
+								v[i + d] += e[d];
+						}
+					} else {
+						for (uint32_t i = 0; i < rs.psize; i += dims) {
+							uint32_t idx;
+							if (!r.code(T, cb, idx))
+								return;
+							const float *e = vq + idx * dims;
+							for (uint32_t d = 0; d < dims; d++) {
+								const uint32_t el = offs + i + d;
+								out[(el % deint_ch) * half + el / deint_ch] += e[d];
+							}
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
+// Floors and residues of one packet (what lw::entropy_decode does after the prologue).  floor_out [ch][fstride],
+// res_out [ch][n/2] zero on entry, ws = T.ws_bytes of scratch (4-byte aligned).
+LW_HD void lw_ent_decode_packet(const LwEntTables &T, const uint32_t *words, uint32_t len_bytes, uint32_t start_bit,
+		uint32_t mode, uint32_t n, uint16_t *floor_out, float *res_out, uint8_t *ws)
+{
+	LwEntReader r;
+	r.w = words;
+	r.nbits = len_bytes * 8u;
+	r.pos = start_bit;
+	const LwEntMode &m = T.modes[mode];
+	const uint32_t ch = T.ch, half = n >> 1;
+	uint32_t *y = (uint32_t *)ws;
+	uint8_t *cls = ws + LW_ENT_POSTS_BYTES;
+	bool no_residue[LW_ENT_MAX_CH];
+	// floor_decode, audio.rs:557-585
+	for (uint32_t c = 0; c < ch; c++) {
+		const LwEntFloor &fl = T.floors[m.floor_of_ch[c]];
+		uint16_t *rec = floor_out + c * T.fstride;
+		if (!lw_ent_floor_decode(T, fl, r, y)) {
+			rec[0] = LW_FLOOR_UNUSED;
+			no_residue[c] = true;
+		} else {
+			lw_ent_floor_record(fl, y, rec);
+			no_residue[c] = false;
+		}
+	}
+	// audio.rs:948-955
+	for (uint32_t i = 0; i < m.n_coupling; i++) {
+		const uint32_t mg = m.mag[i], an = m.ang[i];
+		if (!(no_residue[mg] && no_residue[an]))
+			no_residue[mg] = no_residue[an] = false;
+	}
+	// audio.rs:957-986, one submap: every channel, in order
+	const LwEntResidue &rs = T.residues[m.residue];
+	if (rs.type != 2) {
+		lw_ent_residue(T, rs, r, ch, half, no_residue, res_out, half, 0u, cls);
+		return;
+	}
+	// audio.rs:722-760: type 2 = one interleaved vector of ch * n/2 elements, decoded unless EVERY channel is marked
+	bool any = false;
+	for (uint32_t c = 0; c < ch; c++)
+		any |= !no_residue[c];
+	if (!any)
+		return;
+	const bool one_dnd[1] = {false};
+	lw_ent_residue(T, rs, r, 1u, ch * half, one_dnd, res_out, half, ch, cls);
+}

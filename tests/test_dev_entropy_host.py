@@ -1,0 +1,55 @@
+"""The device entropy stage's per-packet algorithm (lewton_amd/csrc/lw_dev_entropy.h -- the very function the HIP kernel runs
+in every lane) compiled for the host and held against the host entropy stage (lw::entropy_decode) bit for bit: floor
+records and residue vectors of intact, truncated and bit-flipped packets of every eligible stream shape, under ASan/UBSan.
+The GPU side of the same comparison is tests/test_gpu_dev_entropy.py."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+from common import HOST_SETUPS, ROOT
+from lewton_amd import streamgen as sg
+
+CS = os.path.join(ROOT, "lewton_amd", "csrc")
+SRC = [os.path.join(ROOT, "tests", "san", "dev_entropy_host.cpp")] + [
+    os.path.join(CS, n) for n in ("lw_dev_entropy.cpp", "lw_entropy.cpp", "lw_headers.cpp")]
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("deventropy") / "dev_entropy_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off"] + SRC + ["-o", exe])
+    return exe
+
+
+def _case(path, setup, pattern, count, **kw):
+    idp, _, stp = setup.headers()
+    pk = sg.make_stream(setup, pattern, count, **kw)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 1))
+        for b in (idp, stp):
+            f.write(struct.pack("<I", len(b)) + bytes(b))
+        f.write(struct.pack("<I", len(pk)))
+        for p in pk:
+            f.write(struct.pack("<I", len(p)) + bytes(p))
+
+
+@pytest.mark.parametrize("name,pattern", [("stereo", "LLSSLSL"), ("stereo_t1", "LSL"), ("mono_small", "LSSLL"), ("stereo_9_12", "LSL"),
+                                          ("stereo_7_7", "LSL"), ("stereo_single_entry", "LLS")])
+def test_device_algorithm_equals_host_stage(harness, tmp_path, name, pattern):
+    case = str(tmp_path / "case.bin")
+    _case(case, HOST_SETUPS[name](), pattern, 60, seed=11, p_floor_unused=0.15)
+    out = subprocess.run([harness, case, "6", "3"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "device entropy algorithm == host entropy stage" in out.stdout, out.stdout
+
+
+def test_ineligible_streams_say_why(harness, tmp_path):
+    from common import FLOOR0_SETUPS, SETUPS
+    for setup, word in ((SETUPS["surround51"](), "submap"), (FLOOR0_SETUPS["floor0"](), "floor type 0")):
+        case = str(tmp_path / "case.bin")
+        _case(case, setup, "LS", 4, seed=1)
+        out = subprocess.run([harness, case, "0"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "not eligible" in out.stdout and word in out.stdout, out.stdout + out.stderr
