@@ -193,6 +193,19 @@ void lw_batch_set_force_generic(lw_batch *b, int on);
  * partition size (then no codeword crosses a partition end); otherwise LW_ERR_UNSUPPORTED and the batch stays in host
  * mode -- lw_decoder_supports_device_vq says which (and why not). */
 int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why);
+/* Entropy stage on the device ("Tier C"; csrc/lw_dev_entropy.h, k_entropy): the bit-serial half of
+ * read_audio_packet_generic (audio.rs:921-986: floor-1 decode :215-251 + amplitude unwrap :391-435, residue decode
+ * :587-760) runs on the GPU, one lane per packet; lw_batch_entropy then only reads the prologues, copies the packets
+ * into pinned staging and plans the batch, and the packets themselves (~0.5 KB instead of 8.3 KB of records per stereo
+ * long block) cross PCIe.  Records, PCM and statuses are bit-identical to the host stage's.  Eligible streams: floor type
+ * 1, one submap per mapping, residue books whose dimension divides the partition size, every Huffman code inside the
+ * two table levels (`why` names the reason otherwise; LW_ERR_UNSUPPORTED from the setters). */
+int lw_decoder_supports_device_entropy(const lw_decoder *d, const char **why);
+int lw_batch_set_entropy_on_device(lw_batch *b, int on);
+/* Runs k_entropy for the records uploaded last (after lw_batch_upload, on the same stream), ahead of lw_batch_synth: the
+ * entropy kernel touches no stream state, so a pipeline may queue it before it orders the synthesis kernels behind the
+ * previous batch's (the staging ring does).  lw_batch_synth runs it itself when this was not called.  No-op in host mode. */
+int lw_batch_device_entropy(lw_batch *b, void *hip_stream);
 int lw_batch_set_residue_on_device(lw_batch *b, int on);
 /* names of the kernels the last lw_batch_synth used, comma separated (introspection for tests/bench) */
 const char *lw_batch_last_kernels(const lw_batch *b);
@@ -225,6 +238,7 @@ int lw_ring_drain(lw_ring *r);
 size_t lw_ring_slots(const lw_ring *r);
 size_t lw_ring_in_flight(lw_ring *r); /* slots staged, launched or collected and not yet released */
 int lw_ring_set_residue_on_device(lw_ring *r, int on); /* lw_batch_set_residue_on_device for every slot (ring must be idle) */
+int lw_ring_set_entropy_on_device(lw_ring *r, int on); /* lw_batch_set_entropy_on_device for every slot (ring must be idle) */
 const char *lw_ring_last_kernels(const lw_ring *r);
 /* The host half of a PreviousWindowRight (whether a right part is stored, its length, which of the two device buffers
  * holds it).  lw_batch_entropy / lw_ring_stage advance it when they plan a batch; a caller that drops a staged batch (or

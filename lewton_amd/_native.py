@@ -120,6 +120,9 @@ SYMBOLS = {
     "lw_batch_last_kernels": (C.c_char_p, [C.c_void_p]),
     "lw_decoder_supports_device_vq": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
     "lw_batch_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "lw_decoder_supports_device_entropy": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
+    "lw_batch_set_entropy_on_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "lw_batch_device_entropy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lw_ring_create": (C.c_void_p, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, intp]),
     "lw_ring_destroy": (None, [C.c_void_p]),
     "lw_ring_stage": (C.c_int, [C.c_void_p, C.POINTER(Packet), C.c_size_t, C.c_int]),
@@ -131,6 +134,7 @@ SYMBOLS = {
     "lw_ring_slots": (C.c_size_t, [C.c_void_p]),
     "lw_ring_in_flight": (C.c_size_t, [C.c_void_p]),
     "lw_ring_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "lw_ring_set_entropy_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_ring_last_kernels": (C.c_char_p, [C.c_void_p]),
     "lw_sharder_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_size_t, C.c_size_t, C.c_int, intp]),
     "lw_sharder_destroy": (None, [C.c_void_p]),

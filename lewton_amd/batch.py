@@ -115,6 +115,16 @@ class Batch:
             raise RuntimeError("lw_batch_set_residue_on_device: %d %s" % (rc, N.device_error()))
         return True
 
+    def set_entropy_on_device(self, on=True):
+        """Entropy stage on the device (lw_batch_set_entropy_on_device, k_entropy).  Returns False when the stream is not
+        eligible (lw_decoder_supports_device_entropy says why)."""
+        rc = N.lw_batch_set_entropy_on_device(self._h, 1 if on else 0)
+        if rc == N.ERR_UNSUPPORTED:
+            return False
+        if rc:
+            raise RuntimeError("lw_batch_set_entropy_on_device: %d %s" % (rc, N.device_error()))
+        return True
+
     def split(self, flat, channels):
         """Split the flat output of synth_to_host into per-packet arrays ([ch][m], or [m*ch] interleaved)."""
         out = []

@@ -90,6 +90,14 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_sym);
 	if (b->h_sym_off)
 		(void)hipHostFree(b->h_sym_off);
+	if (b->h_pk)
+		(void)hipHostFree(b->h_pk);
+	if (b->h_pool)
+		(void)hipHostFree(b->h_pool);
+	void *ent[] = {b->d_pk, b->d_pool, b->d_ws};
+	for (void *p : ent)
+		if (p)
+			(void)hipFree(p);
 	void *dev[] = {b->d_slab, b->d_sym, b->d_sym_off, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
 	for (void *p : dev)
 		if (p)
@@ -101,6 +109,31 @@ void lw_batch_set_force_generic(lw_batch *b, int on)
 {
 	if (b)
 		b->force_generic = on != 0;
+}
+
+/* Entropy stage on the device (lw_dev_entropy.h, k_entropy): lw_batch_entropy then only reads the packet prologues, copies
+ * the packets into pinned staging and plans the batch; floors and residues are decoded by one GPU lane per packet. */
+int lw_batch_set_entropy_on_device(lw_batch *b, int on)
+{
+	if (!b)
+		return LW_ERR_NULL_ARG;
+	if (!on) {
+		b->dev_entropy = false;
+		return LW_OK;
+	}
+	lw_decoder *d = b->dec;
+	if (!d->dev_entropy_ok)
+		return LW_ERR_UNSUPPORTED; // lw_decoder_supports_device_entropy says why
+	if (int rc = lw_decoder_set_device(d))
+		return rc;
+	if (!b->h_pk) {
+		HIP_TRY(hipHostMalloc((void **)&b->h_pk, b->max_packets * sizeof(LwEntPacket)));
+		HIP_TRY(hipMalloc((void **)&b->d_pk, b->max_packets * sizeof(LwEntPacket)));
+		HIP_TRY(hipMalloc((void **)&b->d_ws, b->max_packets * (size_t)d->E.ws_bytes));
+	}
+	b->symbols = false;
+	b->dev_entropy = true;
+	return LW_OK;
 }
 
 int lw_batch_set_residue_on_device(lw_batch *b, int on)
@@ -121,6 +154,7 @@ int lw_batch_set_residue_on_device(lw_batch *b, int on)
 			return LW_ERR_DEVICE;
 	}
 	b->symbols = true;
+	b->dev_entropy = false;
 	return LW_OK;
 }
 
@@ -184,10 +218,51 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		if (b->status[i] == LW_OK) {
 			res_off += ch * (b->prologues[i].n / 2);
 			max_n = std::max(max_n, b->prologues[i].n);
+			if (b->dev_entropy)
+				b->h_pk[i].start_bit = (uint8_t)br.pos;
 		}
 	}
 	b->res_floats = res_off;
 	b->max_n = max_n;
+	if (b->dev_entropy) {
+		// entropy stage on the device: the packets go up as they are, word-aligned and followed by at least 8 zero bytes (the
+		// device reader looks two words ahead); for the eligible setups the prologue alone decides a packet's status
+		size_t words = 0;
+		for (size_t i = 0; i < n; i++) {
+			if (b->status[i] != LW_OK)
+				continue;
+			b->h_pk[i].word_off = (uint32_t)words;
+			b->h_pk[i].len = (uint32_t)pkts[i].len;
+			words += (pkts[i].len + 3) / 4 + 2;
+		}
+		if (words > b->pool_cap_words) {
+			const size_t cap = words + words / 2 + 1024;
+			if (b->d_pool) {
+				if (!lw_hip_ok(hipDeviceSynchronize(), "sync before growing the packet pool"))
+					return LW_ERR_DEVICE;
+				(void)hipFree(b->d_pool);
+				b->d_pool = nullptr;
+			}
+			if (b->h_pool)
+				(void)hipHostFree(b->h_pool);
+			b->h_pool = nullptr;
+			b->pool_cap_words = 0;
+			if (!lw_hip_ok(hipHostMalloc((void **)&b->h_pool, cap * 4), "hipHostMalloc(packet pool)") ||
+					!lw_hip_ok(hipMalloc((void **)&b->d_pool, cap * 4), "hipMalloc(packet pool)"))
+				return LW_ERR_DEVICE;
+			b->pool_cap_words = cap;
+		}
+		b->pool_words = words;
+		for (size_t i = 0; i < n; i++) {
+			if (b->status[i] != LW_OK)
+				continue;
+			uint8_t *dst = (uint8_t *)(b->h_pool + b->h_pk[i].word_off);
+			const size_t len = pkts[i].len, padded = ((len + 3) / 4 + 2) * 4;
+			if (len)
+				std::memcpy(dst, pkts[i].data, len);
+			std::memset(dst + len, 0, padded - len);
+		}
+	}
 
 	// pass 2 (parallel): entropy decode straight into the pinned staging buffers
 	unsigned nt = n_threads > 0 ? (unsigned)n_threads : lw::default_host_threads();
@@ -252,7 +327,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			}
 		}
 	};
-	lw::entropy_pool().run(nt, worker);
+	if (!b->dev_entropy)
+		lw::entropy_pool().run(nt, worker);
 	if (b->symbols) {
 		const size_t total = pool_used.load();
 		if (overflow) {
@@ -529,14 +605,21 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	const size_t ch = b->dec->T.ch;
 	if (b->n == 0)
 		return LW_OK;
-	if (b->slab_bytes <= 64 * 1024 && !b->symbols) { // small batch: the whole slab in one copy
+	b->ent_done = false;
+	if (b->dev_entropy) {
+		HIP_TRY(hipMemcpyAsync(b->d_pk, b->h_pk, b->n * sizeof(LwEntPacket), hipMemcpyHostToDevice, st));
+		if (b->pool_words)
+			HIP_TRY(hipMemcpyAsync(b->d_pool, b->h_pool, b->pool_words * 4, hipMemcpyHostToDevice, st));
+	}
+	if (b->slab_bytes <= 64 * 1024 && !b->symbols && !b->dev_entropy) { // small batch: the whole slab in one copy
 		HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_slab, b->slab_bytes, hipMemcpyHostToDevice, st));
 		return LW_OK;
 	}
 	HIP_TRY(hipMemcpyAsync(b->d_recs, b->h_recs, b->n * sizeof(LwPacketRec), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(b->d_floor, b->h_floor, b->n * ch * b->dec->T.fstride * sizeof(uint16_t),
-				hipMemcpyHostToDevice, st));
-	if (b->res_floats && !b->symbols)
+	if (!b->dev_entropy)
+		HIP_TRY(hipMemcpyAsync(b->d_floor, b->h_floor, b->n * ch * b->dec->T.fstride * sizeof(uint16_t),
+					hipMemcpyHostToDevice, st));
+	if (b->res_floats && !b->symbols && !b->dev_entropy)
 		HIP_TRY(hipMemcpyAsync(b->d_res, b->h_res, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
 	if (b->symbols) {
 		HIP_TRY(hipMemcpyAsync(b->d_sym_off, b->h_sym_off, b->n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -559,6 +642,20 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
 		HIP_TRY(hipMemcpyAsync(b->d_halo_items, b->h_halo_items, b->n_halo_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
+	return LW_OK;
+}
+
+// entropy stage on the device: zero the residue vectors, one lane per packet decodes floors and residues (once per upload)
+static int device_entropy(lw_batch *b, hipStream_t st)
+{
+	if (!b->dev_entropy || b->ent_done || b->n == 0)
+		return LW_OK;
+	lw_decoder *d = b->dec;
+	if (b->res_floats)
+		HIP_TRY(hipMemsetAsync(b->d_res, 0, b->res_floats * sizeof(float), st));
+	lw_launch_entropy(d->E, b->d_pk, b->d_recs, b->d_pool, b->d_floor, b->d_res, b->d_ws, (uint32_t)b->n, st);
+	HIP_TRY(hipGetLastError());
+	b->ent_done = true;
 	return LW_OK;
 }
 
@@ -605,6 +702,11 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.sym = b->symbols ? b->d_sym : nullptr;
 	B.sym_off = b->d_sym_off;
 	b->last_kernels.clear();
+	if (b->dev_entropy) {
+		if (int rc = device_entropy(b, st))
+			return rc;
+		b->last_kernels = "k_entropy,";
+	}
 	if (b->symbols) {
 		lw_launch_residue_vq(d->T, d->V, B, st, b->max_n, d->vq_book_ends.data(), d->vq_book_ends.size());
 		b->last_kernels = "k_residue_vq,";
@@ -654,6 +756,15 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		b->last_kernels.pop_back();
 	HIP_TRY(hipGetLastError());
 	return LW_OK;
+}
+
+int lw_batch_device_entropy(lw_batch *b, void *hip_stream)
+{
+	if (!b)
+		return LW_ERR_NULL_ARG;
+	if (int rc = lw_decoder_set_device(b->dec))
+		return rc;
+	return device_entropy(b, (hipStream_t)hip_stream);
 }
 
 int lw_batch_synth(lw_batch *b, void *d_out, size_t out_capacity_elems, void *hip_stream)
@@ -713,7 +824,7 @@ int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats
 	const size_t want = tap == LW_TAP_POST_MDCT ? ch * n : ch * n / 2;
 	if (cap_floats < want)
 		return LW_ERR_CAPACITY;
-	if (tap == LW_TAP_RESIDUE_PRE_INVERSE && !b->symbols) {
+	if (tap == LW_TAP_RESIDUE_PRE_INVERSE && !b->symbols && !b->dev_entropy) {
 		std::memcpy(dst, b->h_res + r.res_off, want * sizeof(float));
 		return LW_OK;
 	}

@@ -21,8 +21,8 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__)
-#define LW_HD __host__ __device__ __forceinline__
+#if defined(__HIP__) // compiled as HIP (lw_kernels_entropy.hip); plain C++ translation units get the host version only
+#define LW_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define LW_HD inline
 #endif
@@ -184,11 +184,9 @@ LW_HD uint32_t lw_ent_render_point(uint32_t y0, uint32_t y1, uint32_t dx, uint64
 	const int32_t dy = (int32_t)(y1 - y0);
 	const uint32_t ady = dy < 0 ? 0u - (uint32_t)dy : (uint32_t)dy;
 	const uint32_t num = ady * dx;
-#if defined(__HIP_DEVICE_COMPILE__)
-	const uint32_t off = (uint32_t)__umul64hi((uint64_t)num, adx_magic);
-#else
-	const uint32_t off = (uint32_t)(((unsigned __int128)num * adx_magic) >> 64);
-#endif
+	// (num * magic) >> 64 in 64-bit pieces: adx >= 2 (a post lies strictly between its neighbours), so magic <= 2^63 + 1
+	const uint64_t hi = (uint64_t)num * (adx_magic >> 32), lo = (uint64_t)num * (adx_magic & 0xffffffffu);
+	const uint32_t off = (uint32_t)((hi + (lo >> 32)) >> 32);
 	return dy < 0 ? y0 - off : y0 + off;
 }
 

@@ -8,6 +8,7 @@
 #include "lw_entropy.hpp"
 #include "lw_fast.hpp"
 #include "lw_host.hpp"
+#include "lw_dev_entropy.h"
 #include "lw_kernels.hpp"
 
 #include <memory>
@@ -48,6 +49,11 @@ struct lw_decoder {
 	LwVqTables V{};
 	void *d_vq_blob = nullptr;
 	std::vector<uint32_t> vq_book_ends; // cumulative float offsets of the book tables in V.vq (ascending table size)
+	// entropy stage on the device (lw_dev_entropy.h): the flattened setup image in HBM, or why the stream is not eligible
+	bool dev_entropy_ok = false;
+	std::string dev_entropy_why;
+	void *d_ent_blob = nullptr;
+	LwEntTables E{};
 	uint32_t max_posts = 2;
 	std::vector<uint64_t> mode_floor_bytes; // per mode: bytes of floor input over all channels (SURVEY 8(d) accounting)
 	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
@@ -92,6 +98,13 @@ struct lw_batch {
 	bool symbols = false;
 	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
 	size_t sym_cap_words = 0, sym_words = 0;
+	// entropy stage on the device: the packets themselves go up (word-aligned, zero padded) with one descriptor each
+	bool dev_entropy = false;
+	LwEntPacket *h_pk = nullptr, *d_pk = nullptr; // [max_packets]
+	uint32_t *h_pool = nullptr, *d_pool = nullptr;
+	size_t pool_cap_words = 0, pool_words = 0;
+	uint8_t *d_ws = nullptr; // [max_packets][E.ws_bytes] per-packet scratch of k_entropy
+	bool ent_done = false;   // k_entropy has run for the records uploaded last (lw_batch_device_entropy ahead of lw_batch_synth)
 	LwPacketRec *d_recs = nullptr;
 	uint16_t *d_floor = nullptr;
 	float *d_res = nullptr;

@@ -142,6 +142,20 @@ int lw_ring_set_residue_on_device(lw_ring *r, int on)
 	return LW_OK;
 }
 
+int lw_ring_set_entropy_on_device(lw_ring *r, int on)
+{
+	if (!r)
+		return LW_ERR_NULL_ARG;
+	std::lock_guard<std::mutex> g(r->mu);
+	for (Slot &s : r->slots)
+		if (s.state != SLOT_FREE)
+			return LW_ERR_CAPACITY; // only between batches
+	for (Slot &s : r->slots)
+		if (int rc = lw_batch_set_entropy_on_device(s.batch, on))
+			return rc;
+	return LW_OK;
+}
+
 size_t lw_ring_slots(const lw_ring *r)
 {
 	return r ? r->slots.size() : 0;
@@ -200,6 +214,8 @@ int lw_ring_launch(lw_ring *r)
 	if (!ok(hipSetDevice(r->device)))
 		return LW_ERR_DEVICE;
 	int rc = lw_batch_upload(s->batch, s->stream);
+	if (rc == LW_OK) // entropy stage on the device: no stream state involved, so it runs beside the previous launches' kernels
+		rc = lw_batch_device_entropy(s->batch, s->stream);
 	if (rc == LW_OK && r->last_kernels && !ok(hipStreamWaitEvent(s->stream, r->last_kernels, 0)))
 		rc = LW_ERR_DEVICE;
 	if (rc == LW_OK)

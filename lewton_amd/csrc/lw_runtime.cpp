@@ -7,6 +7,7 @@
 #include "../../include/lewton_amd.h"
 
 #include "lw_internal.hpp"
+#include "lw_dev_entropy.hpp"
 #include "lw_pool.hpp"
 
 #include <algorithm>
@@ -624,6 +625,23 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			d->V.chmap = (const LwChanMap *)(vbase + o_ch);
 		}
 	}
+	{ // entropy stage on the device: the flattened setup image (eligible streams only; the host stage serves the others)
+		lw::DevEntropyImage img;
+		const char *why = "";
+		if (lw::dev_entropy_build(id, s, (unsigned)d->T.fstride, img, &why)) {
+			if (!lw_hip_ok(hipMalloc(&d->d_ent_blob, img.blob.size()), "hipMalloc(entropy image)") ||
+					!lw_hip_ok(hipMemcpy(d->d_ent_blob, img.blob.data(), img.blob.size(), hipMemcpyHostToDevice),
+						"hipMemcpy(entropy image)")) {
+				*err = LW_ERR_DEVICE;
+				(void)hipFree(d->d_blob);
+				return nullptr;
+			}
+			d->E = lw::dev_entropy_view(img, (const uint8_t *)d->d_ent_blob);
+			d->dev_entropy_ok = true;
+		} else {
+			d->dev_entropy_why = why;
+		}
+	}
 	lw::build_fast_plan(id, s, d->fast);
 	if (d->fast.eligible) {
 		std::memcpy(d->fast.image.data() + d->fast.off.inv_db, kInverseDbTable, sizeof(float) * 256);
@@ -657,6 +675,8 @@ void lw_decoder_destroy(lw_decoder *d)
 		(void)hipFree(d->d_blob);
 	if (d->d_vq_blob)
 		(void)hipFree(d->d_vq_blob);
+	if (d->d_ent_blob)
+		(void)hipFree(d->d_ent_blob);
 	if (d->d_fast_image)
 		(void)hipFree(d->d_fast_image);
 	if (d->d_fast_units)
@@ -781,6 +801,13 @@ int lw_pwr_copy_to_host(const lw_pwr *p, float *dst)
 	HIP_TRY(hipMemcpy2D(dst, p->len * sizeof(float), src, d->T.state_chan_stride * sizeof(float), p->len * sizeof(float),
 				d->T.ch, hipMemcpyDeviceToHost));
 	return LW_OK;
+}
+
+int lw_decoder_supports_device_entropy(const lw_decoder *d, const char **why)
+{
+	if (why)
+		*why = d ? d->dev_entropy_why.c_str() : "";
+	return d && d->dev_entropy_ok ? 1 : 0;
 }
 
 int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why)

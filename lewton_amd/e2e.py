@@ -16,7 +16,7 @@ from .ring import Ring
 
 
 def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots=3, device_vq=False, callers=1, seed=1,
-            samples="i16", warm=4):
+            samples="i16", warm=4, device_entropy=False):
     """Returns a dict: packets/s, H2D / D2H GB/s, host entropy stage alone, kernels used.
     Every caller thread owns a ring and `streams` independent streams, each contributing packets/streams consecutive
     packets per batch (the bench workload, BASELINE configs[1])."""
@@ -27,6 +27,8 @@ def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots
         ring = Ring(dec, slots, packets, samples)
         if device_vq and not ring.set_residue_on_device(True):
             raise RuntimeError("stream not eligible for the device inverse VQ")
+        if device_entropy and not ring.set_entropy_on_device(True):
+            raise RuntimeError("stream not eligible for the device entropy stage")
         pwrs = [audio.PreviousWindowRight() for _ in range(streams)]
         batches = []
         for b in range(min(n_batches, 8)):       # 8 distinct batches, reused round-robin
@@ -73,10 +75,13 @@ def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots
     npk = n_batches * packets * callers
     ch, half = dec.ident.audio_channels, (1 << dec.ident.blocksize_1) // 2
     rec_bytes = ch * half * 4 + 132 + 32 if not device_vq else None   # f32 residues + floor records + packet record
+    if device_entropy:
+        rec_bytes = payload / packets + 8 + 16 + 32                     # the packet, its padding and descriptor, the packet record
     esz = 4 if samples == "f32" else 2
     out = {
         "value": npk / dt, "unit": "packets/s", "packets": npk, "seconds": dt,
-        "records": "codeword symbols (Tier B)" if device_vq else "f32 residue vectors (Tier A)",
+        "records": "raw packets, entropy stage on the device (Tier C)" if device_entropy else
+                   "codeword symbols (Tier B)" if device_vq else "f32 residue vectors (Tier A)",
         "h2d_GBps": (npk * rec_bytes / dt / 1e9) if rec_bytes else None,
         "d2h_GBps": npk * ch * half * esz / dt / 1e9,
         "vorbis_payload_MBps": payload / packets * npk / dt / 1e6,

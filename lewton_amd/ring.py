@@ -56,6 +56,16 @@ class Ring:
             raise RuntimeError("lw_ring_set_residue_on_device: %d" % rc)
         return True
 
+    def set_entropy_on_device(self, on=True):
+        """Entropy stage on the device (lw_ring_set_entropy_on_device): the packets themselves cross PCIe, k_entropy decodes
+        floors and residues, one lane per packet.  Returns False (host stage stays) when the stream is not eligible."""
+        rc = N.lw_ring_set_entropy_on_device(self._h, 1 if on else 0)
+        if rc == N.ERR_UNSUPPORTED:
+            return False
+        if rc:
+            raise RuntimeError("lw_ring_set_entropy_on_device: %d" % rc)
+        return True
+
     def _call(self, name, rc):
         if rc:
             raise RuntimeError("%s: %d %s" % (name, rc, N.device_error()))

@@ -11,7 +11,7 @@ import pytest
 from common import ROOT, sg
 
 SRC = [os.path.join(ROOT, "tools", "micro", "batch_host_bench.cpp")] + [
-    os.path.join(ROOT, "lewton_amd", "csrc", n) for n in ("lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_pool.cpp", "lw_entropy.cpp", "lw_headers.cpp", "lw_fast.cpp")]
+    os.path.join(ROOT, "lewton_amd", "csrc", n) for n in ("lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_pool.cpp", "lw_dev_entropy.cpp", "lw_entropy.cpp", "lw_headers.cpp", "lw_fast.cpp")]
 HIP_INC = "/opt/rocm/include"
 
 

@@ -15,7 +15,7 @@ from test_ogg import GOLDEN, _vorbis_stream
 
 CS = os.path.join(ROOT, "lewton_amd", "csrc")
 SRC = [os.path.join(ROOT, "tests", "san", "ogg_stream_host.cpp")] + [
-    os.path.join(CS, n) for n in ("lw_ogg.cpp", "lw_ring.cpp", "lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_pool.cpp", "lw_entropy.cpp", "lw_headers.cpp", "lw_fast.cpp")]
+    os.path.join(CS, n) for n in ("lw_ogg.cpp", "lw_ring.cpp", "lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_pool.cpp", "lw_dev_entropy.cpp", "lw_entropy.cpp", "lw_headers.cpp", "lw_fast.cpp")]
 HIP_INC = "/opt/rocm/include"
 
 

@@ -36,7 +36,7 @@ with tempfile.TemporaryDirectory() as tmp:
             f.write(struct.pack("<I", len(p)) + bytes(p))
     exe = os.path.join(tmp, "batch_host_bench")
     src = [os.path.join(ROOT, "tools", "micro", "batch_host_bench.cpp")] + [
-        os.path.join(ROOT, "lewton_amd", "csrc", n) for n in ("lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_pool.cpp", "lw_entropy.cpp", "lw_headers.cpp", "lw_fast.cpp")]
+        os.path.join(ROOT, "lewton_amd", "csrc", n) for n in ("lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_pool.cpp", "lw_dev_entropy.cpp", "lw_entropy.cpp", "lw_headers.cpp", "lw_fast.cpp")]
     subprocess.check_call([args.cxx, "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__",
                            "-I/opt/rocm/include"] + src + ["-lpthread", "-o", exe])
     subprocess.check_call([exe, case, str(args.packets), str(args.streams), str(args.reps), "1" if args.symbols else "0"]

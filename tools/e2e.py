@@ -18,6 +18,7 @@ ap.add_argument("--streams", type=int, default=256)
 ap.add_argument("--slots", type=int, default=3)
 ap.add_argument("--device-vq", action="store_true", help="Tier B: ship codeword symbols, inverse VQ in k_residue_vq")
 ap.add_argument("--callers", type=int, default=1, help="host threads, each with its own ring and its own streams")
+ap.add_argument("--device-entropy", action="store_true", help="Tier C: ship the packets, entropy stage in k_entropy")
 args = ap.parse_args()
 
 setup = sg.stereo_setup(44100, 8, 11)
@@ -26,7 +27,8 @@ ident = header.read_header_ident(idp)
 st = header.read_header_setup(stp, 2, (8, 11))
 dec = audio.decoder_for(ident, st, 0)
 pool = sg.make_stream(setup, "L", 512, seed=9)
-r = e2e.measure(dec, pool, args.batches, args.packets, args.streams, args.threads, args.slots, args.device_vq, args.callers)
+r = e2e.measure(dec, pool, args.batches, args.packets, args.streams, args.threads, args.slots, args.device_vq, args.callers,
+                device_entropy=args.device_entropy)
 print(json.dumps(r))
 print("end-to-end: %d packets in %.3f s -> %.2f M packets/s (%s; H2D %s GB/s, D2H %.2f GB/s); host entropy stage alone "
       "%.2f M packets/s on %s threads, %d caller(s), %d slots" % (
