@@ -306,6 +306,20 @@ def main():
                 e2e_obj["tier_b"] = {k: r_[k] for k in ("value", "unit", "records", "d2h_GBps", "host_entropy_stage_alone", "kernels")}
             except Exception as e:
                 e2e_obj["tier_b"] = {"error": repr(e)}
+            try:   # entropy stage on the device (k_entropy, one lane per packet): the packets themselves cross PCIe, two host
+                   # threads read prologues and plan; at the bench's batch size and with larger batches in flight
+                keys = ("value", "unit", "records", "h2d_GBps", "d2h_GBps", "host_entropy_stage_alone", "host_threads", "ring_slots",
+                        "kernels", "packets")
+                r_ = e2e_mod.measure(dec, pool, n_batches=args.e2e_batches, packets=PACKETS_PER_BATCH, streams=S, threads=2, slots=3,
+                                     callers=1, samples=args.format, device_entropy=True)
+                e2e_obj["tier_c"] = {k: r_[k] for k in keys}
+                e2e_obj["tier_c"]["packets_per_batch"] = PACKETS_PER_BATCH
+                big = 4 * PACKETS_PER_BATCH
+                r_ = e2e_mod.measure(dec, pool, n_batches=max(8, args.e2e_batches // 4), packets=big, streams=4 * S, threads=2, slots=4,
+                                     callers=1, samples=args.format, device_entropy=True)
+                e2e_obj["tier_c"]["large_batches"] = dict({k: r_[k] for k in keys}, packets_per_batch=big)
+            except Exception as e:
+                e2e_obj["tier_c"] = {"error": repr(e)}
         except Exception as e:
             e2e_obj = {"error": repr(e)}
 

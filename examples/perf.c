@@ -4,6 +4,7 @@
  *
  *   perf file.ogg            packet by packet, like `while let Some(pck) = srr.read_dec_packet()?`
  *   perf file.ogg K [T]      look-ahead queue: K packets per batch (one set of kernel launches), T host entropy threads
+ *   perf file.ogg K T dev    the same with the entropy stage on the device (eligible streams; T is then of no consequence)
  *
  * Build: cc -O2 -Iinclude examples/perf.c -Llewton_amd/_lib -llewton_amd -Wl,-rpath,$PWD/lewton_amd/_lib -o examples/perf
  */
@@ -28,6 +29,7 @@ int main(int argc, char **argv)
 	}
 	const size_t K = argc > 2 ? (size_t)strtoul(argv[2], NULL, 10) : 0;
 	const int threads = argc > 3 ? atoi(argv[3]) : 0;
+	const int dev_entropy = argc > 4;
 	int err = 0;
 	printf("Opening file: %s\n", argv[1]);
 	lw_ogg_reader *rdr = lw_ogg_reader_open_file(argv[1], &err);
@@ -40,6 +42,8 @@ int main(int argc, char **argv)
 		fprintf(stderr, "Error: %d\n", err);
 		return 1;
 	}
+	if (dev_entropy)
+		lw_ogg_stream_set_entropy_on_device(srr, 1);
 	lw_ident_info info;
 	lw_ident_get_info(lw_ogg_stream_ident(srr), &info);
 	printf("Sample rate: %u\n", info.audio_sample_rate);

@@ -363,6 +363,9 @@ int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t c
  * LW_OGG_EOF when no packet is left, or an error. */
 int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out,
 		size_t cap_elems, uint32_t *n_samples, int32_t *status, size_t *n_packets);
+/* Look-ahead batches with the entropy stage on the device (lw_ring_set_entropy_on_device) whenever the current logical
+ * stream is eligible; other streams (and the packet-by-packet call) keep the host stage.  Results are identical. */
+int lw_ogg_stream_set_entropy_on_device(lw_ogg_stream *s, int on);
 /* skip_samples_linear<S> (:244-283): *got_packet = 0 is (None, left); otherwise the decoded packet that contains the
  * target is in out and *left samples of it remain to be skipped.  LW_ERR_CAPACITY as above: call again with
  * to_skip = *left and a buffer for the current logical stream. */

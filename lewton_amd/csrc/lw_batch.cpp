@@ -94,7 +94,7 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_pk);
 	if (b->h_pool)
 		(void)hipHostFree(b->h_pool);
-	void *ent[] = {b->d_pk, b->d_pool, b->d_ws};
+	void *ent[] = {b->d_pk, b->d_pool};
 	for (void *p : ent)
 		if (p)
 			(void)hipFree(p);
@@ -112,7 +112,7 @@ void lw_batch_set_force_generic(lw_batch *b, int on)
 }
 
 /* Entropy stage on the device (lw_dev_entropy.h, k_entropy): lw_batch_entropy then only reads the packet prologues, copies
- * the packets into pinned staging and plans the batch; floors and residues are decoded by one GPU lane per packet. */
+ * the packets into pinned staging and plans the batch; floors and residues are decoded by one GPU wave per packet. */
 int lw_batch_set_entropy_on_device(lw_batch *b, int on)
 {
 	if (!b)
@@ -129,7 +129,6 @@ int lw_batch_set_entropy_on_device(lw_batch *b, int on)
 	if (!b->h_pk) {
 		HIP_TRY(hipHostMalloc((void **)&b->h_pk, b->max_packets * sizeof(LwEntPacket)));
 		HIP_TRY(hipMalloc((void **)&b->d_pk, b->max_packets * sizeof(LwEntPacket)));
-		HIP_TRY(hipMalloc((void **)&b->d_ws, b->max_packets * (size_t)d->E.ws_bytes));
 	}
 	b->symbols = false;
 	b->dev_entropy = true;
@@ -225,15 +224,15 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->res_floats = res_off;
 	b->max_n = max_n;
 	if (b->dev_entropy) {
-		// entropy stage on the device: the packets go up as they are, word-aligned and followed by at least 8 zero bytes (the
-		// device reader looks two words ahead); for the eligible setups the prologue alone decides a packet's status
+		// entropy stage on the device: the packets go up as they are, word-aligned and followed by at least 3 zero words (the
+		// device reader requests its window one refill ahead); for the eligible setups the prologue alone decides a packet's status
 		size_t words = 0;
 		for (size_t i = 0; i < n; i++) {
 			if (b->status[i] != LW_OK)
 				continue;
 			b->h_pk[i].word_off = (uint32_t)words;
 			b->h_pk[i].len = (uint32_t)pkts[i].len;
-			words += (pkts[i].len + 3) / 4 + 2;
+			words += (pkts[i].len + 3) / 4 + 3;
 		}
 		if (words > b->pool_cap_words) {
 			const size_t cap = words + words / 2 + 1024;
@@ -257,7 +256,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			if (b->status[i] != LW_OK)
 				continue;
 			uint8_t *dst = (uint8_t *)(b->h_pool + b->h_pk[i].word_off);
-			const size_t len = pkts[i].len, padded = ((len + 3) / 4 + 2) * 4;
+			const size_t len = pkts[i].len, padded = ((len + 3) / 4 + 3) * 4;
 			if (len)
 				std::memcpy(dst, pkts[i].data, len);
 			std::memset(dst + len, 0, padded - len);
@@ -645,15 +644,13 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	return LW_OK;
 }
 
-// entropy stage on the device: zero the residue vectors, one lane per packet decodes floors and residues (once per upload)
+// entropy stage on the device: one wave per packet decodes floors and residues (once per upload)
 static int device_entropy(lw_batch *b, hipStream_t st)
 {
 	if (!b->dev_entropy || b->ent_done || b->n == 0)
 		return LW_OK;
 	lw_decoder *d = b->dec;
-	if (b->res_floats)
-		HIP_TRY(hipMemsetAsync(b->d_res, 0, b->res_floats * sizeof(float), st));
-	lw_launch_entropy(d->E, b->d_pk, b->d_recs, b->d_pool, b->d_floor, b->d_res, b->d_ws, (uint32_t)b->n, st);
+	lw_launch_entropy(d->E, b->d_pk, b->d_recs, b->d_pool, b->d_floor, b->d_res, (uint32_t)b->n, st);
 	HIP_TRY(hipGetLastError());
 	b->ent_done = true;
 	return LW_OK;

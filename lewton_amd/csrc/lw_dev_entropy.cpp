@@ -182,7 +182,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 			return false;
 		}
 		const Codebook &cbk = s.codebooks[rs.classbook];
-		if (cbk.dims == 0 || cbk.dims > 255) {
+		if (cbk.dims == 0 || cbk.dims > 64) {
 			*why = "classbook dimensions";
 			return false;
 		}
@@ -206,7 +206,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 					return false;
 				}
 				const Codebook &cb = s.codebooks[bi];
-				if (cb.dims == 0 || cb.dims > 255 || !cb.has_vq || cb.vq.size() < (size_t)cb.entries * cb.dims) {
+				if (cb.dims == 0 || cb.dims > 64 || !cb.has_vq || cb.vq.size() < (size_t)cb.entries * cb.dims) {
 					*why = "a residue book without a vector lookup";
 					return false;
 				}
@@ -271,6 +271,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	img.ch = (uint32_t)ch;
 	img.fstride = fstride;
 	img.ws_bytes = (uint32_t)((LW_ENT_POSTS_BYTES + cls_bytes + 15) & ~(size_t)15);
+	img.res_floats = (uint32_t)(ch * (n1 / 2));
 	return true;
 }
 
@@ -287,6 +288,7 @@ LwEntTables dev_entropy_view(const DevEntropyImage &img, const uint8_t *base)
 	T.ch = img.ch;
 	T.fstride = img.fstride;
 	T.ws_bytes = img.ws_bytes;
+	T.res_floats = img.res_floats;
 	return T;
 }
 

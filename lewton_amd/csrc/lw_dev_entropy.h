@@ -1,18 +1,18 @@
 // Entropy stage ON THE DEVICE (product code): the bit-serial half of read_audio_packet_generic (audio.rs:921-986 --
 // floor-1 decode :215-251 with the amplitude unwrap :391-435, residue decode :587-760) restated so that it compiles for the
-// GPU (lw_kernels_entropy.hip: one LANE per packet, 64 packets per wave) and, unchanged, for the host, where the CPU
-// suite runs it packet by packet against the host entropy stage (lw_entropy.cpp) on intact, truncated and mutated packets.
+// GPU (lw_kernels_entropy.hip: one WAVE per packet) and, unchanged, for the host, where the CPU suite runs it packet by
+// packet against the host entropy stage (lw_entropy.cpp) on intact, truncated and mutated packets.
 //
 // Why: the host stage costs 5.4-6 us per stereo long-block packet and core; a GPU box grants its container 16 CPUs, so the
 // staging ring tops out at 2.7-2.8 M packets/s while the synthesis kernels take 16.5 us per 4096 packets.
-// Huffman decoding is serial inside a packet but packets are independent: 4096 lanes decode 4096 packets side by side,
-// and only the packets themselves (~0.5 KB instead of 8.3 KB of records) cross PCIe.
+// Huffman decoding is serial inside a packet but packets are independent: thousands of waves decode thousands of packets
+// side by side, and only the packets themselves (~0.5 KB instead of 8.3 KB of records) cross PCIe.
 //
 // Everything here is plain data and pointers: the setup header is flattened once into one image (lw_dev_entropy.cpp,
-// LwEntImage) that lives in HBM.  The function writes exactly what the host stage writes into a batch's staging -- floor
-// records [ch][fstride] u16 and residue vectors [ch][n/2] f32 before inverse coupling -- so the synthesis kernels run
-// unchanged behind it.  Eligible setups only (lw::dev_entropy_build says why not): floor type 1, one submap per mapping,
-// residue books of 1/2/4/8 dimensions dividing the partition size, every Huffman code inside the two table levels.
+// lw::DevEntropyImage) that lives in HBM.  The function produces exactly what the host stage writes into a batch's staging
+// -- floor records [ch][fstride] u16 and residue vectors [ch][n/2] f32 before inverse coupling -- so the synthesis kernels
+// run unchanged behind it.  Eligible setups only (lw::dev_entropy_build says why not): floor type 1, one submap per mapping,
+// residue books whose dimension divides the partition size, every Huffman code inside the two table levels.
 // For those the packet status is decided by the prologue alone (the host reads it: mode number, window flags), so the
 // host's planning pass needs nothing back from the device.
 #pragma once
@@ -27,12 +27,28 @@
 #define LW_HD inline
 #endif
 
+// On the device the packet's working set lives in the wave's LDS: residue accumulator, posts, classification digits
+// (address space 3: ds_ instructions, no flat addressing), and the additions of one codeword's vector are spread over the
+// lanes (element d on lane d).  On the host the same names are plain pointers and a loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) float *LwEntAcc;
+typedef __attribute__((address_space(3))) uint32_t *LwEntPosts;
+typedef __attribute__((address_space(3))) uint8_t *LwEntDigits;
+#define LW_ENT_EACH(d, cnt)                                                                                          \
+	for (uint32_t d = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), once_ = 1; once_ && d < (cnt); once_ = 0)
+#else
+typedef float *LwEntAcc;
+typedef uint32_t *LwEntPosts;
+typedef uint8_t *LwEntDigits;
+#define LW_ENT_EACH(d, cnt) for (uint32_t d = 0; d < (cnt); d++)
+#endif
+
 #define LW_ENT_MAX_CH 8
 #define LW_ENT_MAX_CLASSES 64
 #define LW_ENT_MAX_COUPLING 16
 #define LW_ENT_LINK 0x80000000u
 
-struct LwEntBook { // 16 bytes
+struct alignas(16) LwEntBook { // 16 bytes, read with one load
 	uint32_t lut_off;  // first-level table (2^lut_bits entries) in the image's u32 pool; sub-tables follow at offsets relative to it
 	uint32_t vq_off;   // entries * dims floats in the image's f32 pool
 	uint8_t lut_bits, dims;
@@ -77,12 +93,13 @@ struct LwEntTables {
 	const float *vq;
 	const uint8_t *bytes;
 	uint32_t ch, fstride;
-	uint32_t ws_bytes; // per-packet scratch: posts (4 * LW_MAX_POSTS rounded up) + classification digits
+	uint32_t ws_bytes;  // per-packet scratch: posts (4 * LW_MAX_POSTS rounded up) + classification digits
+	uint32_t res_floats; // largest residue block of a packet: ch * blocksize_1 / 2
 };
 
 // One packet of a device-entropy batch
 struct LwEntPacket { // 16 bytes
-	uint32_t word_off; // packet bytes in the batch's packet pool (u32 words; padded with >= 8 zero bytes)
+	uint32_t word_off; // packet bytes in the batch's packet pool (u32 words; followed by >= 3 zero words)
 	uint32_t len;      // bytes
 	uint8_t start_bit; // first bit after the prologue (audio.rs:921-938, read by the host)
 	uint8_t pad[3];
@@ -91,16 +108,65 @@ struct LwEntPacket { // 16 bytes
 
 #define LW_ENT_POSTS_BYTES ((4u * LW_MAX_POSTS + 15u) & ~15u)
 
+// A codebook as the decode loops hold it: everything in registers, fetched with ONE load of the 16-byte table entry.  (Read
+// field by field through a pointer, every codeword paid 3-4 dependent table accesses before its own look-up: the compiler
+// may not keep byte-typed fields in registers across the residue stores.)
+struct LwEntBookRegs {
+	const uint32_t *lut;
+	const float *vq;
+	uint32_t lut_mask, lut_bits, dims;
+	int32_t single;
+};
+
+LW_HD LwEntBookRegs lw_ent_book(const LwEntTables &T, uint32_t bi)
+{
+	const LwEntBook b = T.books[bi];
+	LwEntBookRegs r;
+	r.lut = T.lut + b.lut_off;
+	r.vq = T.vq + b.vq_off;
+	r.lut_bits = b.lut_bits;
+	r.lut_mask = (1u << b.lut_bits) - 1u;
+	r.dims = b.dims;
+	r.single = b.single;
+	return r;
+}
+
+// LSb-first reader with the bit window in registers: `win` holds the next `have` bits (>= 32 after peek()), `nxt` the word
+// after them, requested one refill ahead -- the packet bytes are read sequentially whatever the code lengths, so their
+// loads are never on a codeword's dependency chain.  The pool keeps >= 3 zero words behind every packet.
 struct LwEntReader {
 	const uint32_t *w;
 	uint32_t nbits, pos;
+	uint64_t win;
+	uint32_t have, wi, nxt;
 
-	// the next 32 bits (at least), zero past the end of the packet (the pool is zero padded)
-	LW_HD uint32_t peek() const
+	LW_HD void init(const uint32_t *words, uint32_t len_bytes, uint32_t start_bit)
 	{
+		w = words;
+		nbits = len_bytes * 8u;
+		pos = start_bit;
 		const uint32_t i = pos >> 5, s = pos & 31u;
-		const uint64_t x = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
-		return (uint32_t)(x >> s);
+		win = (uint64_t)(w[i] >> s);
+		have = 32u - s;
+		nxt = w[i + 1];
+		wi = i + 2;
+	}
+	// the next 32 bits, zero past the end of the packet
+	LW_HD uint32_t peek()
+	{
+		if (have < 32u) {
+			win |= (uint64_t)nxt << have;
+			have += 32u;
+			nxt = w[wi];
+			wi++;
+		}
+		return (uint32_t)win;
+	}
+	LW_HD void skip(uint32_t n) // n <= 32, after peek()
+	{
+		win >>= n;
+		have -= n;
+		pos += n;
 	}
 	// bitpacking.rs:291-297: a fixed-width read that does not fit fails without consuming anything; n <= 32
 	LW_HD bool read(uint32_t n, uint32_t &v)
@@ -113,65 +179,63 @@ struct LwEntReader {
 			return false;
 		const uint32_t x = peek();
 		v = n >= 32 ? x : (x & ((1u << n) - 1u));
-		pos += n;
+		skip(n);
 		return true;
 	}
 	// huffman_tree.rs:362-381 through the two table levels: a code that runs past the end consumes the rest and fails
-	LW_HD bool code(const LwEntTables &T, const LwEntBook &b, uint32_t &sym)
+	// (after that every read fails on its bounds check; the window is not looked at again)
+	LW_HD bool code(const LwEntBookRegs &b, uint32_t &sym)
 	{
 		if (b.single >= 0) {
 			if (pos + 1 > nbits)
 				return false;
-			pos += 1;
+			(void)peek();
+			skip(1);
 			sym = (uint32_t)b.single;
 			return true;
 		}
 		const uint32_t x = peek();
-		const uint32_t *lut = T.lut + b.lut_off;
-		uint32_t e = lut[x & ((1u << b.lut_bits) - 1u)];
+		uint32_t e = b.lut[x & b.lut_mask];
 		if (e & LW_ENT_LINK)
-			e = lut[(e & 0xffffffu) + ((x >> b.lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
+			e = b.lut[(e & 0xffffffu) + ((x >> b.lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
 		const uint32_t len = e >> 24;
 		if (len > nbits - pos) {
 			pos = nbits;
 			return false;
 		}
-		pos += len;
+		skip(len);
 		sym = e & 0xffffffu;
 		return true;
 	}
 };
 
 // audio.rs:215-251; y = the packet's scratch.  false = unused floor (FloorSpecialCase::Unused)
-LW_HD bool lw_ent_floor_decode(const LwEntTables &T, const LwEntFloor &fl, LwEntReader &r, uint32_t *y)
+LW_HD bool lw_ent_floor_decode(const LwEntTables &T, const LwEntFloor &fl, LwEntReader &r, LwEntPosts y)
 {
 	uint32_t nonzero;
 	if (!r.read(1, nonzero) || !nonzero)
 		return false;
-	uint32_t k = 0;
-	if (!r.read(fl.range_bits, y[k]))
+	uint32_t k = 0, v;
+	if (!r.read(fl.range_bits, v))
 		return false;
-	k++;
-	if (!r.read(fl.range_bits, y[k]))
+	y[k++] = v;
+	if (!r.read(fl.range_bits, v))
 		return false;
-	k++;
+	y[k++] = v;
 	for (uint32_t p = 0; p < fl.n_part; p++) {
 		const uint32_t c = fl.partition_class[p];
 		const uint32_t cdim = fl.class_dim[c], cbits = fl.class_sub[c];
 		const uint32_t csub = (1u << cbits) - 1u;
 		uint32_t cval = 0;
-		if (cbits && !r.code(T, T.books[fl.class_master[c]], cval))
+		if (cbits && !r.code(lw_ent_book(T, fl.class_master[c]), cval))
 			return false;
 		for (uint32_t d = 0; d < cdim; d++) {
 			const int book = fl.sub_books[c][cval & csub];
 			cval >>= cbits;
-			if (book >= 0) {
-				if (!r.code(T, T.books[book], y[k]))
-					return false;
-			} else {
-				y[k] = 0;
-			}
-			k++;
+			v = 0;
+			if (book >= 0 && !r.code(lw_ent_book(T, (uint32_t)book), v))
+				return false;
+			y[k++] = v;
 		}
 	}
 	return true;
@@ -192,7 +256,7 @@ LW_HD uint32_t lw_ent_render_point(uint32_t y0, uint32_t y1, uint32_t dx, uint64
 
 // audio.rs:391-435 -> device record: per post in ascending-x order, (final_y * multiplier) | active flag.  y is updated in
 // place (a post's neighbours precede it in header order).
-LW_HD void lw_ent_floor_record(const LwEntFloor &fl, uint32_t *y, uint16_t *rec)
+LW_HD void lw_ent_floor_record(const LwEntFloor &fl, LwEntPosts y, uint16_t *rec)
 {
 	const uint32_t F = fl.F, range = fl.range;
 	uint32_t act0 = 3u, act1 = 0u, act2 = 0u; // step2 flags of posts 0-31, 32-63, 64
@@ -239,85 +303,147 @@ LW_HD void lw_ent_floor_record(const LwEntFloor &fl, uint32_t *y, uint16_t *rec)
 // ONE interleaved vector of ch * n/2 elements is written straight to its channel-major place (audio.rs:748-754: element i
 // belongs to channel i % ch, bin i / ch) -- every element receives the same additions in the same order as in the
 // reference's interleaved buffer.  `out` holds zeros on entry.  `cls` = scratch for nch * (parts + cpc) digits.
+//
+// The reference's loop nest (pass / group of cpc partitions / [classification codewords of every vector] / partition /
+// vector / codewords of the partition) is walked by a CURSOR, one codeword per step: on the GPU the 64 lanes of a wave
+// decode 64 packets, and a nest of loops would make every lane sit through the union of all lanes' partitions and the
+// longest trip count of each (a partition takes psize / dims codewords and dims differs per lane) -- with the cursor a
+// wave takes as many steps as its longest packet has codewords.  Slots in stream order:
+//   pass 0: group g: class slot of vector 0..nch-1, then partition slots (k = 0..cpc-1) x (vector 0..nch-1)
+//   pass p: group g: partition slots only
 LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntReader &r, uint32_t nch, uint32_t actual,
-		const bool *dnd, float *out, uint32_t half, uint32_t deint_ch, uint8_t *cls)
+		const bool *dnd, LwEntAcc out, uint32_t half, uint32_t deint_ch, LwEntDigits cls)
 {
 	const uint32_t begin = rs.begin < actual ? rs.begin : actual, end = rs.end < actual ? rs.end : actual;
-	const uint32_t cpc = rs.cpc;
+	const uint32_t cpc = rs.cpc, psize = rs.psize;
 	const uint32_t n_to_read = end - begin;
-	const uint32_t parts = n_to_read / rs.psize;
-	if (n_to_read == 0)
+	const uint32_t parts = n_to_read / psize;
+	if (n_to_read == 0 || parts == 0)
 		return;
 	const uint32_t stride = parts + cpc;
-	const LwEntBook &classbook = T.books[rs.classbook];
 	const uint32_t ncls = rs.classifications;
-	for (uint32_t pass = 0; pass < 8; pass++) {
-		uint32_t pc = 0;
-		while (pc < parts) {
-			if (pass == 0) {
-				for (uint32_t j = 0; j < nch; j++) {
-					if (dnd[j])
-						continue;
-					uint32_t t;
-					if (!r.code(T, classbook, t))
-						return; // end of packet is normal (audio.rs:655-660)
-					uint8_t *c = cls + j * stride + pc;
-					if (rs.digits_off != 0xFFFFFFFFu) {
-						const uint8_t *dg = T.bytes + rs.digits_off + t * cpc;
-						for (uint32_t i = 0; i < cpc; i++)
-							c[i] = dg[i];
-					} else {
-						for (uint32_t i = cpc; i-- > 0;) {
-							c[i] = (uint8_t)(t % ncls);
-							t /= ncls;
+	uint32_t used_any = 0; // passes some class of this residue uses at all
+	for (uint32_t c = 0; c < ncls; c++)
+		used_any |= rs.vals_used[c];
+	uint32_t dnd_mask = 0;
+	for (uint32_t j = 0; j < nch; j++)
+		dnd_mask |= dnd[j] ? 1u << j : 0u;
+	if (dnd_mask == (1u << nch) - 1u)
+		return; // nothing is read for vectors marked do-not-decode
+	// cursor
+	uint32_t pass = 0, pc0 = 0, k = 0, j = 0;
+	bool klass = true; // at a classification slot (pass 0 only)
+	// the partition being decoded: position, step count and book
+	uint32_t i = 0, lim = 0, dims = 1, step = 0, offs = 0, vec = 0;
+	bool first = false, in_part = false;
+	const uint32_t rtype = rs.type, digits_off = rs.digits_off;
+	const LwEntBookRegs classbook = lw_ent_book(T, rs.classbook);
+	LwEntBookRegs cb = classbook;
+	for (;;) {
+		if (!in_part) {
+			// find the next slot that reads something
+			for (;;) {
+				if ((used_any >> pass) == 0)
+					return; // no later pass decodes anything
+				if (!((dnd_mask >> j) & 1u)) {
+					if (klass)
+						break;
+					const uint32_t cl = cls[j * stride + pc0 + k];
+					const uint32_t vu = rs.vals_used[cl];
+					if (vu & (1u << pass)) {
+						cb = lw_ent_book(T, rs.val_i[cl][pass]);
+						dims = cb.dims;
+						offs = begin + (pc0 + k) * psize;
+						vec = j;
+						first = (vu & ((1u << pass) - 1u)) == 0;
+						step = psize / dims;
+						lim = rtype == 0 ? step : psize;
+						i = 0;
+						in_part = lim != 0;
+						if (in_part)
+							break;
+					}
+				}
+				// advance the cursor by one slot
+				if (++j == nch) {
+					j = 0;
+					if (klass) {
+						klass = false;
+						k = 0;
+					} else if (++k == cpc || pc0 + k >= parts) {
+						k = 0;
+						pc0 += cpc;
+						if (pc0 >= parts) {
+							pc0 = 0;
+							if (++pass == 8)
+								return;
 						}
+						klass = pass == 0;
 					}
 				}
 			}
-			for (uint32_t k = 0; k < cpc && pc < parts; k++, pc++) {
-				for (uint32_t j = 0; j < nch; j++) {
-					if (dnd[j])
-						continue;
-					const uint32_t cl = cls[j * stride + pc];
-					if (!(rs.vals_used[cl] & (1u << pass)))
-						continue;
-					const LwEntBook &cb = T.books[rs.val_i[cl][pass]];
-					const uint32_t dims = cb.dims;
-					const uint32_t offs = begin + pc * rs.psize;
-					const float *vq = T.vq + cb.vq_off;
-					// audio.rs:587-618 (the whole partition lies inside the vector; dims divides the partition size)
-					if (rs.type == 0) {
-						const uint32_t step = rs.psize / dims;
-						for (uint32_t i = 0; i < step; i++) {
-							uint32_t idx;
-							if (!r.code(T, cb, idx))
-								return;
-							const float *e = vq + idx * dims;
-							for (uint32_t d = 0; d < dims; d++)
-								out[j * half + offs + i + d * step] += e[d];
-						}
-					} else if (deint_ch == 0) {
-						float *v = out + j * half + offs;
-						for (uint32_t i = 0; i < rs.psize; i += dims) {
-							uint32_t idx;
-							if (!r.code(T, cb, idx))
-								return;
-							const float *e = vq + idx * dims;
-							for (uint32_t d = 0; d < dims; d++)
-								v[i + d] += e[d];
-						}
-					} else {
-						for (uint32_t i = 0; i < rs.psize; i += dims) {
-							uint32_t idx;
-							if (!r.code(T, cb, idx))
-								return;
-							const float *e = vq + idx * dims;
-							for (uint32_t d = 0; d < dims; d++) {
-								const uint32_t el = offs + i + d;
-								out[(el % deint_ch) * half + el / deint_ch] += e[d];
-							}
-						}
+		}
+		if (!in_part) { // classification codeword of vector j for the group at pc0 (audio.rs:655-668)
+			uint32_t t;
+			if (!r.code(classbook, t))
+				return; // end of packet is normal (audio.rs:655-660)
+			LwEntDigits c = cls + j * stride + pc0;
+			if (digits_off != 0xFFFFFFFFu) {
+				const uint8_t *dg = T.bytes + digits_off + t * cpc;
+				LW_ENT_EACH(q, cpc)
+					c[q] = dg[q];
+			} else {
+				for (uint32_t q = cpc; q-- > 0;) {
+					c[q] = (uint8_t)(t % ncls);
+					t /= ncls;
+				}
+			}
+			if (++j == nch) {
+				j = 0;
+				klass = false;
+				k = 0;
+			}
+			continue;
+		}
+		// one codeword of the current partition (audio.rs:587-618; the whole partition lies inside the vector and dims divides
+		// the partition size).  The first pass that touches a partition finds zeros there (a pass adds to an element at most
+		// once): it stores 0.0f + e without reading the element back from HBM.
+		uint32_t idx;
+		if (!r.code(cb, idx))
+			return;
+		const float *e = cb.vq + idx * dims;
+		if (rtype == 0) {
+			LwEntAcc v = out + vec * half + offs + i;
+			LW_ENT_EACH(d, dims)
+				v[d * step] = (first ? 0.0f : v[d * step]) + e[d];
+			i += 1;
+		} else if (deint_ch == 0) {
+			LwEntAcc v = out + vec * half + offs + i;
+			LW_ENT_EACH(d, dims)
+				v[d] = (first ? 0.0f : v[d]) + e[d];
+			i += dims;
+		} else {
+			LW_ENT_EACH(d, dims) {
+				const uint32_t el = offs + i + d;
+				LwEntAcc v = out + (el % deint_ch) * half + el / deint_ch;
+				*v = (first ? 0.0f : *v) + e[d];
+			}
+			i += dims;
+		}
+		if (i >= lim) {
+			in_part = false;
+			// this partition slot is done: advance the cursor past it
+			if (++j == nch) {
+				j = 0;
+				if (++k == cpc || pc0 + k >= parts) {
+					k = 0;
+					pc0 += cpc;
+					if (pc0 >= parts) {
+						pc0 = 0;
+						if (++pass == 8)
+							return;
 					}
+					klass = pass == 0;
 				}
 			}
 		}
@@ -327,16 +453,12 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 // Floors and residues of one packet (what lw::entropy_decode does after the prologue).  floor_out [ch][fstride],
 // res_out [ch][n/2] zero on entry, ws = T.ws_bytes of scratch (4-byte aligned).
 LW_HD void lw_ent_decode_packet(const LwEntTables &T, const uint32_t *words, uint32_t len_bytes, uint32_t start_bit,
-		uint32_t mode, uint32_t n, uint16_t *floor_out, float *res_out, uint8_t *ws)
+		uint32_t mode, uint32_t n, uint16_t *floor_out, LwEntAcc res_out, LwEntPosts y, LwEntDigits cls)
 {
 	LwEntReader r;
-	r.w = words;
-	r.nbits = len_bytes * 8u;
-	r.pos = start_bit;
+	r.init(words, len_bytes, start_bit);
 	const LwEntMode &m = T.modes[mode];
 	const uint32_t ch = T.ch, half = n >> 1;
-	uint32_t *y = (uint32_t *)ws;
-	uint8_t *cls = ws + LW_ENT_POSTS_BYTES;
 	bool no_residue[LW_ENT_MAX_CH];
 	// floor_decode, audio.rs:557-585
 	for (uint32_t c = 0; c < ch; c++) {

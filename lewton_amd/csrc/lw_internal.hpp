@@ -103,7 +103,6 @@ struct lw_batch {
 	LwEntPacket *h_pk = nullptr, *d_pk = nullptr; // [max_packets]
 	uint32_t *h_pool = nullptr, *d_pool = nullptr;
 	size_t pool_cap_words = 0, pool_words = 0;
-	uint8_t *d_ws = nullptr; // [max_packets][E.ws_bytes] per-packet scratch of k_entropy
 	bool ent_done = false;   // k_entropy has run for the records uploaded last (lw_batch_device_entropy ahead of lw_batch_synth)
 	LwPacketRec *d_recs = nullptr;
 	uint16_t *d_floor = nullptr;

@@ -114,7 +114,7 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 struct LwEntTables;
 struct LwEntPacket;
 void lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPacketRec *d_recs, const uint32_t *d_pool,
-		uint16_t *d_floor, float *d_res, uint8_t *d_ws, uint32_t n, hipStream_t st);
+		uint16_t *d_floor, float *d_res, uint32_t n, hipStream_t st);
 void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBatchDev &B, hipStream_t st, uint32_t max_n,
 		const uint32_t *book_ends, size_t n_book_ends);
 void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast);

@@ -1,37 +1,62 @@
-// Entropy stage on the device (product code, gfx950): one LANE per packet, 64 packets per wave.  Every lane runs
-// lw_ent_decode_packet (lw_dev_entropy.h -- the same source the CPU suite holds against the host entropy stage bit for bit)
-// on its packet: floor-1 decode + amplitude unwrap into the floor record, residue Huffman / VQ decode accumulated straight
-// into the packet's residue vectors [ch][n/2] in HBM (zeroed by a memset in front of this kernel), i.e. exactly the records
-// the host stage would have staged -- the synthesis kernels behind it do not know the difference.
+// Entropy stage on the device (product code, gfx950): one WAVE per packet.  The wave runs lw_ent_decode_packet
+// (lw_dev_entropy.h -- the same source the CPU suite holds against the host entropy stage bit for bit) with wave-uniform
+// control: floor-1 decode + amplitude unwrap into the floor record, residue Huffman / VQ decode accumulated into the packet's
+// residue vectors, which live in the wave's LDS until the end and then leave in one coalesced write -- exactly the records
+// the host stage would have staged, so the synthesis kernels behind it do not know the difference.
 //
-// Bound: latency.  A packet is a serial chain of ~700 codewords, each a dependent table look-up (L2-resident tables: the
-// image of a typical setup is a few hundred KB) plus the read-modify-write of 1-8 residue elements that nothing later in
-// the chain waits for.  Lanes of a wave diverge only in trip counts (a partition takes psize / dims codewords), not in
-// the loop structure; packets of similar size finish together.  Algorithmic bytes per packet: the packet itself in
-// (~0.5 KB), floor records + residue vectors out (8.3 KB for a stereo long block).
+// Why a wave and not a lane per packet (first version of this kernel, 2.7 ms per 4096 packets whatever was tuned): on
+// gfx9 stores and loads share one counter, so with the accumulators in HBM every codeword's table look-up also waited for
+// the previous codeword's stores to be acknowledged; 64 packets per wave made every lane sit through every other lane's
+// branch; and per-lane tables meant flat addressing.  Here the accumulators are LDS (ds_ instructions, their own
+// counter), the control flow is uniform, one codeword's vector is added by dims lanes at once.
+//
+// Bound: latency -- a packet is a serial chain of ~700 codewords, each a dependent table look-up (L1 / L2-resident
+// tables: the image of a typical setup is a few hundred KB; ~70-130 ns per dependent access on this chip,
+// tools/micro/chase.hip).  Up to 16 packets per CU in flight (9 KB of LDS each).  Algorithmic bytes per packet: the packet
+// itself in (~0.5 KB), floor records + residue vectors out (8.3 KB for a stereo long block).
 #include "lw_dev_entropy.h"
 #include "lw_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 
 __global__ void __launch_bounds__(64) k_entropy(LwEntTables T, const LwEntPacket *pk, const LwPacketRec *recs, const uint32_t *pool,
-		uint16_t *floors, float *residue, uint8_t *ws, uint32_t n)
+		uint16_t *floors, float *residue, uint32_t n)
 {
-	const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-	if (i >= n)
-		return;
+	extern __shared__ __attribute__((aligned(16))) float smem[]; // [T.res_floats accumulators][posts][digits]
+	const uint32_t i = blockIdx.x; // wave-uniform: the decode state stays in SGPRs
 	const LwPacketRec rec = recs[i];
 	if (rec.flags & LW_RF_SKIP)
 		return;
 	const LwEntPacket p = pk[i];
-	lw_ent_decode_packet(T, pool + p.word_off, p.len, p.start_bit, rec.mode, 1u << rec.bs, floors + rec.floor_off,
-			residue + rec.res_off, ws + (size_t)i * T.ws_bytes);
+	const uint32_t blk = 1u << rec.bs, res_n = T.ch * (blk >> 1);
+	for (uint32_t k = threadIdx.x; k < res_n; k += 64)
+		smem[k] = 0.0f;
+	__syncthreads();
+	LwEntAcc acc = (LwEntAcc)smem;
+	LwEntPosts posts = (LwEntPosts)(smem + T.res_floats);
+	LwEntDigits digits = (LwEntDigits)(smem + T.res_floats) + LW_ENT_POSTS_BYTES;
+	lw_ent_decode_packet(T, pool + p.word_off, p.len, p.start_bit, rec.mode, blk, floors + rec.floor_off, acc, posts, digits);
+	__syncthreads();
+	// residue blocks start at multiples of ch * n0 / 2 floats: 16-byte aligned
+	float *out = (float *)__builtin_assume_aligned(residue + rec.res_off, 16);
+	for (uint32_t k = threadIdx.x * 4; k < res_n; k += 256) {
+		float4 v;
+		v.x = smem[k];
+		v.y = smem[k + 1];
+		v.z = smem[k + 2];
+		v.w = smem[k + 3];
+		*(float4 *)(out + k) = v;
+	}
 }
 
 void lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPacketRec *d_recs, const uint32_t *d_pool,
-		uint16_t *d_floor, float *d_res, uint8_t *d_ws, uint32_t n, hipStream_t st)
+		uint16_t *d_floor, float *d_res, uint32_t n, hipStream_t st)
 {
 	if (n == 0)
 		return;
-	hipLaunchKernelGGL(k_entropy, dim3((n + 63) / 64), dim3(64), 0, st, T, d_pk, d_recs, d_pool, d_floor, d_res, d_ws, n);
+	const size_t lds = (size_t)T.res_floats * 4 + T.ws_bytes;
+	static LwPerDeviceOnce once;
+	if (once.first_launch_on_device())
+		(void)hipFuncSetAttribute((const void *)k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	hipLaunchKernelGGL(k_entropy, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
 }

@@ -418,6 +418,7 @@ struct lw_ogg_stream {
 	int ring_fmt = -1;
 	bool pipe_active = false;
 	int pipe_fmt = -1, pipe_threads = 0;
+	bool want_dev_entropy = false; // lw_ogg_stream_set_entropy_on_device: applied whenever the look-ahead pipeline (re)starts
 	size_t pipe_k = 0;
 	struct PipeSlot {
 		std::vector<QueuedPacket> ahead;
@@ -794,6 +795,8 @@ struct lw_ogg_stream {
 			ring_cap = k;
 			ring_fmt = fmt;
 		}
+		// entropy stage on the device when asked for and the current logical stream is eligible (else the host stage)
+		(void)lw_ring_set_entropy_on_device(ring, want_dev_entropy ? 1 : 0);
 		pipe_fmt = fmt;
 		pipe_k = k;
 		pipe_threads = n_threads;
@@ -1050,6 +1053,17 @@ int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t c
 	if (int rc = s->decode(q, fmt, out, cap_elems, &m))
 		return rc;
 	*n_samples = s->account(q, fmt, out, m);
+	return LW_OK;
+}
+
+int lw_ogg_stream_set_entropy_on_device(lw_ogg_stream *s, int on)
+{
+	if (!s)
+		return LW_ERR_NULL_ARG;
+	if (s->want_dev_entropy != (on != 0)) {
+		s->rollback(); // the look-ahead restarts in the other mode from what the caller has been handed
+		s->want_dev_entropy = on != 0;
+	}
 	return LW_OK;
 }
 

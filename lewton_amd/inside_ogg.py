@@ -136,6 +136,10 @@ class OggStreamReader:
     def read_dec_packet_itl(self):
         return self.read_dec_packet_generic("i16_interleaved")
 
+    def set_entropy_on_device(self, on=True):
+        """look-ahead batches decode their floors and residues on the GPU (k_entropy) when the stream is eligible"""
+        N.lw_ogg_stream_set_entropy_on_device(self._h, 1 if on else 0)
+
     def read_dec_packets(self, max_packets, samples="i16", n_threads=0):
         """Look-ahead queue: up to max_packets packets with one batch.  Returns a list of (samples | AudioReadError);
         [] in front of a chain boundary (call read_dec_packet_generic to cross it), None at the end of the stream."""

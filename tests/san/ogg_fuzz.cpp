@@ -30,6 +30,7 @@ int lw_ring_launch(lw_ring *) { return LW_ERR_DEVICE; }
 int lw_ring_collect(lw_ring *, const lw_packet_result **, size_t *, const void **, size_t *) { return LW_ERR_DEVICE; }
 int lw_ring_release(lw_ring *) { return LW_ERR_DEVICE; }
 int lw_ring_drain(lw_ring *) { return LW_OK; }
+int lw_ring_set_entropy_on_device(lw_ring *, int) { return LW_ERR_DEVICE; }
 void lw_pwr_get_state(const lw_pwr *, lw_pwr_state *) {}
 void lw_pwr_set_state(lw_pwr *, const lw_pwr_state *) {}
 lw_batch *lw_batch_create(lw_decoder *, size_t, int, int *) { return nullptr; }

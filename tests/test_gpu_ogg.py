@@ -94,8 +94,9 @@ def test_chained_streams_reinitialise_the_context(fmt):
     assert serials == [0x100, 0x101, 0x102] and chans == [2, 6, 1]
 
 
+@pytest.mark.parametrize("dev_entropy", [False, True])
 @pytest.mark.parametrize("max_packets", [1, 4, 64])
-def test_look_ahead_queue_equals_packet_by_packet(max_packets):
+def test_look_ahead_queue_equals_packet_by_packet(max_packets, dev_entropy):
     for data in (open(GOLDEN, "rb").read(), _chained(), _vorbis_stream("stereo", "LLSL", 40, per_page=7, trim=300)[2].bytes()):
         one = IO.OggStreamReader(data)
         ref = []
@@ -105,6 +106,8 @@ def test_look_ahead_queue_equals_packet_by_packet(max_packets):
                 break
             ref.append(p)
         s = IO.OggStreamReader(data)
+        if dev_entropy:                    # floors and residues of the look-ahead batches decoded by k_entropy
+            s.set_entropy_on_device(True)
         got = []
         while True:
             r = s.read_dec_packets(max_packets)
@@ -215,14 +218,17 @@ def test_ogg2wav_example_matches_oracle(tmp_path, lookahead):
         assert len(raw) == 44 + n_bytes and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("dev_entropy", [False, True])
 @pytest.mark.parametrize("k,singles,skip,goal", [(4, 2, 900, None), (9, 0, 1, 5000), (3, 4, 3000, 0), (64, 1, 128, 20000)])
-def test_single_skip_seek_between_batched_calls_sample_values(k, singles, skip, goal):
+def test_single_skip_seek_between_batched_calls_sample_values(k, singles, skip, goal, dev_entropy):
     """The look-ahead pipeline (three batches staged / in flight behind read_dec_packets) rolled back by read_dec_packet,
     skip_samples_linear and seek_absgp_pg (inside_ogg.rs:167-313): every sample delivered afterwards equals the oracle's
     OggStreamReader driven with the same calls packet by packet -- i.e. the PreviousWindowRight really is back at the state
     after the last DELIVERED packet, on the device too."""
     data = _vorbis_stream("stereo", "LLSLLLSSL", 80, per_page=4, trim=123)[2].bytes()
     s = IO.OggStreamReader(data)
+    if dev_entropy:
+        s.set_entropy_on_device(True)
     o = pyogg.OggStreamReader(data)
 
     def same(a, b):

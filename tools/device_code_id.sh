@@ -6,7 +6,7 @@
 D=${1:-lewton_amd/_lib}
 B=/opt/rocm/lib/llvm/bin
 T=$(mktemp -d)
-for f in lw_kernels lw_kernels_long; do
+for f in lw_kernels lw_kernels_long lw_kernels_entropy; do
   objcopy -O binary --only-section=.hip_fatbin $D/$f.hip.o $T/$f.bin &&
   $B/clang-offload-bundler --unbundle --type=o --input=$T/$f.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/$f.co &&
   echo "$($B/llvm-objdump -d $T/$f.co | tail -n +3 | sha256sum | cut -d' ' -f1)  $f.hip (gfx950 disassembly)"
