@@ -273,6 +273,7 @@ lw_sharder *lw_sharder_create(const lw_ident *id, const lw_setup *setup, const i
 		size_t max_packets_per_shard, int fmt, int *err);
 void lw_sharder_destroy(lw_sharder *sh); /* close the streams first */
 size_t lw_sharder_shards(const lw_sharder *sh);
+int lw_sharder_set_entropy_on_device(lw_sharder *sh, int on); /* every shard's entropy stage on its own GPU (k_entropy) */
 size_t lw_sharder_shard_of(const lw_sharder *sh, uint64_t stream_id);
 int lw_sharder_device_of(const lw_sharder *sh, size_t shard);
 lw_shard_stream *lw_sharder_stream_open(lw_sharder *sh, uint64_t stream_id);

@@ -138,6 +138,7 @@ SYMBOLS = {
     "lw_ring_last_kernels": (C.c_char_p, [C.c_void_p]),
     "lw_sharder_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_size_t, C.c_size_t, C.c_int, intp]),
     "lw_sharder_destroy": (None, [C.c_void_p]),
+    "lw_sharder_set_entropy_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_sharder_shards": (C.c_size_t, [C.c_void_p]),
     "lw_sharder_shard_of": (C.c_size_t, [C.c_void_p, C.c_uint64]),
     "lw_sharder_device_of": (C.c_int, [C.c_void_p, C.c_size_t]),

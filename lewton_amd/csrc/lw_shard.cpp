@@ -176,6 +176,17 @@ void lw_sharder_destroy(lw_sharder *sh)
 	delete sh;
 }
 
+int lw_sharder_set_entropy_on_device(lw_sharder *sh, int on)
+{
+	if (!sh)
+		return LW_ERR_NULL_ARG;
+	std::lock_guard<std::mutex> call(sh->call_mu);
+	for (auto &s : sh->shards)
+		if (int rc = lw_batch_set_entropy_on_device(s->batch, on))
+			return rc; // LW_ERR_UNSUPPORTED: the stream is not eligible (every shard has the same headers: none was switched)
+	return LW_OK;
+}
+
 size_t lw_sharder_shards(const lw_sharder *sh)
 {
 	return sh ? sh->shards.size() : 0;

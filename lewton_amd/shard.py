@@ -57,6 +57,15 @@ class Sharder:
     def shard_of(self, stream_id):
         return self._N.lw_sharder_shard_of(self._h, stream_id)
 
+    def set_entropy_on_device(self, on=True):
+        """every shard decodes floors and residues on its own GPU (k_entropy); False when the stream is not eligible"""
+        rc = self._N.lw_sharder_set_entropy_on_device(self._h, 1 if on else 0)
+        if rc == self._N.ERR_UNSUPPORTED:
+            return False
+        if rc:
+            raise RuntimeError("lw_sharder_set_entropy_on_device: %d" % rc)
+        return True
+
     def stream(self, stream_id):
         if stream_id not in self._streams:
             h = self._N.lw_sharder_stream_open(self._h, stream_id)

@@ -129,3 +129,31 @@ def test_ineligible_streams_stay_on_the_host_stage():
         why = C.c_char_p()
         assert N.lw_decoder_supports_device_entropy(dec._h, C.byref(why)) == 0 and word in why.value
         ring.close()
+
+
+def test_sharder_with_device_entropy_matches_oracle():
+    """lw_sharder_set_entropy_on_device: three logical shards, every shard's k_entropy and synthesis kernels on its own
+    stream; mixed short / long streams with damaged packets, two calls with the state carried between them"""
+    from lewton_amd import shard
+    setup = SETUPS["stereo"]()
+    audio, ident, st = _product(setup)
+    o_id, o_st = oracle_headers(setup)
+    n_streams, per = 50, 6
+    sh = shard.Sharder(ident, st, [0, 0, 0], max_packets_per_shard=n_streams * per, samples="i16")
+    assert sh.set_entropy_on_device(True)
+    rng = np.random.default_rng(5)
+    streams = [_damage(sg.make_stream(setup, "LLSSL", 2 * per, seed=300 + s, p_floor_unused=0.1), rng) for s in range(n_streams)]
+    opws = [po.Pwr() for _ in range(n_streams)]
+    for half in range(2):
+        items = [(s, streams[s][half * per + t]) for t in range(per) for s in range(n_streams)]
+        blocks, res = sh.decode(items, n_threads=2)
+        for (s, pkt), b, r in zip(items, blocks, res):
+            try:
+                want = po.read_audio_packet(o_id, o_st, pkt, opws[s], "i16")
+                rc = 0
+            except po.OracleError as e:
+                rc = e.code
+            assert r[0] == rc, (half, s)
+            if rc == 0:
+                assert b.shape == want.shape and np.array_equal(b, want), (half, s)
+    sh.close()
