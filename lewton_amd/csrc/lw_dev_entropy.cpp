@@ -8,34 +8,6 @@ namespace lw {
 
 namespace {
 
-// every bit pattern resolves inside the two table levels (no tree walk on the device)
-bool tables_complete(const Huffman &h)
-{
-	if (h.single >= 0)
-		return true;
-	if (!h.has_lut || h.lut.empty())
-		return false;
-	const size_t first = (size_t)1 << h.lut_bits;
-	if (h.lut.size() < first)
-		return false;
-	for (size_t i = 0; i < first; i++) {
-		const uint32_t e = h.lut[i];
-		if (e & Huffman::LINK) {
-			const size_t base = e & 0xffffffu, cnt = (size_t)1 << ((e >> 24) & 0x7fu);
-			if (base + cnt > h.lut.size())
-				return false;
-			for (size_t k = 0; k < cnt; k++) {
-				const uint32_t f = h.lut[base + k];
-				if ((f & Huffman::LINK) || (f >> 24) == 0)
-					return false;
-			}
-		} else if ((e >> 24) == 0) {
-			return false;
-		}
-	}
-	return true;
-}
-
 template <class T> size_t put(std::vector<uint8_t> &blob, const T *p, size_t n)
 {
 	const size_t at = (blob.size() + 15) & ~(size_t)15;
@@ -227,6 +199,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	std::vector<LwEntBook> books(s.codebooks.size());
 	std::vector<uint32_t> lut;
 	std::vector<float> vq;
+	std::vector<int32_t> nodes;
 	for (size_t bi = 0; bi < s.codebooks.size(); bi++) {
 		LwEntBook &b = books[bi];
 		std::memset(&b, 0, sizeof(b));
@@ -234,11 +207,10 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		if (!book_used[bi])
 			continue;
 		const Codebook &cb = s.codebooks[bi];
-		if (!tables_complete(cb.huff)) {
-			*why = "a Huffman code longer than the two table levels (or an empty book)";
-			return false;
-		}
-		if (cb.huff.single >= 0) {
+		b.nodes_off = 0xFFFFFFFFu;
+		if (cb.huff.single < 0 && !cb.huff.has_lut) {
+			b.single = -2; // empty book (the host stage ends the packet at its first codeword)
+		} else if (cb.huff.single >= 0) {
 			if (cb.huff.single > 32767) {
 				*why = "single-entry book with a large entry number";
 				return false;
@@ -248,6 +220,13 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 			b.lut_off = (uint32_t)lut.size();
 			b.lut_bits = (uint8_t)cb.huff.lut_bits;
 			lut.insert(lut.end(), cb.huff.lut.begin(), cb.huff.lut.end());
+			bool walks = false; // some code is longer than the two table levels: ship the tree as well
+			for (uint32_t e : cb.huff.lut)
+				walks |= !(e & Huffman::LINK) && (e >> 24) == 0;
+			if (walks && !cb.huff.nodes.empty()) {
+				b.nodes_off = (uint32_t)nodes.size();
+				nodes.insert(nodes.end(), cb.huff.nodes.begin(), cb.huff.nodes.end());
+			}
 		}
 		b.dims = (uint8_t)std::min<unsigned>(cb.dims, 255);
 		if (cb.has_vq && !cb.vq.empty()) {
@@ -260,6 +239,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	lut.push_back(0);
 	vq.push_back(0.0f);
 	bytes.push_back(0);
+	nodes.push_back(0);
 	img.blob.clear();
 	img.off_books = put(img.blob, books.data(), books.size());
 	img.off_floors = put(img.blob, floors.data(), floors.size());
@@ -268,6 +248,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	img.off_lut = put(img.blob, lut.data(), lut.size());
 	img.off_vq = put(img.blob, vq.data(), vq.size());
 	img.off_bytes = put(img.blob, bytes.data(), bytes.size());
+	img.off_nodes = put(img.blob, nodes.data(), nodes.size());
 	img.ch = (uint32_t)ch;
 	img.fstride = fstride;
 	img.ws_bytes = (uint32_t)((LW_ENT_POSTS_BYTES + cls_bytes + 15) & ~(size_t)15);
@@ -285,6 +266,7 @@ LwEntTables dev_entropy_view(const DevEntropyImage &img, const uint8_t *base)
 	T.lut = (const uint32_t *)(base + img.off_lut);
 	T.vq = (const float *)(base + img.off_vq);
 	T.bytes = base + img.off_bytes;
+	T.nodes = (const int32_t *)(base + img.off_nodes);
 	T.ch = img.ch;
 	T.fstride = img.fstride;
 	T.ws_bytes = img.ws_bytes;

@@ -12,7 +12,7 @@
 // lw::DevEntropyImage) that lives in HBM.  The function produces exactly what the host stage writes into a batch's staging
 // -- floor records [ch][fstride] u16 and residue vectors [ch][n/2] f32 before inverse coupling -- so the synthesis kernels
 // run unchanged behind it.  Eligible setups only (lw::dev_entropy_build says why not): floor type 1, one submap per mapping,
-// residue books whose dimension divides the partition size, every Huffman code inside the two table levels.
+// residue books whose dimension divides the partition size.
 // For those the packet status is decided by the prologue alone (the host reads it: mode number, window flags), so the
 // host's planning pass needs nothing back from the device.
 #pragma once
@@ -52,8 +52,8 @@ struct alignas(16) LwEntBook { // 16 bytes, read with one load
 	uint32_t lut_off;  // first-level table (2^lut_bits entries) in the image's u32 pool; sub-tables follow at offsets relative to it
 	uint32_t vq_off;   // entries * dims floats in the image's f32 pool
 	uint8_t lut_bits, dims;
-	int16_t single;    // >= 0: single-entry book, any one bit decodes this entry (huffman_tree.rs:202-217)
-	uint32_t pad;
+	int16_t single;    // >= 0: single-entry book, any one bit decodes this entry (huffman_tree.rs:202-217); -2: empty book
+	uint32_t nodes_off; // binary tree (2 ints per node) in the image's i32 pool for codes beyond the two table levels; ~0u: none
 };
 
 struct LwEntFloor {
@@ -92,6 +92,7 @@ struct LwEntTables {
 	const uint32_t *lut;
 	const float *vq;
 	const uint8_t *bytes;
+	const int32_t *nodes;
 	uint32_t ch, fstride;
 	uint32_t ws_bytes;  // per-packet scratch: posts (4 * LW_MAX_POSTS rounded up) + classification digits
 	uint32_t res_floats; // largest residue block of a packet: ch * blocksize_1 / 2
@@ -114,6 +115,7 @@ struct LwEntPacket { // 16 bytes
 struct LwEntBookRegs {
 	const uint32_t *lut;
 	const float *vq;
+	const int32_t *nodes; // tree for the (rare) codes longer than the two table levels, or null
 	uint32_t lut_mask, lut_bits, dims;
 	int32_t single;
 };
@@ -128,6 +130,7 @@ LW_HD LwEntBookRegs lw_ent_book(const LwEntTables &T, uint32_t bi)
 	r.lut_mask = (1u << b.lut_bits) - 1u;
 	r.dims = b.dims;
 	r.single = b.single;
+	r.nodes = b.nodes_off != 0xFFFFFFFFu ? T.nodes + b.nodes_off : nullptr;
 	return r;
 }
 
@@ -194,11 +197,17 @@ struct LwEntReader {
 			sym = (uint32_t)b.single;
 			return true;
 		}
+		if (b.single == -2) { // empty book: the reference panics; like the host stage, the packet ends here
+			pos = nbits;
+			return false;
+		}
 		const uint32_t x = peek();
 		uint32_t e = b.lut[x & b.lut_mask];
 		if (e & LW_ENT_LINK)
 			e = b.lut[(e & 0xffffffu) + ((x >> b.lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
 		const uint32_t len = e >> 24;
+		if (len == 0)
+			return walk(b, sym);
 		if (len > nbits - pos) {
 			pos = nbits;
 			return false;
@@ -206,6 +215,42 @@ struct LwEntReader {
 		skip(len);
 		sym = e & 0xffffffu;
 		return true;
+	}
+	// a code beyond the table levels (19+ bits: one in 2^18 codewords of a real encoder's books): bit by bit through the tree,
+	// straight from the packet words
+	LW_HD bool walk(const LwEntBookRegs &b, uint32_t &sym)
+	{
+		if (!b.nodes) {
+			pos = nbits;
+			return false;
+		}
+		int32_t node = 0;
+		uint32_t p = pos;
+		for (;;) {
+			if (p >= nbits) {
+				pos = nbits;
+				return false;
+			}
+			const uint32_t bit = (w[p >> 5] >> (p & 31u)) & 1u;
+			p++;
+			const int32_t c = b.nodes[2 * node + (int32_t)bit];
+			if (c == (int32_t)0x80000000) {
+				pos = nbits;
+				return false;
+			}
+			if (c < 0) {
+				sym = (uint32_t)~c;
+				uint32_t left = p - pos;
+				while (left) { // (more than 32 bits are possible)
+					const uint32_t s = left < 32u ? left : 32u;
+					(void)peek();
+					skip(s);
+					left -= s;
+				}
+				return true;
+			}
+			node = c;
+		}
 	}
 };
 

@@ -53,3 +53,27 @@ def test_ineligible_streams_say_why(harness, tmp_path):
         _case(case, setup, "LS", 4, seed=1)
         out = subprocess.run([harness, case, "0"], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "not eligible" in out.stdout and word in out.stdout, out.stdout + out.stderr
+
+
+def test_real_encoder_stream_is_eligible_and_identical(harness, tmp_path):
+    """tests/golden/invalid_keypress.ogg (libvorbis-made: books with codes beyond the two table levels, walked through the
+    tree on the device): its 26 audio packets, each also cut and bit-flipped 300 times"""
+    from oracle import pyogg
+    rd = pyogg.PacketReader(open(os.path.join(ROOT, "tests", "golden", "invalid_keypress.ogg"), "rb").read())
+    pk = []
+    while True:
+        p = rd.read_packet()
+        if p is None:
+            break
+        pk.append(bytes(p.data))
+    case = str(tmp_path / "case.bin")
+    with open(case, "wb") as f:
+        f.write(struct.pack("<I", 1))
+        for b in (pk[0], pk[2]):
+            f.write(struct.pack("<I", len(b)) + b)
+        f.write(struct.pack("<I", len(pk) - 3))
+        for p in pk[3:]:
+            f.write(struct.pack("<I", len(p)) + p)
+    out = subprocess.run([harness, case, "300", "9"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "device entropy algorithm == host entropy stage" in out.stdout, out.stdout

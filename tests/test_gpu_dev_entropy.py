@@ -157,3 +157,51 @@ def test_sharder_with_device_entropy_matches_oracle():
             if rc == 0:
                 assert b.shape == want.shape and np.array_equal(b, want), (half, s)
     sh.close()
+
+
+def test_real_file_through_the_device_entropy_stage():
+    """tests/golden/invalid_keypress.ogg (a real encoder's setup header: 40-odd books, some with codes longer than the table
+    levels): eligible, and every packet -- also cut and bit-flipped copies -- equals the oracle's samples"""
+    import os
+    from common import ROOT
+    from lewton_amd import audio, header
+    from lewton_amd.ring import Ring
+    from oracle import pyogg
+    rd = pyogg.PacketReader(open(os.path.join(ROOT, "tests", "golden", "invalid_keypress.ogg"), "rb").read())
+    pk = []
+    while True:
+        p = rd.read_packet()
+        if p is None:
+            break
+        pk.append(bytes(p.data))
+    ident = header.read_header_ident(pk[0])
+    st = header.read_header_setup(pk[2], ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    o_id = po.Ident(pk[0])
+    o_st = po.Setup(pk[2], o_id)
+    dec = audio.decoder_for(ident, st)
+    rng = np.random.default_rng(3)
+    n_streams = 12
+    streams = [pk[3:]] + [_damage(pk[3:], rng) for _ in range(n_streams - 1)]
+    ring = Ring(dec, 2, n_streams * len(pk), "i16")
+    assert ring.set_entropy_on_device(True)
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    items = [(p, s) for s in range(n_streams) for p in streams[s]]
+    ring.submit(ring.marshal([(p, pwrs[s]) for p, s in items]), n_threads=1)
+    assert "k_entropy" in ring.last_kernels
+    res, pcm = ring.collect()
+    opws = [po.Pwr() for _ in range(n_streams)]
+    ch = ident.audio_channels
+    ok = 0
+    for (pkt, s), (status, m, off) in zip(items, res):
+        try:
+            want = po.read_audio_packet(o_id, o_st, pkt, opws[s], "i16")
+            rc = 0
+        except po.OracleError as e:
+            rc = e.code
+        assert status == rc
+        if rc == 0:
+            ok += 1
+            assert np.array_equal(pcm[off:off + m * ch], want.reshape(-1))
+    assert ok > 200
+    ring.release()
+    ring.close()
