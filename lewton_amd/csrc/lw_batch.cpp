@@ -49,7 +49,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	};
 	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
 	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
-	const size_t o_seg = slice(max_packets * sizeof(LwSegment));
+	const size_t o_seg = slice(max_packets * sizeof(LwSegment)), o_ola = slice(max_packets * sizeof(LwOlaDesc));
 	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
 	b->slab_bytes = off;
 	bool ok = lw_hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
@@ -63,6 +63,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		b->h_halo_items = (LwFastItem *)H(o_halo), b->d_halo_items = (LwFastItem *)D(o_halo);
 		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
 		b->h_seg = (LwSegment *)H(o_seg), b->d_seg = (LwSegment *)D(o_seg);
+		b->h_ola = (LwOlaDesc *)H(o_ola), b->d_ola = (LwOlaDesc *)D(o_ola);
 		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
 		if (d->any_floor0)
 			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
@@ -472,6 +473,36 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	b->out_elems = out_off;
 	b->alg_bytes = alg;
+	// descriptors of the generic overlap-add tasks (records are final now: state hand-over and parities included)
+	for (uint32_t t = 0; t < b->n_gen_ola; t++) {
+		const LwPacketRec &r = b->h_recs[b->h_gen[2 * b->max_packets + t]];
+		LwOlaDesc &o = b->h_ola[t];
+		o.cur_off = 2u * r.res_off;
+		o.out_off = r.out_off;
+		o.state_out = r.state_out;
+		o.n = (uint16_t)(1u << r.bs); // (8192-point blocks: 0x2000 fits)
+		o.ls = r.ls;
+		o.rs = r.rs;
+		o.re = r.re;
+		o.plen = r.plen;
+		o.flags = (uint8_t)(r.flags & (LW_RF_SLOPE_BS1 | LW_RF_PARITY_OUT));
+		o.pad = 0;
+		if (r.prev == -1) {
+			o.prev_kind = 0;
+			o.prev_off = 0;
+			o.prev_stride = 0;
+		} else if (r.prev >= 0) {
+			const LwPacketRec &pr = b->h_recs[r.prev];
+			o.prev_kind = 1;
+			o.prev_off = 2u * pr.res_off + pr.rs;
+			o.prev_stride = (uint16_t)(1u << pr.bs);
+		} else {
+			const uint32_t slot = (uint32_t)(-(r.prev + 2)), par = (r.flags & LW_RF_PARITY_IN) ? 1u : 0u;
+			o.prev_kind = 2;
+			o.prev_off = (uint32_t)(((size_t)slot * 2 + par) * d->T.state_stride);
+			o.prev_stride = (uint16_t)d->T.state_chan_stride;
+		}
+	}
 
 	// ---- workgroups of the fused small-block kernel: runs of consecutive entries of the overlap-add list that are consecutive
 	// packets of one stream, cut at 16 / ch members (one wave per member and channel).  Used when the batch has small generic
@@ -635,6 +666,8 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	if (b->n_gen_ola)
 		HIP_TRY(hipMemcpyAsync(b->d_gen + 2 * b->max_packets, b->h_gen + 2 * b->max_packets, b->n_gen_ola * sizeof(uint32_t),
 					hipMemcpyHostToDevice, st));
+	if (b->n_gen_ola)
+		HIP_TRY(hipMemcpyAsync(b->d_ola, b->h_ola, b->n_gen_ola * sizeof(LwOlaDesc), hipMemcpyHostToDevice, st));
 	if (b->n_seg)
 		HIP_TRY(hipMemcpyAsync(b->d_seg, b->h_seg, b->n_seg * sizeof(LwSegment), hipMemcpyHostToDevice, st));
 	if (b->n_items)
@@ -696,6 +729,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.n_gen_large = b->n_gen_large;
 	B.gen_ola = all_generic ? nullptr : b->d_gen + 2 * b->max_packets;
 	B.n_gen_ola = b->n_gen_ola;
+	B.ola = all_generic || getenv("LW_NO_OLA_DESC") ? nullptr : b->d_ola;
 	B.sym = b->symbols ? b->d_sym : nullptr;
 	B.sym_off = b->d_sym_off;
 	b->last_kernels.clear();

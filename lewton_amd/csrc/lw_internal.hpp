@@ -91,6 +91,7 @@ struct lw_batch {
 	// workgroups that mostly find out they have nothing to do
 	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
 	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
+	LwOlaDesc *h_ola = nullptr, *d_ola = nullptr; // [max_packets] descriptors of k_ola_generic's tasks (order of the third list)
 	LwSegment *h_seg = nullptr, *d_seg = nullptr; // workgroups of the fused small-block kernel over the overlap-add list
 	uint32_t n_seg = 0;
 	bool has_tdonly = false; // the specialised kernel's work list contains LW_RF_TDONLY packets

@@ -584,6 +584,40 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 {
 	// one workgroup per PACKET, all channels: the chain of dependent loads (list -> record -> predecessor's record ->
 	// data) is paid once per packet, and a stereo short block (2 x 128 samples) fills the 256 threads exactly
+	if (B.ola) { // one descriptor = everything this workgroup needs (the planner packed it): one load, then the samples
+		if (blockIdx.x >= B.n_gen_ola)
+			return;
+		const LwOlaDesc o = B.ola[blockIdx.x];
+		const uint32_t n = o.n, ls = o.ls, rs = o.rs, re = o.re, plen = o.plen;
+		const float *cur0 = B.td + o.cur_off;
+		if (o.prev_kind != 0 && rs > ls) {
+			const uint32_t m = rs - ls;
+			const float *slope = T.bs[(o.flags & LW_RF_SLOPE_BS1) ? 1 : 0].window;
+			const float *prev0 = (o.prev_kind == 1 ? B.td : B.state) + o.prev_off;
+			const uint32_t prev_stride = o.prev_stride;
+			for (uint32_t e = threadIdx.x; e < m * T.ch; e += blockDim.x) {
+				const uint32_t c = e / m, i = e - c * m;
+				float x = cur0[c * n + ls + i];
+				if (i < plen)
+					x = (x * slope[i]) + (prev0[c * prev_stride + i] * slope[plen - 1 - i]); // audio.rs:1116-1118
+				if (FMT == LW_OUT_I16_PLANAR)
+					((int16_t *)out_v)[o.out_off + c * m + i] = to_i16(x);
+				else if (FMT == LW_OUT_I16_INTERLEAVED)
+					((int16_t *)out_v)[o.out_off + i * T.ch + c] = to_i16(x);
+				else
+					((float *)out_v)[o.out_off + c * m + i] = x;
+			}
+		}
+		if (o.state_out >= 0 && re > rs) { // audio.rs:1121, :1142-1147: the raw (un-windowed) right part
+			const uint32_t par = (o.flags & LW_RF_PARITY_OUT) ? 1u : 0u, len = re - rs;
+			float *st = B.state + ((size_t)o.state_out * 2 + par) * T.state_stride;
+			for (uint32_t e = threadIdx.x; e < len * T.ch; e += blockDim.x) {
+				const uint32_t c = e / len, i = e - c * len;
+				st[c * T.state_chan_stride + i] = cur0[c * n + rs + i];
+			}
+		}
+		return;
+	}
 	uint32_t pkt = blockIdx.x;
 	if (B.gen_ola) {
 		if (pkt >= B.n_gen_ola)

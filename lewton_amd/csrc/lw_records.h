@@ -55,6 +55,20 @@ static_assert(sizeof(LwPacketRec) == 32, "LwPacketRec must stay 32 bytes");
 
 // One workgroup of the fused small-block kernel (k_small_fused): `count` consecutive entries of the batch's overlap-add list,
 // starting at `first`, that are consecutive packets of ONE stream (entry i+1's predecessor is entry i).
+// One task of the generic overlap-add kernel, packed by the host's planning pass: everything the workgroup needs in ONE load
+// (the list index -> packet record -> predecessor's record chain cost the kernel three dependent round trips before its
+// first sample).  32 bytes.
+struct LwOlaDesc {
+	uint32_t cur_off;   // this packet's time-domain block [ch][n] in B.td (float offset)
+	uint32_t prev_off;  // previous right part: float offset of channel 0 in B.td (kind 1) or in the state pool (kind 2)
+	uint32_t out_off;   // first output element
+	int32_t state_out;  // state slot the raw right part goes to, or -1
+	uint16_t n, ls, rs, re, plen, prev_stride;
+	uint8_t prev_kind;  // 0: no previous window (no samples), 1: predecessor's block in B.td, 2: state pool
+	uint8_t flags;      // LW_RF_SLOPE_BS1 | LW_RF_PARITY_OUT
+	uint16_t pad;
+};
+
 struct LwSegment {
 	uint32_t first;
 	uint16_t count;
