@@ -187,6 +187,31 @@ struct LwEntReader {
 	}
 	// huffman_tree.rs:362-381 through the two table levels: a code that runs past the end consumes the rest and fails
 	// (after that every read fails on its bounds check; the window is not looked at again)
+	// the same in two halves, so that a caller can put other work between the table load and its first use: probe() starts
+	// the first-level look-up of an ordinary book (any value for the special ones), finish() does everything else
+	LW_HD uint32_t probe(const LwEntBookRegs &b)
+	{
+		if (b.single != -1)
+			return 0;
+		return b.lut[peek() & b.lut_mask];
+	}
+	LW_HD bool finish(const LwEntBookRegs &b, uint32_t e, uint32_t &sym)
+	{
+		if (b.single != -1)
+			return code(b, sym);
+		if (e & LW_ENT_LINK)
+			e = b.lut[(e & 0xffffffu) + (((uint32_t)win >> b.lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
+		const uint32_t len = e >> 24;
+		if (len == 0)
+			return walk(b, sym);
+		if (len > nbits - pos) {
+			pos = nbits;
+			return false;
+		}
+		skip(len);
+		sym = e & 0xffffffu;
+		return true;
+	}
 	LW_HD bool code(const LwEntBookRegs &b, uint32_t &sym)
 	{
 		if (b.single >= 0) {
@@ -349,13 +374,54 @@ LW_HD void lw_ent_floor_record(const LwEntFloor &fl, LwEntPosts y, uint16_t *rec
 // belongs to channel i % ch, bin i / ch) -- every element receives the same additions in the same order as in the
 // reference's interleaved buffer.  `out` holds zeros on entry.  `cls` = scratch for nch * (parts + cpc) digits.
 //
-// The reference's loop nest (pass / group of cpc partitions / [classification codewords of every vector] / partition /
-// vector / codewords of the partition) is walked by a CURSOR, one codeword per step: on the GPU the 64 lanes of a wave
-// decode 64 packets, and a nest of loops would make every lane sit through the union of all lanes' partitions and the
-// longest trip count of each (a partition takes psize / dims codewords and dims differs per lane) -- with the cursor a
-// wave takes as many steps as its longest packet has codewords.  Slots in stream order:
-//   pass 0: group g: class slot of vector 0..nch-1, then partition slots (k = 0..cpc-1) x (vector 0..nch-1)
-//   pass p: group g: partition slots only
+// The additions run ONE CODEWORD BEHIND the decoder: a codeword's vector row is requested as soon as its entry number is
+// known, and added (LwEntPending::flush) after the NEXT codeword's table look-up has been started -- the look-up chain
+// (window -> table -> length -> window) is the only thing a packet cannot overlap, everything else hides under it.
+// The first pass that touches a partition finds zeros there (a pass adds to an element at most once): it stores
+// 0.0f + e without reading the accumulator.
+struct LwEntPending {
+	const float *row; // the codeword's VQ row, or null: nothing pending
+	uint32_t dims, base, step, deint, half;
+	bool first;
+#if defined(__HIP_DEVICE_COMPILE__)
+	float rowv; // lane d holds row[d]: requested when the codeword was decoded
+#endif
+	LW_HD void stash(const float *r, uint32_t n_dims, uint32_t base_el, uint32_t step_, uint32_t deint_, uint32_t half_, bool first_)
+	{
+		row = r;
+		dims = n_dims;
+		base = base_el;
+		step = step_;
+		deint = deint_;
+		half = half_;
+		first = first_;
+#if defined(__HIP_DEVICE_COMPILE__)
+		LW_ENT_EACH(d, n_dims)
+			rowv = r[d];
+#endif
+	}
+	// element d of the row goes to: type 0 base + d * step; types 1/2 base + d, de-interleaved for type 2
+	LW_HD void flush(LwEntAcc out)
+	{
+		if (!row)
+			return;
+		LW_ENT_EACH(d, dims) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			const float e = rowv;
+#else
+			const float e = row[d];
+#endif
+			uint32_t at = base + d * step;
+			if (deint == 2)
+				at = (at & 1u) * half + (at >> 1);
+			else if (deint)
+				at = (at % deint) * half + at / deint;
+			out[at] = (first ? 0.0f : out[at]) + e;
+		}
+		row = nullptr;
+	}
+};
+
 LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntReader &r, uint32_t nch, uint32_t actual,
 		const bool *dnd, LwEntAcc out, uint32_t half, uint32_t deint_ch, LwEntDigits cls)
 {
@@ -363,136 +429,70 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 	const uint32_t cpc = rs.cpc, psize = rs.psize;
 	const uint32_t n_to_read = end - begin;
 	const uint32_t parts = n_to_read / psize;
-	if (n_to_read == 0 || parts == 0)
+	if (n_to_read == 0)
 		return;
 	const uint32_t stride = parts + cpc;
-	const uint32_t ncls = rs.classifications;
+	const uint32_t ncls = rs.classifications, rtype = rs.type, digits_off = rs.digits_off;
 	uint32_t used_any = 0; // passes some class of this residue uses at all
 	for (uint32_t c = 0; c < ncls; c++)
 		used_any |= rs.vals_used[c];
-	uint32_t dnd_mask = 0;
-	for (uint32_t j = 0; j < nch; j++)
-		dnd_mask |= dnd[j] ? 1u << j : 0u;
-	if (dnd_mask == (1u << nch) - 1u)
-		return; // nothing is read for vectors marked do-not-decode
-	// cursor
-	uint32_t pass = 0, pc0 = 0, k = 0, j = 0;
-	bool klass = true; // at a classification slot (pass 0 only)
-	// the partition being decoded: position, step count and book
-	uint32_t i = 0, lim = 0, dims = 1, step = 0, offs = 0, vec = 0;
-	bool first = false, in_part = false;
-	const uint32_t rtype = rs.type, digits_off = rs.digits_off;
 	const LwEntBookRegs classbook = lw_ent_book(T, rs.classbook);
-	LwEntBookRegs cb = classbook;
-	for (;;) {
-		if (!in_part) {
-			// find the next slot that reads something
-			for (;;) {
-				if ((used_any >> pass) == 0)
-					return; // no later pass decodes anything
-				if (!((dnd_mask >> j) & 1u)) {
-					if (klass)
-						break;
-					const uint32_t cl = cls[j * stride + pc0 + k];
-					const uint32_t vu = rs.vals_used[cl];
-					if (vu & (1u << pass)) {
-						cb = lw_ent_book(T, rs.val_i[cl][pass]);
-						dims = cb.dims;
-						offs = begin + (pc0 + k) * psize;
-						vec = j;
-						first = (vu & ((1u << pass) - 1u)) == 0;
-						step = psize / dims;
-						lim = rtype == 0 ? step : psize;
-						i = 0;
-						in_part = lim != 0;
-						if (in_part)
-							break;
+	LwEntPending pend;
+	pend.row = nullptr;
+	for (uint32_t pass = 0; pass < 8 && (used_any >> pass) != 0; pass++) {
+		uint32_t pc = 0;
+		while (pc < parts) {
+			if (pass == 0) {
+				for (uint32_t j = 0; j < nch; j++) {
+					if (dnd[j])
+						continue;
+					uint32_t t;
+					if (!r.code(classbook, t)) {
+						pend.flush(out);
+						return; // end of packet is normal (audio.rs:655-660)
 					}
-				}
-				// advance the cursor by one slot
-				if (++j == nch) {
-					j = 0;
-					if (klass) {
-						klass = false;
-						k = 0;
-					} else if (++k == cpc || pc0 + k >= parts) {
-						k = 0;
-						pc0 += cpc;
-						if (pc0 >= parts) {
-							pc0 = 0;
-							if (++pass == 8)
-								return;
+					LwEntDigits c = cls + j * stride + pc;
+					if (digits_off != 0xFFFFFFFFu) {
+						const uint8_t *dg = T.bytes + digits_off + t * cpc;
+						LW_ENT_EACH(q, cpc)
+							c[q] = dg[q];
+					} else {
+						for (uint32_t q = cpc; q-- > 0;) {
+							c[q] = (uint8_t)(t % ncls);
+							t /= ncls;
 						}
-						klass = pass == 0;
 					}
 				}
 			}
-		}
-		if (!in_part) { // classification codeword of vector j for the group at pc0 (audio.rs:655-668)
-			uint32_t t;
-			if (!r.code(classbook, t))
-				return; // end of packet is normal (audio.rs:655-660)
-			LwEntDigits c = cls + j * stride + pc0;
-			if (digits_off != 0xFFFFFFFFu) {
-				const uint8_t *dg = T.bytes + digits_off + t * cpc;
-				LW_ENT_EACH(q, cpc)
-					c[q] = dg[q];
-			} else {
-				for (uint32_t q = cpc; q-- > 0;) {
-					c[q] = (uint8_t)(t % ncls);
-					t /= ncls;
-				}
-			}
-			if (++j == nch) {
-				j = 0;
-				klass = false;
-				k = 0;
-			}
-			continue;
-		}
-		// one codeword of the current partition (audio.rs:587-618; the whole partition lies inside the vector and dims divides
-		// the partition size).  The first pass that touches a partition finds zeros there (a pass adds to an element at most
-		// once): it stores 0.0f + e without reading the element back from HBM.
-		uint32_t idx;
-		if (!r.code(cb, idx))
-			return;
-		const float *e = cb.vq + idx * dims;
-		if (rtype == 0) {
-			LwEntAcc v = out + vec * half + offs + i;
-			LW_ENT_EACH(d, dims)
-				v[d * step] = (first ? 0.0f : v[d * step]) + e[d];
-			i += 1;
-		} else if (deint_ch == 0) {
-			LwEntAcc v = out + vec * half + offs + i;
-			LW_ENT_EACH(d, dims)
-				v[d] = (first ? 0.0f : v[d]) + e[d];
-			i += dims;
-		} else {
-			LW_ENT_EACH(d, dims) {
-				const uint32_t el = offs + i + d;
-				LwEntAcc v = out + (el % deint_ch) * half + el / deint_ch;
-				*v = (first ? 0.0f : *v) + e[d];
-			}
-			i += dims;
-		}
-		if (i >= lim) {
-			in_part = false;
-			// this partition slot is done: advance the cursor past it
-			if (++j == nch) {
-				j = 0;
-				if (++k == cpc || pc0 + k >= parts) {
-					k = 0;
-					pc0 += cpc;
-					if (pc0 >= parts) {
-						pc0 = 0;
-						if (++pass == 8)
+			for (uint32_t k = 0; k < cpc && pc < parts; k++, pc++) {
+				for (uint32_t j = 0; j < nch; j++) {
+					if (dnd[j])
+						continue;
+					const uint32_t cl = cls[j * stride + pc];
+					const uint32_t vu = rs.vals_used[cl];
+					if (!(vu & (1u << pass)))
+						continue;
+					const LwEntBookRegs cb = lw_ent_book(T, rs.val_i[cl][pass]);
+					const uint32_t dims = cb.dims;
+					const bool first = (vu & ((1u << pass) - 1u)) == 0;
+					// audio.rs:587-618 (the whole partition lies inside the vector; dims divides the partition size):
+					// type 0: psize / dims codewords, element d of codeword i at i + d * step; types 1/2: at i * dims + d
+					const uint32_t step = rtype == 0 ? psize / dims : 1u;
+					const uint32_t count = psize / dims, adv = rtype == 0 ? 1u : dims;
+					uint32_t at = (deint_ch ? 0u : j * half) + begin + pc * psize;
+					for (uint32_t i = 0; i < count; i++, at += adv) {
+						const uint32_t e = r.probe(cb); // this codeword's table look-up is under way ...
+						pend.flush(out);                 // ... while the previous codeword's vector is added
+						uint32_t idx;
+						if (!r.finish(cb, e, idx))
 							return;
+						pend.stash(cb.vq + idx * dims, dims, at, step, deint_ch, half, first);
 					}
-					klass = pass == 0;
 				}
 			}
 		}
 	}
+	pend.flush(out);
 }
 
 // Floors and residues of one packet (what lw::entropy_decode does after the prologue).  floor_out [ch][fstride],
