@@ -82,8 +82,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # host threads for the (untimed) entropy stage that prepares the records: an equal share of the cores per rank
-    host_threads = max(4, (os.cpu_count() or 8) // max(1, world))
     from lewton_amd import _native as N
+    # (the CPUs this process may actually use: affinity mask and cgroup quota -- 16 of the GPU box's 256 hardware threads)
+    host_threads = max(2, N.lw_default_host_threads() // max(1, world))
     from lewton_amd import audio, header, streamgen as sg
     from lewton_amd.batch import Batch
 
@@ -270,7 +271,9 @@ def main():
             try:
                 import subprocess
                 import sys
-                ncore = os.cpu_count() or 1
+                # one worker per CPU the container may use (affinity mask, cgroup cpu.max): more runnable processes than that
+                # are only throttled
+                ncore = max(1, N.lw_default_host_threads())
                 procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", str(2000 + i), str(args.cpu_all_cores_seconds)],
                                           cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(ncore)]
                 tot = 0.0
@@ -279,8 +282,8 @@ def main():
                     n_, s_ = out.split()
                     tot += float(n_) / float(s_)
                 cpu["all_cores"] = {"value": tot, "unit": "packets/s", "cores": ncore, "kind": "port",
-                                    "sample": "%d worker processes, one synthetic stream each, %.0f s each" % (
-                                        ncore, args.cpu_all_cores_seconds)}
+                                    "sample": "%d worker processes (= CPUs usable by this container of %d hardware threads), one "
+                                              "synthetic stream each, %.0f s each" % (ncore, os.cpu_count() or 0, args.cpu_all_cores_seconds)}
             except Exception as e:  # informational only
                 cpu["all_cores"] = {"error": repr(e)}
 

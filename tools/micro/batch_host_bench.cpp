@@ -168,6 +168,32 @@ int main(int argc, char **argv)
 			}
 			lw_batch_destroy(b2);
 		}
+		{ // entropy stage on the device: the host side (prologues, packet pool, planning) must decide the same statuses, sample
+		  // counts and offsets as the host stage -- for eligible streams nothing after the prologue can fail
+			lw_batch *b3 = lw_batch_create(dec, NP, LW_FMT_I16_PLANAR, &err);
+			const int rc = lw_batch_set_entropy_on_device(b3, 1);
+			if (rc == LW_OK) {
+				for (auto *p : pwr)
+					lw_pwr_reset(p);
+				if (lw_batch_entropy(b3, pk.data(), NP, 2) || lw_batch_upload(b3, nullptr)) {
+					printf("device-entropy batch failed on the host side\n");
+					return 1;
+				}
+				const lw_packet_result *r3 = lw_batch_results(b3);
+				for (size_t k = 0; k < NP; k++)
+					if (r3[k].status != ref.res[k].status || r3[k].n_samples != ref.res[k].n_samples ||
+							r3[k].out_offset != ref.res[k].out_offset) {
+						printf("packet %zu: device-entropy mode plans differently (%d/%u vs %d/%u)\n", k, r3[k].status, r3[k].n_samples,
+								ref.res[k].status, ref.res[k].n_samples);
+						return 1;
+					}
+				printf("device-entropy mode: host side agrees\n");
+			} else if (rc != LW_ERR_UNSUPPORTED) {
+				printf("lw_batch_set_entropy_on_device: %d\n", rc);
+				return 1;
+			}
+			lw_batch_destroy(b3);
+		}
 		printf("check ok: %zu packets (%zu decodable vs single-packet hook)\n", NP, ok);
 		return 0;
 	}
