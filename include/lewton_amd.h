@@ -198,8 +198,8 @@ int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why);
  * :587-760) runs on the GPU, one lane per packet; lw_batch_entropy then only reads the prologues, copies the packets
  * into pinned staging and plans the batch, and the packets themselves (~0.5 KB instead of 8.3 KB of records per stereo
  * long block) cross PCIe.  Records, PCM and statuses are bit-identical to the host stage's.  Eligible streams: floor type
- * 1, one submap per mapping, residue books whose dimension divides the partition size (`why` names the reason
- * otherwise; LW_ERR_UNSUPPORTED from the setters). */
+ * 1, residue books whose dimension divides the partition size, at most 8 channels (`why` names the reason otherwise;
+ * LW_ERR_UNSUPPORTED from the setters). */
 int lw_decoder_supports_device_entropy(const lw_decoder *d, const char **why);
 int lw_batch_set_entropy_on_device(lw_batch *b, int on);
 /* Runs k_entropy for the records uploaded last (after lw_batch_upload, on the same stream), ahead of lw_batch_synth: the

@@ -27,6 +27,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	*why = "";
 	const size_t ch = id.channels;
 	const size_t n1 = (size_t)1 << id.bs1;
+	img.general = 0;
 	if (ch == 0 || ch > LW_ENT_MAX_CH) {
 		*why = "more than 8 channels";
 		return false;
@@ -46,8 +47,9 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		LwEntMode &m = modes[mi];
 		std::memset(&m, 0, sizeof(m));
 		m.blockflag = s.modes[mi].blockflag ? 1 : 0;
-		if (map.submap_floor.size() != 1 || map.submap_residue.size() != 1) {
-			*why = "a mapping with more than one submap";
+		const size_t nsm = map.submap_floor.size();
+		if (nsm == 0 || nsm > 16 || map.submap_residue.size() != nsm || map.mux.size() < ch) {
+			*why = "mapping shape";
 			return false;
 		}
 		if (map.mag.size() > LW_ENT_MAX_COUPLING) {
@@ -59,11 +61,26 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 			m.mag[i] = map.mag[i];
 			m.ang[i] = map.ang[i];
 		}
-		for (size_t c = 0; c < ch; c++)
-			m.floor_of_ch[c] = map.submap_floor[0];
-		m.residue = map.submap_residue[0];
-		floor_used[map.submap_floor[0]] = true;
-		res_used[map.submap_residue[0]] = true;
+		m.n_submaps = (uint8_t)nsm;
+		if (nsm != 1)
+			img.general = 1;
+		for (size_t c = 0; c < ch; c++) {
+			if (map.mux[c] >= nsm) {
+				*why = "mapping mux";
+				return false;
+			}
+			m.mux[c] = map.mux[c];
+			m.floor_of_ch[c] = map.submap_floor[map.mux[c]];
+			floor_used[map.submap_floor[map.mux[c]]] = true;
+		}
+		for (size_t sm = 0; sm < nsm; sm++) {
+			m.submap_residue[sm] = map.submap_residue[sm];
+			bool has = false;
+			for (size_t c = 0; c < ch; c++)
+				has |= map.mux[c] == sm;
+			if (has) // (a submap without channels decodes nothing, audio.rs:957-986)
+				res_used[map.submap_residue[sm]] = true;
+		}
 	}
 	std::vector<LwEntFloor> floors(s.floors.size());
 	for (size_t fi = 0; fi < s.floors.size(); fi++) {
@@ -271,6 +288,7 @@ LwEntTables dev_entropy_view(const DevEntropyImage &img, const uint8_t *base)
 	T.fstride = img.fstride;
 	T.ws_bytes = img.ws_bytes;
 	T.res_floats = img.res_floats;
+	T.general = img.general;
 	return T;
 }
 

@@ -11,8 +11,8 @@
 // Everything here is plain data and pointers: the setup header is flattened once into one image (lw_dev_entropy.cpp,
 // lw::DevEntropyImage) that lives in HBM.  The function produces exactly what the host stage writes into a batch's staging
 // -- floor records [ch][fstride] u16 and residue vectors [ch][n/2] f32 before inverse coupling -- so the synthesis kernels
-// run unchanged behind it.  Eligible setups only (lw::dev_entropy_build says why not): floor type 1, one submap per mapping,
-// residue books whose dimension divides the partition size.
+// run unchanged behind it.  Eligible setups only (lw::dev_entropy_build says why not): floor type 1, residue books whose
+// dimension divides the partition size, at most 8 channels.
 // For those the packet status is decided by the prologue alone (the host reads it: mode number, window flags), so the
 // host's planning pass needs nothing back from the device.
 #pragma once
@@ -78,8 +78,10 @@ struct LwEntResidue {
 };
 
 struct LwEntMode {
-	uint8_t blockflag, n_coupling, residue, pad;
+	uint8_t blockflag, n_coupling, n_submaps, pad;
 	uint8_t floor_of_ch[LW_ENT_MAX_CH];
+	uint8_t mux[LW_ENT_MAX_CH];           // submap of every channel
+	uint8_t submap_residue[16];
 	uint8_t mag[LW_ENT_MAX_COUPLING], ang[LW_ENT_MAX_COUPLING];
 };
 
@@ -96,6 +98,7 @@ struct LwEntTables {
 	uint32_t ch, fstride;
 	uint32_t ws_bytes;  // per-packet scratch: posts (4 * LW_MAX_POSTS rounded up) + classification digits
 	uint32_t res_floats; // largest residue block of a packet: ch * blocksize_1 / 2
+	uint32_t general;    // 0: every mapping has one submap with all channels (the usual case; its own kernel instantiation)
 };
 
 // One packet of a device-entropy batch
@@ -382,6 +385,8 @@ LW_HD void lw_ent_floor_record(const LwEntFloor &fl, LwEntPosts y, uint16_t *rec
 struct LwEntPending {
 	const float *row; // the codeword's VQ row, or null: nothing pending
 	uint32_t dims, base, step, deint, half;
+	uint64_t cmap;    // channel of vector j in byte j (a submap's vectors are a subset of the packet's channels)
+	bool ident;       // vector j is channel j (the usual one-submap case)
 	bool first;
 #if defined(__HIP_DEVICE_COMPILE__)
 	float rowv; // lane d holds row[d]: requested when the codeword was decoded
@@ -412,10 +417,10 @@ struct LwEntPending {
 			const float e = row[d];
 #endif
 			uint32_t at = base + d * step;
-			if (deint == 2)
-				at = (at & 1u) * half + (at >> 1);
-			else if (deint)
-				at = (at % deint) * half + at / deint;
+			if (deint) { // type 2: element `at` of the interleaved vector belongs to the submap's vector at % deint, bin at / deint
+				const uint32_t v = deint == 2 ? at & 1u : at % deint, q = deint == 2 ? at >> 1 : at / deint;
+				at = (ident ? v : (uint32_t)((cmap >> (8u * v)) & 0xffu)) * half + q;
+			}
 			out[at] = (first ? 0.0f : out[at]) + e;
 		}
 		row = nullptr;
@@ -423,7 +428,7 @@ struct LwEntPending {
 };
 
 LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntReader &r, uint32_t nch, uint32_t actual,
-		const bool *dnd, LwEntAcc out, uint32_t half, uint32_t deint_ch, LwEntDigits cls)
+		const bool *dnd, LwEntAcc out, uint32_t half, uint32_t deint_ch, LwEntDigits cls, uint64_t cmap, const bool general)
 {
 	const uint32_t begin = rs.begin < actual ? rs.begin : actual, end = rs.end < actual ? rs.end : actual;
 	const uint32_t cpc = rs.cpc, psize = rs.psize;
@@ -439,6 +444,11 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 	const LwEntBookRegs classbook = lw_ent_book(T, rs.classbook);
 	LwEntPending pend;
 	pend.row = nullptr;
+	pend.cmap = cmap;
+	pend.ident = true;
+	if (general) // (a compile-time constant at both call sites: the one-submap kernel carries no channel map at all)
+		for (uint32_t v = 0, nv = deint_ch ? deint_ch : nch; v < nv; v++)
+			pend.ident &= ((cmap >> (8u * v)) & 0xffu) == v;
 	for (uint32_t pass = 0; pass < 8 && (used_any >> pass) != 0; pass++) {
 		uint32_t pc = 0;
 		while (pc < parts) {
@@ -479,7 +489,7 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 					// type 0: psize / dims codewords, element d of codeword i at i + d * step; types 1/2: at i * dims + d
 					const uint32_t step = rtype == 0 ? psize / dims : 1u;
 					const uint32_t count = psize / dims, adv = rtype == 0 ? 1u : dims;
-					uint32_t at = (deint_ch ? 0u : j * half) + begin + pc * psize;
+					uint32_t at = (deint_ch ? 0u : (pend.ident ? j : (uint32_t)((cmap >> (8u * j)) & 0xffu)) * half) + begin + pc * psize;
 					for (uint32_t i = 0; i < count; i++, at += adv) {
 						const uint32_t e = r.probe(cb); // this codeword's table look-up is under way ...
 						pend.flush(out);                 // ... while the previous codeword's vector is added
@@ -498,7 +508,7 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 // Floors and residues of one packet (what lw::entropy_decode does after the prologue).  floor_out [ch][fstride],
 // res_out [ch][n/2] zero on entry, ws = T.ws_bytes of scratch (4-byte aligned).
 LW_HD void lw_ent_decode_packet(const LwEntTables &T, const uint32_t *words, uint32_t len_bytes, uint32_t start_bit,
-		uint32_t mode, uint32_t n, uint16_t *floor_out, LwEntAcc res_out, LwEntPosts y, LwEntDigits cls)
+		uint32_t mode, uint32_t n, uint16_t *floor_out, LwEntAcc res_out, LwEntPosts y, LwEntDigits cls, const bool general)
 {
 	LwEntReader r;
 	r.init(words, len_bytes, start_bit);
@@ -523,18 +533,44 @@ LW_HD void lw_ent_decode_packet(const LwEntTables &T, const uint32_t *words, uin
 		if (!(no_residue[mg] && no_residue[an]))
 			no_residue[mg] = no_residue[an] = false;
 	}
-	// audio.rs:957-986, one submap: every channel, in order
-	const LwEntResidue &rs = T.residues[m.residue];
-	if (rs.type != 2) {
-		lw_ent_residue(T, rs, r, ch, half, no_residue, res_out, half, 0u, cls);
+	if (!general) { // one submap holding every channel (T.general == 0): vector j = channel j
+		const LwEntResidue &rs = T.residues[m.submap_residue[0]];
+		if (rs.type != 2) {
+			lw_ent_residue(T, rs, r, ch, half, no_residue, res_out, half, 0u, cls, 0, false);
+			return;
+		}
+		// audio.rs:722-760: type 2 = one interleaved vector of ch * n/2 elements, decoded unless EVERY channel is marked
+		bool any = false;
+		for (uint32_t c = 0; c < ch; c++)
+			any |= !no_residue[c];
+		if (!any)
+			return;
+		const bool one_dnd[1] = {false};
+		lw_ent_residue(T, rs, r, 1u, ch * half, one_dnd, res_out, half, ch, cls, 0, false);
 		return;
 	}
-	// audio.rs:722-760: type 2 = one interleaved vector of ch * n/2 elements, decoded unless EVERY channel is marked
-	bool any = false;
-	for (uint32_t c = 0; c < ch; c++)
-		any |= !no_residue[c];
-	if (!any)
-		return;
-	const bool one_dnd[1] = {false};
-	lw_ent_residue(T, rs, r, 1u, ch * half, one_dnd, res_out, half, ch, cls);
+	// audio.rs:957-986: submap by submap, the vectors of a submap = its channels in channel order
+	for (uint32_t sm = 0; sm < m.n_submaps; sm++) {
+		bool dnd[LW_ENT_MAX_CH];
+		uint64_t cmap = 0;
+		uint32_t sub_ch = 0;
+		bool any = false;
+		for (uint32_t c = 0; c < ch; c++)
+			if (m.mux[c] == sm) {
+				dnd[sub_ch] = no_residue[c];
+				any |= !no_residue[c];
+				cmap |= (uint64_t)c << (8u * sub_ch);
+				sub_ch++;
+			}
+		if (sub_ch == 0)
+			continue;
+		const LwEntResidue &rs = T.residues[m.submap_residue[sm]];
+		if (rs.type != 2) {
+			lw_ent_residue(T, rs, r, sub_ch, half, dnd, res_out, half, 0u, cls, cmap, true);
+		} else if (any) {
+			// audio.rs:722-760: type 2 = one interleaved vector of sub_ch * n/2 elements, decoded unless EVERY channel is marked
+			const bool one_dnd[1] = {false};
+			lw_ent_residue(T, rs, r, 1u, sub_ch * half, one_dnd, res_out, half, sub_ch, cls, cmap, true);
+		}
+	}
 }

@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+template <bool GENERAL> // GENERAL: mappings with several submaps (vectors of a submap = a subset of the channels)
 __global__ void __launch_bounds__(64) k_entropy(LwEntTables T, const LwEntPacket *pk, const LwPacketRec *recs, const uint32_t *pool,
 		uint16_t *floors, float *residue, uint32_t n)
 {
@@ -35,7 +36,7 @@ __global__ void __launch_bounds__(64) k_entropy(LwEntTables T, const LwEntPacket
 	LwEntAcc acc = (LwEntAcc)smem;
 	LwEntPosts posts = (LwEntPosts)(smem + T.res_floats);
 	LwEntDigits digits = (LwEntDigits)(smem + T.res_floats) + LW_ENT_POSTS_BYTES;
-	lw_ent_decode_packet(T, pool + p.word_off, p.len, p.start_bit, rec.mode, blk, floors + rec.floor_off, acc, posts, digits);
+	lw_ent_decode_packet(T, pool + p.word_off, p.len, p.start_bit, rec.mode, blk, floors + rec.floor_off, acc, posts, digits, GENERAL);
 	__syncthreads();
 	// residue blocks start at multiples of ch * n0 / 2 floats: 16-byte aligned
 	float *out = (float *)__builtin_assume_aligned(residue + rec.res_off, 16);
@@ -56,7 +57,12 @@ void lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPa
 		return;
 	const size_t lds = (size_t)T.res_floats * 4 + T.ws_bytes;
 	static LwPerDeviceOnce once;
-	if (once.first_launch_on_device())
-		(void)hipFuncSetAttribute((const void *)k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-	hipLaunchKernelGGL(k_entropy, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
+	if (once.first_launch_on_device()) {
+		(void)hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		(void)hipFuncSetAttribute((const void *)k_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	}
+	if (T.general)
+		hipLaunchKernelGGL(k_entropy<true>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
+	else
+		hipLaunchKernelGGL(k_entropy<false>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
 }

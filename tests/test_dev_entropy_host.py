@@ -37,7 +37,7 @@ def _case(path, setup, pattern, count, **kw):
 
 
 @pytest.mark.parametrize("name,pattern", [("stereo", "LLSSLSL"), ("stereo_t1", "LSL"), ("mono_small", "LSSLL"), ("stereo_9_12", "LSL"),
-                                          ("stereo_7_7", "LSL"), ("stereo_single_entry", "LLS")])
+                                          ("stereo_7_7", "LSL"), ("stereo_single_entry", "LLS"), ("surround51", "LLSL")])
 def test_device_algorithm_equals_host_stage(harness, tmp_path, name, pattern):
     case = str(tmp_path / "case.bin")
     _case(case, HOST_SETUPS[name](), pattern, 60, seed=11, p_floor_unused=0.15)
@@ -48,7 +48,7 @@ def test_device_algorithm_equals_host_stage(harness, tmp_path, name, pattern):
 
 def test_ineligible_streams_say_why(harness, tmp_path):
     from common import FLOOR0_SETUPS, SETUPS
-    for setup, word in ((SETUPS["surround51"](), "submap"), (FLOOR0_SETUPS["floor0"](), "floor type 0")):
+    for setup, word in ((FLOOR0_SETUPS["floor0"](), "floor type 0"), (FLOOR0_SETUPS["floor0_mixed"](), "floor type 0")):
         case = str(tmp_path / "case.bin")
         _case(case, setup, "LS", 4, seed=1)
         out = subprocess.run([harness, case, "0"], capture_output=True, text=True, timeout=300)

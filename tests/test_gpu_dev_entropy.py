@@ -33,7 +33,7 @@ def _damage(pk, rng):
 
 
 @pytest.mark.parametrize("name,pattern", [("stereo", "L"), ("stereo", "LLSSSSLLSL"), ("stereo_t1", "LSL"), ("mono_small", "LSSLL"),
-                                          ("stereo_9_12", "LLS"), ("stereo_7_7", "LSL")])
+                                          ("stereo_9_12", "LLS"), ("stereo_7_7", "LSL"), ("surround51", "LLSL")])
 def test_ring_with_device_entropy_matches_oracle(name, pattern):
     from lewton_amd.ring import Ring
     setup = SETUPS[name]()
@@ -121,7 +121,7 @@ def test_ineligible_streams_stay_on_the_host_stage():
     from lewton_amd import _native as N
     from lewton_amd.ring import Ring
     import ctypes as C
-    for setup, word in ((SETUPS["surround51"](), b"submap"), (FLOOR0_SETUPS["floor0"](), b"floor type 0")):
+    for setup, word in ((FLOOR0_SETUPS["floor0"](), b"floor type 0"), (FLOOR0_SETUPS["floor0_mixed"](), b"floor type 0")):
         audio, ident, st = _product(setup)
         dec = audio.decoder_for(ident, st)
         ring = Ring(dec, 2, 16, "i16")
