@@ -1,4 +1,4 @@
-"""The bench line the driver consumes: the committed profiles/r01_bench.json (output of bench.py on an MI355X) must carry
+"""The bench line the driver consumes: the committed profiles/r0N_bench.json (output of bench.py on an MI355X) must carry
 every field of the contract, with consistent numbers."""
 import json
 import os
@@ -6,8 +6,12 @@ import os
 from common import ROOT
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r01_bench.json")).readline()
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    line = open(os.path.join(ROOT, "profiles", name)).readline()
     d = json.loads(line)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"].split(" (")[0] == base["metric"].split(" (")[0] and d["unit"] == "packets/s"
@@ -28,6 +32,13 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "packets/s" and c["value"] > 0 and "sample" in c
     assert "bit-exact" in d["config"]["parity"]
+    if name >= "r02":
+        # round 2: the timed batch itself is verified, and the PCIe-inclusive rates ride along (never as `value`)
+        assert "4096 packets" in d["config"]["parity"] or "256 streams" in d["config"]["parity"]
+        e = d["end_to_end"]
+        assert e["unit"] == "packets/s" and 0 < e["value"] < d["value"] and e["host_cpus_usable"] >= 1
+        t = e["tier_c"]
+        assert "entropy stage on the device" in t["records"] and "k_entropy" in t["kernels"] and t["value"] > 0
 
 
 def test_device_code_is_the_measured_build():
