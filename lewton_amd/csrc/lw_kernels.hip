@@ -595,6 +595,32 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 			const float *slope = T.bs[(o.flags & LW_RF_SLOPE_BS1) ? 1 : 0].window;
 			const float *prev0 = (o.prev_kind == 1 ? B.td : B.state) + o.prev_off;
 			const uint32_t prev_stride = o.prev_stride;
+			// four samples per thread and step (16-byte loads, one 8- or 16-byte store) when everything is a multiple of four
+			// -- it always is for block sizes >= 64; the long blocks next to short ones move 40 KB each through here
+			const bool quads = FMT != LW_OUT_I16_INTERLEAVED && ((ls | m | plen | n | prev_stride | o.prev_off | o.cur_off | o.out_off) & 3u) == 0 &&
+				((uintptr_t)out_v & 15u) == 0;
+			if (quads) {
+				const uint32_t mq = m >> 2;
+				for (uint32_t q = threadIdx.x; q < mq * T.ch; q += blockDim.x) {
+					const uint32_t c = q / mq, i = 4u * (q - c * mq);
+					float4 x = *(const float4 *)(cur0 + c * n + ls + i);
+					if (i < plen) { // (plen is a multiple of four as well: the four samples are inside together)
+						const float4 s = *(const float4 *)(slope + i), r = *(const float4 *)(slope + plen - 4u - i);
+						const float4 p = *(const float4 *)(prev0 + c * prev_stride + i);
+						x.x = (x.x * s.x) + (p.x * r.w); // audio.rs:1116-1118, slope[plen - 1 - (i + k)] = r[3 - k]
+						x.y = (x.y * s.y) + (p.y * r.z);
+						x.z = (x.z * s.z) + (p.z * r.y);
+						x.w = (x.w * s.w) + (p.w * r.x);
+					}
+					if (FMT == LW_OUT_I16_PLANAR) {
+						const uint32_t lo = (uint32_t)(uint16_t)to_i16(x.x) | ((uint32_t)(uint16_t)to_i16(x.y) << 16);
+						const uint32_t hi = (uint32_t)(uint16_t)to_i16(x.z) | ((uint32_t)(uint16_t)to_i16(x.w) << 16);
+						*(uint2 *)((int16_t *)out_v + o.out_off + c * m + i) = make_uint2(lo, hi);
+					} else {
+						*(float4 *)((float *)out_v + o.out_off + c * m + i) = x;
+					}
+				}
+			} else
 			for (uint32_t e = threadIdx.x; e < m * T.ch; e += blockDim.x) {
 				const uint32_t c = e / m, i = e - c * m;
 				float x = cur0[c * n + ls + i];
@@ -611,6 +637,13 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 		if (o.state_out >= 0 && re > rs) { // audio.rs:1121, :1142-1147: the raw (un-windowed) right part
 			const uint32_t par = (o.flags & LW_RF_PARITY_OUT) ? 1u : 0u, len = re - rs;
 			float *st = B.state + ((size_t)o.state_out * 2 + par) * T.state_stride;
+			if (((len | rs | n | o.cur_off | T.state_chan_stride | T.state_stride) & 3u) == 0) {
+				const uint32_t lq = len >> 2;
+				for (uint32_t q = threadIdx.x; q < lq * T.ch; q += blockDim.x) {
+					const uint32_t c = q / lq, i = 4u * (q - c * lq);
+					*(float4 *)(st + c * T.state_chan_stride + i) = *(const float4 *)(cur0 + c * n + rs + i);
+				}
+			} else
 			for (uint32_t e = threadIdx.x; e < len * T.ch; e += blockDim.x) {
 				const uint32_t c = e / len, i = e - c * len;
 				st[c * T.state_chan_stride + i] = cur0[c * n + rs + i];
