@@ -50,6 +50,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
 	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
 	const size_t o_seg = slice(max_packets * sizeof(LwSegment)), o_ola = slice(max_packets * sizeof(LwOlaDesc));
+	const size_t o_tasks = slice(max_packets * ch * sizeof(LwGenTask));
 	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
 	b->slab_bytes = off;
 	bool ok = lw_hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
@@ -64,6 +65,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
 		b->h_seg = (LwSegment *)H(o_seg), b->d_seg = (LwSegment *)D(o_seg);
 		b->h_ola = (LwOlaDesc *)H(o_ola), b->d_ola = (LwOlaDesc *)D(o_ola);
+		b->h_tasks = (LwGenTask *)H(o_tasks), b->d_tasks = (LwGenTask *)D(o_tasks);
 		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
 		if (d->any_floor0)
 			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
@@ -473,6 +475,20 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	b->out_elems = out_off;
 	b->alg_bytes = alg;
+	// tasks of the short-block transform kernel: record + the per-channel look-ups, one load on the device
+	for (uint32_t t = 0; t < b->n_gen_small; t++) {
+		const LwPacketRec &r = b->h_recs[b->h_gen[t]];
+		for (uint32_t c = 0; c < ch; c++) {
+			LwGenTask &g = b->h_tasks[(size_t)t * ch + c];
+			g.rec = r;
+			g.c = (uint8_t)c;
+			g.fl = d->h_mode_floor[(size_t)r.mode * ch + c];
+			g.F = d->h_floor_F[g.fl];
+			g.partner = d->T.pair_coupling ? d->h_mode_partner[(size_t)r.mode * ch + c] : (int8_t)-1;
+			g.role = d->T.pair_coupling ? d->h_mode_role[(size_t)r.mode * ch + c] : (uint8_t)0;
+			g.pad[0] = g.pad[1] = g.pad[2] = 0;
+		}
+	}
 	// descriptors of the generic overlap-add tasks (records are final now: state hand-over and parities included)
 	for (uint32_t t = 0; t < b->n_gen_ola; t++) {
 		const LwPacketRec &r = b->h_recs[b->h_gen[2 * b->max_packets + t]];
@@ -668,6 +684,8 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 					hipMemcpyHostToDevice, st));
 	if (b->n_gen_ola)
 		HIP_TRY(hipMemcpyAsync(b->d_ola, b->h_ola, b->n_gen_ola * sizeof(LwOlaDesc), hipMemcpyHostToDevice, st));
+	if (b->n_gen_small)
+		HIP_TRY(hipMemcpyAsync(b->d_tasks, b->h_tasks, (size_t)b->n_gen_small * ch * sizeof(LwGenTask), hipMemcpyHostToDevice, st));
 	if (b->n_seg)
 		HIP_TRY(hipMemcpyAsync(b->d_seg, b->h_seg, b->n_seg * sizeof(LwSegment), hipMemcpyHostToDevice, st));
 	if (b->n_items)
@@ -730,6 +748,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.gen_ola = all_generic ? nullptr : b->d_gen + 2 * b->max_packets;
 	B.n_gen_ola = b->n_gen_ola;
 	B.ola = all_generic || getenv("LW_NO_OLA_DESC") ? nullptr : b->d_ola;
+	B.gen_tasks = all_generic || tap || d->any_floor0 || getenv("LW_NO_GEN_TASKS") ? nullptr : b->d_tasks;
 	B.sym = b->symbols ? b->d_sym : nullptr;
 	B.sym_off = b->d_sym_off;
 	b->last_kernels.clear();

@@ -54,6 +54,8 @@ struct lw_decoder {
 	std::string dev_entropy_why;
 	void *d_ent_blob = nullptr;
 	LwEntTables E{};
+	std::vector<uint8_t> h_mode_floor, h_floor_F, h_mode_role; // host copies of the device tables of the same names
+	std::vector<int8_t> h_mode_partner;
 	uint32_t max_posts = 2;
 	std::vector<uint64_t> mode_floor_bytes; // per mode: bytes of floor input over all channels (SURVEY 8(d) accounting)
 	// PreviousWindowRight pool: [slots][2][ch][n1/2] floats
@@ -91,6 +93,7 @@ struct lw_batch {
 	// workgroups that mostly find out they have nothing to do
 	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
 	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
+	LwGenTask *h_tasks = nullptr, *d_tasks = nullptr; // [max_packets * ch] tasks of the short-block transform kernel
 	LwOlaDesc *h_ola = nullptr, *d_ola = nullptr; // [max_packets] descriptors of k_ola_generic's tasks (order of the third list)
 	LwSegment *h_seg = nullptr, *d_seg = nullptr; // workgroups of the fused small-block kernel over the overlap-add list
 	uint32_t n_seg = 0;

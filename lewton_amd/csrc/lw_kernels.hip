@@ -293,7 +293,8 @@ __device__ __forceinline__ LwBlockTables global_tables(const LwDevTables &T, con
 
 template <int TPB>
 __device__ __forceinline__ void imdct_block(const LwDevTables &T, const LwBatchDev &B, const LwPacketRec &rec, uint32_t c, uint32_t tid,
-		float *smem, float *out, float *tap_spec, int use_decoupled, int partner, int role, const LwBlockTables tabs)
+		float *smem, float *out, float *tap_spec, int use_decoupled, int partner, int role, const LwBlockTables tabs,
+		int fl_known = -1, int F_known = -1)
 {
 	const uint32_t bs = rec.bs, n = 1u << bs, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
 	float *u = smem, *v = smem + n2;
@@ -301,21 +302,49 @@ __device__ __forceinline__ void imdct_block(const LwDevTables &T, const LwBatchD
 	uint8_t *py = (uint8_t *)(px + LW_XSTRIDE);
 	int *s_Kp = (int *)(py + LW_XSTRIDE + 2); // 4-byte aligned: 2 * n2 floats + 66 * 2 + 68 bytes
 
+	// ---- the residue values this thread will multiply (short blocks, task descriptors: the addresses are known from the one
+	//      load that brought the task) are requested first, together with the floor record: one round trip for everything
+	const float *src = (use_decoupled ? B.decoupled : B.residue) + rec.res_off + c * n2;
+	const float *psrc = partner >= 0 ? B.residue + rec.res_off + (uint32_t)partner * n2 : nullptr;
+	const bool prefetched = TPB == 64 && F_known >= 0 && n2 <= 4u * TPB;
+	float pre_r[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pre_p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	if (TPB == 64 && prefetched) {
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) {
+			const uint32_t k = tid + q * TPB;
+			if (k < n2) {
+				pre_r[q] = src[k];
+				if (psrc)
+					pre_p[q] = psrc[k];
+			}
+		}
+	}
 	// ---- active floor posts, ascending x (audio.rs:536-545 walks exactly these)
 	const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
-	const uint32_t fl = T.mode_floor[rec.mode * T.ch + c];
-	const bool unused = frec[0] == LW_FLOOR_UNUSED;
-	const bool explicit_curve = frec[0] == LW_FLOOR_EXPLICIT; // floor 0: curve evaluated by the host stage
-	// one thread per post (F <= 65): a serial walk by thread 0 is a chain of ~2 F dependent global loads, tens of
-	// microseconds -- it used to be most of this kernel's run time
+	const uint32_t fl = fl_known >= 0 ? (uint32_t)fl_known : T.mode_floor[rec.mode * T.ch + c];
 	uint8_t *act = (uint8_t *)(s_Kp + 1);
-	const uint32_t F = (unused || explicit_curve) ? 0u : T.floor_F[fl];
+	// one thread per post (F <= 65): a serial walk by thread 0 is a chain of ~2 F dependent global loads, tens of
+	// microseconds -- it used to be most of this kernel's run time.  With the post count known from the task descriptor the
+	// posts are requested before the record's first entry has said whether the floor is used at all.
 	uint16_t my_e = 0, my_x = 0;
+	if (F_known >= 0) {
+		const uint32_t sidx = tid; // (TPB = 64; a 65th post is reloaded below like in the other path)
+		if (sidx < (uint32_t)F_known) {
+			my_e = frec[sidx];
+			my_x = T.floor_x[fl * LW_XSTRIDE + sidx];
+		}
+	}
+	const uint16_t e0 = frec[0];
+	const bool unused = e0 == LW_FLOOR_UNUSED;
+	const bool explicit_curve = e0 == LW_FLOOR_EXPLICIT; // floor 0: curve evaluated by the host stage
+	const uint32_t F = (unused || explicit_curve) ? 0u : F_known >= 0 ? (uint32_t)F_known : T.floor_F[fl];
 	for (uint32_t s0 = 0; s0 < F; s0 += TPB) { // one iteration unless TPB = 64 and F = 65
 		const uint32_t sidx = s0 + tid;
 		if (sidx < F) {
-			my_e = frec[sidx];
-			my_x = T.floor_x[fl * LW_XSTRIDE + sidx];
+			if (!(F_known >= 0 && s0 == 0)) {
+				my_e = frec[sidx];
+				my_x = T.floor_x[fl * LW_XSTRIDE + sidx];
+			}
 			act[sidx] = (my_e & LW_POST_ACTIVE) ? 1 : 0;
 		}
 	}
@@ -347,9 +376,8 @@ __device__ __forceinline__ void imdct_block(const LwDevTables &T, const LwBatchD
 	// residue of this channel after inverse coupling: from k_decouple's buffer, or -- `partner` >= 0: this channel takes part
 	// in exactly one coupling step of the mode with that channel (role 1 = magnitude, 2 = angle) -- computed here from the two
 	// raw vectors (audio.rs:762-777), or the raw vector itself
-	const float *src = (use_decoupled ? B.decoupled : B.residue) + rec.res_off + c * n2;
-	const float *psrc = partner >= 0 ? B.residue + rec.res_off + (uint32_t)partner * n2 : nullptr;
-	for (uint32_t k = tid; k < n2; k += TPB) {
+#pragma unroll 4
+	for (uint32_t k = tid, q = 0; k < n2; k += TPB, q++) {
 		float f;
 		if (unused) {
 			f = 0.0f;
@@ -376,9 +404,10 @@ __device__ __forceinline__ void imdct_block(const LwDevTables &T, const LwBatchD
 			}
 			f = tabs.inv_db[y];
 		}
-		float r = src[k];
+		float r = TPB == 64 && prefetched ? pre_r[q & 3u] : src[k];
 		if (psrc) {
-			const float m = role == 1 ? r : psrc[k], a = role == 1 ? psrc[k] : r;
+			const float pr = TPB == 64 && prefetched ? pre_p[q & 3u] : psrc[k];
+			const float m = role == 1 ? r : pr, a = role == 1 ? pr : r;
 			float nm, na;
 			if (m > 0.0f) {
 				if (a > 0.0f) {
@@ -548,6 +577,18 @@ k_imdct_generic(LwDevTables T, LwBatchDev B, float *tap_spec, int use_decoupled,
 	// the residues through HBM less)
 	extern __shared__ __attribute__((aligned(16))) float smem_all[];
 	const uint32_t task = TPB == LW_BLOCK ? blockIdx.x : blockIdx.x * (LW_BLOCK / TPB) + threadIdx.x / TPB;
+	if (TPB != LW_BLOCK && B.gen_tasks) { // short blocks with host-packed tasks: one load, then floor record and residues at once
+		if (task >= B.n_gen_small * T.ch)
+			return;
+		const LwGenTask t = B.gen_tasks[task];
+		if ((t.rec.flags & skip_mask) || t.rec.bs > LW_SMALL_BS)
+			return;
+		const bool inl2 = use_decoupled == 2;
+		imdct_block<TPB>(T, B, t.rec, t.c, threadIdx.x % TPB, smem_all + (threadIdx.x / TPB) * task_floats,
+				B.td + 2u * t.rec.res_off + t.c * (1u << t.rec.bs), tap_spec, use_decoupled == 1, inl2 ? (int)t.partner : -1,
+				inl2 ? (int)t.role : 0, global_tables(T, t.rec), (int)t.fl, (int)t.F);
+		return;
+	}
 	const uint32_t *list = TPB == LW_BLOCK ? B.gen_large : B.gen_small;
 	const uint32_t n_list = TPB == LW_BLOCK ? B.n_gen_large : B.n_gen_small;
 	if (task >= (list ? n_list : B.n_packets) * T.ch)

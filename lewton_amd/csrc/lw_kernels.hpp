@@ -101,6 +101,7 @@ struct LwBatchDev {
 	const uint32_t *gen_ola; // packets of k_ola_generic: the two lists above plus the LW_RF_TDONLY packets
 	uint32_t n_gen_ola;
 	const LwOlaDesc *ola;    // one descriptor per entry of gen_ola (null: k_ola_generic reads the records)
+	const LwGenTask *gen_tasks; // [n_gen_small * ch] tasks of k_imdct_generic<64> (null: it reads lists and records)
 	const LwSegment *seg;    // workgroups of k_small_fused over gen_ola (null: the three-kernel generic path)
 	uint32_t n_seg;
 };

@@ -69,6 +69,19 @@ struct LwOlaDesc {
 	uint16_t pad;
 };
 
+// One task of the short-block transform kernel (a packet's channel), packed by the host's planning pass: the packet record
+// and what the kernel used to look up behind it (floor number and post count of the channel, its coupling partner), so that
+// one load replaces the chain list index -> record -> mode tables -> floor tables.  40 bytes.
+struct LwGenTask {
+	LwPacketRec rec;
+	uint8_t c;        // channel
+	uint8_t fl;       // its floor (mode_floor)
+	uint8_t F;        // posts of that floor (floor_F)
+	uint8_t role;     // 1 magnitude / 2 angle of the one coupling step the channel is in (pair_coupling streams), 0 none
+	int8_t partner;   // the other channel of that step, or -1
+	uint8_t pad[3];
+};
+
 struct LwSegment {
 	uint32_t first;
 	uint16_t count;

@@ -501,6 +501,10 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			mode_role[m * ch + an] = 2;
 		}
 	}
+	d->h_mode_floor = mode_floor; // host copies: the planner packs them into the short-block kernel's task descriptors
+	d->h_floor_F = fF;
+	d->h_mode_partner = mode_partner;
+	d->h_mode_role = mode_role;
 	const size_t off_fx = put(fx.data(), fx.size() * 2);
 	const size_t off_fF = put(fF.data(), fF.size());
 	const size_t off_mf = put(mode_floor.data(), mode_floor.size());

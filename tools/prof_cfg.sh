@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/cfg/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python $GRAFT_REPO_ROOT/tools/bench_configs.py --steps 80 > $OUT/out.txt 2> $OUT/rocprof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python $GRAFT_REPO_ROOT/tools/bench_configs.py --only 3 --steps 80 > $OUT/out.txt 2> $OUT/rocprof.log
 python3 - <<PY
 import csv
 for r in csv.DictReader(open("$OUT/stats_kernel_stats.csv")):
