@@ -53,6 +53,8 @@ int main(int argc, char **argv)
 		printf("E %d\n", err);
 		return 0;
 	}
+	if (getenv("LW_OSH_DEVICE_ENTROPY")) // look-ahead batches in device-entropy mode: the host side copies packets, plans, rolls back
+		lw_ogg_stream_set_entropy_on_device(s, 1);
 	std::vector<int16_t> out(cap_for(s));
 	auto drain = [&]() {
 		for (;;) {
