@@ -86,19 +86,19 @@ def test_lane_model_floor_matches_oracle():
 
 
 def test_floor_division_by_reciprocal_is_exact():
-    """trunc((t*dy +- 0.5) * fl(1/adx)) == trunc(t*dy/adx) for every segment the long-block kernel can meet:
-    0 <= t < adx <= 32768 (t < 1024 rendered), |dy| <= 255; checked exhaustively on a 1-ulp-perturbed reciprocal
-    as well (the device uses v_rcp_f32, 1 ulp)."""
-    t = np.arange(0, 1024, dtype=np.int64)
-    for adx in list(range(1, 1100)) + [2048, 4096, 8191, 32768]:
-        tt = t[t < adx] if adx < 1024 else t
-        for rinv in (np.float32(1.0) / np.float32(adx), np.nextafter(np.float32(1.0) / np.float32(adx), np.float32(2)),
-                     np.nextafter(np.float32(1.0) / np.float32(adx), np.float32(0))):
-            for dy in (-255, -254, -129, -3, -1, 0, 1, 2, 77, 128, 255):
-                z = (tt * dy).astype(np.float32) + np.float32(0.5 if dy >= 0 else -0.5)
-                q = np.trunc(z * rinv).astype(np.int64)
-                want = np.sign(dy) * ((tt * abs(dy)) // adx)
-                assert np.array_equal(q, want), (adx, dy)
+    """trunc((t*dy +- 0.5) * fl(1/adx)) == trunc(t*dy/adx) for EVERY segment the long-block kernel can meet: every
+    dy in -255..255, every adx in 1..1024 (and some larger ones) with every offset 0 <= t < min(adx, 1024) inside it --
+    exhaustively, and on a reciprocal perturbed by one ulp either way as well (the device uses v_rcp_f32, 1 ulp)."""
+    dy = np.arange(-255, 256, dtype=np.int64)[:, None]
+    half = np.where(dy >= 0, np.float32(0.5), np.float32(-0.5)).astype(np.float32)
+    for adx in list(range(1, 1025)) + [1100, 2048, 4096, 8191, 32768]:
+        t = np.arange(0, min(adx, 1024), dtype=np.int64)[None, :]
+        z = (t * dy).astype(np.float32) + half                      # exact: |t * dy| < 2^18
+        want = np.sign(dy) * ((t * np.abs(dy)) // adx)
+        r0 = np.float32(1.0) / np.float32(adx)
+        for rinv in (r0, np.nextafter(r0, np.float32(2)), np.nextafter(r0, np.float32(0))):
+            q = np.trunc(z * rinv).astype(np.int64)
+            assert np.array_equal(q, want), (adx, rinv)
 
 
 def test_packed_op_model_bit_exact():
