@@ -386,15 +386,17 @@ template <bool PAIR = false>
 __device__ __forceinline__ void issue_residue_loads(const LwFastArgs &F, const ItemRegs &it, const LwFastUnit &un,
 		uint32_t lane, Pref &p)
 {
+	// non-temporal loads: the residues are read once -- streaming them past the caches instead of allocating 33 MB per launch
+	// in L2 / MALL took the launch from 16.7 to 15.6 us (interleaved A/B, 2000 steps each)
 	const float4_t *s0 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
 #pragma unroll
 	for (int x = 0; x < 4; x++)
-		p.r[0][x] = s0[64 * x + lane];
+		p.r[0][x] = __builtin_nontemporal_load(&s0[64 * x + lane]);
 	if (PAIR || un.ch_b >= 0) {
 		const float4_t *s1 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_b * 1024u);
 #pragma unroll
 		for (int x = 0; x < 4; x++)
-			p.r[1][x] = s1[64 * x + lane];
+			p.r[1][x] = __builtin_nontemporal_load(&s1[64 * x + lane]);
 	}
 }
 
