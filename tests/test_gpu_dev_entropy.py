@@ -33,7 +33,7 @@ def _damage(pk, rng):
 
 
 @pytest.mark.parametrize("name,pattern", [("stereo", "L"), ("stereo", "LLSSSSLLSL"), ("stereo_t1", "LSL"), ("mono_small", "LSSLL"),
-                                          ("stereo_9_12", "LLS"), ("stereo_7_7", "LSL"), ("surround51", "LLSL")])
+                                          ("stereo_9_12", "LLS"), ("stereo_7_7", "LSL"), ("surround51", "LLSL"), ("stereo_6_13", "LSL")])
 def test_ring_with_device_entropy_matches_oracle(name, pattern):
     from lewton_amd.ring import Ring
     setup = SETUPS[name]()
