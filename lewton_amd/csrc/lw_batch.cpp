@@ -583,10 +583,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
 		if (const char *e = getenv("LW_FAST_ROUNDS")) { // test hook: force the number of rounds per workgroup
 			rounds = (uint32_t)std::min(LW_FAST_MAX_ROUNDS, std::max(1, atoi(e)));
-		} else if (rounds == 1) {
-			// fewer packets than one full round per CU (the long blocks of a mixed short/long batch, a small batch): fewer
-			// packets per workgroup, so that every CU gets some (1 117 long packets in chunks of 16 kept 186 of 256 CUs idle)
-			per_round = (uint32_t)std::min<size_t>(per_round, std::max<size_t>(1, (nf + d->n_cus - 1) / std::max(1, d->n_cus)));
+		} else {
+			// spread the packets evenly over the CUs: with fewer packets than one full round per CU (the long blocks of a mixed
+			// short/long batch, a small batch: 1 117 long packets in chunks of 16 kept 186 of 256 CUs idle) or a packets-per-round
+			// count that does not divide the batch (5.1 with three units per packet: 5 packets x 4 rounds = 20 per workgroup put
+			// 4096 packets on 205 of 256 CUs) a workgroup takes fewer packets per round instead
+			const size_t cus = (size_t)std::max(1, d->n_cus);
+			per_round = (uint32_t)std::min<size_t>(per_round, std::max<size_t>(1, (nf + cus * rounds - 1) / (cus * rounds)));
 		}
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;

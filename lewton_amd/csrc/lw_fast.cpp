@@ -1,6 +1,7 @@
 // Host side of the specialised long-block kernel: see lw_fast.hpp.  Product code.
 #include "lw_fast.hpp"
 
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -77,17 +78,38 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 		}
 		return floor_slot[fl];
 	};
+	// Units: a coupling step's two channels share a wave (the inverse coupling needs both); the channels that are in no step
+	// are paired up two by two as well, without coupling -- a wave works through two channels as one software pipeline, a
+	// single channel leaves half of it empty (5.1: two coupled pairs + one uncoupled pair = 3 waves per packet instead of 4).
 	std::vector<bool> done(ch, false);
-	for (size_t c = 0; c < ch; c++) {
-		if (done[c])
-			continue;
+	int pending_single = -1; // an uncoupled channel waiting for a partner
+	for (size_t c = 0; c <= ch; c++) {
 		LwFastUnit u{};
-		if (partner[c] >= 0) {
+		if (c == ch) { // the odd one out stays a single-channel unit
+			if (pending_single < 0)
+				break;
+			u.ch_a = (int8_t)pending_single;
+			u.ch_b = -1;
+			u.coupled = 0;
+			pending_single = -1;
+		} else if (done[c]) {
+			continue;
+		} else if (partner[c] >= 0) {
 			const int m = role[c] == 1 ? (int)c : partner[c], a = role[c] == 1 ? partner[c] : (int)c;
 			u.ch_a = (int8_t)m;
 			u.ch_b = (int8_t)a;
 			u.coupled = 1;
 			done[m] = done[a] = true;
+		} else if (pending_single < 0 && !getenv("LW_NO_UNCOUPLED_PAIRS")) {
+			pending_single = (int)c;
+			done[c] = true;
+			continue;
+		} else if (pending_single >= 0) {
+			u.ch_a = (int8_t)pending_single;
+			u.ch_b = (int8_t)c;
+			u.coupled = 0;
+			pending_single = -1;
+			done[c] = true;
 		} else {
 			u.ch_a = (int8_t)c;
 			u.ch_b = -1;
