@@ -128,23 +128,9 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 		uint16_t *floor_out, float *residue_out, size_t residue_cap_floats, uint8_t *blocksize_log2, uint8_t *mode,
 		uint8_t *flags, uint64_t *bits_consumed, float *floor_curve_out);
 
-/* The same stage producing codeword symbols instead of residue vectors (the record format of
- * lw_batch_set_residue_on_device; no GPU needed): one 64-bit symbol per decoded codeword,
- *   bits 0-23 start coordinate in the submap's vector space ([sub_ch][n/2], or the interleaved type-2 vector of
- *   audio.rs:745-754), bits 24-31 codebook, bits 32-55 codebook entry, bits 56-59 submap, bits 60-62 cascade pass,
- * sorted by pass (decode order inside a pass); pass_off[p] .. pass_off[p+1] are the symbols of pass p.
- * floor_out / floor_curve_out / blocksize_log2 / mode / flags as above.  LW_ERR_CAPACITY if cap_symbols is too small,
- * LW_ERR_UNSUPPORTED if the stream is not eligible (lw_setup_supports_device_vq). */
-int lw_entropy_symbols_host(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len,
-		uint16_t *floor_out, uint64_t *symbols, size_t cap_symbols, size_t *n_symbols, uint32_t pass_off[9],
-		uint8_t *blocksize_log2, uint8_t *mode, uint8_t *flags, float *floor_curve_out);
-int lw_setup_supports_device_vq(const lw_ident *id, const lw_setup *s, const char **why);
 /* Introspection for tests and tools: the dense VQ table of a codebook (header.rs:495-531; entries x dims floats,
- * dst may be NULL to query the sizes; returns LW_ERR_UNSUPPORTED for a book without a lookup table) and the residue
- * layout of a submap of a mode (type, partition size, channels in mapping_mux order). */
+ * dst may be NULL to query the sizes; returns LW_ERR_UNSUPPORTED for a book without a lookup table). */
 int lw_setup_codebook_vq(const lw_setup *s, unsigned book, float *dst, size_t cap_floats, uint32_t *dims, uint32_t *entries);
-int lw_setup_submap_info(const lw_setup *s, unsigned mode, unsigned submap, uint8_t *residue_type, uint32_t *partition_size,
-		uint8_t *channels, size_t cap_channels, size_t *n_channels);
 
 /* ---- batches ------------------------------------------------------------------------------ */
 typedef struct {
@@ -185,14 +171,9 @@ uint64_t lw_batch_algorithmic_bytes(const lw_batch *b);
 int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats);
 /* Force the generic (any block size / window shape) kernels even where a specialised one applies. */
 void lw_batch_set_force_generic(lw_batch *b, int on);
-/* Where the residue inverse VQ runs.  Default (off): the host entropy stage adds the VQ vectors
- * (audio.rs:587-618) and ships f32 residue vectors ([ch][n/2] per packet, 8 KiB for a stereo long block).  On: the host
- * only decodes the codewords and ships one 8-byte symbol per codeword (2.5-5x fewer bytes over PCIe at usual bit rates);
- * the additions and the type-2 de-interleave (:748-754) run in the k_residue_vq kernel, pass by pass in the
- * reference's order, so the residue vectors are bit-identical.  Needs every residue book's dimension to divide its
- * partition size (then no codeword crosses a partition end); otherwise LW_ERR_UNSUPPORTED and the batch stays in host
- * mode -- lw_decoder_supports_device_vq says which (and why not). */
-int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why);
+/* Test hook: rounds per workgroup of the specialised long-block kernel for this batch's next lw_batch_entropy (1..16;
+ * 0 = the planner decides).  Exercises the hand-over of window state across rounds and workgroups on small batches. */
+void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
 /* Entropy stage on the device ("Tier C"; csrc/lw_dev_entropy.h, k_entropy): the bit-serial half of
  * read_audio_packet_generic (audio.rs:921-986: floor-1 decode :215-251 + amplitude unwrap :391-435, residue decode
  * :587-760) runs on the GPU, one lane per packet; lw_batch_entropy then only reads the prologues, copies the packets
@@ -206,7 +187,6 @@ int lw_batch_set_entropy_on_device(lw_batch *b, int on);
  * entropy kernel touches no stream state, so a pipeline may queue it before it orders the synthesis kernels behind the
  * previous batch's (the staging ring does).  lw_batch_synth runs it itself when this was not called.  No-op in host mode. */
 int lw_batch_device_entropy(lw_batch *b, void *hip_stream);
-int lw_batch_set_residue_on_device(lw_batch *b, int on);
 /* names of the kernels the last lw_batch_synth used, comma separated (introspection for tests/bench) */
 const char *lw_batch_last_kernels(const lw_batch *b);
 
@@ -237,7 +217,6 @@ int lw_ring_release(lw_ring *r);
 int lw_ring_drain(lw_ring *r);
 size_t lw_ring_slots(const lw_ring *r);
 size_t lw_ring_in_flight(lw_ring *r); /* slots staged, launched or collected and not yet released */
-int lw_ring_set_residue_on_device(lw_ring *r, int on); /* lw_batch_set_residue_on_device for every slot (ring must be idle) */
 int lw_ring_set_entropy_on_device(lw_ring *r, int on); /* lw_batch_set_entropy_on_device for every slot (ring must be idle) */
 const char *lw_ring_last_kernels(const lw_ring *r);
 /* The host half of a PreviousWindowRight (whether a right part is stored, its length, which of the two device buffers
@@ -361,7 +340,17 @@ int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t c
  * blocks back to back; n_samples[i] / status[i] per packet (a packet that fails to decode has its AudioReadError in
  * status[i] and no samples).  Stops early at the end of the stream and in front of a chain boundary.
  * Returns LW_OK (also with *n_packets == 0 in front of a chain boundary: call lw_ogg_stream_read_dec_packet),
- * LW_OGG_EOF when no packet is left, or an error. */
+ * LW_OGG_EOF when no packet is left, or an error.
+ * THREADING AND READ-AHEAD CONTRACT.  From the first call on the stream runs two library threads (a demultiplexer and an
+ * entropy-staging thread) that keep reading the source through the reader's lw_ogg_io callbacks BETWEEN calls and after
+ * a call has returned, holding up to about 5 x max_packets packets ahead of what the caller has been handed.  Hence:
+ * (1) the io callbacks are invoked on library threads, never concurrently with each other, but concurrently with the
+ * caller's own code -- they must not share unsynchronised state with it; (2) the position of the underlying source
+ * between calls is unspecified (ahead of the last delivered packet); (3) every other entry point of the stream
+ * (read_dec_packet, skip_samples_linear, seek_absgp_pg, into_inner, set_entropy_on_device, close) first stops both
+ * threads and rolls the stream back to exactly what the caller has been handed, so the sequence of packets, errors
+ * and samples is the one the packet-by-packet calls produce; (4) a device failure on the staging thread is reported
+ * by the next call on the caller's thread, with its text republished through lw_last_device_error(). */
 int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out,
 		size_t cap_elems, uint32_t *n_samples, int32_t *status, size_t *n_packets);
 /* Look-ahead batches with the entropy stage on the device (lw_ring_set_entropy_on_device) whenever the current logical

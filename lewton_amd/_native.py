@@ -97,11 +97,7 @@ SYMBOLS = {
     "lw_setup_floor_stride": (C.c_uint32, [C.c_void_p]),
     "lw_entropy_decode_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, u16p, f32p, C.c_size_t, u8p,
                                          u8p, u8p, C.POINTER(C.c_uint64), f32p]),
-    "lw_entropy_symbols_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, u16p, C.POINTER(C.c_uint64), C.c_size_t, szp,
-                                          C.POINTER(C.c_uint32), u8p, u8p, u8p, f32p]),
-    "lw_setup_supports_device_vq": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p)]),
     "lw_setup_codebook_vq": (C.c_int, [C.c_void_p, C.c_uint, f32p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
-    "lw_setup_submap_info": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, u8p, C.POINTER(C.c_uint32), u8p, C.c_size_t, szp]),
     "lw_huffman_check": (C.c_int, [u8p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, szp]),
     "lw_debug_imdct": (C.c_int, [C.c_void_p, C.c_int, f32p, f32p]),
     "lw_debug_fast_image": (C.c_size_t, [C.c_void_p, C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -117,9 +113,8 @@ SYMBOLS = {
     "lw_batch_algorithmic_bytes": (C.c_uint64, [C.c_void_p]),
     "lw_batch_tap": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, f32p, C.c_size_t]),
     "lw_batch_set_force_generic": (None, [C.c_void_p, C.c_int]),
+    "lw_debug_batch_set_rounds": (None, [C.c_void_p, C.c_int]),
     "lw_batch_last_kernels": (C.c_char_p, [C.c_void_p]),
-    "lw_decoder_supports_device_vq": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
-    "lw_batch_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_decoder_supports_device_entropy": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
     "lw_batch_set_entropy_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_batch_device_entropy": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -133,7 +128,6 @@ SYMBOLS = {
     "lw_ring_drain": (C.c_int, [C.c_void_p]),
     "lw_ring_slots": (C.c_size_t, [C.c_void_p]),
     "lw_ring_in_flight": (C.c_size_t, [C.c_void_p]),
-    "lw_ring_set_residue_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_ring_set_entropy_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_ring_last_kernels": (C.c_char_p, [C.c_void_p]),
     "lw_sharder_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_size_t, C.c_size_t, C.c_int, intp]),

@@ -79,6 +79,10 @@ class Batch:
     def set_force_generic(self, on):
         N.lw_batch_set_force_generic(self._h, 1 if on else 0)
 
+    def debug_set_rounds(self, rounds):
+        """test hook (lw_debug_batch_set_rounds): rounds per workgroup of the specialised kernel, 0 = planner's choice"""
+        N.lw_debug_batch_set_rounds(self._h, int(rounds))
+
     def upload(self, stream=None):
         rc = N.lw_batch_upload(self._h, stream)
         if rc:
@@ -104,16 +108,6 @@ class Batch:
         if rc:
             raise RuntimeError("lw_batch_tap: %d %s" % (rc, N.device_error()))
         return out.reshape(ch, -1)
-
-    def set_residue_on_device(self, on=True):
-        """Tier B (lw_batch_set_residue_on_device): ship codeword symbols, run the inverse VQ in k_residue_vq.
-        Returns False (and stays in host mode) when the stream is not eligible."""
-        rc = N.lw_batch_set_residue_on_device(self._h, 1 if on else 0)
-        if rc == N.ERR_UNSUPPORTED:
-            return False
-        if rc:
-            raise RuntimeError("lw_batch_set_residue_on_device: %d %s" % (rc, N.device_error()))
-        return True
 
     def set_entropy_on_device(self, on=True):
         """Entropy stage on the device (lw_batch_set_entropy_on_device, k_entropy).  Returns False when the stream is not

@@ -49,7 +49,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	};
 	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
 	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
-	const size_t o_seg = slice(max_packets * sizeof(LwSegment)), o_ola = slice(max_packets * sizeof(LwOlaDesc));
+	const size_t o_ola = slice(max_packets * sizeof(LwOlaDesc));
 	const size_t o_tasks = slice(max_packets * ch * sizeof(LwGenTask));
 	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
 	b->slab_bytes = off;
@@ -63,7 +63,6 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		b->h_items = (LwFastItem *)H(o_items), b->d_items = (LwFastItem *)D(o_items);
 		b->h_halo_items = (LwFastItem *)H(o_halo), b->d_halo_items = (LwFastItem *)D(o_halo);
 		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
-		b->h_seg = (LwSegment *)H(o_seg), b->d_seg = (LwSegment *)D(o_seg);
 		b->h_ola = (LwOlaDesc *)H(o_ola), b->d_ola = (LwOlaDesc *)D(o_ola);
 		b->h_tasks = (LwGenTask *)H(o_tasks), b->d_tasks = (LwGenTask *)D(o_tasks);
 		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
@@ -89,10 +88,6 @@ void lw_batch_destroy(lw_batch *b)
 	(void)hipDeviceSynchronize();
 	if (b->h_slab)
 		(void)hipHostFree(b->h_slab);
-	if (b->h_sym)
-		(void)hipHostFree(b->h_sym);
-	if (b->h_sym_off)
-		(void)hipHostFree(b->h_sym_off);
 	if (b->h_pk)
 		(void)hipHostFree(b->h_pk);
 	if (b->h_pool)
@@ -101,7 +96,7 @@ void lw_batch_destroy(lw_batch *b)
 	for (void *p : ent)
 		if (p)
 			(void)hipFree(p);
-	void *dev[] = {b->d_slab, b->d_sym, b->d_sym_off, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
+	void *dev[] = {b->d_slab, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -112,6 +107,12 @@ void lw_batch_set_force_generic(lw_batch *b, int on)
 {
 	if (b)
 		b->force_generic = on != 0;
+}
+
+void lw_debug_batch_set_rounds(lw_batch *b, int rounds)
+{
+	if (b)
+		b->forced_rounds = rounds > 0 ? rounds : 0;
 }
 
 /* Entropy stage on the device (lw_dev_entropy.h, k_entropy): lw_batch_entropy then only reads the packet prologues, copies
@@ -133,30 +134,7 @@ int lw_batch_set_entropy_on_device(lw_batch *b, int on)
 		HIP_TRY(hipHostMalloc((void **)&b->h_pk, b->max_packets * sizeof(LwEntPacket)));
 		HIP_TRY(hipMalloc((void **)&b->d_pk, b->max_packets * sizeof(LwEntPacket)));
 	}
-	b->symbols = false;
 	b->dev_entropy = true;
-	return LW_OK;
-}
-
-int lw_batch_set_residue_on_device(lw_batch *b, int on)
-{
-	if (!b)
-		return LW_ERR_NULL_ARG;
-	if (!on) {
-		b->symbols = false;
-		return LW_OK;
-	}
-	if (!b->dec->symbols_ok)
-		return LW_ERR_UNSUPPORTED;
-	if (int rc = lw_decoder_set_device(b->dec))
-		return rc;
-	if (!b->h_sym_off) {
-		if (!lw_hip_ok(hipHostMalloc((void **)&b->h_sym_off, b->max_packets * sizeof(uint32_t)), "hipHostMalloc(symbol offsets)") ||
-				!lw_hip_ok(hipMalloc((void **)&b->d_sym_off, b->max_packets * sizeof(uint32_t)), "hipMalloc(symbol offsets)"))
-			return LW_ERR_DEVICE;
-	}
-	b->symbols = true;
-	b->dev_entropy = false;
 	return LW_OK;
 }
 
@@ -196,6 +174,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	const lw::Setup &s = *d->setup;
 	const size_t ch = d->T.ch, fstride = d->T.fstride;
 	b->n = n;
+	// The device entropy stage grows its pinned / device packet pool in here, and this function is entered from threads the
+	// library did not create on the decoder's GPU (the Ogg reader's staging thread, any caller of lw_ring_stage): a fresh
+	// thread's current HIP device is 0, so the pool of a decoder on GPU N would land on GPU 0 (and the hipDeviceSynchronize
+	// before it is freed would wait for the wrong device).
+	if (b->dev_entropy)
+		if (int rc = lw_decoder_set_device(d))
+			return rc;
 
 	// pass 1 (sequential, cheap): prologues -> block sizes -> residue offsets
 	size_t res_off = 0;
@@ -272,24 +257,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	alignas(128) std::atomic<size_t> next{0}; // (its own cache line: every worker adds to it once per LW_ENTROPY_CHUNK packets)
 	alignas(128) char next_pad[8] = {0};
 	(void)next_pad;
-	// Tier B: a worker reserves room for a packet's symbol block in the pinned pool with one atomic add once the packet
-	// is decoded (block sizes are not known before).  Blocks that no longer fit are parked in the worker's own arena and
-	// gathered after the pool has been enlarged (first batches only).
-	struct SymRef {
-		int32_t arena = -1; // -1: already in the pool at h_sym_off[i]
-		uint32_t off = 0, words = 0;
-	};
-	std::vector<SymRef> sym_ref(b->symbols ? n : 0);
-	std::vector<std::vector<uint32_t>> arenas(b->symbols ? std::max(1u, nt) : 0);
-	std::atomic<unsigned> next_arena{0};
-	std::atomic<size_t> pool_used{0};
-	std::atomic<bool> overflow{false};
 	auto worker = [&]() {
 		// scratch vectors keep their capacity from batch to batch (pool threads are persistent)
 		static thread_local lw::EntropyScratch scr;
-		static thread_local lw::SymbolSink sink;
-		static thread_local std::vector<uint64_t> tmp;
-		const unsigned my = b->symbols ? next_arena.fetch_add(1) : 0;
 		for (;;) {
 			const size_t i0 = next.fetch_add(LW_ENTROPY_CHUNK);
 			if (i0 >= n)
@@ -298,72 +268,14 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				if (b->status[i] != LW_OK)
 					continue;
 				LwPacketRec &r = b->h_recs[i];
-				if (b->symbols)
-					sink.clear();
 				b->status[i] = lw::entropy_decode(id, s, pkts[i].data, pkts[i].len, b->prologues[i],
 						b->h_floor + r.floor_off, (unsigned)fstride, b->h_res + r.res_off, scr, nullptr,
-						b->h_fcurve ? b->h_fcurve + r.res_off : nullptr, b->symbols ? &sink : nullptr);
-				if (b->symbols && b->status[i] == LW_OK) {
-					sink.sort_by_pass(tmp);
-					SymRef &ref = sym_ref[i];
-					ref.words = 10 + 2 * (uint32_t)sink.ops.size();
-					const size_t at = pool_used.fetch_add(ref.words);
-					uint32_t *w;
-					if (at + ref.words <= b->sym_cap_words) {
-						b->h_sym_off[i] = (uint32_t)at;
-						w = b->h_sym + at;
-					} else {
-						overflow = true;
-						std::vector<uint32_t> &a = arenas[my];
-						ref.arena = (int32_t)my;
-						ref.off = (uint32_t)a.size();
-						a.resize(a.size() + ref.words);
-						w = a.data() + ref.off;
-					}
-					for (int q = 0; q < 9; q++)
-						w[q] = sink.pass_off[q];
-					w[9] = 0;
-					if (!sink.ops.empty())
-						std::memcpy(w + 10, sink.ops.data(), sink.ops.size() * 8);
-				}
+						b->h_fcurve ? b->h_fcurve + r.res_off : nullptr);
 			}
 		}
 	};
 	if (!b->dev_entropy)
 		lw::entropy_pool().run(nt, worker);
-	if (b->symbols) {
-		const size_t total = pool_used.load();
-		if (overflow) {
-			// enlarge the pool, keep what is already in it, append the parked blocks
-			uint32_t *nh = nullptr, *nd = nullptr;
-			const size_t cap = total + total / 2 + 1024;
-			if (!lw_hip_ok(hipHostMalloc((void **)&nh, cap * 4), "hipHostMalloc(symbols)") ||
-					!lw_hip_ok(hipMalloc((void **)&nd, cap * 4), "hipMalloc(symbols)"))
-				return LW_ERR_DEVICE;
-			size_t at = 0;
-			for (size_t i = 0; i < n; i++) {
-				const SymRef &ref = sym_ref[i];
-				if (!ref.words)
-					continue;
-				const uint32_t *src = ref.arena < 0 ? b->h_sym + b->h_sym_off[i] : arenas[ref.arena].data() + ref.off;
-				std::memcpy(nh + at, src, (size_t)ref.words * 4);
-				b->h_sym_off[i] = (uint32_t)at;
-				at += ref.words;
-			}
-			if (b->h_sym)
-				(void)hipHostFree(b->h_sym);
-			if (b->d_sym) {
-				(void)hipDeviceSynchronize();
-				(void)hipFree(b->d_sym);
-			}
-			b->h_sym = nh;
-			b->d_sym = nd;
-			b->sym_cap_words = cap;
-			b->sym_words = at;
-		} else {
-			b->sym_words = total;
-		}
-	}
 
 	// pass 3 (sequential): window geometry, state hand-over, output offsets, error semantics
 	if (b->slot_last.size() < d->state_cap) {
@@ -520,43 +432,6 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		}
 	}
 
-	// ---- workgroups of the fused small-block kernel: runs of consecutive entries of the overlap-add list that are consecutive
-	// packets of one stream, cut at 16 / ch members (one wave per member and channel).  Used when the batch has small generic
-	// blocks, every coupling step is a disjoint pair and a packet's channels fit one workgroup -- and only on request
-	// (LW_SMALL_FUSED=1): measured slower than the three generic kernels so far (lw_kernels.hip); otherwise those run as
-	// before (b->n_seg == 0).
-	b->n_seg = 0;
-	if (b->n_gen_small && d->T.pair_coupling && ch <= 8 && !b->force_generic && getenv("LW_SMALL_FUSED")) {
-		const uint32_t *e = b->h_gen + 2 * b->max_packets;
-		const uint32_t ppw = lw_small_fused_members((uint32_t)ch);
-		auto small_generic = [&](const LwPacketRec &r) { return !(r.flags & LW_RF_FAST) && r.bs <= LW_SMALL_BS; };
-		uint32_t start = 0;
-		auto close = [&](uint32_t end) {
-			if (end == start)
-				return;
-			LwSegment &sg = b->h_seg[b->n_seg++];
-			sg.first = start;
-			sg.count = (uint16_t)(end - start);
-			const int32_t p = b->h_recs[e[start]].prev;
-			sg.halo = (p >= 0 && small_generic(b->h_recs[p])) ? 1 : 0;
-			start = end;
-		};
-		// (a segment whose first member's predecessor is a small block of another segment recomputes that block on the
-		// waves of one member slot: such a segment holds ppw - 1 members, and at least one)
-		auto cap_of = [&](uint32_t first) {
-			const int32_t p = b->h_recs[e[first]].prev;
-			const bool halo = p >= 0 && small_generic(b->h_recs[p]);
-			return halo ? std::max(1u, ppw - 1) : ppw;
-		};
-		uint32_t cap = b->n_gen_ola ? cap_of(0) : ppw;
-		for (uint32_t i = 1; i < b->n_gen_ola; i++)
-			if (b->h_recs[e[i]].prev != (int32_t)e[i - 1] || i - start == cap) {
-				close(i);
-				cap = cap_of(i);
-			}
-		close(b->n_gen_ola);
-	}
-
 	// ---- work plan of the specialised kernel: items sorted by stream so that consecutive packets of a
 	// stream sit in consecutive items; a workgroup works through a chunk of rounds * per_round consecutive
 	// items and hands right halves over in LDS; a predecessor outside the chunk is recomputed by the halo pre-pass
@@ -581,8 +456,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
 		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
 		uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
-		if (const char *e = getenv("LW_FAST_ROUNDS")) { // test hook: force the number of rounds per workgroup
-			rounds = (uint32_t)std::min(LW_FAST_MAX_ROUNDS, std::max(1, atoi(e)));
+		if (b->forced_rounds) { // lw_debug_batch_set_rounds (tests: hand-over paths across rounds and workgroups)
+			rounds = (uint32_t)std::min<int>(LW_FAST_MAX_ROUNDS, b->forced_rounds);
 		} else {
 			// spread the packets evenly over the CUs: with fewer packets than one full round per CU (the long blocks of a mixed
 			// short/long batch, a small batch: 1 117 long packets in chunks of 16 kept 186 of 256 CUs idle) or a packets-per-round
@@ -660,7 +535,7 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 		if (b->pool_words)
 			HIP_TRY(hipMemcpyAsync(b->d_pool, b->h_pool, b->pool_words * 4, hipMemcpyHostToDevice, st));
 	}
-	if (b->slab_bytes <= 64 * 1024 && !b->symbols && !b->dev_entropy) { // small batch: the whole slab in one copy
+	if (b->slab_bytes <= 64 * 1024 && !b->dev_entropy) { // small batch: the whole slab in one copy
 		HIP_TRY(hipMemcpyAsync(b->d_slab, b->h_slab, b->slab_bytes, hipMemcpyHostToDevice, st));
 		return LW_OK;
 	}
@@ -668,13 +543,8 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	if (!b->dev_entropy)
 		HIP_TRY(hipMemcpyAsync(b->d_floor, b->h_floor, b->n * ch * b->dec->T.fstride * sizeof(uint16_t),
 					hipMemcpyHostToDevice, st));
-	if (b->res_floats && !b->symbols && !b->dev_entropy)
+	if (b->res_floats && !b->dev_entropy)
 		HIP_TRY(hipMemcpyAsync(b->d_res, b->h_res, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
-	if (b->symbols) {
-		HIP_TRY(hipMemcpyAsync(b->d_sym_off, b->h_sym_off, b->n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-		if (b->sym_words)
-			HIP_TRY(hipMemcpyAsync(b->d_sym, b->h_sym, b->sym_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-	}
 	if (b->res_floats && b->d_fcurve)
 		HIP_TRY(hipMemcpyAsync(b->d_fcurve, b->h_fcurve, b->res_floats * sizeof(float), hipMemcpyHostToDevice, st));
 	if (b->n_gen_small)
@@ -689,8 +559,6 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 		HIP_TRY(hipMemcpyAsync(b->d_ola, b->h_ola, b->n_gen_ola * sizeof(LwOlaDesc), hipMemcpyHostToDevice, st));
 	if (b->n_gen_small)
 		HIP_TRY(hipMemcpyAsync(b->d_tasks, b->h_tasks, (size_t)b->n_gen_small * ch * sizeof(LwGenTask), hipMemcpyHostToDevice, st));
-	if (b->n_seg)
-		HIP_TRY(hipMemcpyAsync(b->d_seg, b->h_seg, b->n_seg * sizeof(LwSegment), hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
@@ -750,30 +618,16 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	B.n_gen_large = b->n_gen_large;
 	B.gen_ola = all_generic ? nullptr : b->d_gen + 2 * b->max_packets;
 	B.n_gen_ola = b->n_gen_ola;
-	B.ola = all_generic || getenv("LW_NO_OLA_DESC") ? nullptr : b->d_ola;
-	B.gen_tasks = all_generic || tap || d->any_floor0 || getenv("LW_NO_GEN_TASKS") ? nullptr : b->d_tasks;
-	B.sym = b->symbols ? b->d_sym : nullptr;
-	B.sym_off = b->d_sym_off;
+	B.ola = all_generic ? nullptr : b->d_ola;
+	B.gen_tasks = all_generic || tap || d->any_floor0 ? nullptr : b->d_tasks;
 	b->last_kernels.clear();
 	if (b->dev_entropy) {
 		if (int rc = device_entropy(b, st))
 			return rc;
 		b->last_kernels = "k_entropy,";
 	}
-	if (b->symbols) {
-		lw_launch_residue_vq(d->T, d->V, B, st, b->max_n, d->vq_book_ends.data(), d->vq_book_ends.size());
-		b->last_kernels = "k_residue_vq,";
-	}
-	const bool fused_small = run_generic && !all_generic && !tap && b->n_seg > 0;
-	B.seg = fused_small ? b->d_seg : nullptr;
-	B.n_seg = fused_small ? b->n_seg : 0;
-	if (fused_small) {
-		if (b->n_gen_large) { // large generic blocks still go through k_decouple / k_imdct_generic into B.td
-			lw_launch_generic_imdct_large(d->T, B, st, b->max_n, d->any_coupling);
-			b->last_kernels += d->any_coupling && !d->T.pair_coupling ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
-		}
-	} else if (run_generic) {
-		lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic);
+	if (run_generic) {
+		HIP_TRY(lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic));
 		b->last_kernels += d->any_coupling && (!d->T.pair_coupling || tap) ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 	}
 	if (run_fast) {
@@ -790,18 +644,13 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.dense = b->fast_dense;
 		L.late_from = b->fast_late_from;
 		L.has_tdonly = b->has_tdonly ? 1u : 0u;
-		if (const char *e = getenv("LW_PACE_GROUP"))
-			L.late_from = (uint32_t)atoi(e);
 		for (size_t i = 0; i < d->fast.units.size() && i < LW_FAST_WAVES; i++)
 			L.units[i] = d->fast.units[i];
 		L.d_halo = b->d_halo;
-		lw_launch_long(d->T, B, L, d_out, b->fmt, st);
+		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
 	}
-	if (fused_small) {
-		lw_launch_small_fused(d->T, B, d_out, b->fmt, st, b->max_n);
-		b->last_kernels += "k_small_fused,";
-	} else if (run_generic) {
+	if (run_generic) {
 		lw_launch_generic_ola(d->T, B, d_out, b->fmt, st, all_generic);
 		b->last_kernels += "k_ola_generic,";
 	}
@@ -877,7 +726,7 @@ int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats
 	const size_t want = tap == LW_TAP_POST_MDCT ? ch * n : ch * n / 2;
 	if (cap_floats < want)
 		return LW_ERR_CAPACITY;
-	if (tap == LW_TAP_RESIDUE_PRE_INVERSE && !b->symbols && !b->dev_entropy) {
+	if (tap == LW_TAP_RESIDUE_PRE_INVERSE && !b->dev_entropy) {
 		std::memcpy(dst, b->h_res + r.res_off, want * sizeof(float));
 		return LW_OK;
 	}
@@ -890,7 +739,7 @@ int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats
 	HIP_TRY(hipDeviceSynchronize());
 	const float *src;
 	if (tap == LW_TAP_RESIDUE_PRE_INVERSE)
-		src = b->d_res + r.res_off; // Tier B: the vectors k_residue_vq built on the device
+		src = b->d_res + r.res_off; // the vectors k_entropy built on the device
 	else if (tap == LW_TAP_RESIDUE_POST_INVERSE)
 		src = (d->any_coupling ? b->d_decoupled : b->d_res) + r.res_off;
 	else if (tap == LW_TAP_PRE_MDCT)

@@ -226,10 +226,9 @@ template <unsigned DIMS> inline void add_entry(float *v, const float *e)
 		v[j] += e[j];
 }
 
-// audio.rs:587-618.  With a sink the additions are recorded (coordinate `coord` of v[0]) instead of performed.
+// audio.rs:587-618.
 // 1 = partition done, 0 = end of packet, -1 = the reference panics (residue type 0 divides by a zero book dimension)
-inline int read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len,
-		SymbolSink *sink, uint32_t coord, uint32_t book, unsigned pass)
+inline int read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, unsigned psize, float *v, size_t vec_len)
 {
 	const unsigned dims = cb.dims;
 	const Huffman &h = cb.huff;
@@ -249,10 +248,6 @@ inline int read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, un
 		for (unsigned i = 0; i < step; i++) {
 			if (!cr.next(h, idx))
 				return 0;
-			if (sink) {
-				sink->push(coord + i, book, idx, pass);
-				continue;
-			}
 			const float *e = &cb.vq[(size_t)idx * dims];
 			for (unsigned j = 0; j < dims; j++)
 				v[i + j * step] += e[j];
@@ -260,7 +255,7 @@ inline int read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, un
 		return 1;
 	}
 	const float *vq = cb.vq.data();
-	if (!sink && (size_t)psize <= vec_len && psize % dims == 0) { // the whole partition is inside the vector
+	if ((size_t)psize <= vec_len && psize % dims == 0) { // the whole partition is inside the vector
 		switch (dims) {
 #define LW_PART_LOOP(D)                               \
 	case D:                                           \
@@ -285,13 +280,9 @@ inline int read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, un
 			return 0;
 		if ((size_t)i + dims > vec_len)
 			break;
-		if (sink) {
-			sink->push(coord + i, book, idx, pass);
-		} else {
-			const float *e = vq + (size_t)idx * dims;
-			for (unsigned j = 0; j < dims; j++)
-				v[i + j] += e[j];
-		}
+		const float *e = vq + (size_t)idx * dims;
+		for (unsigned j = 0; j < dims; j++)
+			v[i + j] += e[j];
 		i += dims;
 	}
 	return 1;
@@ -299,7 +290,7 @@ inline int read_partition(CodeReader &cr, const Codebook &cb, unsigned rtype, un
 
 // audio.rs:620-717; `vectors` = ch * (cur_blocksize/2) zeros.  false = Err(()) (packet undecodable)
 bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_blocksize, const bool *dnd, size_t ch,
-		float *vectors, EntropyScratch &scr, SymbolSink *sink)
+		float *vectors, EntropyScratch &scr)
 {
 	const size_t actual = cur_blocksize / 2;
 	const size_t begin = std::min<size_t>(rs.begin, actual), end = std::min<size_t>(rs.end, actual);
@@ -351,7 +342,7 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 						continue;
 					const size_t offs = begin + pc * rs.partition_size;
 					const int pr = read_partition(cr, s.codebooks[rb.val_i[pass]], rs.type, rs.partition_size,
-							vectors + j * actual + offs, actual - offs, sink, (uint32_t)(j * actual + offs), rb.val_i[pass], pass);
+							vectors + j * actual + offs, actual - offs);
 					if (pr < 0)
 						return false;
 					if (pr == 0)
@@ -366,26 +357,24 @@ bool residue_inner(BitReader &r, const Setup &s, const Residue &rs, size_t cur_b
 
 // audio.rs:722-760
 bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, const bool *dnd, size_t ch, float *out,
-		EntropyScratch &scr, SymbolSink *sink)
+		EntropyScratch &scr)
 {
 	const size_t half = n / 2;
 	bool any = false;
 	for (size_t j = 0; j < ch; j++)
 		any |= !dnd[j];
-	if (!sink && (rs.type != 2 || !any)) // (the type-2 path below writes every element of `out`)
+	if (rs.type != 2 || !any) // (the type-2 path below writes every element of `out`)
 		std::memset(out, 0, sizeof(float) * ch * half);
 	if (rs.type != 2)
-		return residue_inner(r, s, rs, n, dnd, ch, out, scr, sink);
+		return residue_inner(r, s, rs, n, dnd, ch, out, scr);
 	if (!any)
 		return true;
 	const size_t bs2 = (size_t)(uint16_t)((uint16_t)n * (uint16_t)ch); // `cur_blocksize * ch as u16` wraps (:745)
 	if (bs2 / 2 < ch * half)
 		return false; // wrapped: the reference panics slicing the short vector; report the packet as bad
 	const bool one_dnd[1] = {false};
-	if (sink)
-		return residue_inner(r, s, rs, bs2, one_dnd, 1, nullptr, scr, sink); // de-interleaved by k_residue_vq
 	scr.interleaved.assign(ch * half, 0.0f);
-	if (!residue_inner(r, s, rs, bs2, one_dnd, 1, scr.interleaved.data(), scr, nullptr))
+	if (!residue_inner(r, s, rs, bs2, one_dnd, 1, scr.interleaved.data(), scr))
 		return false;
 	const float *v = scr.interleaved.data();
 	if (ch == 2) {
@@ -405,8 +394,7 @@ bool residue_decode(BitReader &r, const Setup &s, const Residue &rs, size_t n, c
 } // namespace
 
 int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t len, Prologue &p, uint16_t *floor_out,
-		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed, float *fcurve_out,
-		SymbolSink *sink)
+		unsigned fstride, float *residue_out, EntropyScratch &scr, uint64_t *bits_consumed, float *fcurve_out)
 {
 	BitReader r(pkt, len);
 	int rc = read_prologue(id, s, r, p);
@@ -471,22 +459,16 @@ int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t l
 			}
 		}
 		const Residue &rs = s.residues[map.submap_residue[sm]];
-		if (sink) { // Tier B: record the codewords; coordinates are relative to this submap's vector space
-			sink->submap = (uint32_t)sm;
-			if (sub_ch && !residue_decode(r, s, rs, p.n, dnd, sub_ch, nullptr, scr, sink))
-				return AUDIO_BAD_FORMAT;
-			continue;
-		}
 		// channels of a submap are usually contiguous and in order: decode straight into the output block
 		bool contiguous = sub_ch > 0;
 		for (size_t k = 1; k < sub_ch; k++)
 			contiguous &= chans[k] == chans[0] + k;
 		if (contiguous) {
-			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, residue_out + chans[0] * half, scr, nullptr))
+			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, residue_out + chans[0] * half, scr))
 				return AUDIO_BAD_FORMAT;
 		} else {
 			scr.sub.assign(sub_ch * half + 1, 0.0f);
-			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, scr.sub.data(), scr, nullptr))
+			if (!residue_decode(r, s, rs, p.n, dnd, sub_ch, scr.sub.data(), scr))
 				return AUDIO_BAD_FORMAT;
 			for (size_t k = 0; k < sub_ch; k++)
 				std::memcpy(residue_out + chans[k] * half, scr.sub.data() + k * half, sizeof(float) * half);
@@ -495,69 +477,6 @@ int entropy_decode(const Ident &id, const Setup &s, const uint8_t *pkt, size_t l
 	if (bits_consumed)
 		*bits_consumed = r.pos;
 	return OK;
-}
-
-void SymbolSink::sort_by_pass(std::vector<uint64_t> &tmp)
-{
-	uint32_t cnt[9] = {0};
-	for (uint64_t o : ops)
-		cnt[((o >> 60) & 7u) + 1]++;
-	for (int p = 0; p < 8; p++)
-		cnt[p + 1] += cnt[p];
-	for (int p = 0; p < 9; p++)
-		pass_off[p] = cnt[p];
-	if (in_order)
-		return;
-	tmp.resize(ops.size());
-	uint32_t at[8];
-	for (int p = 0; p < 8; p++)
-		at[p] = cnt[p];
-	for (uint64_t o : ops)
-		tmp[at[(o >> 60) & 7u]++] = o; // stable: decode order is kept inside a pass
-	ops.swap(tmp);
-}
-
-bool symbols_supported(const Ident &id, const Setup &s, const char **why)
-{
-	const char *dummy;
-	if (!why)
-		why = &dummy;
-	*why = "";
-	if (s.codebooks.size() > 256) {
-		*why = "more than 256 codebooks";
-		return false;
-	}
-	for (const Mapping &mp : s.mappings)
-		if (mp.submap_floor.size() > 16) {
-			*why = "more than 16 submaps";
-			return false;
-		}
-	if ((size_t)id.channels * ((size_t)1 << id.bs1) / 2 * sizeof(float) > 64 * 1024) {
-		*why = "channels x blocksize_1 / 2 floats exceed the 64 KB accumulation buffer";
-		return false;
-	}
-	for (const Residue &rs : s.residues)
-		for (const ResidueBook &rb : rs.books)
-			for (unsigned pass = 0; pass < 8; pass++)
-				if (rb.vals_used & (1u << pass)) {
-					const Codebook &cb = s.codebooks[rb.val_i[pass]];
-					if (!cb.has_vq || cb.dims == 0 || rs.partition_size % cb.dims != 0) {
-						*why = "a residue book's dimension does not divide the partition size (or it has no VQ table)";
-						return false;
-					}
-					if (cb.dims != 1 && cb.dims != 2 && cb.dims != 4 && cb.dims != 8) {
-						*why = "a residue book's dimension is not 1, 2, 4 or 8";
-						return false;
-					}
-					// the device adds with LDS float atomics, which need not honour subnormals: with every table value 0 or
-					// >= 2^-100 in magnitude no operand and no partial sum of <= 8 passes can be subnormal
-					for (float v : cb.vq)
-						if (v != 0.0f && std::fabs(v) < 7.8886090522101181e-31f) {
-							*why = "a residue book has values below 2^-100";
-							return false;
-						}
-				}
-	return true;
 }
 
 } // namespace lw

@@ -1,7 +1,6 @@
 // Host side of the specialised long-block kernel: see lw_fast.hpp.  Product code.
 #include "lw_fast.hpp"
 
-#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -100,7 +99,7 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 			u.ch_b = (int8_t)a;
 			u.coupled = 1;
 			done[m] = done[a] = true;
-		} else if (pending_single < 0 && !getenv("LW_NO_UNCOUPLED_PAIRS")) {
+		} else if (pending_single < 0) {
 			pending_single = (int)c;
 			done[c] = true;
 			continue;

@@ -44,11 +44,6 @@ struct lw_decoder {
 	void *d_blob = nullptr; // one allocation holding every table
 	bool any_coupling = false;
 	bool any_floor0 = false; // some floor is of type 0: batches carry explicit floor curves
-	bool symbols_ok = false; // Tier B (device-side inverse VQ) is possible for this stream
-	std::string symbols_why;
-	LwVqTables V{};
-	void *d_vq_blob = nullptr;
-	std::vector<uint32_t> vq_book_ends; // cumulative float offsets of the book tables in V.vq (ascending table size)
 	// entropy stage on the device (lw_dev_entropy.h): the flattened setup image in HBM, or why the stream is not eligible
 	bool dev_entropy_ok = false;
 	std::string dev_entropy_why;
@@ -95,13 +90,7 @@ struct lw_batch {
 	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
 	LwGenTask *h_tasks = nullptr, *d_tasks = nullptr; // [max_packets * ch] tasks of the short-block transform kernel
 	LwOlaDesc *h_ola = nullptr, *d_ola = nullptr; // [max_packets] descriptors of k_ola_generic's tasks (order of the third list)
-	LwSegment *h_seg = nullptr, *d_seg = nullptr; // workgroups of the fused small-block kernel over the overlap-add list
-	uint32_t n_seg = 0;
 	bool has_tdonly = false; // the specialised kernel's work list contains LW_RF_TDONLY packets
-	// Tier B: codeword symbols instead of residue vectors (inverse VQ in k_residue_vq)
-	bool symbols = false;
-	uint32_t *h_sym = nullptr, *d_sym = nullptr, *h_sym_off = nullptr, *d_sym_off = nullptr;
-	size_t sym_cap_words = 0, sym_words = 0;
 	// entropy stage on the device: the packets themselves go up (word-aligned, zero padded) with one descriptor each
 	bool dev_entropy = false;
 	LwEntPacket *h_pk = nullptr, *d_pk = nullptr; // [max_packets]
@@ -120,7 +109,7 @@ struct lw_batch {
 	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
 	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = 1;
-	// (debug: LW_PACE_GROUP=<waves per pacing group> overrides)
+	int forced_rounds = 0; // lw_debug_batch_set_rounds: rounds per workgroup of the specialised kernel (0 = the planner decides)
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
 	bool has_generic = false, has_fast = false, force_generic = false;

@@ -19,156 +19,7 @@
 #define LW_BLOCK 256
 // workgroup size of k_decouple / k_ola_generic (64-thread workgroups measured slower: 20.7 / 14.2 us vs 11.9 / 11.6 us on the
 // mixed short/long configuration)
-#ifndef LW_ELEMENTWISE_BLOCK
 #define LW_ELEMENTWISE_BLOCK 256
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// Tier B: residue vectors from codeword symbols (audio.rs:587-618 additions, :748-754 de-interleave)
-// ---------------------------------------------------------------------------------------------
-// One WAVE per packet (like the long-block kernel), up to 16 packets per workgroup.  A packet's vectors are accumulated
-// in the wave's own LDS slice IN THE COORDINATES THE BITSTREAM USES (per submap: [sub_ch][n/2], or the interleaved
-// type-2 vector), so the elements of a codeword are consecutive words and need no address arithmetic; the mapping to
-// [channel][bin] (for type 2 the de-interleave of audio.rs:748-754) happens once, in the coalesced write-out.
-// A position receives at most one vector element per cascade pass (partitions are disjoint and, for eligible streams,
-// no codeword crosses a partition end), so inside a pass the lanes work on different symbols without conflicts, and the
-// passes follow each other in program order -- LDS operations of one wave execute in order, no barrier is needed --
-// so every bin sees exactly the reference's sequence 0.0 + e(pass 0) + e(pass 1) + ...
-// Bound: latency and instruction issue, not bandwidth.  Lane = symbol (coalesced 8-byte symbol loads, a whole chunk of
-// 1024 symbols in flight at once); rows of window u+1 are in flight while window u is added; the tables of the small books are copied to LDS (8..32-byte gathers out of 128-byte L2 lines
-// otherwise); all reads of a window go before its writes (element-by-element `acc[i] += v` serialises on possible
-// aliasing, LDS float atomics run at about a lane per clock: 48 / 61 us per 4096-packet batch).
-// A window may straddle pass boundaries: its lanes are then added pass by pass (symbols are sorted by pass).
-#define LW_VQ_DIMS 8 // codebook dimensions the device path accepts: 1, 2, 4, 8 (lw::symbols_supported)
-#define LW_VQ_WIN 16 // windows of 64 symbols per chunk (a stereo long block at 128 kbit/s has well under 1024 symbols)
-struct LwVqRow {
-	float2 v[LW_VQ_DIMS / 2];
-};
-
-// rows of the first `staged` floats of the pool come from the LDS copy, the others from L2
-__device__ __forceinline__ void vq_gather(const float *vq, const float *s_vq, uint32_t staged, const uint32_t *s_boff,
-		const uint16_t *s_bdims, bool valid, unsigned long long op, LwVqRow &row, uint32_t &dims)
-{
-	dims = 0;
-	if (!valid)
-		return;
-	const uint32_t book = ((uint32_t)op >> 24) & 0xffu, entry = (uint32_t)(op >> 32) & 0xffffffu;
-	dims = s_bdims[book];
-	const uint32_t at = s_boff[book] + entry * dims;
-	const bool in_lds = at + dims <= staged;
-	if (dims == 1) {
-		row.v[0].x = in_lds ? s_vq[at] : vq[at];
-		return;
-	}
-	// two explicit address spaces (ds_read / global_load under exec masks), not one generic pointer: flat loads wait on
-	// both memory counters and take the slow path to LDS
-	if (in_lds) {
-#pragma unroll
-		for (int q = 0; q < LW_VQ_DIMS / 2; q++)
-			if (2u * (uint32_t)q < dims)
-				row.v[q] = *reinterpret_cast<const float2 *>(s_vq + at + 2 * q);
-	} else {
-#pragma unroll
-		for (int q = 0; q < LW_VQ_DIMS / 2; q++)
-			if (2u * (uint32_t)q < dims)
-				row.v[q] = *reinterpret_cast<const float2 *>(vq + at + 2 * q);
-	}
-}
-
-__global__ void __launch_bounds__(1024) k_residue_vq(LwDevTables T, LwVqTables V, LwBatchDev B, uint32_t slice_floats,
-		uint32_t staged)
-{
-	extern __shared__ __attribute__((aligned(16))) float acc_all[];
-	__shared__ uint32_t s_boff[256];
-	__shared__ uint16_t s_bdims[256];
-	__shared__ LwSubmapDesc s_desc_all[16][16]; // [wave][submap] of the wave's packet mode
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
-	if (tid < 256) {
-		s_boff[tid] = V.book_off[tid];
-		s_bdims[tid] = V.book_dims[tid];
-	}
-	float *s_vq = acc_all + (size_t)waves * slice_floats; // LDS copy of the small VQ tables, behind the accumulation slices
-	for (uint32_t i = tid; i < staged / 4u; i += blockDim.x)
-		reinterpret_cast<float4 *>(s_vq)[i] = reinterpret_cast<const float4 *>(V.vq)[i];
-	const uint32_t pkt = blockIdx.x * waves + wave;
-	const bool have = pkt < B.n_packets;
-	LwPacketRec rec{};
-	if (have)
-		rec = B.recs[pkt];
-	const bool work = have && !(rec.flags & LW_RF_SKIP);
-	if (work && lane < 16)
-		s_desc_all[wave][lane] = V.submap[(uint32_t)rec.mode * 16u + lane];
-	__syncthreads();
-	if (!work)
-		return;
-	const LwSubmapDesc *s_desc = s_desc_all[wave];
-	float *acc = acc_all + (size_t)wave * slice_floats;
-	const uint32_t hshift = rec.bs - 1u, half = 1u << hshift, total = T.ch * half;
-	for (uint32_t i = lane; i < total; i += 64)
-		acc[i] = 0.0f;
-	const uint32_t *blk = B.sym + B.sym_off[pkt];
-	const unsigned long long *ops = reinterpret_cast<const unsigned long long *>(blk + 10);
-	const uint32_t n_ops = blk[8];
-	// A chunk = LW_VQ_WIN windows of 64 symbols: all its symbol loads are issued back to back (one HBM round trip per
-	// chunk -- s_waitcnt vmcnt counts in order, so a rolling prefetch of symbols would be waited for anyway whenever a
-	// younger row gather is), then the windows are processed from registers, the rows of window u+1 in flight while
-	// window u is added.
-	for (uint32_t base = 0; base < n_ops; base += 64u * LW_VQ_WIN) {
-		unsigned long long opq[LW_VQ_WIN];
-#pragma unroll
-		for (int u = 0; u < LW_VQ_WIN; u++) {
-			const uint32_t i = base + 64u * (uint32_t)u + lane;
-			opq[u] = i < n_ops ? ops[i] : 0ull;
-		}
-		LwVqRow row0, row1;
-		uint32_t dims0 = 0, dims1 = 0;
-		vq_gather(V.vq, s_vq, staged, s_boff, s_bdims, base + lane < n_ops, opq[0], row0, dims0);
-#pragma unroll
-		for (int u = 0; u < LW_VQ_WIN; u++) {
-			const uint32_t w0 = base + 64u * (uint32_t)u; // first symbol of this window
-			if (w0 >= n_ops)
-				break;
-			const unsigned long long op0 = opq[u];
-			if (u + 1 < LW_VQ_WIN)
-				vq_gather(V.vq, s_vq, staged, s_boff, s_bdims, w0 + 64u + lane < n_ops, opq[u + 1 < LW_VQ_WIN ? u + 1 : u], row1, dims1);
-			// ---- add this window, pass by pass
-			const uint32_t my_pass = (uint32_t)(op0 >> 60) & 7u;
-			const uint32_t last_lane = min(63u, n_ops - 1u - w0);
-			const uint32_t pmin = __builtin_amdgcn_readfirstlane(my_pass), pmax = __builtin_amdgcn_readlane(my_pass, last_lane);
-			const LwSubmapDesc d = s_desc[(uint32_t)(op0 >> 56) & 0xfu];
-			const uint32_t at = ((uint32_t)d.vbase_ch << hshift) + ((uint32_t)op0 & 0xffffffu);
-			uint32_t step = 1u;
-			if (__builtin_amdgcn_ballot_w64(d.type == 0 && dims0 != 0) != 0) // residue type 0 (strided vectors) is rare: keep
-				step = d.type == 0 && dims0 ? d.psize / dims0 : 1u;          // the division off the usual path
-			const float rv[LW_VQ_DIMS] = {row0.v[0].x, row0.v[0].y, row0.v[1].x, row0.v[1].y, row0.v[2].x, row0.v[2].y,
-				row0.v[3].x, row0.v[3].y};
-			for (uint32_t p = pmin; p <= pmax; p++) {
-				const bool mine = dims0 && my_pass == p;
-				float cur[LW_VQ_DIMS];
-#pragma unroll
-				for (int j = 0; j < LW_VQ_DIMS; j++)
-					cur[j] = mine && (uint32_t)j < dims0 ? acc[at + (uint32_t)j * step] : 0.0f;
-#pragma unroll
-				for (int j = 0; j < LW_VQ_DIMS; j++)
-					if (mine && (uint32_t)j < dims0)
-						acc[at + (uint32_t)j * step] = cur[j] + rv[j];
-			}
-			row0 = row1;
-			dims0 = dims1;
-		}
-	}
-	// ---- write-out: [channel][bin] <- accumulation coordinates
-	float *out = const_cast<float *>(B.residue) + rec.res_off;
-	const LwChanMap *chmap = V.chmap + (size_t)rec.mode * T.ch;
-	for (uint32_t c = 0; c < T.ch; c++) {
-		const LwChanMap m = chmap[c]; // uniform
-		const uint32_t vb = (uint32_t)m.vbase_ch << hshift;
-		for (uint32_t k = lane; k < half; k += 64) {
-			const uint32_t src = m.type == 2 ? vb + k * m.sub_ch + m.pos : vb + ((uint32_t)m.pos << hshift) + k;
-			out[c * half + k] = acc[src];
-		}
-	}
-}
 
 // ---------------------------------------------------------------------------------------------
 // inverse coupling
@@ -746,211 +597,11 @@ __global__ void __launch_bounds__(LW_BLOCK) k_ola_generic(LwDevTables T, LwBatch
 	}
 }
 
-// ---------------------------------------------------------------------------------------------
-// fused small-block path
-// ---------------------------------------------------------------------------------------------
-// One workgroup = one LwSegment: up to 16 / ch consecutive packets of ONE stream out of the batch's overlap-add list, one
-// wave per (packet, channel).  Phase A: every wave whose packet is a small generic block (<= 2^LW_SMALL_BS points) does
-// inverse coupling (its own side of the one coupling step it is in), floor curve, floor x residue and the IMDCT in its
-// LDS slice and leaves the time-domain block in LDS.  One barrier.  Phase B: window / overlap-add / conversion / state of
-// every member (audio.rs:1056-1154) -- the previous packet's raw right part comes from the neighbouring wave's LDS block,
-// from the block the segment recomputed for that purpose (`halo`: the predecessor is a small block of another segment; its
-// IMDCT costs less than a round trip through HBM and a second launch would), from B.td (predecessor transformed by the
-// specialised kernel or the large generic IMDCT, which ran before) or from the stream's state slot.  Members that are not
-// small blocks (long blocks next to short ones, LW_RF_TDONLY; large generic blocks) take their own block from B.td.
-// An alternative to k_decouple + k_imdct_generic<64> + k_ola_generic (three launches, two round trips of every block
-// through HBM) for the mixed short/long streams of BASELINE configs[2]; bit-identical to them (tests).  MEASURED SLOWER on
-// MI355X as it stands (35 us against 30 us for the three kernels on 2 979 short + 745 adjacent long packets; without
-// either phase the workgroups' skeleton alone -- descriptor, records, table staging, five barriers -- takes 8.6 us, phase
-// A 16 us, phase B 12 us: every part is a chain of dependent L2 / HBM round trips, as in the kernels it replaces), so the
-// runtime only takes this path when LW_SMALL_FUSED=1 is set (profiles/r02_small_fused.txt).
-template <int FMT>
-__global__ void __launch_bounds__(1024) k_small_fused(LwDevTables T, LwBatchDev B, void *out_v, uint32_t task_floats, uint32_t td_floats)
-{
-	extern __shared__ __attribute__((aligned(16))) float smem_all[];
-	__shared__ LwPacketRec s_rec[17]; // the members' records, [16] = the halo packet's
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
-	const LwSegment seg = B.seg[blockIdx.x];
-	const uint32_t ch = T.ch, m = wave / ch, c = wave - m * ch;
-	float *work = smem_all + (size_t)wave * task_floats;                       // IMDCT scratch of this wave
-	float *td_all = smem_all + (size_t)n_waves * task_floats;                  // [wave][td_floats] time-domain blocks
-	float *halo_all = td_all + (size_t)n_waves * td_floats;                    // [ch][td_floats] recomputed predecessor
-	float *tab = halo_all + (size_t)ch * td_floats;                            // table copies (below)
-	// ---- tables of the small block sizes and the inverse-dB table: L2 -> LDS once per workgroup.  Every stage of the
-	// transform reads its twiddles; from L2 that is one ~0.5 us round trip per stage and block, ~10 us per 256-point block.
-	float *s_inv_db = tab;
-	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
-		s_inv_db[i] = T.inv_db[i];
-	// (two named structs selected by value, not an array indexed at run time: that would live in scratch memory)
-	float *p0 = tab + 256;
-	const uint32_t n0 = T.bs[0].n, n1 = T.bs[1].n;
-	const bool small0 = T.bs[0].bs <= LW_SMALL_BS, small1 = T.bs[1].bs <= LW_SMALL_BS;
-	float *p1 = p0 + (small0 ? n0 + n0 / 4 + n0 / 8 : 0u);
-#define LW_STAGE_TABLES(P, N, TB)                                                     \
-	do {                                                                              \
-		for (uint32_t i = threadIdx.x; i < (N) / 2; i += blockDim.x) {                \
-			(P)[i] = (TB).A[i];                                                       \
-			(P)[(N) / 2 + i] = (TB).B[i];                                             \
-		}                                                                             \
-		for (uint32_t i = threadIdx.x; i < (N) / 4; i += blockDim.x)                  \
-			(P)[(N) + i] = (TB).C[i];                                                 \
-		for (uint32_t i = threadIdx.x; i < (N) / 8; i += blockDim.x)                  \
-			(P)[(N) + (N) / 4 + i] = __uint_as_float((TB).bitrev[i]);                 \
-	} while (0)
-	if (small0)
-		LW_STAGE_TABLES(p0, n0, T.bs[0]);
-	if (small1)
-		LW_STAGE_TABLES(p1, n1, T.bs[1]);
-#undef LW_STAGE_TABLES
-	// (only small blocks are transformed here: a larger size gets LDS pointers too, never followed -- with nothing but LDS
-	// pointers in these structs hipcc addresses the tables with ds_read instead of flat loads)
-	const LwBlockTables lt0{p0, p0 + n0 / 2, p0 + n0, s_inv_db, reinterpret_cast<const uint32_t *>(p0 + n0 + n0 / 4)};
-	const LwBlockTables lt1{p1, p1 + n1 / 2, p1 + n1, s_inv_db, reinterpret_cast<const uint32_t *>(p1 + n1 + n1 / 4)};
-	if (threadIdx.x < seg.count)
-		s_rec[threadIdx.x] = B.recs[B.gen_ola[seg.first + threadIdx.x]];
-	__syncthreads();
-	if (seg.halo && threadIdx.x == 0)
-		s_rec[16] = B.recs[s_rec[0].prev];
-	__syncthreads();
-	// ---- phase A: one wave per (member, channel); the halo block on the waves of the first unused member slot (the host
-	// keeps one free in a segment that needs a halo)
-	const bool member = m < seg.count, halo_wave = seg.halo && m == seg.count;
-	if (member || halo_wave) {
-		const LwPacketRec rec = s_rec[halo_wave ? 16 : m];
-		if (halo_wave || (!(rec.flags & LW_RF_FAST) && rec.bs <= LW_SMALL_BS))
-			imdct_block<64>(T, B, rec, c, lane, work, halo_wave ? halo_all + (size_t)c * td_floats : td_all + (size_t)wave * td_floats,
-					nullptr, 0, T.pair_coupling ? T.mode_partner[rec.mode * ch + c] : -1,
-					T.pair_coupling ? T.mode_role[rec.mode * ch + c] : 0, (rec.flags & LW_RF_LONG) ? lt1 : lt0);
-	}
-	__syncthreads();
-	// ---- phase B: window / overlap-add / conversion / state of every member (audio.rs:1056-1154).  All (member, channel,
-	// sample) triples of the segment form ONE index space that the workgroup's threads stride through: every load of a pass is
-	// independent of every other (a loop over members would pay one HBM / L2 round trip per member and channel: a long block
-	// next to short ones has 1472 samples per channel, a short block 128).
-	__shared__ uint32_t s_out_end[17], s_st_end[17]; // running totals of output samples / state samples per (member, channel)
-	__shared__ const float *s_prev[16 * 8], *s_cur[16 * 8];
-	const uint32_t n_mc = seg.count * ch;
-	if (threadIdx.x < n_mc) {
-		const uint32_t mi = threadIdx.x / ch, cc = threadIdx.x - mi * ch;
-		const LwPacketRec rec = s_rec[mi];
-		const bool small = !(rec.flags & LW_RF_FAST) && rec.bs <= LW_SMALL_BS;
-		const uint32_t n = 1u << rec.bs;
-		s_cur[threadIdx.x] = small ? td_all + (size_t)(mi * ch + cc) * td_floats : B.td + 2u * rec.res_off + cc * n;
-		const float *prev = nullptr;
-		if (rec.prev >= 0) {
-			const LwPacketRec prg = mi > 0 ? s_rec[mi - 1] : (seg.halo ? s_rec[16] : B.recs[rec.prev]);
-			const bool pr_small = !(prg.flags & LW_RF_FAST) && prg.bs <= LW_SMALL_BS;
-			if (pr_small && mi > 0)         // (the host links a small predecessor either into this segment ...
-				prev = td_all + (size_t)((mi - 1) * ch + cc) * td_floats + prg.rs;
-			else if (pr_small)              // ... or marks the segment `halo`)
-				prev = halo_all + (size_t)cc * td_floats + prg.rs;
-			else
-				prev = B.td + 2u * prg.res_off + cc * (1u << prg.bs) + prg.rs;
-		} else if (rec.prev <= -2) {
-			const uint32_t slot = (uint32_t)(-(rec.prev + 2));
-			const uint32_t par = (rec.flags & LW_RF_PARITY_IN) ? 1u : 0u;
-			prev = B.state + ((size_t)slot * 2 + par) * T.state_stride + cc * T.state_chan_stride;
-		}
-		s_prev[threadIdx.x] = prev;
-	}
-	if (threadIdx.x == 0) {
-		uint32_t a = 0, st = 0;
-		for (uint32_t j = 0; j < n_mc; j++) {
-			const LwPacketRec &rec = s_rec[j / ch];
-			a += (rec.prev != -1 && rec.rs > rec.ls) ? (uint32_t)(rec.rs - rec.ls) : 0u;
-			st += (rec.state_out >= 0 && rec.re > rec.rs) ? (uint32_t)(rec.re - rec.rs) : 0u;
-			s_out_end[j] = a;
-			s_st_end[j] = st;
-		}
-	}
-	__syncthreads();
-	const uint32_t total_out = n_mc ? s_out_end[n_mc - 1] : 0, total_st = n_mc ? s_st_end[n_mc - 1] : 0;
-	for (uint32_t idx = threadIdx.x; idx < total_out; idx += blockDim.x) {
-		uint32_t j = 0;
-		while (s_out_end[j] <= idx)
-			j++;
-		const uint32_t i = idx - (j ? s_out_end[j - 1] : 0u), mi = j / ch, cc = j - mi * ch;
-		const LwPacketRec &rec = s_rec[mi];
-		const uint32_t ls = rec.ls, mm = rec.rs - ls, plen = rec.plen;
-		float x = s_cur[j][ls + i];
-		if (i < plen) {
-			const float *slope = T.bs[(rec.flags & LW_RF_SLOPE_BS1) ? 1 : 0].window;
-			x = (x * slope[i]) + (s_prev[j][i] * slope[plen - 1 - i]); // audio.rs:1116-1118
-		}
-		if (FMT == LW_OUT_I16_PLANAR)
-			((int16_t *)out_v)[rec.out_off + cc * mm + i] = to_i16(x);
-		else if (FMT == LW_OUT_I16_INTERLEAVED)
-			((int16_t *)out_v)[rec.out_off + i * ch + cc] = to_i16(x);
-		else
-			((float *)out_v)[rec.out_off + cc * mm + i] = x;
-	}
-	for (uint32_t idx = threadIdx.x; idx < total_st; idx += blockDim.x) { // audio.rs:1121, :1142-1147: the raw right part
-		uint32_t j = 0;
-		while (s_st_end[j] <= idx)
-			j++;
-		const uint32_t i = idx - (j ? s_st_end[j - 1] : 0u), mi = j / ch, cc = j - mi * ch;
-		const LwPacketRec &rec = s_rec[mi];
-		const uint32_t par = (rec.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
-		B.state[((size_t)rec.state_out * 2 + par) * T.state_stride + cc * T.state_chan_stride + i] = s_cur[j][rec.rs + i];
-	}
-}
-
-static uint32_t small_task_floats(uint32_t max_n)
-{
-	const uint32_t small_n = std::min(max_n, 1u << LW_SMALL_BS);
-	return (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 7u) & ~3u;
-}
-
-void lw_launch_small_fused(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, uint32_t max_n)
-{
-	if (!B.seg || B.n_seg == 0)
-		return;
-	const uint32_t ppw = lw_small_fused_members(T.ch), waves = ppw * T.ch;
-	const uint32_t task_floats = small_task_floats(max_n), td_floats = std::min(max_n, 1u << LW_SMALL_BS);
-	size_t tab_floats = 256; // inverse-dB table + A, B, C, bitrev of every block size the kernel transforms
-	for (int q = 0; q < 2; q++)
-		if (T.bs[q].bs <= LW_SMALL_BS)
-			tab_floats += T.bs[q].n + T.bs[q].n / 4 + T.bs[q].n / 8;
-	const size_t lds = ((size_t)waves * (task_floats + td_floats) + (size_t)T.ch * td_floats + tab_floats) * sizeof(float);
-	static LwPerDeviceOnce once;
-	if (once.first_launch_on_device()) {
-		(void)hipFuncSetAttribute((const void *)k_small_fused<LW_OUT_I16_PLANAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_small_fused<LW_OUT_I16_INTERLEAVED>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_small_fused<LW_OUT_F32_PLANAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-	}
-	const dim3 g(B.n_seg), b(64 * waves);
-	if (fmt == LW_OUT_I16_PLANAR)
-		hipLaunchKernelGGL(k_small_fused<LW_OUT_I16_PLANAR>, g, b, lds, st, T, B, out, task_floats, td_floats);
-	else if (fmt == LW_OUT_I16_INTERLEAVED)
-		hipLaunchKernelGGL(k_small_fused<LW_OUT_I16_INTERLEAVED>, g, b, lds, st, T, B, out, task_floats, td_floats);
-	else
-		hipLaunchKernelGGL(k_small_fused<LW_OUT_F32_PLANAR>, g, b, lds, st, T, B, out, task_floats, td_floats);
-}
-
-// the large generic blocks only (their small siblings go through k_small_fused): inverse coupling + IMDCT into B.td
-void lw_launch_generic_imdct_large(const LwDevTables &T, const LwBatchDev &B, hipStream_t st, uint32_t max_n, bool any_coupling)
-{
-	if (!B.gen_large || B.n_gen_large == 0)
-		return;
-	LwBatchDev L = B;
-	L.gen_small = B.gen_large; // k_decouple walks gen_small then gen_large: give it the large list alone
-	L.n_gen_small = 0;
-	const int coupling = !any_coupling ? 0 : T.pair_coupling ? 2 : 1;
-	if (coupling == 1)
-		hipLaunchKernelGGL(k_decouple, dim3(B.n_gen_large), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T, L, (uint32_t)(LW_RF_SKIP | LW_RF_FAST));
-	static LwPerDeviceOnce once;
-	if (once.first_launch_on_device())
-		(void)hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-	const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 4) * sizeof(float);
-	hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(B.n_gen_large * T.ch), dim3(LW_BLOCK), lds, st, T, B, (float *)nullptr,
-			coupling, (uint32_t)(LW_RF_SKIP | LW_RF_FAST), 0u);
-}
-
-void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
+hipError_t lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
 		bool any_coupling, bool include_fast)
 {
 	if (B.n_packets == 0)
-		return;
+		return hipSuccess;
 	const uint32_t skip_mask = include_fast ? LW_RF_SKIP : (LW_RF_SKIP | LW_RF_FAST);
 	// inverse coupling: inside the transform kernel when every channel is in at most one step (and nobody taps the
 	// intermediate vectors), otherwise by k_decouple into B.decoupled first
@@ -960,8 +611,13 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 				B, skip_mask);
 	static LwPerDeviceOnce once;
 	if (once.first_launch_on_device()) {
-		(void)hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_imdct_generic<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		hipError_t e = hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		if (e == hipSuccess)
+			e = hipFuncSetAttribute((const void *)k_imdct_generic<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		if (e != hipSuccess) {
+			once.forget_device(); // try again at the next launch; the caller reports this one
+			return e;
+		}
 	}
 	// large block sizes: one (packet, channel) block per workgroup; small ones: four per workgroup, one per wave
 	const uint32_t n_large = (B.gen_large ? B.n_gen_large : B.n_packets) * T.ch;
@@ -977,29 +633,7 @@ void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *t
 		hipLaunchKernelGGL(k_imdct_generic<64>, dim3((n_small + per_wg - 1) / per_wg), dim3(LW_BLOCK),
 				(size_t)per_wg * task_floats * sizeof(float), st, T, B, tap_spec, coupling, skip_mask, task_floats);
 	}
-}
-
-void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBatchDev &B, hipStream_t st, uint32_t max_n,
-		const uint32_t *book_ends, size_t n_book_ends)
-{
-	if (B.n_packets == 0)
-		return;
-	static LwPerDeviceOnce once;
-	if (once.first_launch_on_device()) {
-		(void)hipFuncSetAttribute((const void *)k_residue_vq, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
-	}
-	const uint32_t budget = 36u * 1024u; // floats of dynamic LDS (144 KB; 8 KB of static tables beside it)
-	const uint32_t slice = ((T.ch * (max_n / 2)) + 3u) & ~3u; // floats per packet (<= 16384, lw::symbols_supported)
-	// at least 4 K floats are kept for VQ tables when the slices allow 8 or more waves anyway
-	uint32_t waves = std::max(1u, std::min(16u, budget / slice));
-	if (waves >= 8 && waves * slice + 4096u > budget)
-		waves = std::max(8u, (budget - 4096u) / slice);
-	uint32_t staged = 0; // whole book tables only, smallest first
-	for (size_t i = 0; i < n_book_ends && waves * slice + book_ends[i] <= budget; i++)
-		staged = book_ends[i];
-	staged &= ~3u;
-	const uint32_t grid = (B.n_packets + waves - 1) / waves;
-	hipLaunchKernelGGL(k_residue_vq, dim3(grid), dim3(64 * waves), (size_t)(waves * slice + staged) * 4, st, T, V, B, slice, staged);
+	return hipSuccess;
 }
 
 void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast)

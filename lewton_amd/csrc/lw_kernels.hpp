@@ -23,6 +23,14 @@ struct LwPerDeviceOnce {
 		done[dev >> 6] |= 1ull << (dev & 63);
 		return first;
 	}
+	void forget_device() // the first launch failed to set its attributes: the next one tries again
+	{
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256)
+			return;
+		std::lock_guard<std::mutex> g(mu);
+		done[dev >> 6] &= ~(1ull << (dev & 63));
+	}
 };
 
 // CachedBlocksizeDerived (header_cached.rs:19-110) in HBM; computed on the host, never on the device.
@@ -53,34 +61,7 @@ struct LwDevTables {
 
 // generic kernels: blocks up to 2^LW_SMALL_BS points are transformed by ONE wave each (four per workgroup), larger ones by
 // a 256-thread workgroup (host: lw_runtime.cpp builds one task list per class)
-#ifndef LW_SMALL_BS
 #define LW_SMALL_BS 9
-#endif
-
-// Tier B: residue inverse VQ on the device
-struct LwSubmapDesc {
-	uint8_t type;      // residue type 0/1/2 of the submap
-	uint8_t sub_ch;    // channels in the submap
-	uint16_t psize;    // partition size
-	uint16_t vbase_ch; // channels in the submaps before this one: the submap's vector space starts at vbase_ch * n/2
-	uint16_t pad;
-};
-
-// where channel c of a mode finds its residue in the accumulation space of k_residue_vq
-struct LwChanMap {
-	uint8_t vbase_ch; // of the channel's submap
-	uint8_t sub_ch;   // channels in that submap
-	uint8_t pos;      // position of the channel inside the submap (mapping_mux order)
-	uint8_t type;     // residue type: 2 = interleaved vector (audio.rs:748-754), else [sub_ch][n/2]
-};
-
-struct LwVqTables {
-	const float *vq;            // dense VQ tables of all codebooks (header.rs:495-531), concatenated
-	const uint32_t *book_off;   // [256] float offset of a book's table in vq
-	const uint16_t *book_dims;  // [256]
-	const LwSubmapDesc *submap; // [n_modes][16]
-	const LwChanMap *chmap;     // [n_modes][ch]
-};
 
 enum LwOutFmt { LW_OUT_I16_PLANAR = 0, LW_OUT_I16_INTERLEAVED = 1, LW_OUT_F32_PLANAR = 2 };
 
@@ -89,8 +70,6 @@ struct LwBatchDev {
 	const uint16_t *floors;
 	const float *residue;
 	const float *fcurve; // explicit floor curves (floor 0), layout of residue; nullptr when the setup has none
-	const uint32_t *sym;     // Tier B: per packet 10 header words (9 pass offsets, pad) + 64-bit ops; nullptr for Tier A
-	const uint32_t *sym_off; // [n_packets] word offset of a packet's block in sym
 	float *decoupled; // scratch [same layout as residue]
 	float *td;        // scratch: per packet [ch][n] time-domain blocks at float offset 2 * res_off
 	float *state;     // state pool [slots][2][ch][n1/2]
@@ -102,37 +81,21 @@ struct LwBatchDev {
 	uint32_t n_gen_ola;
 	const LwOlaDesc *ola;    // one descriptor per entry of gen_ola (null: k_ola_generic reads the records)
 	const LwGenTask *gen_tasks; // [n_gen_small * ch] tasks of k_imdct_generic<64> (null: it reads lists and records)
-	const LwSegment *seg;    // workgroups of k_small_fused over gen_ola (null: the three-kernel generic path)
-	uint32_t n_seg;
 };
 
 // Generic path (any block size 64..8192, any window shape, any channel count / coupling list), two phases so
 // that the specialised kernel can run in between (it reads td blocks of generic predecessors and writes td
 // right halves for generic successors).
-void lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
+// (the launchers that opt a kernel into a large dynamic LDS segment return the result of that call)
+hipError_t lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
 		bool any_coupling, bool include_fast);
-// Tier B pre-pass: residue vectors from codeword symbols (writes B.residue)
 // entropy stage on the device (lw_kernels_entropy.hip): floor records and residue vectors of n packets from their raw bytes
 struct LwEntTables;
 struct LwEntPacket;
 void lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPacketRec *d_recs, const uint32_t *d_pool,
 		uint16_t *d_floor, float *d_res, uint32_t n, hipStream_t st);
-void lw_launch_residue_vq(const LwDevTables &T, const LwVqTables &V, const LwBatchDev &B, hipStream_t st, uint32_t max_n,
-		const uint32_t *book_ends, size_t n_book_ends);
 void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast);
-// Fused path of the small blocks (<= 2^LW_SMALL_BS points): inverse coupling, floor, IMDCT, window / overlap-add, conversion
-// in ONE launch over B.seg; also does window / overlap-add of the other packets of the overlap-add list (their time-domain
-// blocks must be in B.td: specialised kernel / large generic IMDCT run before).  `large_only` variant of the generic IMDCT:
-void lw_launch_generic_imdct_large(const LwDevTables &T, const LwBatchDev &B, hipStream_t st, uint32_t max_n, bool any_coupling);
-// members (packets) per workgroup of k_small_fused: 8 waves per workgroup where the channel count allows, at least 2 members
-// (a segment that recomputes its predecessor block keeps one member slot free for it); channels <= 8
-static inline uint32_t lw_small_fused_members(uint32_t ch)
-{
-	const uint32_t m = 8u / (ch ? ch : 1u);
-	return m < 2u ? 2u : m;
-}
-void lw_launch_small_fused(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, uint32_t max_n);
 
 // Specialised long-block path (lw_kernels_long.hip): optional halo pre-pass + main pass.
 struct LwFastLaunch;
-void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
+hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);

@@ -34,27 +34,13 @@
 
 #define LW_WG (64 * LW_FAST_WAVES)
 // wave priorities (s_setprio 0..3) of the three kinds of phases; measured on MI355X (tools/exp.sh)
-#ifndef LW_PRIO_FLOOR
 #define LW_PRIO_FLOOR 2
-#endif
-#ifndef LW_PRIO_IMDCT
 #define LW_PRIO_IMDCT 0
-#endif
-#ifndef LW_PRIO_FINISH
 #define LW_PRIO_FINISH 3
-#endif
-#ifndef LW_FLOOR_FIRST_FROM
 #define LW_FLOOR_FIRST_FROM 7 // first wave of a workgroup that builds its floor curve before it requests its residues (>= 4)
-#endif
-#ifndef LW_IMDCT_PRIO_LATE
 #define LW_IMDCT_PRIO_LATE 12
-#endif
-#ifndef LW_PRIO_PACE
 #define LW_PRIO_PACE 0 // while a wave waits for its turn in the load queue and requests its residues
-#endif
-#ifndef LW_PRIO_READY
 #define LW_PRIO_READY 3 // inverse coupling + floor multiply of a wave whose floor curve was built ahead
-#endif
 #define LW_SCR_BYTES 4096u // per wave: transposes of one channel at a time / 2 x 1 KB floor segment tables
 #define LW_PUB_BYTES 4096u // per wave: published right half [2 channels][2][64] float4
 #define LW_LDS_BYTES (LWI_TOTAL + LW_FAST_WAVES * (LW_SCR_BYTES + LW_PUB_BYTES) + 3 * LW_FAST_WAVES * 4)
@@ -1295,11 +1281,9 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	const uint32_t item0 = blockIdx.x * per_round * rounds + slot;      // item of round j = item0 + j * per_round
 	const bool two = un.ch_b >= 0;
 	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
-#ifndef LW_PRE_WAVES
 #define LW_PRE_WAVES 2 // waves that queue their HBM loads before the barrier (waves 0-3 can: the others stage the image);
                        // measured: 1 -> 17.33, 2 -> 17.0-17.16, 4 -> 17.73 us; releasing the next wave of the chain before
                        // (18.0) or half-way through (17.17) the own loads is slower than after them
-#endif
 	const bool late = !RIGHT_ONLY && wave >= (F.late_from > LW_PRE_WAVES ? F.late_from : (uint32_t)LW_PRE_WAVES);
 
 	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
@@ -1348,9 +1332,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	// queue advances by one wave per ~0.6 us; the floor stage is ~1.8 us of LDS round trips with the VALU mostly idle):
 	// when its residues land, only inverse coupling, one multiply per bin and the IMDCT are left.  The first waves of the
 	// queue request their residues first (the queue must not wait for them) and build the curve afterwards.
-#ifndef LW_PACE_VMCNT
 #define LW_PACE_VMCNT 63
-#endif
 	// Order the HBM queue: wave w issues its loads when wave w - late_from has issued its own (LW_PACE_VMCNT = 63) or
 	// has all but LW_PACE_VMCNT of them back.  Requests of one CU are served in issue order, so the data arrives
 	// wave by wave instead of all at the end of the burst: the first waves compute while the later waves' data is
@@ -1559,7 +1541,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
-void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st)
+hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st)
 {
 	LwFastArgs F{};
 	F.image = L.d_image;
@@ -1588,8 +1570,13 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 			(const void *)k_long<LW_OUT_I16_PLANAR, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, true>,
 			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, true>, (const void *)k_long<LW_OUT_I16_ITL_STEREO, false, true>,
 			(const void *)k_long<LW_OUT_F32_PLANAR, false, true>};
-		for (const void *f : fns)
-			(void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		for (const void *f : fns) {
+			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			if (e != hipSuccess) {
+				once.forget_device(); // try again at the next launch; the caller reports this one
+				return e;
+			}
+		}
 	}
 	if (L.n_halo_items) {
 		F.items = L.d_halo_items;
@@ -1625,4 +1612,5 @@ void lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunc
 			LW_LAUNCH_MAIN(LW_OUT_F32_PLANAR);
 #undef LW_LAUNCH_MAIN
 	}
+	return hipSuccess;
 }

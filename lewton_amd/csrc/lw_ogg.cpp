@@ -16,6 +16,8 @@
 #include <unordered_map>
 #include <vector>
 
+void lw_set_device_error(const std::string &msg); // lw_runtime.cpp: thread-local text behind lw_last_device_error()
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -433,6 +435,11 @@ struct lw_ogg_stream {
 	std::deque<Collected> collected; // guarded by pmu
 	Collected *in_stage = nullptr;   // the batch the staging thread is working on (its packets have left `collected`)
 	std::vector<QueuedPacket> stage_failed;
+	// what the failed batch carried besides its packets: the reason why no batch follows it (a one-shot container error must
+	// not be lost when the packets are staged again), and the staging thread's HIP error text (lw_last_device_error is
+	// thread-local: the caller's thread re-publishes it when it reports the failure)
+	int stage_failed_term = TERM_NONE, stage_failed_term_rc = LW_OK;
+	std::string stage_err_text;
 	std::thread demuxer;
 	std::deque<PipeSlot> staged;  // FIFO image of the ring's busy slots (guarded by pmu)
 	int terminal = TERM_NONE, terminal_rc = LW_OK; // why the producer stopped reading (guarded by pmu)
@@ -758,6 +765,10 @@ struct lw_ogg_stream {
 				if (rc != LW_OK) { // (cannot happen for a well-formed call: the packets go back, the error is reported)
 					lw_pwr_set_state(pwr, &ps.saved);
 					stage_failed = std::move(ps.ahead);
+					stage_failed_term = c.term; // the batch's own end marker travels with its packets (rollback)
+					stage_failed_term_rc = c.term_rc;
+					if (const char *t = lw_last_device_error())
+						stage_err_text = t;
 					ps.ahead.clear();
 					term = TERM_ERROR;
 					term_rc = rc;
@@ -796,7 +807,10 @@ struct lw_ogg_stream {
 			ring_fmt = fmt;
 		}
 		// entropy stage on the device when asked for and the current logical stream is eligible (else the host stage)
-		(void)lw_ring_set_entropy_on_device(ring, want_dev_entropy ? 1 : 0);
+		// (LW_ERR_UNSUPPORTED = not eligible: expected, the host stage stays; anything else is a device failure)
+		if (const int rc = lw_ring_set_entropy_on_device(ring, want_dev_entropy ? 1 : 0))
+			if (rc != LW_ERR_UNSUPPORTED)
+				return rc;
 		pipe_fmt = fmt;
 		pipe_k = k;
 		pipe_threads = n_threads;
@@ -841,6 +855,13 @@ struct lw_ogg_stream {
 		give_back(stage_failed);
 		stage_failed.clear();
 		bool error_queued = false;
+		if (stage_failed_term == TERM_ERROR) { // the container error that ended the batch whose staging failed: behind its packets
+			Requeued r;
+			r.rc = stage_failed_term_rc;
+			back.push_back(std::move(r));
+			error_queued = true;
+		}
+		stage_failed_term = TERM_NONE;
 		for (Collected &c : collected) {
 			give_back(c.ahead);
 			if (c.term == TERM_ERROR) {
@@ -1089,6 +1110,10 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 	if (!ps) {
 		const int term = s->terminal, rc = s->terminal_rc;
 		s->terminal = lw_ogg_stream::TERM_NONE; // reported by this call
+		if (!s->stage_err_text.empty()) { // a failure on the staging thread: its HIP error text, on the thread that reports it
+			lw_set_device_error(s->stage_err_text);
+			s->stage_err_text.clear();
+		}
 		s->rollback(); // both threads have stopped or stop now; nothing is staged; what the demultiplexer still holds goes back
 		if (term == lw_ogg_stream::TERM_ERROR)
 			return rc;
@@ -1116,6 +1141,7 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 			if (s->staged.size() >= 2 && !s->staged[1].launched)
 				next = &s->staged[1];
 		}
+		// (a failure here is not lost: the slot stays un-launched and the next call launches it again and reports the error)
 		if (next && lw_ring_launch(s->ring) == LW_OK)
 			next->launched = true;
 	}

@@ -52,16 +52,10 @@ struct EntropyPool::Impl {
 	std::condition_variable cv;
 	std::vector<std::thread> threads; // under mu
 	unsigned demand = 0;              // helpers wanted by the open regions together (under mu)
-	// how long a helper without work spins before it sleeps (LW_POOL_SPIN_US overrides).  Longer spins were measured on the
-	// GPU box (2 x EPYC 9575F shared with other jobs, load average 20+): 3 ms instead of 100 us made every configuration
-	// slower -- the spinning helpers take the cores the box's other work needs, and then their own.
-	long spin_us = 100;
-
-	Impl()
-	{
-		if (const char *e = getenv("LW_POOL_SPIN_US"))
-			spin_us = std::max(0L, atol(e));
-	}
+	// how long a helper without work spins before it sleeps.  Longer spins were measured on the GPU box (2 x EPYC 9575F shared
+	// with other jobs, load average 20+): 3 ms instead of 100 us made every configuration slower -- the spinning helpers
+	// take the cores the box's other work needs, and then their own.
+	static constexpr long spin_us = 100;
 
 	// joins every open region that still wants helpers; true if this thread did any work
 	bool serve()

@@ -53,8 +53,6 @@ static_assert(sizeof(LwPacketRec) == 32, "LwPacketRec must stay 32 bytes");
 #define LW_RF_PARITY_OUT 64u
 #define LW_RF_PARITY_IN 128u
 
-// One workgroup of the fused small-block kernel (k_small_fused): `count` consecutive entries of the batch's overlap-add list,
-// starting at `first`, that are consecutive packets of ONE stream (entry i+1's predecessor is entry i).
 // One task of the generic overlap-add kernel, packed by the host's planning pass: everything the workgroup needs in ONE load
 // (the list index -> packet record -> predecessor's record chain cost the kernel three dependent round trips before its
 // first sample).  32 bytes.
@@ -82,8 +80,3 @@ struct LwGenTask {
 	uint8_t pad[3];
 };
 
-struct LwSegment {
-	uint32_t first;
-	uint16_t count;
-	uint16_t halo; // 1: the first member's predecessor is a small generic block of ANOTHER segment: its IMDCT is recomputed here
-};

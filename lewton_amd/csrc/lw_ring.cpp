@@ -128,20 +128,6 @@ void lw_ring_destroy(lw_ring *r)
 	delete r;
 }
 
-int lw_ring_set_residue_on_device(lw_ring *r, int on)
-{
-	if (!r)
-		return LW_ERR_NULL_ARG;
-	std::lock_guard<std::mutex> g(r->mu);
-	for (Slot &s : r->slots)
-		if (s.state != SLOT_FREE)
-			return LW_ERR_CAPACITY; // only between batches
-	for (Slot &s : r->slots)
-		if (int rc = lw_batch_set_residue_on_device(s.batch, on))
-			return rc;
-	return LW_OK;
-}
-
 int lw_ring_set_entropy_on_device(lw_ring *r, int on)
 {
 	if (!r)

@@ -255,53 +255,6 @@ int lw_entropy_decode_host(const lw_ident *id, const lw_setup *s, const uint8_t 
 	return rc;
 }
 
-int lw_setup_supports_device_vq(const lw_ident *id, const lw_setup *s, const char **why)
-{
-	static thread_local std::string msg;
-	const char *w = "";
-	const bool ok = id && s && lw::symbols_supported(*id->p, *s->p, &w);
-	msg = w;
-	if (why)
-		*why = msg.c_str();
-	return ok ? 1 : 0;
-}
-
-int lw_entropy_symbols_host(const lw_ident *id, const lw_setup *s, const uint8_t *packet, size_t len, uint16_t *floor_out,
-		uint64_t *symbols, size_t cap_symbols, size_t *n_symbols, uint32_t pass_off[9], uint8_t *blocksize_log2,
-		uint8_t *mode, uint8_t *flags, float *floor_curve_out)
-{
-	if (!id || !s || (!packet && len) || !floor_out || !symbols || !n_symbols || !pass_off)
-		return LW_ERR_NULL_ARG;
-	if (!setup_matches_ident(*id->p, *s->p))
-		return LW_ERR_STATE_MISMATCH;
-	if (!lw::symbols_supported(*id->p, *s->p, nullptr))
-		return LW_ERR_UNSUPPORTED;
-	lw::Prologue p;
-	lw::EntropyScratch scr;
-	lw::SymbolSink sink;
-	std::vector<uint64_t> tmp;
-	sink.clear();
-	const int rc = lw::entropy_decode(*id->p, *s->p, packet, len, p, floor_out, floor_stride_of(*s->p), nullptr, scr, nullptr,
-			floor_curve_out, &sink);
-	if (blocksize_log2)
-		*blocksize_log2 = p.bs;
-	if (mode)
-		*mode = p.mode;
-	if (flags)
-		*flags = (uint8_t)((p.blockflag ? 1 : 0) | (p.prev_flag ? 2 : 0) | (p.next_flag ? 4 : 0));
-	if (rc)
-		return rc;
-	sink.sort_by_pass(tmp);
-	*n_symbols = sink.ops.size();
-	for (int q = 0; q < 9; q++)
-		pass_off[q] = sink.pass_off[q];
-	if (sink.ops.size() > cap_symbols)
-		return LW_ERR_CAPACITY;
-	if (!sink.ops.empty())
-		std::memcpy(symbols, sink.ops.data(), sink.ops.size() * 8);
-	return LW_OK;
-}
-
 int lw_setup_codebook_vq(const lw_setup *s, unsigned book, float *dst, size_t cap_floats, uint32_t *dims, uint32_t *entries)
 {
 	if (!s || book >= s->p->codebooks.size())
@@ -319,31 +272,6 @@ int lw_setup_codebook_vq(const lw_setup *s, unsigned book, float *dst, size_t ca
 		std::memcpy(dst, cb.vq.data(), cb.vq.size() * sizeof(float));
 	}
 	return LW_OK;
-}
-
-int lw_setup_submap_info(const lw_setup *s, unsigned mode, unsigned submap, uint8_t *residue_type, uint32_t *partition_size,
-		uint8_t *channels, size_t cap_channels, size_t *n_channels)
-{
-	if (!s || mode >= s->p->modes.size())
-		return LW_ERR_NULL_ARG;
-	const lw::Mapping &mp = s->p->mappings[s->p->modes[mode].mapping];
-	if (submap >= mp.submap_residue.size())
-		return LW_ERR_NULL_ARG;
-	const lw::Residue &rs = s->p->residues[mp.submap_residue[submap]];
-	if (residue_type)
-		*residue_type = rs.type;
-	if (partition_size)
-		*partition_size = rs.partition_size;
-	size_t n = 0;
-	for (size_t c = 0; c < mp.mux.size(); c++)
-		if (mp.mux[c] == submap) {
-			if (channels && n < cap_channels)
-				channels[n] = (uint8_t)c;
-			n++;
-		}
-	if (n_channels)
-		*n_channels = n;
-	return channels && n > cap_channels ? LW_ERR_CAPACITY : LW_OK;
 }
 
 size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint32_t *offsets16)
@@ -546,89 +474,6 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	d->T.n_floors = (uint32_t)nfl;
 	d->T.state_chan_stride = (1u << id.bs1) / 2;
 	d->T.state_stride = d->T.ch * d->T.state_chan_stride;
-	// ---- Tier B tables: dense VQ tables, per-mode submap descriptors
-	{
-		const char *why = "";
-		d->symbols_ok = lw::symbols_supported(id, s, &why);
-		d->symbols_why = why;
-		if (d->symbols_ok) {
-			std::vector<uint8_t> vb;
-			auto putv = [&](const void *p, size_t bytes) {
-				const size_t off = (vb.size() + 255) & ~(size_t)255;
-				vb.resize(off + bytes);
-				std::memcpy(vb.data() + off, p, bytes);
-				return off;
-			};
-			// the tables of the books used by residues, smallest first: k_residue_vq stages a prefix of the pool in LDS (the
-			// gathers of 8..32 bytes out of 128-byte L2 lines are what bounds that kernel otherwise)
-			std::vector<float> pool;
-			std::vector<uint32_t> boff(256, 0);
-			std::vector<uint16_t> bdims(256, 0);
-			std::vector<bool> in_residue(s.codebooks.size(), false);
-			for (const lw::Residue &rs : s.residues)
-				for (const lw::ResidueBook &rb : rs.books)
-					for (unsigned pass = 0; pass < 8; pass++)
-						if (rb.vals_used & (1u << pass))
-							in_residue[rb.val_i[pass]] = true;
-			std::vector<size_t> order;
-			for (size_t k = 0; k < s.codebooks.size(); k++) {
-				bdims[k] = s.codebooks[k].dims;
-				if (s.codebooks[k].has_vq && in_residue[k])
-					order.push_back(k);
-			}
-			std::stable_sort(order.begin(), order.end(),
-					[&](size_t a, size_t b) { return s.codebooks[a].vq.size() < s.codebooks[b].vq.size(); });
-			d->vq_book_ends.clear();
-			for (size_t k : order) {
-				const lw::Codebook &cb = s.codebooks[k];
-				pool.resize((pool.size() + 3) & ~(size_t)3); // rows of 2 / 4 / 8 floats stay 8 / 16 / 32-byte aligned
-				boff[k] = (uint32_t)pool.size();
-				pool.insert(pool.end(), cb.vq.begin(), cb.vq.end());
-				d->vq_book_ends.push_back((uint32_t)pool.size());
-			}
-			if (pool.empty())
-				pool.push_back(0.0f);
-			std::vector<LwSubmapDesc> sd(nmodes * 16);
-			std::vector<LwChanMap> cm(nmodes * ch);
-			for (size_t m = 0; m < nmodes; m++) {
-				const lw::Mapping &mp = s.mappings[s.modes[m].mapping];
-				unsigned before = 0;
-				for (size_t sm = 0; sm < mp.submap_residue.size(); sm++) {
-					const lw::Residue &rs = s.residues[mp.submap_residue[sm]];
-					LwSubmapDesc &e = sd[m * 16 + sm];
-					e.type = rs.type;
-					e.psize = (uint16_t)rs.partition_size;
-					e.vbase_ch = (uint16_t)before;
-					e.pad = 0;
-					uint8_t n = 0;
-					for (size_t c = 0; c < ch; c++)
-						if (mp.mux[c] == sm)
-							n++;
-					e.sub_ch = n;
-					uint8_t pos = 0;
-					for (size_t c = 0; c < ch; c++)
-						if (mp.mux[c] == sm)
-							cm[m * ch + c] = LwChanMap{(uint8_t)before, n, pos++, rs.type};
-					before += n;
-				}
-			}
-			const size_t o_vq = putv(pool.data(), pool.size() * 4), o_bo = putv(boff.data(), boff.size() * 4);
-			const size_t o_bd = putv(bdims.data(), bdims.size() * 2), o_sd = putv(sd.data(), sd.size() * sizeof(LwSubmapDesc));
-			const size_t o_ch = putv(cm.data(), cm.size() * sizeof(LwChanMap));
-			if (!lw_hip_ok(hipMalloc(&d->d_vq_blob, vb.size()), "hipMalloc(vq tables)") ||
-					!lw_hip_ok(hipMemcpy(d->d_vq_blob, vb.data(), vb.size(), hipMemcpyHostToDevice), "hipMemcpy(vq tables)")) {
-				*err = LW_ERR_DEVICE;
-				(void)hipFree(d->d_blob);
-				return nullptr;
-			}
-			const uint8_t *vbase = (const uint8_t *)d->d_vq_blob;
-			d->V.vq = (const float *)(vbase + o_vq);
-			d->V.book_off = (const uint32_t *)(vbase + o_bo);
-			d->V.book_dims = (const uint16_t *)(vbase + o_bd);
-			d->V.submap = (const LwSubmapDesc *)(vbase + o_sd);
-			d->V.chmap = (const LwChanMap *)(vbase + o_ch);
-		}
-	}
 	{ // entropy stage on the device: the flattened setup image (eligible streams only; the host stage serves the others)
 		lw::DevEntropyImage img;
 		const char *why = "";
@@ -677,8 +522,6 @@ void lw_decoder_destroy(lw_decoder *d)
 		(void)hipFree(d->d_state);
 	if (d->d_blob)
 		(void)hipFree(d->d_blob);
-	if (d->d_vq_blob)
-		(void)hipFree(d->d_vq_blob);
 	if (d->d_ent_blob)
 		(void)hipFree(d->d_ent_blob);
 	if (d->d_fast_image)
@@ -812,13 +655,6 @@ int lw_decoder_supports_device_entropy(const lw_decoder *d, const char **why)
 	if (why)
 		*why = d ? d->dev_entropy_why.c_str() : "";
 	return d && d->dev_entropy_ok ? 1 : 0;
-}
-
-int lw_decoder_supports_device_vq(const lw_decoder *d, const char **why)
-{
-	if (why)
-		*why = d ? d->symbols_why.c_str() : "";
-	return d && d->symbols_ok ? 1 : 0;
 }
 
 

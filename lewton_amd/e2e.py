@@ -15,7 +15,7 @@ from . import _native as _N
 from .ring import Ring
 
 
-def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots=3, device_vq=False, callers=1, seed=1,
+def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots=3, callers=1, seed=1,
             samples="i16", warm=4, device_entropy=False):
     """Returns a dict: packets/s, H2D / D2H GB/s, host entropy stage alone, kernels used.
     Every caller thread owns a ring and `streams` independent streams, each contributing packets/streams consecutive
@@ -25,8 +25,6 @@ def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots
     rings, work, payload = [], [], 0
     for c in range(callers):
         ring = Ring(dec, slots, packets, samples)
-        if device_vq and not ring.set_residue_on_device(True):
-            raise RuntimeError("stream not eligible for the device inverse VQ")
         if device_entropy and not ring.set_entropy_on_device(True):
             raise RuntimeError("stream not eligible for the device entropy stage")
         pwrs = [audio.PreviousWindowRight() for _ in range(streams)]
@@ -74,15 +72,14 @@ def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots
     dt = time.perf_counter() - t0
     npk = n_batches * packets * callers
     ch, half = dec.ident.audio_channels, (1 << dec.ident.blocksize_1) // 2
-    rec_bytes = ch * half * 4 + 132 + 32 if not device_vq else None   # f32 residues + floor records + packet record
+    rec_bytes = ch * half * 4 + 132 + 32   # f32 residues + floor records + packet record
     if device_entropy:
         rec_bytes = payload / packets + 8 + 16 + 32                     # the packet, its padding and descriptor, the packet record
     esz = 4 if samples == "f32" else 2
     out = {
         "value": npk / dt, "unit": "packets/s", "packets": npk, "seconds": dt,
-        "records": "raw packets, entropy stage on the device (Tier C)" if device_entropy else
-                   "codeword symbols (Tier B)" if device_vq else "f32 residue vectors (Tier A)",
-        "h2d_GBps": (npk * rec_bytes / dt / 1e9) if rec_bytes else None,
+        "records": "raw packets, entropy stage on the device (k_entropy)" if device_entropy else "f32 residue vectors (host entropy stage)",
+        "h2d_GBps": npk * rec_bytes / dt / 1e9,
         "d2h_GBps": npk * ch * half * esz / dt / 1e9,
         "vorbis_payload_MBps": payload / packets * npk / dt / 1e6,
         "host_threads": threads or _N.lw_default_host_threads(), "callers": callers, "ring_slots": slots,

@@ -23,8 +23,6 @@ class Ring:
         self._h = N.lw_ring_create(decoder._h, slots, max_packets, self.fmt, C.byref(err))
         if not self._h:
             raise RuntimeError("lw_ring_create failed (%d): %s" % (err.value, N.device_error()))
-        self._keep = {}
-        self._seq = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -48,14 +46,6 @@ class Ring:
             arr[i].pwr = pwr._bind(self.dec)
         return (arr, bufs, n)
 
-    def set_residue_on_device(self, on=True):
-        rc = N.lw_ring_set_residue_on_device(self._h, 1 if on else 0)
-        if rc == N.ERR_UNSUPPORTED:
-            return False
-        if rc:
-            raise RuntimeError("lw_ring_set_residue_on_device: %d" % rc)
-        return True
-
     def set_entropy_on_device(self, on=True):
         """Entropy stage on the device (lw_ring_set_entropy_on_device): the packets themselves cross PCIe, k_entropy decodes
         floors and residues, one lane per packet.  Returns False (host stage stays) when the stream is not eligible."""
@@ -71,9 +61,9 @@ class Ring:
             raise RuntimeError("%s: %d %s" % (name, rc, N.device_error()))
 
     def stage(self, marshalled, n_threads=0):
+        # lw_ring_stage is synchronous: every packet has been decoded (or copied into pinned staging) when it returns, so
+        # `marshalled` only has to live for the duration of this call -- the local reference does that
         arr, bufs, n = marshalled
-        self._keep[self._seq] = marshalled  # the packet bytes must outlive the host stage
-        self._seq += 1
         self._call("lw_ring_stage", N.lw_ring_stage(self._h, arr, n, n_threads))
 
     def launch(self):

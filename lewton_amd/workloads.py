@@ -1,0 +1,88 @@
+"""The synthetic workloads BASELINE.json's `configs` name, as the bench tools lay them out (one definition shared by
+tools/bench_configs.py, which times them, and tests/test_gpu_quoted_shapes.py, which checks every packet of the same
+shapes against the oracle -- a number is only quoted for a shape that is also verified).
+
+A workload = `n_streams` logical streams, each primed with ONE packet in an earlier launch (so that every timed packet
+yields samples) and contributing `per_stream` consecutive packets to one dense launch, stream-major.
+
+This module only builds inputs (streamgen); it contains no decoding logic."""
+from dataclasses import dataclass
+from typing import Callable, List
+
+from . import streamgen as sg
+
+
+def uncoupled_stereo():
+    """the bench stream without its coupling step: one uncoupled channel pair per packet (k_long pairs up channels that
+    are in no coupling step, lw_fast.cpp)"""
+    st = sg.stereo_setup(44100, 8, 11, residue_type=1)
+    for m in st.mappings:
+        m.coupling = []
+    return st
+
+
+def mono():
+    st = sg.stereo_setup(44100, 8, 11, residue_type=1)
+    st.channels = 1
+    st.mappings = [sg.Mapping([], [0], [0], [0]), sg.Mapping([], [0], [1], [1])]
+    return st
+
+
+@dataclass
+class Workload:
+    key: str
+    name: str
+    setup: Callable[[], "sg.StreamSetup"]
+    pattern: str
+    n_streams: int
+    per_stream: int
+    note: str
+    distinct: int = 64          # distinct packet sequences generated (stream s uses sequence s % distinct)
+
+
+def configs(packets: int = 4096) -> List[Workload]:
+    per = max(1, packets // 256)
+    return [
+        Workload("3", "3 mixed short/long", lambda: sg.stereo_setup(44100, 8, 11), "LLSSSSSSSSL", 256, per,
+                 "256 streams x %d consecutive packets of the pattern; state carried inside the launch" % per),
+        Workload("4", "4 5.1 @ 48 kHz long blocks", lambda: sg.surround51_setup(48000, 8, 11), "L", 256, per,
+                 "6 channels = 3 units per packet (2 coupled pairs + 1 uncoupled pair)"),
+        Workload("5", "5 independent streams, 1 packet per stream per launch", lambda: sg.stereo_setup(44100, 8, 11), "L",
+                 packets, 1, "state read from and written to the HBM state pool by every packet"),
+        # design probes for k_long (not BASELINE configs)
+        Workload("6", "6 stereo long blocks WITHOUT coupling", uncoupled_stereo, "L", 256, per,
+                 "one uncoupled channel pair per packet"),
+        Workload("7", "7 mono long blocks", mono, "L", 256, per, "one single-channel unit per packet"),
+        Workload("8", "8 mono long blocks, 2 x packets", mono, "L", 256, 2 * per, "single-channel units, 2 rounds"),
+        Workload("9", "9 stereo long blocks, 2 x packets", lambda: sg.stereo_setup(44100, 8, 11), "L", 256, 2 * per,
+                 "coupled pairs, 2 rounds per workgroup"),
+        # BASELINE configs[4] on ONE GPU (the share of an 8-GPU job is 1250 streams; here all 10 000): 4 consecutive packets
+        # of every stream per launch = 40 000 packets per launch, state through the HBM state pool between launches
+        Workload("10", "5b 10 000 independent streams x 4 packets per launch", lambda: sg.stereo_setup(44100, 8, 11), "L",
+                 10000, 4, "configs[4] stepping: 16 launches of this shape = 10 000 streams x 64 packets"),
+        # other long block sizes (header.rs:236-247 allows 6..13)
+        Workload("11", "stereo long blocks n = 4096", lambda: sg.stereo_setup(44100, 9, 12), "L", 256, per,
+                 "blocksize_1 = 12"),
+        Workload("12", "stereo long blocks n = 1024", lambda: sg.stereo_setup(44100, 8, 10), "L", 256, per,
+                 "blocksize_1 = 10"),
+    ]
+
+
+def by_key(key: str, packets: int = 4096) -> Workload:
+    for w in configs(packets):
+        if w.key == key:
+            return w
+    raise KeyError(key)
+
+
+def stream_material(w: Workload, setup, batch: int = 0):
+    """Packet sequences of one batch: `distinct` sequences of per_stream + 1 packets (element 0 primes the stream)."""
+    n = min(w.n_streams, w.distinct)
+    return [sg.make_stream(setup, w.pattern, w.per_stream + 1, seed=1000 * batch + s) for s in range(n)]
+
+
+def items_of(w: Workload, seqs, pwrs):
+    """(prime items, timed items): lists of (packet bytes, pwr) in submission order."""
+    prime = [(seqs[s % len(seqs)][0], pwrs[s]) for s in range(w.n_streams)]
+    timed = [(seqs[s % len(seqs)][1 + k], pwrs[s]) for s in range(w.n_streams) for k in range(w.per_stream)]
+    return prime, timed

@@ -61,3 +61,30 @@ def floor_from_record(rec, xs, n2, inv_db):
     if lx < n2:
         y[lx:] = ly
     return inv_db[y].astype(np.float32)
+
+
+def verify_workload_batch(w, setup, seqs, results, flat, fmt="i16"):
+    """Every timed packet of a lewton_amd.workloads batch against the ORACLE: stream s = sequence s % len(seqs), primed
+    with element 0, then per_stream consecutive packets (stream-major in `results` / `flat`).  Returns the number of
+    packets that differ (0 = bit-exact); raises on a status or shape mismatch."""
+    o_id, o_st = oracle_headers(setup)
+    ch = setup.channels
+    ofmt = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}[fmt]
+    bad, k = 0, 0
+    cache = {}
+    for s in range(w.n_streams):
+        q = s % len(seqs)
+        if q not in cache:                      # streams that share a sequence share the expected output
+            opw = po.Pwr()
+            po.read_audio_packet(o_id, o_st, seqs[q][0], opw, ofmt)
+            cache[q] = [np.asarray(po.read_audio_packet(o_id, o_st, p, opw, ofmt)).reshape(-1) for p in seqs[q][1:]]
+        for want in cache[q]:
+            status, m, off = results[k]
+            assert status == 0 and m * ch == want.size, (s, k, status, m, want.size)
+            got = np.asarray(flat[off:off + m * ch]).reshape(-1)
+            if fmt == "f32":
+                bad += not np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            else:
+                bad += not np.array_equal(got, want)
+            k += 1
+    return bad

@@ -8,7 +8,9 @@
 #include <vector>
 
 // ---- stubs for the rest of the C ABI (never reached with a NULL decoder; they only have to link)
+void lw_set_device_error(const std::string &) {}
 extern "C" {
+const char *lw_last_device_error(void) { return ""; }
 lw_ident *lw_read_header_ident(const uint8_t *, size_t, int *err) { if (err) *err = LW_HDR_NOT_VORBIS; return nullptr; }
 int lw_ident_get_info(const lw_ident *, lw_ident_info *) { return LW_ERR_NULL_ARG; }
 void lw_ident_free(lw_ident *) {}

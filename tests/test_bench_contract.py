@@ -37,7 +37,7 @@ def test_committed_bench_line_has_the_contract_fields(name):
         assert "4096 packets" in d["config"]["parity"] or "256 streams" in d["config"]["parity"]
         e = d["end_to_end"]
         assert e["unit"] == "packets/s" and 0 < e["value"] < d["value"] and e["host_cpus_usable"] >= 1
-        t = e["tier_c"]
+        t = e.get("device_entropy") or e["tier_c"]   # (round 2 called it tier_c)
         assert "entropy stage on the device" in t["records"] and "k_entropy" in t["kernels"] and t["value"] > 0
 
 

@@ -194,7 +194,7 @@ def test_batch_many_streams_matches_oracle(name):
     assert any(k in batch.last_kernels for k in ("k_imdct_generic", "k_long", "k_small_fused"))
 
 
-def _decode_batch(setup, items_streams, fmt="i16", force_generic=False, batch=None):
+def _decode_batch(setup, items_streams, fmt="i16", force_generic=False, batch=None, rounds=0):
     """items_streams: list of (packet, stream_index). Returns (per-packet outputs, batch, pwrs)."""
     from lewton_amd.batch import Batch
     audio, ident, st = _product(setup)
@@ -203,6 +203,7 @@ def _decode_batch(setup, items_streams, fmt="i16", force_generic=False, batch=No
     pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
     b = batch or Batch(dec, len(items_streams), fmt)
     b.set_force_generic(force_generic)
+    b.debug_set_rounds(rounds)
     b.entropy([(p, pwrs[s]) for p, s in items_streams], n_threads=2)
     b.upload()
     return b.split(b.synth_to_host(), setup.channels), b, pwrs
@@ -260,16 +261,15 @@ def test_long_block_kernel_equals_generic_kernels_many_streams():
 
 @pytest.mark.parametrize("rounds", [1, 2, 3, 5])
 @pytest.mark.parametrize("name", ["stereo", "surround51"])
-def test_long_block_kernel_rounds_and_handover(name, rounds, monkeypatch):
+def test_long_block_kernel_rounds_and_handover(name, rounds):
     """The specialised kernel with a forced number of rounds per workgroup: right halves travel through LDS inside a
     round, across rounds, through the halo pre-pass at chunk boundaries and through the state pool; streams of
     different lengths so that chunks start and end in the middle of streams.  Bit-exact vs the oracle per stream."""
-    monkeypatch.setenv("LW_FAST_ROUNDS", str(rounds))
     setup = SETUPS[name]()
     lens = [1, 2, 5, 16, 17, 33, 40, 7]
     streams = [sg.make_stream(setup, "L", n + 1, seed=900 + i) for i, n in enumerate(lens)]
     items = [(p, s) for s, st in enumerate(streams) for p in st]
-    got, b, _ = _decode_batch(setup, items, "i16")
+    got, b, _ = _decode_batch(setup, items, "i16", rounds=rounds)
     assert "k_long" in b.last_kernels
     o_id, o_st = oracle_headers(setup)
     k = 0
@@ -297,72 +297,6 @@ def test_full_size_batch_properties():
     again = bf.synth_to_host()
     assert np.array_equal(again, fa)
     assert bf.algorithmic_bytes == 4096 * (8192 + 132) + 4095 * 4096
-
-
-# ---- Tier B: residue inverse VQ on the device ---------------------------------------------------
-@pytest.mark.parametrize("name", sorted(ALL_SETUPS))
-def test_device_inverse_vq_matches_oracle(name):
-    """Codeword symbols from the host, additions + de-interleave in k_residue_vq: the residue vectors (tap), the PCM and
-    the stream state must equal the oracle's bit for bit, incl. packets that end in the middle of the residue."""
-    from lewton_amd import _native as N
-    from lewton_amd.batch import Batch
-    setup = ALL_SETUPS[name]()
-    audio, ident, st = _product(setup)
-    o_id, o_st = oracle_headers(setup)
-    dec = audio.decoder_for(ident, st)
-    ch = setup.channels
-    why = C.c_char_p()
-    ok = bool(N.lw_decoder_supports_device_vq(dec._h, C.byref(why)))
-    batch = Batch(dec, 64, "i16")
-    assert batch.set_residue_on_device(True) == ok
-    if not ok:
-        assert name == "mono_small" and b"partition size" in why.value   # dims 2/4/8 vs partition sizes 8 and 24
-        return
-    n_streams, per = 4, 10
-    rng = np.random.default_rng(3)
-    streams = [sg.make_stream(setup, PATTERNS[name], per, seed=300 + s, p_floor_unused=0.1) for s in range(n_streams)]
-    for s in range(n_streams):                                   # end-of-packet inside the residue (audio.rs:655-660)
-        k = int(rng.integers(2, per))
-        streams[s][k] = streams[s][k][: max(8, len(streams[s][k]) * 2 // 3)]
-    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
-    o_pwrs = [po.Pwr() for _ in range(n_streams)]
-    items, want = [], []
-    for t in range(per):
-        for s in range(n_streams):
-            items.append((streams[s][t], pwrs[s]))
-            try:
-                want.append(po.read_audio_packet(o_id, o_st, streams[s][t], o_pwrs[s], "f32", taps=True))
-            except po.OracleError as e:
-                want.append(e.code)
-    res = batch.entropy(items, n_threads=3)
-    batch.upload()
-    got = batch.split(batch.synth_to_host(), ch)
-    assert batch.last_kernels.startswith("k_residue_vq,")
-    for i, (w, g, r) in enumerate(zip(want, got, res)):
-        if isinstance(w, int):
-            assert r[0] == w
-            continue
-        out, taps = w
-        assert r[0] == 0 and r[1] == out.shape[1]
-        wi = np.vectorize(po.lib().lwo_sample_i16, otypes=[np.int16])(out) if out.size else out.astype(np.int16)
-        assert np.array_equal(g, wi), i
-    for i in range(0, len(items), 7):
-        if isinstance(want[i], int):
-            continue
-        n = want[i][1]["n"]
-        t = batch.tap(i, N.TAP_RESIDUE_PRE_INVERSE, ch, n)
-        assert np.array_equal(t.view(np.uint32), want[i][1]["residue_pre_inverse"].view(np.uint32)), i
-    for s in range(n_streams):
-        assert np.array_equal(pwrs[s].data().view(np.uint32), o_pwrs[s].data(ch).view(np.uint32))
-    # the same batch object back in host mode gives the same PCM
-    assert batch.set_residue_on_device(False)
-    pw2 = [audio.PreviousWindowRight() for _ in range(n_streams)]
-    batch.entropy([(p, pw2[i % n_streams]) for i, (p, _) in enumerate(items)], n_threads=2)
-    batch.upload()
-    again = batch.split(batch.synth_to_host(), ch)
-    assert "k_residue_vq" not in batch.last_kernels
-    for a, g in zip(again, got):
-        assert (a is None) == (g is None) and (a is None or np.array_equal(a, g))
 
 
 @pytest.mark.parametrize("name,pattern", [("stereo", "LLLLLLSSLLLSLLLLLLLLLLLLLLLLLLLLLLLLLSSSSL"), ("surround51", "LLLSLLLLLLLLLLLLLLLLSSL")])
@@ -396,11 +330,10 @@ def test_long_mixed_single_stream_in_one_batch(name, pattern, fmt):
 
 @pytest.mark.parametrize("name", sorted(ALL_SETUPS))
 @pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
-def test_fused_small_block_kernel_equals_three_kernel_path(name, fmt, monkeypatch):
-    """k_small_fused (inverse coupling, floor, IMDCT, window / overlap-add of short blocks and of the long blocks next to them
-    in one launch; segments of consecutive packets with LDS hand-over, halo recomputation at segment starts) against the
-    oracle AND against the three generic kernels it replaces, on streams interleaved round-robin (every segment then starts
-    with a halo) and stream-major (long segments), with unused floors and packets cut short."""
+def test_mixed_short_long_streams_both_batch_orders(name, fmt):
+    """Runs of short blocks of every length up to 10 between long blocks, six streams interleaved round-robin (every
+    packet's predecessor is far away in the batch) and stream-major (runs of consecutive packets), with unused floors and
+    packets cut short, against the oracle -- and the product's default path against its generic kernels on the same batch."""
     from lewton_amd.batch import Batch
     setup = ALL_SETUPS[name]()
     audio, ident, st = _product(setup)
@@ -418,21 +351,16 @@ def test_fused_small_block_kernel_equals_three_kernel_path(name, fmt, monkeypatc
         else:
             items = [(streams[s][t], s) for t in range(per) for s in range(n_streams)]
         outs = {}
-        for fused in (True, False):
-            if fused:
-                monkeypatch.setenv("LW_SMALL_FUSED", "1")
-            else:
-                monkeypatch.delenv("LW_SMALL_FUSED", raising=False)
+        for generic in (False, True):
             pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
             b = Batch(dec, len(items), fmt)
+            b.set_force_generic(generic)
             res = b.entropy([(p, pwrs[s]) for p, s in items], n_threads=2)
             b.upload()
-            outs[fused] = (b.split(b.synth_to_host(), ch), res, b.last_kernels, pwrs)
-        got, res, kernels, pwrs = outs[True]
-        ref, _res2, kernels2, pwrs2 = outs[False]
-        if setup.channels <= 8:
-            assert "k_small_fused" in kernels and "k_ola_generic" not in kernels, kernels
-        assert "k_small_fused" not in kernels2 and "k_ola_generic" in kernels2, kernels2
+            outs[generic] = (b.split(b.synth_to_host(), ch), res, b.last_kernels, pwrs)
+        got, res, kernels, pwrs = outs[False]
+        ref, _res2, kernels2, pwrs2 = outs[True]
+        assert "k_long" not in kernels2 and "k_ola_generic" in kernels2, kernels2
         opws = [po.Pwr() for _ in range(n_streams)]
         for i, (p, s) in enumerate(items):
             try:
@@ -446,8 +374,9 @@ def test_fused_small_block_kernel_equals_three_kernel_path(name, fmt, monkeypatc
             for g in (got[i], ref[i]):
                 assert g.size == want.size, (order, i)
                 if fmt == "f32":
-                    assert np.array_equal(g.reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32)), (order, i)
+                    assert np.array_equal(g.reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32)), (order, i, kernels)
                 else:
-                    assert np.array_equal(g.reshape(-1), want.reshape(-1)), (order, i)
+                    assert np.array_equal(g.reshape(-1), want.reshape(-1)), (order, i, kernels)
         for s in range(n_streams):
             assert np.array_equal(pwrs[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32))
+            assert np.array_equal(pwrs2[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32))

@@ -1,0 +1,121 @@
+"""Every shape a number is quoted for (profiles/*_other_configs.jsonl, bench `end_to_end`) checked packet by
+packet against the ORACLE at that very shape (-m gpu):
+
+* BASELINE configs[2] as tools/bench_configs.py lays it out: 256 streams x 16 consecutive packets of `LLSSSSSSSSL`
+  in ONE launch (mixed short/long windows, state carried inside the launch);
+* BASELINE configs[3] dense: 256 streams x 16 packets of 5.1 @ 48 kHz (two coupled pairs + one uncoupled pair per packet);
+* the stereo stream with its coupling list removed (uncoupled-pair units of k_long), mono (single-channel units);
+* other long block sizes at the quoted shape;
+* one 4096-packet batch through the staging ring per record tier (host entropy stage / k_entropy), PCM compared.
+
+The workload definitions are the ones tools/bench_configs.py times (lewton_amd/workloads.py)."""
+import numpy as np
+import pytest
+
+from common import po, sg, verify_workload_batch  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder(setup):
+    from lewton_amd import audio, header
+    idp, _, stp = setup.headers()
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    return audio, audio.decoder_for(ident, st)
+
+
+def _run_dense(key, fmt="i16", packets=4096):
+    from lewton_amd import workloads as wl
+    from lewton_amd.batch import Batch
+    w = wl.by_key(key, packets)
+    setup = w.setup()
+    audio, dec = _decoder(setup)
+    seqs = wl.stream_material(w, setup, batch=3)
+    pwrs = [audio.PreviousWindowRight() for _ in range(w.n_streams)]
+    prime_items, items = wl.items_of(w, seqs, pwrs)
+    prime = Batch(dec, w.n_streams, fmt)
+    prime.entropy(prime_items, n_threads=4)
+    prime.upload()
+    prime.synth_to_host()
+    prime.close()
+    bt = Batch(dec, len(items), fmt)
+    res = bt.entropy(items, n_threads=4)
+    bt.upload()
+    flat = bt.synth_to_host()
+    kernels = bt.last_kernels
+    bad = verify_workload_batch(w, setup, seqs, res, flat, fmt)
+    bt.close()
+    return bad, kernels, len(items)
+
+
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_configs2_mixed_short_long_bench_shape(fmt):
+    bad, kernels, n = _run_dense("3", fmt)
+    assert n == 4096 and bad == 0, (bad, kernels)
+    assert "k_long" in kernels
+
+
+@pytest.mark.parametrize("fmt", ["i16", "f32"])
+def test_configs3_surround51_dense_bench_shape(fmt):
+    bad, kernels, n = _run_dense("4", fmt)
+    assert n == 4096 and bad == 0, (bad, kernels)
+    assert kernels == "k_long"
+
+
+@pytest.mark.parametrize("key", ["6", "7"])
+def test_uncoupled_pair_and_single_channel_units_bench_shape(key):
+    bad, kernels, n = _run_dense(key)
+    assert n == 4096 and bad == 0, (bad, kernels)
+    assert kernels == "k_long"
+
+
+@pytest.mark.parametrize("key", ["11", "12"])
+def test_other_long_block_sizes_bench_shape(key):
+    bad, kernels, n = _run_dense(key, packets=1024)
+    assert n == 1024 and bad == 0, (bad, kernels)
+
+
+@pytest.mark.parametrize("tier,pattern", [("host", "L"), ("device", "L"), ("host", "LLSSSSSSSSL"), ("device", "LLSSSSSSSSL")])
+def test_ring_4096_packet_batches_pcm_vs_oracle(tier, pattern):
+    """the end_to_end object of the bench line is a rate of THESE bytes: three 4096-packet batches through a 3-slot ring,
+    the same 256 streams in every batch, every packet's PCM against the oracle"""
+    from lewton_amd import workloads as wl
+    from lewton_amd.ring import Ring
+    w = wl.Workload("r", "ring", lambda: sg.stereo_setup(44100, 8, 11), pattern, 256, 16, "", distinct=32)
+    setup = w.setup()
+    audio, dec = _decoder(setup)
+    n_batches = 3
+    seqs = [sg.make_stream(setup, pattern, n_batches * w.per_stream + 1, seed=900 + s) for s in range(w.distinct)]
+    pwrs = [audio.PreviousWindowRight() for _ in range(w.n_streams)]
+    ring = Ring(dec, 3, w.n_streams * w.per_stream, "i16")
+    if tier == "device":
+        assert ring.set_entropy_on_device(True)
+    ring.submit(ring.marshal([(seqs[s % len(seqs)][0], pwrs[s]) for s in range(w.n_streams)]), n_threads=4)
+    ring.collect()
+    ring.release()
+    for b in range(n_batches):
+        items = [(seqs[s % len(seqs)][1 + b * w.per_stream + k], pwrs[s]) for s in range(w.n_streams) for k in range(w.per_stream)]
+        ring.submit(ring.marshal(items), n_threads=4)
+    if tier == "device":
+        assert "k_entropy" in ring.last_kernels
+    from common import oracle_headers
+    o_id, o_st = oracle_headers(setup)
+    expect = []
+    for q in range(len(seqs)):
+        opw = po.Pwr()
+        po.read_audio_packet(o_id, o_st, seqs[q][0], opw, "i16")
+        expect.append([np.asarray(po.read_audio_packet(o_id, o_st, p, opw, "i16")).reshape(-1) for p in seqs[q][1:]])
+    for b in range(n_batches):
+        res, pcm = ring.collect()
+        bad, k = 0, 0
+        for s in range(w.n_streams):
+            for t in range(w.per_stream):
+                want = expect[s % len(seqs)][b * w.per_stream + t]
+                status, m, off = res[k]
+                assert status == 0 and 2 * m == want.size, (b, s, t, status, m)
+                bad += not np.array_equal(pcm[off:off + 2 * m], want)
+                k += 1
+        ring.release()
+        assert bad == 0, (tier, pattern, b, bad)
+    ring.close()

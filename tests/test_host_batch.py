@@ -37,14 +37,13 @@ def harness(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("name,pattern,symbols", [("stereo", "L", 0), ("stereo", "LLSSLSL", 0), ("stereo", "LSL", 1),
-                                                  ("surround51", "LLSL", 0), ("mono_small", "LSSLL", 0)])
-def test_batch_entropy_threads_agree_under_tsan(harness, tmp_path, name, pattern, symbols):
+@pytest.mark.parametrize("name,pattern", [("stereo", "L"), ("stereo", "LLSSLSL"), ("surround51", "LLSL"), ("mono_small", "LSSLL")])
+def test_batch_entropy_threads_agree_under_tsan(harness, tmp_path, name, pattern):
     from common import SETUPS
     case = str(tmp_path / "case.bin")
     _case(case, SETUPS[name](), pattern, 96, seed=7, p_floor_unused=0.1)
     env = dict(os.environ, LW_HOST_BENCH_CHECK="1", TSAN_OPTIONS="halt_on_error=1")
-    out = subprocess.run([harness, case, "384", "12", "2", str(symbols), "2", "5", "8"], env=env, capture_output=True, text=True,
+    out = subprocess.run([harness, case, "384", "12", "2", "0", "2", "5", "8"], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "check ok: 384 packets" in out.stdout

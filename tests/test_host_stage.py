@@ -295,51 +295,7 @@ def test_floor0_undecodable_and_unused_semantics():
     assert e.value.code == eo.value.code == po.AUDIO_END_OF_PACKET
 
 
-# ---- codeword symbols: host side of the device inverse VQ ------------------------------------------
 from common import SETUPS  # noqa: E402
-import vq_model  # noqa: E402
-
-
-@pytest.mark.parametrize("name", sorted(set(HOST_SETUPS) | set(FLOOR0_SETUPS)))
-def test_symbols_rebuild_the_residue_vectors(name):
-    """The symbol records, replayed by a numpy model of k_residue_vq, give exactly the vectors the host path adds up
-    (audio.rs:587-618, :748-754) -- also for packets that end inside the residue."""
-    setup = dict(HOST_SETUPS, **FLOOR0_SETUPS)[name]()
-    idp, _cmt, stp = setup.headers()
-    hid = header.read_header_ident(idp)
-    hst = header.read_header_setup(stp, hid.audio_channels, (hid.blocksize_0, hid.blocksize_1))
-    why = C.c_char_p()
-    ok = bool(N.lw_setup_supports_device_vq(hid._h, hst._h, C.byref(why)))
-    pk = sg.make_stream(setup, "LSSL", 8, seed=12, p_floor_unused=0.1)
-    pk[5] = pk[5][: max(6, len(pk[5]) * 3 // 5)]
-    if not ok:
-        assert name == "mono_small" and b"partition size" in why.value
-        rc, _ = vq_model.symbols(hid, hst, pk[0])
-        assert rc == N.ERR_UNSUPPORTED
-        return
-    n_sym = 0
-    for p in pk:
-        want = audio.entropy_decode_host(hid, hst, p)
-        rc, sym = vq_model.symbols(hid, hst, p)
-        assert rc == 0 and sym["bs"] == want["bs"] and sym["mode"] == want["mode"]
-        assert np.array_equal(sym["floor"], want["floor"])
-        got = vq_model.residue_from_symbols(hid, hst, sym)
-        assert np.array_equal(got.view(np.uint32), want["residue"].view(np.uint32))
-        n_sym += len(sym["ops"])
-    assert n_sym > 100
-
-
-def test_symbol_capacity_and_null_arguments():
-    setup = SETUPS["stereo"]()
-    idp, _cmt, stp = setup.headers()
-    hid = header.read_header_ident(idp)
-    hst = header.read_header_setup(stp, 2, (hid.blocksize_0, hid.blocksize_1))
-    p = sg.make_stream(setup, "L", 1, seed=1)[0]
-    rc, sym = vq_model.symbols(hid, hst, p)
-    assert rc == 0 and len(sym["ops"]) > 8
-    rc2, _ = vq_model.symbols(hid, hst, p, cap=4)
-    assert rc2 == N.ERR_CAPACITY
-    assert N.lw_entropy_symbols_host(None, hst._h, p, len(p), None, None, 0, None, None, None, None, None, None) == N.ERR_NULL_ARG
 
 
 def test_headers_are_plain_c(tmp_path):

@@ -3,8 +3,11 @@
   3: mixed short/long stream(s), block pattern L L S S S S S S S S L with overlap-add state carry
   4: 5.1-channel 48 kHz long blocks with channel coupling
   5: many independent stereo streams, ONE packet per stream per launch (state round trip through HBM every launch)
-Same method as bench.py: records resident in HBM, hipGraph replay of rotated batches, HIP events.
-    python tools/bench_configs.py [--steps 400]"""
+  (6-12: design probes, see lewton_amd/workloads.py)
+Same method as bench.py: records resident in HBM, hipGraph replay of rotated batches, HIP events -- and, like bench.py,
+the PCM the timed launches left for batch 0 is compared with the oracle, every packet (`parity` of each line; --no-verify
+skips it).  The oracle is the checker only; nothing timed touches it.
+    python tools/bench_configs.py [--steps 400] [--only 3,4]"""
 import argparse
 import ctypes as C
 import json
@@ -16,44 +19,46 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from lewton_amd import audio, header, streamgen as sg  # noqa: E402
+from lewton_amd import audio, header, workloads as wl  # noqa: E402
 from lewton_amd.batch import Batch  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=400)
 ap.add_argument("--packets", type=int, default=4096)
 ap.add_argument("--only", default="", help="comma-separated config numbers (default: 3,4,5)")
+ap.add_argument("--no-verify", action="store_true")
+ap.add_argument("--force-generic", action="store_true")
 args = ap.parse_args()
 ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
 NB = 4
 
 
-def run(name, setup, pattern, n_streams, per_stream, note):
+def run(w):
+    setup = w.setup()
     idp, _, stp = setup.headers()
     ident = header.read_header_ident(idp)
     st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
     dec = audio.decoder_for(ident, st, 0)
-    NP = n_streams * per_stream
-    rng = np.random.default_rng(7)
-    batches, outs = [], []
+    NP = w.n_streams * w.per_stream
+    batches, outs, material = [], [], []
     for b in range(NB):
-        pw = [audio.PreviousWindowRight() for _ in range(n_streams)]
+        pw = [audio.PreviousWindowRight() for _ in range(w.n_streams)]
         # every stream is primed with the packet that precedes its first timed one, so all timed packets yield samples
-        streams = [sg.make_stream(setup, pattern, per_stream + 1, seed=1000 * b + s) for s in range(min(n_streams, 64))]
-        prime = Batch(dec, n_streams, "i16")
-        prime.entropy([(streams[s % len(streams)][0], pw[s]) for s in range(n_streams)], n_threads=0)
+        seqs = wl.stream_material(w, setup, batch=b)
+        prime_items, items = wl.items_of(w, seqs, pw)
+        prime = Batch(dec, w.n_streams, "i16")
+        prime.entropy(prime_items, n_threads=0)
         prime.upload(None)
         prime.synth_to_host(None)
         prime.close()
         bt = Batch(dec, NP, "i16")
-        items = []
-        for s in range(n_streams):
-            for k in range(per_stream):
-                items.append((streams[s % len(streams)][1 + k], pw[s]))
+        if args.force_generic:
+            bt.set_force_generic(True)
         bt.entropy(items, n_threads=0)
         bt.upload(None)
         outs.append(torch.empty(max(1, bt.out_elems), dtype=torch.int16, device="cuda"))
         batches.append((bt, pw))
+        material.append(seqs)
     torch.cuda.synchronize()
     alg = batches[0][0].algorithmic_bytes
     stream = torch.cuda.current_stream()
@@ -80,50 +85,24 @@ def run(name, setup, pattern, n_streams, per_stream, note):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (args.steps // NB * NB)
-    res = {"config": name, "packets_per_launch": NP, "streams": n_streams, "us_per_launch": round(us, 2),
+    parity = "unchecked"
+    if not args.no_verify:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from common import verify_workload_batch
+            bad = verify_workload_batch(w, setup, material[0], batches[0][0].results(), outs[0].cpu().numpy(), "i16")
+            parity = ("timed batch 0: %d packets i16 bit-exact vs oracle" % NP) if bad == 0 else "MISMATCH: %d of %d packets" % (bad, NP)
+        except Exception as e:  # the oracle is only a checker here
+            parity = "unchecked: %r" % (e,)
+    res = {"config": w.name, "packets_per_launch": NP, "streams": w.n_streams, "us_per_launch": round(us, 2),
            "M_packets_per_s": round(NP / us, 2), "algorithmic_bytes_per_launch": alg,
-           "pct_of_8TBps": round(100 * alg / (us * 1e-6) / 8e12, 2), "kernels": batches[0][0].last_kernels, "note": note}
-    print(json.dumps(res))
+           "pct_of_8TBps": round(100 * alg / (us * 1e-6) / 8e12, 2), "kernels": batches[0][0].last_kernels, "parity": parity,
+           "note": w.note}
+    print(json.dumps(res), flush=True)
     for bt, _ in batches:
         bt.close()
 
-def uncoupled_stereo():
-    """the bench stream without its coupling step: two single-channel units per packet instead of one coupled pair"""
-    st = sg.stereo_setup(44100, 8, 11, residue_type=1)
-    for m in st.mappings:
-        m.coupling = []
-    return st
 
-
-def mono():
-    st = sg.stereo_setup(44100, 8, 11, residue_type=1)
-    st.channels = 1
-    st.mappings = [sg.Mapping([], [0], [0], [0]), sg.Mapping([], [0], [1], [1])]
-    return st
-
-
-if "3" in ONLY:
-    run("3 mixed short/long", sg.stereo_setup(44100, 8, 11), "LLSSSSSSSSL", 256, args.packets // 256,
-        "256 streams x 16 consecutive packets of the pattern; state carried inside the launch")
-if "4" in ONLY:
-    run("4 5.1 @ 48 kHz long blocks", sg.surround51_setup(48000, 8, 11), "L", 256, args.packets // 256,
-        "6 channels = 4 units per packet (2 coupled pairs + 2 single channels)")
-if "5" in ONLY:
-    run("5 independent streams, 1 packet per stream per launch", sg.stereo_setup(44100, 8, 11), "L", args.packets, 1,
-        "state read from and written to the HBM state pool by every packet")
-# design probes for k_long (not BASELINE configs): what single-channel waves cost
-if "6" in ONLY:
-    run("6 stereo long blocks WITHOUT coupling", uncoupled_stereo(), "L", 256, args.packets // 256,
-        "two single-channel units per packet: 8 packets per round, 2 rounds per workgroup")
-if "7" in ONLY:
-    run("7 mono long blocks", mono(), "L", 256, args.packets // 256, "one single-channel unit per packet, 1 round")
-if "8" in ONLY:
-    run("8 mono long blocks, 2 x packets", mono(), "L", 256, 2 * args.packets // 256, "single-channel units, 2 rounds")
-if "9" in ONLY:
-    run("9 stereo long blocks, 2 x packets", sg.stereo_setup(44100, 8, 11), "L", 256, 2 * args.packets // 256,
-        "coupled pairs, 2 rounds per workgroup")
-if "10" in ONLY:
-    # BASELINE configs[4] on ONE GPU (the share of an 8-GPU job is 1250 streams; here all 10 000): 4 consecutive packets of
-    # every stream per launch = 40 000 packets per launch, state through the HBM state pool between launches
-    run("5b 10 000 independent streams x 4 packets per launch", sg.stereo_setup(44100, 8, 11), "L", 10000, 4,
-        "configs[4] stepping: 16 launches of this shape = 10 000 streams x 64 packets")
+for w in wl.configs(args.packets):
+    if w.key in ONLY:
+        run(w)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end throughput through the library's staging ring (see lewton_amd/e2e.py).
-    python tools/e2e.py [--batches 48] [--threads 0] [--slots 3] [--device-vq] [--callers 2]"""
+    python tools/e2e.py [--batches 48] [--threads 0] [--slots 3] [--callers 2]"""
 import argparse
 import json
 import os
@@ -16,9 +16,8 @@ ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--packets", type=int, default=4096)
 ap.add_argument("--streams", type=int, default=256)
 ap.add_argument("--slots", type=int, default=3)
-ap.add_argument("--device-vq", action="store_true", help="Tier B: ship codeword symbols, inverse VQ in k_residue_vq")
 ap.add_argument("--callers", type=int, default=1, help="host threads, each with its own ring and its own streams")
-ap.add_argument("--device-entropy", action="store_true", help="Tier C: ship the packets, entropy stage in k_entropy")
+ap.add_argument("--device-entropy", action="store_true", help="ship the packets, entropy stage in k_entropy")
 args = ap.parse_args()
 
 setup = sg.stereo_setup(44100, 8, 11)
@@ -27,7 +26,7 @@ ident = header.read_header_ident(idp)
 st = header.read_header_setup(stp, 2, (8, 11))
 dec = audio.decoder_for(ident, st, 0)
 pool = sg.make_stream(setup, "L", 512, seed=9)
-r = e2e.measure(dec, pool, args.batches, args.packets, args.streams, args.threads, args.slots, args.device_vq, args.callers,
+r = e2e.measure(dec, pool, args.batches, args.packets, args.streams, args.threads, args.slots, args.callers,
                 device_entropy=args.device_entropy)
 print(json.dumps(r))
 print("end-to-end: %d packets in %.3f s -> %.2f M packets/s (%s; H2D %s GB/s, D2H %.2f GB/s); host entropy stage alone "

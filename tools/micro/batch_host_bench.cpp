@@ -2,7 +2,7 @@
 // linked against tests/san/hip_standins.inc (device memory = malloc, copies = memcpy, kernel launchers = no-ops), to time
 // lw_batch_entropy -- prologue pass, threaded entropy decode into the staging slab, planning pass -- on this machine's
 // cores.  A profiling tool only (tools/batch_host_bench.py builds and runs it); nothing here is shipped or tested against.
-//   usage: batch_host_bench case.bin [packets 4096] [streams 256] [reps 20] [symbols 0/1] [threads...]
+//   usage: batch_host_bench case.bin [packets 4096] [streams 256] [reps 20] [0] [threads...]
 // With LW_HOST_BENCH_CHECK=1 in the environment it does not time anything: it runs the batch on one thread and on every
 // listed thread count and compares statuses, sample counts, output offsets and the staged residue vectors (against each
 // other and against lw_entropy_decode_host packet by packet); tests/test_host_batch.py runs that under ThreadSanitizer
@@ -35,7 +35,8 @@ int main(int argc, char **argv)
 	if (!f)
 		return 2;
 	const size_t NP = argc > 2 ? atoi(argv[2]) : 4096, S = argc > 3 ? atoi(argv[3]) : 256;
-	const int reps = argc > 4 ? atoi(argv[4]) : 20, sym = argc > 5 ? atoi(argv[5]) : 0;
+	const int reps = argc > 4 ? atoi(argv[4]) : 20;
+	const int sym = 0; // (argv[5]: former record-format switch, kept as a placeholder so that the thread list stays at argv[6..])
 	uint32_t nc, npk;
 	std::vector<uint8_t> idp, stp;
 	if (!rd(f, nc) || !rdv(f, idp) || !rdv(f, stp) || !rd(f, npk))
@@ -55,10 +56,6 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	lw_batch *b = lw_batch_create(dec, NP, LW_FMT_I16_PLANAR, &err);
-	if (sym && lw_batch_set_residue_on_device(b, 1)) {
-		printf("symbols mode not available\n");
-		return 1;
-	}
 	std::vector<lw_pwr *> pwr(S);
 	for (auto &p : pwr)
 		p = lw_pwr_new(dec);
@@ -137,8 +134,6 @@ int main(int argc, char **argv)
 		}
 		{ // two callers, each with its own batch and streams, share the decoder and the worker pool
 			lw_batch *b2 = lw_batch_create(dec, NP, LW_FMT_I16_PLANAR, &err);
-			if (sym)
-				lw_batch_set_residue_on_device(b2, 1);
 			std::vector<lw_pwr *> pwr2(S);
 			for (auto &p : pwr2)
 				p = lw_pwr_new(dec);
