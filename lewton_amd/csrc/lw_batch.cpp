@@ -51,6 +51,10 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
 	const size_t o_ola = slice(max_packets * sizeof(LwOlaDesc));
 	const size_t o_tasks = slice(max_packets * ch * sizeof(LwGenTask));
+	// k_short: at most two slots per short packet (a recomputed predecessor in front of it) plus one per long block with a
+	// short left slope, in tasks of LW_SHORT_SLOTS
+	const size_t max_tasks = d->shortp.eligible ? (3 * max_packets + LW_SHORT_SLOTS - 1) / LW_SHORT_SLOTS + 1 : 0;
+	const size_t o_slots = slice(max_tasks * LW_SHORT_SLOTS * sizeof(LwShortSlot));
 	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
 	b->slab_bytes = off;
 	bool ok = lw_hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
@@ -65,6 +69,8 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
 		b->h_ola = (LwOlaDesc *)H(o_ola), b->d_ola = (LwOlaDesc *)D(o_ola);
 		b->h_tasks = (LwGenTask *)H(o_tasks), b->d_tasks = (LwGenTask *)D(o_tasks);
+		b->h_slots = (LwShortSlot *)H(o_slots), b->d_slots = (LwShortSlot *)D(o_slots);
+		b->max_tasks = max_tasks;
 		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
 		if (d->any_floor0)
 			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
@@ -96,7 +102,7 @@ void lw_batch_destroy(lw_batch *b)
 	for (void *p : ent)
 		if (p)
 			(void)hipFree(p);
-	void *dev[] = {b->d_slab, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
+	void *dev[] = {b->d_slab, b->d_edge, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -292,6 +298,11 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->has_generic = b->has_fast = false;
 	b->n_gen_small = b->n_gen_large = b->n_gen_ola = 0;
 	b->has_tdonly = false;
+	b->short_idx.clear();
+	b->short_slot.clear();
+	b->n_tasks = 0;
+	const bool short_ok = d->fast.eligible && d->shortp.eligible && !b->force_generic;
+	b->edge_mode = false; // set when the batch has a long block with a short slope (an all-(1,1) batch keeps the plain k_long)
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
 	for (size_t i = 0; i < n; i++) {
 		LwPacketRec &r = b->h_recs[i];
@@ -347,13 +358,31 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		// length) still get floor, decoupling and IMDCT from the specialised kernel, which writes their whole time-domain
 		// block; k_ola_generic does their window / overlap-add / state (LW_RF_TDONLY).
 		if (d->fast.eligible && !b->force_generic && p.blockflag && (d->fast.long_mode_mask[p.mode >> 3] & (1u << (p.mode & 7)))) {
-			r.flags |= LW_RF_FAST;
-			if (!(p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h))) {
-				r.flags |= LW_RF_TDONLY;
-				b->has_tdonly = true;
+			if (short_ok) {
+				// the stream's short blocks run through k_short: a long block with a short slope keeps everything but the
+				// 128-sample overlap with its short neighbour in k_long (LW_XF_EDGE_*).  A stored right part of another length
+				// than the slope's (legal, never produced by an encoder) sends the packet to the generic kernels.
+				if (r.prev == -1 || r.plen == (p.prev_flag ? n1h : n0h)) {
+					r.flags |= LW_RF_FAST;
+					r.xflags = (uint8_t)((p.prev_flag ? 0u : LW_XF_EDGE_L) | (p.next_flag ? 0u : LW_XF_EDGE_R));
+					b->edge_mode |= r.xflags != 0;
+					b->fast_idx.push_back((uint32_t)i);
+					b->fast_slot.push_back((uint32_t)pw->slot);
+				}
+			} else {
+				r.flags |= LW_RF_FAST;
+				if (!(p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h))) {
+					r.flags |= LW_RF_TDONLY;
+					b->has_tdonly = true;
+				}
+				b->fast_idx.push_back((uint32_t)i);
+				b->fast_slot.push_back((uint32_t)pw->slot);
 			}
-			b->fast_idx.push_back((uint32_t)i);
-			b->fast_slot.push_back((uint32_t)pw->slot);
+		} else if (short_ok && !p.blockflag && (d->shortp.short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) &&
+				(r.prev == -1 || r.plen == n0h)) {
+			r.flags |= LW_RF_FAST; // (LW_RF_FAST without LW_RF_LONG: a block of k_short)
+			b->short_idx.push_back((uint32_t)i);
+			b->short_slot.push_back((uint32_t)pw->slot);
 		}
 		pw->present = true;
 		pw->len = w.right_end - w.right_start;
@@ -387,6 +416,133 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	b->out_elems = out_off;
 	b->alg_bytes = alg;
+	if (!b->fast_idx.empty() || !b->short_idx.empty())
+		for (size_t i = 0; i < n; i++) { // generic successors of packets of the specialised kernels read the td block
+			const LwPacketRec &r = b->h_recs[i];
+			const bool ola_generic = !(r.flags & LW_RF_FAST) || (r.flags & LW_RF_TDONLY);
+			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
+				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
+		}
+	// ---- slots of k_short (lw_fast.hpp): the short blocks of the streams it covers, sorted by stream so that consecutive blocks
+	// of a stream sit in consecutive slots of a wave and hand their right part over through LDS; a block whose short
+	// predecessor is not the slot in front of it (wave boundary, another stream's packets in between in a batch that is not
+	// stream-major... after sorting: only the wave boundary) gets that predecessor recomputed in the slot in front (LW_SS_HALO).
+	// A short block followed by a long one with a short left slope also does that block's first 128 samples; such a long
+	// block whose predecessor is NOT a block of k_short gets a slot of its own that only carries the stored right part
+	// (LW_SS_EDGE).
+	if (short_ok && (!b->short_idx.empty() || !b->fast_idx.empty())) {
+		b->succ.assign(n, -1);
+		for (size_t i = 0; i < n; i++)
+			if (!(b->h_recs[i].flags & LW_RF_SKIP) && b->h_recs[i].prev >= 0)
+				b->succ[b->h_recs[i].prev] = (int32_t)i;
+		auto is_short_fast = [&](const LwPacketRec &r) { return (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == LW_RF_FAST; };
+		auto is_long_fast = [&](const LwPacketRec &r) { return (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == (LW_RF_FAST | LW_RF_LONG); };
+		// events: short blocks, and long blocks with a short left slope whose predecessor is not a short block of k_short
+		struct Ev {
+			uint32_t slot, idx;
+		};
+		std::vector<Ev> ev;
+		ev.reserve(b->short_idx.size() + 16);
+		for (size_t k = 0; k < b->short_idx.size(); k++)
+			ev.push_back(Ev{b->short_slot[k], b->short_idx[k]});
+		for (size_t k = 0; k < b->fast_idx.size(); k++) {
+			const LwPacketRec &r = b->h_recs[b->fast_idx[k]];
+			if ((r.xflags & LW_XF_EDGE_L) && r.prev != -1 && !(r.prev >= 0 && is_short_fast(b->h_recs[r.prev])))
+				ev.push_back(Ev{b->fast_slot[k], b->fast_idx[k]});
+		}
+		std::stable_sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &c) { return a.slot != c.slot ? a.slot < c.slot : a.idx < c.idx; });
+		LwShortSlot *slots = b->h_slots;
+		size_t n_slots = 0; // slots used so far (tasks are consecutive groups of LW_SHORT_SLOTS)
+		auto room = [&](size_t want) { // the next `want` slots lie in one task
+			const size_t used = n_slots % LW_SHORT_SLOTS;
+			if (used + want > LW_SHORT_SLOTS)
+				while (n_slots % LW_SHORT_SLOTS) {
+					std::memset(&slots[n_slots], 0, sizeof(LwShortSlot));
+					slots[n_slots].next_edge = 0xFFFFFFFFu;
+					slots[n_slots].state_out = -1;
+					n_slots++;
+				}
+		};
+		auto blank = [&](uint32_t idx, uint8_t kind) -> LwShortSlot & {
+			LwShortSlot &sl = slots[n_slots++];
+			std::memset(&sl, 0, sizeof(sl));
+			const LwPacketRec &r = b->h_recs[idx];
+			sl.res_off = r.res_off;
+			sl.floor_off = r.floor_off;
+			sl.out_off = r.out_off;
+			sl.state_out = -1;
+			sl.next_edge = 0xFFFFFFFFu;
+			sl.kind = kind;
+			sl.prev_kind = LW_SP_NONE;
+			sl.pkt = idx;
+			return sl;
+		};
+		// where the stored right part in front of packet `r` lives when it is not a slot of this kernel
+		auto outside_prev = [&](const LwPacketRec &r, LwShortSlot &sl) {
+			if (r.prev <= -2) {
+				sl.prev_kind = LW_SP_STATE;
+				sl.prev_arg = (uint32_t)(-(r.prev + 2));
+				sl.flags |= r.flags & LW_RF_PARITY_IN;
+			} else if (r.prev >= 0) {
+				const LwPacketRec &pr = b->h_recs[r.prev];
+				if (is_long_fast(pr)) { // (its right slope is short: the stored part has the short slope's length)
+					sl.prev_kind = LW_SP_EDGE;
+					sl.prev_arg = (uint32_t)r.prev;
+				} else {
+					sl.prev_kind = LW_SP_TD;
+					sl.prev_arg = 2u * pr.res_off + pr.rs;
+					sl.prev_stride = (uint16_t)(1u << pr.bs);
+				}
+			}
+		};
+		auto set_next = [&](uint32_t idx, LwShortSlot &sl) { // the long successor with a short left slope, if any
+			const int32_t nx = b->succ[idx];
+			if (nx < 0)
+				return;
+			const LwPacketRec &nr = b->h_recs[nx];
+			if (is_long_fast(nr) && (nr.xflags & LW_XF_EDGE_L)) {
+				sl.next_edge = (uint32_t)nx;
+				sl.next_out = nr.out_off;
+				sl.next_m = (uint32_t)(nr.rs - nr.ls);
+			}
+		};
+		int64_t last_pkt = -1; // packet of the slot placed last (a block or a halo), -1 after anything else
+		for (const Ev &e : ev) {
+			const LwPacketRec &r = b->h_recs[e.idx];
+			if (r.flags & LW_RF_LONG) { // LW_SS_EDGE
+				room(1);
+				LwShortSlot &sl = blank(e.idx, LW_SS_EDGE);
+				outside_prev(r, sl);
+				sl.next_edge = e.idx;
+				sl.next_out = r.out_off;
+				sl.next_m = (uint32_t)(r.rs - r.ls);
+				last_pkt = -1;
+				continue;
+			}
+			const bool pred_short = r.prev >= 0 && is_short_fast(b->h_recs[r.prev]);
+			bool lane = pred_short && last_pkt == (int64_t)r.prev && (n_slots % LW_SHORT_SLOTS) != 0;
+			if (pred_short && !lane) { // recompute the predecessor in the slot in front
+				room(2);
+				blank((uint32_t)r.prev, LW_SS_HALO);
+				lane = true;
+			} else if (!lane) {
+				room(1);
+			}
+			LwShortSlot &sl = blank(e.idx, LW_SS_BLOCK);
+			if (lane)
+				sl.prev_kind = LW_SP_LANE;
+			else
+				outside_prev(r, sl);
+			sl.state_out = r.state_out;
+			sl.flags |= r.flags & LW_RF_PARITY_OUT;
+			if (r.flags & LW_RF_WRITE_TD)
+				sl.flags |= LW_SF_WRITE_TD;
+			set_next(e.idx, sl);
+			last_pkt = (int64_t)e.idx;
+		}
+		room(LW_SHORT_SLOTS + 1); // pad the last task
+		b->n_tasks = n_slots / LW_SHORT_SLOTS;
+	}
 	// tasks of the short-block transform kernel: record + the per-channel look-ups, one load on the device
 	for (uint32_t t = 0; t < b->n_gen_small; t++) {
 		const LwPacketRec &r = b->h_recs[b->h_gen[t]];
@@ -439,12 +595,6 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->has_fast = !b->fast_idx.empty();
 	if (b->has_fast) {
 		const size_t nf = b->fast_idx.size();
-		for (size_t i = 0; i < n; i++) { // generic successors of fast packets read the td block
-			const LwPacketRec &r = b->h_recs[i];
-			const bool ola_generic = !(r.flags & LW_RF_FAST) || (r.flags & LW_RF_TDONLY);
-			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
-				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
-		}
 		b->fast_order.resize(nf);
 		for (size_t k = 0; k < nf; k++)
 			b->fast_order[k] = (uint32_t)k;
@@ -478,7 +628,10 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			it.out_off = r.out_off;
 			it.state_out = r.state_out;
 			it.mode = r.mode;
-			it.flags = (uint8_t)(r.flags & (LW_RF_PARITY_IN | LW_RF_PARITY_OUT | LW_RF_WRITE_TD | LW_RF_TDONLY));
+			it.flags = (uint8_t)((r.flags & (LW_RF_PARITY_IN | LW_RF_PARITY_OUT | LW_RF_WRITE_TD | LW_RF_TDONLY)) |
+					(r.xflags & (LW_XF_EDGE_L | LW_XF_EDGE_R)));
+			if (r.prev == -1)
+				it.flags |= LW_IF_SILENT;
 			if (r.flags & LW_RF_TDONLY) {
 				it.flags |= LW_RF_WRITE_TD; // left AND right half go to the td block
 				it.state_out = -1;          // the state slot is written by k_ola_generic
@@ -492,12 +645,12 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			fill(it, idx);
 			if (it.res_off != (uint32_t)(k * ch * n1h) || it.floor_off != (uint32_t)(k * ch * fstride))
 				b->fast_dense = 0;
-			if (r.prev == -1 || (r.flags & LW_RF_TDONLY)) {
-				it.src_kind = LW_SRC_NONE; // (a TD-only packet is overlapped later, by k_ola_generic)
+			if (r.prev == -1 || (r.flags & LW_RF_TDONLY) || (r.xflags & LW_XF_EDGE_L)) {
+				it.src_kind = LW_SRC_NONE; // (a TD-only packet is overlapped later, by k_ola_generic; a short left slope by k_short)
 			} else if (r.prev <= -2) {
 				it.src_kind = LW_SRC_STATE;
 				it.src_arg = (uint32_t)(-(r.prev + 2));
-			} else if (b->h_recs[r.prev].flags & LW_RF_FAST) {
+			} else if ((b->h_recs[r.prev].flags & (LW_RF_FAST | LW_RF_LONG)) == (LW_RF_FAST | LW_RF_LONG)) {
 				if ((k % chunk) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev) {
 					it.src_kind = LW_SRC_LDS;
 					b->h_items[k - 1].flags |= LW_IF_NEXT_LDS;
@@ -559,6 +712,8 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 		HIP_TRY(hipMemcpyAsync(b->d_ola, b->h_ola, b->n_gen_ola * sizeof(LwOlaDesc), hipMemcpyHostToDevice, st));
 	if (b->n_gen_small)
 		HIP_TRY(hipMemcpyAsync(b->d_tasks, b->h_tasks, (size_t)b->n_gen_small * ch * sizeof(LwGenTask), hipMemcpyHostToDevice, st));
+	if (b->n_tasks)
+		HIP_TRY(hipMemcpyAsync(b->d_slots, b->h_slots, b->n_tasks * LW_SHORT_SLOTS * sizeof(LwShortSlot), hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
@@ -585,6 +740,13 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		return LW_OK;
 	const bool run_generic = b->has_generic || all_generic;
 	const bool run_fast = b->has_fast && !all_generic;
+	const bool run_short = b->n_tasks > 0 && !all_generic;
+	if (b->edge_mode && (run_fast || run_short) && !b->d_edge)
+		HIP_TRY(hipMalloc((void **)&b->d_edge, b->max_packets * 2 * d->T.ch * LW_EDGE_VALUES * sizeof(float)));
+	if (run_short && (b->has_generic || all_generic) && !b->d_td) { // (k_short may read / write td blocks next to generic packets)
+		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
+		HIP_TRY(hipMalloc((void **)&b->d_td, 2 * maxres * sizeof(float)));
+	}
 	if (run_generic) {
 		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
 		if (d->any_coupling && !b->d_decoupled)
@@ -644,11 +806,25 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.dense = b->fast_dense;
 		L.late_from = b->fast_late_from;
 		L.has_tdonly = b->has_tdonly ? 1u : 0u;
+		L.edge_mode = b->edge_mode ? 1u : 0u;
+		L.d_edge = b->d_edge;
 		for (size_t i = 0; i < d->fast.units.size() && i < LW_FAST_WAVES; i++)
 			L.units[i] = d->fast.units[i];
 		L.d_halo = b->d_halo;
 		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
+	}
+	if (run_short) {
+		LwShortLaunch S{};
+		S.d_image = d->d_short_image;
+		S.d_slots = b->d_slots;
+		S.n_tasks = (uint32_t)b->n_tasks;
+		S.n_units = (uint32_t)d->shortp.units.size();
+		for (size_t i = 0; i < d->shortp.units.size() && i < LW_FAST_WAVES; i++)
+			S.units[i] = d->shortp.units[i];
+		S.d_edge = b->d_edge;
+		HIP_TRY(lw_launch_short(d->T, B, S, d_out, b->fmt, st));
+		b->last_kernels += "k_short,";
 	}
 	if (run_generic) {
 		lw_launch_generic_ola(d->T, B, d_out, b->fmt, st, all_generic);

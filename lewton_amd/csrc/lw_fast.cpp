@@ -22,60 +22,61 @@ struct Writer {
 };
 } // namespace
 
-void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
+// The unit list of the modes with `blockflag` (shared by k_long and k_short): every such mode must use the same mapping shape
+// (mux, floors, coupling), coupling steps must be disjoint channel pairs, at most LW_FAST_MAX_FLOORS distinct floor-1
+// configurations of at most max_posts posts.  Returns nullptr, or why the stream shape is not covered.
+struct UnitPlan {
+	const Mapping *ref = nullptr;
+	std::vector<LwFastUnit> units;
+	std::vector<int> floor_slot; // per floor of the setup: staged slot or -1
+	uint32_t n_staged = 0;
+	uint8_t staged_F[LW_FAST_MAX_FLOORS] = {0};
+	uint8_t mode_mask[32] = {0};
+};
+
+static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, size_t max_posts, UnitPlan &up)
 {
-	plan = LwFastPlan();
-	if (id.bs1 != LW_FAST_BS) {
-		plan.why_not = "blocksize_1 is not 11";
-		return;
-	}
-	const uint32_t n = 1u << id.bs1, n2 = n / 2, n8 = n / 8;
 	const size_t ch = id.channels;
-	// every long mode must use the same mapping shape: same mux/floors/coupling
+	// every covered mode must use the same mapping shape: same mux/floors/coupling
 	const Mapping *ref = nullptr;
 	for (size_t m = 0; m < s.modes.size() && m < 256; m++) {
-		if (!s.modes[m].blockflag)
+		if ((bool)s.modes[m].blockflag != blockflag)
 			continue;
 		const Mapping &mp = s.mappings[s.modes[m].mapping];
-		if (!ref) {
+		if (!ref)
 			ref = &mp;
-		} else if (mp.mag != ref->mag || mp.ang != ref->ang || mp.mux != ref->mux || mp.submap_floor != ref->submap_floor) {
-			plan.why_not = "long modes with different mappings";
-			return;
-		}
-		plan.long_mode_mask[m >> 3] |= (uint8_t)(1u << (m & 7));
+		else if (mp.mag != ref->mag || mp.ang != ref->ang || mp.mux != ref->mux || mp.submap_floor != ref->submap_floor)
+			return blockflag ? "long modes with different mappings" : "short modes with different mappings";
+		up.mode_mask[m >> 3] |= (uint8_t)(1u << (m & 7));
 	}
-	if (!ref) {
-		plan.why_not = "no long mode";
-		return;
-	}
+	if (!ref)
+		return blockflag ? "no long mode" : "no short mode";
+	up.ref = ref;
 	// coupling steps must be disjoint pairs
 	std::vector<int> partner(ch, -1), role(ch, 0);
 	for (size_t k = 0; k < ref->mag.size(); k++) {
 		const int m = ref->mag[k], a = ref->ang[k];
-		if (partner[m] != -1 || partner[a] != -1) {
-			plan.why_not = "a channel takes part in more than one coupling step";
-			return;
-		}
+		if (partner[m] != -1 || partner[a] != -1)
+			return "a channel takes part in more than one coupling step";
 		partner[m] = a;
 		partner[a] = m;
 		role[m] = 1;
 		role[a] = 2;
 	}
 	// staged floors
-	std::vector<int> floor_slot(s.floors.size(), -1);
+	up.floor_slot.assign(s.floors.size(), -1);
 	auto slot_of = [&](size_t c) -> int {
 		const uint8_t fl = ref->submap_floor[ref->mux[c]];
-		if (floor_slot[fl] < 0) {
-			if (plan.n_staged_floors == LW_FAST_MAX_FLOORS)
+		if (up.floor_slot[fl] < 0) {
+			if (up.n_staged == LW_FAST_MAX_FLOORS)
 				return -1;
 			const Floor1 &f1 = s.floors[fl].f1;
-			if (s.floors[fl].type != 1 || f1.sorted_x.size() > 64)
+			if (s.floors[fl].type != 1 || f1.sorted_x.size() > max_posts)
 				return -1;
-			floor_slot[fl] = (int)plan.n_staged_floors;
-			plan.staged_floor_F[plan.n_staged_floors++] = (uint8_t)f1.sorted_x.size();
+			up.floor_slot[fl] = (int)up.n_staged;
+			up.staged_F[up.n_staged++] = (uint8_t)f1.sorted_x.size();
 		}
-		return floor_slot[fl];
+		return up.floor_slot[fl];
 	};
 	// Units: a coupling step's two channels share a wave (the inverse coupling needs both); the channels that are in no step
 	// are paired up two by two as well, without coupling -- a wave works through two channels as one software pipeline, a
@@ -103,34 +104,46 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 			pending_single = (int)c;
 			done[c] = true;
 			continue;
-		} else if (pending_single >= 0) {
+		} else {
 			u.ch_a = (int8_t)pending_single;
 			u.ch_b = (int8_t)c;
 			u.coupled = 0;
 			pending_single = -1;
 			done[c] = true;
-		} else {
-			u.ch_a = (int8_t)c;
-			u.ch_b = -1;
-			u.coupled = 0;
-			done[c] = true;
 		}
 		const int sa = slot_of((size_t)u.ch_a), sb = u.ch_b >= 0 ? slot_of((size_t)u.ch_b) : 0;
-		if (sa < 0 || sb < 0) {
-			plan.why_not = "more than two distinct floor configurations (or > 64 posts) in long blocks";
-			plan.units.clear();
-			return;
-		}
+		if (sa < 0 || sb < 0)
+			return blockflag ? "more than two distinct floor configurations (or > 64 posts) in long blocks"
+			                 : "more than two distinct floor configurations (or > 32 posts) in short blocks";
 		u.floor_a = (uint8_t)sa;
 		u.floor_b = (uint8_t)sb;
-		u.F_a = plan.staged_floor_F[sa];
-		u.F_b = plan.staged_floor_F[sb];
-		plan.units.push_back(u);
+		u.F_a = up.staged_F[sa];
+		u.F_b = up.staged_F[sb];
+		up.units.push_back(u);
 	}
-	if (plan.units.size() > LW_FAST_WAVES) {
-		plan.why_not = "more units than waves in a workgroup";
+	if (up.units.size() > LW_FAST_WAVES)
+		return "more units than waves in a workgroup";
+	return nullptr;
+}
+
+void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
+{
+	plan = LwFastPlan();
+	if (id.bs1 != LW_FAST_BS) {
+		plan.why_not = "blocksize_1 is not 11";
 		return;
 	}
+	const uint32_t n = 1u << id.bs1, n2 = n / 2, n8 = n / 8;
+	UnitPlan up;
+	if (const char *why = plan_units(id, s, true, 64, up)) {
+		plan.why_not = why;
+		return;
+	}
+	std::memcpy(plan.long_mode_mask, up.mode_mask, sizeof(plan.long_mode_mask));
+	plan.units = up.units;
+	plan.n_staged_floors = up.n_staged;
+	std::memcpy(plan.staged_floor_F, up.staged_F, sizeof(plan.staged_floor_F));
+	const std::vector<int> &floor_slot = up.floor_slot;
 
 	// ---- LDS image
 	const BlocksizeTables &t = id.tab[1];
@@ -229,6 +242,88 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 			o.total != LWI_TOTAL) {
 		plan.why_not = "LDS image layout differs from the kernel's compile-time layout (LWI_*)";
 		return;
+	}
+	plan.eligible = true;
+}
+
+void build_short_plan(const Ident &id, const Setup &s, const LwFastPlan &fast, LwShortPlan &plan)
+{
+	plan = LwShortPlan();
+	if (!fast.eligible) {
+		plan.why_not = "long blocks not covered by the specialised kernel";
+		return;
+	}
+	if (id.bs0 != LW_SHORT_BS) {
+		plan.why_not = "blocksize_0 is not 8";
+		return;
+	}
+	const uint32_t n = 1u << id.bs0, n2 = n / 2, n8 = n / 8, P = n / 4;
+	UnitPlan up;
+	if (const char *why = plan_units(id, s, false, LW_SHORT_MAX_POSTS, up)) {
+		plan.why_not = why;
+		return;
+	}
+	std::memcpy(plan.short_mode_mask, up.mode_mask, sizeof(plan.short_mode_mask));
+	plan.units = up.units;
+	plan.n_staged_floors = up.n_staged;
+	std::memcpy(plan.staged_floor_F, up.staged_F, sizeof(plan.staged_floor_F));
+	// ---- LDS image (index conventions of lw_fast.hpp: l = lane inside the block, 0..7)
+	const BlocksizeTables &t = id.tab[0];
+	const float *A = t.A.data(), *B = t.B.data(), *C = t.C.data(), *W = t.window.data();
+	plan.image.assign(LWS_TOTAL, 0);
+	auto f = [&](uint32_t off) { return reinterpret_cast<float *>(plan.image.data() + off); };
+	auto h = [&](uint32_t off) { return reinterpret_cast<uint16_t *>(plan.image.data() + off); };
+	std::memcpy(f(LWS_APAIR), A, n2 * 4);
+	for (uint32_t x = 0; x < 4; x++)
+		for (uint32_t l = 0; l < 8; l++) {
+			const uint32_t p = 8 * x + l, a = n2 - 4 - 4 * p; // imdct.rs:385-430
+			f(LWS_TW_S2)[2 * (8 * x + l)] = A[a];
+			f(LWS_TW_S2)[2 * (8 * x + l) + 1] = A[a + 1];
+		}
+	for (uint32_t b = 0; b < 2; b++)
+		for (uint32_t l = 0; l < 8; l++) {
+			const uint32_t r = 15 - 8 * b - l; // imdct.rs:445-446: A[8 r]
+			f(LWS_TW_L0)[2 * (8 * b + l)] = A[8 * r];
+			f(LWS_TW_L0)[2 * (8 * b + l) + 1] = A[8 * r + 1];
+		}
+	for (uint32_t l = 0; l < 8; l++) {
+		const uint32_t r = 7 - l; // imdct.rs:449-452: A[16 r]
+		f(LWS_TW_L1)[2 * l] = A[16 * r];
+		f(LWS_TW_L1)[2 * l + 1] = A[16 * r + 1];
+	}
+	f(LWS_A2)[0] = A[n8];
+	for (uint32_t c = 0; c < 2; c++)
+		for (uint32_t l = 0; l < 8; l++) {
+			const uint32_t mp = 2 * l + c, e = 8 * c + l;
+			for (uint32_t j = 0; j < 4; j++) {
+				f(LWS_C4)[4 * e + j] = C[4 * mp + j];
+				f(LWS_B_LO)[4 * e + j] = B[4 * mp + j];
+				f(LWS_B_HI)[4 * e + j] = B[4 * (P / 2 - 1 - mp) + j];
+			}
+			const uint32_t q[4] = {P - 1 - 2 * mp, P - 2 - 2 * mp, 1 + 2 * mp, 2 * mp};
+			for (uint32_t k = 0; k < 4; k++) {
+				f(LWS_WIN)[8 * e + 2 * k] = W[q[k]];
+				f(LWS_WIN)[8 * e + 2 * k + 1] = W[n2 - 1 - q[k]];
+			}
+		}
+	// (LWS_INV_DB is filled by the runtime: it owns the spec table)
+	for (size_t fl = 0; fl < s.floors.size(); fl++) {
+		const int slot = up.floor_slot[fl];
+		if (slot < 0)
+			continue;
+		const Floor1 &f1 = s.floors[fl].f1;
+		const size_t F = f1.sorted_x.size();
+		for (size_t i = 0; i < 64; i++)
+			f(LWS_XSF)[64 * slot + i] = i < F ? (float)f1.sorted_x[i] : std::numeric_limits<float>::infinity();
+		for (uint32_t x = 0; x < 4; x++)
+			for (uint32_t l = 0; l < 8; l++)
+				for (uint32_t j = 0; j < 4; j++) {
+					const uint32_t k = 4 * (8 * x + l) + j;
+					size_t sidx = 0; // largest s with xs[s] <= k (xs[0] = 0)
+					while (sidx + 1 < F && f1.sorted_x[sidx + 1] <= k)
+						sidx++;
+					h(LWS_SID16)[((slot * 4 + x) * 8 + l) * 4 + j] = (uint16_t)(16 * sidx);
+				}
 	}
 	plan.eligible = true;
 }

@@ -82,6 +82,9 @@ struct LwFastPlan {
 #define LW_SRC_TD 4u     // time-domain block at float offset src_arg of B.td (generic-kernel predecessor)
 
 #define LW_IF_NEXT_LDS 1u // the next item of the list takes this packet's right half through LDS
+#define LW_IF_EDGE_L 2u   // (edge mode: short blocks in k_short) short slope on the left: samples 128.. and the raw left edge from here
+#define LW_IF_EDGE_R 4u   // short slope on the right: samples up to 1472, the raw right edge / 128-sample state from here
+#define LW_IF_SILENT 8u   // no previous window: the packet yields no samples (audio.rs:1140-1152), also none past a short slope
 #define LW_IF_TDONLY 32u  // = LW_RF_TDONLY: no overlap-add here, the whole time-domain block goes to td
 
 // One work item of the specialised kernel = one packet; everything the kernel needs, in one 32-byte scalar load.
@@ -113,11 +116,96 @@ struct LwFastLaunch {
 	uint32_t dense;     // item k == packet k with uniform block sizes
 	uint32_t late_from; // first wave of a workgroup that issues its first HBM loads late
 	uint32_t has_tdonly; // some item is LW_IF_TDONLY
+	uint32_t edge_mode;  // the stream's short blocks run through k_short: EDGE instantiation, d_edge valid
+	float *d_edge;       // [packet][side][ch][64]
 	LwFastUnit units[LW_FAST_WAVES];
 	float *d_halo;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Short-block kernel k_short (n = 256 next to n = 2048): one wave = eight short blocks ("slots") of one unit, eight lanes per
+// block, the transform in registers with the layouts of k_long cut down to 64 complex pairs per block:
+//   B': lane = p[2:0], reg = p[5:3]   step 1, step 2, stages l = 0, 1     D': lane = p[5:3], reg = p[2:0]  fused last stages
+//   E': lane l of a block handles m' = 2 l + c (c = 0, 1): bit-reverse gather, step 7, step 8, window / overlap-add
+// ---------------------------------------------------------------------------------------------
+#define LW_SHORT_BS 8           // blocksize_0 the kernel is specialised for
+#define LW_SHORT_SLOTS 8        // blocks per wave
+#define LW_SHORT_MAX_POSTS 32   // floor-1 posts per short-block floor (4 per lane of a block)
+
+// byte offsets inside the short-block LDS image (compile-time layout, checked by build_short_plan)
+enum : uint32_t {
+	LWS_APAIR = 0,      // float2[64]          A as pairs: step 1 reads [m] and [63 - m]
+	LWS_TW_S2 = 512,    // float2[4][8]        step 2 twiddle of lower pair p = 8x + l: A[n/2 - 4 - 4p ..]
+	LWS_TW_L0 = 768,    // float2[2][8]        stage l = 0: A[8r ..], r = 15 - 8b - l
+	LWS_TW_L1 = 896,    // float2[8]           stage l = 1: A[16r ..], r = 7 - l
+	LWS_A2 = 960,       // float               A[n/8]
+	LWS_C4 = 976,       // float4[2][8]        C[4m' .. 4m'+3]
+	LWS_B_LO = 1232,    // float4[2][8]        B[4m' .. 4m'+3]
+	LWS_B_HI = 1488,    // float4[2][8]        B[4(31 - m') .. +3]
+	LWS_WIN = 1744,     // float[2][8][8]      window slope pairs (s[q], s[127 - q]) for q = 63-2m', 62-2m', 1+2m', 2m'
+	LWS_INV_DB = 2256,  // float[256]
+	LWS_XSF = 3280,     // float[LW_FAST_MAX_FLOORS][64]  ascending post x of each staged floor (padded with +inf)
+	LWS_SID16 = 3792,   // u16[LW_FAST_MAX_FLOORS][4][8][4] 16 * (static interval index) of bin 4(8x + l) + j
+	LWS_TOTAL = 5120    // 4304 padded: 64 lanes x 16 bytes x 5
+};
+
+struct LwShortPlan {
+	bool eligible = false;
+	const char *why_not = "";
+	std::vector<uint8_t> image;
+	uint8_t short_mode_mask[32] = {0};
+	std::vector<LwFastUnit> units;
+	uint32_t n_staged_floors = 0;
+	uint8_t staged_floor_F[LW_FAST_MAX_FLOORS] = {0};
+};
+
+// what a slot of k_short is
+#define LW_SS_IDLE 0u      // nothing
+#define LW_SS_BLOCK 1u     // a short block: transform, overlap-add with its predecessor's right part, samples out
+#define LW_SS_HALO 2u      // a short block whose right part the NEXT slot needs (its own samples are another slot's business)
+#define LW_SS_EDGE 3u      // no transform: the stored right part `prev` only feeds the long successor's short-slope overlap
+// where a slot's previous right part (64 values pb(0..63) per channel; the other 64 are their mirror image) comes from
+#define LW_SP_NONE 0u      // no previous window: no samples (audio.rs:1140-1152)
+#define LW_SP_LANE 1u      // the previous slot of the same wave
+#define LW_SP_STATE 2u     // state pool: prev_arg = slot, parity in flags
+#define LW_SP_EDGE 3u      // edge buffer entry prev_arg (right side) written by k_long for a long block with a short right slope
+#define LW_SP_TD 4u        // float offset prev_arg in B.td (channel 0), channel stride prev_stride: a generic-kernel predecessor
+#define LW_SF_WRITE_TD 2u     // also store the raw right part into this packet's td block (generic successor)
+
+// One slot = one 8-lane group of a k_short wave; 48 bytes (three 16-byte loads by every lane of the group).
+struct LwShortSlot {
+	uint32_t res_off;     // float offset of the packet's [ch][128] residue block
+	uint32_t floor_off;   // u16 offset of its floor block
+	uint32_t out_off;     // element offset of its output block
+	uint32_t prev_arg;    // see LW_SP_*
+	int32_t state_out;    // state slot that receives the raw right part (128 floats per channel), or -1
+	uint32_t next_edge;   // packet index of the long successor whose left edge is overlapped here (edge buffer entry), or 0xFFFFFFFF
+	uint32_t next_out;    // that successor's out_off
+	uint32_t next_m;      // samples per channel that successor yields (576 or 1024): channel stride of its planar output block
+	uint16_t prev_stride; // LW_SP_TD: channel stride of the source block
+	uint8_t kind;         // LW_SS_*
+	uint8_t prev_kind;    // LW_SP_*
+	uint32_t flags;       // LW_RF_PARITY_IN / LW_RF_PARITY_OUT (state pool) | LW_SF_*
+	uint32_t pkt;         // batch index (host bookkeeping)
+	uint32_t pad;
+};
+static_assert(sizeof(LwShortSlot) == 48, "LwShortSlot is 48 bytes");
+
+// floats per packet in the edge buffer: [side: 0 = left edge pa(448..511), 1 = right edge pb(448..511)][ch][64]
+#define LW_EDGE_VALUES 64u
+
+struct LwShortLaunch {
+	const uint8_t *d_image;
+	const LwShortSlot *d_slots; // [n_tasks][LW_SHORT_SLOTS]
+	uint32_t n_tasks;
+	uint32_t n_units;
+	LwFastUnit units[LW_FAST_WAVES];
+	float *d_edge;
 };
 
 namespace lw {
 // Decide whether the stream shape is covered by the specialised kernel and build its LDS image.
 void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan);
+// The same for the short blocks of a stream whose long blocks are covered (k_short).
+void build_short_plan(const Ident &id, const Setup &s, const LwFastPlan &fast, LwShortPlan &plan);
 }

@@ -99,3 +99,6 @@ void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out,
 // Specialised long-block path (lw_kernels_long.hip): optional halo pre-pass + main pass.
 struct LwFastLaunch;
 hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
+// Short blocks of such streams (k_short, same translation unit); runs after lw_launch_long (it reads the edge buffer).
+struct LwShortLaunch;
+hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st);

@@ -64,6 +64,7 @@ struct LwFastArgs {
 	float *state;              // state pool [slots][2][ch][n1/2]
 	float *td;                 // time-domain blocks of the generic kernels
 	float *halo;               // [slots][ch][512]
+	float *edge;               // EDGE kernels: [packet][side][ch][64] raw edges of long blocks with short slopes (lw_fast.hpp)
 	void *out;
 	uint32_t state_stride, state_chan_stride;
 };
@@ -345,6 +346,7 @@ struct ItemRegs {
 	uint32_t res_off, floor_off, out_off, src_arg;
 	int32_t state_out;
 	uint32_t halo_out, src_kind, flags;
+	uint32_t pkt; // batch index of the packet: its entry in the edge buffer (EDGE instantiation only)
 };
 
 struct Pref {          // what one wave loads from HBM for one item
@@ -1094,9 +1096,10 @@ __device__ __forceinline__ void store_interleaved2(const LwFastArgs &F, uint32_t
 }
 
 // ---- window + overlap-add (audio.rs:1116-1118), sample conversion (samples.rs:92-103), stores of one channel
+// (mch = samples per channel of the packet's output block: 1024 unless the block has a short right slope, EDGE kernels)
 template <int FMT>
 __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, uint32_t lane, int chn,
-		uint32_t out_off, const float2_t (&Rc)[2][4], const PrevHalf &h)
+		uint32_t out_off, const float2_t (&Rc)[2][4], const PrevHalf &h, uint32_t mch = 1024u)
 {
 	// (out[q], out[1023-q]) = (pa s[q] + pb' s[r], -pa s[r] + pb' s[q]), times 32768 for the i16 formats
 	float2_t O[2][4];
@@ -1110,7 +1113,7 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 	//            [512+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [1020-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
 	const uint32_t p0 = 4u * lane, p1 = 508u - 4u * lane, p2 = 512u + 4u * lane, p3 = 1020u - 4u * lane;
 	if (FMT == LW_OUT_F32_PLANAR) {
-		float *o = reinterpret_cast<float *>(F.out) + out_off + (uint32_t)chn * 1024u;
+		float *o = reinterpret_cast<float *>(F.out) + out_off + (uint32_t)chn * mch;
 		store16_wt(o + p0, float4_t{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x});
 		store16_wt(o + p1, float4_t{O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x});
 		store16_wt(o + p2, float4_t{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y});
@@ -1132,7 +1135,7 @@ __device__ __forceinline__ void ola_store(const LwFastArgs &F, const char *img, 
 				short2_t s;
 				uint32_t u;
 			} a, b;
-			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn * 1024u;
+			int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off + (uint32_t)chn * mch;
 			{
 			a.s = __builtin_amdgcn_cvt_pk_i16(iq[0][3], iq[0][2]);
 			b.s = __builtin_amdgcn_cvt_pk_i16(iq[1][3], iq[1][2]);
@@ -1196,6 +1199,38 @@ __device__ __forceinline__ void store_right_half(float *dst, uint32_t lane, floa
 	store16_wt(dst + 1020u - 4u * lane, hi1);
 }
 
+// ---- four consecutive un-windowed samples of one channel (audio.rs:1119: positions past the overlap are copied), converted
+//      and stored at sample index `rel` of the packet's output block (EDGE kernels: long blocks next to short ones)
+template <int FMT>
+__device__ __forceinline__ void store_quad(const LwFastArgs &F, int chn, uint32_t out_off, uint32_t mch, uint32_t rel, float4_t v, bool valid)
+{
+	if (!valid)
+		return;
+	if (FMT == LW_OUT_F32_PLANAR) {
+		store16_wt(reinterpret_cast<float *>(F.out) + out_off + (uint32_t)chn * mch + rel, v);
+		return;
+	}
+	typedef short short2_t __attribute__((ext_vector_type(2)));
+	const float2_t k = float2_t{32768.0f, 32768.0f};
+	const float2_t lo = pk_mul(float2_t{v.x, v.y}, k), hi = pk_mul(float2_t{v.z, v.w}, k); // samples.rs:92-103
+	union {
+		short2_t s;
+		uint32_t u;
+	} a, b;
+	a.s = __builtin_amdgcn_cvt_pk_i16((int)lo.x, (int)lo.y);
+	b.s = __builtin_amdgcn_cvt_pk_i16((int)hi.x, (int)hi.y);
+	int16_t *o = reinterpret_cast<int16_t *>(F.out) + out_off;
+	if (FMT == LW_OUT_I16_PLANAR) {
+		store_pcm8(o + (uint32_t)chn * mch + rel, a.u, b.u);
+	} else {
+		uint32_t off = rel * F.ch + (uint32_t)chn;
+		o[off] = a.s.x;
+		o[off + F.ch] = a.s.y;
+		o[off + 2u * F.ch] = b.s.x;
+		o[off + 3u * F.ch] = b.s.y;
+	}
+}
+
 // One work item = one 32-byte scalar load (the vector-memory path would park it in eight VGPRs per item).  In registers
 // every field is a full dword: byte-sized struct members make hipcc copy the item byte by byte when it is carried from
 // one round to the next.
@@ -1215,6 +1250,7 @@ __device__ __forceinline__ ItemRegs load_item(const LwFastItem *items, uint32_t 
 	it.halo_out = v[5];
 	it.src_kind = v[6] & 0xffu;
 	it.flags = (v[6] >> 16) & 0xffu;
+	it.pkt = v[7];
 	return it;
 }
 
@@ -1254,7 +1290,10 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t byte_addr, uint32_t need)
 
 // TD: the batch contains LW_IF_TDONLY items (long blocks next to short ones): a separate instantiation, so that the
 // all-(1,1) batches keep the kernel without that branch (its presence alone cost 2 % of the headline launch time)
-template <int FMT, bool RIGHT_ONLY, bool TD = false>
+// EDGE: the batch's short blocks run through k_short (lw_fast.hpp): long blocks with a short slope on either side
+// (LW_IF_EDGE_L / LW_IF_EDGE_R) do everything but the 128-sample overlap with the short neighbour here -- the samples past a
+// short slope are copied un-windowed (audio.rs:1119), the raw edges pa(448..511) / pb(448..511) go to the edge buffer.
+template <int FMT, bool RIGHT_ONLY, bool TD = false, bool EDGE = false>
 __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1424,6 +1463,10 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 					}
 			} else {
 				__builtin_amdgcn_s_setprio(LW_PRIO_FINISH); // finish: hand-over, overlap-add, stores
+				// EDGE kernels: geometry of a long block with a short slope on the left (window starts at 448, the first 128
+				// samples are k_short's) and / or on the right (samples up to 1472, 128-sample right part)
+				const bool edge_l = EDGE && (it.flags & LW_IF_EDGE_L), edge_r = EDGE && (it.flags & LW_IF_EDGE_R);
+				const uint32_t e_ls = edge_l ? 448u : 0u, e_m = EDGE ? (edge_r ? 1472u : 1024u) - e_ls : 1024u;
 				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
 				if (it.flags & LW_IF_NEXT_LDS) {
 					lds_wait_ge(LW_CNT_ACK(wave), n_pub_used);
@@ -1484,7 +1527,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 									prev_from_lds(src + 2048 * c, lane, ph);
 								else
 									prev_from_global(g + (uint32_t)chn[c] * cstride, lane, ph);
-								ola_store<FMT>(F, img, lane, chn[c], it.out_off, R[c], ph);
+								ola_store<FMT>(F, img, lane, chn[c], it.out_off, R[c], ph, e_m);
 							}
 					}
 					if (src) {
@@ -1492,8 +1535,41 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 						lds_store_u32(LW_CNT_ACK(wprev), n_got);
 					}
 				}
+				if (EDGE && (edge_l || edge_r)) {
+					// ---- short slopes: the un-windowed samples past them, the raw edges for k_short, the 128-sample state
+#pragma unroll
+					for (int c = 0; c < 2; c++)
+						if (c == 0 || two) {
+							const bool inner = lane >= 16u; // this lane's q in [508 - 4 lane, +4) lies below 448
+							const bool sound = !(it.flags & LW_IF_SILENT); // (the first packet of a stream yields no samples at all)
+							float *edge = F.edge + ((size_t)it.pkt * 2u * F.ch + (uint32_t)chn[c]) * LW_EDGE_VALUES;
+							if (edge_l) {
+								// cur[1023 - q] = -pa(q) for q < 448 (imdct.rs:589-658), positions 576..1023 -> samples 128..575
+								const float4_t lo0 = LW_PA_LO0(c), lo1 = LW_PA_LO1(c);
+								store_quad<FMT>(F, chn[c], it.out_off, e_m, 1020u - 4u * lane - 448u, float4_t{-lo0.w, -lo0.z, -lo0.y, -lo0.x}, sound);
+								store_quad<FMT>(F, chn[c], it.out_off, e_m, 512u + 4u * lane - 448u, float4_t{-lo1.w, -lo1.z, -lo1.y, -lo1.x}, sound && inner);
+								if (!inner) // raw left edge pa(448 + i), i = 60 - 4 lane ..
+									store16_wt(edge + 60u - 4u * lane, lo1);
+							}
+							if (edge_r) {
+								// cur[1024 + q] = pb(q) for q < 448: positions 1024..1471
+								const float4_t lo0 = LW_PB_LO0(c), lo1 = LW_PB_LO1(c);
+								store_quad<FMT>(F, chn[c], it.out_off, e_m, 1024u + 4u * lane - e_ls, lo0, sound);
+								store_quad<FMT>(F, chn[c], it.out_off, e_m, 1532u - 4u * lane - e_ls, lo1, sound && inner);
+								if (!inner) { // raw right part cur[1472 .. 1600): pb(448 + i), then mirrored
+									store16_wt(edge + (size_t)F.ch * LW_EDGE_VALUES + 60u - 4u * lane, lo1);
+									if (it.state_out >= 0) {
+										float *dst = F.state + ((size_t)it.state_out * 2 + ((it.flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride +
+											(uint32_t)chn[c] * F.state_chan_stride;
+										store16_wt(dst + 60u - 4u * lane, lo1);
+										store16_wt(dst + 64u + 4u * lane, float4_t{lo1.w, lo1.z, lo1.y, lo1.x});
+									}
+								}
+							}
+						}
+				}
 				// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
-				const bool to_state = it.state_out >= 0, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
+				const bool to_state = it.state_out >= 0 && !edge_r, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
 				if (to_state || to_td) {
 #pragma unroll
 					for (int c = 0; c < 2; c++)
@@ -1539,6 +1615,417 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_short: short blocks (n = 256) of streams whose long blocks run through k_long
+// ---------------------------------------------------------------------------------------------
+// One wave64 = one workgroup = eight "slots" (8 lanes each) x one unit (a coupled channel pair, or one channel): eight short
+// blocks from their entropy records to PCM, no barrier, no communication with other waves.  The transform is k_long's,
+// cut down to 64 complex pairs per block (layouts B' / D' / E' of lw_fast.hpp; tests/short_model.py is the executable
+// specification): step 1 on the coalesced load layout, exchange with the mirror lane of the 8-lane group (DPP
+// row_half_mirror), step 2 and stages l = 0, 1 register-local, ONE 8 x 8 register <-> lane transpose (t3_inreg), the fused
+// last three stages register-local, the bit-reverse gather through 512 bytes of LDS per block, steps 7 and 8, window /
+// overlap-add, conversion, stores.  A slot's previous right part comes from the previous slot of the same wave (through
+// LDS: consecutive short blocks of a stream sit in consecutive slots), from the stream's state slot, from the edge
+// buffer k_long fills for long blocks with a short right slope, or from a generic predecessor's time-domain block.  A
+// slot whose successor is a long block with a short LEFT slope also does that block's first 128 samples (its raw left
+// edge pa(448..511) comes from the edge buffer; k_long runs before this kernel), so neither kernel waits for the other
+// inside a launch and no time-domain block makes a round trip through HBM.
+// Floor curve: as in k_long (interval entries {dy, 0.5 sgn(dy) - x0 dy, 1/adx, 4 y0} per post, y(k) = y0 + trunc((k dy +
+// c0) / adx) -- tests/test_fast_model.py), with the 8 lanes of a slot building the <= 32 entries of each channel: the
+// active-post mask of a slot is one byte of a wave-wide ballot per group of 8 posts.
+#define LWK_REC_BYTES (LW_SHORT_SLOTS * 2u * LW_SHORT_MAX_POSTS * 2u)   // floor records  [slot][channel][32] u16
+#define LWK_TAB_BYTES (LW_SHORT_SLOTS * 2u * LW_SHORT_MAX_POSTS * 16u)  // interval entries [slot][channel][32] x 16 bytes
+#define LWK_SCR_BYTES (LW_SHORT_SLOTS * 64u * 8u)                       // bit-reverse gather of one channel: [slot][64] pairs
+#define LWK_PUB_BYTES (LW_SHORT_SLOTS * 2u * 2u * 8u * 16u)             // right parts [slot][channel][c2][l] float4
+#define LWK_OFF_REC LWS_TOTAL
+#define LWK_OFF_TAB (LWK_OFF_REC + LWK_REC_BYTES)
+#define LWK_OFF_SCR (LWK_OFF_TAB + LWK_TAB_BYTES)
+#define LWK_OFF_PUB (LWK_OFF_SCR + LWK_SCR_BYTES)
+#define LWK_LDS_BYTES (LWK_OFF_PUB + LWK_PUB_BYTES)
+
+struct LwShortArgs {
+	const float *residue;
+	const uint16_t *floors;
+	const LwShortSlot *slots;
+	const uint8_t *image;
+	float *state, *td, *edge;
+	void *out;
+	uint32_t n_units, ch, fstride, state_stride, state_chan_stride;
+	LwFastUnit units[LW_FAST_WAVES];
+};
+
+// the 4 + 4 values a lane holds of a [64]-float half block q = 0..63 (pa or pb): lo = q in [4l, 4l+4), hi = q in [60-4l, 64-4l)
+struct Half8 {
+	float4_t lo, hi;
+};
+
+__device__ __forceinline__ Half8 load_half8(const float *src, uint32_t l)
+{
+	Half8 h;
+	h.lo = *reinterpret_cast<const float4_t *>(src + 4u * l);
+	h.hi = *reinterpret_cast<const float4_t *>(src + 60u - 4u * l);
+	return h;
+}
+
+// previous right part as the overlap-add consumes it (see prev_from_global)
+__device__ __forceinline__ void prev_from_half8(const Half8 &g, PrevHalf &h)
+{
+	h.pp[0][1] = float2_t{g.lo.y, g.lo.x};
+	h.pp[1][1] = float2_t{g.lo.w, g.lo.z};
+	h.pp[1][0] = float2_t{g.hi.y, g.hi.x};
+	h.pp[0][0] = float2_t{g.hi.w, g.hi.z};
+}
+
+// interval entries of one channel of this lane's slot: posts i = l + 8 t (see floor_table for the entry)
+__device__ __forceinline__ bool short_floor_table(const char *img, char *rec, char *tab, uint32_t g, uint32_t l, const uint32_t (&e)[4],
+		uint32_t fslot, uint32_t Fp, bool has_floor)
+{
+	uint32_t mask = 0;
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const unsigned long long bal = __ballot(has_floor && (e[t] & LW_POST_ACTIVE) != 0);
+		mask |= ((uint32_t)(bal >> (8u * g)) & 0xffu) << (8 * t);
+		const uint32_t i = l + 8u * t;
+		*reinterpret_cast<uint16_t *>(rec + 2u * i) = (uint16_t)e[t];
+	}
+	const unsigned long long ub = __ballot(l == 0 && e[0] == LW_FLOOR_UNUSED);
+	const bool unused = !has_floor || ((ub >> (8u * g)) & 1ull) != 0;
+	lds_fence();
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const uint32_t i = l + 8u * t;
+		const uint32_t lowmask = (2u << i) - 1u; // (i = 31: 2u << 31 wraps to 0, the mask becomes all ones)
+		const uint32_t below = mask & lowmask, above = mask & ~lowmask;
+		const int lo = below ? 31 - __builtin_clz(below) : 0;
+		const int hi = above ? __builtin_ctz(above) : lo;
+		const int ylo = (int)(*reinterpret_cast<const uint16_t *>(rec + 2 * lo) & 0xffu);
+		const int yhi = (int)(*reinterpret_cast<const uint16_t *>(rec + 2 * hi) & 0xffu);
+		const float xlo = *reinterpret_cast<const float *>(img + LWS_XSF + 4u * (64u * fslot + (uint32_t)lo));
+		const float xhi = *reinterpret_cast<const float *>(img + LWS_XSF + 4u * (64u * fslot + (uint32_t)hi));
+		const float dy = (float)(yhi - ylo); // 0 when there is no later active post (flat, audio.rs:546-548)
+		float4_t ent;
+		ent.x = dy;
+		ent.y = __builtin_copysignf(0.5f, dy) - xlo * dy; // exact
+		ent.z = above ? __builtin_amdgcn_rcpf(xhi - xlo) : 1.0f;
+		ent.w = __int_as_float(ylo << 2);
+		if (i < Fp)
+			*reinterpret_cast<float4_t *>(tab + 16u * i) = ent;
+	}
+	return unused;
+}
+
+// floor x residue of one channel of this lane's slot, in place (audio.rs:1035-1037); bins 4 (8 x + l) + j
+__device__ __forceinline__ void short_spectrum(const char *img, const char *tab, uint32_t l, uint32_t fslot, bool unused, float4_t (&r)[4])
+{
+	const float kf0 = (float)(4 * (int)l);
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		const uint2_t sw = *reinterpret_cast<const uint2_t *>(img + LWS_SID16 + 8u * ((fslot * 4 + x) * 8u + l));
+		const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
+		float4_t fl;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const float4_t ent = lds4(tab, s16[j]);
+			const float z = __builtin_fmaf(kf0 + (float)(32 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^15
+			const int q = (int)(z * ent.z);
+			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
+			fl[j] = *reinterpret_cast<const float *>(img + LWS_INV_DB + idx);
+		}
+		if (unused)
+			fl = float4_t{0.0f, 0.0f, 0.0f, 0.0f}; // zero floor (audio.rs:1021-1024): 0.0 x residue keeps the residue's sign
+		const float2_t lo2 = pk_mul(float2_t{fl.x, fl.y}, float2_t{r[x].x, r[x].y});
+		const float2_t hi2 = pk_mul(float2_t{fl.z, fl.w}, float2_t{r[x].z, r[x].w});
+		r[x] = float4_t{lo2.x, lo2.y, hi2.x, hi2.y};
+	}
+}
+
+// the transform of one channel of the wave's eight blocks: spectrum r (load layout) -> R[c2][k] = (pa, pb) at
+// q = 63 - 2m', 62 - 2m', 1 + 2m', 2m' for m' = 2 l + c2 (imdct.rs:291-659)
+__device__ __forceinline__ void short_imdct(const char *img, char *scr, uint32_t g, uint32_t l, const float4_t (&r)[4], float2_t (&R)[2][4])
+{
+	float2_t au[4], al[4], s2[4], l0[2], l1;
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		const uint32_t m = 8u * x + l;
+		au[x] = lds2(img + LWS_APAIR, 8u * m);         // (A[2m], A[2m+1])
+		al[x] = lds2(img + LWS_APAIR, 8u * (63u - m)); // (A[126-2m], A[127-2m])
+		s2[x] = lds2(img + LWS_TW_S2, 8u * m);
+	}
+	l0[0] = lds2(img + LWS_TW_L0, 8u * l);
+	l0[1] = lds2(img + LWS_TW_L0, 8u * (8u + l));
+	l1 = lds2(img + LWS_TW_L1, 8u * l);
+	float2_t Q[8], U[4];
+	step1x2(r[0], au[0], al[0], r[1], au[1], al[1], U[0], Q[0], U[1], Q[1]);
+	step1x2(r[2], au[2], al[2], r[3], au[3], al[3], U[2], Q[2], U[3], Q[3]);
+#pragma unroll
+	for (int x = 0; x < 4; x++) { // pair 63 - m lives on the mirror lane of the 8-lane group (DPP row_half_mirror)
+		Q[7 - x].x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(U[x].x), 0x141, 0xf, 0xf, false));
+		Q[7 - x].y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(U[x].y), 0x141, 0xf, 0xf, false));
+	}
+	bfly2x4(Q[4], Q[0], s2[0], Q[5], Q[1], s2[1], Q[6], Q[2], s2[2], Q[7], Q[3], s2[3]); // step 2 (imdct.rs:385-430)
+	bfly2x4(Q[2], Q[0], l0[0], Q[6], Q[4], l0[0], Q[3], Q[1], l0[1], Q[7], Q[5], l0[1]); // l = 0
+	bfly2x4(Q[1], Q[0], l1, Q[3], Q[2], l1, Q[5], Q[4], l1, Q[7], Q[6], l1);             // l = 1
+	t3_inreg(Q);                                                                         // B' -> D'
+	const float a2s = *reinterpret_cast<const float *>(img + LWS_A2);
+	stage_d_block(float2_t{a2s, a2s}, Q);                                                // imdct.rs:234-288
+	char *blk = scr + 512u * g;
+#pragma unroll
+	for (int zz = 0; zz < 8; zz++)
+		*reinterpret_cast<float2_t *>(blk + 8u * (8u * l + zz)) = Q[zz];
+	lds_fence();
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) { // bit-reverse gather (imdct.rs:490-528), step 7 (:533-580), step 8 (:589-658)
+		const uint32_t v = __builtin_bitreverse32(2u * l + c2) >> 28;
+		const float2_t pq = lds2(blk, 8u * (2u * v)), pq32 = lds2(blk, 8u * (2u * v + 32u));
+		const float2_t p31 = lds2(blk, 8u * (31u - 2u * v)), p63 = lds2(blk, 8u * (63u - 2u * v));
+		const float4_t Cq = lds4(img + LWS_C4, 16u * (8u * c2 + l));
+		const float4_t Bl = lds4(img + LWS_B_LO, 16u * (8u * c2 + l)), Bh = lds4(img + LWS_B_HI, 16u * (8u * c2 + l));
+		step78_block(p63, pq, p31, pq32, Cq, Bl, Bh, R[c2]);
+	}
+	lds_fence();
+}
+
+// window + overlap-add (audio.rs:1116-1118) of the 128 samples of one channel of this lane's slot, conversion
+// (samples.rs:92-103), stores.  R[c2][k].x = raw left half at q_k, h = the previous right part; `o` = element 0 of the
+// channel's samples; stride = distance of consecutive samples (1: planar, ch: interleaved)
+template <int FMT>
+__device__ __forceinline__ void short_ola_store(const char *img, uint32_t l, void *out, uint32_t elem0, uint32_t stride,
+		const float2_t (&Rc)[2][4], const PrevHalf &h)
+{
+	float2_t O[2][4];
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) {
+		const float4_t w0 = lds4(img + LWS_WIN, 32u * (8u * c2 + l));
+		const float4_t w1 = lds4(img + LWS_WIN, 32u * (8u * c2 + l) + 16u);
+		ola_block<FMT != LW_OUT_F32_PLANAR>(Rc[c2], h.pp[c2][0], h.pp[c2][1], w0, w1, O[c2]);
+	}
+	// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [60-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
+	//            [64+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [124-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
+	const uint32_t pos[4] = {4u * l, 60u - 4u * l, 64u + 4u * l, 124u - 4u * l};
+	const float v[4][4] = {{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x}, {O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x},
+		{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y}, {O[1][2].y, O[1][3].y, O[0][2].y, O[0][3].y}};
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		if (FMT == LW_OUT_F32_PLANAR) {
+			store16_wt(reinterpret_cast<float *>(out) + elem0 + pos[q], float4_t{v[q][0], v[q][1], v[q][2], v[q][3]});
+		} else {
+			// samples.rs:92-103: x * 32768 (done in ola_block), truncate toward zero (v_cvt_i32_f32: saturating, NaN -> 0), clamp
+			// to i16 by the saturating pack
+			typedef short short2_t __attribute__((ext_vector_type(2)));
+			union {
+				short2_t s;
+				uint32_t u;
+			} a, b;
+			a.s = __builtin_amdgcn_cvt_pk_i16((int)v[q][0], (int)v[q][1]);
+			b.s = __builtin_amdgcn_cvt_pk_i16((int)v[q][2], (int)v[q][3]);
+			int16_t *o = reinterpret_cast<int16_t *>(out) + elem0;
+			if (FMT == LW_OUT_I16_PLANAR) {
+				store_pcm8(o + pos[q], a.u, b.u);
+			} else {
+				uint32_t off = pos[q] * stride;
+				o[off] = a.s.x;
+				o[off + stride] = a.s.y;
+				o[off + 2u * stride] = b.s.x;
+				o[off + 3u * stride] = b.s.y;
+			}
+		}
+	}
+}
+
+// raw right part (128 floats: pb(q) for q ascending, then mirrored) of one channel to a state slot / td block
+__device__ __forceinline__ void short_store_right(float *dst, uint32_t l, const float2_t (&Rc)[2][4])
+{
+	const float4_t lo0 = float4_t{Rc[0][3].y, Rc[0][2].y, Rc[1][3].y, Rc[1][2].y}; // q = 4l ..
+	const float4_t lo1 = float4_t{Rc[1][1].y, Rc[1][0].y, Rc[0][1].y, Rc[0][0].y}; // q = 60 - 4l ..
+	store16_wt(dst + 4u * l, lo0);
+	store16_wt(dst + 60u - 4u * l, lo1);
+	store16_wt(dst + 64u + 4u * l, float4_t{lo1.w, lo1.z, lo1.y, lo1.x});
+	store16_wt(dst + 124u - 4u * l, float4_t{lo0.w, lo0.z, lo0.y, lo0.x});
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(64) k_short(LwShortArgs F)
+{
+	__shared__ __attribute__((aligned(16))) char smem[LWK_LDS_BYTES];
+	const uint32_t lane = threadIdx.x, g = lane >> 3, l = lane & 7u;
+	const uint32_t task = blockIdx.x / F.n_units, uidx = blockIdx.x - task * F.n_units;
+	const LwFastUnit un = F.units[uidx];
+	const bool two = un.ch_b >= 0;
+	const uint32_t chn[2] = {(uint32_t)un.ch_a, (uint32_t)(two ? un.ch_b : un.ch_a)};
+	// ---- slot descriptor (all lanes of a group read the same 48 bytes) and the table image
+	const uint4 *sp = reinterpret_cast<const uint4 *>(F.slots + ((size_t)task * LW_SHORT_SLOTS + g));
+	const uint4 d0 = sp[0], d1 = sp[1], d2 = sp[2];
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(F.image);
+		uint4 *dst = reinterpret_cast<uint4 *>(smem);
+		uint4 v[LWS_TOTAL / 1024];
+#pragma unroll
+		for (uint32_t k = 0; k < LWS_TOTAL / 1024; k++)
+			v[k] = src[lane + 64u * k];
+#pragma unroll
+		for (uint32_t k = 0; k < LWS_TOTAL / 1024; k++)
+			dst[lane + 64u * k] = v[k];
+	}
+	const uint32_t res_off = d0.x, floor_off = d0.y, out_off = d0.z, prev_arg = d0.w;
+	const int32_t state_out = (int32_t)d1.x;
+	const uint32_t next_edge = d1.y, next_out = d1.z, next_m = d1.w;
+	const uint32_t prev_stride = d2.x & 0xffffu, kind = (d2.x >> 16) & 0xffu, prev_kind = d2.x >> 24, flags = d2.y;
+	const bool has_block = kind == LW_SS_BLOCK || kind == LW_SS_HALO;
+	// ---- HBM loads, all at once: floor records, residues, the previous right part and the successor's left edge
+	uint32_t fe[2][4];
+	float4_t r[2][4];
+	Half8 prv[2], nxt[2];
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+		const bool on = c == 0 || two;
+		const uint32_t Fp = c == 0 ? un.F_a : un.F_b;
+		const uint16_t *f = F.floors + floor_off + chn[c] * F.fstride;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const uint32_t i = l + 8u * t;
+			fe[c][t] = on && has_block && i < Fp ? (uint32_t)f[i] : 0u;
+		}
+		const float4_t *s = reinterpret_cast<const float4_t *>(F.residue + res_off + chn[c] * 128u);
+#pragma unroll
+		for (int x = 0; x < 4; x++)
+			r[c][x] = on && has_block ? __builtin_nontemporal_load(&s[8 * x + l]) : float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+		const float *pbase = F.state;
+		uint32_t poff = 0;
+		if (prev_kind == LW_SP_STATE) {
+			poff = (prev_arg * 2u + ((flags & LW_RF_PARITY_IN) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride;
+		} else if (prev_kind == LW_SP_EDGE) {
+			pbase = F.edge;
+			poff = ((prev_arg * 2u + 1u) * F.ch + chn[c]) * LW_EDGE_VALUES;
+		} else if (prev_kind == LW_SP_TD) {
+			pbase = F.td;
+			poff = prev_arg + chn[c] * prev_stride;
+		}
+		prv[c].lo = prv[c].hi = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+		if (on && prev_kind >= LW_SP_STATE)
+			prv[c] = load_half8(pbase + poff, l);
+		nxt[c].lo = nxt[c].hi = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+		if (on && next_edge != 0xFFFFFFFFu)
+			nxt[c] = load_half8(F.edge + ((size_t)next_edge * 2u * F.ch + chn[c]) * LW_EDGE_VALUES, l);
+	}
+	const char *img = smem;
+	char *scr = smem + LWK_OFF_SCR, *pub = smem + LWK_OFF_PUB;
+	lds_fence();
+	// ---- floor curves (interval entries by lanes = posts), inverse coupling, floor x residue
+	bool unused[2] = {true, true};
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+		if (c == 1 && !two)
+			break;
+		char *rec = smem + LWK_OFF_REC + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 2u);
+		char *tab = smem + LWK_OFF_TAB + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 16u);
+		unused[c] = short_floor_table(img, rec, tab, g, l, fe[c], c == 0 ? un.floor_a : un.floor_b, c == 0 ? un.F_a : un.F_b, has_block);
+	}
+	lds_fence();
+	if (two && un.coupled) {
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+			float m[4] = {r[0][x].x, r[0][x].y, r[0][x].z, r[0][x].w};
+			float a[4] = {r[1][x].x, r[1][x].y, r[1][x].z, r[1][x].w};
+			decouple4(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
+			r[0][x] = float4_t{m[0], m[1], m[2], m[3]};
+			r[1][x] = float4_t{a[0], a[1], a[2], a[3]};
+		}
+	}
+	float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb)
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+		if (c == 1 && !two)
+			break;
+		const char *tab = smem + LWK_OFF_TAB + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 16u);
+		short_spectrum(img, tab, l, c == 0 ? un.floor_a : un.floor_b, unused[c], r[c]);
+		short_imdct(img, scr, g, l, r[c], R[c]);
+		if (kind == LW_SS_EDGE) { // no block of its own: the stored right part stands in for it (feeds the successor's left edge)
+			R[c][0][3].y = prv[c].lo.x, R[c][0][2].y = prv[c].lo.y, R[c][1][3].y = prv[c].lo.z, R[c][1][2].y = prv[c].lo.w;
+			R[c][1][1].y = prv[c].hi.x, R[c][1][0].y = prv[c].hi.y, R[c][0][1].y = prv[c].hi.z, R[c][0][0].y = prv[c].hi.w;
+		}
+		// right part for the next slot of the wave: [slot][channel][c2][l] float4 = pb at k = 0..3
+#pragma unroll
+		for (int c2 = 0; c2 < 2; c2++)
+			*reinterpret_cast<float4_t *>(pub + 16u * (((g * 2u + c) * 2u + c2) * 8u + l)) =
+				float4_t{R[c][c2][0].y, R[c][c2][1].y, R[c][c2][2].y, R[c][c2][3].y};
+	}
+	lds_fence();
+	// ---- window / overlap-add / stores of the slot's own samples; state; the successor's left edge
+	const uint32_t esz_stride = FMT == LW_OUT_I16_INTERLEAVED ? F.ch : 1u;
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+		if (c == 1 && !two)
+			break;
+		if (kind == LW_SS_BLOCK && prev_kind != LW_SP_NONE) {
+			PrevHalf ph;
+			if (prev_kind == LW_SP_LANE) {
+#pragma unroll
+				for (int c2 = 0; c2 < 2; c2++) {
+					const float4_t v = *reinterpret_cast<const float4_t *>(pub + 16u * ((((g - 1u) * 2u + c) * 2u + c2) * 8u + l));
+					ph.pp[c2][0] = float2_t{v.x, v.y};
+					ph.pp[c2][1] = float2_t{v.z, v.w};
+				}
+			} else {
+				prev_from_half8(prv[c], ph);
+			}
+			const uint32_t e0 = FMT == LW_OUT_I16_INTERLEAVED ? out_off + chn[c] : out_off + chn[c] * 128u;
+			short_ola_store<FMT>(img, l, F.out, e0, esz_stride, R[c], ph);
+		}
+		if (kind == LW_SS_BLOCK && state_out >= 0)
+			short_store_right(F.state + ((size_t)state_out * 2u + ((flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride +
+					chn[c] * F.state_chan_stride, l, R[c]);
+		if (kind == LW_SS_BLOCK && (flags & LW_SF_WRITE_TD))
+			short_store_right(F.td + 2u * (size_t)res_off + chn[c] * 256u + 128u, l, R[c]);
+		if (next_edge != 0xFFFFFFFFu && (kind == LW_SS_BLOCK || kind == LW_SS_EDGE)) {
+			// the long successor's first 128 samples: its raw left edge pa(448 + i) against this slot's right part, short slope
+			float2_t Rn[2][4];
+			Rn[0][3].x = nxt[c].lo.x, Rn[0][2].x = nxt[c].lo.y, Rn[1][3].x = nxt[c].lo.z, Rn[1][2].x = nxt[c].lo.w;
+			Rn[1][1].x = nxt[c].hi.x, Rn[1][0].x = nxt[c].hi.y, Rn[0][1].x = nxt[c].hi.z, Rn[0][0].x = nxt[c].hi.w;
+			PrevHalf ph;
+#pragma unroll
+			for (int c2 = 0; c2 < 2; c2++) {
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					Rn[c2][k].y = 0.0f;
+				ph.pp[c2][0] = float2_t{R[c][c2][0].y, R[c][c2][1].y};
+				ph.pp[c2][1] = float2_t{R[c][c2][2].y, R[c][c2][3].y};
+			}
+			const uint32_t e0 = FMT == LW_OUT_I16_INTERLEAVED ? next_out + chn[c] : next_out + chn[c] * next_m;
+			short_ola_store<FMT>(img, l, F.out, e0, esz_stride, Rn, ph);
+		}
+	}
+}
+
+hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st)
+{
+	if (L.n_tasks == 0)
+		return hipSuccess;
+	LwShortArgs F{};
+	F.residue = B.residue;
+	F.floors = B.floors;
+	F.slots = L.d_slots;
+	F.image = L.d_image;
+	F.state = B.state;
+	F.td = B.td;
+	F.edge = L.d_edge;
+	F.out = out;
+	F.n_units = L.n_units;
+	F.ch = T.ch;
+	F.fstride = T.fstride;
+	F.state_stride = T.state_stride;
+	F.state_chan_stride = T.state_chan_stride;
+	for (uint32_t u = 0; u < L.n_units && u < LW_FAST_WAVES; u++)
+		F.units[u] = L.units[u];
+	const dim3 grid(L.n_tasks * L.n_units), block(64);
+	if (fmt == LW_OUT_I16_PLANAR)
+		hipLaunchKernelGGL((k_short<LW_OUT_I16_PLANAR>), grid, block, 0, st, F);
+	else if (fmt == LW_OUT_I16_INTERLEAVED)
+		hipLaunchKernelGGL((k_short<LW_OUT_I16_INTERLEAVED>), grid, block, 0, st, F);
+	else
+		hipLaunchKernelGGL((k_short<LW_OUT_F32_PLANAR>), grid, block, 0, st, F);
+	return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
 hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st)
@@ -1555,6 +2042,7 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 	F.state_chan_stride = T.state_chan_stride;
 	F.n_units = L.n_units;
 	F.halo = L.d_halo;
+	F.edge = L.d_edge;
 	F.out = out;
 	const size_t lds = LW_LDS_BYTES + LW_STAMP_LDS_EXTRA;
 	for (uint32_t w = 0; w < LW_FAST_WAVES; w++) {
@@ -1569,7 +2057,8 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 			(const void *)k_long<LW_OUT_I16_ITL_STEREO, false>, (const void *)k_long<LW_OUT_F32_PLANAR, false>,
 			(const void *)k_long<LW_OUT_I16_PLANAR, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, true>,
 			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, true>, (const void *)k_long<LW_OUT_I16_ITL_STEREO, false, true>,
-			(const void *)k_long<LW_OUT_F32_PLANAR, false, true>};
+			(const void *)k_long<LW_OUT_F32_PLANAR, false, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, false, true>,
+			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true>};
 		for (const void *f : fns) {
 			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			if (e != hipSuccess) {
@@ -1596,7 +2085,10 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 		F.late_from = L.late_from;
 #define LW_LAUNCH_MAIN(F_)                                                                                     \
 	do {                                                                                                      \
-		if (L.has_tdonly) {                                                                                   \
+		if (L.edge_mode) {                                                                                    \
+			hipLaunchKernelGGL((k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true>), dim3(grid), \
+					dim3(LW_WG), lds, st, F);                                                                  \
+		} else if (L.has_tdonly) {                                                                            \
 			hipLaunchKernelGGL((k_long<F_, false, true>), dim3(grid), dim3(LW_WG), lds, st, F);                \
 		} else {                                                                                              \
 			hipLaunchKernelGGL((k_long<F_, false, false>), dim3(grid), dim3(LW_WG), lds, st, F);               \

@@ -43,12 +43,16 @@ struct LwPacketRec {
 	uint8_t bs;         // log2(n)
 	uint8_t mode;       // mode number
 	uint8_t flags;      // LW_RF_*; bit 6: state_out parity, bit 7: state-in parity
-	uint8_t reserved;
+	uint8_t xflags;     // LW_XF_* (host planning only)
 };                      // samples per channel = (prev == -1) ? 0 : rs - ls
 
 #ifdef __cplusplus
 static_assert(sizeof(LwPacketRec) == 32, "LwPacketRec must stay 32 bytes");
 #endif
+
+// rec.xflags: long blocks of streams whose short blocks run through k_short (values of LW_IF_EDGE_* in lw_fast.hpp)
+#define LW_XF_EDGE_L 2u        // short slope on the left
+#define LW_XF_EDGE_R 4u        // short slope on the right
 
 #define LW_RF_PARITY_OUT 64u
 #define LW_RF_PARITY_IN 128u

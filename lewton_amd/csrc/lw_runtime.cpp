@@ -290,6 +290,28 @@ size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, 
 	return plan.image.size();
 }
 
+size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint8_t *units8, size_t *n_units)
+{
+	if (!id || !s)
+		return 0;
+	LwFastPlan fast;
+	lw::build_fast_plan(*id->p, *s->p, fast);
+	LwShortPlan plan;
+	lw::build_short_plan(*id->p, *s->p, fast, plan);
+	if (!plan.eligible)
+		return 0;
+	std::memcpy(plan.image.data() + LWS_INV_DB, kInverseDbTable, sizeof(float) * 256);
+	if (dst)
+		std::memcpy(dst, plan.image.data(), std::min(cap, plan.image.size()));
+	if (units8 && n_units) {
+		const size_t n = std::min(*n_units, plan.units.size());
+		std::memcpy(units8, plan.units.data(), n * sizeof(LwFastUnit));
+	}
+	if (n_units)
+		*n_units = plan.units.size();
+	return plan.image.size();
+}
+
 int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bits, size_t bits_len, uint32_t *syms,
 		size_t max_syms, size_t *n_syms)
 {
@@ -505,6 +527,17 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			return nullptr;
 		}
 	}
+	lw::build_short_plan(id, s, d->fast, d->shortp);
+	if (d->shortp.eligible) {
+		std::memcpy(d->shortp.image.data() + LWS_INV_DB, kInverseDbTable, sizeof(float) * 256);
+		if (!lw_hip_ok(hipMalloc((void **)&d->d_short_image, d->shortp.image.size()), "hipMalloc(short image)") ||
+				!lw_hip_ok(hipMemcpy(d->d_short_image, d->shortp.image.data(), d->shortp.image.size(), hipMemcpyHostToDevice),
+					"hipMemcpy(short image)")) {
+			*err = LW_ERR_DEVICE;
+			(void)hipFree(d->d_blob);
+			return nullptr;
+		}
+	}
 	return d.release();
 }
 
@@ -528,6 +561,8 @@ void lw_decoder_destroy(lw_decoder *d)
 		(void)hipFree(d->d_fast_image);
 	if (d->d_fast_units)
 		(void)hipFree(d->d_fast_units);
+	if (d->d_short_image)
+		(void)hipFree(d->d_short_image);
 	delete d;
 }
 

@@ -191,7 +191,7 @@ def test_batch_many_streams_matches_oracle(name):
                 assert np.array_equal(t.view(np.uint32), ref.view(np.uint32)), key
         for s in range(n_streams):
             assert np.array_equal(pwrs[s].data().view(np.uint32), o_pwrs[s].data(ch).view(np.uint32))
-    assert any(k in batch.last_kernels for k in ("k_imdct_generic", "k_long", "k_small_fused"))
+    assert any(k in batch.last_kernels for k in ("k_imdct_generic", "k_long", "k_short"))
 
 
 def _decode_batch(setup, items_streams, fmt="i16", force_generic=False, batch=None, rounds=0):
@@ -303,8 +303,8 @@ def test_full_size_batch_properties():
 @pytest.mark.parametrize("fmt", ["i16", "f32"])
 def test_long_mixed_single_stream_in_one_batch(name, pattern, fmt):
     """ONE stream, 700 packets in one batch: chunks of the specialised kernel joined by the halo pre-pass, LDS hand-over
-    inside the chunks, long blocks next to short ones split between the specialised kernel (IMDCT) and the generic
-    overlap-add, short blocks on the generic path -- against the oracle, packet by packet."""
+    inside the chunks, long blocks with short slopes split between k_long (everything but the 128-sample overlap) and
+    k_short (the short blocks and that overlap) -- against the oracle, packet by packet."""
     from lewton_amd.batch import Batch
     setup = ALL_SETUPS[name]()
     audio, ident, st = _product(setup)
@@ -317,7 +317,7 @@ def test_long_mixed_single_stream_in_one_batch(name, pattern, fmt):
     res = b.entropy([(p, pwr) for p in pk], n_threads=4)
     b.upload()
     got = b.split(b.synth_to_host(), ch)
-    assert "k_long" in b.last_kernels and "k_ola_generic" in b.last_kernels
+    assert "k_long" in b.last_kernels and "k_short" in b.last_kernels and "generic" not in b.last_kernels
     for i, p in enumerate(pk):
         want = po.read_audio_packet(o_id, o_st, p, o_pwr, fmt)
         assert res[i][0] == 0 and got[i].shape == want.shape, i

@@ -53,7 +53,7 @@ def _run_dense(key, fmt="i16", packets=4096):
 def test_configs2_mixed_short_long_bench_shape(fmt):
     bad, kernels, n = _run_dense("3", fmt)
     assert n == 4096 and bad == 0, (bad, kernels)
-    assert "k_long" in kernels
+    assert kernels == "k_long,k_short"      # two launches, no generic kernel, no time-domain block through HBM
 
 
 @pytest.mark.parametrize("fmt", ["i16", "f32"])
