@@ -1632,6 +1632,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 // Floor curve: as in k_long (interval entries {dy, 0.5 sgn(dy) - x0 dy, 1/adx, 4 y0} per post, y(k) = y0 + trunc((k dy +
 // c0) / adx) -- tests/test_fast_model.py), with the 8 lanes of a slot building the <= 32 entries of each channel: the
 // active-post mask of a slot is one byte of a wave-wide ballot per group of 8 posts.
+#define LW_SHORT_SPLIT_BELOW 1024u // waves (tasks x units) below which a launch splits channel pairs over two waves
 #define LWK_REC_BYTES (LW_SHORT_SLOTS * 2u * LW_SHORT_MAX_POSTS * 2u)   // floor records  [slot][channel][32] u16
 #define LWK_TAB_BYTES (LW_SHORT_SLOTS * 2u * LW_SHORT_MAX_POSTS * 16u)  // interval entries [slot][channel][32] x 16 bytes
 #define LWK_SCR_BYTES (LW_SHORT_SLOTS * 64u * 8u)                       // bit-reverse gather of one channel: [slot][64] pairs
@@ -1851,6 +1852,12 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	const LwFastUnit un = F.units[uidx];
 	const bool two = un.ch_b >= 0;
 	const uint32_t chn[2] = {(uint32_t)un.ch_a, (uint32_t)(two ? un.ch_b : un.ch_a)};
+	// Small launches split a channel pair over two waves (un.slot = the one channel this wave finishes, 0xFF = both): the
+	// launch lasts as long as one wave's dependent chain, and past the inverse coupling the channels need nothing from each
+	// other.  Both waves load both residue vectors (a coupled pair) and decouple; each does floor, transform and samples
+	// of its own channel only.
+	const uint32_t only = un.slot;
+	const bool mine[2] = {only != 1u, two && only != 0u};
 	// ---- slot descriptor (all lanes of a group read the same 48 bytes) and the table image
 	const uint4 *sp = reinterpret_cast<const uint4 *>(F.slots + ((size_t)task * LW_SHORT_SLOTS + g));
 	const uint4 d0 = sp[0], d1 = sp[1], d2 = sp[2];
@@ -1876,7 +1883,8 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	Half8 prv[2], nxt[2];
 #pragma unroll
 	for (int c = 0; c < 2; c++) {
-		const bool on = c == 0 || two;
+		const bool on = mine[c];
+		const bool need_res = (c == 0 || two) && (on || un.coupled); // (the partner's vector: for the inverse coupling only)
 		const uint32_t Fp = c == 0 ? un.F_a : un.F_b;
 		const uint16_t *f = F.floors + floor_off + chn[c] * F.fstride;
 #pragma unroll
@@ -1887,7 +1895,7 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 		const float4_t *s = reinterpret_cast<const float4_t *>(F.residue + res_off + chn[c] * 128u);
 #pragma unroll
 		for (int x = 0; x < 4; x++)
-			r[c][x] = on && has_block ? __builtin_nontemporal_load(&s[8 * x + l]) : float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+			r[c][x] = need_res && has_block ? __builtin_nontemporal_load(&s[8 * x + l]) : float4_t{0.0f, 0.0f, 0.0f, 0.0f};
 		const float *pbase = F.state;
 		uint32_t poff = 0;
 		if (prev_kind == LW_SP_STATE) {
@@ -1913,8 +1921,8 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	bool unused[2] = {true, true};
 #pragma unroll
 	for (int c = 0; c < 2; c++) {
-		if (c == 1 && !two)
-			break;
+		if (!mine[c])
+			continue;
 		char *rec = smem + LWK_OFF_REC + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 2u);
 		char *tab = smem + LWK_OFF_TAB + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 16u);
 		unused[c] = short_floor_table(img, rec, tab, g, l, fe[c], c == 0 ? un.floor_a : un.floor_b, c == 0 ? un.F_a : un.F_b, has_block);
@@ -1933,8 +1941,8 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb)
 #pragma unroll
 	for (int c = 0; c < 2; c++) {
-		if (c == 1 && !two)
-			break;
+		if (!mine[c])
+			continue;
 		const char *tab = smem + LWK_OFF_TAB + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 16u);
 		short_spectrum(img, tab, l, c == 0 ? un.floor_a : un.floor_b, unused[c], r[c]);
 		short_imdct(img, scr, g, l, r[c], R[c]);
@@ -1953,8 +1961,8 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	const uint32_t esz_stride = FMT == LW_OUT_I16_INTERLEAVED ? F.ch : 1u;
 #pragma unroll
 	for (int c = 0; c < 2; c++) {
-		if (c == 1 && !two)
-			break;
+		if (!mine[c])
+			continue;
 		if (kind == LW_SS_BLOCK && prev_kind != LW_SP_NONE) {
 			PrevHalf ph;
 			if (prev_kind == LW_SP_LANE) {
@@ -2013,9 +2021,22 @@ hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwSh
 	F.fstride = T.fstride;
 	F.state_stride = T.state_stride;
 	F.state_chan_stride = T.state_chan_stride;
-	for (uint32_t u = 0; u < L.n_units && u < LW_FAST_WAVES; u++)
-		F.units[u] = L.units[u];
-	const dim3 grid(L.n_tasks * L.n_units), block(64);
+	// a launch of few waves splits channel pairs over two waves each (see the kernel)
+	const bool split = (size_t)L.n_tasks * L.n_units <= LW_SHORT_SPLIT_BELOW && 2 * L.n_units <= LW_FAST_WAVES;
+	uint32_t nu = 0;
+	for (uint32_t u = 0; u < L.n_units && u < LW_FAST_WAVES; u++) {
+		if (split && L.units[u].ch_b >= 0) {
+			F.units[nu] = L.units[u];
+			F.units[nu++].slot = 0;
+			F.units[nu] = L.units[u];
+			F.units[nu++].slot = 1;
+		} else {
+			F.units[nu] = L.units[u];
+			F.units[nu++].slot = 0xFF;
+		}
+	}
+	F.n_units = nu;
+	const dim3 grid(L.n_tasks * nu), block(64);
 	if (fmt == LW_OUT_I16_PLANAR)
 		hipLaunchKernelGGL((k_short<LW_OUT_I16_PLANAR>), grid, block, 0, st, F);
 	else if (fmt == LW_OUT_I16_INTERLEAVED)
