@@ -319,6 +319,15 @@ def main():
                 e2e_obj["device_entropy"]["large_batches"] = dict({k: r_[k] for k in keys}, packets_per_batch=big)
             except Exception as e:
                 e2e_obj["device_entropy"] = {"error": repr(e)}
+            try:   # one process, every GPU of the node (lw_sharder_*: a staging ring per device, streams sharded stream_id mod G,
+                   # no collective); a one-GPU box runs two logical shards on the same device
+                ndev = max(1, N_.lw_device_count())
+                devs = list(range(ndev)) if ndev > 1 else [0, 0]
+                r_ = e2e_mod.measure_sharder(ident, st, pool, devs, n_calls=max(8, args.e2e_batches // 4), packets_per_shard=PACKETS_PER_BATCH,
+                                             streams_per_shard=S, threads=0, samples=args.format, device_entropy=True)
+                e2e_obj["sharder"] = r_
+            except Exception as e:
+                e2e_obj["sharder"] = {"error": repr(e)}
         except Exception as e:
             e2e_obj = {"error": repr(e)}
 

@@ -217,6 +217,7 @@ int lw_ring_release(lw_ring *r);
 int lw_ring_drain(lw_ring *r);
 size_t lw_ring_slots(const lw_ring *r);
 size_t lw_ring_in_flight(lw_ring *r); /* slots staged, launched or collected and not yet released */
+size_t lw_ring_last_staged_elems(lw_ring *r); /* elements the batch staged last will produce (known after lw_ring_stage) */
 int lw_ring_set_entropy_on_device(lw_ring *r, int on); /* lw_batch_set_entropy_on_device for every slot (ring must be idle) */
 const char *lw_ring_last_kernels(const lw_ring *r);
 /* The host half of a PreviousWindowRight (whether a right part is stored, its length, which of the two device buffers
@@ -235,11 +236,17 @@ size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0
  * Streams never exchange data (audio.rs:919 touches only its own pwr): shard g owns the streams with stream_id mod G == g.
  * A shard = one lw_decoder on devices[g] (tables + the state pool of its streams in that GPU's HBM), one batch with pinned
  * staging, one HIP stream, one worker thread.  devices[] may name a device several times (logical shards).
- * lw_sharder_decode takes packets of any streams (those of one stream in stream order), runs every shard's host entropy
- * stage, H2D, kernels and D2H on the shard's own thread and device, all shards at once, and returns when the last one is
- * done: no collective, nothing crosses xGMI.  out = host memory for cap_elems elements; results[i] (status, n_samples,
- * out_offset = element offset of packet i's block in out) come back in the order of pkts; blocks are laid out shard by
- * shard.  LW_ERR_CAPACITY: more than max_packets_per_shard packets for one shard, or out too small.
+ * A shard runs on a staging ring of its own (lw_ring_*: pinned records and pinned PCM per slot).
+ * lw_sharder_submit takes packets of any streams (those of one stream in stream order), has every shard run the host
+ * entropy stage of its packets and queue H2D, kernels and D2H on the shard's own thread and device, all shards at once,
+ * and returns when every shard has launched -- while the GPUs work (no collective, nothing crosses xGMI).  The packet
+ * bytes are consumed when it returns.  *out_elems = elements the call will produce.  Up to 3 calls may be in flight, so
+ * the host stage of call k+1 overlaps the GPU work of call k on every device.
+ * lw_sharder_collect waits for the OLDEST call: out = host memory for cap_elems elements; results[i] (status, n_samples,
+ * out_offset = element offset of packet i's block in out) come back in the order of that call's pkts; blocks are laid out
+ * shard by shard.  LW_ERR_CAPACITY: more than max_packets_per_shard packets for one shard, three calls already in flight
+ * (submit), nothing in flight or out too small (collect: nothing is consumed).
+ * lw_sharder_decode = submit + collect on an empty pipeline.
  * The process-per-GPU form of the same rule is lewton_amd/shard.py + bench.py under torch.distributed.run. */
 typedef struct lw_sharder lw_sharder;
 typedef struct lw_shard_stream lw_shard_stream; /* one logical stream: its PreviousWindowRight lives on the owning shard */
@@ -260,6 +267,14 @@ void lw_sharder_stream_close(lw_shard_stream *st);
 void lw_sharder_stream_reset(lw_shard_stream *st); /* `pwr = PreviousWindowRight::new()` */
 int lw_sharder_decode(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int n_threads_per_shard, void *out,
 		size_t cap_elems, lw_packet_result *results);
+int lw_sharder_submit(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int n_threads_per_shard, size_t *out_elems);
+int lw_sharder_collect(lw_sharder *sh, void *out, size_t cap_elems, lw_packet_result *results, size_t n_results);
+size_t lw_sharder_in_flight(lw_sharder *sh); /* calls submitted and not yet collected */
+/* Zero-copy form of collect: the oldest call's PCM stays where the GPUs' copy engines put it, in the shards' pinned ring
+ * buffers -- pcm[g] / elems[g] for shard g (arrays of lw_sharder_shards() entries); results[i].out_offset is relative to
+ * the block of the shard that owns packet i (lw_sharder_shard_of).  Valid until lw_sharder_release, which frees the slots. */
+int lw_sharder_collect_pinned(lw_sharder *sh, lw_packet_result *results, size_t n_results, const void **pcm, size_t *elems);
+int lw_sharder_release(lw_sharder *sh);
 
 /* ---- Ogg container either side of the path ---------------------------- */
 /* lewton reads Ogg through the external crate `ogg` 0.8.0 (Cargo.lock; `PacketReader`, `Packet`) and wraps it

@@ -129,6 +129,7 @@ SYMBOLS = {
     "lw_ring_drain": (C.c_int, [C.c_void_p]),
     "lw_ring_slots": (C.c_size_t, [C.c_void_p]),
     "lw_ring_in_flight": (C.c_size_t, [C.c_void_p]),
+    "lw_ring_last_staged_elems": (C.c_size_t, [C.c_void_p]),
     "lw_ring_set_entropy_on_device": (C.c_int, [C.c_void_p, C.c_int]),
     "lw_ring_last_kernels": (C.c_char_p, [C.c_void_p]),
     "lw_sharder_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_size_t, C.c_size_t, C.c_int, intp]),
@@ -142,6 +143,11 @@ SYMBOLS = {
     "lw_sharder_stream_reset": (None, [C.c_void_p]),
     "lw_sharder_decode": (C.c_int, [C.c_void_p, C.POINTER(ShardPacket), C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                     C.POINTER(PacketResult)]),
+    "lw_sharder_submit": (C.c_int, [C.c_void_p, C.POINTER(ShardPacket), C.c_size_t, C.c_int, szp]),
+    "lw_sharder_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(PacketResult), C.c_size_t]),
+    "lw_sharder_in_flight": (C.c_size_t, [C.c_void_p]),
+    "lw_sharder_collect_pinned": (C.c_int, [C.c_void_p, C.POINTER(PacketResult), C.c_size_t, C.POINTER(C.c_void_p), szp]),
+    "lw_sharder_release": (C.c_int, [C.c_void_p]),
     "lw_pwr_get_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
     "lw_pwr_set_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
     "lw_decoder_device": (C.c_int, [C.c_void_p]),

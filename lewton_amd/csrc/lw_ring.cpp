@@ -302,6 +302,15 @@ const char *lw_ring_last_kernels(const lw_ring *r)
 	return lw_batch_last_kernels(r->slots[i].batch);
 }
 
+/* elements the most recently staged batch will produce (known once lw_ring_stage has planned it; no GPU involved) */
+size_t lw_ring_last_staged_elems(lw_ring *r)
+{
+	if (!r)
+		return 0;
+	std::lock_guard<std::mutex> g(r->mu);
+	return r->slots[(r->i_stage + r->slots.size() - 1) % r->slots.size()].out_elems;
+}
+
 uint64_t lw_ring_slot_algorithmic_bytes(const lw_ring *r)
 {
 	if (!r)

@@ -2,10 +2,10 @@
 //
 // A stream's decode touches only its own PreviousWindowRight and the immutable headers (audio.rs:919), so streams never
 // exchange data: shard g owns the streams with stream_id mod G == g (BASELINE configs[4]).  A shard = one device
-// context (lw_decoder: tables and the state pool of its streams in that GPU's HBM), one batch with pinned staging, one HIP
-// stream and one worker thread.  lw_sharder_decode splits a list of packets by owner, runs every shard's host entropy stage,
-// H2D, kernels and D2H on its own thread and device -- all shards at once, no collective, nothing crossing xGMI -- and
-// returns when the last shard is done.  A device may be listed several times (logical shards): that is how the N > 1 logic
+// context (lw_decoder: tables and the state pool of its streams in that GPU's HBM), one staging ring (pinned records and pinned
+// PCM per slot, a HIP stream per slot) and one worker thread.  lw_sharder_submit splits a list of packets by owner and has every
+// shard stage (host entropy decode) and launch (H2D, kernels, D2H, asynchronous) its part on its own thread and device -- all
+// shards at once, no collective, nothing crossing xGMI; lw_sharder_collect waits for the oldest call.  A device may be listed several times (logical shards): that is how the N > 1 logic
 // is tested on a one-GPU box.  The process-per-GPU form (bench.py under torch.distributed.run) uses the same rule through
 // lewton_amd/shard.py; this is the single-process form INTEGRATION.md section 3 describes.
 #include "../../include/lewton_amd.h"
@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -29,87 +30,159 @@ struct lw_shard_stream {
 
 namespace {
 
-struct Shard {
-	int device = 0;
-	lw_decoder *dec = nullptr;
-	lw_batch *batch = nullptr;
-	hipStream_t stream = nullptr;
-	std::thread worker;
-	// work of the current call
-	std::vector<size_t> idx;       // positions (in the caller's packet list) of this shard's packets, in list order
+// what one lw_sharder_submit call put on one shard
+struct Part {
+	std::vector<size_t> idx;        // positions (in the caller's packet list) of this shard's packets, in list order
 	std::vector<lw_packet> pk;
 	size_t out_elems = 0, base = 0; // elements this shard produces / where its first block starts in the caller's buffer
 	int rc = LW_OK;
+	bool launched = false;          // a ring slot holds this part (must be collected and released)
+};
+
+struct Call {
+	std::vector<Part> parts;        // one per shard
+	size_t n = 0, total_elems = 0;
+	int n_threads = 0;
+	// collect phase
+	void *out = nullptr;
+	lw_packet_result *results = nullptr;
+	bool keep = false;              // zero-copy collect: the slots stay with the call until lw_sharder_release
+	const void **pcm = nullptr;     // zero-copy collect: per shard, the pinned PCM of its slot
+	size_t *elems = nullptr;
+	bool collected = false;
+};
+
+enum JobKind { JOB_STAGE, JOB_COLLECT, JOB_RELEASE };
+
+struct Job {
+	JobKind kind;
+	Call *call;
+};
+
+struct Shard {
+	size_t index = 0;
+	int device = 0;
+	lw_decoder *dec = nullptr;
+	lw_ring *ring = nullptr;        // pinned records + pinned PCM per slot, H2D / kernels / D2H asynchronous on the slot's stream
+	std::thread worker;
+	std::deque<Job> jobs;           // guarded by lw_sharder::mu
 };
 
 } // namespace
+
+// Every shard runs on a staging ring (lw_ring_*): lw_sharder_submit has each shard's worker thread run the host entropy stage
+// of its packets into the next ring slot and queue H2D, kernels and D2H (into the slot's PINNED PCM buffer) without waiting;
+// it returns when every shard has staged and launched, i.e. while all GPUs work.  The caller's next submit therefore
+// overlaps every shard's host stage of call k+1 with the GPU work of call k on all devices -- no GPU idles through the
+// host phase of a call, which is what the lock-step form of round 2 did.  lw_sharder_collect waits for the oldest call,
+// copies each shard's PCM from pinned memory into the caller's buffer (the shards' workers, in parallel) and frees the
+// slots.  Up to LW_SHARD_SLOTS calls may be in flight.
+#define LW_SHARD_SLOTS 3
+
+extern "C" size_t lw_ring_last_staged_elems(lw_ring *r); // lw_ring.cpp
 
 struct lw_sharder {
 	std::vector<std::unique_ptr<Shard>> shards;
 	size_t max_packets = 0;
 	int fmt = 0;
 	size_t esz = 2;
-	// one call at a time; the workers walk through phase 1 (host entropy stage) and phase 2 (device) of it
 	std::mutex mu;
-	std::condition_variable cv;
-	uint64_t phase = 0;     // 2 * call + {1, 2}; the workers run phase p when they see phase == p
-	size_t done = 0;        // workers that finished the current phase
+	std::condition_variable cv;     // jobs arrive (workers) / jobs finish (callers)
 	bool quit = false;
-	int n_threads = 0;
-	void *out = nullptr;
-	std::mutex call_mu;     // serialises lw_sharder_decode callers
-	uint64_t call_no = 0;
+	size_t pending = 0;             // jobs of the call being waited for that have not finished
+	std::mutex call_mu;             // serialises the public calls
+	std::deque<std::unique_ptr<Call>> calls; // submitted and not yet collected, oldest first (guarded by call_mu)
 
-	void run_phase(Shard &s, bool device_phase)
+	void stage(Shard &s, Call &c)
 	{
-		if (!device_phase) {
-			s.rc = LW_OK;
-			s.out_elems = 0;
-			if (s.pk.empty())
-				return;
-			s.rc = lw_batch_entropy(s.batch, s.pk.data(), s.pk.size(), n_threads);
-			if (s.rc == LW_OK)
-				s.out_elems = lw_batch_out_elems(s.batch);
+		Part &p = c.parts[s.index];
+		p.rc = LW_OK;
+		p.out_elems = 0;
+		p.launched = false;
+		if (p.pk.empty())
+			return;
+		p.rc = lw_ring_stage(s.ring, p.pk.data(), p.pk.size(), c.n_threads);
+		if (p.rc != LW_OK)
+			return;
+		p.rc = lw_ring_launch(s.ring);
+		if (p.rc != LW_OK) {
+			(void)lw_ring_drain(s.ring); // (a device failure: nothing of this shard survives it)
 			return;
 		}
-		if (s.pk.empty() || s.rc != LW_OK)
+		p.launched = true;
+		// sample counts and offsets are known once the batch is planned (lw_ring_stage): the sizes need no GPU
+		p.out_elems = lw_ring_last_staged_elems(s.ring);
+	}
+
+	void collect(Shard &s, Call &c)
+	{
+		Part &p = c.parts[s.index];
+		if (!p.launched)
 			return;
-		if (hipSetDevice(s.device) != hipSuccess) {
-			s.rc = LW_ERR_DEVICE;
-			return;
+		const lw_packet_result *r = nullptr;
+		const void *pcm = nullptr;
+		size_t n = 0, elems = 0;
+		int rc = lw_ring_collect(s.ring, &r, &n, &pcm, &elems);
+		if (rc == LW_OK) {
+			if (c.out && elems)
+				std::memcpy((char *)c.out + p.base * esz, pcm, elems * esz);
+			for (size_t k = 0; k < p.idx.size() && k < n; k++) {
+				c.results[p.idx[k]] = r[k];
+				if (!c.keep) // (zero-copy form: offsets stay relative to the shard's own block)
+					c.results[p.idx[k]].out_offset += p.base;
+			}
+			if (c.keep) {
+				c.pcm[s.index] = pcm;
+				c.elems[s.index] = elems;
+			} else {
+				rc = lw_ring_release(s.ring);
+			}
 		}
-		s.rc = lw_batch_upload(s.batch, s.stream);
-		if (s.rc == LW_OK) // kernels -> internal device buffer -> D2H straight into the caller's buffer at this shard's base
-			s.rc = lw_batch_synth_to_host(s.batch, (char *)out + s.base * esz, s.out_elems, s.stream);
+		if (rc != LW_OK)
+			p.rc = rc;
+	}
+
+	void release(Shard &s, Call &c)
+	{
+		Part &p = c.parts[s.index];
+		if (p.launched && lw_ring_release(s.ring) != LW_OK && p.rc == LW_OK)
+			p.rc = LW_ERR_DEVICE;
 	}
 
 	void worker_main(Shard *s)
 	{
 		(void)hipSetDevice(s->device);
-		uint64_t seen = 0;
 		for (;;) {
-			uint64_t p;
+			Job j;
 			{
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&]() { return quit || phase != seen; });
+				cv.wait(g, [&]() { return quit || !s->jobs.empty(); });
 				if (quit)
 					return;
-				p = seen = phase;
+				j = s->jobs.front();
+				s->jobs.pop_front();
 			}
-			run_phase(*s, (p & 1) == 0);
+			if (j.kind == JOB_STAGE)
+				stage(*s, *j.call);
+			else if (j.kind == JOB_COLLECT)
+				collect(*s, *j.call);
+			else
+				release(*s, *j.call);
 			std::unique_lock<std::mutex> g(mu);
-			done++;
+			pending--;
 			cv.notify_all();
 		}
 	}
 
-	void all_workers(uint64_t p)
+	// one job per shard, wait for all of them
+	void all_workers(JobKind kind, Call *c)
 	{
 		std::unique_lock<std::mutex> g(mu);
-		phase = p;
-		done = 0;
+		pending = shards.size();
+		for (auto &s : shards)
+			s->jobs.push_back(Job{kind, c});
 		cv.notify_all();
-		cv.wait(g, [&]() { return done == shards.size(); });
+		cv.wait(g, [&]() { return pending == 0; });
 	}
 };
 
@@ -132,13 +205,13 @@ lw_sharder *lw_sharder_create(const lw_ident *id, const lw_setup *setup, const i
 	sh->esz = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
 	for (size_t g = 0; g < n_shards; g++) {
 		auto s = std::make_unique<Shard>();
+		s->index = g;
 		s->device = devices[g];
 		int e = 0;
 		s->dec = lw_decoder_create(id, setup, devices[g], &e);
 		if (s->dec)
-			s->batch = lw_batch_create(s->dec, max_packets_per_shard, fmt, &e);
-		const bool ok = s->dec && s->batch && hipSetDevice(devices[g]) == hipSuccess &&
-			hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+			s->ring = lw_ring_create(s->dec, LW_SHARD_SLOTS, max_packets_per_shard, fmt, &e);
+		const bool ok = s->dec && s->ring;
 		sh->shards.push_back(std::move(s));
 		if (!ok) {
 			*err = e ? e : LW_ERR_DEVICE;
@@ -163,13 +236,10 @@ void lw_sharder_destroy(lw_sharder *sh)
 	for (auto &s : sh->shards) {
 		if (s->worker.joinable())
 			s->worker.join();
-		(void)hipSetDevice(s->device);
-		if (s->stream) {
-			(void)hipStreamSynchronize(s->stream);
-			(void)hipStreamDestroy(s->stream);
+		if (s->ring) {
+			(void)lw_ring_drain(s->ring);
+			lw_ring_destroy(s->ring);
 		}
-		if (s->batch)
-			lw_batch_destroy(s->batch);
 		if (s->dec)
 			lw_decoder_destroy(s->dec); // (streams opened on the shard must have been closed: their pwr lives in this decoder)
 	}
@@ -181,8 +251,10 @@ int lw_sharder_set_entropy_on_device(lw_sharder *sh, int on)
 	if (!sh)
 		return LW_ERR_NULL_ARG;
 	std::lock_guard<std::mutex> call(sh->call_mu);
+	if (!sh->calls.empty())
+		return LW_ERR_CAPACITY; // only between calls
 	for (auto &s : sh->shards)
-		if (int rc = lw_batch_set_entropy_on_device(s->batch, on))
+		if (int rc = lw_ring_set_entropy_on_device(s->ring, on))
 			return rc; // LW_ERR_UNSUPPORTED: the stream is not eligible (every shard has the same headers: none was switched)
 	return LW_OK;
 }
@@ -232,58 +304,165 @@ void lw_sharder_stream_reset(lw_shard_stream *st)
 		lw_pwr_reset(st->pwr);
 }
 
+size_t lw_sharder_in_flight(lw_sharder *sh)
+{
+	if (!sh)
+		return 0;
+	std::lock_guard<std::mutex> call(sh->call_mu);
+	return sh->calls.size();
+}
+
+static int submit_locked(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int n_threads_per_shard, size_t *out_elems)
+{
+	if (sh->calls.size() >= LW_SHARD_SLOTS)
+		return LW_ERR_CAPACITY; // collect the oldest call first
+	auto c = std::make_unique<Call>();
+	c->parts.resize(sh->shards.size());
+	c->n = n;
+	for (size_t i = 0; i < n; i++) {
+		const lw_shard_stream *st = pkts[i].stream;
+		if (!st || st->owner != sh)
+			return LW_ERR_STATE_MISMATCH;
+		Part &p = c->parts[st->shard];
+		if (p.idx.size() == sh->max_packets)
+			return LW_ERR_CAPACITY;
+		p.idx.push_back(i);
+		p.pk.push_back(lw_packet{pkts[i].data, pkts[i].len, st->pwr});
+	}
+	// all shards run their host entropy stage at once (the worker pool serves their parallel regions side by side): by
+	// default they share the CPUs this process may use
+	c->n_threads = n_threads_per_shard > 0 ? n_threads_per_shard
+			: std::max(1, lw_default_host_threads() / (int)sh->shards.size());
+	sh->all_workers(JOB_STAGE, c.get()); // host entropy stage + asynchronous H2D / kernels / D2H of every shard
+	int rc = LW_OK;
+	size_t total = 0;
+	for (Part &p : c->parts) {
+		if (p.rc != LW_OK)
+			rc = p.rc;
+		p.base = total;
+		total += p.out_elems;
+	}
+	c->total_elems = total;
+	if (out_elems)
+		*out_elems = total;
+	// (on an error the shards that did launch still hold a slot each: the call stays in the queue so that a collect frees them)
+	sh->calls.push_back(std::move(c));
+	return rc;
+}
+
+static int collect_locked(lw_sharder *sh, void *out, size_t cap_elems, lw_packet_result *results, size_t n_results)
+{
+	if (sh->calls.empty())
+		return LW_ERR_CAPACITY; // nothing in flight
+	Call &c = *sh->calls.front();
+	if (c.collected)
+		return LW_ERR_CAPACITY; // held by lw_sharder_collect_pinned: release it first
+	if (n_results < c.n || (!results && c.n) || (!out && c.total_elems))
+		return LW_ERR_NULL_ARG;
+	if (cap_elems < c.total_elems)
+		return LW_ERR_CAPACITY; // nothing consumed: call again with room for lw_sharder_submit's out_elems
+	c.out = out;
+	c.results = results;
+	for (size_t i = 0; i < c.n; i++) // (packets of a shard whose stage failed keep this)
+		results[i] = lw_packet_result{LW_ERR_DEVICE, 0, 0};
+	sh->all_workers(JOB_COLLECT, &c);
+	int rc = LW_OK;
+	for (Part &p : c.parts)
+		if (p.rc != LW_OK)
+			rc = p.rc;
+	sh->calls.pop_front();
+	return rc;
+}
+
+int lw_sharder_collect_pinned(lw_sharder *sh, lw_packet_result *results, size_t n_results, const void **pcm, size_t *elems)
+{
+	if (!sh || !pcm || !elems)
+		return LW_ERR_NULL_ARG;
+	std::lock_guard<std::mutex> call(sh->call_mu);
+	if (sh->calls.empty())
+		return LW_ERR_CAPACITY;
+	Call &c = *sh->calls.front();
+	if (c.collected)
+		return LW_ERR_CAPACITY; // release it first
+	if (n_results < c.n || (!results && c.n))
+		return LW_ERR_NULL_ARG;
+	c.out = nullptr;
+	c.results = results;
+	c.keep = true;
+	c.pcm = pcm;
+	c.elems = elems;
+	for (size_t g = 0; g < sh->shards.size(); g++) {
+		pcm[g] = nullptr;
+		elems[g] = 0;
+	}
+	for (size_t i = 0; i < c.n; i++)
+		results[i] = lw_packet_result{LW_ERR_DEVICE, 0, 0};
+	sh->all_workers(JOB_COLLECT, &c);
+	c.collected = true;
+	int rc = LW_OK;
+	for (Part &p : c.parts)
+		if (p.rc != LW_OK)
+			rc = p.rc;
+	return rc;
+}
+
+int lw_sharder_release(lw_sharder *sh)
+{
+	if (!sh)
+		return LW_ERR_NULL_ARG;
+	std::lock_guard<std::mutex> call(sh->call_mu);
+	if (sh->calls.empty() || !sh->calls.front()->collected)
+		return LW_ERR_CAPACITY;
+	Call &c = *sh->calls.front();
+	sh->all_workers(JOB_RELEASE, &c);
+	int rc = LW_OK;
+	for (Part &p : c.parts)
+		if (p.rc != LW_OK)
+			rc = p.rc;
+	sh->calls.pop_front();
+	return rc;
+}
+
+int lw_sharder_submit(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int n_threads_per_shard, size_t *out_elems)
+{
+	if (!sh || (!pkts && n))
+		return LW_ERR_NULL_ARG;
+	std::lock_guard<std::mutex> call(sh->call_mu);
+	return submit_locked(sh, pkts, n, n_threads_per_shard, out_elems);
+}
+
+int lw_sharder_collect(lw_sharder *sh, void *out, size_t cap_elems, lw_packet_result *results, size_t n_results)
+{
+	if (!sh)
+		return LW_ERR_NULL_ARG;
+	std::lock_guard<std::mutex> call(sh->call_mu);
+	return collect_locked(sh, out, cap_elems, results, n_results);
+}
+
 int lw_sharder_decode(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int n_threads_per_shard, void *out,
 		size_t cap_elems, lw_packet_result *results)
 {
 	if (!sh || (!pkts && n) || (!results && n) || (!out && cap_elems))
 		return LW_ERR_NULL_ARG;
 	std::lock_guard<std::mutex> call(sh->call_mu);
-	for (auto &s : sh->shards) {
-		s->idx.clear();
-		s->pk.clear();
-	}
-	for (size_t i = 0; i < n; i++) {
-		const lw_shard_stream *st = pkts[i].stream;
-		if (!st || st->owner != sh)
-			return LW_ERR_STATE_MISMATCH;
-		Shard &s = *sh->shards[st->shard];
-		if (s.idx.size() == sh->max_packets)
-			return LW_ERR_CAPACITY;
-		s.idx.push_back(i);
-		s.pk.push_back(lw_packet{pkts[i].data, pkts[i].len, st->pwr});
-	}
-	// all shards run their host entropy stage at once (the worker pool serves their parallel regions side by side): by
-	// default they share the CPUs this process may use
-	sh->n_threads = n_threads_per_shard > 0 ? n_threads_per_shard
-			: std::max(1, lw_default_host_threads() / (int)sh->shards.size());
-	sh->out = out;
-	const uint64_t base_phase = 2 * (++sh->call_no);
-	sh->all_workers(base_phase + 1); // phase 1: host entropy stage of every shard (sample counts, offsets inside the shard)
+	if (!sh->calls.empty())
+		return LW_ERR_CAPACITY; // the synchronous form needs an empty pipeline
 	size_t total = 0;
-	int rc = LW_OK;
-	for (auto &s : sh->shards) {
-		if (s->rc != LW_OK)
-			rc = s->rc;
-		s->base = total;
-		total += s->out_elems;
-	}
+	int rc = submit_locked(sh, pkts, n, n_threads_per_shard, &total);
 	if (rc == LW_OK && total > cap_elems)
 		rc = LW_ERR_CAPACITY; // (the host halves of the streams' states have advanced: the call cannot be repeated as is)
-	if (rc != LW_OK)
+	if (sh->calls.empty())
 		return rc;
-	sh->all_workers(base_phase + 2); // phase 2: H2D, kernels, D2H of every shard, each on its own device and thread
-	for (auto &s : sh->shards) {
-		if (s->rc != LW_OK)
-			rc = s->rc;
-		if (s->pk.empty())
-			continue;
-		const lw_packet_result *r = lw_batch_results(s->batch);
-		for (size_t k = 0; k < s->idx.size(); k++) {
-			results[s->idx[k]] = r[k];
-			results[s->idx[k]].out_offset += s->base;
-		}
+	if (rc != LW_OK) { // free the slots the shards hold; the results are dropped
+		Call &c = *sh->calls.front();
+		std::vector<lw_packet_result> scratch(c.n);
+		c.out = nullptr;
+		c.results = scratch.data();
+		sh->all_workers(JOB_COLLECT, &c);
+		sh->calls.pop_front();
+		return rc;
 	}
-	return rc;
+	return collect_locked(sh, out, cap_elems, results, n);
 }
 
 } // extern "C"

@@ -91,3 +91,56 @@ def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots
     for r in rings:
         r.close()
     return out
+
+
+def measure_sharder(ident, setup, pool, devices, n_calls=32, packets_per_shard=4096, streams_per_shard=256, threads=0,
+                    samples="i16", device_entropy=False, seed=1, warm=4, copy_out=False):
+    """End-to-end rate of the one-process multi-device path (lw_sharder_*): packets of len(devices) x streams_per_shard
+    streams per call, stream_id mod G onto the shards, every shard on its own staging ring; up to three calls in flight.
+    Returns a dict like measure()."""
+    from .shard import Sharder
+    G = len(devices)
+    sh = Sharder(ident, setup, list(devices), packets_per_shard, samples)
+    if device_entropy and not sh.set_entropy_on_device(True):
+        raise RuntimeError("stream not eligible for the device entropy stage")
+    rng = np.random.default_rng(seed)
+    n_streams = G * streams_per_shard
+    per = packets_per_shard // streams_per_shard
+    calls = []
+    for b in range(min(n_calls, 6)):
+        order = rng.integers(0, len(pool), n_streams * per)
+        # stream-major: the packets of a stream are consecutive (LDS hand-over inside the launch); the sharder sorts out owners
+        calls.append(sh.marshal([(k // per, pool[int(i)]) for k, i in enumerate(order)]))
+    out = None
+
+    def take():   # the oldest call out: copied into one buffer, or left in the shards' pinned buffers (like Ring.collect_nocopy)
+        nonlocal out
+        if copy_out:
+            out, _ = sh.collect(out, want_results=False)
+        else:
+            sh.collect_pinned(want_results=False)
+            sh.release()
+
+    def run(n):
+        for k in range(n):
+            if sh.in_flight == 3:
+                take()
+            sh.submit(calls[k % len(calls)], threads)
+        while sh.in_flight:
+            take()
+
+    run(warm)
+    t0 = time.perf_counter()
+    run(n_calls)
+    dt = time.perf_counter() - t0
+    npk = n_calls * n_streams * per
+    res = {"value": npk / dt, "unit": "packets/s", "packets": npk, "seconds": dt, "shards": G, "devices": list(devices),
+           "per_shard": npk / dt / G, "packets_per_call": n_streams * per, "host_threads_per_shard": threads or
+           max(1, _N.lw_default_host_threads() // G),
+           "records": "raw packets, entropy stage on each shard's device (k_entropy)" if device_entropy else
+                      "f32 residue vectors (host entropy stage)",
+           "path": "lw_sharder_submit (per shard: lw_ring_stage + lw_ring_launch on the shard's thread and device) -> " +
+                   ("lw_sharder_collect (pinned PCM -> caller's buffer)" if copy_out else
+                    "lw_sharder_collect_pinned / lw_sharder_release (PCM left in the shards' pinned buffers)") + ", 3 calls in flight"}
+    sh.close()
+    return res

@@ -34,8 +34,9 @@ def job_throughput(units_per_rank, elapsed_seconds, dist=None, device=None):
 
 
 class Sharder:
-    """Single-process form (lw_sharder_*): one decoder, batch, HIP stream and worker thread per entry of `devices`; streams
-    are opened through the sharder and live on shard stream_id mod G."""
+    """Single-process form (lw_sharder_*): one decoder, staging ring and worker thread per entry of `devices`; streams are
+    opened through the sharder and live on shard stream_id mod G.  decode() is synchronous; submit() / collect() keep up to
+    three calls in flight so that every shard's host stage overlaps the GPU work of the call before."""
 
     def __init__(self, ident, setup, devices, max_packets_per_shard, samples="i16"):
         import ctypes as C
@@ -104,6 +105,88 @@ class Sharder:
             else:
                 blocks.append(out[res[i].out_offset: res[i].out_offset + res[i].n_samples * ch].reshape(ch, res[i].n_samples))
         return blocks, [(res[i].status, res[i].n_samples, res[i].out_offset) for i in range(n)]
+
+    def marshal(self, packets):
+        """lw_shard_packet array for `packets` (list of (stream_id, bytes)); build once, submit many times."""
+        N, C = self._N, self._C
+        n = len(packets)
+        arr = (N.ShardPacket * n)()
+        keep = []
+        for i, (sid, data) in enumerate(packets):
+            data = bytes(data)
+            keep.append(data)
+            arr[i].stream = self.stream(sid)
+            arr[i].data = C.cast(C.c_char_p(data), C.c_void_p)
+            arr[i].len = len(data)
+        return arr, keep, n
+
+    def submit(self, marshalled, n_threads=0):
+        """lw_sharder_submit: every shard stages and launches its part; returns the elements the call will produce."""
+        arr, _keep, n = marshalled
+        elems = self._C.c_size_t(0)
+        rc = self._N.lw_sharder_submit(self._h, arr, n, n_threads, self._C.byref(elems))
+        if rc:
+            raise RuntimeError("lw_sharder_submit: %d %s" % (rc, self._N.device_error()))
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append((n, elems.value))
+        return elems.value
+
+    @property
+    def in_flight(self):
+        return self._N.lw_sharder_in_flight(self._h)
+
+    def collect(self, out=None, want_results=True):
+        """lw_sharder_collect of the oldest call: (flat sample array, [(status, n_samples, out_offset)]).  `out`: a numpy
+        array to receive the samples (reused by throughput loops), else a fresh one; want_results=False skips building the
+        Python list (the C array is still filled and checked for the call's status)."""
+        import numpy as np
+        N, C = self._N, self._C
+        n, elems = self._pending[0]
+        if out is None or out.size < elems:
+            out = np.zeros(max(1, elems), np.float32 if self.fmt == N.FMT_F32_PLANAR else np.int16)
+        if getattr(self, "_res_cap", 0) < n:
+            self._res = (N.PacketResult * max(1, n))()
+            self._res_cap = n
+        res = self._res
+        rc = N.lw_sharder_collect(self._h, out.ctypes.data_as(C.c_void_p), out.size, res, n)
+        if rc:
+            raise RuntimeError("lw_sharder_collect: %d %s" % (rc, N.device_error()))
+        self._pending.pop(0)
+        if not want_results:
+            return out[:elems], None
+        return out[:elems], [(res[i].status, res[i].n_samples, res[i].out_offset) for i in range(n)]
+
+    def collect_pinned(self, want_results=True):
+        """lw_sharder_collect_pinned: per shard a numpy VIEW of its pinned PCM (valid until release()), and the results with
+        out_offset relative to the owning shard's block."""
+        import numpy as np
+        N, C = self._N, self._C
+        n, _elems = self._pending[0]
+        if getattr(self, "_res_cap", 0) < n:
+            self._res = (N.PacketResult * max(1, n))()
+            self._res_cap = n
+        G = self.shards
+        pcm = (C.c_void_p * G)()
+        el = (C.c_size_t * G)()
+        rc = N.lw_sharder_collect_pinned(self._h, self._res, n, pcm, el)
+        if rc:
+            raise RuntimeError("lw_sharder_collect_pinned: %d %s" % (rc, N.device_error()))
+        dt = np.float32 if self.fmt == N.FMT_F32_PLANAR else np.int16
+        views = []
+        for g in range(G):
+            if el[g]:
+                buf = (C.c_char * (el[g] * np.dtype(dt).itemsize)).from_address(pcm[g])
+                views.append(np.frombuffer(buf, dtype=dt))
+            else:
+                views.append(np.zeros(0, dt))
+        res = [(self._res[i].status, self._res[i].n_samples, self._res[i].out_offset) for i in range(n)] if want_results else None
+        return views, res
+
+    def release(self):
+        rc = self._N.lw_sharder_release(self._h)
+        if rc:
+            raise RuntimeError("lw_sharder_release: %d" % rc)
+        self._pending.pop(0)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -195,3 +195,66 @@ def test_sharder_ten_thousand_streams_one_process():
             want = po.read_audio_packet(o_id, o_st, pkt, opws[s], "i16")
             assert r[0] == 0 and b.shape == want.shape and np.array_equal(b, want), (half, s)
     sh.close()
+
+
+@pytest.mark.parametrize("tier", ["host", "device"])
+def test_sharder_pipelined_calls_in_flight(tier):
+    """lw_sharder_submit / lw_sharder_collect: three logical shards, each on its own staging ring, up to three calls in
+    flight (the host stage of call k+1 overlaps the GPU work of call k on every shard), the same streams carried from call
+    to call, mixed block sizes; every packet of every call against the oracle, and the states at the end."""
+    from lewton_amd import _native as N
+    from lewton_amd import shard
+    setup = SETUPS["stereo"]()
+    audio, ident, st = _product(setup)
+    o_id, o_st = oracle_headers(setup)
+    G, n_streams, per, n_calls = 3, 30, 6, 7
+    ndev = max(1, N.lw_device_count())
+    sh = shard.Sharder(ident, st, [g % ndev for g in range(G)], max_packets_per_shard=per * (n_streams // G + 1), samples="i16")
+    if tier == "device":
+        assert sh.set_entropy_on_device(True)
+    streams = [sg.make_stream(setup, "LLSSSLLSL", per * n_calls, seed=300 + s, p_floor_unused=0.04) for s in range(n_streams)]
+    opws = [po.Pwr() for _ in range(n_streams)]
+    calls = [[(s, streams[s][c * per + t]) for s in range(n_streams) for t in range(per)] for c in range(n_calls)]
+    pending = []
+
+    def check(items, flat, res):
+        for (s, pkt), (status, m, off) in zip(items, res):
+            want = po.read_audio_packet(o_id, o_st, pkt, opws[s], "i16")
+            assert status == 0 and m == want.shape[1]
+            assert np.array_equal(flat[off:off + 2 * m], want.reshape(-1)), s
+
+    def check_pinned(items):   # the zero-copy form: per-shard views of the pinned PCM, offsets relative to the owner's block
+        views, res = sh.collect_pinned()
+        for (s, pkt), (status, m, off) in zip(items, res):
+            want = po.read_audio_packet(o_id, o_st, pkt, opws[s], "i16")
+            assert status == 0 and m == want.shape[1]
+            assert np.array_equal(views[sh.shard_of(s)][off:off + 2 * m], want.reshape(-1)), s
+        sh.release()
+
+    taken = 0
+
+    def take():
+        nonlocal taken
+        if taken % 2:
+            check_pinned(pending.pop(0))
+        else:
+            flat, res = sh.collect()
+            check(pending.pop(0), flat, res)
+        taken += 1
+
+    for items in calls:
+        if sh.in_flight == 3:
+            take()
+        sh.submit(sh.marshal(items), n_threads=2)
+        pending.append(items)
+    assert sh.in_flight == 3
+    while pending:
+        take()
+    assert sh.in_flight == 0
+    # the synchronous form still works on the drained pipeline
+    tail = [(s, sg.make_stream(setup, "L", 1, seed=900 + s)[0]) for s in range(n_streams)]
+    blocks, res = sh.decode(tail, n_threads=2)
+    for (s, pkt), b in zip(tail, blocks):
+        want = po.read_audio_packet(o_id, o_st, pkt, opws[s], "i16")
+        assert b.shape == want.shape and np.array_equal(b, want)
+    sh.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host entropy stage alone, one thread, no GPU: builds tools/micro/entropy_bench.cpp from the product sources and runs it
 on the packets of the bench workload (512 stereo long-block packets, the pool bench.py and tools/e2e.py draw from).
-    python tools/entropy_bench.py [--reps 30] [--runs 5] [--symbols]"""
+    python tools/entropy_bench.py [--reps 30] [--runs 5]"""
 import argparse
 import os
 import struct
@@ -16,7 +16,6 @@ from lewton_amd import streamgen as sg  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--runs", type=int, default=5, help="process launches (heap placement changes the result by ~10 %)")
-ap.add_argument("--symbols", action="store_true", help="Tier B records instead of residue vectors")
 ap.add_argument("--cxx", default="/opt/rocm/lib/llvm/bin/clang++", help="the compiler lewton_amd/build.py uses for host code")
 args = ap.parse_args()
 
@@ -37,4 +36,4 @@ with tempfile.TemporaryDirectory() as tmp:
         os.path.join(ROOT, "lewton_amd", "csrc", n) for n in ("lw_entropy.cpp", "lw_headers.cpp")]
     subprocess.check_call([args.cxx, "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math"] + src + ["-o", exe])
     for _ in range(args.runs):
-        print(subprocess.check_output([exe, case, str(args.reps), "1" if args.symbols else "0"], text=True).strip())
+        print(subprocess.check_output([exe, case, str(args.reps)], text=True).strip())

@@ -11,8 +11,6 @@ timeout 300 python bench.py > $D/bench.json 2> $D/bench.err
 for t in 16 32 64 128 0; do
   timeout 120 python tools/e2e.py --batches 48 --threads $t > $D/e2e_t$t.txt 2>&1
 done
-timeout 120 python tools/e2e.py --batches 48 --device-vq > $D/e2e_vq.txt 2>&1
 timeout 120 python tools/e2e.py --batches 48 --callers 2 > $D/e2e_c2.txt 2>&1
-timeout 120 python tools/e2e.py --batches 48 --callers 2 --device-vq > $D/e2e_c2_vq.txt 2>&1
 timeout 120 python tools/batch_host_bench.py --threads 1 16 32 64 128 > $D/batch_host.txt 2>&1
 tail -n 3 $D/pytest.log; cat $D/smoke.log | tail -1; cat $D/bench.json | head -c 600; echo; grep -h "end-to-end" $D/e2e_*.txt
