@@ -9,7 +9,7 @@ from common import ROOT
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json"])
+@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).readline()
     d = json.loads(line)
@@ -39,10 +39,15 @@ def test_committed_bench_line_has_the_contract_fields(name):
         assert e["unit"] == "packets/s" and 0 < e["value"] < d["value"] and e["host_cpus_usable"] >= 1
         t = e.get("device_entropy") or e["tier_c"]   # (round 2 called it tier_c)
         assert "entropy stage on the device" in t["records"] and "k_entropy" in t["kernels"] and t["value"] > 0
+    if name >= "r03":
+        # round 3: the like-for-like CPU figure rides along, and the one-process multi-device path has its end-to-end leg
+        assert c["synthesis_only"]["value"] > c["value"]
+        sh = d["end_to_end"]["sharder"]
+        assert sh["unit"] == "packets/s" and sh["shards"] >= 2 and sh["value"] > 0
 
 
 def test_device_code_is_the_measured_build():
-    """profiles/r02_device_code.sha256 identifies the kernels the round's GPU parity run, bench line and rocprof summaries were
+    """profiles/r03_device_code.sha256 identifies the kernels the round's GPU parity run, bench line and rocprof summaries were
     taken on (sha256 of the gfx950 disassembly, tools/device_code_id.sh).  Host-side work done without a GPU at hand must
     not change them: a kernel edit has to go through the GPU tests again and refresh the file together with the profiles."""
     import shutil
@@ -52,5 +57,5 @@ def test_device_code_is_the_measured_build():
         pytest.skip("binutils / ROCm LLVM tools not installed")
     import lewton_amd  # noqa: F401  (makes sure the library is built)
     out = subprocess.check_output([os.path.join(ROOT, "tools", "device_code_id.sh")], cwd=ROOT, text=True)
-    want = open(os.path.join(ROOT, "profiles", "r02_device_code.sha256")).read()
+    want = open(os.path.join(ROOT, "profiles", "r03_device_code.sha256")).read()
     assert out.split() == want.split()

@@ -119,3 +119,96 @@ def test_ring_4096_packet_batches_pcm_vs_oracle(tier, pattern):
         ring.release()
         assert bad == 0, (tier, pattern, b, bad)
     ring.close()
+
+
+def _mono_8_11():
+    from lewton_amd import workloads as wl
+    return wl.mono()
+
+
+def _uncoupled_8_11():
+    from lewton_amd import workloads as wl
+    return wl.uncoupled_stereo()
+
+
+MIXED_SETUPS = {"stereo": lambda: sg.stereo_setup(44100, 8, 11), "surround51": lambda: sg.surround51_setup(48000, 8, 11),
+                "mono": _mono_8_11, "uncoupled": _uncoupled_8_11}
+
+
+@pytest.mark.parametrize("name", sorted(MIXED_SETUPS))
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_mixed_streams_one_packet_per_launch(name, fmt):
+    """Every window shape with its previous right part coming from the STATE POOL (one packet per stream per launch): short
+    after long and long after short across launches (the 128-sample state written by k_long<EDGE> / k_short, read by a
+    k_short block or by the slot that only carries a stored right part to a long block's left edge), single-channel and
+    uncoupled-pair units, all three sample formats; every packet and the final states against the oracle."""
+    from lewton_amd.batch import Batch
+    from common import oracle_headers
+    setup = MIXED_SETUPS[name]()
+    audio, dec = _decoder(setup)
+    o_id, o_st = oracle_headers(setup)
+    ch = setup.channels
+    n_streams, steps = 12, 14
+    streams = [sg.make_stream(setup, "LSLLSSLSSSL"[s % 5:] + "LS", steps, seed=70 + s, p_floor_unused=0.08) for s in range(n_streams)]
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    opws = [po.Pwr() for _ in range(n_streams)]
+    ofmt = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}[fmt]
+    bt = Batch(dec, n_streams, fmt)
+    seen = set()
+    for t in range(steps):
+        res = bt.entropy([(streams[s][t], pwrs[s]) for s in range(n_streams)], n_threads=2)
+        bt.upload()
+        got = bt.split(bt.synth_to_host(), ch)
+        seen.update(bt.last_kernels.split(","))
+        for s in range(n_streams):
+            want = np.asarray(po.read_audio_packet(o_id, o_st, streams[s][t], opws[s], ofmt))
+            assert res[s][0] == 0 and got[s].size == want.size, (t, s)
+            if fmt == "f32":
+                assert np.array_equal(got[s].reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32)), (t, s, bt.last_kernels)
+            else:
+                assert np.array_equal(got[s].reshape(-1), want.reshape(-1)), (t, s, bt.last_kernels)
+    assert "k_short" in seen and "k_long" in seen and not any("generic" in k for k in seen), seen
+    for s in range(n_streams):
+        assert np.array_equal(pwrs[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32)), s
+    bt.close()
+
+
+def test_many_short_blocks_one_wave_per_channel_pair():
+    """more than 1024 waves' worth of short blocks in one launch: k_short keeps a channel pair in ONE wave then (smaller
+    launches split it over two); runs of 37 consecutive short blocks per stream cross wave boundaries (recomputed
+    predecessor in the first slot)"""
+    from lewton_amd.batch import Batch
+    from common import oracle_headers
+    setup = sg.stereo_setup(44100, 8, 11)
+    audio, dec = _decoder(setup)
+    o_id, o_st = oracle_headers(setup)
+    n_streams, per, distinct = 256, 37, 16
+    seqs = [sg.make_stream(setup, "S", per + 1, seed=500 + q, p_floor_unused=0.05) for q in range(distinct)]
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    prime = Batch(dec, n_streams, "i16")
+    prime.entropy([(seqs[s % distinct][0], pwrs[s]) for s in range(n_streams)], n_threads=4)
+    prime.upload()
+    prime.synth_to_host()
+    prime.close()
+    bt = Batch(dec, n_streams * per, "i16")
+    res = bt.entropy([(seqs[s % distinct][1 + k], pwrs[s]) for s in range(n_streams) for k in range(per)], n_threads=4)
+    bt.upload()
+    flat = bt.synth_to_host()
+    assert bt.last_kernels == "k_short"
+    expect = []
+    for q in range(distinct):
+        opw = po.Pwr()
+        po.read_audio_packet(o_id, o_st, seqs[q][0], opw, "i16")
+        expect.append(([np.asarray(po.read_audio_packet(o_id, o_st, p, opw, "i16")).reshape(-1) for p in seqs[q][1:]], opw))
+    bad, k = 0, 0
+    for s in range(n_streams):
+        for t in range(per):
+            want = expect[s % distinct][0][t]
+            status, m, off = res[k]
+            assert status == 0 and 2 * m == want.size
+            bad += not np.array_equal(flat[off:off + 2 * m], want)
+            k += 1
+    assert bad == 0
+    for s in range(0, n_streams, 17):
+        assert np.array_equal(pwrs[s].data().view(np.uint32), expect[s % distinct][1].data(2).view(np.uint32))
+    bt.close()
