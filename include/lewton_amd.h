@@ -242,10 +242,12 @@ size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0
  * and returns when every shard has launched -- while the GPUs work (no collective, nothing crosses xGMI).  The packet
  * bytes are consumed when it returns.  *out_elems = elements the call will produce.  Up to 3 calls may be in flight, so
  * the host stage of call k+1 overlaps the GPU work of call k on every device.
- * lw_sharder_collect waits for the OLDEST call: out = host memory for cap_elems elements; results[i] (status, n_samples,
+ * lw_sharder_collect waits for the OLDEST call: out = host memory for cap_elems elements (NULL: drop the samples); results[i] (status, n_samples,
  * out_offset = element offset of packet i's block in out) come back in the order of that call's pkts; blocks are laid out
  * shard by shard.  LW_ERR_CAPACITY: more than max_packets_per_shard packets for one shard, three calls already in flight
  * (submit), nothing in flight or out too small (collect: nothing is consumed).
+ * A submit that fails AFTER some shards have launched (a device error on one shard) still queues the call, so that the
+ * slots those shards hold can be freed: collect it (its packets on the failed shard come back with LW_ERR_DEVICE).
  * lw_sharder_decode = submit + collect on an empty pipeline.
  * The process-per-GPU form of the same rule is lewton_amd/shard.py + bench.py under torch.distributed.run. */
 typedef struct lw_sharder lw_sharder;

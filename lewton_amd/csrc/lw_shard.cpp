@@ -357,9 +357,9 @@ static int collect_locked(lw_sharder *sh, void *out, size_t cap_elems, lw_packet
 	Call &c = *sh->calls.front();
 	if (c.collected)
 		return LW_ERR_CAPACITY; // held by lw_sharder_collect_pinned: release it first
-	if (n_results < c.n || (!results && c.n) || (!out && c.total_elems))
+	if (n_results < c.n || (!results && c.n))
 		return LW_ERR_NULL_ARG;
-	if (cap_elems < c.total_elems)
+	if (out && cap_elems < c.total_elems) // (out == NULL: the samples are dropped, only statuses and counts come back)
 		return LW_ERR_CAPACITY; // nothing consumed: call again with room for lw_sharder_submit's out_elems
 	c.out = out;
 	c.results = results;

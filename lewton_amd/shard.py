@@ -124,10 +124,22 @@ class Sharder:
         """lw_sharder_submit: every shard stages and launches its part; returns the elements the call will produce."""
         arr, _keep, n = marshalled
         elems = self._C.c_size_t(0)
+        before = self._N.lw_sharder_in_flight(self._h)
         rc = self._N.lw_sharder_submit(self._h, arr, n, n_threads, self._C.byref(elems))
-        if rc:
-            raise RuntimeError("lw_sharder_submit: %d %s" % (rc, self._N.device_error()))
         self._pending = getattr(self, "_pending", [])
+        if rc:
+            msg = "lw_sharder_submit: %d %s" % (rc, self._N.device_error())
+            if self._N.lw_sharder_in_flight(self._h) > before:
+                # a shard failed after others had launched: the call is queued so that its slots can be freed -- it is the
+                # YOUNGEST call, so everything in front of it is collected (and dropped) with it
+                self._pending.append((n, elems.value))
+                while self._pending:
+                    cn, _ce = self._pending.pop(0)
+                    scratch = (self._N.PacketResult * max(1, cn))()
+                    self._N.lw_sharder_collect(self._h, None, 0, scratch, cn)
+                    if self._N.lw_sharder_in_flight(self._h) == len(self._pending) + 1:
+                        break   # (collect refused: leave the rest to close())
+            raise RuntimeError(msg)
         self._pending.append((n, elems.value))
         return elems.value
 
