@@ -616,6 +616,10 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			const size_t cus = (size_t)std::max(1, d->n_cus);
 			per_round = (uint32_t)std::min<size_t>(per_round, std::max<size_t>(1, (nf + cus * rounds - 1) / (cus * rounds)));
 		}
+		// a sparse launch (one round, at most half of a workgroup's waves in use) lasts as long as ONE wave's dependent chain:
+		// split every channel pair over two waves (LW_UNIT_SPLIT_*) -- each half does one channel's floor, transform and samples
+		b->fast_split = !b->forced_rounds && !b->has_tdonly && rounds == 1 && d->fast.units_split.size() > d->fast.units.size() &&
+			per_round * d->fast.units_split.size() <= LW_FAST_WAVES;
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
 		b->fast_rounds = rounds;
@@ -727,7 +731,7 @@ static int device_entropy(lw_batch *b, hipStream_t st)
 	if (!b->dev_entropy || b->ent_done || b->n == 0)
 		return LW_OK;
 	lw_decoder *d = b->dec;
-	lw_launch_entropy(d->E, b->d_pk, b->d_recs, b->d_pool, b->d_floor, b->d_res, (uint32_t)b->n, st);
+	HIP_TRY(lw_launch_entropy(d->E, b->d_pk, b->d_recs, b->d_pool, b->d_floor, b->d_res, (uint32_t)b->n, st));
 	HIP_TRY(hipGetLastError());
 	b->ent_done = true;
 	return LW_OK;
@@ -800,16 +804,18 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.n_items = (uint32_t)b->n_items;
 		L.d_halo_items = b->d_halo_items;
 		L.n_halo_items = (uint32_t)b->n_halo_items;
-		L.n_units = (uint32_t)d->fast.units.size();
+		const std::vector<LwFastUnit> &units = b->fast_split ? d->fast.units_split : d->fast.units;
+		L.n_units = (uint32_t)units.size();
 		L.per_round = b->fast_per_round;
 		L.rounds = b->fast_rounds;
 		L.dense = b->fast_dense;
 		L.late_from = b->fast_late_from;
 		L.has_tdonly = b->has_tdonly ? 1u : 0u;
+		L.split = b->fast_split ? 1u : 0u;
 		L.edge_mode = b->edge_mode ? 1u : 0u;
 		L.d_edge = b->d_edge;
-		for (size_t i = 0; i < d->fast.units.size() && i < LW_FAST_WAVES; i++)
-			L.units[i] = d->fast.units[i];
+		for (size_t i = 0; i < units.size() && i < LW_FAST_WAVES; i++)
+			L.units[i] = units[i];
 		L.d_halo = b->d_halo;
 		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";

@@ -141,6 +141,28 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 	}
 	std::memcpy(plan.long_mode_mask, up.mode_mask, sizeof(plan.long_mode_mask));
 	plan.units = up.units;
+	// the same units with every channel pair split over two waves
+	for (const LwFastUnit &u : up.units) {
+		if (u.ch_b < 0) {
+			plan.units_split.push_back(u);
+			continue;
+		}
+		LwFastUnit a = u, b = u;
+		a.coupled = u.coupled ? LW_UNIT_SPLIT_MAG : 0; // ch_a stays; ch_b only as the partner of the coupling step
+		if (!u.coupled)
+			a.ch_b = -1;
+		b.ch_a = u.ch_b;
+		b.ch_b = u.coupled ? u.ch_a : (int8_t)-1;
+		b.coupled = u.coupled ? LW_UNIT_SPLIT_ANG : 0;
+		b.floor_a = u.floor_b;
+		b.F_a = u.F_b;
+		b.floor_b = u.floor_a;
+		b.F_b = u.F_a;
+		plan.units_split.push_back(a);
+		plan.units_split.push_back(b);
+	}
+	if (plan.units_split.size() > LW_FAST_WAVES)
+		plan.units_split.clear();
 	plan.n_staged_floors = up.n_staged;
 	std::memcpy(plan.staged_floor_F, up.staged_F, sizeof(plan.staged_floor_F));
 	const std::vector<int> &floor_slot = up.floor_slot;

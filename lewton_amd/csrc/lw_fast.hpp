@@ -54,9 +54,13 @@ enum : uint32_t {
 	LWI_TOTAL = 24576   // 24016 padded to a multiple of 1024
 };
 
+// unit.coupled
+#define LW_UNIT_SPLIT_MAG 2u // half of a coupled pair: this wave finishes ch_a = the magnitude channel; ch_b = its partner, whose raw
+#define LW_UNIT_SPLIT_ANG 3u // residues are loaded for the inverse coupling only (3: ch_a is the angle channel)
+
 struct LwFastUnit {
 	int8_t ch_a, ch_b;  // channels handled by one wave; ch_b = -1 for a single channel
-	uint8_t coupled;    // (ch_a = magnitude, ch_b = angle) form a coupling step
+	uint8_t coupled;    // 1: (ch_a = magnitude, ch_b = angle) form a coupling step; LW_UNIT_SPLIT_*: see above
 	uint8_t floor_a, floor_b; // staged floor slot (0 / 1) of each channel
 	uint8_t F_a, F_b;   // floor-1 post count of each channel (<= 64)
 	uint8_t slot;       // kernel argument copy only: packet slot of the wave inside a round (0xFF = idle wave)
@@ -70,6 +74,7 @@ struct LwFastPlan {
 	LwFastImage off{};
 	uint8_t long_mode_mask[32] = {0};        // bit m set: mode m is a long mode covered by the plan
 	std::vector<LwFastUnit> units;           // same for every covered mode
+	std::vector<LwFastUnit> units_split;     // one channel per wave (sparse launches: the launch lasts as long as one wave's chain)
 	uint32_t n_staged_floors = 0;
 	uint8_t staged_floor_F[LW_FAST_MAX_FLOORS] = {0};
 };
@@ -116,6 +121,7 @@ struct LwFastLaunch {
 	uint32_t dense;     // item k == packet k with uniform block sizes
 	uint32_t late_from; // first wave of a workgroup that issues its first HBM loads late
 	uint32_t has_tdonly; // some item is LW_IF_TDONLY
+	uint32_t split;      // the units are LW_UNIT_SPLIT_* halves (sparse launch): SPLIT instantiation
 	uint32_t edge_mode;  // the stream's short blocks run through k_short: EDGE instantiation, d_edge valid
 	float *d_edge;       // [packet][side][ch][64]
 	LwFastUnit units[LW_FAST_WAVES];

@@ -118,6 +118,7 @@ struct lw_batch {
 	size_t halo_cap = 0, n_items = 0, n_halo_items = 0;
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
 	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = 1;
+	bool fast_split = false; // the specialised kernel runs one channel per wave (sparse launch)
 	int forced_rounds = 0; // lw_debug_batch_set_rounds: rounds per workgroup of the specialised kernel (0 = the planner decides)
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;

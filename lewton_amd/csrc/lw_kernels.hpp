@@ -92,7 +92,7 @@ hipError_t lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, fl
 // entropy stage on the device (lw_kernels_entropy.hip): floor records and residue vectors of n packets from their raw bytes
 struct LwEntTables;
 struct LwEntPacket;
-void lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPacketRec *d_recs, const uint32_t *d_pool,
+hipError_t lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPacketRec *d_recs, const uint32_t *d_pool,
 		uint16_t *d_floor, float *d_res, uint32_t n, hipStream_t st);
 void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out, int fmt, hipStream_t st, bool include_fast);
 

@@ -50,19 +50,25 @@ __global__ void __launch_bounds__(64) k_entropy(LwEntTables T, const LwEntPacket
 	}
 }
 
-void lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPacketRec *d_recs, const uint32_t *d_pool,
+hipError_t lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, const LwPacketRec *d_recs, const uint32_t *d_pool,
 		uint16_t *d_floor, float *d_res, uint32_t n, hipStream_t st)
 {
 	if (n == 0)
-		return;
+		return hipSuccess;
 	const size_t lds = (size_t)T.res_floats * 4 + T.ws_bytes;
 	static LwPerDeviceOnce once;
 	if (once.first_launch_on_device()) {
-		(void)hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		(void)hipFuncSetAttribute((const void *)k_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		hipError_t e = hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		if (e == hipSuccess)
+			e = hipFuncSetAttribute((const void *)k_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		if (e != hipSuccess) {
+			once.forget_device(); // try again at the next launch; the caller reports this one
+			return e;
+		}
 	}
 	if (T.general)
 		hipLaunchKernelGGL(k_entropy<true>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
 	else
 		hipLaunchKernelGGL(k_entropy<false>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
+	return hipSuccess;
 }

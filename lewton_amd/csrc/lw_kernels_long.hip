@@ -901,7 +901,7 @@ __device__ __forceinline__ void decouple_pair(Pref &pf)
 
 // ---- from the landed residues to the spectrum, floor stage included (the path of a wave whose residues were requested
 //      before it had time for the floor stage): segment tables, inverse coupling, floor x residue fused into the gathers
-template <int NCH>
+template <int NCH, bool SPLIT = false>
 __device__ __forceinline__ void spectrum_fused(const LwFastArgs &F, const char *img, char *sc, uint32_t lane,
 		const LwFastUnit &un, Pref &pf)
 {
@@ -913,6 +913,24 @@ __device__ __forceinline__ void spectrum_fused(const LwFastArgs &F, const char *
 	lds_fence();
 	if (NCH == 2 && un.coupled)
 		decouple_pair(pf);
+	if (SPLIT && NCH == 1 && un.coupled >= LW_UNIT_SPLIT_MAG) {
+		// half of a coupled pair (sparse launches, lw_fast.hpp): both raw vectors are here, r[0] = this wave's channel, r[1] =
+		// its partner; after the inverse coupling only this wave's channel goes on
+		if (un.coupled == LW_UNIT_SPLIT_ANG) { // decouple_pair wants (magnitude, angle)
+#pragma unroll
+			for (int x = 0; x < 4; x++) {
+				const float4_t t = pf.r[0][x];
+				pf.r[0][x] = pf.r[1][x];
+				pf.r[1][x] = t;
+			}
+			decouple_pair(pf);
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+				pf.r[0][x] = pf.r[1][x];
+		} else {
+			decouple_pair(pf);
+		}
+	}
 	if (NCH == 2 && !unused0 && !unused1) {
 		spectrum_pair(img, sc, lane, un.floor_a, un.floor_b, pf.r);
 	} else {
@@ -1293,7 +1311,9 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t byte_addr, uint32_t need)
 // EDGE: the batch's short blocks run through k_short (lw_fast.hpp): long blocks with a short slope on either side
 // (LW_IF_EDGE_L / LW_IF_EDGE_R) do everything but the 128-sample overlap with the short neighbour here -- the samples past a
 // short slope are copied un-windowed (audio.rs:1119), the raw edges pa(448..511) / pb(448..511) go to the edge buffer.
-template <int FMT, bool RIGHT_ONLY, bool TD = false, bool EDGE = false>
+// SPLIT: sparse launches run one channel per wave (LW_UNIT_SPLIT_*, lw_fast.hpp); a separate instantiation, so that the dense
+// launches keep their register allocation.
+template <int FMT, bool RIGHT_ONLY, bool TD = false, bool EDGE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1318,7 +1338,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 	const uint32_t slot = un.slot, uidx = wave - slot * n_units; // packet slot of the round, unit of the packet
 	const bool active = slot < per_round;
 	const uint32_t item0 = blockIdx.x * per_round * rounds + slot;      // item of round j = item0 + j * per_round
-	const bool two = un.ch_b >= 0;
+	const bool two = !SPLIT && un.ch_b >= 0; // (SPLIT: every unit is one channel; ch_b, if any, is the coupling partner whose residues are loaded)
 	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
 #define LW_PRE_WAVES 2 // waves that queue their HBM loads before the barrier (waves 0-3 can: the others stage the image);
                        // measured: 1 -> 17.33, 2 -> 17.0-17.16, 4 -> 17.73 us; releasing the next wave of the chain before
@@ -1424,7 +1444,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 			if (two)
 				spectrum_fused<2>(F, img, sc, lane0, un, pf);
 			else
-				spectrum_fused<1>(F, img, sc, lane0, un, pf);
+				spectrum_fused<1, SPLIT>(F, img, sc, lane0, un, pf);
 		}
 		LW_STAMP(4);
 	}
@@ -1605,7 +1625,7 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 			if (two)
 				spectrum_fused<2>(F, img, sc, lane, un, pf);
 			else
-				spectrum_fused<1>(F, img, sc, lane, un, pf);
+				spectrum_fused<1, SPLIT>(F, img, sc, lane, un, pf);
 		}
 		it = itn;
 		valid = valid_n;
@@ -2079,7 +2099,11 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 			(const void *)k_long<LW_OUT_I16_PLANAR, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, true>,
 			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, true>, (const void *)k_long<LW_OUT_I16_ITL_STEREO, false, true>,
 			(const void *)k_long<LW_OUT_F32_PLANAR, false, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, false, true>,
-			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true>};
+			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true>,
+			(const void *)k_long<LW_OUT_I16_PLANAR, true, false, false, true>,
+			(const void *)k_long<LW_OUT_I16_PLANAR, false, false, false, true>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, false, true>,
+			(const void *)k_long<LW_OUT_F32_PLANAR, false, false, false, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, false, true, true>,
+			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true, true>};
 		for (const void *f : fns) {
 			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			if (e != hipSuccess) {
@@ -2093,7 +2117,10 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 		F.n_items = L.n_halo_items;
 		F.per_round = 1; // spread the few halo packets over the whole chip: one packet per workgroup
 		F.rounds = 1;
-		hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
+		if (L.split)
+			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true, false, false, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
+		else
+			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
 	}
 	if (L.n_items) {
 		F.items = L.d_items;
@@ -2106,7 +2133,14 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 		F.late_from = L.late_from;
 #define LW_LAUNCH_MAIN(F_)                                                                                     \
 	do {                                                                                                      \
-		if (L.edge_mode) {                                                                                    \
+		if (L.split && !L.has_tdonly) { /* sparse launch: one channel per wave (generic interleaved stores: a wave has one channel) */ \
+			if (L.edge_mode)                                                                                  \
+				hipLaunchKernelGGL((k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true, true>),  \
+						dim3(grid), dim3(LW_WG), lds, st, F);                                                  \
+			else                                                                                              \
+				hipLaunchKernelGGL((k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, false, true>), \
+						dim3(grid), dim3(LW_WG), lds, st, F);                                                  \
+		} else if (L.edge_mode) {                                                                             \
 			hipLaunchKernelGGL((k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true>), dim3(grid), \
 					dim3(LW_WG), lds, st, F);                                                                  \
 		} else if (L.has_tdonly) {                                                                            \
