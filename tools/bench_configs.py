@@ -28,8 +28,6 @@ ap.add_argument("--packets", type=int, default=4096)
 ap.add_argument("--only", default="", help="comma-separated config numbers (default: 3,4,5)")
 ap.add_argument("--no-verify", action="store_true")
 ap.add_argument("--force-generic", action="store_true")
-ap.add_argument("--one-round", action="store_true", help="lw_debug_batch_set_rounds(1): k_long with whole channel pairs per wave "
-                                                         "also in sparse launches (A/B of the split units)")
 args = ap.parse_args()
 ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
 NB = 4
@@ -56,8 +54,6 @@ def run(w):
         bt = Batch(dec, NP, "i16")
         if args.force_generic:
             bt.set_force_generic(True)
-        if args.one_round:
-            bt.debug_set_rounds(1)
         bt.entropy(items, n_threads=0)
         bt.upload(None)
         outs.append(torch.empty(max(1, bt.out_elems), dtype=torch.int16, device="cuda"))
