@@ -398,10 +398,12 @@ int lw_debug_imdct(lw_decoder *d, int blockflag, const float *spectrum, float *o
  * offsets (order of struct LwFastImage in csrc/lw_fast.hpp).  Returns the image size in bytes, 0 if the
  * stream shape is not covered by that kernel; copies min(size, cap) bytes. */
 size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint32_t *offsets16);
-/* The same for the short-block kernel (k_short; section offsets are the compile-time LWS_* of csrc/lw_fast.hpp) and its
- * unit list (8 bytes per unit: channel a, channel b or -1, coupled, floor slot a / b, post count a / b, 0).  *n_units: in =
- * room in units8, out = units of the stream.  0 if the short blocks of the stream are not covered. */
-size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint8_t *units8, size_t *n_units);
+/* The same for the block kernel k_short<L> (L = lanes per block = block size / 32; section offsets: LwBlkLayout<L> in
+ * csrc/lw_fast.hpp) and its unit list (8 bytes per unit: channel a, channel b or -1, coupled, floor slot a / b, post count
+ * a / b, 0).  blockflag 0: the short blocks; 1: the long blocks of a stream k_long does not cover.  *n_units: in = room in
+ * units8, out = units of the stream.  0 if those blocks are not covered. */
+size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, int blockflag, uint8_t *dst, size_t cap, uint8_t *units8,
+		size_t *n_units, uint32_t *lanes);
 
 /* Library/version introspection */
 const char *lw_version(void);

@@ -53,8 +53,14 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	const size_t o_tasks = slice(max_packets * ch * sizeof(LwGenTask));
 	// k_short: at most two slots per short packet (a recomputed predecessor in front of it) plus one per long block with a
 	// short left slope, in tasks of LW_SHORT_SLOTS
-	const size_t max_tasks = d->shortp.eligible ? (3 * max_packets + LW_SHORT_SLOTS - 1) / LW_SHORT_SLOTS + 1 : 0;
-	const size_t o_slots = slice(max_tasks * LW_SHORT_SLOTS * sizeof(LwShortSlot));
+	size_t max_tasks[2] = {0, 0}, o_slots[2] = {0, 0};
+	for (int cls = 0; cls < 2; cls++)
+		if (d->blkp[cls].eligible) {
+			// (sized in slots: at most three per packet plus one task of padding, whatever the passes per task)
+			const size_t per_wave = 64 / d->blkp[cls].lanes;
+			max_tasks[cls] = 3 * max_packets + 2 * per_wave * d->blkp[cls].passes;
+			o_slots[cls] = slice(max_tasks[cls] * sizeof(LwShortSlot));
+		}
 	const size_t o_res = slice(res_b), o_fc = d->any_floor0 ? slice(res_b) : 0;
 	b->slab_bytes = off;
 	bool ok = lw_hip_ok(hipHostMalloc((void **)&b->h_slab, off), "hipHostMalloc(batch records)") &&
@@ -69,8 +75,11 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		b->h_gen = (uint32_t *)H(o_gen), b->d_gen = (uint32_t *)D(o_gen);
 		b->h_ola = (LwOlaDesc *)H(o_ola), b->d_ola = (LwOlaDesc *)D(o_ola);
 		b->h_tasks = (LwGenTask *)H(o_tasks), b->d_tasks = (LwGenTask *)D(o_tasks);
-		b->h_slots = (LwShortSlot *)H(o_slots), b->d_slots = (LwShortSlot *)D(o_slots);
-		b->max_tasks = max_tasks;
+		for (int cls = 0; cls < 2; cls++)
+			if (max_tasks[cls]) {
+				b->h_slots[cls] = (LwShortSlot *)H(o_slots[cls]), b->d_slots[cls] = (LwShortSlot *)D(o_slots[cls]);
+				b->max_tasks[cls] = max_tasks[cls];
+			}
 		b->h_res = (float *)H(o_res), b->d_res = (float *)D(o_res);
 		if (d->any_floor0)
 			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
@@ -298,10 +307,15 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->has_generic = b->has_fast = false;
 	b->n_gen_small = b->n_gen_large = b->n_gen_ola = 0;
 	b->has_tdonly = false;
-	b->short_idx.clear();
-	b->short_slot.clear();
-	b->n_tasks = 0;
-	const bool short_ok = d->fast.eligible && d->shortp.eligible && !b->force_generic;
+	for (int cls = 0; cls < 2; cls++) {
+		b->blk_idx[cls].clear();
+		b->blk_slot[cls].clear();
+		b->n_tasks[cls] = 0;
+	}
+	// k_short<L> covers the short blocks (class 0) and, where k_long does not apply, the long blocks with two long slopes (class 1)
+	const bool blk_ok[2] = {d->blkp[0].eligible && !b->force_generic, d->blkp[1].eligible && !b->force_generic};
+	// short blocks of 256 points next to k_long: long blocks with short slopes stay in k_long<EDGE> (lw_fast.hpp)
+	const bool short_ok = d->fast.eligible && blk_ok[0] && d->blkp[0].bs == 8;
 	b->edge_mode = false; // set when the batch has a long block with a short slope (an all-(1,1) batch keeps the plain k_long)
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
 	for (size_t i = 0; i < n; i++) {
@@ -378,11 +392,16 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				b->fast_idx.push_back((uint32_t)i);
 				b->fast_slot.push_back((uint32_t)pw->slot);
 			}
-		} else if (short_ok && !p.blockflag && (d->shortp.short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) &&
+		} else if (blk_ok[1] && p.blockflag && p.prev_flag && p.next_flag &&
+				(d->blkp[1].short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) && (r.prev == -1 || r.plen == n1h)) {
+			r.flags |= LW_RF_FAST; // (a long block of a stream without k_long: k_short<L>, class 1; other window shapes: generic)
+			b->blk_idx[1].push_back((uint32_t)i);
+			b->blk_slot[1].push_back((uint32_t)pw->slot);
+		} else if (blk_ok[0] && !p.blockflag && (d->blkp[0].short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) &&
 				(r.prev == -1 || r.plen == n0h)) {
-			r.flags |= LW_RF_FAST; // (LW_RF_FAST without LW_RF_LONG: a block of k_short)
-			b->short_idx.push_back((uint32_t)i);
-			b->short_slot.push_back((uint32_t)pw->slot);
+			r.flags |= LW_RF_FAST; // (LW_RF_FAST without LW_RF_LONG: a short block of k_short<L>, class 0)
+			b->blk_idx[0].push_back((uint32_t)i);
+			b->blk_slot[0].push_back((uint32_t)pw->slot);
 		}
 		pw->present = true;
 		pw->len = w.right_end - w.right_start;
@@ -416,132 +435,157 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	b->out_elems = out_off;
 	b->alg_bytes = alg;
-	if (!b->fast_idx.empty() || !b->short_idx.empty())
+	if (!b->fast_idx.empty() || !b->blk_idx[0].empty() || !b->blk_idx[1].empty())
 		for (size_t i = 0; i < n; i++) { // generic successors of packets of the specialised kernels read the td block
 			const LwPacketRec &r = b->h_recs[i];
 			const bool ola_generic = !(r.flags & LW_RF_FAST) || (r.flags & LW_RF_TDONLY);
 			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
 				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
 		}
-	// ---- slots of k_short (lw_fast.hpp): the short blocks of the streams it covers, sorted by stream so that consecutive blocks
-	// of a stream sit in consecutive slots of a wave and hand their right part over through LDS; a block whose short
-	// predecessor is not the slot in front of it (wave boundary, another stream's packets in between in a batch that is not
-	// stream-major... after sorting: only the wave boundary) gets that predecessor recomputed in the slot in front (LW_SS_HALO).
-	// A short block followed by a long one with a short left slope also does that block's first 128 samples; such a long
-	// block whose predecessor is NOT a block of k_short gets a slot of its own that only carries the stored right part
-	// (LW_SS_EDGE).
-	if (short_ok && (!b->short_idx.empty() || !b->fast_idx.empty())) {
+	// ---- slots of k_short<L> (lw_fast.hpp), per block class: the blocks sorted by stream so that consecutive blocks of a stream sit
+	// in consecutive slots of a wave and hand their right part over through LDS; a block whose predecessor of the same class is
+	// not the slot in front of it (wave boundary) gets that predecessor recomputed in the slot in front (LW_SS_HALO).
+	// With 256-point short blocks next to k_long (short_ok): a short block followed by a long one with a short left slope also
+	// does that block's first 128 samples; such a long block whose predecessor is NOT a block of k_short gets a slot of its own
+	// that only carries the stored right part (LW_SS_EDGE).
+	if ((blk_ok[0] || blk_ok[1]) && (!b->blk_idx[0].empty() || !b->blk_idx[1].empty() || (short_ok && !b->fast_idx.empty()))) {
 		b->succ.assign(n, -1);
 		for (size_t i = 0; i < n; i++)
 			if (!(b->h_recs[i].flags & LW_RF_SKIP) && b->h_recs[i].prev >= 0)
 				b->succ[b->h_recs[i].prev] = (int32_t)i;
-		auto is_short_fast = [&](const LwPacketRec &r) { return (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == LW_RF_FAST; };
-		auto is_long_fast = [&](const LwPacketRec &r) { return (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == (LW_RF_FAST | LW_RF_LONG); };
-		// events: short blocks, and long blocks with a short left slope whose predecessor is not a short block of k_short
+		const bool klong = d->fast.eligible;
+		// a packet of k_long / a block of k_short<L> of class `cls`
+		auto is_long_fast = [&](const LwPacketRec &r) {
+			return klong && (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == (LW_RF_FAST | LW_RF_LONG);
+		};
+		auto is_blk = [&](const LwPacketRec &r, int cls) {
+			if ((r.flags & (LW_RF_FAST | LW_RF_SKIP)) != LW_RF_FAST || is_long_fast(r))
+				return false;
+			return ((r.flags & LW_RF_LONG) ? 1 : 0) == cls;
+		};
 		struct Ev {
 			uint32_t slot, idx;
 		};
 		std::vector<Ev> ev;
-		ev.reserve(b->short_idx.size() + 16);
-		for (size_t k = 0; k < b->short_idx.size(); k++)
-			ev.push_back(Ev{b->short_slot[k], b->short_idx[k]});
-		for (size_t k = 0; k < b->fast_idx.size(); k++) {
-			const LwPacketRec &r = b->h_recs[b->fast_idx[k]];
-			if ((r.xflags & LW_XF_EDGE_L) && r.prev != -1 && !(r.prev >= 0 && is_short_fast(b->h_recs[r.prev])))
-				ev.push_back(Ev{b->fast_slot[k], b->fast_idx[k]});
-		}
-		std::stable_sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &c) { return a.slot != c.slot ? a.slot < c.slot : a.idx < c.idx; });
-		LwShortSlot *slots = b->h_slots;
-		size_t n_slots = 0; // slots used so far (tasks are consecutive groups of LW_SHORT_SLOTS)
-		auto room = [&](size_t want) { // the next `want` slots lie in one task
-			const size_t used = n_slots % LW_SHORT_SLOTS;
-			if (used + want > LW_SHORT_SLOTS)
-				while (n_slots % LW_SHORT_SLOTS) {
-					std::memset(&slots[n_slots], 0, sizeof(LwShortSlot));
-					slots[n_slots].next_edge = 0xFFFFFFFFu;
-					slots[n_slots].state_out = -1;
-					n_slots++;
-				}
-		};
-		auto blank = [&](uint32_t idx, uint8_t kind) -> LwShortSlot & {
-			LwShortSlot &sl = slots[n_slots++];
-			std::memset(&sl, 0, sizeof(sl));
-			const LwPacketRec &r = b->h_recs[idx];
-			sl.res_off = r.res_off;
-			sl.floor_off = r.floor_off;
-			sl.out_off = r.out_off;
-			sl.state_out = -1;
-			sl.next_edge = 0xFFFFFFFFu;
-			sl.kind = kind;
-			sl.prev_kind = LW_SP_NONE;
-			sl.pkt = idx;
-			return sl;
-		};
-		// where the stored right part in front of packet `r` lives when it is not a slot of this kernel
-		auto outside_prev = [&](const LwPacketRec &r, LwShortSlot &sl) {
-			if (r.prev <= -2) {
-				sl.prev_kind = LW_SP_STATE;
-				sl.prev_arg = (uint32_t)(-(r.prev + 2));
-				sl.flags |= r.flags & LW_RF_PARITY_IN;
-			} else if (r.prev >= 0) {
-				const LwPacketRec &pr = b->h_recs[r.prev];
-				if (is_long_fast(pr)) { // (its right slope is short: the stored part has the short slope's length)
-					sl.prev_kind = LW_SP_EDGE;
-					sl.prev_arg = (uint32_t)r.prev;
-				} else {
-					sl.prev_kind = LW_SP_TD;
-					sl.prev_arg = 2u * pr.res_off + pr.rs;
-					sl.prev_stride = (uint16_t)(1u << pr.bs);
-				}
-			}
-		};
-		auto set_next = [&](uint32_t idx, LwShortSlot &sl) { // the long successor with a short left slope, if any
-			const int32_t nx = b->succ[idx];
-			if (nx < 0)
-				return;
-			const LwPacketRec &nr = b->h_recs[nx];
-			if (is_long_fast(nr) && (nr.xflags & LW_XF_EDGE_L)) {
-				sl.next_edge = (uint32_t)nx;
-				sl.next_out = nr.out_off;
-				sl.next_m = (uint32_t)(nr.rs - nr.ls);
-			}
-		};
-		int64_t last_pkt = -1; // packet of the slot placed last (a block or a halo), -1 after anything else
-		for (const Ev &e : ev) {
-			const LwPacketRec &r = b->h_recs[e.idx];
-			if (r.flags & LW_RF_LONG) { // LW_SS_EDGE
-				room(1);
-				LwShortSlot &sl = blank(e.idx, LW_SS_EDGE);
-				outside_prev(r, sl);
-				sl.next_edge = e.idx;
-				sl.next_out = r.out_off;
-				sl.next_m = (uint32_t)(r.rs - r.ls);
-				last_pkt = -1;
+		for (int cls = 0; cls < 2; cls++) {
+			if (!blk_ok[cls])
 				continue;
+			// passes per wave: more slots per recomputed predecessor -- but only while the launch keeps enough waves to fill the
+			// chip (a wave's passes run one after the other: 4096 blocks of 1024 points in 820 waves of 3 passes were slower
+			// than in 4096 waves of one)
+			const size_t per_wave = 64 / d->blkp[cls].lanes;
+			uint32_t passes = 1;
+			while (passes < d->blkp[cls].passes &&
+					b->blk_idx[cls].size() / (per_wave * (passes + 1) - 1) >= 8 * (size_t)std::max(1, d->n_cus))
+				passes++;
+			b->blk_passes[cls] = passes;
+			const size_t per_task = per_wave * passes;
+			// events: the class's blocks, and (class 0, short_ok) long blocks with a short left slope whose predecessor is not a
+			// short block of k_short
+			ev.clear();
+			for (size_t k = 0; k < b->blk_idx[cls].size(); k++)
+				ev.push_back(Ev{b->blk_slot[cls][k], b->blk_idx[cls][k]});
+			if (cls == 0 && short_ok)
+				for (size_t k = 0; k < b->fast_idx.size(); k++) {
+					const LwPacketRec &r = b->h_recs[b->fast_idx[k]];
+					if ((r.xflags & LW_XF_EDGE_L) && r.prev != -1 && !(r.prev >= 0 && is_blk(b->h_recs[r.prev], 0)))
+						ev.push_back(Ev{b->fast_slot[k], b->fast_idx[k]});
+				}
+			if (ev.empty())
+				continue;
+			std::stable_sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &c) { return a.slot != c.slot ? a.slot < c.slot : a.idx < c.idx; });
+			LwShortSlot *slots = b->h_slots[cls];
+			size_t n_slots = 0; // slots used so far (tasks are consecutive groups of per_task)
+			auto room = [&](size_t want) { // the next `want` slots lie in one task
+				const size_t used = n_slots % per_task;
+				if (used + want > per_task)
+					while (n_slots % per_task) {
+						std::memset(&slots[n_slots], 0, sizeof(LwShortSlot));
+						slots[n_slots].next_edge = 0xFFFFFFFFu;
+						slots[n_slots].state_out = -1;
+						n_slots++;
+					}
+			};
+			auto blank = [&](uint32_t idx, uint8_t kind) -> LwShortSlot & {
+				LwShortSlot &sl = slots[n_slots++];
+				std::memset(&sl, 0, sizeof(sl));
+				const LwPacketRec &r = b->h_recs[idx];
+				sl.res_off = r.res_off;
+				sl.floor_off = r.floor_off;
+				sl.out_off = r.out_off;
+				sl.state_out = -1;
+				sl.next_edge = 0xFFFFFFFFu;
+				sl.kind = kind;
+				sl.prev_kind = LW_SP_NONE;
+				sl.pkt = idx;
+				return sl;
+			};
+			// where the stored right part in front of packet `r` lives when it is not a slot of this launch
+			auto outside_prev = [&](const LwPacketRec &r, LwShortSlot &sl) {
+				if (r.prev <= -2) {
+					sl.prev_kind = LW_SP_STATE;
+					sl.prev_arg = (uint32_t)(-(r.prev + 2));
+					sl.flags |= r.flags & LW_RF_PARITY_IN;
+				} else if (r.prev >= 0) {
+					const LwPacketRec &pr = b->h_recs[r.prev];
+					if (short_ok && is_long_fast(pr)) { // (its right slope is short: the stored part has the short slope's length)
+						sl.prev_kind = LW_SP_EDGE;
+						sl.prev_arg = (uint32_t)r.prev;
+					} else { // generic kernels, or k_long<TD>: the whole time-domain block is in td
+						sl.prev_kind = LW_SP_TD;
+						sl.prev_arg = 2u * pr.res_off + pr.rs;
+						sl.prev_stride = (uint16_t)(1u << pr.bs);
+					}
+				}
+			};
+			auto set_next = [&](uint32_t idx, LwShortSlot &sl) { // the long successor with a short left slope, if any
+				const int32_t nx = b->succ[idx];
+				if (nx < 0 || !short_ok)
+					return;
+				const LwPacketRec &nr = b->h_recs[nx];
+				if (is_long_fast(nr) && (nr.xflags & LW_XF_EDGE_L)) {
+					sl.next_edge = (uint32_t)nx;
+					sl.next_out = nr.out_off;
+					sl.next_m = (uint32_t)(nr.rs - nr.ls);
+				}
+			};
+			int64_t last_pkt = -1; // packet of the slot placed last (a block or a halo), -1 after anything else
+			for (const Ev &e : ev) {
+				const LwPacketRec &r = b->h_recs[e.idx];
+				if (is_long_fast(r)) { // LW_SS_EDGE
+					room(1);
+					LwShortSlot &sl = blank(e.idx, LW_SS_EDGE);
+					outside_prev(r, sl);
+					sl.next_edge = e.idx;
+					sl.next_out = r.out_off;
+					sl.next_m = (uint32_t)(r.rs - r.ls);
+					last_pkt = -1;
+					continue;
+				}
+				const bool pred_same = r.prev >= 0 && is_blk(b->h_recs[r.prev], cls);
+				bool lane = pred_same && last_pkt == (int64_t)r.prev && (n_slots % per_task) != 0;
+				if (pred_same && !lane) { // recompute the predecessor in the slot in front
+					room(2);
+					blank((uint32_t)r.prev, LW_SS_HALO);
+					lane = true;
+				} else if (!lane) {
+					room(1);
+				}
+				LwShortSlot &sl = blank(e.idx, LW_SS_BLOCK);
+				if (lane)
+					sl.prev_kind = LW_SP_LANE;
+				else
+					outside_prev(r, sl);
+				sl.state_out = r.state_out;
+				sl.flags |= r.flags & LW_RF_PARITY_OUT;
+				if (r.flags & LW_RF_WRITE_TD)
+					sl.flags |= LW_SF_WRITE_TD;
+				set_next(e.idx, sl);
+				last_pkt = (int64_t)e.idx;
 			}
-			const bool pred_short = r.prev >= 0 && is_short_fast(b->h_recs[r.prev]);
-			bool lane = pred_short && last_pkt == (int64_t)r.prev && (n_slots % LW_SHORT_SLOTS) != 0;
-			if (pred_short && !lane) { // recompute the predecessor in the slot in front
-				room(2);
-				blank((uint32_t)r.prev, LW_SS_HALO);
-				lane = true;
-			} else if (!lane) {
-				room(1);
-			}
-			LwShortSlot &sl = blank(e.idx, LW_SS_BLOCK);
-			if (lane)
-				sl.prev_kind = LW_SP_LANE;
-			else
-				outside_prev(r, sl);
-			sl.state_out = r.state_out;
-			sl.flags |= r.flags & LW_RF_PARITY_OUT;
-			if (r.flags & LW_RF_WRITE_TD)
-				sl.flags |= LW_SF_WRITE_TD;
-			set_next(e.idx, sl);
-			last_pkt = (int64_t)e.idx;
+			room(per_task + 1); // pad the last task
+			b->n_tasks[cls] = n_slots / per_task;
 		}
-		room(LW_SHORT_SLOTS + 1); // pad the last task
-		b->n_tasks = n_slots / LW_SHORT_SLOTS;
 	}
 	// tasks of the short-block transform kernel: record + the per-channel look-ups, one load on the device
 	for (uint32_t t = 0; t < b->n_gen_small; t++) {
@@ -716,8 +760,11 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 		HIP_TRY(hipMemcpyAsync(b->d_ola, b->h_ola, b->n_gen_ola * sizeof(LwOlaDesc), hipMemcpyHostToDevice, st));
 	if (b->n_gen_small)
 		HIP_TRY(hipMemcpyAsync(b->d_tasks, b->h_tasks, (size_t)b->n_gen_small * ch * sizeof(LwGenTask), hipMemcpyHostToDevice, st));
-	if (b->n_tasks)
-		HIP_TRY(hipMemcpyAsync(b->d_slots, b->h_slots, b->n_tasks * LW_SHORT_SLOTS * sizeof(LwShortSlot), hipMemcpyHostToDevice, st));
+	for (int cls = 0; cls < 2; cls++)
+		if (b->n_tasks[cls])
+			HIP_TRY(hipMemcpyAsync(b->d_slots[cls], b->h_slots[cls],
+						b->n_tasks[cls] * (64 / b->dec->blkp[cls].lanes * b->blk_passes[cls]) * sizeof(LwShortSlot),
+						hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
 	if (b->n_halo_items)
@@ -744,7 +791,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		return LW_OK;
 	const bool run_generic = b->has_generic || all_generic;
 	const bool run_fast = b->has_fast && !all_generic;
-	const bool run_short = b->n_tasks > 0 && !all_generic;
+	const bool run_short = (b->n_tasks[0] > 0 || b->n_tasks[1] > 0) && !all_generic;
 	if (b->edge_mode && (run_fast || run_short) && !b->d_edge)
 		HIP_TRY(hipMalloc((void **)&b->d_edge, b->max_packets * 2 * d->T.ch * LW_EDGE_VALUES * sizeof(float)));
 	if (run_short && (b->has_generic || all_generic) && !b->d_td) { // (k_short may read / write td blocks next to generic packets)
@@ -820,18 +867,24 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
 	}
-	if (run_short) {
-		LwShortLaunch S{};
-		S.d_image = d->d_short_image;
-		S.d_slots = b->d_slots;
-		S.n_tasks = (uint32_t)b->n_tasks;
-		S.n_units = (uint32_t)d->shortp.units.size();
-		for (size_t i = 0; i < d->shortp.units.size() && i < LW_FAST_WAVES; i++)
-			S.units[i] = d->shortp.units[i];
-		S.d_edge = b->d_edge;
-		HIP_TRY(lw_launch_short(d->T, B, S, d_out, b->fmt, st));
-		b->last_kernels += "k_short,";
-	}
+	if (run_short)
+		for (int cls = 1; cls >= 0; cls--) { // (the two classes never touch: generic packets lie between them)
+			if (!b->n_tasks[cls])
+				continue;
+			const LwShortPlan &bp = d->blkp[cls];
+			LwShortLaunch S{};
+			S.d_image = d->d_blk_image[cls];
+			S.d_slots = b->d_slots[cls];
+			S.lanes = bp.lanes;
+			S.passes = b->blk_passes[cls];
+			S.n_tasks = (uint32_t)b->n_tasks[cls];
+			S.n_units = (uint32_t)bp.units.size();
+			for (size_t i = 0; i < bp.units.size() && i < LW_FAST_WAVES; i++)
+				S.units[i] = bp.units[i];
+			S.d_edge = b->d_edge;
+			HIP_TRY(lw_launch_short(d->T, B, S, d_out, b->fmt, st));
+			b->last_kernels += "k_short,";
+		}
 	if (run_generic) {
 		lw_launch_generic_ola(d->T, B, d_out, b->fmt, st, all_generic);
 		b->last_kernels += "k_ola_generic,";

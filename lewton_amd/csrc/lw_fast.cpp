@@ -268,20 +268,113 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 	plan.eligible = true;
 }
 
-void build_short_plan(const Ident &id, const Setup &s, const LwFastPlan &fast, LwShortPlan &plan)
+namespace {
+// the LDS image of k_short<L> (index conventions of lw_fast.hpp: l = lane inside the block, 0 .. L-1)
+template <int L>
+void fill_blk_image(const BlocksizeTables &t, const Setup &s, const std::vector<int> &floor_slot, std::vector<uint8_t> &image)
+{
+	typedef LwBlkLayout<L> Y;
+	const uint32_t P = 8u * L, n = 4u * P, n2 = n / 2, n8 = n / 8;
+	const float *A = t.A.data(), *B = t.B.data(), *C = t.C.data(), *W = t.window.data();
+	image.assign(Y::TOTAL, 0);
+	auto f = [&](uint32_t off) { return reinterpret_cast<float *>(image.data() + off); };
+	auto h = [&](uint32_t off) { return reinterpret_cast<uint16_t *>(image.data() + off); };
+	std::memcpy(f(Y::APAIR), A, n2 * 4);
+	for (uint32_t x = 0; x < 4; x++)
+		for (uint32_t l = 0; l < L; l++) {
+			const uint32_t p = L * x + l, a = n2 - 4 - 4 * p; // imdct.rs:385-430
+			f(Y::TW_S2)[2 * p] = A[a];
+			f(Y::TW_S2)[2 * p + 1] = A[a + 1];
+		}
+	for (uint32_t b = 0; b < 2; b++)
+		for (uint32_t l = 0; l < L; l++) {
+			const uint32_t r = 2 * L - 1 - L * b - l; // imdct.rs:445-446: A[8 r]
+			f(Y::TW_L0)[2 * (L * b + l)] = A[8 * r];
+			f(Y::TW_L0)[2 * (L * b + l) + 1] = A[8 * r + 1];
+		}
+	for (uint32_t l = 0; l < L; l++) {
+		const uint32_t r = L - 1 - l; // imdct.rs:449-452: A[16 r]
+		f(Y::TW_L1)[2 * l] = A[16 * r];
+		f(Y::TW_L1)[2 * l + 1] = A[16 * r + 1];
+	}
+	// stages l >= 2 (imdct.rs:454-477): twiddle A[(8 << l) r], r = the complement of the pair bits below the butterfly's bit
+	if (L == 32) {
+		for (uint32_t b = 0; b < 2; b++)
+			for (uint32_t lo3 = 0; lo3 < 8; lo3++) {
+				const uint32_t r = 15 - (8 * b + lo3);
+				f(Y::TW_C2)[2 * (8 * b + lo3)] = A[32 * r];
+				f(Y::TW_C2)[2 * (8 * b + lo3) + 1] = A[32 * r + 1];
+			}
+		for (uint32_t lo3 = 0; lo3 < 8; lo3++) {
+			const uint32_t r = 7 - lo3;
+			f(Y::TW_C3)[2 * lo3] = A[64 * r];
+			f(Y::TW_C3)[2 * lo3 + 1] = A[64 * r + 1];
+		}
+	} else if (L == 16) {
+		for (uint32_t lo3 = 0; lo3 < 8; lo3++) {
+			const uint32_t r = 7 - lo3;
+			f(Y::TW_C2)[2 * lo3] = A[32 * r];
+			f(Y::TW_C2)[2 * lo3 + 1] = A[32 * r + 1];
+		}
+	}
+	f(Y::A2)[0] = A[n8];
+	for (uint32_t c = 0; c < 2; c++)
+		for (uint32_t l = 0; l < L; l++) {
+			const uint32_t mp = 2 * l + c, e = L * c + l;
+			for (uint32_t j = 0; j < 4; j++) {
+				f(Y::C4)[4 * e + j] = C[4 * mp + j];
+				f(Y::B_LO)[4 * e + j] = B[4 * mp + j];
+				f(Y::B_HI)[4 * e + j] = B[4 * (P / 2 - 1 - mp) + j];
+			}
+			const uint32_t q[4] = {P - 1 - 2 * mp, P - 2 - 2 * mp, 1 + 2 * mp, 2 * mp};
+			for (uint32_t k = 0; k < 4; k++) {
+				f(Y::WIN)[8 * e + 2 * k] = W[q[k]];
+				f(Y::WIN)[8 * e + 2 * k + 1] = W[n2 - 1 - q[k]];
+			}
+		}
+	// (INV_DB is filled by the runtime: it owns the spec table)
+	for (size_t fl = 0; fl < s.floors.size(); fl++) {
+		const int slot = floor_slot[fl];
+		if (slot < 0)
+			continue;
+		const Floor1 &f1 = s.floors[fl].f1;
+		const size_t F = f1.sorted_x.size();
+		for (size_t i = 0; i < 64; i++)
+			f(Y::XSF)[64 * slot + i] = i < F ? (float)f1.sorted_x[i] : std::numeric_limits<float>::infinity();
+		for (uint32_t x = 0; x < 4; x++)
+			for (uint32_t l = 0; l < L; l++)
+				for (uint32_t j = 0; j < 4; j++) {
+					const uint32_t k = 4 * (L * x + l) + j;
+					size_t sidx = 0; // largest s with xs[s] <= k (xs[0] = 0)
+					while (sidx + 1 < F && f1.sorted_x[sidx + 1] <= k)
+						sidx++;
+					h(Y::SID16)[((slot * 4 + x) * L + l) * 4 + j] = (uint16_t)(16 * sidx);
+				}
+	}
+}
+} // namespace
+
+void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFastPlan &fast, LwShortPlan &plan)
 {
 	plan = LwShortPlan();
-	if (!fast.eligible) {
-		plan.why_not = "long blocks not covered by the specialised kernel";
+	const uint32_t bs = blockflag ? id.bs1 : id.bs0;
+	if (blockflag && fast.eligible) {
+		plan.why_not = "long blocks run through k_long";
 		return;
 	}
-	if (id.bs0 != LW_SHORT_BS) {
-		plan.why_not = "blocksize_0 is not 8";
+	if (blockflag && id.bs1 == id.bs0) {
+		plan.why_not = "blocksize_1 = blocksize_0: the two block classes are neighbours with full overlap (generic kernels)";
 		return;
 	}
-	const uint32_t n = 1u << id.bs0, n2 = n / 2, n8 = n / 8, P = n / 4;
+	if (bs < LW_BLK_MIN_BS || bs > LW_BLK_MAX_BS) {
+		plan.why_not = "block size outside 256 .. 1024";
+		return;
+	}
+	plan.bs = bs;
+	plan.lanes = 1u << (bs - 5);
+	plan.passes = plan.lanes == 32 ? 3 : plan.lanes == 16 ? 2 : 1;
 	UnitPlan up;
-	if (const char *why = plan_units(id, s, false, LW_SHORT_MAX_POSTS, up)) {
+	if (const char *why = plan_units(id, s, blockflag, LW_BLK_MAX_POSTS(plan.lanes), up)) {
 		plan.why_not = why;
 		return;
 	}
@@ -289,64 +382,13 @@ void build_short_plan(const Ident &id, const Setup &s, const LwFastPlan &fast, L
 	plan.units = up.units;
 	plan.n_staged_floors = up.n_staged;
 	std::memcpy(plan.staged_floor_F, up.staged_F, sizeof(plan.staged_floor_F));
-	// ---- LDS image (index conventions of lw_fast.hpp: l = lane inside the block, 0..7)
-	const BlocksizeTables &t = id.tab[0];
-	const float *A = t.A.data(), *B = t.B.data(), *C = t.C.data(), *W = t.window.data();
-	plan.image.assign(LWS_TOTAL, 0);
-	auto f = [&](uint32_t off) { return reinterpret_cast<float *>(plan.image.data() + off); };
-	auto h = [&](uint32_t off) { return reinterpret_cast<uint16_t *>(plan.image.data() + off); };
-	std::memcpy(f(LWS_APAIR), A, n2 * 4);
-	for (uint32_t x = 0; x < 4; x++)
-		for (uint32_t l = 0; l < 8; l++) {
-			const uint32_t p = 8 * x + l, a = n2 - 4 - 4 * p; // imdct.rs:385-430
-			f(LWS_TW_S2)[2 * (8 * x + l)] = A[a];
-			f(LWS_TW_S2)[2 * (8 * x + l) + 1] = A[a + 1];
-		}
-	for (uint32_t b = 0; b < 2; b++)
-		for (uint32_t l = 0; l < 8; l++) {
-			const uint32_t r = 15 - 8 * b - l; // imdct.rs:445-446: A[8 r]
-			f(LWS_TW_L0)[2 * (8 * b + l)] = A[8 * r];
-			f(LWS_TW_L0)[2 * (8 * b + l) + 1] = A[8 * r + 1];
-		}
-	for (uint32_t l = 0; l < 8; l++) {
-		const uint32_t r = 7 - l; // imdct.rs:449-452: A[16 r]
-		f(LWS_TW_L1)[2 * l] = A[16 * r];
-		f(LWS_TW_L1)[2 * l + 1] = A[16 * r + 1];
-	}
-	f(LWS_A2)[0] = A[n8];
-	for (uint32_t c = 0; c < 2; c++)
-		for (uint32_t l = 0; l < 8; l++) {
-			const uint32_t mp = 2 * l + c, e = 8 * c + l;
-			for (uint32_t j = 0; j < 4; j++) {
-				f(LWS_C4)[4 * e + j] = C[4 * mp + j];
-				f(LWS_B_LO)[4 * e + j] = B[4 * mp + j];
-				f(LWS_B_HI)[4 * e + j] = B[4 * (P / 2 - 1 - mp) + j];
-			}
-			const uint32_t q[4] = {P - 1 - 2 * mp, P - 2 - 2 * mp, 1 + 2 * mp, 2 * mp};
-			for (uint32_t k = 0; k < 4; k++) {
-				f(LWS_WIN)[8 * e + 2 * k] = W[q[k]];
-				f(LWS_WIN)[8 * e + 2 * k + 1] = W[n2 - 1 - q[k]];
-			}
-		}
-	// (LWS_INV_DB is filled by the runtime: it owns the spec table)
-	for (size_t fl = 0; fl < s.floors.size(); fl++) {
-		const int slot = up.floor_slot[fl];
-		if (slot < 0)
-			continue;
-		const Floor1 &f1 = s.floors[fl].f1;
-		const size_t F = f1.sorted_x.size();
-		for (size_t i = 0; i < 64; i++)
-			f(LWS_XSF)[64 * slot + i] = i < F ? (float)f1.sorted_x[i] : std::numeric_limits<float>::infinity();
-		for (uint32_t x = 0; x < 4; x++)
-			for (uint32_t l = 0; l < 8; l++)
-				for (uint32_t j = 0; j < 4; j++) {
-					const uint32_t k = 4 * (8 * x + l) + j;
-					size_t sidx = 0; // largest s with xs[s] <= k (xs[0] = 0)
-					while (sidx + 1 < F && f1.sorted_x[sidx + 1] <= k)
-						sidx++;
-					h(LWS_SID16)[((slot * 4 + x) * 8 + l) * 4 + j] = (uint16_t)(16 * sidx);
-				}
-	}
+	const BlocksizeTables &t = id.tab[blockflag ? 1 : 0];
+	if (plan.lanes == 8)
+		fill_blk_image<8>(t, s, up.floor_slot, plan.image);
+	else if (plan.lanes == 16)
+		fill_blk_image<16>(t, s, up.floor_slot, plan.image);
+	else
+		fill_blk_image<32>(t, s, up.floor_slot, plan.image);
 	plan.eligible = true;
 }
 

@@ -129,37 +129,50 @@ struct LwFastLaunch {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Short-block kernel k_short (n = 256 next to n = 2048): one wave = eight short blocks ("slots") of one unit, eight lanes per
-// block, the transform in registers with the layouts of k_long cut down to 64 complex pairs per block:
-//   B': lane = p[2:0], reg = p[5:3]   step 1, step 2, stages l = 0, 1     D': lane = p[5:3], reg = p[2:0]  fused last stages
+// Block kernel k_short<L> (n = 32 L = 256 / 512 / 1024): one wave = 64 / L blocks ("slots") of one unit, L lanes per block,
+// the transform in registers with the layouts of k_long cut down to 8 L complex pairs per block (b = log2 L):
+//   B': lane = p[b-1:0], reg = p[b+2:b]   step 1, step 2, stages l = 0, 1
+//   C': (L >= 16) register bits 1, 0 exchanged with lane bits 4, 3 (L = 16: register bit 0 with lane bit 3): stages l = 2 (, 3)
+//   D': register = p[2:0] after the 8 x 8 register <-> lane-bits-2..0 transpose: fused last three stages
 //   E': lane l of a block handles m' = 2 l + c (c = 0, 1): bit-reverse gather, step 7, step 8, window / overlap-add
+// It serves the short blocks (blocksize_0 = 8, 9, 10) of a stream and, where k_long (n = 2048) does not apply, its long blocks
+// (blocksize_1 = 9, 10) whose window slopes are both long.
 // ---------------------------------------------------------------------------------------------
-#define LW_SHORT_BS 8           // blocksize_0 the kernel is specialised for
-#define LW_SHORT_SLOTS 8        // blocks per wave
-#define LW_SHORT_MAX_POSTS 32   // floor-1 posts per short-block floor (4 per lane of a block)
+#define LW_BLK_MIN_BS 8         // block sizes the kernel is instantiated for: 2^8 .. 2^10
+#define LW_BLK_MAX_BS 10
+#define LW_BLK_MAX_SLOTS 8      // blocks per wave: 64 / L
+#define LW_BLK_MAX_POSTS(L) ((L) >= 16 ? 64 : 32) // floor-1 posts per channel of a block: 4 per lane (L = 8, 16), 2 per lane (L = 32)
 
-// byte offsets inside the short-block LDS image (compile-time layout, checked by build_short_plan)
-enum : uint32_t {
-	LWS_APAIR = 0,      // float2[64]          A as pairs: step 1 reads [m] and [63 - m]
-	LWS_TW_S2 = 512,    // float2[4][8]        step 2 twiddle of lower pair p = 8x + l: A[n/2 - 4 - 4p ..]
-	LWS_TW_L0 = 768,    // float2[2][8]        stage l = 0: A[8r ..], r = 15 - 8b - l
-	LWS_TW_L1 = 896,    // float2[8]           stage l = 1: A[16r ..], r = 7 - l
-	LWS_A2 = 960,       // float               A[n/8]
-	LWS_C4 = 976,       // float4[2][8]        C[4m' .. 4m'+3]
-	LWS_B_LO = 1232,    // float4[2][8]        B[4m' .. 4m'+3]
-	LWS_B_HI = 1488,    // float4[2][8]        B[4(31 - m') .. +3]
-	LWS_WIN = 1744,     // float[2][8][8]      window slope pairs (s[q], s[127 - q]) for q = 63-2m', 62-2m', 1+2m', 2m'
-	LWS_INV_DB = 2256,  // float[256]
-	LWS_XSF = 3280,     // float[LW_FAST_MAX_FLOORS][64]  ascending post x of each staged floor (padded with +inf)
-	LWS_SID16 = 3792,   // u16[LW_FAST_MAX_FLOORS][4][8][4] 16 * (static interval index) of bin 4(8x + l) + j
-	LWS_TOTAL = 5120    // 4304 padded: 64 lanes x 16 bytes x 5
+// byte offsets inside the LDS image of k_short<L> (compile-time layout; build_blk_plan writes the same)
+template <int L>
+struct LwBlkLayout {
+	static constexpr uint32_t APAIR = 0;                  // float2[8L]       A as pairs: step 1 reads [m] and [8L - 1 - m]
+	static constexpr uint32_t TW_S2 = APAIR + 64u * L;    // float2[4][L]     step 2 twiddle of lower pair p = L x + l: A[n/2 - 4 - 4p ..]
+	static constexpr uint32_t TW_L0 = TW_S2 + 32u * L;    // float2[2][L]     stage l = 0: A[8r ..], r = 2L - 1 - L b - l
+	static constexpr uint32_t TW_L1 = TW_L0 + 16u * L;    // float2[L]        stage l = 1: A[16r ..], r = L - 1 - l
+	static constexpr uint32_t TW_C2 = TW_L1 + 8u * L;     // float2[2][8]     stage l = 2 (L >= 16): A[32r ..]; L = 32: r = 15 - 8 b - lo3, L = 16: r = 7 - lo3 ([0] only)
+	static constexpr uint32_t TW_C3 = TW_C2 + 128u;       // float2[8]        stage l = 3 (L = 32): A[64r ..], r = 7 - lo3
+	static constexpr uint32_t A2 = TW_C3 + 64u;           // float            A[n/8]
+	static constexpr uint32_t C4 = A2 + 16u;              // float4[2][L]     C[4m' .. 4m'+3]
+	static constexpr uint32_t B_LO = C4 + 32u * L;        // float4[2][L]     B[4m' .. 4m'+3]
+	static constexpr uint32_t B_HI = B_LO + 32u * L;      // float4[2][L]     B[4(4L - 1 - m') .. +3]
+	static constexpr uint32_t WIN = B_HI + 32u * L;       // float[2][L][8]   window slope pairs (s[q], s[16L - 1 - q]) for q = 8L-1-2m', 8L-2-2m', 1+2m', 2m'
+	static constexpr uint32_t INV_DB = WIN + 64u * L;     // float[256]
+	static constexpr uint32_t XSF = INV_DB + 1024u;       // float[LW_FAST_MAX_FLOORS][64]  ascending post x of each staged floor (padded with +inf)
+	static constexpr uint32_t SID16 = XSF + 512u;         // u16[LW_FAST_MAX_FLOORS][4][L][4] 16 * (static interval index) of bin 4(L x + l) + j
+	static constexpr uint32_t END = SID16 + 64u * L;
+	static constexpr uint32_t TOTAL = (END + 1023u) & ~1023u; // whole 1 KB rows: 64 lanes x 16 bytes per staging step
 };
 
 struct LwShortPlan {
 	bool eligible = false;
 	const char *why_not = "";
+	uint32_t lanes = 0;            // L: lanes per block = 2^(bs - 5)
+	uint32_t passes = 1;           // most passes of 64 / L slots a wave may work through (more slots per recomputed predecessor where
+	                               // a wave holds few blocks: L = 32 -> 3, L = 16 -> 2); the planner picks per batch
+	uint32_t bs = 0;               // log2 of the block size
 	std::vector<uint8_t> image;
-	uint8_t short_mode_mask[32] = {0};
+	uint8_t short_mode_mask[32] = {0}; // modes covered (of the plan's blockflag)
 	std::vector<LwFastUnit> units;
 	uint32_t n_staged_floors = 0;
 	uint8_t staged_floor_F[LW_FAST_MAX_FLOORS] = {0};
@@ -178,7 +191,7 @@ struct LwShortPlan {
 #define LW_SP_TD 4u        // float offset prev_arg in B.td (channel 0), channel stride prev_stride: a generic-kernel predecessor
 #define LW_SF_WRITE_TD 2u     // also store the raw right part into this packet's td block (generic successor)
 
-// One slot = one 8-lane group of a k_short wave; 48 bytes (three 16-byte loads by every lane of the group).
+// One slot = one L-lane group of a k_short wave; 48 bytes (three 16-byte loads by every lane of the group).
 struct LwShortSlot {
 	uint32_t res_off;     // float offset of the packet's [ch][128] residue block
 	uint32_t floor_off;   // u16 offset of its floor block
@@ -202,16 +215,24 @@ static_assert(sizeof(LwShortSlot) == 48, "LwShortSlot is 48 bytes");
 
 struct LwShortLaunch {
 	const uint8_t *d_image;
-	const LwShortSlot *d_slots; // [n_tasks][LW_SHORT_SLOTS]
+	const LwShortSlot *d_slots; // [n_tasks][passes][64 / lanes]
+	uint32_t lanes;             // L
+	uint32_t passes;            // passes of 64 / L slots a wave works through
 	uint32_t n_tasks;
 	uint32_t n_units;
 	LwFastUnit units[LW_FAST_WAVES];
 	float *d_edge;
 };
 
+static inline uint32_t lw_blk_inv_db_offset(uint32_t lanes)
+{
+	return lanes == 8 ? LwBlkLayout<8>::INV_DB : lanes == 16 ? LwBlkLayout<16>::INV_DB : LwBlkLayout<32>::INV_DB;
+}
+
 namespace lw {
 // Decide whether the stream shape is covered by the specialised kernel and build its LDS image.
 void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan);
-// The same for the short blocks of a stream whose long blocks are covered (k_short).
-void build_short_plan(const Ident &id, const Setup &s, const LwFastPlan &fast, LwShortPlan &plan);
+// The same for k_short<L>: the blocks of the modes with `blockflag` (0: the short blocks; 1: the long blocks of a stream
+// k_long does not cover).
+void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFastPlan &fast, LwShortPlan &plan);
 }

@@ -61,8 +61,8 @@ struct lw_decoder {
 	LwFastPlan fast;               // specialised long-block kernel: eligibility, units, LDS image
 	uint8_t *d_fast_image = nullptr;
 	LwFastUnit *d_fast_units = nullptr;
-	LwShortPlan shortp;            // short-block kernel (k_short): eligibility, units, LDS image
-	uint8_t *d_short_image = nullptr;
+	LwShortPlan blkp[2];           // block kernel k_short<L>: [0] the short blocks, [1] the long blocks where k_long does not apply
+	uint8_t *d_blk_image[2] = {nullptr, nullptr};
 	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
 	void *one_out = nullptr; // pinned host output for the single-packet path
 	size_t one_out_bytes = 0;
@@ -94,11 +94,12 @@ struct lw_batch {
 	LwOlaDesc *h_ola = nullptr, *d_ola = nullptr; // [max_packets] descriptors of k_ola_generic's tasks (order of the third list)
 	bool has_tdonly = false; // the specialised kernel's work list contains LW_RF_TDONLY packets
 	// k_short: the short blocks of streams it covers, eight slots per task (lw_fast.hpp)
-	LwShortSlot *h_slots = nullptr, *d_slots = nullptr;
-	size_t max_tasks = 0, n_tasks = 0;
+	LwShortSlot *h_slots[2] = {nullptr, nullptr}, *d_slots[2] = {nullptr, nullptr}; // per block class
+	size_t max_tasks[2] = {0, 0}, n_tasks[2] = {0, 0}; // (max_tasks: capacity in SLOTS)
+	uint32_t blk_passes[2] = {1, 1}; // passes per wave of this batch (lw_fast.hpp)
 	bool edge_mode = false;  // short blocks in k_short, long blocks with short slopes in k_long<EDGE>
 	float *d_edge = nullptr; // [max_packets][2][ch][64]
-	std::vector<uint32_t> short_idx, short_slot, short_order;
+	std::vector<uint32_t> blk_idx[2], blk_slot[2];
 	std::vector<int32_t> succ; // per packet: the next packet of the same stream in this batch, or -1
 	// entropy stage on the device: the packets themselves go up (word-aligned, zero padded) with one descriptor each
 	bool dev_entropy = false;

@@ -27,6 +27,7 @@
 // Arithmetic contract: identical to lw_kernels.hip -- same f32 operations on the same operands as the
 // reference, compiled with -ffp-contract=off.  The floor curve uses trunc((t*dy +- 0.5) * (1/adx)), proven
 // equal to the reference's integer render_line for every reachable segment (tests/test_fast_model.py).
+#include <algorithm>
 #include <cstddef>
 
 #include "lw_fast.hpp"
@@ -1635,33 +1636,44 @@ __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_short: short blocks (n = 256) of streams whose long blocks run through k_long
+// k_short<L>: blocks of 32 L = 256 / 512 / 1024 points -- the short blocks of a stream, and the long blocks k_long does not cover
 // ---------------------------------------------------------------------------------------------
-// One wave64 = one workgroup = eight "slots" (8 lanes each) x one unit (a coupled channel pair, or one channel): eight short
-// blocks from their entropy records to PCM, no barrier, no communication with other waves.  The transform is k_long's,
-// cut down to 64 complex pairs per block (layouts B' / D' / E' of lw_fast.hpp; tests/short_model.py is the executable
-// specification): step 1 on the coalesced load layout, exchange with the mirror lane of the 8-lane group (DPP
-// row_half_mirror), step 2 and stages l = 0, 1 register-local, ONE 8 x 8 register <-> lane transpose (t3_inreg), the fused
-// last three stages register-local, the bit-reverse gather through 512 bytes of LDS per block, steps 7 and 8, window /
-// overlap-add, conversion, stores.  A slot's previous right part comes from the previous slot of the same wave (through
-// LDS: consecutive short blocks of a stream sit in consecutive slots), from the stream's state slot, from the edge
-// buffer k_long fills for long blocks with a short right slope, or from a generic predecessor's time-domain block.  A
-// slot whose successor is a long block with a short LEFT slope also does that block's first 128 samples (its raw left
-// edge pa(448..511) comes from the edge buffer; k_long runs before this kernel), so neither kernel waits for the other
-// inside a launch and no time-domain block makes a round trip through HBM.
+// One wave64 = one workgroup = 64 / L "slots" (L lanes each) x one unit (a coupled channel pair, or one channel): blocks from
+// their entropy records to PCM, no barrier, no communication with other waves.  The transform is k_long's, cut down to 8 L
+// complex pairs per block (layouts B' / C' / D' / E' of lw_fast.hpp; tests/short_model.py is the executable specification):
+// step 1 on the coalesced load layout, exchange with the mirror lane of the L-lane group, step 2 and stages l = 0, 1
+// register-local, (L >= 16) one or two register <-> lane exchanges and stages l = 2 (, 3), ONE 8 x 8 register <-> lane
+// transpose (t3_inreg), the fused last three stages register-local, the bit-reverse gather through LDS, steps 7 and 8,
+// window / overlap-add, conversion, stores.  A slot's previous right part comes from the previous slot of the same wave
+// (through LDS: consecutive blocks of a stream sit in consecutive slots), from the stream's state slot, from the edge
+// buffer k_long fills for long blocks with a short right slope, or from the time-domain block of a predecessor the generic
+// kernels (or k_long<TD>) transformed.  With 256-point short blocks next to k_long, a slot whose successor is a long block with
+// a short LEFT slope also does that block's first 128 samples (its raw left edge pa(448..511) comes from the edge buffer;
+// k_long runs before this kernel), so neither kernel waits for the other inside a launch and no time-domain block makes a
+// round trip through HBM.
 // Floor curve: as in k_long (interval entries {dy, 0.5 sgn(dy) - x0 dy, 1/adx, 4 y0} per post, y(k) = y0 + trunc((k dy +
-// c0) / adx) -- tests/test_fast_model.py), with the 8 lanes of a slot building the <= 32 entries of each channel: the
-// active-post mask of a slot is one byte of a wave-wide ballot per group of 8 posts.
+// c0) / adx) -- tests/test_fast_model.py), with the L lanes of a slot building the entries of each channel: the active-post
+// mask of a slot is L bits of a wave-wide ballot per group of L posts.
 #define LW_SHORT_SPLIT_BELOW 1024u // waves (tasks x units) below which a launch splits channel pairs over two waves
-#define LWK_REC_BYTES (LW_SHORT_SLOTS * 2u * LW_SHORT_MAX_POSTS * 2u)   // floor records  [slot][channel][32] u16
-#define LWK_TAB_BYTES (LW_SHORT_SLOTS * 2u * LW_SHORT_MAX_POSTS * 16u)  // interval entries [slot][channel][32] x 16 bytes
-#define LWK_SCR_BYTES (LW_SHORT_SLOTS * 64u * 8u)                       // bit-reverse gather of one channel: [slot][64] pairs
-#define LWK_PUB_BYTES (LW_SHORT_SLOTS * 2u * 2u * 8u * 16u)             // right parts [slot][channel][c2][l] float4
-#define LWK_OFF_REC LWS_TOTAL
-#define LWK_OFF_TAB (LWK_OFF_REC + LWK_REC_BYTES)
-#define LWK_OFF_SCR (LWK_OFF_TAB + LWK_TAB_BYTES)
-#define LWK_OFF_PUB (LWK_OFF_SCR + LWK_SCR_BYTES)
-#define LWK_LDS_BYTES (LWK_OFF_PUB + LWK_PUB_BYTES)
+
+template <int L>
+struct LwBlkLds { // compile-time facts of the LDS layout: [table image][gather][right parts][records][interval entries]
+	static constexpr uint32_t SLOTS = 64u / L;
+	static constexpr uint32_t POSTS = LW_BLK_MAX_POSTS(L);          // most posts per channel of a block
+	static constexpr uint32_t PT = POSTS / L;                      // posts per lane
+};
+
+// LDS of a wave behind the image.  Every area sits at a compile-time offset (ds offsets fold into the instructions: sizing the
+// floor areas for the stream's real post count at run time saved 3 KB per wave and cost 8 % at 16 384 packets per launch).
+template <int L>
+struct LwBlkWave {
+	static constexpr uint32_t SLOTS = 64u / L, POSTS = LW_BLK_MAX_POSTS(L);
+	static constexpr uint32_t SCR = 0;                              // bit-reverse gather of one channel: [slot][8 L] pairs
+	static constexpr uint32_t PUB = 4096u;                          // right parts [pass parity][slot][channel][c2][l] float4
+	static constexpr uint32_t REC = PUB + 8192u;                    // floor records [slot][channel][POSTS] u16
+	static constexpr uint32_t TAB = REC + SLOTS * 2u * POSTS * 2u;  // interval entries [slot][channel][POSTS] x 16 bytes
+	static constexpr uint32_t BYTES = TAB + SLOTS * 2u * POSTS * 16u;
+};
 
 struct LwShortArgs {
 	const float *residue;
@@ -1671,19 +1683,23 @@ struct LwShortArgs {
 	float *state, *td, *edge;
 	void *out;
 	uint32_t n_units, ch, fstride, state_stride, state_chan_stride;
+	uint32_t n_waves;  // tasks x units = workgroups of one wave
+	uint32_t passes; // a wave works through `passes` x 64 / L consecutive slots, 64 / L at a time (the last slot of a pass hands its
+	                 // right part to the first slot of the next through LDS: a recomputed predecessor only at the start of a wave)
 	LwFastUnit units[LW_FAST_WAVES];
 };
 
-// the 4 + 4 values a lane holds of a [64]-float half block q = 0..63 (pa or pb): lo = q in [4l, 4l+4), hi = q in [60-4l, 64-4l)
+// the 4 + 4 values a lane holds of a half block q = 0 .. 8L-1 (pa or pb): lo = q in [4l, 4l+4), hi = q in [8L-4-4l, 8L-4l)
 struct Half8 {
 	float4_t lo, hi;
 };
 
+template <int L>
 __device__ __forceinline__ Half8 load_half8(const float *src, uint32_t l)
 {
 	Half8 h;
 	h.lo = *reinterpret_cast<const float4_t *>(src + 4u * l);
-	h.hi = *reinterpret_cast<const float4_t *>(src + 60u - 4u * l);
+	h.hi = *reinterpret_cast<const float4_t *>(src + (8u * L - 4u) - 4u * l);
 	return h;
 }
 
@@ -1696,32 +1712,35 @@ __device__ __forceinline__ void prev_from_half8(const Half8 &g, PrevHalf &h)
 	h.pp[0][0] = float2_t{g.hi.w, g.hi.z};
 }
 
-// interval entries of one channel of this lane's slot: posts i = l + 8 t (see floor_table for the entry)
-__device__ __forceinline__ bool short_floor_table(const char *img, char *rec, char *tab, uint32_t g, uint32_t l, const uint32_t (&e)[4],
-		uint32_t fslot, uint32_t Fp, bool has_floor)
+// interval entries of one channel of this lane's slot: posts i = l + L t (see floor_table for the entry)
+template <int L>
+__device__ __forceinline__ bool short_floor_table(const char *img, char *rec, char *tab, uint32_t g, uint32_t l,
+		const uint32_t (&e)[LwBlkLds<L>::PT], uint32_t fslot, uint32_t Fp, bool has_floor)
 {
-	uint32_t mask = 0;
+	constexpr int PT = LwBlkLds<L>::PT;
+	unsigned long long mask = 0;
 #pragma unroll
-	for (int t = 0; t < 4; t++) {
+	for (int t = 0; t < PT; t++) {
 		const unsigned long long bal = __ballot(has_floor && (e[t] & LW_POST_ACTIVE) != 0);
-		mask |= ((uint32_t)(bal >> (8u * g)) & 0xffu) << (8 * t);
-		const uint32_t i = l + 8u * t;
-		*reinterpret_cast<uint16_t *>(rec + 2u * i) = (uint16_t)e[t];
+		mask |= ((bal >> (L * g)) & ((1ull << L) - 1ull)) << (L * t);
+		const uint32_t i = l + L * (uint32_t)t;
+		if (i < Fp)
+			*reinterpret_cast<uint16_t *>(rec + 2u * i) = (uint16_t)e[t];
 	}
 	const unsigned long long ub = __ballot(l == 0 && e[0] == LW_FLOOR_UNUSED);
-	const bool unused = !has_floor || ((ub >> (8u * g)) & 1ull) != 0;
+	const bool unused = !has_floor || ((ub >> (L * g)) & 1ull) != 0;
 	lds_fence();
 #pragma unroll
-	for (int t = 0; t < 4; t++) {
-		const uint32_t i = l + 8u * t;
-		const uint32_t lowmask = (2u << i) - 1u; // (i = 31: 2u << 31 wraps to 0, the mask becomes all ones)
-		const uint32_t below = mask & lowmask, above = mask & ~lowmask;
-		const int lo = below ? 31 - __builtin_clz(below) : 0;
-		const int hi = above ? __builtin_ctz(above) : lo;
+	for (int t = 0; t < PT; t++) {
+		const uint32_t i = l + L * (uint32_t)t;
+		const unsigned long long lowmask = (2ull << i) - 1ull; // (i = 63: 2 << 63 wraps to 0, the mask becomes all ones)
+		const unsigned long long below = mask & lowmask, above = mask & ~lowmask;
+		const int lo = below ? 63 - __builtin_clzll(below) : 0;
+		const int hi = above ? __builtin_ctzll(above) : lo;
 		const int ylo = (int)(*reinterpret_cast<const uint16_t *>(rec + 2 * lo) & 0xffu);
 		const int yhi = (int)(*reinterpret_cast<const uint16_t *>(rec + 2 * hi) & 0xffu);
-		const float xlo = *reinterpret_cast<const float *>(img + LWS_XSF + 4u * (64u * fslot + (uint32_t)lo));
-		const float xhi = *reinterpret_cast<const float *>(img + LWS_XSF + 4u * (64u * fslot + (uint32_t)hi));
+		const float xlo = *reinterpret_cast<const float *>(img + LwBlkLayout<L>::XSF + 4u * (64u * fslot + (uint32_t)lo));
+		const float xhi = *reinterpret_cast<const float *>(img + LwBlkLayout<L>::XSF + 4u * (64u * fslot + (uint32_t)hi));
 		const float dy = (float)(yhi - ylo); // 0 when there is no later active post (flat, audio.rs:546-548)
 		float4_t ent;
 		ent.x = dy;
@@ -1734,22 +1753,23 @@ __device__ __forceinline__ bool short_floor_table(const char *img, char *rec, ch
 	return unused;
 }
 
-// floor x residue of one channel of this lane's slot, in place (audio.rs:1035-1037); bins 4 (8 x + l) + j
+// floor x residue of one channel of this lane's slot, in place (audio.rs:1035-1037); bins 4 (L x + l) + j
+template <int L>
 __device__ __forceinline__ void short_spectrum(const char *img, const char *tab, uint32_t l, uint32_t fslot, bool unused, float4_t (&r)[4])
 {
 	const float kf0 = (float)(4 * (int)l);
 #pragma unroll
 	for (int x = 0; x < 4; x++) {
-		const uint2_t sw = *reinterpret_cast<const uint2_t *>(img + LWS_SID16 + 8u * ((fslot * 4 + x) * 8u + l));
+		const uint2_t sw = *reinterpret_cast<const uint2_t *>(img + LwBlkLayout<L>::SID16 + 8u * ((fslot * 4 + x) * L + l));
 		const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
 		float4_t fl;
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const float4_t ent = lds4(tab, s16[j]);
-			const float z = __builtin_fmaf(kf0 + (float)(32 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^15
+			const float z = __builtin_fmaf(kf0 + (float)(4 * L * x + j), ent.x, ent.y); // exact: |k*dy| < 2^17
 			const int q = (int)(z * ent.z);
 			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
-			fl[j] = *reinterpret_cast<const float *>(img + LWS_INV_DB + idx);
+			fl[j] = *reinterpret_cast<const float *>(img + LwBlkLayout<L>::INV_DB + idx);
 		}
 		if (unused)
 			fl = float4_t{0.0f, 0.0f, 0.0f, 0.0f}; // zero floor (audio.rs:1021-1024): 0.0 x residue keeps the residue's sign
@@ -1759,69 +1779,136 @@ __device__ __forceinline__ void short_spectrum(const char *img, const char *tab,
 	}
 }
 
-// the transform of one channel of the wave's eight blocks: spectrum r (load layout) -> R[c2][k] = (pa, pb) at
-// q = 63 - 2m', 62 - 2m', 1 + 2m', 2m' for m' = 2 l + c2 (imdct.rs:291-659)
+// exchange of register-index bits with lane bits 4 / 3 for the eight pairs of a lane (the last one / two steps of t2_inreg)
+template <int L>
+__device__ __forceinline__ void blk_t2(float2_t (&P)[8])
+{
+	if (L == 32) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) { // register bit 1 <-> lane bit 4
+			const int x = (i & 1) | ((i & 2) << 1);
+			auto r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[x].x), __float_as_uint(P[x + 2].x), false, false);
+			P[x].x = __uint_as_float(r0[0]);
+			P[x + 2].x = __uint_as_float(r0[1]);
+			auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[x].y), __float_as_uint(P[x + 2].y), false, false);
+			P[x].y = __uint_as_float(r1[0]);
+			P[x + 2].y = __uint_as_float(r1[1]);
+		}
+	}
+	if (L >= 16) {
+#pragma unroll
+		for (int x = 0; x < 8; x += 2) { // register bit 0 <-> lane bit 3 (tied DPP moves under bank masks)
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const int a_ = __float_as_int(k ? P[x].y : P[x].x), b_ = __float_as_int(k ? P[x + 1].y : P[x + 1].x);
+				const float na = __int_as_float(__builtin_amdgcn_update_dpp(a_, b_, 0x128, 0xf, 0xc, false)); // lanes 8-15 of a row <- b[l ^ 8]
+				const float nb = __int_as_float(__builtin_amdgcn_update_dpp(b_, a_, 0x128, 0xf, 0x3, false)); // lanes 0-7  of a row <- a[l ^ 8]
+				if (k) {
+					P[x].y = na;
+					P[x + 1].y = nb;
+				} else {
+					P[x].x = na;
+					P[x + 1].x = nb;
+				}
+			}
+		}
+	}
+}
+
+// the transform of one channel of the wave's blocks: spectrum r (load layout) -> R[c2][k] = (pa, pb) at
+// q = 8L-1 - 2m', 8L-2 - 2m', 1 + 2m', 2m' for m' = 2 l + c2 (imdct.rs:291-659)
+template <int L>
 __device__ __forceinline__ void short_imdct(const char *img, char *scr, uint32_t g, uint32_t l, const float4_t (&r)[4], float2_t (&R)[2][4])
 {
+	typedef LwBlkLayout<L> Y;
+	constexpr uint32_t P = 8u * L;
 	float2_t au[4], al[4], s2[4], l0[2], l1;
 #pragma unroll
 	for (int x = 0; x < 4; x++) {
-		const uint32_t m = 8u * x + l;
-		au[x] = lds2(img + LWS_APAIR, 8u * m);         // (A[2m], A[2m+1])
-		al[x] = lds2(img + LWS_APAIR, 8u * (63u - m)); // (A[126-2m], A[127-2m])
-		s2[x] = lds2(img + LWS_TW_S2, 8u * m);
+		const uint32_t m = L * x + l;
+		au[x] = lds2(img + Y::APAIR, 8u * m);           // (A[2m], A[2m+1])
+		al[x] = lds2(img + Y::APAIR, 8u * (P - 1u - m)); // (A[n/2-2-2m], A[n/2-1-2m])
+		s2[x] = lds2(img + Y::TW_S2, 8u * m);
 	}
-	l0[0] = lds2(img + LWS_TW_L0, 8u * l);
-	l0[1] = lds2(img + LWS_TW_L0, 8u * (8u + l));
-	l1 = lds2(img + LWS_TW_L1, 8u * l);
+	l0[0] = lds2(img + Y::TW_L0, 8u * l);
+	l0[1] = lds2(img + Y::TW_L0, 8u * (L + l));
+	l1 = lds2(img + Y::TW_L1, 8u * l);
 	float2_t Q[8], U[4];
 	step1x2(r[0], au[0], al[0], r[1], au[1], al[1], U[0], Q[0], U[1], Q[1]);
 	step1x2(r[2], au[2], al[2], r[3], au[3], al[3], U[2], Q[2], U[3], Q[3]);
 #pragma unroll
-	for (int x = 0; x < 4; x++) { // pair 63 - m lives on the mirror lane of the 8-lane group (DPP row_half_mirror)
-		Q[7 - x].x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(U[x].x), 0x141, 0xf, 0xf, false));
-		Q[7 - x].y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(U[x].y), 0x141, 0xf, 0xf, false));
+	for (int x = 0; x < 4; x++) { // pair 8L-1 - m lives on the mirror lane of the L-lane group
+		if (L == 32) {
+			const uint32_t mirror = (threadIdx.x ^ 31u) << 2;
+			Q[7 - x].x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U[x].x)));
+			Q[7 - x].y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(U[x].y)));
+		} else { // DPP row_half_mirror (8 lanes) / row_mirror (16 lanes)
+			Q[7 - x].x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(U[x].x), L == 8 ? 0x141 : 0x140, 0xf, 0xf, false));
+			Q[7 - x].y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(U[x].y), L == 8 ? 0x141 : 0x140, 0xf, 0xf, false));
+		}
 	}
 	bfly2x4(Q[4], Q[0], s2[0], Q[5], Q[1], s2[1], Q[6], Q[2], s2[2], Q[7], Q[3], s2[3]); // step 2 (imdct.rs:385-430)
 	bfly2x4(Q[2], Q[0], l0[0], Q[6], Q[4], l0[0], Q[3], Q[1], l0[1], Q[7], Q[5], l0[1]); // l = 0
 	bfly2x4(Q[1], Q[0], l1, Q[3], Q[2], l1, Q[5], Q[4], l1, Q[7], Q[6], l1);             // l = 1
-	t3_inreg(Q);                                                                         // B' -> D'
-	const float a2s = *reinterpret_cast<const float *>(img + LWS_A2);
+	if (L >= 16) { // stages l = 2 (, 3) on pair bits that were lane bits 4 / 3 (imdct.rs:454-477)
+		blk_t2<L>(Q);
+		const uint32_t lo3 = l & 7u;
+		if (L == 32) {
+			const float2_t c2a = lds2(img + Y::TW_C2, 8u * lo3), c2b = lds2(img + Y::TW_C2, 8u * (8u + lo3));
+			const float2_t c3 = lds2(img + Y::TW_C3, 8u * lo3);
+			bfly2x4(Q[2], Q[0], c2a, Q[6], Q[4], c2a, Q[3], Q[1], c2b, Q[7], Q[5], c2b); // l = 2
+			bfly2x4(Q[1], Q[0], c3, Q[3], Q[2], c3, Q[5], Q[4], c3, Q[7], Q[6], c3);     // l = 3
+		} else {
+			const float2_t c2 = lds2(img + Y::TW_C2, 8u * lo3);
+			bfly2x4(Q[1], Q[0], c2, Q[3], Q[2], c2, Q[5], Q[4], c2, Q[7], Q[6], c2);     // l = 2
+		}
+	}
+	t3_inreg(Q);                                                                         // -> D': register = p[2:0]
+	const float a2s = *reinterpret_cast<const float *>(img + Y::A2);
 	stage_d_block(float2_t{a2s, a2s}, Q);                                                // imdct.rs:234-288
-	char *blk = scr + 512u * g;
+	// pair index bits above the register's three, from the lane bits (the exchanges above permuted them)
+	uint32_t hi;
+	if (L == 8)
+		hi = l;                                                                          // (p5, p4, p3)
+	else if (L == 16)
+		hi = ((l >> 2) & 1u) << 3 | ((l >> 1) & 1u) << 2 | ((l >> 3) & 1u) << 1 | (l & 1u); // (p6, p5, p4, p3) = lane bits (2, 1, 3, 0)
+	else
+		hi = ((l >> 2) & 1u) << 4 | ((l >> 4) & 1u) << 3 | ((l >> 3) & 1u) << 2 | ((l >> 1) & 1u) << 1 | (l & 1u); // (p7 .. p3) = lane bits (2, 4, 3, 1, 0)
+	char *blk = scr + 8u * P * g;
 #pragma unroll
 	for (int zz = 0; zz < 8; zz++)
-		*reinterpret_cast<float2_t *>(blk + 8u * (8u * l + zz)) = Q[zz];
+		*reinterpret_cast<float2_t *>(blk + 8u * (8u * hi + zz)) = Q[zz];
 	lds_fence();
+	constexpr int VB = (L == 8 ? 4 : L == 16 ? 5 : 6); // bits of m' = 2 l + c2
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) { // bit-reverse gather (imdct.rs:490-528), step 7 (:533-580), step 8 (:589-658)
-		const uint32_t v = __builtin_bitreverse32(2u * l + c2) >> 28;
-		const float2_t pq = lds2(blk, 8u * (2u * v)), pq32 = lds2(blk, 8u * (2u * v + 32u));
-		const float2_t p31 = lds2(blk, 8u * (31u - 2u * v)), p63 = lds2(blk, 8u * (63u - 2u * v));
-		const float4_t Cq = lds4(img + LWS_C4, 16u * (8u * c2 + l));
-		const float4_t Bl = lds4(img + LWS_B_LO, 16u * (8u * c2 + l)), Bh = lds4(img + LWS_B_HI, 16u * (8u * c2 + l));
-		step78_block(p63, pq, p31, pq32, Cq, Bl, Bh, R[c2]);
+		const uint32_t v = __builtin_bitreverse32(2u * l + c2) >> (32 - VB);
+		const float2_t pq = lds2(blk, 8u * (2u * v)), pqh = lds2(blk, 8u * (2u * v + P / 2));
+		const float2_t ph = lds2(blk, 8u * (P / 2 - 1u - 2u * v)), pf = lds2(blk, 8u * (P - 1u - 2u * v));
+		const float4_t Cq = lds4(img + Y::C4, 16u * (L * c2 + l));
+		const float4_t Bl = lds4(img + Y::B_LO, 16u * (L * c2 + l)), Bh = lds4(img + Y::B_HI, 16u * (L * c2 + l));
+		step78_block(pf, pq, ph, pqh, Cq, Bl, Bh, R[c2]);
 	}
 	lds_fence();
 }
 
-// window + overlap-add (audio.rs:1116-1118) of the 128 samples of one channel of this lane's slot, conversion
+// window + overlap-add (audio.rs:1116-1118) of the 16 L samples of one channel of this lane's slot, conversion
 // (samples.rs:92-103), stores.  R[c2][k].x = raw left half at q_k, h = the previous right part; `o` = element 0 of the
 // channel's samples; stride = distance of consecutive samples (1: planar, ch: interleaved)
-template <int FMT>
+template <int FMT, int L>
 __device__ __forceinline__ void short_ola_store(const char *img, uint32_t l, void *out, uint32_t elem0, uint32_t stride,
 		const float2_t (&Rc)[2][4], const PrevHalf &h)
 {
 	float2_t O[2][4];
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) {
-		const float4_t w0 = lds4(img + LWS_WIN, 32u * (8u * c2 + l));
-		const float4_t w1 = lds4(img + LWS_WIN, 32u * (8u * c2 + l) + 16u);
+		const float4_t w0 = lds4(img + LwBlkLayout<L>::WIN, 32u * (L * c2 + l));
+		const float4_t w1 = lds4(img + LwBlkLayout<L>::WIN, 32u * (L * c2 + l) + 16u);
 		ola_block<FMT != LW_OUT_F32_PLANAR>(Rc[c2], h.pp[c2][0], h.pp[c2][1], w0, w1, O[c2]);
 	}
-	// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [60-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
-	//            [64+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [124-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
-	const uint32_t pos[4] = {4u * l, 60u - 4u * l, 64u + 4u * l, 124u - 4u * l};
+	// positions: [4l..4l+3] = .x of (0,3) (0,2) (1,3) (1,2); [8L-4-4l..] = .x of (1,1) (1,0) (0,1) (0,0)
+	//            [8L+4l..] = .y of (0,0) (0,1) (1,0) (1,1); [16L-4-4l..] = .y of (1,2) (1,3) (0,2) (0,3)
+	const uint32_t pos[4] = {4u * l, 8u * L - 4u - 4u * l, 8u * L + 4u * l, 16u * L - 4u - 4u * l};
 	const float v[4][4] = {{O[0][3].x, O[0][2].x, O[1][3].x, O[1][2].x}, {O[1][1].x, O[1][0].x, O[0][1].x, O[0][0].x},
 		{O[0][0].y, O[0][1].y, O[1][0].y, O[1][1].y}, {O[1][2].y, O[1][3].y, O[0][2].y, O[0][3].y}};
 #pragma unroll
@@ -1852,23 +1939,28 @@ __device__ __forceinline__ void short_ola_store(const char *img, uint32_t l, voi
 	}
 }
 
-// raw right part (128 floats: pb(q) for q ascending, then mirrored) of one channel to a state slot / td block
+// raw right part (16 L floats: pb(q) for q ascending, then mirrored) of one channel to a state slot / td block
+template <int L>
 __device__ __forceinline__ void short_store_right(float *dst, uint32_t l, const float2_t (&Rc)[2][4])
 {
 	const float4_t lo0 = float4_t{Rc[0][3].y, Rc[0][2].y, Rc[1][3].y, Rc[1][2].y}; // q = 4l ..
-	const float4_t lo1 = float4_t{Rc[1][1].y, Rc[1][0].y, Rc[0][1].y, Rc[0][0].y}; // q = 60 - 4l ..
+	const float4_t lo1 = float4_t{Rc[1][1].y, Rc[1][0].y, Rc[0][1].y, Rc[0][0].y}; // q = 8L - 4 - 4l ..
 	store16_wt(dst + 4u * l, lo0);
-	store16_wt(dst + 60u - 4u * l, lo1);
-	store16_wt(dst + 64u + 4u * l, float4_t{lo1.w, lo1.z, lo1.y, lo1.x});
-	store16_wt(dst + 124u - 4u * l, float4_t{lo0.w, lo0.z, lo0.y, lo0.x});
+	store16_wt(dst + 8u * L - 4u - 4u * l, lo1);
+	store16_wt(dst + 8u * L + 4u * l, float4_t{lo1.w, lo1.z, lo1.y, lo1.x});
+	store16_wt(dst + 16u * L - 4u - 4u * l, float4_t{lo0.w, lo0.z, lo0.y, lo0.x});
 }
 
-template <int FMT>
+template <int FMT, int L>
 __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 {
-	__shared__ __attribute__((aligned(16))) char smem[LWK_LDS_BYTES];
-	const uint32_t lane = threadIdx.x, g = lane >> 3, l = lane & 7u;
-	const uint32_t task = blockIdx.x / F.n_units, uidx = blockIdx.x - task * F.n_units;
+	typedef LwBlkLayout<L> Y;
+	typedef LwBlkLds<L> D;
+	constexpr int PT = D::PT;
+	__shared__ __attribute__((aligned(16))) char smem_all[LwBlkLayout<L>::TOTAL + LwBlkWave<L>::BYTES];
+	const uint32_t lane = threadIdx.x, g = lane / L, l_id = lane % L;
+	const uint32_t wid = blockIdx.x;                                   // this wave's (task, unit)
+	const uint32_t task = wid / F.n_units, uidx = wid - task * F.n_units;
 	const LwFastUnit un = F.units[uidx];
 	const bool two = un.ch_b >= 0;
 	const uint32_t chn[2] = {(uint32_t)un.ch_a, (uint32_t)(two ? un.ch_b : un.ch_a)};
@@ -1878,27 +1970,41 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	// of its own channel only.
 	const uint32_t only = un.slot;
 	const bool mine[2] = {only != 1u, two && only != 0u};
-	// ---- slot descriptor (all lanes of a group read the same 48 bytes) and the table image
-	const uint4 *sp = reinterpret_cast<const uint4 *>(F.slots + ((size_t)task * LW_SHORT_SLOTS + g));
-	const uint4 d0 = sp[0], d1 = sp[1], d2 = sp[2];
+	// ---- the table image (L2-resident), staged by the wave that uses it.  (Workgroups of 8-12 waves sharing one image were
+	// measured 6-17 % slower on every shape: their waves start together and move through the memory- and compute-bound
+	// phases in lock step, and a CU takes the next workgroup only when the whole previous one is done; single waves are
+	// dispatched one by one and interleave.)
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(F.image);
-		uint4 *dst = reinterpret_cast<uint4 *>(smem);
-		uint4 v[LWS_TOTAL / 1024];
+		uint4 *dst = reinterpret_cast<uint4 *>(smem_all);
+		static_assert(Y::TOTAL % 1024u == 0, "whole rows of 64 lanes x 16 bytes");
+		constexpr uint32_t ROUNDS = Y::TOTAL / 1024u;
+		uint4 v[ROUNDS]; // all loads in flight at once: one L2 round trip for the whole image
 #pragma unroll
-		for (uint32_t k = 0; k < LWS_TOTAL / 1024; k++)
+		for (uint32_t k = 0; k < ROUNDS; k++)
 			v[k] = src[lane + 64u * k];
 #pragma unroll
-		for (uint32_t k = 0; k < LWS_TOTAL / 1024; k++)
+		for (uint32_t k = 0; k < ROUNDS; k++)
 			dst[lane + 64u * k] = v[k];
 	}
+	char *smem = smem_all + Y::TOTAL; // the wave's working areas
+	typedef LwBlkWave<L> W;
+	constexpr uint32_t OFF_SCR = W::SCR, OFF_PUB = W::PUB, OFF_REC = W::REC, OFF_TAB = W::TAB, POSTS_ = W::POSTS;
+	for (uint32_t pass = 0; pass < F.passes; pass++) {
+	// launder the lane index once per pass: everything derived from it (table addresses, twiddles) is recomputed where it is
+	// used instead of being hoisted out of the loop and kept in ~70 registers
+	uint32_t l = l_id;
+	asm volatile("" : "+v"(l));
+	// ---- slot descriptor (all lanes of a group read the same 48 bytes)
+	const uint4 *sp = reinterpret_cast<const uint4 *>(F.slots + (((size_t)task * F.passes + pass) * D::SLOTS + g));
+	const uint4 d0 = sp[0], d1 = sp[1], d2 = sp[2];
 	const uint32_t res_off = d0.x, floor_off = d0.y, out_off = d0.z, prev_arg = d0.w;
 	const int32_t state_out = (int32_t)d1.x;
 	const uint32_t next_edge = d1.y, next_out = d1.z, next_m = d1.w;
 	const uint32_t prev_stride = d2.x & 0xffffu, kind = (d2.x >> 16) & 0xffu, prev_kind = d2.x >> 24, flags = d2.y;
 	const bool has_block = kind == LW_SS_BLOCK || kind == LW_SS_HALO;
 	// ---- HBM loads, all at once: floor records, residues, the previous right part and the successor's left edge
-	uint32_t fe[2][4];
+	uint32_t fe[2][PT];
 	float4_t r[2][4];
 	Half8 prv[2], nxt[2];
 #pragma unroll
@@ -1908,14 +2014,14 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 		const uint32_t Fp = c == 0 ? un.F_a : un.F_b;
 		const uint16_t *f = F.floors + floor_off + chn[c] * F.fstride;
 #pragma unroll
-		for (int t = 0; t < 4; t++) {
-			const uint32_t i = l + 8u * t;
+		for (int t = 0; t < PT; t++) {
+			const uint32_t i = l + L * (uint32_t)t;
 			fe[c][t] = on && has_block && i < Fp ? (uint32_t)f[i] : 0u;
 		}
-		const float4_t *s = reinterpret_cast<const float4_t *>(F.residue + res_off + chn[c] * 128u);
+		const float4_t *s = reinterpret_cast<const float4_t *>(F.residue + res_off + chn[c] * (16u * L));
 #pragma unroll
 		for (int x = 0; x < 4; x++)
-			r[c][x] = need_res && has_block ? __builtin_nontemporal_load(&s[8 * x + l]) : float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+			r[c][x] = need_res && has_block ? __builtin_nontemporal_load(&s[L * x + l]) : float4_t{0.0f, 0.0f, 0.0f, 0.0f};
 		const float *pbase = F.state;
 		uint32_t poff = 0;
 		if (prev_kind == LW_SP_STATE) {
@@ -1929,13 +2035,15 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 		}
 		prv[c].lo = prv[c].hi = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
 		if (on && prev_kind >= LW_SP_STATE)
-			prv[c] = load_half8(pbase + poff, l);
+			prv[c] = load_half8<L>(pbase + poff, l);
 		nxt[c].lo = nxt[c].hi = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
-		if (on && next_edge != 0xFFFFFFFFu)
-			nxt[c] = load_half8(F.edge + ((size_t)next_edge * 2u * F.ch + chn[c]) * LW_EDGE_VALUES, l);
+		if (L == 8 && on && next_edge != 0xFFFFFFFFu)
+			nxt[c] = load_half8<L>(F.edge + ((size_t)next_edge * 2u * F.ch + chn[c]) * LW_EDGE_VALUES, l);
 	}
-	const char *img = smem;
-	char *scr = smem + LWK_OFF_SCR, *pub = smem + LWK_OFF_PUB;
+	const char *img = smem_all;
+	char *scr = smem + OFF_SCR, *pub = smem + OFF_PUB + 4096u * (pass & 1u);
+	// (the previous slot of group 0 is the last slot of the pass before: the other half of the double buffer)
+	const char *pub_prev = g != 0 ? pub + 16u * ((g - 1u) * 4u * L) : smem + OFF_PUB + 4096u * ((pass & 1u) ^ 1u) + 16u * ((D::SLOTS - 1u) * 4u * L);
 	lds_fence();
 	// ---- floor curves (interval entries by lanes = posts), inverse coupling, floor x residue
 	bool unused[2] = {true, true};
@@ -1943,9 +2051,9 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	for (int c = 0; c < 2; c++) {
 		if (!mine[c])
 			continue;
-		char *rec = smem + LWK_OFF_REC + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 2u);
-		char *tab = smem + LWK_OFF_TAB + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 16u);
-		unused[c] = short_floor_table(img, rec, tab, g, l, fe[c], c == 0 ? un.floor_a : un.floor_b, c == 0 ? un.F_a : un.F_b, has_block);
+		char *rec = smem + OFF_REC + (g * 2u + c) * (POSTS_ * 2u);
+		char *tab = smem + OFF_TAB + (g * 2u + c) * (POSTS_ * 16u);
+		unused[c] = short_floor_table<L>(img, rec, tab, g, l, fe[c], c == 0 ? un.floor_a : un.floor_b, c == 0 ? un.F_a : un.F_b, has_block);
 	}
 	lds_fence();
 	if (two && un.coupled) {
@@ -1963,17 +2071,17 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	for (int c = 0; c < 2; c++) {
 		if (!mine[c])
 			continue;
-		const char *tab = smem + LWK_OFF_TAB + (g * 2u + c) * (LW_SHORT_MAX_POSTS * 16u);
-		short_spectrum(img, tab, l, c == 0 ? un.floor_a : un.floor_b, unused[c], r[c]);
-		short_imdct(img, scr, g, l, r[c], R[c]);
-		if (kind == LW_SS_EDGE) { // no block of its own: the stored right part stands in for it (feeds the successor's left edge)
+		const char *tab = smem + OFF_TAB + (g * 2u + c) * (POSTS_ * 16u);
+		short_spectrum<L>(img, tab, l, c == 0 ? un.floor_a : un.floor_b, unused[c], r[c]);
+		short_imdct<L>(img, scr, g, l, r[c], R[c]);
+		if (L == 8 && kind == LW_SS_EDGE) { // no block of its own: the stored right part stands in for it (feeds the successor's left edge)
 			R[c][0][3].y = prv[c].lo.x, R[c][0][2].y = prv[c].lo.y, R[c][1][3].y = prv[c].lo.z, R[c][1][2].y = prv[c].lo.w;
 			R[c][1][1].y = prv[c].hi.x, R[c][1][0].y = prv[c].hi.y, R[c][0][1].y = prv[c].hi.z, R[c][0][0].y = prv[c].hi.w;
 		}
 		// right part for the next slot of the wave: [slot][channel][c2][l] float4 = pb at k = 0..3
 #pragma unroll
 		for (int c2 = 0; c2 < 2; c2++)
-			*reinterpret_cast<float4_t *>(pub + 16u * (((g * 2u + c) * 2u + c2) * 8u + l)) =
+			*reinterpret_cast<float4_t *>(pub + 16u * (((g * 2u + c) * 2u + c2) * L + l)) =
 				float4_t{R[c][c2][0].y, R[c][c2][1].y, R[c][c2][2].y, R[c][c2][3].y};
 	}
 	lds_fence();
@@ -1988,22 +2096,22 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 			if (prev_kind == LW_SP_LANE) {
 #pragma unroll
 				for (int c2 = 0; c2 < 2; c2++) {
-					const float4_t v = *reinterpret_cast<const float4_t *>(pub + 16u * ((((g - 1u) * 2u + c) * 2u + c2) * 8u + l));
+					const float4_t v = *reinterpret_cast<const float4_t *>(pub_prev + 16u * ((c * 2u + c2) * L + l));
 					ph.pp[c2][0] = float2_t{v.x, v.y};
 					ph.pp[c2][1] = float2_t{v.z, v.w};
 				}
 			} else {
 				prev_from_half8(prv[c], ph);
 			}
-			const uint32_t e0 = FMT == LW_OUT_I16_INTERLEAVED ? out_off + chn[c] : out_off + chn[c] * 128u;
-			short_ola_store<FMT>(img, l, F.out, e0, esz_stride, R[c], ph);
+			const uint32_t e0 = FMT == LW_OUT_I16_INTERLEAVED ? out_off + chn[c] : out_off + chn[c] * (16u * L);
+			short_ola_store<FMT, L>(img, l, F.out, e0, esz_stride, R[c], ph);
 		}
 		if (kind == LW_SS_BLOCK && state_out >= 0)
-			short_store_right(F.state + ((size_t)state_out * 2u + ((flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride +
+			short_store_right<L>(F.state + ((size_t)state_out * 2u + ((flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride +
 					chn[c] * F.state_chan_stride, l, R[c]);
 		if (kind == LW_SS_BLOCK && (flags & LW_SF_WRITE_TD))
-			short_store_right(F.td + 2u * (size_t)res_off + chn[c] * 256u + 128u, l, R[c]);
-		if (next_edge != 0xFFFFFFFFu && (kind == LW_SS_BLOCK || kind == LW_SS_EDGE)) {
+			short_store_right<L>(F.td + 2u * (size_t)res_off + chn[c] * (32u * L) + 16u * L, l, R[c]);
+		if (L == 8 && next_edge != 0xFFFFFFFFu && (kind == LW_SS_BLOCK || kind == LW_SS_EDGE)) {
 			// the long successor's first 128 samples: its raw left edge pa(448 + i) against this slot's right part, short slope
 			float2_t Rn[2][4];
 			Rn[0][3].x = nxt[c].lo.x, Rn[0][2].x = nxt[c].lo.y, Rn[1][3].x = nxt[c].lo.z, Rn[1][2].x = nxt[c].lo.w;
@@ -2018,9 +2126,26 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 				ph.pp[c2][1] = float2_t{R[c][c2][2].y, R[c][c2][3].y};
 			}
 			const uint32_t e0 = FMT == LW_OUT_I16_INTERLEAVED ? next_out + chn[c] : next_out + chn[c] * next_m;
-			short_ola_store<FMT>(img, l, F.out, e0, esz_stride, Rn, ph);
+			short_ola_store<FMT, L>(img, l, F.out, e0, esz_stride, Rn, ph);
 		}
 	}
+	lds_fence(); // (the next pass re-uses the record / table / gather areas)
+	} // pass
+}
+
+template <int L>
+static hipError_t launch_short(LwShortArgs &F, int fmt, hipStream_t st)
+{
+	// one wave per workgroup with 17-30 KB of LDS (below the 64 KB that need no attribute): the waves a CU holds at a time
+	// are bounded by LDS for L = 16 / 32 and by registers for L = 8
+	const dim3 grid(F.n_waves), block(64);
+	if (fmt == LW_OUT_I16_PLANAR)
+		hipLaunchKernelGGL((k_short<LW_OUT_I16_PLANAR, L>), grid, block, 0, st, F);
+	else if (fmt == LW_OUT_I16_INTERLEAVED)
+		hipLaunchKernelGGL((k_short<LW_OUT_I16_INTERLEAVED, L>), grid, block, 0, st, F);
+	else
+		hipLaunchKernelGGL((k_short<LW_OUT_F32_PLANAR, L>), grid, block, 0, st, F);
+	return hipSuccess;
 }
 
 hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st)
@@ -2036,11 +2161,11 @@ hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwSh
 	F.td = B.td;
 	F.edge = L.d_edge;
 	F.out = out;
-	F.n_units = L.n_units;
 	F.ch = T.ch;
 	F.fstride = T.fstride;
 	F.state_stride = T.state_stride;
 	F.state_chan_stride = T.state_chan_stride;
+	F.passes = L.passes ? L.passes : 1u;
 	// a launch of few waves splits channel pairs over two waves each (see the kernel)
 	const bool split = (size_t)L.n_tasks * L.n_units <= LW_SHORT_SPLIT_BELOW && 2 * L.n_units <= LW_FAST_WAVES;
 	uint32_t nu = 0;
@@ -2056,14 +2181,14 @@ hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwSh
 		}
 	}
 	F.n_units = nu;
-	const dim3 grid(L.n_tasks * nu), block(64);
-	if (fmt == LW_OUT_I16_PLANAR)
-		hipLaunchKernelGGL((k_short<LW_OUT_I16_PLANAR>), grid, block, 0, st, F);
-	else if (fmt == LW_OUT_I16_INTERLEAVED)
-		hipLaunchKernelGGL((k_short<LW_OUT_I16_INTERLEAVED>), grid, block, 0, st, F);
-	else
-		hipLaunchKernelGGL((k_short<LW_OUT_F32_PLANAR>), grid, block, 0, st, F);
-	return hipSuccess;
+	F.n_waves = L.n_tasks * nu;
+	if (L.lanes == 8)
+		return launch_short<8>(F, fmt, st);
+	if (L.lanes == 16)
+		return launch_short<16>(F, fmt, st);
+	if (L.lanes == 32)
+		return launch_short<32>(F, fmt, st);
+	return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------

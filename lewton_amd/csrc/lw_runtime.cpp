@@ -290,17 +290,18 @@ size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, 
 	return plan.image.size();
 }
 
-size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, size_t cap, uint8_t *units8, size_t *n_units)
+size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, int blockflag, uint8_t *dst, size_t cap, uint8_t *units8,
+		size_t *n_units, uint32_t *lanes)
 {
 	if (!id || !s)
 		return 0;
 	LwFastPlan fast;
 	lw::build_fast_plan(*id->p, *s->p, fast);
 	LwShortPlan plan;
-	lw::build_short_plan(*id->p, *s->p, fast, plan);
+	lw::build_blk_plan(*id->p, *s->p, blockflag != 0, fast, plan);
 	if (!plan.eligible)
 		return 0;
-	std::memcpy(plan.image.data() + LWS_INV_DB, kInverseDbTable, sizeof(float) * 256);
+	std::memcpy(plan.image.data() + lw_blk_inv_db_offset(plan.lanes), kInverseDbTable, sizeof(float) * 256);
 	if (dst)
 		std::memcpy(dst, plan.image.data(), std::min(cap, plan.image.size()));
 	if (units8 && n_units) {
@@ -309,6 +310,8 @@ size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, uint8_t *dst,
 	}
 	if (n_units)
 		*n_units = plan.units.size();
+	if (lanes)
+		*lanes = plan.lanes;
 	return plan.image.size();
 }
 
@@ -527,12 +530,16 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			return nullptr;
 		}
 	}
-	lw::build_short_plan(id, s, d->fast, d->shortp);
-	if (d->shortp.eligible) {
-		std::memcpy(d->shortp.image.data() + LWS_INV_DB, kInverseDbTable, sizeof(float) * 256);
-		if (!lw_hip_ok(hipMalloc((void **)&d->d_short_image, d->shortp.image.size()), "hipMalloc(short image)") ||
-				!lw_hip_ok(hipMemcpy(d->d_short_image, d->shortp.image.data(), d->shortp.image.size(), hipMemcpyHostToDevice),
-					"hipMemcpy(short image)")) {
+	// k_short<L>: class 0 = the short blocks, class 1 = the long blocks of a stream k_long does not cover
+	for (int cls = 0; cls < 2; cls++) {
+		LwShortPlan &bp = d->blkp[cls];
+		lw::build_blk_plan(id, s, cls != 0, d->fast, bp);
+		if (!bp.eligible)
+			continue;
+		std::memcpy(bp.image.data() + lw_blk_inv_db_offset(bp.lanes), kInverseDbTable, sizeof(float) * 256);
+		if (!lw_hip_ok(hipMalloc((void **)&d->d_blk_image[cls], bp.image.size()), "hipMalloc(block kernel image)") ||
+				!lw_hip_ok(hipMemcpy(d->d_blk_image[cls], bp.image.data(), bp.image.size(), hipMemcpyHostToDevice),
+					"hipMemcpy(block kernel image)")) {
 			*err = LW_ERR_DEVICE;
 			(void)hipFree(d->d_blob);
 			return nullptr;
@@ -561,8 +568,9 @@ void lw_decoder_destroy(lw_decoder *d)
 		(void)hipFree(d->d_fast_image);
 	if (d->d_fast_units)
 		(void)hipFree(d->d_fast_units);
-	if (d->d_short_image)
-		(void)hipFree(d->d_short_image);
+	for (uint8_t *p : d->d_blk_image)
+		if (p)
+			(void)hipFree(p);
 	delete d;
 }
 

@@ -19,6 +19,12 @@ SETUPS = {
     "stereo_9_12": lambda: sg.stereo_setup(bs0=9, bs1=12),
     "stereo_6_13": lambda: sg.stereo_setup(bs0=6, bs1=13),
     "stereo_7_7": lambda: sg.stereo_setup(bs0=7, bs1=7),
+    # block sizes of k_short<L> in both roles: 512 / 1024 (what libvorbis writes at 16-22 kHz), 256 / 1024, 256 / 512, and
+    # 1024-point SHORT blocks next to 4096-point long ones (generic)
+    "stereo_9_10": lambda: sg.stereo_setup(22050, 9, 10),
+    "stereo_8_10": lambda: sg.stereo_setup(22050, 8, 10, residue_type=1),
+    "stereo_8_9": lambda: sg.stereo_setup(11025, 8, 9),
+    "stereo_10_12": lambda: sg.stereo_setup(44100, 10, 12),
 }
 # host-stage tests only (no GPU test iterates these): a residue pass through a one-entry codebook
 HOST_SETUPS = dict(SETUPS, stereo_single_entry=lambda: sg.stereo_setup(single_entry_book=True))

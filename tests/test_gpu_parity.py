@@ -65,6 +65,8 @@ def test_device_imdct_random_all_sizes(name):
 
 PATTERNS = {"stereo": "LLSSSSSSSSL", "stereo_t1": "LSLLS", "surround51": "LLSSL", "mono_small": "LSSLLSL",
             "stereo_9_12": "LLSL", "stereo_6_13": "LSSL", "stereo_7_7": "LSLL",
+            "stereo_9_10": "LLLSSSLLLL", "stereo_8_10": "LLLLSSSSSL", "stereo_8_9": "LLLSSL", "stereo_10_12": "LSSSSL",
+
             "floor0": "LLSSL", "floor0_mixed": "LSLLS", "floor0_8_11": "LLLSL"}
 ALL_SETUPS = dict(SETUPS, **FLOOR0_SETUPS)   # floor-0 streams: curve from the host stage, multiply + IMDCT on the GPU
 

@@ -135,6 +135,73 @@ MIXED_SETUPS = {"stereo": lambda: sg.stereo_setup(44100, 8, 11), "surround51": l
                 "mono": _mono_8_11, "uncoupled": _uncoupled_8_11}
 
 
+BLK_SETUPS = {"stereo_9_10": lambda: sg.stereo_setup(22050, 9, 10), "stereo_8_10": lambda: sg.stereo_setup(22050, 8, 10, residue_type=1),
+              "stereo_8_9": lambda: sg.stereo_setup(11025, 8, 9),
+              "stereo_9_11": lambda: sg.stereo_setup(44100, 9, 11), "stereo_10_12": lambda: sg.stereo_setup(44100, 10, 12)}
+
+
+@pytest.mark.parametrize("name", sorted(BLK_SETUPS))
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_block_kernel_streams_state_round_trip_and_runs(name, fmt):
+    """Streams whose blocks run through k_short<L> in either role (512 / 1024-point long blocks with two long slopes, 256 /
+    512 / 1024-point short blocks; the long blocks next to short ones through the generic kernels or k_long<TD>): first one
+    packet per stream per launch (every right part through the state pool), then the rest of every stream in ONE launch
+    (runs inside a wave, recomputed predecessors at wave boundaries, time-domain blocks exchanged with the generic kernels)."""
+    from lewton_amd.batch import Batch
+    from common import oracle_headers
+    setup = BLK_SETUPS[name]()
+    audio, dec = _decoder(setup)
+    o_id, o_st = oracle_headers(setup)
+    ch = setup.channels
+    n_streams, steps, tail = 10, 9, 40
+    streams = [sg.make_stream(setup, "LLLLSSSLLSLLLLLLLSSSSSSSSSL"[s % 7:], steps + tail, seed=170 + s, p_floor_unused=0.06)
+               for s in range(n_streams)]
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    opws = [po.Pwr() for _ in range(n_streams)]
+    ofmt = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}[fmt]
+    seen = set()
+
+    def check(bt, items):
+        res = bt.entropy([(streams[s][t], pwrs[s]) for s, t in items], n_threads=2)
+        bt.upload()
+        got = bt.split(bt.synth_to_host(), ch)
+        seen.update(bt.last_kernels.split(","))
+        for i, (s, t) in enumerate(items):
+            want = np.asarray(po.read_audio_packet(o_id, o_st, streams[s][t], opws[s], ofmt))
+            assert res[i][0] == 0 and got[i].size == want.size, (s, t)
+            if fmt == "f32":
+                assert np.array_equal(got[i].reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32)), (s, t, bt.last_kernels)
+            else:
+                assert np.array_equal(got[i].reshape(-1), want.reshape(-1)), (s, t, bt.last_kernels)
+
+    b1 = Batch(dec, n_streams, fmt)
+    for t in range(steps):
+        check(b1, [(s, t) for s in range(n_streams)])
+    b2 = Batch(dec, n_streams * tail, fmt)
+    check(b2, [(s, steps + t) for s in range(n_streams) for t in range(tail)])
+    assert "k_short" in seen, seen
+    for s in range(n_streams):
+        assert np.array_equal(pwrs[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32)), s
+    b1.close()
+    b2.close()
+
+
+def test_long_blocks_of_1024_points_dense_bench_shape():
+    """blocksize_1 = 10 (what libvorbis writes at 16-22 kHz): 256 streams x 16 long blocks in one launch, all through
+    k_short<32> (a block's predecessor recomputed in the slot in front: two slots per wave)"""
+    bad, kernels, n = _run_dense("12", "i16", packets=4096)
+    assert n == 4096 and bad == 0, (bad, kernels)
+    assert kernels == "k_short"
+
+
+def test_long_blocks_of_1024_points_three_passes_per_wave():
+    """a launch with enough blocks that a wave works through three passes of two slots (one recomputed predecessor per five
+    blocks, right parts handed from pass to pass through the double-buffered LDS area): 256 streams x 48 blocks"""
+    bad, kernels, n = _run_dense("12", "i16", packets=12288)
+    assert n == 12288 and bad == 0, (bad, kernels)
+    assert kernels == "k_short"
+
+
 @pytest.mark.parametrize("name", sorted(MIXED_SETUPS))
 @pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
 def test_mixed_streams_one_packet_per_launch(name, fmt):
