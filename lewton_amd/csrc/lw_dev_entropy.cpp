@@ -156,7 +156,8 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		}
 	}
 	std::vector<LwEntResidue> residues(s.residues.size());
-	std::vector<uint8_t> bytes;
+	std::vector<uint16_t> digits;
+	std::vector<LwEntRun> runs;
 	size_t cls_bytes = 0;
 	for (size_t ri = 0; ri < s.residues.size(); ri++) {
 		LwEntResidue &r = residues[ri];
@@ -183,10 +184,17 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		r.begin = rs.begin;
 		r.end = rs.end;
 		r.psize = rs.partition_size;
+		r.runs_off = (uint32_t)runs.size();
+		runs.resize(runs.size() + (size_t)rs.classifications * 8);
 		for (unsigned c = 0; c < rs.classifications; c++) {
 			r.vals_used[c] = rs.books[c].vals_used;
+			r.used_any |= rs.books[c].vals_used;
 			for (unsigned p = 0; p < 8; p++) {
-				r.val_i[c][p] = rs.books[c].val_i[p];
+				LwEntRun &run = runs[r.runs_off + c * 8 + p];
+				std::memset(&run, 0, sizeof(run));
+				run.shape = LW_ENT_SHAPE(0, 0, -2);
+				run.nodes_off = 0xFFFFFFFFu;
+				run.book = 0xFFFFFFFFu;
 				if (!(rs.books[c].vals_used & (1u << p)))
 					continue;
 				const unsigned bi = rs.books[c].val_i[p];
@@ -204,14 +212,19 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 					return false;
 				}
 				book_used[bi] = true;
+				run.count = rs.partition_size / cb.dims;
+				run.step = rs.type == 0 ? rs.partition_size / cb.dims : 1u;
+				run.adv = rs.type == 0 ? 1u : cb.dims;
+				run.book = bi; // (the book's table entries are filled in below)
 			}
 		}
 		if (!rs.class_digits.empty()) {
-			r.digits_off = (uint32_t)bytes.size();
-			bytes.insert(bytes.end(), rs.class_digits.begin(), rs.class_digits.end());
+			r.digits_off = (uint32_t)digits.size();
+			for (uint8_t cl : rs.class_digits)
+				digits.push_back((uint16_t)(cl | ((unsigned)rs.books[cl].vals_used << 8)));
 		}
 		const size_t nch = rs.type == 2 ? 1 : ch, actual = rs.type == 2 ? ch * (n1 / 2) : n1 / 2;
-		cls_bytes = std::max(cls_bytes, nch * (actual / rs.partition_size + cbk.dims));
+		cls_bytes = std::max(cls_bytes, 2 * nch * (actual / rs.partition_size + cbk.dims));
 	}
 	std::vector<LwEntBook> books(s.codebooks.size());
 	std::vector<uint32_t> lut;
@@ -220,22 +233,24 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	for (size_t bi = 0; bi < s.codebooks.size(); bi++) {
 		LwEntBook &b = books[bi];
 		std::memset(&b, 0, sizeof(b));
-		b.single = -1;
+		int single = -1;
+		unsigned lut_bits = 0;
+		b.shape = LW_ENT_SHAPE(0, 0, -1);
 		if (!book_used[bi])
 			continue;
 		const Codebook &cb = s.codebooks[bi];
 		b.nodes_off = 0xFFFFFFFFu;
 		if (cb.huff.single < 0 && !cb.huff.has_lut) {
-			b.single = -2; // empty book (the host stage ends the packet at its first codeword)
+			single = -2; // empty book (the host stage ends the packet at its first codeword)
 		} else if (cb.huff.single >= 0) {
 			if (cb.huff.single > 32767) {
 				*why = "single-entry book with a large entry number";
 				return false;
 			}
-			b.single = (int16_t)cb.huff.single;
+			single = cb.huff.single;
 		} else {
 			b.lut_off = (uint32_t)lut.size();
-			b.lut_bits = (uint8_t)cb.huff.lut_bits;
+			lut_bits = cb.huff.lut_bits;
 			lut.insert(lut.end(), cb.huff.lut.begin(), cb.huff.lut.end());
 			bool walks = false; // some code is longer than the two table levels: ship the tree as well
 			for (uint32_t e : cb.huff.lut)
@@ -245,7 +260,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 				nodes.insert(nodes.end(), cb.huff.nodes.begin(), cb.huff.nodes.end());
 			}
 		}
-		b.dims = (uint8_t)std::min<unsigned>(cb.dims, 255);
+		b.shape = LW_ENT_SHAPE(lut_bits, std::min<unsigned>(cb.dims, 255), single);
 		if (cb.has_vq && !cb.vq.empty()) {
 			while (vq.size() % 8)
 				vq.push_back(0.0f);
@@ -253,9 +268,19 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 			vq.insert(vq.end(), cb.vq.begin(), cb.vq.end());
 		}
 	}
+	for (LwEntRun &run : runs) {
+		if (run.book == 0xFFFFFFFFu)
+			continue; // a (class, pass) without a book
+		const LwEntBook &b = books[run.book];
+		run.lut_off = b.lut_off;
+		run.vq_off = b.vq_off;
+		run.nodes_off = b.nodes_off;
+		run.shape = b.shape;
+	}
 	lut.push_back(0);
 	vq.push_back(0.0f);
-	bytes.push_back(0);
+	digits.push_back(0);
+	runs.emplace_back();
 	nodes.push_back(0);
 	img.blob.clear();
 	img.off_books = put(img.blob, books.data(), books.size());
@@ -264,7 +289,8 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	img.off_modes = put(img.blob, modes.data(), modes.size());
 	img.off_lut = put(img.blob, lut.data(), lut.size());
 	img.off_vq = put(img.blob, vq.data(), vq.size());
-	img.off_bytes = put(img.blob, bytes.data(), bytes.size());
+	img.off_digits = put(img.blob, digits.data(), digits.size());
+	img.off_runs = put(img.blob, runs.data(), runs.size());
 	img.off_nodes = put(img.blob, nodes.data(), nodes.size());
 	img.ch = (uint32_t)ch;
 	img.fstride = fstride;
@@ -276,14 +302,15 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 LwEntTables dev_entropy_view(const DevEntropyImage &img, const uint8_t *base)
 {
 	LwEntTables T;
-	T.books = (const LwEntBook *)(base + img.off_books);
-	T.floors = (const LwEntFloor *)(base + img.off_floors);
-	T.residues = (const LwEntResidue *)(base + img.off_residues);
-	T.modes = (const LwEntMode *)(base + img.off_modes);
-	T.lut = (const uint32_t *)(base + img.off_lut);
-	T.vq = (const float *)(base + img.off_vq);
-	T.bytes = base + img.off_bytes;
-	T.nodes = (const int32_t *)(base + img.off_nodes);
+	T.books = (const LW_K LwEntBook *)(base + img.off_books);
+	T.floors = (const LW_K LwEntFloor *)(base + img.off_floors);
+	T.residues = (const LW_K LwEntResidue *)(base + img.off_residues);
+	T.modes = (const LW_K LwEntMode *)(base + img.off_modes);
+	T.lut = (const LW_K uint32_t *)(base + img.off_lut);
+	T.vq = (const LW_K float *)(base + img.off_vq);
+	T.digits = (const LW_K uint16_t *)(base + img.off_digits);
+	T.runs = (const LW_K LwEntRun *)(base + img.off_runs);
+	T.nodes = (const LW_K int32_t *)(base + img.off_nodes);
 	T.ch = img.ch;
 	T.fstride = img.fstride;
 	T.ws_bytes = img.ws_bytes;

@@ -30,17 +30,56 @@
 // On the device the packet's working set lives in the wave's LDS: residue accumulator, posts, classification digits
 // (address space 3: ds_ instructions, no flat addressing), and the additions of one codeword's vector are spread over the
 // lanes (element d on lane d).  On the host the same names are plain pointers and a loop.
+//   LW_ENT_EACH(d, cnt)   lanes d < cnt (device: the others are masked off)
+//   LW_ENT_LANES(d, cnt)  device: EVERY lane, no masking (a lane >= cnt works on a harmless stand-in -- its own dump slot
+//                         behind the accumulators); host: d < cnt
+//   LW_LV / LW_L          a value per lane: a register on the device, an array on the host
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) float *LwEntAcc;
 typedef __attribute__((address_space(3))) uint32_t *LwEntPosts;
-typedef __attribute__((address_space(3))) uint8_t *LwEntDigits;
-#define LW_ENT_EACH(d, cnt)                                                                                          \
-	for (uint32_t d = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), once_ = 1; once_ && d < (cnt); once_ = 0)
+typedef __attribute__((address_space(3))) uint16_t *LwEntDigits;
+#define LW_ENT_LANE() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))
+#define LW_ENT_EACH(d, cnt) for (uint32_t d = LW_ENT_LANE(), once_ = 1; once_ && d < (cnt); once_ = 0)
+#define LW_ENT_LANES(d, cnt) for (uint32_t d = LW_ENT_LANE(), once_ = 1; once_; once_ = 0)
+#define LW_LV(type, name) type name
+#define LW_L(name) name
 #else
 typedef float *LwEntAcc;
 typedef uint32_t *LwEntPosts;
-typedef uint8_t *LwEntDigits;
+typedef uint16_t *LwEntDigits;
 #define LW_ENT_EACH(d, cnt) for (uint32_t d = 0; d < (cnt); d++)
+#define LW_ENT_LANES(d, cnt) for (uint32_t d = 0; d < (cnt); d++)
+#define LW_LV(type, name) type name[64]
+#define LW_L(name) name[d]
+#endif
+// The image and the packets are read-only for the kernel: on the device they are addressed through the CONSTANT address
+// space, so every wave-uniform look-up is a scalar load whatever the compiler can or cannot prove about stores in between
+// (behind lw_ent_run's asm statement, which clobbers memory, it can prove nothing: as plain global pointers every look-up of
+// the kernel became a vector load and the whole bit reader moved to vector registers).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LW_K __attribute__((address_space(4)))
+#else
+#define LW_K
+#endif
+#define LW_ENT_DUMP_FLOATS 64u // device: one dump slot per lane behind the accumulators
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LW_ENT_ROW_UNIT 4u // a lane's place in a codeword's vector row is kept as a byte offset
+// a lane's accumulator is kept as its LDS byte address
+#define LW_ENT_AT(out, idx) ((uint32_t)(uintptr_t)(out) + 4u * (idx))
+#define LW_ENT_ACC(out, at) (*(LwEntAcc)(uintptr_t)(at))
+// a wave-uniform value read from LDS: into a scalar register, so that what is derived from it stays on the scalar unit
+#define LW_ENT_SCALAR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+__device__ inline __attribute__((always_inline)) uint32_t lw_ent_mad24(uint32_t entry, uint32_t scale, uint32_t add)
+{
+	uint32_t r; // (entry & 0xffffff) * scale + add; entry is wave-uniform
+	asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(entry), "v"(scale), "v"(add));
+	return r;
+}
+#else
+#define LW_ENT_SCALAR(x) (x)
+#define LW_ENT_ROW_UNIT 1u
+#define LW_ENT_AT(out, idx) (idx)
+#define LW_ENT_ACC(out, at) (out)[at]
 #endif
 
 #define LW_ENT_MAX_CH 8
@@ -48,13 +87,16 @@ typedef uint8_t *LwEntDigits;
 #define LW_ENT_MAX_COUPLING 16
 #define LW_ENT_LINK 0x80000000u
 
+// (the fields of the two records the decode loops fetch are whole dwords: a wave-uniform dword is a scalar load, a byte or
+// a halfword at an odd offset is a vector load)
 struct alignas(16) LwEntBook { // 16 bytes, read with one load
 	uint32_t lut_off;  // first-level table (2^lut_bits entries) in the image's u32 pool; sub-tables follow at offsets relative to it
 	uint32_t vq_off;   // entries * dims floats in the image's f32 pool
-	uint8_t lut_bits, dims;
-	int16_t single;    // >= 0: single-entry book, any one bit decodes this entry (huffman_tree.rs:202-217); -2: empty book
+	uint32_t shape;    // lut_bits | dims << 8 | (uint16_t)single << 16; single >= 0: single-entry book, any one bit decodes this
+	                   // entry (huffman_tree.rs:202-217); -2: empty book; -1: an ordinary book
 	uint32_t nodes_off; // binary tree (2 ints per node) in the image's i32 pool for codes beyond the two table levels; ~0u: none
 };
+#define LW_ENT_SHAPE(lut_bits, dims, single) ((uint32_t)(lut_bits) | (uint32_t)(dims) << 8 | (uint32_t)(uint16_t)(single) << 16)
 
 struct LwEntFloor {
 	uint8_t multiplier, range_bits, n_part, F;
@@ -72,9 +114,20 @@ struct LwEntFloor {
 struct LwEntResidue {
 	uint8_t type, classifications, classbook, cpc;
 	uint32_t begin, end, psize;
-	uint32_t digits_off; // u8 [classbook entries][cpc] in the image's byte pool, or 0xFFFFFFFF: digits by division
+	uint32_t digits_off; // u16 [classbook entries][cpc] in the image's digit pool (see LwEntTables::digits), or 0xFFFFFFFF: by division
+	uint32_t runs_off;   // LwEntRun [classifications][8 passes] in the image's run pool
+	uint32_t used_any;   // passes some class of this residue uses at all
 	uint8_t vals_used[LW_ENT_MAX_CLASSES];
-	uint8_t val_i[LW_ENT_MAX_CLASSES][8];
+};
+
+// One (residue, class, pass): everything a partition's run of codewords needs, fetched with ONE 32-byte load (through the
+// residue's class table and the book table it took four dependent accesses and a division per run)
+struct alignas(16) LwEntRun {
+	uint32_t lut_off, vq_off, shape, nodes_off; // as LwEntBook
+	uint32_t count; // codewords per partition: psize / dims
+	uint32_t step;  // element stride inside a codeword's vector: type 0 psize / dims, types 1/2 1 (audio.rs:587-618)
+	uint32_t adv;   // elements between the starts of consecutive codewords: type 0 1, types 1/2 dims
+	uint32_t book;  // (the book's number)
 };
 
 struct LwEntMode {
@@ -87,16 +140,17 @@ struct LwEntMode {
 
 // Resolved view of the image (device pointers on the GPU, host pointers in the CPU harness)
 struct LwEntTables {
-	const LwEntBook *books;
-	const LwEntFloor *floors;
-	const LwEntResidue *residues;
-	const LwEntMode *modes;
-	const uint32_t *lut;
-	const float *vq;
-	const uint8_t *bytes;
-	const int32_t *nodes;
+	const LW_K LwEntBook *books;
+	const LW_K LwEntFloor *floors;
+	const LW_K LwEntResidue *residues;
+	const LW_K LwEntMode *modes;
+	const LW_K uint32_t *lut;
+	const LW_K float *vq;
+	const LW_K uint16_t *digits; // per classbook entry and digit: class | vals_used[class] << 8
+	const LW_K LwEntRun *runs;
+	const LW_K int32_t *nodes;
 	uint32_t ch, fstride;
-	uint32_t ws_bytes;  // per-packet scratch: posts (4 * LW_MAX_POSTS rounded up) + classification digits
+	uint32_t ws_bytes;  // per-packet scratch: posts (4 * LW_MAX_POSTS rounded up) + classification digits (u16)
 	uint32_t res_floats; // largest residue block of a packet: ch * blocksize_1 / 2
 	uint32_t general;    // 0: every mapping has one submap with all channels (the usual case; its own kernel instantiation)
 };
@@ -116,23 +170,24 @@ struct LwEntPacket { // 16 bytes
 // field by field through a pointer, every codeword paid 3-4 dependent table accesses before its own look-up: the compiler
 // may not keep byte-typed fields in registers across the residue stores.)
 struct LwEntBookRegs {
-	const uint32_t *lut;
-	const float *vq;
-	const int32_t *nodes; // tree for the (rare) codes longer than the two table levels, or null
+	const LW_K uint32_t *lut;
+	const LW_K float *vq;
+	const LW_K int32_t *nodes; // tree for the (rare) codes longer than the two table levels, or null
 	uint32_t lut_mask, lut_bits, dims;
 	int32_t single;
 };
 
 LW_HD LwEntBookRegs lw_ent_book(const LwEntTables &T, uint32_t bi)
 {
-	const LwEntBook b = T.books[bi];
+	const LW_K LwEntBook &b = T.books[bi];
 	LwEntBookRegs r;
 	r.lut = T.lut + b.lut_off;
 	r.vq = T.vq + b.vq_off;
-	r.lut_bits = b.lut_bits;
-	r.lut_mask = (1u << b.lut_bits) - 1u;
-	r.dims = b.dims;
-	r.single = b.single;
+	const uint32_t shape = b.shape;
+	r.lut_bits = shape & 0xffu;
+	r.lut_mask = (1u << r.lut_bits) - 1u;
+	r.dims = (shape >> 8) & 0xffu;
+	r.single = (int16_t)(shape >> 16);
 	r.nodes = b.nodes_off != 0xFFFFFFFFu ? T.nodes + b.nodes_off : nullptr;
 	return r;
 }
@@ -140,22 +195,25 @@ LW_HD LwEntBookRegs lw_ent_book(const LwEntTables &T, uint32_t bi)
 // LSb-first reader with the bit window in registers: `win` holds the next `have` bits (>= 32 after peek()), `nxt` the word
 // after them, requested one refill ahead -- the packet bytes are read sequentially whatever the code lengths, so their
 // loads are never on a codeword's dependency chain.  The pool keeps >= 3 zero words behind every packet.
+// `left` = bits of the packet not yet consumed: the reference's bounds checks (bitpacking.rs:291-297, huffman_tree.rs:362-381)
+// are comparisons against it.
+#define LW_ENT_SPECIAL(e) ((uint32_t)((e) - 0x01000000u) >= 0x7f000000u) // a link to a second-level table, or length 0: ONE test
 struct LwEntReader {
-	const uint32_t *w;
-	uint32_t nbits, pos;
+	const LW_K uint32_t *w;
+	uint32_t nbits, left;
 	uint64_t win;
-	uint32_t have, wi, nxt;
+	uint32_t have, wo, nxt; // wo: byte offset of the word after nxt
 
-	LW_HD void init(const uint32_t *words, uint32_t len_bytes, uint32_t start_bit)
+	LW_HD void init(const LW_K uint32_t *words, uint32_t len_bytes, uint32_t start_bit)
 	{
 		w = words;
 		nbits = len_bytes * 8u;
-		pos = start_bit;
-		const uint32_t i = pos >> 5, s = pos & 31u;
+		left = nbits - start_bit;
+		const uint32_t i = start_bit >> 5, s = start_bit & 31u;
 		win = (uint64_t)(w[i] >> s);
 		have = 32u - s;
 		nxt = w[i + 1];
-		wi = i + 2;
+		wo = (i + 2) * 4u;
 	}
 	// the next 32 bits, zero past the end of the packet
 	LW_HD uint32_t peek()
@@ -163,16 +221,16 @@ struct LwEntReader {
 		if (have < 32u) {
 			win |= (uint64_t)nxt << have;
 			have += 32u;
-			nxt = w[wi];
-			wi++;
+			nxt = *(const LW_K uint32_t *)((const LW_K char *)w + wo);
+			wo += 4u;
 		}
 		return (uint32_t)win;
 	}
-	LW_HD void skip(uint32_t n) // n <= 32, after peek()
+	LW_HD void skip(uint32_t n) // n <= 32, n <= left, after peek()
 	{
 		win >>= n;
 		have -= n;
-		pos += n;
+		left -= n;
 	}
 	// bitpacking.rs:291-297: a fixed-width read that does not fit fails without consuming anything; n <= 32
 	LW_HD bool read(uint32_t n, uint32_t &v)
@@ -181,7 +239,7 @@ struct LwEntReader {
 			v = 0;
 			return true;
 		}
-		if (pos + n > nbits)
+		if (n > left)
 			return false;
 		const uint32_t x = peek();
 		v = n >= 32 ? x : (x & ((1u << n) - 1u));
@@ -189,36 +247,34 @@ struct LwEntReader {
 		return true;
 	}
 	// huffman_tree.rs:362-381 through the two table levels: a code that runs past the end consumes the rest and fails
-	// (after that every read fails on its bounds check; the window is not looked at again)
-	// the same in two halves, so that a caller can put other work between the table load and its first use: probe() starts
-	// the first-level look-up of an ordinary book (any value for the special ones), finish() does everything else
-	LW_HD uint32_t probe(const LwEntBookRegs &b)
+	// (after that every read fails on its bounds check; the window is not looked at again).
+	// In two halves, so that a caller can put other work between the table load and its first use: probe() starts the
+	// first-level look-up of an ordinary book, finish() does everything else.
+	LW_HD uint32_t probe(const LW_K uint32_t *lut, uint32_t lut_mask)
 	{
-		if (b.single != -1)
-			return 0;
-		return b.lut[peek() & b.lut_mask];
+		return lut[peek() & lut_mask];
 	}
-	LW_HD bool finish(const LwEntBookRegs &b, uint32_t e, uint32_t &sym)
+	LW_HD bool finish(const LW_K uint32_t *lut, uint32_t lut_bits, const LW_K int32_t *nodes, uint32_t e, uint32_t &sym)
 	{
-		if (b.single != -1)
-			return code(b, sym);
-		if (e & LW_ENT_LINK)
-			e = b.lut[(e & 0xffffffu) + (((uint32_t)win >> b.lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
+		if (LW_ENT_SPECIAL(e)) {
+			if (e & LW_ENT_LINK)
+				e = lut[(e & 0xffffffu) + (((uint32_t)win >> lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
+			if ((e >> 24) == 0)
+				return walk(nodes, sym);
+		}
 		const uint32_t len = e >> 24;
-		if (len == 0)
-			return walk(b, sym);
-		if (len > nbits - pos) {
-			pos = nbits;
+		if (len > left) {
+			left = 0;
 			return false;
 		}
 		skip(len);
-		sym = e & 0xffffffu;
+		sym = e; // (len << 24) | entry: the callers use the low 24 bits
 		return true;
 	}
 	LW_HD bool code(const LwEntBookRegs &b, uint32_t &sym)
 	{
 		if (b.single >= 0) {
-			if (pos + 1 > nbits)
+			if (left < 1)
 				return false;
 			(void)peek();
 			skip(1);
@@ -226,54 +282,46 @@ struct LwEntReader {
 			return true;
 		}
 		if (b.single == -2) { // empty book: the reference panics; like the host stage, the packet ends here
-			pos = nbits;
+			left = 0;
 			return false;
 		}
-		const uint32_t x = peek();
-		uint32_t e = b.lut[x & b.lut_mask];
-		if (e & LW_ENT_LINK)
-			e = b.lut[(e & 0xffffffu) + ((x >> b.lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
-		const uint32_t len = e >> 24;
-		if (len == 0)
-			return walk(b, sym);
-		if (len > nbits - pos) {
-			pos = nbits;
+		const uint32_t e = probe(b.lut, b.lut_mask);
+		if (!finish(b.lut, b.lut_bits, b.nodes, e, sym))
 			return false;
-		}
-		skip(len);
-		sym = e & 0xffffffu;
+		sym &= 0xffffffu;
 		return true;
 	}
 	// a code beyond the table levels (19+ bits: one in 2^18 codewords of a real encoder's books): bit by bit through the tree,
 	// straight from the packet words
-	LW_HD bool walk(const LwEntBookRegs &b, uint32_t &sym)
+	LW_HD bool walk(const LW_K int32_t *nodes, uint32_t &sym)
 	{
-		if (!b.nodes) {
-			pos = nbits;
+		if (!nodes) {
+			left = 0;
 			return false;
 		}
 		int32_t node = 0;
+		const uint32_t pos = nbits - left;
 		uint32_t p = pos;
 		for (;;) {
 			if (p >= nbits) {
-				pos = nbits;
+				left = 0;
 				return false;
 			}
 			const uint32_t bit = (w[p >> 5] >> (p & 31u)) & 1u;
 			p++;
-			const int32_t c = b.nodes[2 * node + (int32_t)bit];
+			const int32_t c = nodes[2 * node + (int32_t)bit];
 			if (c == (int32_t)0x80000000) {
-				pos = nbits;
+				left = 0;
 				return false;
 			}
 			if (c < 0) {
 				sym = (uint32_t)~c;
-				uint32_t left = p - pos;
-				while (left) { // (more than 32 bits are possible)
-					const uint32_t s = left < 32u ? left : 32u;
+				uint32_t n = p - pos;
+				while (n) { // (more than 32 bits are possible)
+					const uint32_t s = n < 32u ? n : 32u;
 					(void)peek();
 					skip(s);
-					left -= s;
+					n -= s;
 				}
 				return true;
 			}
@@ -283,7 +331,7 @@ struct LwEntReader {
 };
 
 // audio.rs:215-251; y = the packet's scratch.  false = unused floor (FloorSpecialCase::Unused)
-LW_HD bool lw_ent_floor_decode(const LwEntTables &T, const LwEntFloor &fl, LwEntReader &r, LwEntPosts y)
+LW_HD bool lw_ent_floor_decode(const LwEntTables &T, const LW_K LwEntFloor &fl, LwEntReader &r, LwEntPosts y)
 {
 	uint32_t nonzero;
 	if (!r.read(1, nonzero) || !nonzero)
@@ -329,7 +377,7 @@ LW_HD uint32_t lw_ent_render_point(uint32_t y0, uint32_t y1, uint32_t dx, uint64
 
 // audio.rs:391-435 -> device record: per post in ascending-x order, (final_y * multiplier) | active flag.  y is updated in
 // place (a post's neighbours precede it in header order).
-LW_HD void lw_ent_floor_record(const LwEntFloor &fl, LwEntPosts y, uint16_t *rec)
+LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t *rec)
 {
 	const uint32_t F = fl.F, range = fl.range;
 	uint32_t act0 = 3u, act1 = 0u, act2 = 0u; // step2 flags of posts 0-31, 32-63, 64
@@ -372,63 +420,147 @@ LW_HD void lw_ent_floor_record(const LwEntFloor &fl, LwEntPosts y, uint16_t *rec
 	}
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The steady state of a partition's run of codewords, by hand (gfx950): per codeword ~15 scalar instructions (the scalar unit
+// paces this kernel: one wave per packet, four packets per SIMD), 4 vector instructions, one table look-up, one row load,
+// one LDS read-modify-write of the PREVIOUS codeword's vector -- what the compiler makes of the same loop in C++ is ~50 + 19.
+//   window refill (every 32 bits) | entry = lut[window & mask] | add the pending vector | link -> second-level entry |
+//   bounds (left -= len borrows: the code runs past the end) | window >>= len | row load for this codeword
+// Returns 0: `todo` codewords done (todo = 0); 1: the codeword at the head of the window needs the tree (entry in `e`: length
+// 0), nothing of it consumed, the pending vector is added; 2: the codeword runs past the end of the packet (pending added).
+// On return no load is outstanding (pv is valid).  s[84:87] and v63 are scratch: the window is shifted as a 64-bit pair.
+__device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader &r, const LW_K uint32_t *lut, const LW_K float *vq,
+		uint32_t lut_mask, uint32_t lut_bits, uint32_t &todo, uint32_t &e, uint32_t &pat, float &pv, uint32_t &at, uint32_t inc,
+		uint32_t row, uint32_t vdims4)
+{
+	uint32_t st, t0, t1;
+	uint32_t neg = LW_ENT_SCALAR(0u - todo); // (wave-uniform like everything scalar here; the compiler keeps this one in a vector register)
+	// The statement with the loop returns scalars only: one that also returned vector registers would be divergent as a
+	// whole to the compiler's analysis, and the reader and every branch behind it would move to vector registers and exec
+	// masks.  So the per-lane values it changes go in as inputs, and an empty statement right behind it hands them back as
+	// outputs of the same registers (both statements name their registers in a comment: tests/test_entropy_asm_pairs.py
+	// checks the generated code).
+	// (fresh values first, used by the two statements below and by nothing else: a register the compiler shares with another
+	// use of the same value -- the constant 0.0f of a cleared pending vector -- must not be modified behind its back)
+	asm volatile("" : "+v"(pat), "+v"(pv), "+v"(at));
+	asm volatile("; lw_ent_run in %[pat] %[pv] %[at]\n"
+	             "s_mov_b64 s[84:85], %[win]\n"
+	             "s_mov_b32 s87, 0\n"
+	             "11:\n" // ---- next codeword
+	             "s_cmp_lt_u32 %[have], 32\n"
+	             "s_cbranch_scc0 12f\n"
+	             "s_mov_b32 s86, %[nxt]\n"
+	             "s_lshl_b64 s[86:87], s[86:87], %[have]\n"
+	             "s_or_b64 s[84:85], s[84:85], s[86:87]\n"
+	             "s_add_u32 %[have], %[have], 32\n"
+	             "s_load_dword %[nxt], %[w], %[wo]\n"
+	             "s_add_u32 %[wo], %[wo], 4\n"
+	             "s_mov_b32 s87, 0\n"
+	             "12:\n"
+	             "s_and_b32 %[t0], s84, %[mask]\n"
+	             "s_lshl_b32 %[t0], %[t0], 2\n"
+	             "s_load_dword %[e], %[lut], %[t0]\n"
+	             "ds_read_b32 v63, %[pat]\n"
+	             "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+	             "v_add_f32 v63, v63, %[pv]\n"
+	             "ds_write_b32 %[pat], v63\n"
+	             "s_sub_u32 %[t0], %[e], 0x1000000\n"
+	             "s_cmp_ge_u32 %[t0], 0x7f000000\n"
+	             "s_cbranch_scc1 14f\n"
+	             "13:\n" // ---- an ordinary entry: (length << 24) | entry number
+	             "s_lshr_b32 %[t0], %[e], 24\n"
+	             "s_sub_u32 %[left], %[left], %[t0]\n"
+	             "s_cbranch_scc1 16f\n"
+	             "s_lshr_b64 s[84:85], s[84:85], %[t0]\n"
+	             "s_sub_u32 %[have], %[have], %[t0]\n"
+	             "v_mad_u32_u24 v63, %[e], %[vd4], %[row]\n"
+	             "global_load_dword %[pv], v63, %[vq]\n"
+	             "v_mov_b32 %[pat], %[at]\n"
+	             "v_add_u32 %[at], %[at], %[inc]\n"
+	             "s_add_u32 %[neg], %[neg], 1\n"
+	             "s_cbranch_scc0 11b\n"
+	             "s_mov_b32 %[st], 0\n"
+	             "s_branch 19f\n"
+	             "14:\n" // ---- a link to a second-level table, or length 0
+	             "s_bitcmp1_b32 %[e], 31\n"
+	             "s_cbranch_scc0 15f\n"
+	             "s_bfe_u32 %[t0], %[e], 0x70018\n"
+	             "s_lshr_b32 %[t1], s84, %[bits]\n"
+	             "s_bfm_b32 %[t0], %[t0], 0\n"
+	             "s_and_b32 %[t1], %[t1], %[t0]\n"
+	             "s_and_b32 %[t0], %[e], 0xffffff\n"
+	             "s_add_u32 %[t0], %[t0], %[t1]\n"
+	             "s_lshl_b32 %[t0], %[t0], 2\n"
+	             "s_load_dword %[e], %[lut], %[t0]\n"
+	             "s_waitcnt lgkmcnt(0)\n"
+	             "s_cmp_lt_u32 %[e], 0x1000000\n"
+	             "s_cbranch_scc0 13b\n"
+	             "15:\n"
+	             "s_mov_b32 %[st], 1\n"
+	             "s_branch 19f\n"
+	             "16:\n"
+	             "s_mov_b32 %[st], 2\n"
+	             "19:\n"
+	             "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+	             "s_mov_b64 %[win], s[84:85]\n"
+	             : [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),
+	               [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1)
+	             : [w] "s"(r.w), [lut] "s"(lut), [vq] "s"(vq), [mask] "s"(lut_mask), [bits] "s"(lut_bits), [inc] "v"(inc), [row] "v"(row),
+	               [vd4] "v"(vdims4), [pat] "v"(pat), [pv] "v"(pv), [at] "v"(at)
+	             : "s84", "s85", "s86", "s87", "v63", "scc", "memory");
+	asm volatile("; lw_ent_run out %0 %1 %2" : "+v"(pat), "+v"(pv), "+v"(at));
+	todo = 0u - neg;
+	return st;
+}
+#endif
+
 // audio.rs:620-717 for `nch` vectors of `actual` elements.  Element e of vector j is out[map(j, e)]: for residue type 2 the
 // ONE interleaved vector of ch * n/2 elements is written straight to its channel-major place (audio.rs:748-754: element i
 // belongs to channel i % ch, bin i / ch) -- every element receives the same additions in the same order as in the
 // reference's interleaved buffer.  `out` holds zeros on entry.  `cls` = scratch for nch * (parts + cpc) digits.
 //
 // The additions run ONE CODEWORD BEHIND the decoder: a codeword's vector row is requested as soon as its entry number is
-// known, and added (LwEntPending::flush) after the NEXT codeword's table look-up has been started -- the look-up chain
+// known, and added (LwEntPend::flush) after the NEXT codeword's table look-up has been started -- the look-up chain
 // (window -> table -> length -> window) is the only thing a packet cannot overlap, everything else hides under it.
-// The first pass that touches a partition finds zeros there (a pass adds to an element at most once): it stores
-// 0.0f + e without reading the accumulator.
-struct LwEntPending {
-	const float *row; // the codeword's VQ row, or null: nothing pending
-	uint32_t dims, base, step, deint, half;
-	uint64_t cmap;    // channel of vector j in byte j (a submap's vectors are a subset of the packet's channels)
-	bool ident;       // vector j is channel j (the usual one-submap case)
-	bool first;
-#if defined(__HIP_DEVICE_COMPILE__)
-	float rowv; // lane d holds row[d]: requested when the codeword was decoded
-#endif
-	LW_HD void stash(const float *r, uint32_t n_dims, uint32_t base_el, uint32_t step_, uint32_t deint_, uint32_t half_, bool first_)
+// Every addition reads the accumulator, also the first one to an element (0.0f + e, as the reference's += on its zeroed
+// vector).  On the device all 64 lanes take part in every flush without masking: a lane beyond the codeword's dimension
+// adds to its own dump slot behind the accumulators.
+struct LwEntPend {
+	LW_LV(uint32_t, at); // this lane's accumulator (LW_ENT_AT)
+	LW_LV(float, v);
+	uint32_t n;          // host: elements pending
+	LW_HD void clear(LwEntAcc out, uint32_t dump)
 	{
-		row = r;
-		dims = n_dims;
-		base = base_el;
-		step = step_;
-		deint = deint_;
-		half = half_;
-		first = first_;
-#if defined(__HIP_DEVICE_COMPILE__)
-		LW_ENT_EACH(d, n_dims)
-			rowv = r[d];
-#endif
+		n = 0;
+		LW_ENT_LANES(d, 0u) {
+			LW_L(at) = LW_ENT_AT(out, dump + d);
+			LW_L(v) = 0.0f;
+		}
 	}
-	// element d of the row goes to: type 0 base + d * step; types 1/2 base + d, de-interleaved for type 2
+	// (a flush is always followed by a stash or by the end of the residue: nothing is added twice)
 	LW_HD void flush(LwEntAcc out)
 	{
-		if (!row)
-			return;
-		LW_ENT_EACH(d, dims) {
-#if defined(__HIP_DEVICE_COMPILE__)
-			const float e = rowv;
-#else
-			const float e = row[d];
-#endif
-			uint32_t at = base + d * step;
-			if (deint) { // type 2: element `at` of the interleaved vector belongs to the submap's vector at % deint, bin at / deint
-				const uint32_t v = deint == 2 ? at & 1u : at % deint, q = deint == 2 ? at >> 1 : at / deint;
-				at = (ident ? v : (uint32_t)((cmap >> (8u * v)) & 0xffu)) * half + q;
-			}
-			out[at] = (first ? 0.0f : out[at]) + e;
-		}
-		row = nullptr;
+		LW_ENT_LANES(d, n)
+			LW_ENT_ACC(out, LW_L(at)) = LW_ENT_ACC(out, LW_L(at)) + LW_L(v);
+		n = 0;
 	}
 };
 
-LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntReader &r, uint32_t nch, uint32_t actual,
-		const bool *dnd, LwEntAcc out, uint32_t half, uint32_t deint_ch, LwEntDigits cls, uint64_t cmap, const bool general)
+// accumulator index of element `el` of the (interleaved, DEINT != 0) vector
+template <int DEINT>
+LW_HD uint32_t lw_ent_place(uint32_t el, uint32_t deint, uint32_t half, uint64_t cmap, bool ident)
+{
+	if (DEINT == 0)
+		return el;
+	const uint32_t v = DEINT == 2 ? el & 1u : el % deint, q = DEINT == 2 ? el >> 1 : el / deint;
+	return (ident ? v : (uint32_t)((cmap >> (8u * v)) & 0xffu)) * half + q;
+}
+
+// DEINT: 0 = the vectors are channels (residue types 0 and 1); 2 = type 2 over two channels; -1 = type 2 over `deint_ch`
+// channels.  dnd = bit j: vector j is not decoded.
+template <int DEINT>
+LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwEntReader &r, uint32_t nch, uint32_t actual,
+		uint32_t dnd, LwEntAcc out, uint32_t half, uint32_t deint_ch, LwEntDigits cls, uint64_t cmap, const bool general)
 {
 	const uint32_t begin = rs.begin < actual ? rs.begin : actual, end = rs.end < actual ? rs.end : actual;
 	const uint32_t cpc = rs.cpc, psize = rs.psize;
@@ -437,24 +569,21 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 	if (n_to_read == 0)
 		return;
 	const uint32_t stride = parts + cpc;
-	const uint32_t ncls = rs.classifications, rtype = rs.type, digits_off = rs.digits_off;
-	uint32_t used_any = 0; // passes some class of this residue uses at all
-	for (uint32_t c = 0; c < ncls; c++)
-		used_any |= rs.vals_used[c];
+	const uint32_t ncls = rs.classifications, digits_off = rs.digits_off, used_any = rs.used_any;
+	const LW_K LwEntRun *const runs = T.runs + rs.runs_off;
 	const LwEntBookRegs classbook = lw_ent_book(T, rs.classbook);
-	LwEntPending pend;
-	pend.row = nullptr;
-	pend.cmap = cmap;
-	pend.ident = true;
+	LwEntPend pend;
+	pend.clear(out, T.res_floats);
+	bool ident = true;
 	if (general) // (a compile-time constant at both call sites: the one-submap kernel carries no channel map at all)
-		for (uint32_t v = 0, nv = deint_ch ? deint_ch : nch; v < nv; v++)
-			pend.ident &= ((cmap >> (8u * v)) & 0xffu) == v;
+		for (uint32_t v = 0, nv = DEINT ? deint_ch : nch; v < nv; v++)
+			ident &= ((cmap >> (8u * v)) & 0xffu) == v;
 	for (uint32_t pass = 0; pass < 8 && (used_any >> pass) != 0; pass++) {
 		uint32_t pc = 0;
 		while (pc < parts) {
 			if (pass == 0) {
 				for (uint32_t j = 0; j < nch; j++) {
-					if (dnd[j])
+					if ((dnd >> j) & 1u)
 						continue;
 					uint32_t t;
 					if (!r.code(classbook, t)) {
@@ -463,12 +592,15 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 					}
 					LwEntDigits c = cls + j * stride + pc;
 					if (digits_off != 0xFFFFFFFFu) {
-						const uint8_t *dg = T.bytes + digits_off + t * cpc;
-						LW_ENT_EACH(q, cpc)
-							c[q] = dg[q];
+						const LW_K uint16_t *dg = T.digits + digits_off + t * cpc;
+						LW_ENT_LANES(q, cpc) { // (device: no masking -- the lanes beyond the last digit copy the last digit again)
+							const uint32_t qq = q < cpc ? q : cpc - 1u;
+							c[qq] = dg[qq];
+						}
 					} else {
 						for (uint32_t q = cpc; q-- > 0;) {
-							c[q] = (uint8_t)(t % ncls);
+							const uint32_t cl = t % ncls;
+							c[q] = (uint16_t)(cl | ((uint32_t)rs.vals_used[cl] << 8));
 							t /= ncls;
 						}
 					}
@@ -476,27 +608,89 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 			}
 			for (uint32_t k = 0; k < cpc && pc < parts; k++, pc++) {
 				for (uint32_t j = 0; j < nch; j++) {
-					if (dnd[j])
+					if ((dnd >> j) & 1u)
 						continue;
-					const uint32_t cl = cls[j * stride + pc];
-					const uint32_t vu = rs.vals_used[cl];
-					if (!(vu & (1u << pass)))
+					const uint32_t cv = LW_ENT_SCALAR(cls[j * stride + pc]); // class | passes it uses << 8
+					if (!((cv >> (8u + pass)) & 1u))
 						continue;
-					const LwEntBookRegs cb = lw_ent_book(T, rs.val_i[cl][pass]);
-					const uint32_t dims = cb.dims;
-					const bool first = (vu & ((1u << pass) - 1u)) == 0;
-					// audio.rs:587-618 (the whole partition lies inside the vector; dims divides the partition size):
-					// type 0: psize / dims codewords, element d of codeword i at i + d * step; types 1/2: at i * dims + d
-					const uint32_t step = rtype == 0 ? psize / dims : 1u;
-					const uint32_t count = psize / dims, adv = rtype == 0 ? 1u : dims;
-					uint32_t at = (deint_ch ? 0u : (pend.ident ? j : (uint32_t)((cmap >> (8u * j)) & 0xffu)) * half) + begin + pc * psize;
-					for (uint32_t i = 0; i < count; i++, at += adv) {
-						const uint32_t e = r.probe(cb); // this codeword's table look-up is under way ...
-						pend.flush(out);                 // ... while the previous codeword's vector is added
-						uint32_t idx;
-						if (!r.finish(cb, e, idx))
-							return;
-						pend.stash(cb.vq + idx * dims, dims, at, step, deint_ch, half, first);
+					const LW_K LwEntRun &rd = runs[(cv & 0xffu) * 8u + pass];
+					const uint32_t shape = rd.shape, count = rd.count, step = rd.step, adv = rd.adv;
+					const uint32_t dims = (shape >> 8) & 0xffu, lut_bits = shape & 0xffu;
+					const int32_t single = (int16_t)(shape >> 16);
+					const LW_K uint32_t *lut = T.lut + rd.lut_off;
+					const LW_K float *vq = T.vq + rd.vq_off;
+					const LW_K int32_t *nodes = rd.nodes_off != 0xFFFFFFFFu ? T.nodes + rd.nodes_off : nullptr;
+					// first element of the partition in its vector; audio.rs:587-618 (the whole partition lies inside the vector,
+					// dims divides the partition size): type 0: element d of codeword i at i + d * step; types 1/2: at i * dims + d
+					const uint32_t el0 = (DEINT ? 0u : (ident ? j : (uint32_t)((cmap >> (8u * j)) & 0xffu)) * half) + begin + pc * psize;
+					const uint32_t dper = DEINT == 2 ? 2u : DEINT ? deint_ch : 1u;
+					if (single == -1 && (DEINT == 0 || dims % dper == 0)) {
+						// the usual run: a lane's element moves by a constant from one codeword to the next (an interleaved vector:
+						// its channel stays, its bin moves by dims / channels)
+						const uint32_t lut_mask = (1u << lut_bits) - 1u;
+						LW_LV(uint32_t, at);
+						LW_LV(uint32_t, inc);
+						LW_LV(uint32_t, row);
+#if defined(__HIP_DEVICE_COMPILE__)
+						// (the row's address is vector work -- one 24-bit multiply-add per lane on the table entry as it is, length
+						// bits and all: the scalar unit, which paces this kernel, is left alone)
+						const uint32_t vdims4 = dims * 4u;
+#define LW_ENT_ROW(idx) (*(const LW_K float *)((const LW_K char *)vq + lw_ent_mad24((idx), vdims4, row)))
+#else
+#define LW_ENT_ROW(idx) vq[((idx) & 0xffffffu) * dims + row[d]]
+#endif
+						LW_ENT_LANES(d, dims) {
+							const bool on = d < dims;
+							LW_L(at) = LW_ENT_AT(out, on ? lw_ent_place<DEINT>(el0 + d * step, deint_ch, half, cmap, ident) : T.res_floats + d);
+							LW_L(inc) = on ? (adv / dper) * (LW_ENT_AT(out, 1u) - LW_ENT_AT(out, 0u)) : 0u;
+							LW_L(row) = on ? d * LW_ENT_ROW_UNIT : 0u;
+						}
+						uint32_t todo = count;
+						while (todo) {
+							uint32_t e;
+#if defined(__HIP_DEVICE_COMPILE__)
+							// the steady state by hand (lw_ent_run): it comes back for what is rare -- a code beyond the two table
+							// levels, the end of the packet
+							const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, e, pend.at, pend.v, at, inc, row, vdims4);
+							if (st == 0u)
+								break;
+							if (st == 2u) {
+								r.left = 0;
+								return;
+							}
+#else
+							e = r.probe(lut, lut_mask); // this codeword's table look-up is under way ...
+							pend.flush(out);            // ... while the previous codeword's vector is added
+#endif
+							uint32_t idx;
+							if (!r.finish(lut, lut_bits, nodes, e, idx))
+								return;
+							LW_ENT_LANES(d, dims) {
+								pend.LW_L(at) = LW_L(at);
+								pend.LW_L(v) = LW_ENT_ROW(idx);
+								LW_L(at) += LW_L(inc);
+							}
+							pend.n = dims;
+							todo--;
+						}
+					} else {
+						// single-entry / empty books, interleaved vectors whose channel count does not divide the dimension
+						const LwEntBookRegs cb = {lut, vq, nodes, (1u << lut_bits) - 1u, lut_bits, dims, single};
+						uint32_t el = el0;
+						for (uint32_t i = 0; i < count; i++, el += adv) {
+							uint32_t idx;
+							if (!r.code(cb, idx)) {
+								pend.flush(out);
+								return;
+							}
+							pend.flush(out);
+							LW_ENT_LANES(d, dims) {
+								const bool on = d < dims;
+								pend.LW_L(at) = LW_ENT_AT(out, on ? lw_ent_place<DEINT>(el + d * step, deint_ch, half, cmap, ident) : T.res_floats + d);
+								pend.LW_L(v) = vq[idx * dims + (on ? d : 0u)];
+							}
+							pend.n = dims;
+						}
 					}
 				}
 			}
@@ -506,71 +700,67 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LwEntResidue &rs, LwEntRea
 }
 
 // Floors and residues of one packet (what lw::entropy_decode does after the prologue).  floor_out [ch][fstride],
-// res_out [ch][n/2] zero on entry, ws = T.ws_bytes of scratch (4-byte aligned).
-LW_HD void lw_ent_decode_packet(const LwEntTables &T, const uint32_t *words, uint32_t len_bytes, uint32_t start_bit,
+// res_out [ch][n/2] zero on entry (device: + LW_ENT_DUMP_FLOATS behind T.res_floats), ws = T.ws_bytes of scratch (4-byte aligned).
+LW_HD void lw_ent_decode_packet(const LwEntTables &T, const LW_K uint32_t *words, uint32_t len_bytes, uint32_t start_bit,
 		uint32_t mode, uint32_t n, uint16_t *floor_out, LwEntAcc res_out, LwEntPosts y, LwEntDigits cls, const bool general)
 {
 	LwEntReader r;
 	r.init(words, len_bytes, start_bit);
-	const LwEntMode &m = T.modes[mode];
+	const LW_K LwEntMode &m = T.modes[mode];
 	const uint32_t ch = T.ch, half = n >> 1;
-	bool no_residue[LW_ENT_MAX_CH];
+	uint32_t no_residue = 0; // bit c: channel c has no residue
 	// floor_decode, audio.rs:557-585
 	for (uint32_t c = 0; c < ch; c++) {
-		const LwEntFloor &fl = T.floors[m.floor_of_ch[c]];
+		const LW_K LwEntFloor &fl = T.floors[m.floor_of_ch[c]];
 		uint16_t *rec = floor_out + c * T.fstride;
 		if (!lw_ent_floor_decode(T, fl, r, y)) {
 			rec[0] = LW_FLOOR_UNUSED;
-			no_residue[c] = true;
+			no_residue |= 1u << c;
 		} else {
 			lw_ent_floor_record(fl, y, rec);
-			no_residue[c] = false;
 		}
 	}
 	// audio.rs:948-955
 	for (uint32_t i = 0; i < m.n_coupling; i++) {
-		const uint32_t mg = m.mag[i], an = m.ang[i];
-		if (!(no_residue[mg] && no_residue[an]))
-			no_residue[mg] = no_residue[an] = false;
+		const uint32_t pair = (1u << m.mag[i]) | (1u << m.ang[i]);
+		if ((no_residue & pair) != pair)
+			no_residue &= ~pair;
 	}
+	const uint32_t all = (1u << ch) - 1u;
 	if (!general) { // one submap holding every channel (T.general == 0): vector j = channel j
-		const LwEntResidue &rs = T.residues[m.submap_residue[0]];
+		const LW_K LwEntResidue &rs = T.residues[m.submap_residue[0]];
 		if (rs.type != 2) {
-			lw_ent_residue(T, rs, r, ch, half, no_residue, res_out, half, 0u, cls, 0, false);
+			lw_ent_residue<0>(T, rs, r, ch, half, no_residue, res_out, half, 0u, cls, 0, false);
 			return;
 		}
 		// audio.rs:722-760: type 2 = one interleaved vector of ch * n/2 elements, decoded unless EVERY channel is marked
-		bool any = false;
-		for (uint32_t c = 0; c < ch; c++)
-			any |= !no_residue[c];
-		if (!any)
+		if ((no_residue & all) == all)
 			return;
-		const bool one_dnd[1] = {false};
-		lw_ent_residue(T, rs, r, 1u, ch * half, one_dnd, res_out, half, ch, cls, 0, false);
+		if (ch == 2)
+			lw_ent_residue<2>(T, rs, r, 1u, ch * half, 0u, res_out, half, ch, cls, 0, false);
+		else
+			lw_ent_residue<-1>(T, rs, r, 1u, ch * half, 0u, res_out, half, ch, cls, 0, false);
 		return;
 	}
 	// audio.rs:957-986: submap by submap, the vectors of a submap = its channels in channel order
 	for (uint32_t sm = 0; sm < m.n_submaps; sm++) {
-		bool dnd[LW_ENT_MAX_CH];
+		uint32_t dnd = 0;
 		uint64_t cmap = 0;
 		uint32_t sub_ch = 0;
 		bool any = false;
 		for (uint32_t c = 0; c < ch; c++)
 			if (m.mux[c] == sm) {
-				dnd[sub_ch] = no_residue[c];
-				any |= !no_residue[c];
+				dnd |= ((no_residue >> c) & 1u) << sub_ch;
+				any |= !((no_residue >> c) & 1u);
 				cmap |= (uint64_t)c << (8u * sub_ch);
 				sub_ch++;
 			}
 		if (sub_ch == 0)
 			continue;
-		const LwEntResidue &rs = T.residues[m.submap_residue[sm]];
-		if (rs.type != 2) {
-			lw_ent_residue(T, rs, r, sub_ch, half, dnd, res_out, half, 0u, cls, cmap, true);
-		} else if (any) {
-			// audio.rs:722-760: type 2 = one interleaved vector of sub_ch * n/2 elements, decoded unless EVERY channel is marked
-			const bool one_dnd[1] = {false};
-			lw_ent_residue(T, rs, r, 1u, sub_ch * half, one_dnd, res_out, half, sub_ch, cls, cmap, true);
-		}
+		const LW_K LwEntResidue &rs = T.residues[m.submap_residue[sm]];
+		if (rs.type != 2)
+			lw_ent_residue<0>(T, rs, r, sub_ch, half, dnd, res_out, half, 0u, cls, cmap, true);
+		else if (any) // audio.rs:722-760: type 2 = one interleaved vector of sub_ch * n/2 elements, decoded unless EVERY channel is marked
+			lw_ent_residue<-1>(T, rs, r, 1u, sub_ch * half, 0u, res_out, half, sub_ch, cls, cmap, true);
 	}
 }

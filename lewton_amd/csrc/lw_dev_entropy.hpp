@@ -10,8 +10,8 @@
 namespace lw {
 
 struct DevEntropyImage {
-	std::vector<uint8_t> blob; // [books][floors][residues][modes][lut u32][vq f32][bytes][tree nodes i32], sections 16-byte aligned
-	size_t off_books = 0, off_floors = 0, off_residues = 0, off_modes = 0, off_lut = 0, off_vq = 0, off_bytes = 0, off_nodes = 0;
+	std::vector<uint8_t> blob; // [books][floors][residues][modes][lut u32][vq f32][digits u16][runs][tree nodes i32], sections 16-byte aligned
+	size_t off_books = 0, off_floors = 0, off_residues = 0, off_modes = 0, off_lut = 0, off_vq = 0, off_digits = 0, off_runs = 0, off_nodes = 0;
 	uint32_t ch = 0, fstride = 0, ws_bytes = 0, res_floats = 0, general = 0;
 };
 

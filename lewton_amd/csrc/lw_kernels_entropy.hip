@@ -23,7 +23,7 @@ template <bool GENERAL> // GENERAL: mappings with several submaps (vectors of a 
 __global__ void __launch_bounds__(64) k_entropy(LwEntTables T, const LwEntPacket *pk, const LwPacketRec *recs, const uint32_t *pool,
 		uint16_t *floors, float *residue, uint32_t n)
 {
-	extern __shared__ __attribute__((aligned(16))) float smem[]; // [T.res_floats accumulators][posts][digits]
+	extern __shared__ __attribute__((aligned(16))) float smem[]; // [T.res_floats accumulators][64 dump slots][posts][digits]
 	const uint32_t i = blockIdx.x; // wave-uniform: the decode state stays in SGPRs
 	const LwPacketRec rec = recs[i];
 	if (rec.flags & LW_RF_SKIP)
@@ -32,11 +32,12 @@ __global__ void __launch_bounds__(64) k_entropy(LwEntTables T, const LwEntPacket
 	const uint32_t blk = 1u << rec.bs, res_n = T.ch * (blk >> 1);
 	for (uint32_t k = threadIdx.x; k < res_n; k += 64)
 		smem[k] = 0.0f;
+	smem[T.res_floats + threadIdx.x] = 0.0f;
 	__syncthreads();
 	LwEntAcc acc = (LwEntAcc)smem;
-	LwEntPosts posts = (LwEntPosts)(smem + T.res_floats);
-	LwEntDigits digits = (LwEntDigits)(smem + T.res_floats) + LW_ENT_POSTS_BYTES;
-	lw_ent_decode_packet(T, pool + p.word_off, p.len, p.start_bit, rec.mode, blk, floors + rec.floor_off, acc, posts, digits, GENERAL);
+	LwEntPosts posts = (LwEntPosts)(smem + T.res_floats + LW_ENT_DUMP_FLOATS);
+	LwEntDigits digits = (LwEntDigits)(smem + T.res_floats + LW_ENT_DUMP_FLOATS + LW_ENT_POSTS_BYTES / 4u);
+	lw_ent_decode_packet(T, (const LW_K uint32_t *)(pool + p.word_off), p.len, p.start_bit, rec.mode, blk, floors + rec.floor_off, acc, posts, digits, GENERAL);
 	__syncthreads();
 	// residue blocks start at multiples of ch * n0 / 2 floats: 16-byte aligned
 	float *out = (float *)__builtin_assume_aligned(residue + rec.res_off, 16);
@@ -55,7 +56,7 @@ hipError_t lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, cons
 {
 	if (n == 0)
 		return hipSuccess;
-	const size_t lds = (size_t)T.res_floats * 4 + T.ws_bytes;
+	const size_t lds = ((size_t)T.res_floats + LW_ENT_DUMP_FLOATS) * 4 + T.ws_bytes;
 	static LwPerDeviceOnce once;
 	if (once.first_launch_on_device()) {
 		hipError_t e = hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);

@@ -111,7 +111,7 @@ int main(int argc, char **argv)
 			std::fill(rb.begin(), rb.begin() + ch * half, 0.0f);
 			uint8_t *w = ws.data() + ((16 - ((uintptr_t)ws.data() & 15)) & 15);
 			lw_ent_decode_packet(T, words.data(), (uint32_t)p.size(), (uint32_t)br.pos, pr2.mode, pr2.n, fb.data(), rb.data(), (uint32_t *)w,
-					w + LW_ENT_POSTS_BYTES, T.general != 0);
+					(uint16_t *)(w + LW_ENT_POSTS_BYTES), T.general != 0);
 			for (size_t c = 0; c < ch; c++) {
 				const uint16_t *a = fa.data() + c * fstride, *b = fb.data() + c * fstride;
 				const lw::Mapping &map = st->mappings[st->modes[pr.mode].mapping];
