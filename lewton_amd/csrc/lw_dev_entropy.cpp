@@ -100,9 +100,9 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		}
 		f.multiplier = fl.multiplier;
 		f.range = fl.range();
-		f.range_bits = (uint8_t)ilog(fl.range() - 1);
-		f.n_part = (uint8_t)fl.partition_class.size();
-		f.F = (uint8_t)F;
+		f.range_bits = ilog(fl.range() - 1);
+		f.n_part = (uint32_t)fl.partition_class.size();
+		f.F = (uint32_t)F;
 		size_t posts = 2;
 		for (size_t p = 0; p < fl.partition_class.size(); p++) {
 			const unsigned c = fl.partition_class[p];
@@ -110,7 +110,6 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 				*why = "floor 1 class number";
 				return false;
 			}
-			f.partition_class[p] = (uint8_t)c;
 			posts += fl.class_dim[c];
 			if (fl.class_sub[c]) {
 				if (fl.class_master[c] >= s.codebooks.size()) {
@@ -123,6 +122,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 				*why = "floor 1 subclass bits";
 				return false;
 			}
+			f.part[p] = (uint32_t)fl.class_dim[c] | (uint32_t)fl.class_sub[c] << 8 | (uint32_t)fl.class_master[c] << 16 | (uint32_t)c << 24;
 			for (unsigned k = 0; k < (1u << fl.class_sub[c]); k++) {
 				const int b = fl.sub_books[c][k];
 				if (b >= 0) {
@@ -138,21 +138,22 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 			*why = "floor 1 post count";
 			return false;
 		}
-		for (int c = 0; c < 16; c++) {
-			f.class_dim[c] = fl.class_dim[c];
-			f.class_sub[c] = fl.class_sub[c];
-			f.class_master[c] = fl.class_master[c];
+		for (int c = 0; c < 16; c++)
 			for (int k = 0; k < 8; k++)
-				f.sub_books[c][k] = fl.sub_books[c][k];
-		}
+				f.sub_books[c * 8 + k] = fl.sub_books[c][k];
+		std::vector<unsigned> level(F, 0);
 		for (size_t i = 0; i < F; i++) {
-			f.sorted_idx[i] = (uint8_t)fl.sorted_idx[i];
+			unsigned lo = 0, hi = 0;
 			if (i >= 2) {
-				f.lo_idx[i] = (uint8_t)fl.lo_idx[i];
-				f.hi_idx[i] = (uint8_t)fl.hi_idx[i];
+				lo = fl.lo_idx[i];
+				hi = fl.hi_idx[i];
+				level[i] = 1 + std::max(level[lo], level[hi]);
+				f.n_levels = std::max<uint32_t>(f.n_levels, level[i]);
 				f.dx[i] = fl.dx[i];
-				f.adx_magic[i] = fl.adx_magic[i];
+				f.magic_lo[i] = (uint32_t)(fl.adx_magic[i] & 0xffffffffu);
+				f.magic_hi[i] = (uint32_t)(fl.adx_magic[i] >> 32);
 			}
+			f.post[i] = lo | hi << 8 | level[i] << 16 | (uint32_t)fl.sorted_idx[i] << 24;
 		}
 	}
 	std::vector<LwEntResidue> residues(s.residues.size());

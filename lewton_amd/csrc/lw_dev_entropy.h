@@ -43,6 +43,11 @@ typedef __attribute__((address_space(3))) uint16_t *LwEntDigits;
 #define LW_ENT_LANES(d, cnt) for (uint32_t d = LW_ENT_LANE(), once_ = 1; once_; once_ = 0)
 #define LW_LV(type, name) type name
 #define LW_L(name) name
+typedef __attribute__((address_space(3))) uint8_t *LwEntFlags;
+// posts on lanes: post i = h * 64 + lane for h = 0 (and h = 1 when there are 65 posts); LW_PV / LW_P: a value per post
+#define LW_ENT_POSTS(i, h, F) _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) if (h * 64u < (F)) for (uint32_t i = h * 64u + LW_ENT_LANE(), once_ = 1; once_; once_ = 0)
+#define LW_PV(type, name) type name[2]
+#define LW_P(name) name[h]
 #else
 typedef float *LwEntAcc;
 typedef uint32_t *LwEntPosts;
@@ -51,6 +56,10 @@ typedef uint16_t *LwEntDigits;
 #define LW_ENT_LANES(d, cnt) for (uint32_t d = 0; d < (cnt); d++)
 #define LW_LV(type, name) type name[64]
 #define LW_L(name) name[d]
+typedef uint8_t *LwEntFlags;
+#define LW_ENT_POSTS(i, h, F) for (uint32_t h = 0; h < 1u; h++) for (uint32_t i = 0; i < (F); i++)
+#define LW_PV(type, name) type name[LW_MAX_POSTS]
+#define LW_P(name) name[i]
 #endif
 // The image and the packets are read-only for the kernel: on the device they are addressed through the CONSTANT address
 // space, so every wave-uniform look-up is a scalar load whatever the compiler can or cannot prove about stores in between
@@ -98,17 +107,17 @@ struct alignas(16) LwEntBook { // 16 bytes, read with one load
 };
 #define LW_ENT_SHAPE(lut_bits, dims, single) ((uint32_t)(lut_bits) | (uint32_t)(dims) << 8 | (uint32_t)(uint16_t)(single) << 16)
 
-struct LwEntFloor {
-	uint8_t multiplier, range_bits, n_part, F;
-	uint32_t range;
-	uint8_t partition_class[32];
-	uint8_t class_dim[16], class_sub[16], class_master[16];
-	int16_t sub_books[16][8];
-	uint8_t lo_idx[LW_MAX_POSTS], hi_idx[LW_MAX_POSTS], sorted_idx[LW_MAX_POSTS];
-	uint8_t pad0;
+struct LwEntFloor { // (dwords throughout: see LwEntBook)
+	uint32_t multiplier, range_bits, n_part, F, range;
+	uint32_t n_levels;               // depth of the posts' dependence on their neighbours (LW_ENT_POST_LEVEL)
+	uint32_t part[32];               // per partition: class_dim | subclass bits << 8 | master book << 16 | class << 24
+	int32_t sub_books[16 * 8];       // [class][subclass value]
+	// per post i in header order: its neighbours lo | hi << 8 (audio.rs:391-435), level << 16: 0 for posts 0 and 1, else
+	// 1 + the larger level of its neighbours (posts of one level do not depend on each other: one lane each, level by
+	// level); << 24: the header index of the i-th post in ASCENDING-x order (the order of the record)
+	uint32_t post[LW_MAX_POSTS];
 	uint32_t dx[LW_MAX_POSTS];
-	uint32_t pad1;
-	uint64_t adx_magic[LW_MAX_POSTS];
+	uint32_t magic_lo[LW_MAX_POSTS], magic_hi[LW_MAX_POSTS];
 };
 
 struct LwEntResidue {
@@ -164,7 +173,10 @@ struct LwEntPacket { // 16 bytes
 	uint32_t pad1;
 };
 
-#define LW_ENT_POSTS_BYTES ((4u * LW_MAX_POSTS + 15u) & ~15u)
+// posts scratch: u32 y[LW_MAX_POSTS] + one dump entry, then u8 step-2 flags [LW_MAX_POSTS] + one dump entry
+#define LW_ENT_Y_DUMP LW_MAX_POSTS
+#define LW_ENT_FLAGS_OFF (4u * (LW_MAX_POSTS + 1u))
+#define LW_ENT_POSTS_BYTES ((LW_ENT_FLAGS_OFF + LW_MAX_POSTS + 1u + 15u) & ~15u)
 
 // A codebook as the decode loops hold it: everything in registers, fetched with ONE load of the 16-byte table entry.  (Read
 // field by field through a pointer, every codeword paid 3-4 dependent table accesses before its own look-up: the compiler
@@ -337,21 +349,22 @@ LW_HD bool lw_ent_floor_decode(const LwEntTables &T, const LW_K LwEntFloor &fl, 
 	if (!r.read(1, nonzero) || !nonzero)
 		return false;
 	uint32_t k = 0, v;
-	if (!r.read(fl.range_bits, v))
+	const uint32_t range_bits = fl.range_bits, n_part = fl.n_part;
+	if (!r.read(range_bits, v))
 		return false;
 	y[k++] = v;
-	if (!r.read(fl.range_bits, v))
+	if (!r.read(range_bits, v))
 		return false;
 	y[k++] = v;
-	for (uint32_t p = 0; p < fl.n_part; p++) {
-		const uint32_t c = fl.partition_class[p];
-		const uint32_t cdim = fl.class_dim[c], cbits = fl.class_sub[c];
+	for (uint32_t p = 0; p < n_part; p++) {
+		const uint32_t pt = fl.part[p];
+		const uint32_t cdim = pt & 0xffu, cbits = (pt >> 8) & 0xffu, c = pt >> 24;
 		const uint32_t csub = (1u << cbits) - 1u;
 		uint32_t cval = 0;
-		if (cbits && !r.code(lw_ent_book(T, fl.class_master[c]), cval))
+		if (cbits && !r.code(lw_ent_book(T, (pt >> 16) & 0xffu), cval))
 			return false;
 		for (uint32_t d = 0; d < cdim; d++) {
-			const int book = fl.sub_books[c][cval & csub];
+			const int32_t book = fl.sub_books[c * 8u + (cval & csub)];
 			cval >>= cbits;
 			v = 0;
 			if (book >= 0 && !r.code(lw_ent_book(T, (uint32_t)book), v))
@@ -364,91 +377,103 @@ LW_HD bool lw_ent_floor_decode(const LwEntTables &T, const LW_K LwEntFloor &fl, 
 
 // audio.rs:354-367 with wrapping u32 arithmetic; the division by the header constant adx is a multiplication by its
 // precomputed 2^64 / adx + 1 (exact for every 32-bit dividend)
-LW_HD uint32_t lw_ent_render_point(uint32_t y0, uint32_t y1, uint32_t dx, uint64_t adx_magic)
+LW_HD uint32_t lw_ent_render_point(uint32_t y0, uint32_t y1, uint32_t dx, uint32_t magic_lo, uint32_t magic_hi)
 {
 	const int32_t dy = (int32_t)(y1 - y0);
 	const uint32_t ady = dy < 0 ? 0u - (uint32_t)dy : (uint32_t)dy;
 	const uint32_t num = ady * dx;
 	// (num * magic) >> 64 in 64-bit pieces: adx >= 2 (a post lies strictly between its neighbours), so magic <= 2^63 + 1
-	const uint64_t hi = (uint64_t)num * (adx_magic >> 32), lo = (uint64_t)num * (adx_magic & 0xffffffffu);
+	const uint64_t hi = (uint64_t)num * magic_hi, lo = (uint64_t)num * magic_lo;
 	const uint32_t off = (uint32_t)((hi + (lo >> 32)) >> 32);
 	return dy < 0 ? y0 - off : y0 + off;
 }
 
-// audio.rs:391-435 -> device record: per post in ascending-x order, (final_y * multiplier) | active flag.  y is updated in
-// place (a post's neighbours precede it in header order).
+// audio.rs:391-435 -> device record: per post in ascending-x order, (final_y * multiplier) | active flag.  One lane per
+// post, level by level: a post's neighbours lie on lower levels, the posts of one level are independent of each other
+// (the serial loop over the posts cost the device more than their decoding).  y is updated in place.
 LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t *rec)
 {
-	const uint32_t F = fl.F, range = fl.range;
-	uint32_t act0 = 3u, act1 = 0u, act2 = 0u; // step2 flags of posts 0-31, 32-63, 64
-	for (uint32_t i = 2; i < F; i++) {
-		const uint32_t lo = fl.lo_idx[i], hi = fl.hi_idx[i];
-		const int32_t predicted = (int32_t)lw_ent_render_point(y[lo], y[hi], fl.dx[i], fl.adx_magic[i]);
-		const int32_t val = (int32_t)y[i];
-		const int32_t highroom = (int32_t)(range - (uint32_t)predicted);
-		const int32_t lowroom = predicted;
-		const int32_t room = (int32_t)((uint32_t)(highroom < lowroom ? highroom : lowroom) * 2u);
-		if (val > 0) {
-			const uint32_t idx[3] = {lo, hi, i};
-			for (int q = 0; q < 3; q++) {
-				const uint32_t j = idx[q];
-				if (j < 32)
-					act0 |= 1u << j;
-				else if (j < 64)
-					act1 |= 1u << (j - 32);
-				else
-					act2 |= 1u;
+	const uint32_t F = fl.F, range = fl.range, n_levels = fl.n_levels, mult = fl.multiplier;
+	LwEntFlags flag = (LwEntFlags)y + LW_ENT_FLAGS_OFF;
+	LW_PV(uint32_t, pk);
+	LW_PV(uint32_t, dxv);
+	LW_PV(uint32_t, mlo);
+	LW_PV(uint32_t, mhi);
+	LW_PV(int32_t, val);
+	LW_ENT_POSTS(i, h, F) {
+		const uint32_t ii = i < F ? i : F - 1u; // (device: the lanes beyond the last post repeat its work; no lane is masked off)
+		LW_P(pk) = fl.post[ii];
+		LW_P(dxv) = fl.dx[ii];
+		LW_P(mlo) = fl.magic_lo[ii];
+		LW_P(mhi) = fl.magic_hi[ii];
+		LW_P(val) = (int32_t)y[ii];
+		flag[i < F ? i : LW_ENT_Y_DUMP] = i < 2u ? 1u : 0u;
+	}
+	for (uint32_t lvl = 1; lvl <= n_levels; lvl++) {
+		LW_ENT_POSTS(i, h, F) {
+			const uint32_t p = LW_P(pk);
+			const uint32_t lo = p & 0xffu, hi = (p >> 8) & 0xffu;
+			const bool mine = i < F && ((p >> 16) & 0xffu) == lvl;
+			const int32_t predicted = (int32_t)lw_ent_render_point(y[lo], y[hi], LW_P(dxv), LW_P(mlo), LW_P(mhi));
+			const int32_t v = LW_P(val);
+			const int32_t highroom = (int32_t)(range - (uint32_t)predicted);
+			const int32_t lowroom = predicted;
+			const int32_t room = (int32_t)((uint32_t)(highroom < lowroom ? highroom : lowroom) * 2u);
+			uint32_t fy = (uint32_t)predicted;
+			if (v > 0) {
+				if (v >= room) {
+					fy = highroom > lowroom ? (uint32_t)predicted + (uint32_t)v - (uint32_t)lowroom
+					                        : (uint32_t)predicted - (uint32_t)v + (uint32_t)highroom - 1u;
+				} else {
+					const int32_t t = (v % 2 == 1) ? (int32_t)(0u - (uint32_t)v - 1u) : v;
+					fy = (uint32_t)predicted + (uint32_t)(t >> 1);
+				}
 			}
-			uint32_t fy;
-			if (val >= room) {
-				fy = highroom > lowroom ? (uint32_t)predicted + (uint32_t)val - (uint32_t)lowroom
-				                        : (uint32_t)predicted - (uint32_t)val + (uint32_t)highroom - 1u;
-			} else {
-				const int32_t t = (val % 2 == 1) ? (int32_t)(0u - (uint32_t)val - 1u) : val;
-				fy = (uint32_t)predicted + (uint32_t)(t >> 1);
-			}
-			y[i] = fy;
-		} else {
-			y[i] = (uint32_t)predicted;
+			y[mine ? i : LW_ENT_Y_DUMP] = fy;
+			// step 2 flags of the post and of both neighbours (a lane without a mark to set writes the dump entry)
+			const bool marks = mine && v > 0;
+			flag[marks ? lo : LW_ENT_Y_DUMP] = 1u;
+			flag[marks ? hi : LW_ENT_Y_DUMP] = 1u;
+			flag[marks ? i : LW_ENT_Y_DUMP] = 1u;
 		}
 	}
-	for (uint32_t sidx = 0; sidx < F; sidx++) {
-		const uint32_t i = fl.sorted_idx[sidx];
-		const uint32_t fy = y[i] < range - 1u ? y[i] : range - 1u; // :431-433
-		const uint32_t on = i < 32 ? (act0 >> i) & 1u : i < 64 ? (act1 >> (i - 32)) & 1u : act2 & 1u;
-		rec[sidx] = (uint16_t)(((fy * fl.multiplier) & 0xffu) | (on ? LW_POST_ACTIVE : 0u));
+	LW_ENT_POSTS(i, h, F) { // i: position in ascending-x order
+		const uint32_t src = LW_P(pk) >> 24;
+		const uint32_t fy = y[src] < range - 1u ? y[src] : range - 1u; // :431-433
+		const uint32_t on = flag[src];
+		rec[i < F ? i : F - 1u] = (uint16_t)(((fy * mult) & 0xffu) | (on ? LW_POST_ACTIVE : 0u));
 	}
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // The steady state of a partition's run of codewords, by hand (gfx950): per codeword ~15 scalar instructions (the scalar unit
 // paces this kernel: one wave per packet, four packets per SIMD), 4 vector instructions, one table look-up, one row load,
-// one LDS read-modify-write of the PREVIOUS codeword's vector -- what the compiler makes of the same loop in C++ is ~50 + 19.
-//   window refill (every 32 bits) | entry = lut[window & mask] | add the pending vector | link -> second-level entry |
-//   bounds (left -= len borrows: the code runs past the end) | window >>= len | row load for this codeword
+// one LDS read-modify-write -- what the compiler makes of the same loop in C++ is ~50 + 19.
+//   window refill (every 32 bits) | entry = lut[window & mask] | add the vector of the codeword before the last one |
+//   link -> second-level entry | bounds (left -= len borrows: the code runs past the end) | window >>= len | row load
+// The vectors are added TWO codewords behind the decoder (two pending slots, v60/v61 and v62/v63, used in turn: the loop
+// body exists twice): a row load has two look-ups to arrive in; one behind, every codeword waited ~350 cycles for its
+// predecessor's row.  Additions to one accumulator keep their order (the slots are a FIFO; within a run no two codewords
+// touch the same element).  The statement starts and ends with nothing pending and no load outstanding.
 // Returns 0: `todo` codewords done (todo = 0); 1: the codeword at the head of the window needs the tree (entry in `e`: length
-// 0), nothing of it consumed, the pending vector is added; 2: the codeword runs past the end of the packet (pending added).
-// On return no load is outstanding (pv is valid).  s[84:87] and v63 are scratch: the window is shifted as a 64-bit pair.
+// 0), nothing of it consumed; 2: the codeword runs past the end of the packet.  `at` is not changed: the caller advances it
+// by inc per codeword done.  Scratch: s[84:87] (the window is shifted as a 64-bit pair), v58-v63.
 __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader &r, const LW_K uint32_t *lut, const LW_K float *vq,
-		uint32_t lut_mask, uint32_t lut_bits, uint32_t &todo, uint32_t &e, uint32_t &pat, float &pv, uint32_t &at, uint32_t inc,
-		uint32_t row, uint32_t vdims4)
+		uint32_t lut_mask, uint32_t lut_bits, uint32_t &todo, uint32_t &e, uint32_t at, uint32_t inc, uint32_t row, uint32_t vdims4,
+		uint32_t dump)
 {
 	uint32_t st, t0, t1;
 	uint32_t neg = LW_ENT_SCALAR(0u - todo); // (wave-uniform like everything scalar here; the compiler keeps this one in a vector register)
-	// The statement with the loop returns scalars only: one that also returned vector registers would be divergent as a
-	// whole to the compiler's analysis, and the reader and every branch behind it would move to vector registers and exec
-	// masks.  So the per-lane values it changes go in as inputs, and an empty statement right behind it hands them back as
-	// outputs of the same registers (both statements name their registers in a comment: tests/test_entropy_asm_pairs.py
-	// checks the generated code).
-	// (fresh values first, used by the two statements below and by nothing else: a register the compiler shares with another
-	// use of the same value -- the constant 0.0f of a cleared pending vector -- must not be modified behind its back)
-	asm volatile("" : "+v"(pat), "+v"(pv), "+v"(at));
-	asm volatile("; lw_ent_run in %[pat] %[pv] %[at]\n"
-	             "s_mov_b64 s[84:85], %[win]\n"
+	asm volatile("s_mov_b64 s[84:85], %[win]\n"
 	             "s_mov_b32 s87, 0\n"
-	             "11:\n" // ---- next codeword
+	             "v_mov_b32 v58, %[at]\n"
+	             "v_mov_b32 v60, %[dump]\n"
+	             "v_mov_b32 v61, 0\n"
+	             "v_mov_b32 v62, %[dump]\n"
+	             "v_mov_b32 v63, 0\n"
+	             "79:\n" // ---- a codeword through slot A (v60 = accumulator address, v61 = value)
 	             "s_cmp_lt_u32 %[have], 32\n"
-	             "s_cbranch_scc0 12f\n"
+	             "s_cbranch_scc0 602f\n"
 	             "s_mov_b32 s86, %[nxt]\n"
 	             "s_lshl_b64 s[86:87], s[86:87], %[have]\n"
 	             "s_or_b64 s[84:85], s[84:85], s[86:87]\n"
@@ -456,34 +481,34 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 	             "s_load_dword %[nxt], %[w], %[wo]\n"
 	             "s_add_u32 %[wo], %[wo], 4\n"
 	             "s_mov_b32 s87, 0\n"
-	             "12:\n"
+	             "602:\n"
 	             "s_and_b32 %[t0], s84, %[mask]\n"
 	             "s_lshl_b32 %[t0], %[t0], 2\n"
 	             "s_load_dword %[e], %[lut], %[t0]\n"
-	             "ds_read_b32 v63, %[pat]\n"
-	             "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-	             "v_add_f32 v63, v63, %[pv]\n"
-	             "ds_write_b32 %[pat], v63\n"
+	             "ds_read_b32 v59, v60\n"
+	             "s_waitcnt vmcnt(1) lgkmcnt(0)\n"
+	             "v_add_f32 v59, v59, v61\n"
+	             "ds_write_b32 v60, v59\n"
 	             "s_sub_u32 %[t0], %[e], 0x1000000\n"
 	             "s_cmp_ge_u32 %[t0], 0x7f000000\n"
-	             "s_cbranch_scc1 14f\n"
-	             "13:\n" // ---- an ordinary entry: (length << 24) | entry number
+	             "s_cbranch_scc1 604f\n"
+	             "603:\n"
 	             "s_lshr_b32 %[t0], %[e], 24\n"
 	             "s_sub_u32 %[left], %[left], %[t0]\n"
-	             "s_cbranch_scc1 16f\n"
+	             "s_cbranch_scc1 606f\n"
 	             "s_lshr_b64 s[84:85], s[84:85], %[t0]\n"
 	             "s_sub_u32 %[have], %[have], %[t0]\n"
-	             "v_mad_u32_u24 v63, %[e], %[vd4], %[row]\n"
-	             "global_load_dword %[pv], v63, %[vq]\n"
-	             "v_mov_b32 %[pat], %[at]\n"
-	             "v_add_u32 %[at], %[at], %[inc]\n"
+	             "v_mad_u32_u24 v59, %[e], %[vd4], %[row]\n"
+	             "global_load_dword v61, v59, %[vq]\n"
+	             "v_mov_b32 v60, v58\n"
+	             "v_add_u32 v58, v58, %[inc]\n"
 	             "s_add_u32 %[neg], %[neg], 1\n"
-	             "s_cbranch_scc0 11b\n"
+	             "s_cbranch_scc0 80f\n"
 	             "s_mov_b32 %[st], 0\n"
-	             "s_branch 19f\n"
-	             "14:\n" // ---- a link to a second-level table, or length 0
+	             "s_branch 71f\n"
+	             "604:\n" // a link to a second-level table, or length 0
 	             "s_bitcmp1_b32 %[e], 31\n"
-	             "s_cbranch_scc0 15f\n"
+	             "s_cbranch_scc0 605f\n"
 	             "s_bfe_u32 %[t0], %[e], 0x70018\n"
 	             "s_lshr_b32 %[t1], s84, %[bits]\n"
 	             "s_bfm_b32 %[t0], %[t0], 0\n"
@@ -494,21 +519,101 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 	             "s_load_dword %[e], %[lut], %[t0]\n"
 	             "s_waitcnt lgkmcnt(0)\n"
 	             "s_cmp_lt_u32 %[e], 0x1000000\n"
-	             "s_cbranch_scc0 13b\n"
-	             "15:\n"
+	             "s_cbranch_scc0 603b\n"
+	             "605:\n"
 	             "s_mov_b32 %[st], 1\n"
-	             "s_branch 19f\n"
-	             "16:\n"
+	             "v_mov_b32 v60, %[dump]\n"
+	             "s_branch 71f\n"
+	             "606:\n"
 	             "s_mov_b32 %[st], 2\n"
-	             "19:\n"
-	             "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+	             "v_mov_b32 v60, %[dump]\n"
+	             "s_branch 71f\n"
+	             "80:\n" // ---- a codeword through slot B (v62, v63)
+	             "s_cmp_lt_u32 %[have], 32\n"
+	             "s_cbranch_scc0 622f\n"
+	             "s_mov_b32 s86, %[nxt]\n"
+	             "s_lshl_b64 s[86:87], s[86:87], %[have]\n"
+	             "s_or_b64 s[84:85], s[84:85], s[86:87]\n"
+	             "s_add_u32 %[have], %[have], 32\n"
+	             "s_load_dword %[nxt], %[w], %[wo]\n"
+	             "s_add_u32 %[wo], %[wo], 4\n"
+	             "s_mov_b32 s87, 0\n"
+	             "622:\n"
+	             "s_and_b32 %[t0], s84, %[mask]\n"
+	             "s_lshl_b32 %[t0], %[t0], 2\n"
+	             "s_load_dword %[e], %[lut], %[t0]\n"
+	             "ds_read_b32 v59, v62\n"
+	             "s_waitcnt vmcnt(1) lgkmcnt(0)\n"
+	             "v_add_f32 v59, v59, v63\n"
+	             "ds_write_b32 v62, v59\n"
+	             "s_sub_u32 %[t0], %[e], 0x1000000\n"
+	             "s_cmp_ge_u32 %[t0], 0x7f000000\n"
+	             "s_cbranch_scc1 624f\n"
+	             "623:\n"
+	             "s_lshr_b32 %[t0], %[e], 24\n"
+	             "s_sub_u32 %[left], %[left], %[t0]\n"
+	             "s_cbranch_scc1 626f\n"
+	             "s_lshr_b64 s[84:85], s[84:85], %[t0]\n"
+	             "s_sub_u32 %[have], %[have], %[t0]\n"
+	             "v_mad_u32_u24 v59, %[e], %[vd4], %[row]\n"
+	             "global_load_dword v63, v59, %[vq]\n"
+	             "v_mov_b32 v62, v58\n"
+	             "v_add_u32 v58, v58, %[inc]\n"
+	             "s_add_u32 %[neg], %[neg], 1\n"
+	             "s_cbranch_scc0 79b\n"
+	             "s_mov_b32 %[st], 0\n"
+	             "s_branch 72f\n"
+	             "624:\n" // a link to a second-level table, or length 0
+	             "s_bitcmp1_b32 %[e], 31\n"
+	             "s_cbranch_scc0 625f\n"
+	             "s_bfe_u32 %[t0], %[e], 0x70018\n"
+	             "s_lshr_b32 %[t1], s84, %[bits]\n"
+	             "s_bfm_b32 %[t0], %[t0], 0\n"
+	             "s_and_b32 %[t1], %[t1], %[t0]\n"
+	             "s_and_b32 %[t0], %[e], 0xffffff\n"
+	             "s_add_u32 %[t0], %[t0], %[t1]\n"
+	             "s_lshl_b32 %[t0], %[t0], 2\n"
+	             "s_load_dword %[e], %[lut], %[t0]\n"
+	             "s_waitcnt lgkmcnt(0)\n"
+	             "s_cmp_lt_u32 %[e], 0x1000000\n"
+	             "s_cbranch_scc0 623b\n"
+	             "625:\n"
+	             "s_mov_b32 %[st], 1\n"
+	             "v_mov_b32 v62, %[dump]\n"
+	             "s_branch 72f\n"
+	             "626:\n"
+	             "s_mov_b32 %[st], 2\n"
+	             "v_mov_b32 v62, %[dump]\n"
+	             "s_branch 72f\n"
+	             "71:\n" // ---- leaving behind a slot-A codeword: B is the older one
+	             "s_waitcnt vmcnt(0)\n"
+	             "ds_read_b32 v59, v62\n"
+	             "s_waitcnt lgkmcnt(0)\n"
+	             "v_add_f32 v59, v59, v63\n"
+	             "ds_write_b32 v62, v59\n"
+	             "ds_read_b32 v59, v60\n"
+	             "s_waitcnt lgkmcnt(0)\n"
+	             "v_add_f32 v59, v59, v61\n"
+	             "ds_write_b32 v60, v59\n"
+	             "s_branch 73f\n"
+	             "72:\n" // ---- leaving behind a slot-B codeword: A is the older one
+	             "s_waitcnt vmcnt(0)\n"
+	             "ds_read_b32 v59, v60\n"
+	             "s_waitcnt lgkmcnt(0)\n"
+	             "v_add_f32 v59, v59, v61\n"
+	             "ds_write_b32 v60, v59\n"
+	             "ds_read_b32 v59, v62\n"
+	             "s_waitcnt lgkmcnt(0)\n"
+	             "v_add_f32 v59, v59, v63\n"
+	             "ds_write_b32 v62, v59\n"
+	             "73:\n"
+	             "s_waitcnt lgkmcnt(0)\n"
 	             "s_mov_b64 %[win], s[84:85]\n"
 	             : [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),
 	               [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1)
-	             : [w] "s"(r.w), [lut] "s"(lut), [vq] "s"(vq), [mask] "s"(lut_mask), [bits] "s"(lut_bits), [inc] "v"(inc), [row] "v"(row),
-	               [vd4] "v"(vdims4), [pat] "v"(pat), [pv] "v"(pv), [at] "v"(at)
-	             : "s84", "s85", "s86", "s87", "v63", "scc", "memory");
-	asm volatile("; lw_ent_run out %0 %1 %2" : "+v"(pat), "+v"(pv), "+v"(at));
+	             : [w] "s"(r.w), [lut] "s"(lut), [vq] "s"(vq), [mask] "s"(lut_mask), [bits] "s"(lut_bits), [at] "v"(at), [inc] "v"(inc),
+	               [row] "v"(row), [vd4] "v"(vdims4), [dump] "v"(dump)
+	             : "s84", "s85", "s86", "s87", "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory");
 	todo = 0u - neg;
 	return st;
 }
@@ -519,29 +624,36 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 // belongs to channel i % ch, bin i / ch) -- every element receives the same additions in the same order as in the
 // reference's interleaved buffer.  `out` holds zeros on entry.  `cls` = scratch for nch * (parts + cpc) digits.
 //
-// The additions run ONE CODEWORD BEHIND the decoder: a codeword's vector row is requested as soon as its entry number is
-// known, and added (LwEntPend::flush) after the NEXT codeword's table look-up has been started -- the look-up chain
-// (window -> table -> length -> window) is the only thing a packet cannot overlap, everything else hides under it.
-// Every addition reads the accumulator, also the first one to an element (0.0f + e, as the reference's += on its zeroed
-// vector).  On the device all 64 lanes take part in every flush without masking: a lane beyond the codeword's dimension
-// adds to its own dump slot behind the accumulators.
+// The additions run BEHIND the decoder: a codeword's vector row is requested as soon as its entry number is known, and
+// added after the next codeword's table look-up has been started (LwEntPend, one behind: the C++ form of the loop, which the
+// host runs for every codeword and the device for the rare ones; lw_ent_run, the device's steady state, stays two behind)
+// -- the look-up chain (window -> table -> length -> window) is the only thing a packet cannot overlap, everything else
+// hides under it.  Every addition reads the accumulator, also the first one to an element (0.0f + e, as the reference's +=
+// on its zeroed vector).  On the device all 64 lanes take part in every addition without masking: a lane beyond the
+// codeword's dimension adds to its own dump slot behind the accumulators.
 struct LwEntPend {
 	LW_LV(uint32_t, at); // this lane's accumulator (LW_ENT_AT)
 	LW_LV(float, v);
+	LW_LV(uint32_t, dump); // device: this lane's dump slot
 	uint32_t n;          // host: elements pending
-	LW_HD void clear(LwEntAcc out, uint32_t dump)
+	LW_HD void clear(LwEntAcc out, uint32_t dump_el)
 	{
 		n = 0;
 		LW_ENT_LANES(d, 0u) {
-			LW_L(at) = LW_ENT_AT(out, dump + d);
+			LW_L(dump) = LW_ENT_AT(out, dump_el + d);
+			LW_L(at) = LW_L(dump);
 			LW_L(v) = 0.0f;
 		}
 	}
-	// (a flush is always followed by a stash or by the end of the residue: nothing is added twice)
+	// (nothing is added twice: a flushed vector's place is taken by the dump slot)
 	LW_HD void flush(LwEntAcc out)
 	{
-		LW_ENT_LANES(d, n)
+		LW_ENT_LANES(d, n) {
 			LW_ENT_ACC(out, LW_L(at)) = LW_ENT_ACC(out, LW_L(at)) + LW_L(v);
+#if defined(__HIP_DEVICE_COMPILE__)
+			LW_L(at) = LW_L(dump);
+#endif
+		}
 		n = 0;
 	}
 };
@@ -649,9 +761,12 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 						while (todo) {
 							uint32_t e;
 #if defined(__HIP_DEVICE_COMPILE__)
-							// the steady state by hand (lw_ent_run): it comes back for what is rare -- a code beyond the two table
-							// levels, the end of the packet
-							const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, e, pend.at, pend.v, at, inc, row, vdims4);
+							// the steady state by hand (lw_ent_run, which starts and ends with nothing pending): it comes back for
+							// what is rare -- a code beyond the two table levels, the end of the packet
+							pend.flush(out);
+							const uint32_t before = todo;
+							const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, e, at, inc, row, vdims4, pend.dump);
+							at += inc * (before - todo);
 							if (st == 0u)
 								break;
 							if (st == 2u) {

@@ -13,7 +13,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("/tmp/ep/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("k_entropy"):
+        if "k_entropy" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 pm = {k: sum(v) / len(v) for k, v in agg.items()}
 w = pm.get("SQ_WAVES", 1)
