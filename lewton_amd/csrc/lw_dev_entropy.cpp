@@ -159,6 +159,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	std::vector<LwEntResidue> residues(s.residues.size());
 	std::vector<uint16_t> digits;
 	std::vector<LwEntRun> runs;
+	std::vector<uint32_t> run_book; // the book of every run record, 0xFFFFFFFF: none
 	size_t cls_bytes = 0;
 	for (size_t ri = 0; ri < s.residues.size(); ri++) {
 		LwEntResidue &r = residues[ri];
@@ -187,6 +188,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		r.psize = rs.partition_size;
 		r.runs_off = (uint32_t)runs.size();
 		runs.resize(runs.size() + (size_t)rs.classifications * 8);
+		run_book.resize(runs.size(), 0xFFFFFFFFu);
 		for (unsigned c = 0; c < rs.classifications; c++) {
 			r.vals_used[c] = rs.books[c].vals_used;
 			r.used_any |= rs.books[c].vals_used;
@@ -195,7 +197,6 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 				std::memset(&run, 0, sizeof(run));
 				run.shape = LW_ENT_SHAPE(0, 0, -2);
 				run.nodes_off = 0xFFFFFFFFu;
-				run.book = 0xFFFFFFFFu;
 				if (!(rs.books[c].vals_used & (1u << p)))
 					continue;
 				const unsigned bi = rs.books[c].val_i[p];
@@ -216,7 +217,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 				run.count = rs.partition_size / cb.dims;
 				run.step = rs.type == 0 ? rs.partition_size / cb.dims : 1u;
 				run.adv = rs.type == 0 ? 1u : cb.dims;
-				run.book = bi; // (the book's table entries are filled in below)
+				run_book[r.runs_off + c * 8 + p] = bi; // (the book's table entries are filled in below)
 			}
 		}
 		if (!rs.class_digits.empty()) {
@@ -269,14 +270,20 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 			vq.insert(vq.end(), cb.vq.begin(), cb.vq.end());
 		}
 	}
-	for (LwEntRun &run : runs) {
-		if (run.book == 0xFFFFFFFFu)
+	for (size_t k = 0; k < runs.size(); k++) {
+		if (run_book[k] == 0xFFFFFFFFu)
 			continue; // a (class, pass) without a book
-		const LwEntBook &b = books[run.book];
-		run.lut_off = b.lut_off;
-		run.vq_off = b.vq_off;
+		LwEntRun &run = runs[k];
+		const LwEntBook &b = books[run_book[k]];
+		run.lut_off = b.lut_off * 4;
+		run.vq_off = b.vq_off * 4;
 		run.nodes_off = b.nodes_off;
 		run.shape = b.shape;
+		const unsigned dims = (b.shape >> 8) & 0xffu;
+		if ((int16_t)(b.shape >> 16) == -1 && run.count >= 1 && dims)
+			for (unsigned d = 1; d <= 8; d++)
+				if (dims % d == 0)
+					run.fast |= 1u << d;
 	}
 	lut.push_back(0);
 	vq.push_back(0.0f);

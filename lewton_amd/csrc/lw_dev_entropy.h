@@ -132,11 +132,12 @@ struct LwEntResidue {
 // One (residue, class, pass): everything a partition's run of codewords needs, fetched with ONE 32-byte load (through the
 // residue's class table and the book table it took four dependent accesses and a division per run)
 struct alignas(16) LwEntRun {
-	uint32_t lut_off, vq_off, shape, nodes_off; // as LwEntBook
+	uint32_t lut_off, vq_off; // as LwEntBook, but in BYTES
+	uint32_t shape, nodes_off; // as LwEntBook
 	uint32_t count; // codewords per partition: psize / dims
 	uint32_t step;  // element stride inside a codeword's vector: type 0 psize / dims, types 1/2 1 (audio.rs:587-618)
 	uint32_t adv;   // elements between the starts of consecutive codewords: type 0 1, types 1/2 dims
-	uint32_t book;  // (the book's number)
+	uint32_t fast;  // bit k (1..8): an ordinary book with count >= 1 whose dimension is a multiple of k (lw_ent_range)
 };
 
 struct LwEntMode {
@@ -619,6 +620,182 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// One codeword of lw_ent_range through pending slot P (accumulator address) / PV (value): see lw_ent_run for the steps.
+// NEXT: the other slot's step; PH_DONE: the slot the next partition starts with; PH_EXIT: drain order when leaving here
+// (this slot is empty then: the other one first).
+#define LW_ENT_RANGE_STEP(P, PV, NEXT, PH_DONE, PH_EXIT)                                                              \
+	"s_cmp_lt_u32 %[have], 32\n"                                                                                      \
+	"s_cbranch_scc0 " P "2f\n"                                                                                        \
+	"s_mov_b32 s66, %[nxt]\n"                                                                                         \
+	"s_lshl_b64 s[66:67], s[66:67], %[have]\n"                                                                        \
+	"s_or_b64 s[64:65], s[64:65], s[66:67]\n"                                                                         \
+	"s_add_u32 %[have], %[have], 32\n"                                                                                \
+	"s_load_dword %[nxt], %[w], %[wo]\n"                                                                              \
+	"s_add_u32 %[wo], %[wo], 4\n"                                                                                     \
+	"s_mov_b32 s67, 0\n" P "2:\n"                                                                                     \
+	"s_and_b32 %[t0], s64, s80\n"                                                                                    \
+	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
+	"s_load_dword %[e], s[76:77], %[t0]\n"                                                                            \
+	"ds_read_b32 v59, v" P "\n"                                                                                       \
+	"s_waitcnt vmcnt(1) lgkmcnt(0)\n"                                                                                 \
+	"v_add_f32 v59, v59, v" PV "\n"                                                                                   \
+	"ds_write_b32 v" P ", v59\n"                                                                                      \
+	"s_sub_u32 %[t0], %[e], 0x1000000\n"                                                                              \
+	"s_cmp_ge_u32 %[t0], 0x7f000000\n"                                                                                \
+	"s_cbranch_scc1 " P "4f\n" P "3:\n"                                                                               \
+	"s_lshr_b32 %[t0], %[e], 24\n"                                                                                    \
+	"s_sub_u32 %[left], %[left], %[t0]\n"                                                                             \
+	"s_cbranch_scc1 " P "6f\n"                                                                                        \
+	"s_lshr_b64 s[64:65], s[64:65], %[t0]\n"                                                                          \
+	"s_sub_u32 %[have], %[have], %[t0]\n"                                                                             \
+	"v_mad_u32_u24 v59, %[e], v54, v55\n"                                                                             \
+	"global_load_dword v" PV ", v59, s[78:79]\n"                                                                      \
+	"v_mov_b32 v" P ", v58\n"                                                                                         \
+	"v_add_u32 v58, v58, v56\n"                                                                                       \
+	"s_add_u32 %[neg], %[neg], 1\n"                                                                                   \
+	"s_cbranch_scc0 " NEXT "\n"                                                                                       \
+	"s_mov_b32 %[ph], " PH_DONE "\n"                                                                                  \
+	"s_branch 28f\n" P "4:\n"                                                                                         \
+	"s_bitcmp1_b32 %[e], 31\n"                                                                                        \
+	"s_cbranch_scc0 " P "5f\n"                                                                                        \
+	"s_bfe_u32 %[t0], %[e], 0x70018\n"                                                                                \
+	"s_lshr_b32 %[t1], s64, s81\n"                                                                                   \
+	"s_bfm_b32 %[t0], %[t0], 0\n"                                                                                     \
+	"s_and_b32 %[t1], %[t1], %[t0]\n"                                                                                 \
+	"s_and_b32 %[t0], %[e], 0xffffff\n"                                                                               \
+	"s_add_u32 %[t0], %[t0], %[t1]\n"                                                                                 \
+	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
+	"s_load_dword %[e], s[76:77], %[t0]\n"                                                                            \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"s_cmp_lt_u32 %[e], 0x1000000\n"                                                                                  \
+	"s_cbranch_scc0 " P "3b\n" P "5:\n"                                                                               \
+	"s_mov_b32 %[st], 1\n"                                                                                            \
+	"v_mov_b32 v" P ", %[dump]\n"                                                                                     \
+	"s_mov_b32 %[ph], " PH_EXIT "\n"                                                                                  \
+	"s_branch 70f\n" P "6:\n"                                                                                         \
+	"s_mov_b32 %[st], 2\n"                                                                                            \
+	"v_mov_b32 v" P ", %[dump]\n"                                                                                     \
+	"s_mov_b32 %[ph], " PH_EXIT "\n"                                                                                  \
+	"s_branch 70f\n"
+
+// A RANGE of partitions of one vector in one pass, by hand: per partition the class digit (LDS), the test whether the class
+// has a book in this pass, the (residue, class, pass) record, the lanes' accumulator addresses, then the run of codewords as
+// in lw_ent_run -- with the two pending vectors carried from one partition into the next (nothing is drained between runs).
+// In C++ a partition cost ~100 scalar instructions before its first codeword and a drain behind its last one.
+//   DEINT 0: element el + lane * step of the accumulators (el includes the channel's base); 2: the interleaved vector of two
+//   channels: element a = el + lane goes to (a & 1) * half + (a >> 1).
+// n: partitions to visit; on return the ones not visited yet (the one a return code names included).  Returns 0: all
+// visited; 1: a codeword of partition (first + visited) needs the tree -- `todo` of its codewords are left, that one
+// included; 2: a codeword runs past the end of the packet; 3: that partition is not one for this loop (single-entry book,
+// dimension not a multiple of the channel count): not started.  Starts and ends with nothing pending, no load outstanding.
+// Scratch: s[64:81], v53-v63, vcc.
+template <int DEINT>
+__device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntReader &r, const LW_K LwEntRun *runs, const LW_K uint32_t *lut,
+		const LW_K float *vq, uint32_t pass, uint32_t &n, uint32_t cls_at, uint32_t el, uint32_t psize, uint32_t half, uint32_t acc_base,
+		uint32_t dump, uint32_t &todo)
+{
+	uint32_t st, t0, t1, e, ph = 0, neg = 0;
+	const uint32_t lane = LW_ENT_LANE();
+	const uint32_t lutlo = (uint32_t)(uintptr_t)lut, luthi = (uint32_t)((uintptr_t)lut >> 32);
+	const uint32_t vqlo = (uint32_t)(uintptr_t)vq, vqhi = (uint32_t)((uintptr_t)vq >> 32);
+	const uint32_t pass32 = pass * 32u, passmask = 0x100u << pass, dper = DEINT == 2 ? 2u : 1u, half4 = half * 4u;
+	n = LW_ENT_SCALAR(n); // (wave-uniform like everything scalar here; the compiler keeps the loop-carried ones in vector registers)
+	el = LW_ENT_SCALAR(el);
+	cls_at = LW_ENT_SCALAR(cls_at);
+#define LW_ENT_RANGE_HEAD                                                                                             \
+	"s_mov_b64 s[64:65], %[win]\n"                                                                                    \
+	"s_mov_b32 s67, 0\n"                                                                                              \
+	"v_mov_b32 v57, %[cls]\n"                                                                                         \
+	"v_mov_b32 v60, %[dump]\n"                                                                                        \
+	"v_mov_b32 v61, 0\n"                                                                                              \
+	"v_mov_b32 v62, %[dump]\n"                                                                                        \
+	"v_mov_b32 v63, 0\n"                                                                                              \
+	"20:\n" /* ---- the next partition: its class digit | the passes of that class << 8 */                           \
+	"ds_read_u16 v59, v57\n"                                                                                          \
+	"v_add_u32 v57, 2, v57\n"                                                                                         \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"v_readfirstlane_b32 %[t0], v59\n"                                                                                \
+	"s_and_b32 %[t1], %[t0], %[passmask]\n"                                                                           \
+	"s_cbranch_scc0 28f\n"                                                                                            \
+	"s_and_b32 %[t0], %[t0], 0xff\n"                                                                                  \
+	"s_lshl_b32 %[t0], %[t0], 8\n"                                                                                    \
+	"s_add_u32 %[t0], %[t0], %[pass32]\n"                                                                             \
+	"s_load_dwordx8 s[68:75], %[runs], %[t0]\n" /* lut, vq (byte offsets), shape, nodes, count, step, adv, fast */    \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"s_bitcmp1_b32 s75, %[dper]\n"                                                                                    \
+	"s_cbranch_scc0 33f\n"                                                                                            \
+	"s_add_u32 s76, %[lutlo], s68\n"                                                                                  \
+	"s_addc_u32 s77, %[luthi], 0\n"                                                                                   \
+	"s_add_u32 s78, %[vqlo], s69\n"                                                                                   \
+	"s_addc_u32 s79, %[vqhi], 0\n"                                                                                    \
+	"s_and_b32 s81, s70, 0xff\n"                                                                                     \
+	"s_bfm_b32 s80, s81, 0\n"                                                                                       \
+	"s_bfe_u32 %[t0], s70, 0x80008\n" /* dims */                                                                      \
+	"s_sub_u32 %[neg], 0, s72\n"                                                                                      \
+	"v_cmp_gt_u32 vcc, %[t0], %[lane]\n" /* this lane holds an element of the codewords' vectors */                   \
+	"s_lshl_b32 %[t1], %[t0], 2\n"                                                                                    \
+	"v_mov_b32 v54, %[t1]\n"                                                                                          \
+	"v_lshlrev_b32 v59, 2, %[lane]\n"                                                                                 \
+	"v_cndmask_b32 v55, 0, v59, vcc\n"                                                                                \
+	"v_mov_b32 v53, %[el]\n"                                                                                          \
+	"v_mad_u32_u24 v59, %[lane], s73, v53\n"
+// the lane's accumulator address (v59) and its step from one codeword to the next in bytes (t1)
+#define LW_ENT_RANGE_PLACE0                                                                                           \
+	"v_lshl_add_u32 v59, v59, 2, %[accbase]\n"                                                                        \
+	"s_lshl_b32 %[t1], s74, 2\n"
+#define LW_ENT_RANGE_PLACE2                                                                                           \
+	"v_and_b32 v53, 1, v59\n"                                                                                         \
+	"v_lshrrev_b32 v59, 1, v59\n"                                                                                     \
+	"v_mul_u32_u24 v53, %[half4], v53\n"                                                                              \
+	"v_lshl_add_u32 v59, v59, 2, v53\n"                                                                               \
+	"v_add_u32 v59, %[accbase], v59\n"                                                                                \
+	"s_lshl_b32 %[t1], %[t0], 1\n"
+#define LW_ENT_RANGE_FLUSH(P, PV)                                                                                     \
+	"ds_read_b32 v59, v" P "\n"                                                                                       \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"v_add_f32 v59, v59, v" PV "\n"                                                                                   \
+	"ds_write_b32 v" P ", v59\n"
+#define LW_ENT_RANGE_TAIL                                                                                             \
+	"v_cndmask_b32 v58, %[dump], v59, vcc\n"                                                                          \
+	"v_mov_b32 v59, %[t1]\n"                                                                                          \
+	"v_cndmask_b32 v56, 0, v59, vcc\n"                                                                                \
+	"s_cmp_eq_u32 %[ph], 0\n"                                                                                         \
+	"s_cbranch_scc0 80f\n"                                                                                            \
+	"79:\n" LW_ENT_RANGE_STEP("60", "61", "80f", "1", "1") "80:\n" LW_ENT_RANGE_STEP("62", "63", "79b", "0", "0")     \
+	"28:\n" /* ---- on to the next partition */                                                                       \
+	"s_add_u32 %[el], %[el], %[psize]\n"                                                                              \
+	"s_sub_u32 %[n], %[n], 1\n"                                                                                       \
+	"s_cmp_lg_u32 %[n], 0\n"                                                                                          \
+	"s_cbranch_scc1 20b\n"                                                                                            \
+	"s_mov_b32 %[st], 0\n"                                                                                            \
+	"s_branch 70f\n"                                                                                                  \
+	"33:\n"                                                                                                           \
+	"s_mov_b32 %[st], 3\n"                                                                                            \
+	"70:\n" /* ---- leaving: the older pending vector first (ph: the slot the next codeword would have used) */       \
+	"s_waitcnt vmcnt(0)\n"                                                                                            \
+	"s_cmp_eq_u32 %[ph], 0\n"                                                                                         \
+	"s_cbranch_scc0 72f\n" LW_ENT_RANGE_FLUSH("60", "61") LW_ENT_RANGE_FLUSH("62", "63") "s_branch 73f\n"            \
+	"72:\n" LW_ENT_RANGE_FLUSH("62", "63") LW_ENT_RANGE_FLUSH("60", "61") "73:\n"                                     \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"s_mov_b64 %[win], s[64:65]\n"
+#define LW_ENT_RANGE_OPERANDS                                                                                         \
+	: [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),  \
+	  [n] "+s"(n), [el] "+s"(el), [ph] "+s"(ph), [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1)          \
+	: [w] "s"(r.w), [runs] "s"(runs), [lutlo] "s"(lutlo), [luthi] "s"(luthi), [vqlo] "s"(vqlo), [vqhi] "s"(vqhi),        \
+	  [pass32] "s"(pass32), [passmask] "s"(passmask), [dper] "s"(dper), [psize] "s"(psize), [cls] "s"(cls_at),           \
+	  [accbase] "s"(acc_base), [half4] "s"(half4), [lane] "v"(lane), [dump] "v"(dump)                                    \
+	: "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",  \
+	  "s81", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
+	if (DEINT == 0)
+		asm volatile(LW_ENT_RANGE_HEAD LW_ENT_RANGE_PLACE0 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
+	else
+		asm volatile(LW_ENT_RANGE_HEAD LW_ENT_RANGE_PLACE2 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
+	todo = 0u - neg;
+	return st;
+}
+#endif
+
 // audio.rs:620-717 for `nch` vectors of `actual` elements.  Element e of vector j is out[map(j, e)]: for residue type 2 the
 // ONE interleaved vector of ch * n/2 elements is written straight to its channel-major place (audio.rs:748-754: element i
 // belongs to channel i % ch, bin i / ch) -- every element receives the same additions in the same order as in the
@@ -668,8 +845,150 @@ LW_HD uint32_t lw_ent_place(uint32_t el, uint32_t deint, uint32_t half, uint64_t
 	return (ident ? v : (uint32_t)((cmap >> (8u * v)) & 0xffu)) * half + q;
 }
 
+// What the partitions of one residue vector share
+struct LwEntVec {
+	const LW_K LwEntRun *runs; // [class][pass] of this residue
+	LwEntAcc out;
+	LwEntDigits cls;           // this vector's digits: [partition]
+	uint32_t base;             // first element of partition 0 (types 0/1: incl. the channel's base; type 2: interleaved index)
+	uint32_t psize, half, deint_ch;
+	uint64_t cmap;
+	bool ident;
+};
+
+// One partition of one vector in one pass, from its codeword i0 on (the host's whole path; on the device what lw_ent_range
+// hands back: the partitions with a rare book shape, the rest of a partition behind a code that needs the tree).
+// false: the packet ends here (nothing left pending).
 // DEINT: 0 = the vectors are channels (residue types 0 and 1); 2 = type 2 over two channels; -1 = type 2 over `deint_ch`
-// channels.  dnd = bit j: vector j is not decoded.
+// channels.
+template <int DEINT>
+LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader &r, LwEntPend &pend, uint32_t pass, uint32_t pc, uint32_t i0)
+{
+	LwEntAcc out = V.out;
+	const uint32_t cv = LW_ENT_SCALAR(V.cls[pc]); // class | passes it uses << 8
+	if (!((cv >> (8u + pass)) & 1u))
+		return true;
+	const LW_K LwEntRun &rd = V.runs[(cv & 0xffu) * 8u + pass];
+	const uint32_t shape = rd.shape, count = rd.count, step = rd.step, adv = rd.adv;
+	const uint32_t dims = (shape >> 8) & 0xffu, lut_bits = shape & 0xffu;
+	const int32_t single = (int16_t)(shape >> 16);
+	const LW_K uint32_t *lut = (const LW_K uint32_t *)((const LW_K char *)T.lut + rd.lut_off);
+	const LW_K float *vq = (const LW_K float *)((const LW_K char *)T.vq + rd.vq_off);
+	const LW_K int32_t *nodes = rd.nodes_off != 0xFFFFFFFFu ? T.nodes + rd.nodes_off : nullptr;
+	// first element of the partition in its vector; audio.rs:587-618 (the whole partition lies inside the vector, dims
+	// divides the partition size): type 0: element d of codeword i at i + d * step; types 1/2: at i * dims + d
+	const uint32_t el0 = V.base + pc * V.psize + i0 * adv;
+	const uint32_t dper = DEINT == 2 ? 2u : DEINT ? V.deint_ch : 1u;
+	if (i0 >= count)
+		return true;
+	if (single == -1 && (DEINT == 0 || dims % dper == 0)) {
+		// the usual run: a lane's element moves by a constant from one codeword to the next (an interleaved vector: its
+		// channel stays, its bin moves by dims / channels)
+		const uint32_t lut_mask = (1u << lut_bits) - 1u;
+		LW_LV(uint32_t, at);
+		LW_LV(uint32_t, inc);
+		LW_LV(uint32_t, row);
+#if defined(__HIP_DEVICE_COMPILE__)
+		// (the row's address is vector work -- one 24-bit multiply-add per lane on the table entry as it is, length bits and
+		// all: the scalar unit, which paces this kernel, is left alone)
+		const uint32_t vdims4 = dims * 4u;
+#define LW_ENT_ROW(idx) (*(const LW_K float *)((const LW_K char *)vq + lw_ent_mad24((idx), vdims4, row)))
+#else
+#define LW_ENT_ROW(idx) vq[((idx) & 0xffffffu) * dims + row[d]]
+#endif
+		LW_ENT_LANES(d, dims) {
+			const bool on = d < dims;
+			LW_L(at) = LW_ENT_AT(out, on ? lw_ent_place<DEINT>(el0 + d * step, V.deint_ch, V.half, V.cmap, V.ident) : T.res_floats + d);
+			LW_L(inc) = on ? (adv / dper) * (LW_ENT_AT(out, 1u) - LW_ENT_AT(out, 0u)) : 0u;
+			LW_L(row) = on ? d * LW_ENT_ROW_UNIT : 0u;
+		}
+		uint32_t todo = count - i0;
+		while (todo) {
+			uint32_t e;
+#if defined(__HIP_DEVICE_COMPILE__)
+			// the steady state by hand (lw_ent_run, which starts and ends with nothing pending): it comes back for what is
+			// rare -- a code beyond the two table levels, the end of the packet
+			pend.flush(out);
+			const uint32_t before = todo;
+			const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, e, at, inc, row, vdims4, pend.dump);
+			at += inc * (before - todo);
+			if (st == 0u)
+				break;
+			if (st == 2u) {
+				r.left = 0;
+				return false;
+			}
+#else
+			e = r.probe(lut, lut_mask); // this codeword's table look-up is under way ...
+			pend.flush(out);            // ... while the previous codeword's vector is added
+#endif
+			uint32_t idx;
+			if (!r.finish(lut, lut_bits, nodes, e, idx))
+				return false;
+			LW_ENT_LANES(d, dims) {
+				pend.LW_L(at) = LW_L(at);
+				pend.LW_L(v) = LW_ENT_ROW(idx);
+				LW_L(at) += LW_L(inc);
+			}
+			pend.n = dims;
+			todo--;
+		}
+		return true;
+	}
+	// single-entry / empty books, interleaved vectors whose channel count does not divide the dimension
+	const LwEntBookRegs cb = {lut, vq, nodes, (1u << lut_bits) - 1u, lut_bits, dims, single};
+	uint32_t el = el0;
+	for (uint32_t i = i0; i < count; i++, el += adv) {
+		uint32_t idx;
+		if (!r.code(cb, idx)) {
+			pend.flush(out);
+			return false;
+		}
+		pend.flush(out);
+		LW_ENT_LANES(d, dims) {
+			const bool on = d < dims;
+			pend.LW_L(at) = LW_ENT_AT(out, on ? lw_ent_place<DEINT>(el + d * step, V.deint_ch, V.half, V.cmap, V.ident) : T.res_floats + d);
+			pend.LW_L(v) = vq[idx * dims + (on ? d : 0u)];
+		}
+		pend.n = dims;
+	}
+	return true;
+}
+
+// Partitions [p0, p1) of one vector in one pass.  false: the packet ends here.
+template <int DEINT>
+LW_HD bool lw_ent_partitions(const LwEntTables &T, const LwEntVec &V, LwEntReader &r, LwEntPend &pend, uint32_t pass, uint32_t p0, uint32_t p1)
+{
+	uint32_t n = p1 - p0;
+	while (n) {
+		uint32_t i0 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (DEINT == 0 || (DEINT == 2 && V.ident)) {
+			// the device's steady state (lw_ent_range starts and ends with nothing pending)
+			pend.flush(V.out);
+			uint32_t todo;
+			const uint32_t pc = p1 - n;
+			const uint32_t st = lw_ent_range<DEINT>(r, V.runs, T.lut, T.vq, pass, n, (uint32_t)(uintptr_t)(V.cls + pc), V.base + pc * V.psize,
+					V.psize, V.half, (uint32_t)(uintptr_t)V.out, pend.dump, todo);
+			if (st == 0u)
+				break;
+			if (st == 2u) {
+				r.left = 0;
+				return false;
+			}
+			if (st == 1u) {
+				const uint32_t cv = LW_ENT_SCALAR(V.cls[p1 - n]);
+				i0 = V.runs[(cv & 0xffu) * 8u + pass].count - todo;
+			}
+		}
+#endif
+		if (!lw_ent_partition<DEINT>(T, V, r, pend, pass, p1 - n, i0))
+			return false;
+		n--;
+	}
+	return true;
+}
+
 template <int DEINT>
 LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwEntReader &r, uint32_t nch, uint32_t actual,
 		uint32_t dnd, LwEntAcc out, uint32_t half, uint32_t deint_ch, LwEntDigits cls, uint64_t cmap, const bool general)
@@ -682,14 +1001,20 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 		return;
 	const uint32_t stride = parts + cpc;
 	const uint32_t ncls = rs.classifications, digits_off = rs.digits_off, used_any = rs.used_any;
-	const LW_K LwEntRun *const runs = T.runs + rs.runs_off;
 	const LwEntBookRegs classbook = lw_ent_book(T, rs.classbook);
 	LwEntPend pend;
 	pend.clear(out, T.res_floats);
-	bool ident = true;
+	LwEntVec V;
+	V.runs = T.runs + rs.runs_off;
+	V.out = out;
+	V.psize = psize;
+	V.half = half;
+	V.deint_ch = deint_ch;
+	V.cmap = cmap;
+	V.ident = true;
 	if (general) // (a compile-time constant at both call sites: the one-submap kernel carries no channel map at all)
 		for (uint32_t v = 0, nv = DEINT ? deint_ch : nch; v < nv; v++)
-			ident &= ((cmap >> (8u * v)) & 0xffu) == v;
+			V.ident &= ((cmap >> (8u * v)) & 0xffu) == v;
 	for (uint32_t pass = 0; pass < 8 && (used_any >> pass) != 0; pass++) {
 		uint32_t pc = 0;
 		while (pc < parts) {
@@ -718,97 +1043,30 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 					}
 				}
 			}
-			for (uint32_t k = 0; k < cpc && pc < parts; k++, pc++) {
+			// the partitions this group's class words cover; behind pass 0 nothing separates the groups, so a single
+			// vector's partitions are one range to the end
+			uint32_t pc_end = pc + cpc < parts ? pc + cpc : parts;
+			if (nch == 1u) {
+				if (pass != 0u)
+					pc_end = parts;
+				if (!(dnd & 1u)) {
+					V.cls = cls;
+					V.base = (DEINT ? 0u : (V.ident ? 0u : (uint32_t)(cmap & 0xffu)) * half) + begin;
+					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc_end))
+						return;
+				}
+				pc = pc_end;
+				continue;
+			}
+			for (; pc < pc_end; pc++)
 				for (uint32_t j = 0; j < nch; j++) {
 					if ((dnd >> j) & 1u)
 						continue;
-					const uint32_t cv = LW_ENT_SCALAR(cls[j * stride + pc]); // class | passes it uses << 8
-					if (!((cv >> (8u + pass)) & 1u))
-						continue;
-					const LW_K LwEntRun &rd = runs[(cv & 0xffu) * 8u + pass];
-					const uint32_t shape = rd.shape, count = rd.count, step = rd.step, adv = rd.adv;
-					const uint32_t dims = (shape >> 8) & 0xffu, lut_bits = shape & 0xffu;
-					const int32_t single = (int16_t)(shape >> 16);
-					const LW_K uint32_t *lut = T.lut + rd.lut_off;
-					const LW_K float *vq = T.vq + rd.vq_off;
-					const LW_K int32_t *nodes = rd.nodes_off != 0xFFFFFFFFu ? T.nodes + rd.nodes_off : nullptr;
-					// first element of the partition in its vector; audio.rs:587-618 (the whole partition lies inside the vector,
-					// dims divides the partition size): type 0: element d of codeword i at i + d * step; types 1/2: at i * dims + d
-					const uint32_t el0 = (DEINT ? 0u : (ident ? j : (uint32_t)((cmap >> (8u * j)) & 0xffu)) * half) + begin + pc * psize;
-					const uint32_t dper = DEINT == 2 ? 2u : DEINT ? deint_ch : 1u;
-					if (single == -1 && (DEINT == 0 || dims % dper == 0)) {
-						// the usual run: a lane's element moves by a constant from one codeword to the next (an interleaved vector:
-						// its channel stays, its bin moves by dims / channels)
-						const uint32_t lut_mask = (1u << lut_bits) - 1u;
-						LW_LV(uint32_t, at);
-						LW_LV(uint32_t, inc);
-						LW_LV(uint32_t, row);
-#if defined(__HIP_DEVICE_COMPILE__)
-						// (the row's address is vector work -- one 24-bit multiply-add per lane on the table entry as it is, length
-						// bits and all: the scalar unit, which paces this kernel, is left alone)
-						const uint32_t vdims4 = dims * 4u;
-#define LW_ENT_ROW(idx) (*(const LW_K float *)((const LW_K char *)vq + lw_ent_mad24((idx), vdims4, row)))
-#else
-#define LW_ENT_ROW(idx) vq[((idx) & 0xffffffu) * dims + row[d]]
-#endif
-						LW_ENT_LANES(d, dims) {
-							const bool on = d < dims;
-							LW_L(at) = LW_ENT_AT(out, on ? lw_ent_place<DEINT>(el0 + d * step, deint_ch, half, cmap, ident) : T.res_floats + d);
-							LW_L(inc) = on ? (adv / dper) * (LW_ENT_AT(out, 1u) - LW_ENT_AT(out, 0u)) : 0u;
-							LW_L(row) = on ? d * LW_ENT_ROW_UNIT : 0u;
-						}
-						uint32_t todo = count;
-						while (todo) {
-							uint32_t e;
-#if defined(__HIP_DEVICE_COMPILE__)
-							// the steady state by hand (lw_ent_run, which starts and ends with nothing pending): it comes back for
-							// what is rare -- a code beyond the two table levels, the end of the packet
-							pend.flush(out);
-							const uint32_t before = todo;
-							const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, e, at, inc, row, vdims4, pend.dump);
-							at += inc * (before - todo);
-							if (st == 0u)
-								break;
-							if (st == 2u) {
-								r.left = 0;
-								return;
-							}
-#else
-							e = r.probe(lut, lut_mask); // this codeword's table look-up is under way ...
-							pend.flush(out);            // ... while the previous codeword's vector is added
-#endif
-							uint32_t idx;
-							if (!r.finish(lut, lut_bits, nodes, e, idx))
-								return;
-							LW_ENT_LANES(d, dims) {
-								pend.LW_L(at) = LW_L(at);
-								pend.LW_L(v) = LW_ENT_ROW(idx);
-								LW_L(at) += LW_L(inc);
-							}
-							pend.n = dims;
-							todo--;
-						}
-					} else {
-						// single-entry / empty books, interleaved vectors whose channel count does not divide the dimension
-						const LwEntBookRegs cb = {lut, vq, nodes, (1u << lut_bits) - 1u, lut_bits, dims, single};
-						uint32_t el = el0;
-						for (uint32_t i = 0; i < count; i++, el += adv) {
-							uint32_t idx;
-							if (!r.code(cb, idx)) {
-								pend.flush(out);
-								return;
-							}
-							pend.flush(out);
-							LW_ENT_LANES(d, dims) {
-								const bool on = d < dims;
-								pend.LW_L(at) = LW_ENT_AT(out, on ? lw_ent_place<DEINT>(el + d * step, deint_ch, half, cmap, ident) : T.res_floats + d);
-								pend.LW_L(v) = vq[idx * dims + (on ? d : 0u)];
-							}
-							pend.n = dims;
-						}
-					}
+					V.cls = cls + j * stride;
+					V.base = (DEINT ? 0u : (V.ident ? j : (uint32_t)((cmap >> (8u * j)) & 0xffu)) * half) + begin;
+					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc + 1u))
+						return;
 				}
-			}
 		}
 	}
 	pend.flush(out);
