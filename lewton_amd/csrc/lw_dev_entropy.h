@@ -30,16 +30,18 @@
 // On the device the packet's working set lives in the wave's LDS: residue accumulator, posts, classification digits
 // (address space 3: ds_ instructions, no flat addressing), and the additions of one codeword's vector are spread over the
 // lanes (element d on lane d).  On the host the same names are plain pointers and a loop.
-//   LW_ENT_EACH(d, cnt)   lanes d < cnt (device: the others are masked off)
 //   LW_ENT_LANES(d, cnt)  device: EVERY lane, no masking (a lane >= cnt works on a harmless stand-in -- its own dump slot
 //                         behind the accumulators); host: d < cnt
 //   LW_LV / LW_L          a value per lane: a register on the device, an array on the host
+// There is NO lane-masked region in the device code (no `if (lane < n)`): the packet's control flow is wave-uniform and has
+// to look it to the compiler -- behind one divergent branch it treats what the paths merge as divergent, and from there the
+// bit reader and every loop around it moved to vector registers and exec masks (tests/test_entropy_kernel_scalar.py counts
+// the exec-mask manipulations of the built kernel).
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) float *LwEntAcc;
 typedef __attribute__((address_space(3))) uint32_t *LwEntPosts;
 typedef __attribute__((address_space(3))) uint16_t *LwEntDigits;
 #define LW_ENT_LANE() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))
-#define LW_ENT_EACH(d, cnt) for (uint32_t d = LW_ENT_LANE(), once_ = 1; once_ && d < (cnt); once_ = 0)
 #define LW_ENT_LANES(d, cnt) for (uint32_t d = LW_ENT_LANE(), once_ = 1; once_; once_ = 0)
 #define LW_LV(type, name) type name
 #define LW_L(name) name
@@ -52,7 +54,6 @@ typedef __attribute__((address_space(3))) uint8_t *LwEntFlags;
 typedef float *LwEntAcc;
 typedef uint32_t *LwEntPosts;
 typedef uint16_t *LwEntDigits;
-#define LW_ENT_EACH(d, cnt) for (uint32_t d = 0; d < (cnt); d++)
 #define LW_ENT_LANES(d, cnt) for (uint32_t d = 0; d < (cnt); d++)
 #define LW_LV(type, name) type name[64]
 #define LW_L(name) name[d]
@@ -121,7 +122,7 @@ struct LwEntFloor { // (dwords throughout: see LwEntBook)
 };
 
 struct LwEntResidue {
-	uint8_t type, classifications, classbook, cpc;
+	uint32_t type, classifications, classbook, cpc;
 	uint32_t begin, end, psize;
 	uint32_t digits_off; // u16 [classbook entries][cpc] in the image's digit pool (see LwEntTables::digits), or 0xFFFFFFFF: by division
 	uint32_t runs_off;   // LwEntRun [classifications][8 passes] in the image's run pool
@@ -192,7 +193,7 @@ struct LwEntBookRegs {
 
 LW_HD LwEntBookRegs lw_ent_book(const LwEntTables &T, uint32_t bi)
 {
-	const LW_K LwEntBook &b = T.books[bi];
+	const LW_K LwEntBook &b = T.books[LW_ENT_SCALAR(bi)]; // (a book number may come out of a byte table: a vector load)
 	LwEntBookRegs r;
 	r.lut = T.lut + b.lut_off;
 	r.vq = T.vq + b.vq_off;
@@ -1084,7 +1085,7 @@ LW_HD void lw_ent_decode_packet(const LwEntTables &T, const LW_K uint32_t *words
 	uint32_t no_residue = 0; // bit c: channel c has no residue
 	// floor_decode, audio.rs:557-585
 	for (uint32_t c = 0; c < ch; c++) {
-		const LW_K LwEntFloor &fl = T.floors[m.floor_of_ch[c]];
+		const LW_K LwEntFloor &fl = T.floors[LW_ENT_SCALAR(m.floor_of_ch[c])];
 		uint16_t *rec = floor_out + c * T.fstride;
 		if (!lw_ent_floor_decode(T, fl, r, y)) {
 			rec[0] = LW_FLOOR_UNUSED;
@@ -1101,7 +1102,7 @@ LW_HD void lw_ent_decode_packet(const LwEntTables &T, const LW_K uint32_t *words
 	}
 	const uint32_t all = (1u << ch) - 1u;
 	if (!general) { // one submap holding every channel (T.general == 0): vector j = channel j
-		const LW_K LwEntResidue &rs = T.residues[m.submap_residue[0]];
+		const LW_K LwEntResidue &rs = T.residues[LW_ENT_SCALAR(m.submap_residue[0])];
 		if (rs.type != 2) {
 			lw_ent_residue<0>(T, rs, r, ch, half, no_residue, res_out, half, 0u, cls, 0, false);
 			return;
@@ -1130,7 +1131,7 @@ LW_HD void lw_ent_decode_packet(const LwEntTables &T, const LW_K uint32_t *words
 			}
 		if (sub_ch == 0)
 			continue;
-		const LW_K LwEntResidue &rs = T.residues[m.submap_residue[sm]];
+		const LW_K LwEntResidue &rs = T.residues[LW_ENT_SCALAR(m.submap_residue[sm])];
 		if (rs.type != 2)
 			lw_ent_residue<0>(T, rs, r, sub_ch, half, dnd, res_out, half, 0u, cls, cmap, true);
 		else if (any) // audio.rs:722-760: type 2 = one interleaved vector of sub_ch * n/2 elements, decoded unless EVERY channel is marked
