@@ -159,7 +159,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	std::vector<LwEntResidue> residues(s.residues.size());
 	std::vector<uint16_t> digits;
 	std::vector<LwEntRun> runs;
-	std::vector<uint32_t> run_book; // the book of every run record, 0xFFFFFFFF: none
+	std::vector<uint32_t> run_book, run_psize; // the book (0xFFFFFFFF: none) and the partition size of every run record
 	size_t cls_bytes = 0;
 	for (size_t ri = 0; ri < s.residues.size(); ri++) {
 		LwEntResidue &r = residues[ri];
@@ -189,6 +189,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		r.runs_off = (uint32_t)runs.size();
 		runs.resize(runs.size() + (size_t)rs.classifications * 8);
 		run_book.resize(runs.size(), 0xFFFFFFFFu);
+		run_psize.resize(runs.size(), rs.partition_size);
 		for (unsigned c = 0; c < rs.classifications; c++) {
 			r.vals_used[c] = rs.books[c].vals_used;
 			r.used_any |= rs.books[c].vals_used;
@@ -209,12 +210,8 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 					*why = "a residue book without a vector lookup";
 					return false;
 				}
-				if (rs.type != 0 && rs.partition_size % cb.dims != 0) {
-					*why = "a residue book whose dimension does not divide the partition size";
-					return false;
-				}
 				book_used[bi] = true;
-				run.count = rs.partition_size / cb.dims;
+				run.count = rs.type == 0 ? rs.partition_size / cb.dims : (rs.partition_size + cb.dims - 1) / cb.dims;
 				run.step = rs.type == 0 ? rs.partition_size / cb.dims : 1u;
 				run.adv = rs.type == 0 ? 1u : cb.dims;
 				run_book[r.runs_off + c * 8 + p] = bi; // (the book's table entries are filled in below)
@@ -280,7 +277,8 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		run.nodes_off = b.nodes_off;
 		run.shape = b.shape;
 		const unsigned dims = (b.shape >> 8) & 0xffu;
-		if ((int16_t)(b.shape >> 16) == -1 && run.count >= 1 && dims)
+		const bool whole = run.adv == 1 || run.count * dims == run_psize[k]; // (type 0, or the dimension divides the partition)
+		if ((int16_t)(b.shape >> 16) == -1 && run.count >= 1 && dims && whole)
 			for (unsigned d = 1; d <= 8; d++)
 				if (dims % d == 0)
 					run.fast |= 1u << d;

@@ -135,10 +135,11 @@ struct LwEntResidue {
 struct alignas(16) LwEntRun {
 	uint32_t lut_off, vq_off; // as LwEntBook, but in BYTES
 	uint32_t shape, nodes_off; // as LwEntBook
-	uint32_t count; // codewords per partition: psize / dims
+	uint32_t count; // codewords per partition: type 0 psize / dims, types 1/2 ceil(psize / dims) (audio.rs:587-618)
 	uint32_t step;  // element stride inside a codeword's vector: type 0 psize / dims, types 1/2 1 (audio.rs:587-618)
 	uint32_t adv;   // elements between the starts of consecutive codewords: type 0 1, types 1/2 dims
-	uint32_t fast;  // bit k (1..8): an ordinary book with count >= 1 whose dimension is a multiple of k (lw_ent_range)
+	uint32_t fast;  // bit k (1..8): an ordinary book with count >= 1 whose dimension is a multiple of k and (types 1/2)
+	                // divides the partition size: the runs lw_ent_range and lw_ent_run take
 };
 
 struct LwEntMode {
@@ -853,6 +854,7 @@ struct LwEntVec {
 	LwEntDigits cls;           // this vector's digits: [partition]
 	uint32_t base;             // first element of partition 0 (types 0/1: incl. the channel's base; type 2: interleaved index)
 	uint32_t psize, half, deint_ch;
+	uint32_t room0;            // elements from the start of partition 0 to the end of the vector (types 1/2: audio.rs:604-608)
 	uint64_t cmap;
 	bool ident;
 };
@@ -882,7 +884,7 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 	const uint32_t dper = DEINT == 2 ? 2u : DEINT ? V.deint_ch : 1u;
 	if (i0 >= count)
 		return true;
-	if (single == -1 && (DEINT == 0 || dims % dper == 0)) {
+	if ((rd.fast >> dper) & 1u) {
 		// the usual run: a lane's element moves by a constant from one codeword to the next (an interleaved vector: its
 		// channel stays, its bin moves by dims / channels)
 		const uint32_t lut_mask = (1u << lut_bits) - 1u;
@@ -936,7 +938,10 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 		}
 		return true;
 	}
-	// single-entry / empty books, interleaved vectors whose channel count does not divide the dimension
+	// single-entry / empty books, interleaved vectors whose channel count does not divide the dimension, books whose
+	// dimension does not divide the partition size: their last codeword of a partition reaches into the next partition,
+	// and one that would reach past the end of the vector is read and dropped, which ends the partition (audio.rs:600-612)
+	const uint32_t room = V.room0 - pc * V.psize;
 	const LwEntBookRegs cb = {lut, vq, nodes, (1u << lut_bits) - 1u, lut_bits, dims, single};
 	uint32_t el = el0;
 	for (uint32_t i = i0; i < count; i++, el += adv) {
@@ -946,6 +951,8 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 			return false;
 		}
 		pend.flush(out);
+		if (adv != 1u && i * dims + dims > room)
+			break;
 		LW_ENT_LANES(d, dims) {
 			const bool on = d < dims;
 			pend.LW_L(at) = LW_ENT_AT(out, on ? lw_ent_place<DEINT>(el + d * step, V.deint_ch, V.half, V.cmap, V.ident) : T.res_floats + d);
@@ -1009,6 +1016,7 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 	V.runs = T.runs + rs.runs_off;
 	V.out = out;
 	V.psize = psize;
+	V.room0 = actual - begin;
 	V.half = half;
 	V.deint_ch = deint_ch;
 	V.cmap = cmap;

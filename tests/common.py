@@ -27,7 +27,20 @@ SETUPS = {
     "stereo_10_12": lambda: sg.stereo_setup(44100, 10, 12),
 }
 # host-stage tests only (no GPU test iterates these): a residue pass through a one-entry codebook
-HOST_SETUPS = dict(SETUPS, stereo_single_entry=lambda: sg.stereo_setup(single_entry_book=True))
+def spill_setup(residue_type):
+    """stereo, partitions of 12 / 20 elements against books of 8, 4 and 2 dimensions: the last codeword of a partition
+    reaches into the next one, and one that would reach past the end of the vector is read and dropped (audio.rs:600-612)"""
+    st = sg.stereo_setup(44100, 8, 11, residue_type=residue_type)
+    st.residues[0].partition_size = 12
+    st.residues[1].partition_size = 20
+    for rs, begin in zip(st.residues, (8, 4) if residue_type == 1 else (4, 8)):
+        rs.begin = begin   # the last partition ends exactly at the end of the (clipped) vector: its last codeword is dropped
+        rs.end = 1 << 20
+    return st
+
+
+HOST_SETUPS = dict(SETUPS, stereo_single_entry=lambda: sg.stereo_setup(single_entry_book=True),
+                   stereo_spill_t1=lambda: spill_setup(1), stereo_spill_t2=lambda: spill_setup(2))
 # floor type 0 (SURVEY 8f row f4): curve evaluated by the host stage, multiplied on the GPU
 FLOOR0_SETUPS = {
     "floor0": lambda: sg.floor0_setup(),

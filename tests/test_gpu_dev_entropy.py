@@ -5,7 +5,7 @@ algorithm is held against the host entropy stage on the CPU in tests/test_dev_en
 import numpy as np
 import pytest
 
-from common import FLOOR0_SETUPS, SETUPS, oracle_headers, po, sg
+from common import FLOOR0_SETUPS, HOST_SETUPS, SETUPS, oracle_headers, po, sg
 
 pytestmark = pytest.mark.gpu
 
@@ -33,10 +33,11 @@ def _damage(pk, rng):
 
 
 @pytest.mark.parametrize("name,pattern", [("stereo", "L"), ("stereo", "LLSSSSLLSL"), ("stereo_t1", "LSL"), ("mono_small", "LSSLL"),
-                                          ("stereo_9_12", "LLS"), ("stereo_7_7", "LSL"), ("surround51", "LLSL"), ("stereo_6_13", "LSL")])
+                                          ("stereo_9_12", "LLS"), ("stereo_7_7", "LSL"), ("surround51", "LLSL"), ("stereo_6_13", "LSL"),
+                                          ("stereo_spill_t1", "LSLL"), ("stereo_spill_t2", "LLSL"), ("stereo_single_entry", "LLS")])
 def test_ring_with_device_entropy_matches_oracle(name, pattern):
     from lewton_amd.ring import Ring
-    setup = SETUPS[name]()
+    setup = HOST_SETUPS[name]()
     audio, ident, st = _product(setup)
     o_id, o_st = oracle_headers(setup)
     dec = audio.decoder_for(ident, st)
@@ -80,13 +81,14 @@ def test_ring_with_device_entropy_matches_oracle(name, pattern):
     ring.close()
 
 
-@pytest.mark.parametrize("name,pattern", [("stereo", "LLSL"), ("stereo_t1", "LSL"), ("mono_small", "SLL")])
+@pytest.mark.parametrize("name,pattern", [("stereo", "LLSL"), ("stereo_t1", "LSL"), ("mono_small", "SLL"), ("stereo_spill_t1", "LSL"),
+                                          ("stereo_spill_t2", "LSL")])
 def test_device_entropy_records_equal_host_stage(name, pattern):
     """the residue vectors k_entropy leaves in HBM (tap before inverse coupling) and the final samples, against the same
     batch decoded by the host entropy stage"""
     from lewton_amd import _native as N
     from lewton_amd.batch import Batch
-    setup = SETUPS[name]()
+    setup = HOST_SETUPS[name]()
     audio, ident, st = _product(setup)
     dec = audio.decoder_for(ident, st)
     pk = sg.make_stream(setup, pattern, 48, seed=31, p_floor_unused=0.1)
