@@ -174,12 +174,12 @@ void lw_batch_set_force_generic(lw_batch *b, int on);
 /* Test hook: rounds per workgroup of the specialised long-block kernel for this batch's next lw_batch_entropy (1..16;
  * 0 = the planner decides).  Exercises the hand-over of window state across rounds and workgroups on small batches. */
 void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
-/* Entropy stage on the device ("Tier C"; csrc/lw_dev_entropy.h, k_entropy): the bit-serial half of
- * read_audio_packet_generic (audio.rs:921-986: floor-1 decode :215-251 + amplitude unwrap :391-435, residue decode
- * :587-760) runs on the GPU, one lane per packet; lw_batch_entropy then only reads the prologues, copies the packets
- * into pinned staging and plans the batch, and the packets themselves (~0.5 KB instead of 8.3 KB of records per stereo
- * long block) cross PCIe.  Records, PCM and statuses are bit-identical to the host stage's.  Eligible streams: floor type
- * 1, residue books whose dimension divides the partition size, at most 8 channels (`why` names the reason otherwise;
+/* Entropy stage on the device (csrc/lw_dev_entropy.h, k_entropy): the bit-serial half of read_audio_packet_generic
+ * (audio.rs:921-986: floor-1 decode :215-251 + amplitude unwrap :391-435, residue decode :587-760) runs on the GPU, one
+ * wave per packet; lw_batch_entropy then only reads the prologues, copies the packets into pinned staging and plans the
+ * batch, and the packets themselves (~0.5 KB instead of 8.3 KB of records per stereo long block) cross PCIe.  Records,
+ * PCM and statuses are bit-identical to the host stage's.  Eligible streams: floor type 1, residue books with a vector
+ * lookup of at most 64 dimensions, at most 8 channels and 16 coupling steps (`why` names the reason otherwise;
  * LW_ERR_UNSUPPORTED from the setters). */
 int lw_decoder_supports_device_entropy(const lw_decoder *d, const char **why);
 int lw_batch_set_entropy_on_device(lw_batch *b, int on);
