@@ -470,13 +470,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		for (int cls = 0; cls < 2; cls++) {
 			if (!blk_ok[cls])
 				continue;
-			// passes per wave: more slots per recomputed predecessor -- but only while the launch keeps enough waves to fill the
-			// chip (a wave's passes run one after the other: 4096 blocks of 1024 points in 820 waves of 3 passes were slower
-			// than in 4096 waves of one)
+			// passes per wave: more slots per recomputed predecessor -- but only while the launch keeps the waves the chip holds
+			// at a time (five per CU: LDS) (a wave's passes run one after the other: 4096 blocks of 1024 points in 820 waves of 3
+			// passes were slower than in 4096 waves of one)
 			const size_t per_wave = 64 / d->blkp[cls].lanes;
 			uint32_t passes = 1;
 			while (passes < d->blkp[cls].passes &&
-					b->blk_idx[cls].size() / (per_wave * (passes + 1) - 1) >= 8 * (size_t)std::max(1, d->n_cus))
+					b->blk_idx[cls].size() / (per_wave * (passes + 1) - 1) >= 5 * (size_t)std::max(1, d->n_cus))
 				passes++;
 			b->blk_passes[cls] = passes;
 			const size_t per_task = per_wave * passes;
