@@ -305,7 +305,7 @@ def main():
                     best = r_
             e2e_obj = best
             e2e_obj["host_cpus_usable"] = cpus   # hardware threads cut to the affinity mask and the cgroup CPU quota
-            try:   # entropy stage on the device (k_entropy, one lane per packet): the packets themselves cross PCIe, two host
+            try:   # entropy stage on the device (k_entropy, one wave per packet): the packets themselves cross PCIe, two host
                    # threads read prologues and plan; at the bench's batch size and with larger batches in flight
                 keys = ("value", "unit", "records", "h2d_GBps", "d2h_GBps", "host_entropy_stage_alone", "host_threads", "ring_slots",
                         "kernels", "packets")
@@ -314,7 +314,7 @@ def main():
                 e2e_obj["device_entropy"] = {k: r_[k] for k in keys}
                 e2e_obj["device_entropy"]["packets_per_batch"] = PACKETS_PER_BATCH
                 big = 4 * PACKETS_PER_BATCH
-                r_ = e2e_mod.measure(dec, pool, n_batches=max(8, args.e2e_batches // 4), packets=big, streams=4 * S, threads=2, slots=4,
+                r_ = e2e_mod.measure(dec, pool, n_batches=max(12, args.e2e_batches // 2), packets=big, streams=S, threads=0, slots=3,
                                      callers=1, samples=args.format, device_entropy=True)
                 e2e_obj["device_entropy"]["large_batches"] = dict({k: r_[k] for k in keys}, packets_per_batch=big)
             except Exception as e:
