@@ -250,7 +250,8 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 		} else {
 			b.lut_off = (uint32_t)lut.size();
 			lut_bits = cb.huff.lut_bits;
-			lut.insert(lut.end(), cb.huff.lut.begin(), cb.huff.lut.end());
+			for (uint32_t e : cb.huff.lut) // (length 0 = "not in the tables": its own marker here, see LW_ENT_WALK)
+				lut.push_back(!(e & Huffman::LINK) && (e >> 24) == 0 ? LW_ENT_WALK : e);
 			bool walks = false; // some code is longer than the two table levels: ship the tree as well
 			for (uint32_t e : cb.huff.lut)
 				walks |= !(e & Huffman::LINK) && (e >> 24) == 0;

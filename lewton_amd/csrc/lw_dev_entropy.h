@@ -212,7 +212,11 @@ LW_HD LwEntBookRegs lw_ent_book(const LwEntTables &T, uint32_t bi)
 // loads are never on a codeword's dependency chain.  The pool keeps >= 3 zero words behind every packet.
 // `left` = bits of the packet not yet consumed: the reference's bounds checks (bitpacking.rs:291-297, huffman_tree.rs:362-381)
 // are comparisons against it.
-#define LW_ENT_SPECIAL(e) ((uint32_t)((e) - 0x01000000u) >= 0x7f000000u) // a link to a second-level table, or length 0: ONE test
+// Table entries as the image holds them: (len << 24) | entry for a code of the table level; LW_ENT_LINK | (bits << 24) | offset for
+// a prefix with a second-level table; LW_ENT_WALK for "not in the tables" (a longer code: the tree; the host's tables have
+// length 0 there) -- so that ONE sign test separates the ordinary entries from the rest.
+#define LW_ENT_WALK 0xFF000000u
+#define LW_ENT_SPECIAL(e) ((int32_t)(e) < 0)
 struct LwEntReader {
 	const LW_K uint32_t *w;
 	uint32_t nbits, left;
@@ -272,9 +276,10 @@ struct LwEntReader {
 	LW_HD bool finish(const LW_K uint32_t *lut, uint32_t lut_bits, const LW_K int32_t *nodes, uint32_t e, uint32_t &sym)
 	{
 		if (LW_ENT_SPECIAL(e)) {
-			if (e & LW_ENT_LINK)
-				e = lut[(e & 0xffffffu) + (((uint32_t)win >> lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
-			if ((e >> 24) == 0)
+			if (e >= LW_ENT_WALK)
+				return walk(nodes, sym);
+			e = lut[(e & 0xffffffu) + (((uint32_t)win >> lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
+			if (LW_ENT_SPECIAL(e))
 				return walk(nodes, sym);
 		}
 		const uint32_t len = e >> 24;
@@ -449,208 +454,54 @@ LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// The steady state of a partition's run of codewords, by hand (gfx950): per codeword ~15 scalar instructions (the scalar unit
-// paces this kernel: one wave per packet, four packets per SIMD), 4 vector instructions, one table look-up, one row load,
-// one LDS read-modify-write -- what the compiler makes of the same loop in C++ is ~50 + 19.
-//   window refill (every 32 bits) | entry = lut[window & mask] | add the vector of the codeword before the last one |
-//   link -> second-level entry | bounds (left -= len borrows: the code runs past the end) | window >>= len | row load
-// The vectors are added TWO codewords behind the decoder (two pending slots, v60/v61 and v62/v63, used in turn: the loop
-// body exists twice): a row load has two look-ups to arrive in; one behind, every codeword waited ~350 cycles for its
-// predecessor's row.  Additions to one accumulator keep their order (the slots are a FIFO; within a run no two codewords
-// touch the same element).  The statement starts and ends with nothing pending and no load outstanding.
-// Returns 0: `todo` codewords done (todo = 0); 1: the codeword at the head of the window needs the tree (entry in `e`: length
-// 0), nothing of it consumed; 2: the codeword runs past the end of the packet.  `at` is not changed: the caller advances it
-// by inc per codeword done.  Scratch: s[84:87] (the window is shifted as a 64-bit pair), v58-v63.
-__device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader &r, const LW_K uint32_t *lut, const LW_K float *vq,
-		uint32_t lut_mask, uint32_t lut_bits, uint32_t &todo, uint32_t &e, uint32_t at, uint32_t inc, uint32_t row, uint32_t vdims4,
-		uint32_t dump)
-{
-	uint32_t st, t0, t1;
-	uint32_t neg = LW_ENT_SCALAR(0u - todo); // (wave-uniform like everything scalar here; the compiler keeps this one in a vector register)
-	asm volatile("s_mov_b64 s[84:85], %[win]\n"
-	             "s_mov_b32 s87, 0\n"
-	             "v_mov_b32 v58, %[at]\n"
-	             "v_mov_b32 v60, %[dump]\n"
-	             "v_mov_b32 v61, 0\n"
-	             "v_mov_b32 v62, %[dump]\n"
-	             "v_mov_b32 v63, 0\n"
-	             "79:\n" // ---- a codeword through slot A (v60 = accumulator address, v61 = value)
-	             "s_cmp_lt_u32 %[have], 32\n"
-	             "s_cbranch_scc0 602f\n"
-	             "s_mov_b32 s86, %[nxt]\n"
-	             "s_lshl_b64 s[86:87], s[86:87], %[have]\n"
-	             "s_or_b64 s[84:85], s[84:85], s[86:87]\n"
-	             "s_add_u32 %[have], %[have], 32\n"
-	             "s_load_dword %[nxt], %[w], %[wo]\n"
-	             "s_add_u32 %[wo], %[wo], 4\n"
-	             "s_mov_b32 s87, 0\n"
-	             "602:\n"
-	             "s_and_b32 %[t0], s84, %[mask]\n"
-	             "s_lshl_b32 %[t0], %[t0], 2\n"
-	             "s_load_dword %[e], %[lut], %[t0]\n"
-	             "ds_read_b32 v59, v60\n"
-	             "s_waitcnt vmcnt(1) lgkmcnt(0)\n"
-	             "v_add_f32 v59, v59, v61\n"
-	             "ds_write_b32 v60, v59\n"
-	             "s_sub_u32 %[t0], %[e], 0x1000000\n"
-	             "s_cmp_ge_u32 %[t0], 0x7f000000\n"
-	             "s_cbranch_scc1 604f\n"
-	             "603:\n"
-	             "s_lshr_b32 %[t0], %[e], 24\n"
-	             "s_sub_u32 %[left], %[left], %[t0]\n"
-	             "s_cbranch_scc1 606f\n"
-	             "s_lshr_b64 s[84:85], s[84:85], %[t0]\n"
-	             "s_sub_u32 %[have], %[have], %[t0]\n"
-	             "v_mad_u32_u24 v59, %[e], %[vd4], %[row]\n"
-	             "global_load_dword v61, v59, %[vq]\n"
-	             "v_mov_b32 v60, v58\n"
-	             "v_add_u32 v58, v58, %[inc]\n"
-	             "s_add_u32 %[neg], %[neg], 1\n"
-	             "s_cbranch_scc0 80f\n"
-	             "s_mov_b32 %[st], 0\n"
-	             "s_branch 71f\n"
-	             "604:\n" // a link to a second-level table, or length 0
-	             "s_bitcmp1_b32 %[e], 31\n"
-	             "s_cbranch_scc0 605f\n"
-	             "s_bfe_u32 %[t0], %[e], 0x70018\n"
-	             "s_lshr_b32 %[t1], s84, %[bits]\n"
-	             "s_bfm_b32 %[t0], %[t0], 0\n"
-	             "s_and_b32 %[t1], %[t1], %[t0]\n"
-	             "s_and_b32 %[t0], %[e], 0xffffff\n"
-	             "s_add_u32 %[t0], %[t0], %[t1]\n"
-	             "s_lshl_b32 %[t0], %[t0], 2\n"
-	             "s_load_dword %[e], %[lut], %[t0]\n"
-	             "s_waitcnt lgkmcnt(0)\n"
-	             "s_cmp_lt_u32 %[e], 0x1000000\n"
-	             "s_cbranch_scc0 603b\n"
-	             "605:\n"
-	             "s_mov_b32 %[st], 1\n"
-	             "v_mov_b32 v60, %[dump]\n"
-	             "s_branch 71f\n"
-	             "606:\n"
-	             "s_mov_b32 %[st], 2\n"
-	             "v_mov_b32 v60, %[dump]\n"
-	             "s_branch 71f\n"
-	             "80:\n" // ---- a codeword through slot B (v62, v63)
-	             "s_cmp_lt_u32 %[have], 32\n"
-	             "s_cbranch_scc0 622f\n"
-	             "s_mov_b32 s86, %[nxt]\n"
-	             "s_lshl_b64 s[86:87], s[86:87], %[have]\n"
-	             "s_or_b64 s[84:85], s[84:85], s[86:87]\n"
-	             "s_add_u32 %[have], %[have], 32\n"
-	             "s_load_dword %[nxt], %[w], %[wo]\n"
-	             "s_add_u32 %[wo], %[wo], 4\n"
-	             "s_mov_b32 s87, 0\n"
-	             "622:\n"
-	             "s_and_b32 %[t0], s84, %[mask]\n"
-	             "s_lshl_b32 %[t0], %[t0], 2\n"
-	             "s_load_dword %[e], %[lut], %[t0]\n"
-	             "ds_read_b32 v59, v62\n"
-	             "s_waitcnt vmcnt(1) lgkmcnt(0)\n"
-	             "v_add_f32 v59, v59, v63\n"
-	             "ds_write_b32 v62, v59\n"
-	             "s_sub_u32 %[t0], %[e], 0x1000000\n"
-	             "s_cmp_ge_u32 %[t0], 0x7f000000\n"
-	             "s_cbranch_scc1 624f\n"
-	             "623:\n"
-	             "s_lshr_b32 %[t0], %[e], 24\n"
-	             "s_sub_u32 %[left], %[left], %[t0]\n"
-	             "s_cbranch_scc1 626f\n"
-	             "s_lshr_b64 s[84:85], s[84:85], %[t0]\n"
-	             "s_sub_u32 %[have], %[have], %[t0]\n"
-	             "v_mad_u32_u24 v59, %[e], %[vd4], %[row]\n"
-	             "global_load_dword v63, v59, %[vq]\n"
-	             "v_mov_b32 v62, v58\n"
-	             "v_add_u32 v58, v58, %[inc]\n"
-	             "s_add_u32 %[neg], %[neg], 1\n"
-	             "s_cbranch_scc0 79b\n"
-	             "s_mov_b32 %[st], 0\n"
-	             "s_branch 72f\n"
-	             "624:\n" // a link to a second-level table, or length 0
-	             "s_bitcmp1_b32 %[e], 31\n"
-	             "s_cbranch_scc0 625f\n"
-	             "s_bfe_u32 %[t0], %[e], 0x70018\n"
-	             "s_lshr_b32 %[t1], s84, %[bits]\n"
-	             "s_bfm_b32 %[t0], %[t0], 0\n"
-	             "s_and_b32 %[t1], %[t1], %[t0]\n"
-	             "s_and_b32 %[t0], %[e], 0xffffff\n"
-	             "s_add_u32 %[t0], %[t0], %[t1]\n"
-	             "s_lshl_b32 %[t0], %[t0], 2\n"
-	             "s_load_dword %[e], %[lut], %[t0]\n"
-	             "s_waitcnt lgkmcnt(0)\n"
-	             "s_cmp_lt_u32 %[e], 0x1000000\n"
-	             "s_cbranch_scc0 623b\n"
-	             "625:\n"
-	             "s_mov_b32 %[st], 1\n"
-	             "v_mov_b32 v62, %[dump]\n"
-	             "s_branch 72f\n"
-	             "626:\n"
-	             "s_mov_b32 %[st], 2\n"
-	             "v_mov_b32 v62, %[dump]\n"
-	             "s_branch 72f\n"
-	             "71:\n" // ---- leaving behind a slot-A codeword: B is the older one
-	             "s_waitcnt vmcnt(0)\n"
-	             "ds_read_b32 v59, v62\n"
-	             "s_waitcnt lgkmcnt(0)\n"
-	             "v_add_f32 v59, v59, v63\n"
-	             "ds_write_b32 v62, v59\n"
-	             "ds_read_b32 v59, v60\n"
-	             "s_waitcnt lgkmcnt(0)\n"
-	             "v_add_f32 v59, v59, v61\n"
-	             "ds_write_b32 v60, v59\n"
-	             "s_branch 73f\n"
-	             "72:\n" // ---- leaving behind a slot-B codeword: A is the older one
-	             "s_waitcnt vmcnt(0)\n"
-	             "ds_read_b32 v59, v60\n"
-	             "s_waitcnt lgkmcnt(0)\n"
-	             "v_add_f32 v59, v59, v61\n"
-	             "ds_write_b32 v60, v59\n"
-	             "ds_read_b32 v59, v62\n"
-	             "s_waitcnt lgkmcnt(0)\n"
-	             "v_add_f32 v59, v59, v63\n"
-	             "ds_write_b32 v62, v59\n"
-	             "73:\n"
-	             "s_waitcnt lgkmcnt(0)\n"
-	             "s_mov_b64 %[win], s[84:85]\n"
-	             : [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),
-	               [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1)
-	             : [w] "s"(r.w), [lut] "s"(lut), [vq] "s"(vq), [mask] "s"(lut_mask), [bits] "s"(lut_bits), [at] "v"(at), [inc] "v"(inc),
-	               [row] "v"(row), [vd4] "v"(vdims4), [dump] "v"(dump)
-	             : "s84", "s85", "s86", "s87", "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory");
-	todo = 0u - neg;
-	return st;
-}
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__)
-// One codeword of lw_ent_range through pending slot P (accumulator address) / PV (value): see lw_ent_run for the steps.
-// NEXT: the other slot's step; PH_DONE: the slot the next partition starts with; PH_EXIT: drain order when leaving here
-// (this slot is empty then: the other one first).
-#define LW_ENT_RANGE_STEP(P, PV, NEXT, PH_DONE, PH_EXIT)                                                              \
-	"s_cmp_lt_u32 %[have], 32\n"                                                                                      \
-	"s_cbranch_scc0 " P "2f\n"                                                                                        \
+// ---- The steady state of the residue decode, by hand (gfx950).  One CU's ONE scalar unit serves its 16 resident packets, so
+// the scalar instructions per codeword pace this kernel: here 10 + 4 branches / waits, 4 vector instructions, one table
+// look-up, one row load, one LDS read-modify-write -- what the compiler makes of the same loop in C++ is ~50 + 19.
+//   entry = lut[window & mask] | add the vector of the codeword before the last one | link -> second-level entry |
+//   bounds (left -= len borrows: the code runs past the end) | window >>= len | bits -= len borrows: refill | row load
+// Fixed registers inside the statements (clobbers; everything else is an operand):
+//   s[64:65] bit window, s[66:67] scratch pair, s[68:75] the run record, s[76:77] table, s[78:79] rows, s80 mask, s81 table bits
+//   v53 scratch, v54 dims * 4, v55 the lane's byte in a row, v56 its step per codeword, v57 digit address, v58 its accumulator
+//   address for the next codeword, v59 scratch, v60/v61 and v62/v63 the two pending vectors (address, value)
+// %[have] holds the window's bit count MINUS 32 inside the statements (its borrow is the refill test).
+// The vectors are added TWO codewords behind the decoder (two pending slots used in turn: the step exists twice): a row load
+// has two look-ups to arrive in; one behind, every codeword waited ~350 cycles for its predecessor's row.  Additions to one
+// accumulator keep their order (the slots are a FIFO; within a run no two codewords touch the same element).  Every statement
+// starts and ends with nothing pending and no load outstanding.
+#define LW_ENT_ASM_REFILL /* the window has < 32 bits: %[have] (biased) has wrapped below zero */                      \
+	"s_add_u32 %[have], %[have], 32\n"                                                                                \
 	"s_mov_b32 s66, %[nxt]\n"                                                                                         \
+	"s_mov_b32 s67, 0\n"                                                                                              \
 	"s_lshl_b64 s[66:67], s[66:67], %[have]\n"                                                                        \
 	"s_or_b64 s[64:65], s[64:65], s[66:67]\n"                                                                         \
-	"s_add_u32 %[have], %[have], 32\n"                                                                                \
 	"s_load_dword %[nxt], %[w], %[wo]\n"                                                                              \
-	"s_add_u32 %[wo], %[wo], 4\n"                                                                                     \
-	"s_mov_b32 s67, 0\n" P "2:\n"                                                                                     \
-	"s_and_b32 %[t0], s64, s80\n"                                                                                    \
+	"s_add_u32 %[wo], %[wo], 4\n"
+#define LW_ENT_ASM_ENTER /* the window into its pair, the bit count biased, >= 32 bits in the window */                 \
+	"s_mov_b64 s[64:65], %[win]\n"                                                                                    \
+	"s_sub_u32 %[have], %[have], 32\n"                                                                                \
+	"s_cbranch_scc0 10f\n" LW_ENT_ASM_REFILL "10:\n"                                                                  \
+	"v_mov_b32 v60, %[dump]\n"                                                                                        \
+	"v_mov_b32 v61, 0\n"                                                                                              \
+	"v_mov_b32 v62, %[dump]\n"                                                                                        \
+	"v_mov_b32 v63, 0\n"
+// One codeword through pending slot P (accumulator address) / PV (value).  NEXT: the other slot's step; PH_DONE: the slot
+// the next run starts with; PH_EXIT: drain order when leaving from here (this slot is empty then: the other one first).
+#define LW_ENT_ASM_STEP(P, PV, NEXT, PH_DONE, PH_EXIT)                                                                \
+	"s_and_b32 %[t0], s64, s80\n"                                                                                     \
 	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
 	"s_load_dword %[e], s[76:77], %[t0]\n"                                                                            \
 	"ds_read_b32 v59, v" P "\n"                                                                                       \
 	"s_waitcnt vmcnt(1) lgkmcnt(0)\n"                                                                                 \
 	"v_add_f32 v59, v59, v" PV "\n"                                                                                   \
 	"ds_write_b32 v" P ", v59\n"                                                                                      \
-	"s_sub_u32 %[t0], %[e], 0x1000000\n"                                                                              \
-	"s_cmp_ge_u32 %[t0], 0x7f000000\n"                                                                                \
+	"s_cmp_lt_i32 %[e], 0\n" /* a link to a second-level table, or "not in the tables" */                            \
 	"s_cbranch_scc1 " P "4f\n" P "3:\n"                                                                               \
 	"s_lshr_b32 %[t0], %[e], 24\n"                                                                                    \
 	"s_sub_u32 %[left], %[left], %[t0]\n"                                                                             \
 	"s_cbranch_scc1 " P "6f\n"                                                                                        \
 	"s_lshr_b64 s[64:65], s[64:65], %[t0]\n"                                                                          \
 	"s_sub_u32 %[have], %[have], %[t0]\n"                                                                             \
+	"s_cbranch_scc0 " P "2f\n" LW_ENT_ASM_REFILL P "2:\n"                                                             \
 	"v_mad_u32_u24 v59, %[e], v54, v55\n"                                                                             \
 	"global_load_dword v" PV ", v59, s[78:79]\n"                                                                      \
 	"v_mov_b32 v" P ", v58\n"                                                                                         \
@@ -659,10 +510,10 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 	"s_cbranch_scc0 " NEXT "\n"                                                                                       \
 	"s_mov_b32 %[ph], " PH_DONE "\n"                                                                                  \
 	"s_branch 28f\n" P "4:\n"                                                                                         \
-	"s_bitcmp1_b32 %[e], 31\n"                                                                                        \
-	"s_cbranch_scc0 " P "5f\n"                                                                                        \
 	"s_bfe_u32 %[t0], %[e], 0x70018\n"                                                                                \
-	"s_lshr_b32 %[t1], s64, s81\n"                                                                                   \
+	"s_cmp_eq_u32 %[t0], 0x7f\n"                                                                                      \
+	"s_cbranch_scc1 " P "5f\n"                                                                                        \
+	"s_lshr_b32 %[t1], s64, s81\n"                                                                                    \
 	"s_bfm_b32 %[t0], %[t0], 0\n"                                                                                     \
 	"s_and_b32 %[t1], %[t1], %[t0]\n"                                                                                 \
 	"s_and_b32 %[t0], %[e], 0xffffff\n"                                                                               \
@@ -670,7 +521,7 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
 	"s_load_dword %[e], s[76:77], %[t0]\n"                                                                            \
 	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
-	"s_cmp_lt_u32 %[e], 0x1000000\n"                                                                                  \
+	"s_cmp_lt_i32 %[e], 0\n"                                                                                          \
 	"s_cbranch_scc0 " P "3b\n" P "5:\n"                                                                               \
 	"s_mov_b32 %[st], 1\n"                                                                                            \
 	"v_mov_b32 v" P ", %[dump]\n"                                                                                     \
@@ -680,18 +531,63 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 	"v_mov_b32 v" P ", %[dump]\n"                                                                                     \
 	"s_mov_b32 %[ph], " PH_EXIT "\n"                                                                                  \
 	"s_branch 70f\n"
+#define LW_ENT_ASM_FLUSH(P, PV)                                                                                       \
+	"ds_read_b32 v59, v" P "\n"                                                                                       \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"v_add_f32 v59, v59, v" PV "\n"                                                                                   \
+	"ds_write_b32 v" P ", v59\n"
+#define LW_ENT_ASM_LEAVE /* the older pending vector first (ph: the slot the next codeword would have used) */          \
+	"70:\n"                                                                                                           \
+	"s_waitcnt vmcnt(0)\n"                                                                                            \
+	"s_cmp_eq_u32 %[ph], 0\n"                                                                                         \
+	"s_cbranch_scc0 72f\n" LW_ENT_ASM_FLUSH("60", "61") LW_ENT_ASM_FLUSH("62", "63") "s_branch 73f\n"                \
+	"72:\n" LW_ENT_ASM_FLUSH("62", "63") LW_ENT_ASM_FLUSH("60", "61") "73:\n"                                         \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"s_add_u32 %[have], %[have], 32\n"                                                                                \
+	"s_mov_b64 %[win], s[64:65]\n"
+#define LW_ENT_ASM_CLOBBERS                                                                                           \
+	"s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "v53",  \
+		"v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
 
-// A RANGE of partitions of one vector in one pass, by hand: per partition the class digit (LDS), the test whether the class
-// has a book in this pass, the (residue, class, pass) record, the lanes' accumulator addresses, then the run of codewords as
-// in lw_ent_run -- with the two pending vectors carried from one partition into the next (nothing is drained between runs).
-// In C++ a partition cost ~100 scalar instructions before its first codeword and a drain behind its last one.
+// The run of ONE partition (the C++ path behind a return of lw_ent_range, and the vectors it does not take).
+// Returns 0: `todo` codewords done (todo = 0); 1: the codeword at the head of the window needs the tree, nothing of it
+// consumed; 2: the codeword runs past the end of the packet.  `at` is not changed: the caller advances it by inc per codeword.
+__device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader &r, const LW_K uint32_t *lut, const LW_K float *vq,
+		uint32_t lut_mask, uint32_t lut_bits, uint32_t &todo, uint32_t at, uint32_t inc, uint32_t row, uint32_t vdims4, uint32_t dump)
+{
+	uint32_t st, t0, t1, e, ph = 0;
+	uint32_t neg = LW_ENT_SCALAR(0u - todo); // (wave-uniform like everything scalar here; the compiler keeps this one in a vector register)
+	asm volatile(LW_ENT_ASM_ENTER
+	             "s_mov_b64 s[76:77], %[lut]\n"
+	             "s_mov_b64 s[78:79], %[vq]\n"
+	             "s_mov_b32 s80, %[mask]\n"
+	             "s_mov_b32 s81, %[bits]\n"
+	             "v_mov_b32 v54, %[vd4]\n"
+	             "v_mov_b32 v55, %[row]\n"
+	             "v_mov_b32 v56, %[inc]\n"
+	             "v_mov_b32 v58, %[at]\n"
+	             "79:\n" LW_ENT_ASM_STEP("60", "61", "80f", "1", "1") "80:\n" LW_ENT_ASM_STEP("62", "63", "79b", "0", "0")
+	             "28:\n"
+	             "s_mov_b32 %[st], 0\n" LW_ENT_ASM_LEAVE
+	             : [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),
+	               [ph] "+s"(ph), [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1)
+	             : [w] "s"(r.w), [lut] "s"(lut), [vq] "s"(vq), [mask] "s"(lut_mask), [bits] "s"(lut_bits), [at] "v"(at), [inc] "v"(inc),
+	               [row] "v"(row), [vd4] "v"(vdims4), [dump] "v"(dump)
+	             : LW_ENT_ASM_CLOBBERS);
+	todo = 0u - neg;
+	return st;
+}
+
+// A RANGE of partitions of one vector in one pass: per partition the class digit (LDS), the test whether the class has a book
+// in this pass, the (residue, class, pass) record, the lanes' accumulator addresses, then the run of codewords -- with the two
+// pending vectors carried from one partition into the next (nothing is drained between runs).  In C++ a partition cost ~100
+// scalar instructions before its first codeword and a drain behind its last one.
 //   DEINT 0: element el + lane * step of the accumulators (el includes the channel's base); 2: the interleaved vector of two
 //   channels: element a = el + lane goes to (a & 1) * half + (a >> 1).
 // n: partitions to visit; on return the ones not visited yet (the one a return code names included).  Returns 0: all
 // visited; 1: a codeword of partition (first + visited) needs the tree -- `todo` of its codewords are left, that one
 // included; 2: a codeword runs past the end of the packet; 3: that partition is not one for this loop (single-entry book,
-// dimension not a multiple of the channel count): not started.  Starts and ends with nothing pending, no load outstanding.
-// Scratch: s[64:81], v53-v63, vcc.
+// a dimension that does not divide the partition or is not a multiple of the channel count): not started.
 template <int DEINT>
 __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntReader &r, const LW_K LwEntRun *runs, const LW_K uint32_t *lut,
 		const LW_K float *vq, uint32_t pass, uint32_t &n, uint32_t cls_at, uint32_t el, uint32_t psize, uint32_t half, uint32_t acc_base,
@@ -705,14 +601,8 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntRead
 	n = LW_ENT_SCALAR(n); // (wave-uniform like everything scalar here; the compiler keeps the loop-carried ones in vector registers)
 	el = LW_ENT_SCALAR(el);
 	cls_at = LW_ENT_SCALAR(cls_at);
-#define LW_ENT_RANGE_HEAD                                                                                             \
-	"s_mov_b64 s[64:65], %[win]\n"                                                                                    \
-	"s_mov_b32 s67, 0\n"                                                                                              \
+#define LW_ENT_RANGE_HEAD LW_ENT_ASM_ENTER                                                                            \
 	"v_mov_b32 v57, %[cls]\n"                                                                                         \
-	"v_mov_b32 v60, %[dump]\n"                                                                                        \
-	"v_mov_b32 v61, 0\n"                                                                                              \
-	"v_mov_b32 v62, %[dump]\n"                                                                                        \
-	"v_mov_b32 v63, 0\n"                                                                                              \
 	"20:\n" /* ---- the next partition: its class digit | the passes of that class << 8 */                           \
 	"ds_read_u16 v59, v57\n"                                                                                          \
 	"v_add_u32 v57, 2, v57\n"                                                                                         \
@@ -731,8 +621,8 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntRead
 	"s_addc_u32 s77, %[luthi], 0\n"                                                                                   \
 	"s_add_u32 s78, %[vqlo], s69\n"                                                                                   \
 	"s_addc_u32 s79, %[vqhi], 0\n"                                                                                    \
-	"s_and_b32 s81, s70, 0xff\n"                                                                                     \
-	"s_bfm_b32 s80, s81, 0\n"                                                                                       \
+	"s_and_b32 s81, s70, 0xff\n"                                                                                      \
+	"s_bfm_b32 s80, s81, 0\n"                                                                                         \
 	"s_bfe_u32 %[t0], s70, 0x80008\n" /* dims */                                                                      \
 	"s_sub_u32 %[neg], 0, s72\n"                                                                                      \
 	"v_cmp_gt_u32 vcc, %[t0], %[lane]\n" /* this lane holds an element of the codewords' vectors */                   \
@@ -753,18 +643,13 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntRead
 	"v_lshl_add_u32 v59, v59, 2, v53\n"                                                                               \
 	"v_add_u32 v59, %[accbase], v59\n"                                                                                \
 	"s_lshl_b32 %[t1], %[t0], 1\n"
-#define LW_ENT_RANGE_FLUSH(P, PV)                                                                                     \
-	"ds_read_b32 v59, v" P "\n"                                                                                       \
-	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
-	"v_add_f32 v59, v59, v" PV "\n"                                                                                   \
-	"ds_write_b32 v" P ", v59\n"
 #define LW_ENT_RANGE_TAIL                                                                                             \
 	"v_cndmask_b32 v58, %[dump], v59, vcc\n"                                                                          \
 	"v_mov_b32 v59, %[t1]\n"                                                                                          \
 	"v_cndmask_b32 v56, 0, v59, vcc\n"                                                                                \
 	"s_cmp_eq_u32 %[ph], 0\n"                                                                                         \
 	"s_cbranch_scc0 80f\n"                                                                                            \
-	"79:\n" LW_ENT_RANGE_STEP("60", "61", "80f", "1", "1") "80:\n" LW_ENT_RANGE_STEP("62", "63", "79b", "0", "0")     \
+	"79:\n" LW_ENT_ASM_STEP("60", "61", "80f", "1", "1") "80:\n" LW_ENT_ASM_STEP("62", "63", "79b", "0", "0")         \
 	"28:\n" /* ---- on to the next partition */                                                                       \
 	"s_add_u32 %[el], %[el], %[psize]\n"                                                                              \
 	"s_sub_u32 %[n], %[n], 1\n"                                                                                       \
@@ -773,22 +658,14 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntRead
 	"s_mov_b32 %[st], 0\n"                                                                                            \
 	"s_branch 70f\n"                                                                                                  \
 	"33:\n"                                                                                                           \
-	"s_mov_b32 %[st], 3\n"                                                                                            \
-	"70:\n" /* ---- leaving: the older pending vector first (ph: the slot the next codeword would have used) */       \
-	"s_waitcnt vmcnt(0)\n"                                                                                            \
-	"s_cmp_eq_u32 %[ph], 0\n"                                                                                         \
-	"s_cbranch_scc0 72f\n" LW_ENT_RANGE_FLUSH("60", "61") LW_ENT_RANGE_FLUSH("62", "63") "s_branch 73f\n"            \
-	"72:\n" LW_ENT_RANGE_FLUSH("62", "63") LW_ENT_RANGE_FLUSH("60", "61") "73:\n"                                     \
-	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
-	"s_mov_b64 %[win], s[64:65]\n"
+	"s_mov_b32 %[st], 3\n" LW_ENT_ASM_LEAVE
 #define LW_ENT_RANGE_OPERANDS                                                                                         \
 	: [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),  \
 	  [n] "+s"(n), [el] "+s"(el), [ph] "+s"(ph), [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1)          \
 	: [w] "s"(r.w), [runs] "s"(runs), [lutlo] "s"(lutlo), [luthi] "s"(luthi), [vqlo] "s"(vqlo), [vqhi] "s"(vqhi),        \
 	  [pass32] "s"(pass32), [passmask] "s"(passmask), [dper] "s"(dper), [psize] "s"(psize), [cls] "s"(cls_at),           \
 	  [accbase] "s"(acc_base), [half4] "s"(half4), [lane] "v"(lane), [dump] "v"(dump)                                    \
-	: "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",  \
-	  "s81", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
+	: LW_ENT_ASM_CLOBBERS
 	if (DEINT == 0)
 		asm volatile(LW_ENT_RANGE_HEAD LW_ENT_RANGE_PLACE0 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
 	else
@@ -913,7 +790,7 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 			// rare -- a code beyond the two table levels, the end of the packet
 			pend.flush(out);
 			const uint32_t before = todo;
-			const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, e, at, inc, row, vdims4, pend.dump);
+			const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, at, inc, row, vdims4, pend.dump);
 			at += inc * (before - todo);
 			if (st == 0u)
 				break;
@@ -921,6 +798,7 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 				r.left = 0;
 				return false;
 			}
+			e = r.probe(lut, lut_mask); // (st 1: nothing consumed; finish() takes the codeword to the tree)
 #else
 			e = r.probe(lut, lut_mask); // this codeword's table look-up is under way ...
 			pend.flush(out);            // ... while the previous codeword's vector is added
