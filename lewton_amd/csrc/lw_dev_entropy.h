@@ -276,10 +276,9 @@ struct LwEntReader {
 	LW_HD bool finish(const LW_K uint32_t *lut, uint32_t lut_bits, const LW_K int32_t *nodes, uint32_t e, uint32_t &sym)
 	{
 		if (LW_ENT_SPECIAL(e)) {
-			if (e >= LW_ENT_WALK)
-				return walk(nodes, sym);
-			e = lut[(e & 0xffffffu) + (((uint32_t)win >> lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
-			if (LW_ENT_SPECIAL(e))
+			if (e < LW_ENT_WALK) // a link
+				e = lut[(e & 0xffffffu) + (((uint32_t)win >> lut_bits) & ((1u << ((e >> 24) & 0x7fu)) - 1u))];
+			if (LW_ENT_SPECIAL(e)) // (one call site: walk() is inlined wherever finish() is)
 				return walk(nodes, sym);
 		}
 		const uint32_t len = e >> 24;
@@ -485,11 +484,13 @@ LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t
 	"v_mov_b32 v62, %[dump]\n"                                                                                        \
 	"v_mov_b32 v63, 0\n"
 // One codeword through pending slot P (accumulator address) / PV (value).  NEXT: the other slot's step; PH_DONE: the slot
-// the next run starts with; PH_EXIT: drain order when leaving from here (this slot is empty then: the other one first).
-#define LW_ENT_ASM_STEP(P, PV, NEXT, PH_DONE, PH_EXIT)                                                                \
-	"s_and_b32 %[t0], s64, s80\n"                                                                                     \
+// the next run starts with; PH_EXIT: drain order when leaving from here (this slot is empty then: the other one first);
+// LUT .. INC: where the run's table, rows, mask, table bits, dims * 4, row byte and step live (fixed registers in
+// lw_ent_range, operands in lw_ent_run: there every register the statement clobbers is one the C++ around it has to spill).
+#define LW_ENT_ASM_STEP(P, PV, NEXT, PH_DONE, PH_EXIT, LUT, VQ, MASK, BITS, VD4, ROW, INC)                                                                \
+	"s_and_b32 %[t0], s64, " MASK "\n"                                                                                     \
 	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
-	"s_load_dword %[e], s[76:77], %[t0]\n"                                                                            \
+	"s_load_dword %[e], " LUT ", %[t0]\n"                                                                            \
 	"ds_read_b32 v59, v" P "\n"                                                                                       \
 	"s_waitcnt vmcnt(1) lgkmcnt(0)\n"                                                                                 \
 	"v_add_f32 v59, v59, v" PV "\n"                                                                                   \
@@ -502,10 +503,10 @@ LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t
 	"s_lshr_b64 s[64:65], s[64:65], %[t0]\n"                                                                          \
 	"s_sub_u32 %[have], %[have], %[t0]\n"                                                                             \
 	"s_cbranch_scc0 " P "2f\n" LW_ENT_ASM_REFILL P "2:\n"                                                             \
-	"v_mad_u32_u24 v59, %[e], v54, v55\n"                                                                             \
-	"global_load_dword v" PV ", v59, s[78:79]\n"                                                                      \
+	"v_mad_u32_u24 v59, %[e], " VD4 ", " ROW "\n"                                                                             \
+	"global_load_dword v" PV ", v59, " VQ "\n"                                                                      \
 	"v_mov_b32 v" P ", v58\n"                                                                                         \
-	"v_add_u32 v58, v58, v56\n"                                                                                       \
+	"v_add_u32 v58, v58, " INC "\n"                                                                                       \
 	"s_add_u32 %[neg], %[neg], 1\n"                                                                                   \
 	"s_cbranch_scc0 " NEXT "\n"                                                                                       \
 	"s_mov_b32 %[ph], " PH_DONE "\n"                                                                                  \
@@ -513,13 +514,13 @@ LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t
 	"s_bfe_u32 %[t0], %[e], 0x70018\n"                                                                                \
 	"s_cmp_eq_u32 %[t0], 0x7f\n"                                                                                      \
 	"s_cbranch_scc1 " P "5f\n"                                                                                        \
-	"s_lshr_b32 %[t1], s64, s81\n"                                                                                    \
+	"s_lshr_b32 %[t1], s64, " BITS "\n"                                                                                    \
 	"s_bfm_b32 %[t0], %[t0], 0\n"                                                                                     \
 	"s_and_b32 %[t1], %[t1], %[t0]\n"                                                                                 \
 	"s_and_b32 %[t0], %[e], 0xffffff\n"                                                                               \
 	"s_add_u32 %[t0], %[t0], %[t1]\n"                                                                                 \
 	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
-	"s_load_dword %[e], s[76:77], %[t0]\n"                                                                            \
+	"s_load_dword %[e], " LUT ", %[t0]\n"                                                                            \
 	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
 	"s_cmp_lt_i32 %[e], 0\n"                                                                                          \
 	"s_cbranch_scc0 " P "3b\n" P "5:\n"                                                                               \
@@ -531,6 +532,7 @@ LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t
 	"v_mov_b32 v" P ", %[dump]\n"                                                                                     \
 	"s_mov_b32 %[ph], " PH_EXIT "\n"                                                                                  \
 	"s_branch 70f\n"
+#define LW_ENT_ASM_STEP_V(...) LW_ENT_ASM_STEP(__VA_ARGS__) // (the register list of a caller is one macro: expanded first)
 #define LW_ENT_ASM_FLUSH(P, PV)                                                                                       \
 	"ds_read_b32 v59, v" P "\n"                                                                                       \
 	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
@@ -550,30 +552,25 @@ LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t
 		"v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
 
 // The run of ONE partition (the C++ path behind a return of lw_ent_range, and the vectors it does not take).
-// Returns 0: `todo` codewords done (todo = 0); 1: the codeword at the head of the window needs the tree, nothing of it
-// consumed; 2: the codeword runs past the end of the packet.  `at` is not changed: the caller advances it by inc per codeword.
+// Returns 0: `todo` codewords done (todo = 0); 1: the codeword at the head of the window needs the tree (its table entry in
+// `e`), nothing of it consumed; 2: the codeword runs past the end of the packet.  `at` is not changed: the caller advances it by inc per codeword.
 __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader &r, const LW_K uint32_t *lut, const LW_K float *vq,
-		uint32_t lut_mask, uint32_t lut_bits, uint32_t &todo, uint32_t at, uint32_t inc, uint32_t row, uint32_t vdims4, uint32_t dump)
+		uint32_t lut_mask, uint32_t lut_bits, uint32_t &todo, uint32_t &e, uint32_t at, uint32_t inc, uint32_t row, uint32_t vdims4,
+		uint32_t dump)
 {
-	uint32_t st, t0, t1, e, ph = 0;
+	uint32_t st, t0, t1, ph = 0;
 	uint32_t neg = LW_ENT_SCALAR(0u - todo); // (wave-uniform like everything scalar here; the compiler keeps this one in a vector register)
+#define LW_ENT_RUN_REGS "%[lut]", "%[vq]", "%[mask]", "%[bits]", "%[vd4]", "%[row]", "%[inc]"
 	asm volatile(LW_ENT_ASM_ENTER
-	             "s_mov_b64 s[76:77], %[lut]\n"
-	             "s_mov_b64 s[78:79], %[vq]\n"
-	             "s_mov_b32 s80, %[mask]\n"
-	             "s_mov_b32 s81, %[bits]\n"
-	             "v_mov_b32 v54, %[vd4]\n"
-	             "v_mov_b32 v55, %[row]\n"
-	             "v_mov_b32 v56, %[inc]\n"
 	             "v_mov_b32 v58, %[at]\n"
-	             "79:\n" LW_ENT_ASM_STEP("60", "61", "80f", "1", "1") "80:\n" LW_ENT_ASM_STEP("62", "63", "79b", "0", "0")
+	             "79:\n" LW_ENT_ASM_STEP_V("60", "61", "80f", "1", "1", LW_ENT_RUN_REGS) "80:\n" LW_ENT_ASM_STEP_V("62", "63", "79b", "0", "0", LW_ENT_RUN_REGS)
 	             "28:\n"
 	             "s_mov_b32 %[st], 0\n" LW_ENT_ASM_LEAVE
 	             : [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),
 	               [ph] "+s"(ph), [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1)
 	             : [w] "s"(r.w), [lut] "s"(lut), [vq] "s"(vq), [mask] "s"(lut_mask), [bits] "s"(lut_bits), [at] "v"(at), [inc] "v"(inc),
 	               [row] "v"(row), [vd4] "v"(vdims4), [dump] "v"(dump)
-	             : LW_ENT_ASM_CLOBBERS);
+	             : "s64", "s65", "s66", "s67", "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory");
 	todo = 0u - neg;
 	return st;
 }
@@ -643,13 +640,14 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntRead
 	"v_lshl_add_u32 v59, v59, 2, v53\n"                                                                               \
 	"v_add_u32 v59, %[accbase], v59\n"                                                                                \
 	"s_lshl_b32 %[t1], %[t0], 1\n"
+#define LW_ENT_RANGE_REGS "s[76:77]", "s[78:79]", "s80", "s81", "v54", "v55", "v56"
 #define LW_ENT_RANGE_TAIL                                                                                             \
 	"v_cndmask_b32 v58, %[dump], v59, vcc\n"                                                                          \
 	"v_mov_b32 v59, %[t1]\n"                                                                                          \
 	"v_cndmask_b32 v56, 0, v59, vcc\n"                                                                                \
 	"s_cmp_eq_u32 %[ph], 0\n"                                                                                         \
 	"s_cbranch_scc0 80f\n"                                                                                            \
-	"79:\n" LW_ENT_ASM_STEP("60", "61", "80f", "1", "1") "80:\n" LW_ENT_ASM_STEP("62", "63", "79b", "0", "0")         \
+	"79:\n" LW_ENT_ASM_STEP_V("60", "61", "80f", "1", "1", LW_ENT_RANGE_REGS) "80:\n" LW_ENT_ASM_STEP_V("62", "63", "79b", "0", "0", LW_ENT_RANGE_REGS) \
 	"28:\n" /* ---- on to the next partition */                                                                       \
 	"s_add_u32 %[el], %[el], %[psize]\n"                                                                              \
 	"s_sub_u32 %[n], %[n], 1\n"                                                                                       \
@@ -790,7 +788,7 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 			// rare -- a code beyond the two table levels, the end of the packet
 			pend.flush(out);
 			const uint32_t before = todo;
-			const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, at, inc, row, vdims4, pend.dump);
+			const uint32_t st = lw_ent_run(r, lut, vq, lut_mask, lut_bits, todo, e, at, inc, row, vdims4, pend.dump);
 			at += inc * (before - todo);
 			if (st == 0u)
 				break;
@@ -798,7 +796,6 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 				r.left = 0;
 				return false;
 			}
-			e = r.probe(lut, lut_mask); // (st 1: nothing consumed; finish() takes the codeword to the tree)
 #else
 			e = r.probe(lut, lut_mask); // this codeword's table look-up is under way ...
 			pend.flush(out);            // ... while the previous codeword's vector is added
