@@ -551,6 +551,7 @@ LW_HD void lw_ent_floor_record(const LW_K LwEntFloor &fl, LwEntPosts y, uint16_t
 	"s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "v53",  \
 		"v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
 
+#define LW_ENT_RUN_REGS "%[lut]", "%[vq]", "%[mask]", "%[bits]", "%[vd4]", "%[row]", "%[inc]"
 // The run of ONE partition (the C++ path behind a return of lw_ent_range, and the vectors it does not take).
 // Returns 0: `todo` codewords done (todo = 0); 1: the codeword at the head of the window needs the tree (its table entry in
 // `e`), nothing of it consumed; 2: the codeword runs past the end of the packet.  `at` is not changed: the caller advances it by inc per codeword.
@@ -560,7 +561,6 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 {
 	uint32_t st, t0, t1, ph = 0;
 	uint32_t neg = LW_ENT_SCALAR(0u - todo); // (wave-uniform like everything scalar here; the compiler keeps this one in a vector register)
-#define LW_ENT_RUN_REGS "%[lut]", "%[vq]", "%[mask]", "%[bits]", "%[vd4]", "%[row]", "%[inc]"
 	asm volatile(LW_ENT_ASM_ENTER
 	             "v_mov_b32 v58, %[at]\n"
 	             "79:\n" LW_ENT_ASM_STEP_V("60", "61", "80f", "1", "1", LW_ENT_RUN_REGS) "80:\n" LW_ENT_ASM_STEP_V("62", "63", "79b", "0", "0", LW_ENT_RUN_REGS)
@@ -575,29 +575,7 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 	return st;
 }
 
-// A RANGE of partitions of one vector in one pass: per partition the class digit (LDS), the test whether the class has a book
-// in this pass, the (residue, class, pass) record, the lanes' accumulator addresses, then the run of codewords -- with the two
-// pending vectors carried from one partition into the next (nothing is drained between runs).  In C++ a partition cost ~100
-// scalar instructions before its first codeword and a drain behind its last one.
-//   DEINT 0: element el + lane * step of the accumulators (el includes the channel's base); 2: the interleaved vector of two
-//   channels: element a = el + lane goes to (a & 1) * half + (a >> 1).
-// n: partitions to visit; on return the ones not visited yet (the one a return code names included).  Returns 0: all
-// visited; 1: a codeword of partition (first + visited) needs the tree -- `todo` of its codewords are left, that one
-// included; 2: a codeword runs past the end of the packet; 3: that partition is not one for this loop (single-entry book,
-// a dimension that does not divide the partition or is not a multiple of the channel count): not started.
-template <int DEINT>
-__device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntReader &r, const LW_K LwEntRun *runs, const LW_K uint32_t *lut,
-		const LW_K float *vq, uint32_t pass, uint32_t &n, uint32_t cls_at, uint32_t el, uint32_t psize, uint32_t half, uint32_t acc_base,
-		uint32_t dump, uint32_t &todo)
-{
-	uint32_t st, t0, t1, e, ph = 0, neg = 0;
-	const uint32_t lane = LW_ENT_LANE();
-	const uint32_t lutlo = (uint32_t)(uintptr_t)lut, luthi = (uint32_t)((uintptr_t)lut >> 32);
-	const uint32_t vqlo = (uint32_t)(uintptr_t)vq, vqhi = (uint32_t)((uintptr_t)vq >> 32);
-	const uint32_t pass32 = pass * 32u, passmask = 0x100u << pass, dper = DEINT == 2 ? 2u : 1u, half4 = half * 4u;
-	n = LW_ENT_SCALAR(n); // (wave-uniform like everything scalar here; the compiler keeps the loop-carried ones in vector registers)
-	el = LW_ENT_SCALAR(el);
-	cls_at = LW_ENT_SCALAR(cls_at);
+// ---- lw_ent_range's statement in pieces (DEINT 0 / 2 differ in the PLACE piece)
 #define LW_ENT_RANGE_HEAD LW_ENT_ASM_ENTER                                                                            \
 	"v_mov_b32 v57, %[cls]\n"                                                                                         \
 	"20:\n" /* ---- the next partition: its class digit | the passes of that class << 8 */                           \
@@ -664,6 +642,30 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntRead
 	  [pass32] "s"(pass32), [passmask] "s"(passmask), [dper] "s"(dper), [psize] "s"(psize), [cls] "s"(cls_at),           \
 	  [accbase] "s"(acc_base), [half4] "s"(half4), [lane] "v"(lane), [dump] "v"(dump)                                    \
 	: LW_ENT_ASM_CLOBBERS
+
+// A RANGE of partitions of one vector in one pass: per partition the class digit (LDS), the test whether the class has a book
+// in this pass, the (residue, class, pass) record, the lanes' accumulator addresses, then the run of codewords -- with the two
+// pending vectors carried from one partition into the next (nothing is drained between runs).  In C++ a partition cost ~100
+// scalar instructions before its first codeword and a drain behind its last one.
+//   DEINT 0: element el + lane * step of the accumulators (el includes the channel's base); 2: the interleaved vector of two
+//   channels: element a = el + lane goes to (a & 1) * half + (a >> 1).
+// n: partitions to visit; on return the ones not visited yet (the one a return code names included).  Returns 0: all
+// visited; 1: a codeword of partition (first + visited) needs the tree -- `todo` of its codewords are left, that one
+// included; 2: a codeword runs past the end of the packet; 3: that partition is not one for this loop (single-entry book,
+// a dimension that does not divide the partition or is not a multiple of the channel count): not started.
+template <int DEINT>
+__device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntReader &r, const LW_K LwEntRun *runs, const LW_K uint32_t *lut,
+		const LW_K float *vq, uint32_t pass, uint32_t &n, uint32_t cls_at, uint32_t el, uint32_t psize, uint32_t half, uint32_t acc_base,
+		uint32_t dump, uint32_t &todo)
+{
+	uint32_t st, t0, t1, e, ph = 0, neg = 0;
+	const uint32_t lane = LW_ENT_LANE();
+	const uint32_t lutlo = (uint32_t)(uintptr_t)lut, luthi = (uint32_t)((uintptr_t)lut >> 32);
+	const uint32_t vqlo = (uint32_t)(uintptr_t)vq, vqhi = (uint32_t)((uintptr_t)vq >> 32);
+	const uint32_t pass32 = pass * 32u, passmask = 0x100u << pass, dper = DEINT == 2 ? 2u : 1u, half4 = half * 4u;
+	n = LW_ENT_SCALAR(n); // (wave-uniform like everything scalar here; the compiler keeps the loop-carried ones in vector registers)
+	el = LW_ENT_SCALAR(el);
+	cls_at = LW_ENT_SCALAR(cls_at);
 	if (DEINT == 0)
 		asm volatile(LW_ENT_RANGE_HEAD LW_ENT_RANGE_PLACE0 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
 	else
