@@ -79,6 +79,8 @@ typedef uint8_t *LwEntFlags;
 #define LW_ENT_ACC(out, at) (*(LwEntAcc)(uintptr_t)(at))
 // a wave-uniform value read from LDS: into a scalar register, so that what is derived from it stays on the scalar unit
 #define LW_ENT_SCALAR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// (a 64-bit value or a pointer, as an asm statement's scalar operand)
+#define LW_ENT_SCALAR64(x) (((uint64_t)LW_ENT_SCALAR((uint64_t)(x) >> 32) << 32) | LW_ENT_SCALAR((uint32_t)(uint64_t)(x)))
 __device__ inline __attribute__((always_inline)) uint32_t lw_ent_mad24(uint32_t entry, uint32_t scale, uint32_t add)
 {
 	uint32_t r; // (entry & 0xffffff) * scale + add; entry is wave-uniform
@@ -576,9 +578,59 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_run(LwEntReader
 }
 
 // ---- lw_ent_range's statement in pieces (DEINT 0 / 2 differ in the PLACE piece)
-#define LW_ENT_RANGE_HEAD LW_ENT_ASM_ENTER                                                                            \
+#define LW_ENT_RANGE_ENTER LW_ENT_ASM_ENTER                                                                           \
 	"v_mov_b32 v57, %[cls]\n"                                                                                         \
-	"20:\n" /* ---- the next partition: its class digit | the passes of that class << 8 */                           \
+	"20:\n" /* ---- the next partition */
+// pass 0 of a single vector: the class word of a group of cpc partitions, decoded where the group starts (gc = partitions of
+// the current group still to visit); its digits go from the image's digit table to the LDS digits (lane q < cpc each one)
+#define LW_ENT_RANGE_CLASSWORD                                                                                        \
+	"s_cmp_lg_u32 %[gc], 0\n"                                                                                         \
+	"s_cbranch_scc1 29f\n"                                                                                            \
+	"s_and_b32 %[t0], s64, %[cbmask]\n"                                                                               \
+	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
+	"s_load_dword %[e], %[cblut], %[t0]\n"                                                                            \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"s_cmp_lt_i32 %[e], 0\n"                                                                                          \
+	"s_cbranch_scc1 24f\n"                                                                                            \
+	"23:\n"                                                                                                           \
+	"s_lshr_b32 %[t0], %[e], 24\n"                                                                                    \
+	"s_sub_u32 %[left], %[left], %[t0]\n"                                                                             \
+	"s_cbranch_scc1 26f\n"                                                                                            \
+	"s_lshr_b64 s[64:65], s[64:65], %[t0]\n"                                                                          \
+	"s_sub_u32 %[have], %[have], %[t0]\n"                                                                             \
+	"s_cbranch_scc0 22f\n" LW_ENT_ASM_REFILL "22:\n"                                                                 \
+	"s_and_b32 %[t0], %[e], 0xffffff\n"                                                                               \
+	"s_mul_i32 %[t0], %[t0], %[cpc]\n"                                                                                \
+	"v_lshl_add_u32 v59, %[t0], 1, %[q2]\n"                                                                           \
+	"global_load_ushort v53, v59, %[digits]\n"                                                                        \
+	"v_add_u32 v59, v57, %[q2]\n"                                                                                     \
+	"s_waitcnt vmcnt(0)\n"                                                                                            \
+	"ds_write_b16 v59, v53\n"                                                                                         \
+	"s_mov_b32 %[gc], %[cpc]\n"                                                                                       \
+	"s_branch 29f\n"                                                                                                  \
+	"24:\n"                                                                                                           \
+	"s_bfe_u32 %[t0], %[e], 0x70018\n"                                                                                \
+	"s_cmp_eq_u32 %[t0], 0x7f\n"                                                                                      \
+	"s_cbranch_scc1 25f\n"                                                                                            \
+	"s_lshr_b32 %[t1], s64, %[cbbits]\n"                                                                              \
+	"s_bfm_b32 %[t0], %[t0], 0\n"                                                                                     \
+	"s_and_b32 %[t1], %[t1], %[t0]\n"                                                                                 \
+	"s_and_b32 %[t0], %[e], 0xffffff\n"                                                                               \
+	"s_add_u32 %[t0], %[t0], %[t1]\n"                                                                                 \
+	"s_lshl_b32 %[t0], %[t0], 2\n"                                                                                    \
+	"s_load_dword %[e], %[cblut], %[t0]\n"                                                                            \
+	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
+	"s_cmp_lt_i32 %[e], 0\n"                                                                                          \
+	"s_cbranch_scc0 23b\n"                                                                                            \
+	"25:\n"                                                                                                           \
+	"s_mov_b32 %[st], 4\n"                                                                                            \
+	"s_branch 70f\n"                                                                                                  \
+	"26:\n"                                                                                                           \
+	"s_mov_b32 %[st], 2\n"                                                                                            \
+	"s_branch 70f\n"                                                                                                  \
+	"29:\n"                                                                                                           \
+	"s_sub_u32 %[gc], %[gc], 1\n"
+#define LW_ENT_RANGE_VISIT /* the partition's class digit | the passes of that class << 8 */                           \
 	"ds_read_u16 v59, v57\n"                                                                                          \
 	"v_add_u32 v57, 2, v57\n"                                                                                         \
 	"s_waitcnt lgkmcnt(0)\n"                                                                                          \
@@ -667,9 +719,49 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_range(LwEntRead
 	el = LW_ENT_SCALAR(el);
 	cls_at = LW_ENT_SCALAR(cls_at);
 	if (DEINT == 0)
-		asm volatile(LW_ENT_RANGE_HEAD LW_ENT_RANGE_PLACE0 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
+		asm volatile(LW_ENT_RANGE_ENTER LW_ENT_RANGE_VISIT LW_ENT_RANGE_PLACE0 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
 	else
-		asm volatile(LW_ENT_RANGE_HEAD LW_ENT_RANGE_PLACE2 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
+		asm volatile(LW_ENT_RANGE_ENTER LW_ENT_RANGE_VISIT LW_ENT_RANGE_PLACE2 LW_ENT_RANGE_TAIL LW_ENT_RANGE_OPERANDS);
+	todo = 0u - neg;
+	return st;
+}
+
+// The same for PASS 0 of a single vector, class words included: every group of cpc partitions starts with its class word
+// (an ordinary classbook whose digits are in the image), so the whole pass is one statement -- in C++ the class words cost a
+// statement per group, each with its drain.  gc: partitions of the current group still covered by the class word read last
+// (0 at a group's start).  Further return code 4: the class word at the head of the window needs the tree (nothing of it
+// consumed).
+template <int DEINT>
+__device__ inline __attribute__((always_inline)) uint32_t lw_ent_range_cw(LwEntReader &r, const LW_K LwEntRun *runs, const LW_K uint32_t *lut,
+		const LW_K float *vq, uint32_t &n, uint32_t cls_at, uint32_t el, uint32_t psize, uint32_t half, uint32_t acc_base, uint32_t dump,
+		uint32_t &todo, uint32_t gc, const LW_K uint32_t *cblut, uint32_t cbmask, uint32_t cbbits, const LW_K uint16_t *digits, uint32_t cpc)
+{
+	uint32_t st, t0, t1, e, ph = 0, neg = 0;
+	const uint32_t lane = LW_ENT_LANE();
+	const uint32_t lutlo = (uint32_t)(uintptr_t)lut, luthi = (uint32_t)((uintptr_t)lut >> 32);
+	const uint32_t vqlo = (uint32_t)(uintptr_t)vq, vqhi = (uint32_t)((uintptr_t)vq >> 32);
+	const uint32_t pass32 = 0u, passmask = 0x100u, dper = DEINT == 2 ? 2u : 1u, half4 = half * 4u;
+	const uint32_t q2 = 2u * (lane < cpc ? lane : cpc - 1u); // (the lanes beyond the last digit copy the last digit again)
+	n = LW_ENT_SCALAR(n);
+	el = LW_ENT_SCALAR(el);
+	cls_at = LW_ENT_SCALAR(cls_at);
+	gc = LW_ENT_SCALAR(gc);
+	cbmask = LW_ENT_SCALAR(cbmask);
+	cbbits = LW_ENT_SCALAR(cbbits);
+	cpc = LW_ENT_SCALAR(cpc);
+#define LW_ENT_RANGE_CW_OPERANDS                                                                                      \
+	: [win] "+s"(r.win), [have] "+s"(r.have), [left] "+s"(r.left), [nxt] "+s"(r.nxt), [wo] "+s"(r.wo), [neg] "+s"(neg),  \
+	  [n] "+s"(n), [el] "+s"(el), [ph] "+s"(ph), [gc] "+s"(gc), [e] "=&s"(e), [st] "=&s"(st), [t0] "=&s"(t0), [t1] "=&s"(t1) \
+	: [w] "s"(r.w), [runs] "s"(runs), [lutlo] "s"(lutlo), [luthi] "s"(luthi), [vqlo] "s"(vqlo), [vqhi] "s"(vqhi),        \
+	  [pass32] "s"(pass32), [passmask] "s"(passmask), [dper] "s"(dper), [psize] "s"(psize), [cls] "s"(cls_at),           \
+	  [accbase] "s"(acc_base), [half4] "s"(half4), [lane] "v"(lane), [dump] "v"(dump),                                    \
+	  [cblut] "s"(LW_ENT_SCALAR64((uintptr_t)cblut)), [cbmask] "s"(cbmask), [cbbits] "s"(cbbits),                          \
+	  [digits] "s"(LW_ENT_SCALAR64((uintptr_t)digits)), [cpc] "s"(cpc), [q2] "v"(q2)                                       \
+	: LW_ENT_ASM_CLOBBERS
+	if (DEINT == 0)
+		asm volatile(LW_ENT_RANGE_ENTER LW_ENT_RANGE_CLASSWORD LW_ENT_RANGE_VISIT LW_ENT_RANGE_PLACE0 LW_ENT_RANGE_TAIL LW_ENT_RANGE_CW_OPERANDS);
+	else
+		asm volatile(LW_ENT_RANGE_ENTER LW_ENT_RANGE_CLASSWORD LW_ENT_RANGE_VISIT LW_ENT_RANGE_PLACE2 LW_ENT_RANGE_TAIL LW_ENT_RANGE_CW_OPERANDS);
 	todo = 0u - neg;
 	return st;
 }
@@ -840,30 +932,68 @@ LW_HD bool lw_ent_partition(const LwEntTables &T, const LwEntVec &V, LwEntReader
 	return true;
 }
 
+// The class words of pass 0 when lw_ent_partitions reads them itself (device: an ordinary classbook whose digits are in the image)
+struct LwEntCw {
+	LwEntBookRegs book;
+	const LW_K uint16_t *digits; // [entry][cpc]: class | passes of the class << 8
+	uint32_t cpc;
+};
+
 // Partitions [p0, p1) of one vector in one pass.  false: the packet ends here.
+// own_cw / cw (device, pass 0 of a single vector, p0 at a group's start): every group of cpc partitions starts with its class word,
+// read here as well -- the whole pass is then one asm statement (lw_ent_range_cw).
 template <int DEINT>
-LW_HD bool lw_ent_partitions(const LwEntTables &T, const LwEntVec &V, LwEntReader &r, LwEntPend &pend, uint32_t pass, uint32_t p0, uint32_t p1)
+LW_HD bool lw_ent_partitions(const LwEntTables &T, const LwEntVec &V, LwEntReader &r, LwEntPend &pend, uint32_t pass, uint32_t p0, uint32_t p1,
+		const bool own_cw, const LwEntCw cw) // (by value: a struct reached through a pointer stays in scratch memory, and what is
+                                            //  loaded from there is divergent to the compiler)
 {
 	uint32_t n = p1 - p0;
+	uint32_t covered = 0; // (cw) partitions from here on whose class word has been read by the C++ path below
+	(void)covered;
 	while (n) {
 		uint32_t i0 = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (DEINT == 0 || (DEINT == 2 && V.ident)) {
-			// the device's steady state (lw_ent_range starts and ends with nothing pending)
+			// the device's steady state (the statements start and end with nothing pending)
 			pend.flush(V.out);
-			uint32_t todo;
-			const uint32_t pc = p1 - n;
-			const uint32_t st = lw_ent_range<DEINT>(r, V.runs, T.lut, T.vq, pass, n, (uint32_t)(uintptr_t)(V.cls + pc), V.base + pc * V.psize,
-					V.psize, V.half, (uint32_t)(uintptr_t)V.out, pend.dump, todo);
+			uint32_t todo, st;
+			const uint32_t pc = p1 - n, cls_at = (uint32_t)(uintptr_t)(V.cls + pc), el = V.base + pc * V.psize;
+			const uint32_t acc = (uint32_t)(uintptr_t)V.out;
+			if (own_cw) {
+				// gc: 0 at a group's start; inside a group (after a return below) the rest of the group
+				const uint32_t gc = covered ? covered : (cw.cpc - (pc - p0) % cw.cpc) % cw.cpc;
+				st = lw_ent_range_cw<(DEINT == 0 ? 0 : 2)>(r, V.runs, T.lut, T.vq, n, cls_at, el, V.psize, V.half, acc, pend.dump, todo, gc,
+						cw.book.lut, cw.book.lut_mask, cw.book.lut_bits, cw.digits, cw.cpc);
+				covered = 0;
+			} else {
+				st = lw_ent_range<(DEINT == 0 ? 0 : 2)>(r, V.runs, T.lut, T.vq, pass, n, cls_at, el, V.psize, V.half, acc, pend.dump, todo);
+			}
 			if (st == 0u)
 				break;
 			if (st == 2u) {
 				r.left = 0;
 				return false;
 			}
+			if (st == 4u) { // the class word through the tree (the range stopped at a group's start)
+				uint32_t t;
+				if (!r.code(cw.book, t))
+					return false;
+				const uint32_t at = p1 - n, cpc = cw.cpc;
+				const LW_K uint16_t *dg = cw.digits + t * cpc;
+				LW_ENT_LANES(q, cpc) {
+					const uint32_t qq = q < cpc ? q : cpc - 1u;
+					V.cls[at + qq] = dg[qq];
+				}
+				covered = cpc < n ? cpc : n;
+				continue;
+			}
 			if (st == 1u) {
 				const uint32_t cv = LW_ENT_SCALAR(V.cls[p1 - n]);
 				i0 = V.runs[(cv & 0xffu) * 8u + pass].count - todo;
+			}
+			if (own_cw) { // (the partition below belongs to the current group: what is left of the group behind it stays covered)
+				const uint32_t in_group = (p1 - n - p0) % cw.cpc;
+				covered = cw.cpc - 1u - in_group < n - 1u ? cw.cpc - 1u - in_group : n - 1u;
 			}
 		}
 #endif
@@ -901,10 +1031,19 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 	if (general) // (a compile-time constant at both call sites: the one-submap kernel carries no channel map at all)
 		for (uint32_t v = 0, nv = DEINT ? deint_ch : nch; v < nv; v++)
 			V.ident &= ((cmap >> (8u * v)) & 0xffu) == v;
+	// (device) a single vector with an ordinary classbook whose digits are in the image: pass 0 reads its class words inside the
+	// asm statement of its partitions (lw_ent_partitions, cw)
+	LwEntCw cw = {classbook, T.digits + (digits_off != 0xFFFFFFFFu ? digits_off : 0u), cpc};
+	bool own_cw = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+	own_cw = nch == 1u && !(dnd & 1u) && classbook.single == -1 && digits_off != 0xFFFFFFFFu && (DEINT == 0 || DEINT == 2);
+	if (DEINT == 2 && general) // (never instantiated: the interleaved vectors of several submaps go through DEINT = -1)
+		own_cw = false;
+#endif
 	for (uint32_t pass = 0; pass < 8 && (used_any >> pass) != 0; pass++) {
 		uint32_t pc = 0;
 		while (pc < parts) {
-			if (pass == 0) {
+			if (pass == 0 && !own_cw) {
 				for (uint32_t j = 0; j < nch; j++) {
 					if ((dnd >> j) & 1u)
 						continue;
@@ -933,12 +1072,12 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 			// vector's partitions are one range to the end
 			uint32_t pc_end = pc + cpc < parts ? pc + cpc : parts;
 			if (nch == 1u) {
-				if (pass != 0u)
+				if (pass != 0u || own_cw)
 					pc_end = parts;
 				if (!(dnd & 1u)) {
 					V.cls = cls;
 					V.base = (DEINT ? 0u : (V.ident ? 0u : (uint32_t)(cmap & 0xffu)) * half) + begin;
-					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc_end))
+					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc_end, pass == 0u && own_cw, cw))
 						return;
 				}
 				pc = pc_end;
@@ -950,7 +1089,7 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 						continue;
 					V.cls = cls + j * stride;
 					V.base = (DEINT ? 0u : (V.ident ? j : (uint32_t)((cmap >> (8u * j)) & 0xffu)) * half) + begin;
-					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc + 1u))
+					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc + 1u, false, cw))
 						return;
 				}
 		}
