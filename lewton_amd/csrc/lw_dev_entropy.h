@@ -1040,7 +1040,9 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 	if (DEINT == 2 && general) // (never instantiated: the interleaved vectors of several submaps go through DEINT = -1)
 		own_cw = false;
 #endif
-	for (uint32_t pass = 0; pass < 8 && (used_any >> pass) != 0; pass++) {
+	// (pass 0 always runs: it reads the class words even when no class of this residue has a book in any pass, audio.rs:664-676;
+	// the bit reader is shared with the submaps behind this one)
+	for (uint32_t pass = 0; pass < 8 && (pass == 0 || (used_any >> pass) != 0); pass++) {
 		uint32_t pc = 0;
 		while (pc < parts) {
 			if (pass == 0 && !own_cw) {

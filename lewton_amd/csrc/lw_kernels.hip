@@ -610,27 +610,32 @@ hipError_t lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, fl
 		hipLaunchKernelGGL(k_decouple, dim3(B.gen_small ? B.n_gen_small + B.n_gen_large : B.n_packets), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T,
 				B, skip_mask);
 	static LwPerDeviceOnce once;
-	if (once.first_launch_on_device()) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		if (e == hipSuccess)
-			e = hipFuncSetAttribute((const void *)k_imdct_generic<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		if (e != hipSuccess) {
-			once.forget_device(); // try again at the next launch; the caller reports this one
-			return e;
-		}
+	{
+		const hipError_t e = once.run([] {
+			hipError_t r = hipFuncSetAttribute((const void *)k_imdct_generic<LW_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+			if (r == hipSuccess)
+				r = hipFuncSetAttribute((const void *)k_imdct_generic<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+			return r;
+		});
+		if (e != hipSuccess)
+			return e; // the caller reports this launch; the next one tries again
 	}
 	// large block sizes: one (packet, channel) block per workgroup; small ones: four per workgroup, one per wave
 	const uint32_t n_large = (B.gen_large ? B.n_gen_large : B.n_packets) * T.ch;
 	const uint32_t n_small = (B.gen_small ? B.n_gen_small : B.n_packets) * T.ch;
 	if (max_n > (1u << LW_SMALL_BS) && n_large) {
 		const size_t lds = ((size_t)max_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 4) * sizeof(float);
-		hipLaunchKernelGGL(k_imdct_generic<LW_BLOCK>, dim3(n_large), dim3(LW_BLOCK), lds, st, T, B, tap_spec, coupling, skip_mask, 0u);
+		const uint32_t zero = 0u;
+		const hipError_t e = lw_launch_k(k_imdct_generic<LW_BLOCK>, dim3(n_large), dim3(LW_BLOCK), lds, st, T, B, tap_spec, coupling,
+				skip_mask, zero);
+		if (e != hipSuccess)
+			return e;
 	}
 	if (n_small) {
 		const uint32_t small_n = std::min(max_n, 1u << LW_SMALL_BS);
 		const uint32_t task_floats = (small_n + (LW_XSTRIDE * 4 + 24 + 3) / 4 + 7u) & ~3u;
 		const uint32_t per_wg = LW_BLOCK / 64;
-		hipLaunchKernelGGL(k_imdct_generic<64>, dim3((n_small + per_wg - 1) / per_wg), dim3(LW_BLOCK),
+		return lw_launch_k(k_imdct_generic<64>, dim3((n_small + per_wg - 1) / per_wg), dim3(LW_BLOCK),
 				(size_t)per_wg * task_floats * sizeof(float), st, T, B, tap_spec, coupling, skip_mask, task_floats);
 	}
 	return hipSuccess;

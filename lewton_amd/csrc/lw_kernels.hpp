@@ -9,29 +9,34 @@
 #include <mutex>
 
 // hipFuncSetAttribute is per DEVICE, and launchers are entered from several host threads (one decoder per GPU in one
-// process): `first_launch_on_device(flags)` is true exactly once per (flag set, current device).
+// process; the sharder's workers; the Ogg staging thread next to the caller): `run(set)` calls
+// `set` exactly once per (kernel family, current device) -- under the mutex, so that a second thread on the same device
+// cannot launch before the attributes are in place -- and marks the device done only when it succeeded.
 struct LwPerDeviceOnce {
 	std::mutex mu;
 	uint64_t done[4] = {0, 0, 0, 0}; // one bit per device ordinal
-	bool first_launch_on_device()
+	template <class Set> hipError_t run(Set &&set)
 	{
 		int dev = 0;
 		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256)
-			return true; // unknown ordinal: set the attributes every time (cheap, idempotent)
+			return set(); // unknown ordinal: set the attributes every time (cheap, idempotent)
 		std::lock_guard<std::mutex> g(mu);
-		const bool first = !(done[dev >> 6] & (1ull << (dev & 63)));
-		done[dev >> 6] |= 1ull << (dev & 63);
-		return first;
-	}
-	void forget_device() // the first launch failed to set its attributes: the next one tries again
-	{
-		int dev = 0;
-		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256)
-			return;
-		std::lock_guard<std::mutex> g(mu);
-		done[dev >> 6] &= ~(1ull << (dev & 63));
+		if (done[dev >> 6] & (1ull << (dev & 63)))
+			return hipSuccess;
+		const hipError_t e = set();
+		if (e == hipSuccess)
+			done[dev >> 6] |= 1ull << (dev & 63); // (a failure leaves the bit clear: the next launch tries again)
+		return e;
 	}
 };
+
+// Kernel launch that RETURNS the launch status (hipLaunchKernelGGL drops it; hipGetLastError would also pick up an earlier
+// hipErrorNotReady of a polled event): the arguments are passed by address, in the kernel's parameter order.
+template <class K, class... A> static inline hipError_t lw_launch_k(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A &...a)
+{
+	void *args[] = {(void *)&a...};
+	return hipLaunchKernel((const void *)kernel, grid, block, args, lds, st);
+}
 
 // CachedBlocksizeDerived (header_cached.rs:19-110) in HBM; computed on the host, never on the device.
 struct LwDevBs {

@@ -58,18 +58,17 @@ hipError_t lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, cons
 		return hipSuccess;
 	const size_t lds = ((size_t)T.res_floats + LW_ENT_DUMP_FLOATS) * 4 + T.ws_bytes;
 	static LwPerDeviceOnce once;
-	if (once.first_launch_on_device()) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		if (e == hipSuccess)
-			e = hipFuncSetAttribute((const void *)k_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		if (e != hipSuccess) {
-			once.forget_device(); // try again at the next launch; the caller reports this one
-			return e;
-		}
+	{
+		const hipError_t e = once.run([] {
+			hipError_t r = hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+			if (r == hipSuccess)
+				r = hipFuncSetAttribute((const void *)k_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+			return r;
+		});
+		if (e != hipSuccess)
+			return e; // the caller reports this launch; the next one tries again
 	}
 	if (T.general)
-		hipLaunchKernelGGL(k_entropy<true>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
-	else
-		hipLaunchKernelGGL(k_entropy<false>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
-	return hipSuccess;
+		return lw_launch_k(k_entropy<true>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
+	return lw_launch_k(k_entropy<false>, dim3(n), dim3(64), lds, st, T, d_pk, d_recs, d_pool, d_floor, d_res, n);
 }

@@ -397,7 +397,20 @@ __device__ __forceinline__ void issue_loads(const LwFastArgs &F, const ItemRegs 
 }
 
 // ---- floor segment table of one channel (one 16-byte entry per static interval), built by lanes = posts:
-//      {dy, 0.5*sgn(dy) - x0*dy, 1/adx, 4*y0}; y(k) = y0 + trunc((k*dy + c0) * rinv)
+//      {dy, c0, 1/adx, w}; the floor value of bin k is inverse_db[y(k)] with
+//          y(k) = ((bits(fma(fma(k, dy, c0), 1/adx, w)) & 0x7fc) >> 2) - 1
+//      i.e. two fused multiply-adds and one AND per bin, no conversion and no shift: w = 2^21 + 1 + y_base puts the sum into
+//      [2^21, 2^22), where one ulp is 1/4, so the low mantissa bits ARE 4 (y + 1) + (two fraction bits) -- the byte offset of
+//      the table entry (the - 4 goes into the ds_read's immediate offset).  render_line (audio.rs:503-524) is
+//      y = y0 + trunc((k - x0) dy / adx); both signs are written as a FLOOR of something non-negative:
+//          dy >= 0:  y = y0 + floor(((k - x0) dy + 1/2) / adx)                 c0 = 1/2 - x0 dy - adx/8,        y_base = y0
+//          dy <  0:  y = y1 + floor(((x1 - k) |dy| + adx - 1/2) / adx)         c0 = 7 adx/8 - 1/2 - x1 dy,      y_base = y1
+//      (the numerators are integers + 1/2, so the quotient's fraction lies in [1/(2 adx), 1 - 1/(2 adx)]; the - adx/8 moves
+//      it to [-1/8 + 1/(2 adx), 7/8 - 1/(2 adx)], which rounds to a multiple of 1/4 in [0, 3/4]: the integer part is never
+//      touched, whatever the tie rule.  Both inner sums are exact in f32; tests/test_fast_model.py checks every dy, every
+//      adx <= 1024, every offset, with the reciprocal one ulp off either way, as v_rcp_f32 may be.)
+#define LW_FLOOR_W0 2097153.0f // 2^21 + 1
+#define LW_FLOOR_MASK 0x7fcu
 __device__ __forceinline__ bool floor_table(const LwFastArgs &F, const char *img, char *sc, uint32_t lane, uint32_t e,
 		uint32_t fslot, uint32_t Fp)
 {
@@ -414,14 +427,23 @@ __device__ __forceinline__ bool floor_table(const LwFastArgs &F, const char *img
 	const float xlo = __int_as_float(__builtin_amdgcn_ds_bpermute(lo << 2, __float_as_int(xs)));
 	const float xhi = __int_as_float(__builtin_amdgcn_ds_bpermute(hi << 2, __float_as_int(xs)));
 	const float dy = (float)(yhi - ylo); // 0 when there is no later active post (flat, audio.rs:546-548)
+	const float adx = above ? xhi - xlo : 1.0f;
+	const bool down = yhi < ylo;
 	float4_t ent;
 	ent.x = dy;
-	ent.y = __builtin_copysignf(0.5f, dy) - xlo * dy; // exact
-	ent.z = above ? __builtin_amdgcn_rcpf(xhi - xlo) : 1.0f;
-	ent.w = __int_as_float(ylo << 2);
+	ent.y = down ? (0.875f * adx - 0.5f) - xhi * dy : (0.5f - 0.125f * adx) - xlo * dy; // exact (22 bits at most)
+	ent.z = above ? __builtin_amdgcn_rcpf(adx) : 1.0f;
+	ent.w = (float)(down ? yhi : ylo) + LW_FLOOR_W0;
 	if (lane < Fp)
 		*reinterpret_cast<float4_t *>(sc + 16 * lane) = ent;
 	return unused;
+}
+
+// floor value of bin kf through its interval entry (see floor_table)
+__device__ __forceinline__ float floor_bin(float kf, float4_t ent)
+{
+	const float t = __builtin_fmaf(__builtin_fmaf(kf, ent.x, ent.y), ent.z, ent.w);
+	return lds_abs_f32(LWI_INV_DB - 4u + (__float_as_uint(t) & LW_FLOOR_MASK));
 }
 
 // ---- floor value per bin; spectrum = floor * residue in place (audio.rs:1035-1037)
@@ -442,11 +464,7 @@ __device__ __forceinline__ void spectrum(const LwFastArgs &F, const char *img, c
 		float4_t fl;
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
-			const float4_t ent = lds4(sc, s16[j]);
-			const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
-			const int q = (int)(z * ent.z);
-			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
-			fl[j] = lds_abs_f32(LWI_INV_DB + idx);
+			fl[j] = floor_bin(kf0 + (float)(256 * x + j), lds4(sc, s16[j]));
 		}
 		const float2_t lo2 = pk_mul(float2_t{fl.x, fl.y}, float2_t{r[x].x, r[x].y});
 		const float2_t hi2 = pk_mul(float2_t{fl.z, fl.w}, float2_t{r[x].z, r[x].w});
@@ -481,11 +499,7 @@ __device__ __forceinline__ void spectrum_pair(const char *img, const char *sc, u
 #define LW_SP_XI(b)                                                                    \
 	do {                                                                               \
 		_Pragma("unroll") for (int j = 0; j < 4; j++) {                                \
-			const float4_t e = ent[(b) & 1][j];                                        \
-			const float z = __builtin_fmaf(kf0 + (float)(256 * ((b) & 3) + j), e.x, e.y); /* exact: |k*dy| < 2^18 */ \
-			const int q = (int)(z * e.z);                                              \
-			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(e.w));           \
-			fl[(b) & 1][j] = lds_abs_f32(LWI_INV_DB + idx); \
+			fl[(b) & 1][j] = floor_bin(kf0 + (float)(256 * ((b) & 3) + j), ent[(b) & 1][j]); \
 		}                                                                              \
 	} while (0)
 #define LW_SP_M(b)                                                                     \
@@ -530,11 +544,7 @@ __device__ __forceinline__ void floor_values(const char *img, const char *sc, ui
 		const uint32_t s16[4] = {sw.x & 0xffffu, sw.x >> 16, sw.y & 0xffffu, sw.y >> 16};
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
-			const float4_t ent = lds4(sc, s16[j]);
-			const float z = __builtin_fmaf(kf0 + (float)(256 * x + j), ent.x, ent.y); // exact: |k*dy| < 2^18
-			const int q = (int)(z * ent.z);
-			const uint32_t idx = (uint32_t)((q << 2) + __float_as_int(ent.w));
-			fl[x][j] = lds_abs_f32(LWI_INV_DB + idx);
+			fl[x][j] = floor_bin(kf0 + (float)(256 * x + j), lds4(sc, s16[j]));
 		}
 	}
 }
@@ -2140,12 +2150,10 @@ static hipError_t launch_short(LwShortArgs &F, int fmt, hipStream_t st)
 	// are bounded by LDS for L = 16 / 32 and by registers for L = 8
 	const dim3 grid(F.n_waves), block(64);
 	if (fmt == LW_OUT_I16_PLANAR)
-		hipLaunchKernelGGL((k_short<LW_OUT_I16_PLANAR, L>), grid, block, 0, st, F);
-	else if (fmt == LW_OUT_I16_INTERLEAVED)
-		hipLaunchKernelGGL((k_short<LW_OUT_I16_INTERLEAVED, L>), grid, block, 0, st, F);
-	else
-		hipLaunchKernelGGL((k_short<LW_OUT_F32_PLANAR, L>), grid, block, 0, st, F);
-	return hipSuccess;
+		return lw_launch_k(k_short<LW_OUT_I16_PLANAR, L>, grid, block, 0, st, F);
+	if (fmt == LW_OUT_I16_INTERLEAVED)
+		return lw_launch_k(k_short<LW_OUT_I16_INTERLEAVED, L>, grid, block, 0, st, F);
+	return lw_launch_k(k_short<LW_OUT_F32_PLANAR, L>, grid, block, 0, st, F);
 }
 
 hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st)
@@ -2218,7 +2226,7 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 	F.late_from = 0xFFFFFFFFu;
 	// k_long needs its 152 KB of dynamic LDS opted in once per device (LwPerDeviceOnce, lw_kernels.hpp)
 	static LwPerDeviceOnce once;
-	if (once.first_launch_on_device()) {
+	const hipError_t attr_err = once.run([] {
 		const void *fns[] = {(const void *)k_long<LW_OUT_I16_PLANAR, false>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false>,
 			(const void *)k_long<LW_OUT_I16_ITL_STEREO, false>, (const void *)k_long<LW_OUT_F32_PLANAR, false>,
 			(const void *)k_long<LW_OUT_I16_PLANAR, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, true>,
@@ -2231,21 +2239,23 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true, true>};
 		for (const void *f : fns) {
 			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			if (e != hipSuccess) {
-				once.forget_device(); // try again at the next launch; the caller reports this one
+			if (e != hipSuccess)
 				return e;
-			}
 		}
-	}
+		return hipSuccess;
+	});
+	if (attr_err != hipSuccess)
+		return attr_err; // the caller reports this launch; the next one tries again
 	if (L.n_halo_items) {
 		F.items = L.d_halo_items;
 		F.n_items = L.n_halo_items;
 		F.per_round = 1; // spread the few halo packets over the whole chip: one packet per workgroup
 		F.rounds = 1;
-		if (L.split)
-			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true, false, false, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
-		else
-			hipLaunchKernelGGL((k_long<LW_OUT_I16_PLANAR, true>), dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
+		const hipError_t e = L.split
+			? lw_launch_k(k_long<LW_OUT_I16_PLANAR, true, false, false, true>, dim3(L.n_halo_items), dim3(LW_WG), lds, st, F)
+			: lw_launch_k(k_long<LW_OUT_I16_PLANAR, true>, dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
+		if (e != hipSuccess)
+			return e;
 	}
 	if (L.n_items) {
 		F.items = L.d_items;
@@ -2260,19 +2270,17 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 	do {                                                                                                      \
 		if (L.split && !L.has_tdonly) { /* sparse launch: one channel per wave (generic interleaved stores: a wave has one channel) */ \
 			if (L.edge_mode)                                                                                  \
-				hipLaunchKernelGGL((k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true, true>),  \
+				return lw_launch_k(k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true, true>,  \
 						dim3(grid), dim3(LW_WG), lds, st, F);                                                  \
-			else                                                                                              \
-				hipLaunchKernelGGL((k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, false, true>), \
-						dim3(grid), dim3(LW_WG), lds, st, F);                                                  \
-		} else if (L.edge_mode) {                                                                             \
-			hipLaunchKernelGGL((k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true>), dim3(grid), \
-					dim3(LW_WG), lds, st, F);                                                                  \
-		} else if (L.has_tdonly) {                                                                            \
-			hipLaunchKernelGGL((k_long<F_, false, true>), dim3(grid), dim3(LW_WG), lds, st, F);                \
-		} else {                                                                                              \
-			hipLaunchKernelGGL((k_long<F_, false, false>), dim3(grid), dim3(LW_WG), lds, st, F);               \
+			return lw_launch_k(k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, false, true>, \
+					dim3(grid), dim3(LW_WG), lds, st, F);                                                      \
 		}                                                                                                     \
+		if (L.edge_mode)                                                                                      \
+			return lw_launch_k(k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true>, dim3(grid), \
+					dim3(LW_WG), lds, st, F);                                                                  \
+		if (L.has_tdonly)                                                                                     \
+			return lw_launch_k(k_long<F_, false, true>, dim3(grid), dim3(LW_WG), lds, st, F);                  \
+		return lw_launch_k(k_long<F_, false, false>, dim3(grid), dim3(LW_WG), lds, st, F);                    \
 	} while (0)
 		if (fmt == LW_OUT_I16_PLANAR)
 			LW_LAUNCH_MAIN(LW_OUT_I16_PLANAR);

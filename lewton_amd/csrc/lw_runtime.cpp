@@ -469,8 +469,7 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	if (!lw_hip_ok(hipMalloc(&d->d_blob, blob.size()), "hipMalloc(tables)") ||
 			!lw_hip_ok(hipMemcpy(d->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(tables)")) {
 		*err = LW_ERR_DEVICE;
-		if (d->d_blob)
-			(void)hipFree(d->d_blob);
+		lw_decoder_destroy(d.release()); // (every failure below as well: frees whatever has been allocated so far)
 		return nullptr;
 	}
 	const uint8_t *base = (const uint8_t *)d->d_blob;
@@ -507,7 +506,7 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 					!lw_hip_ok(hipMemcpy(d->d_ent_blob, img.blob.data(), img.blob.size(), hipMemcpyHostToDevice),
 						"hipMemcpy(entropy image)")) {
 				*err = LW_ERR_DEVICE;
-				(void)hipFree(d->d_blob);
+				lw_decoder_destroy(d.release());
 				return nullptr;
 			}
 			d->E = lw::dev_entropy_view(img, (const uint8_t *)d->d_ent_blob);
@@ -526,7 +525,7 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 				!lw_hip_ok(hipMalloc((void **)&d->d_fast_units, ub), "hipMalloc(fast units)") ||
 				!lw_hip_ok(hipMemcpy(d->d_fast_units, d->fast.units.data(), ub, hipMemcpyHostToDevice), "hipMemcpy(fast units)")) {
 			*err = LW_ERR_DEVICE;
-			(void)hipFree(d->d_blob);
+			lw_decoder_destroy(d.release());
 			return nullptr;
 		}
 	}
@@ -541,7 +540,7 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 				!lw_hip_ok(hipMemcpy(d->d_blk_image[cls], bp.image.data(), bp.image.size(), hipMemcpyHostToDevice),
 					"hipMemcpy(block kernel image)")) {
 			*err = LW_ERR_DEVICE;
-			(void)hipFree(d->d_blob);
+			lw_decoder_destroy(d.release());
 			return nullptr;
 		}
 	}

@@ -65,6 +65,8 @@ def configs(packets: int = 4096) -> List[Workload]:
                  "blocksize_1 = 12"),
         Workload("12", "stereo long blocks n = 1024", lambda: sg.stereo_setup(44100, 8, 10), "L", 256, per,
                  "blocksize_1 = 10"),
+        Workload("13", "stereo long blocks n = 8192", lambda: sg.stereo_setup(44100, 6, 13), "L", 256, per,
+                 "blocksize_1 = 13"),
     ]
 
 

@@ -39,8 +39,18 @@ def spill_setup(residue_type):
     return st
 
 
+def bookless_submap_setup():
+    """5.1 whose FIRST submap's residues have no book in any class and pass: pass 0 still reads their class words
+    (audio.rs:664-676), and the second submap's residue decodes from the bit position behind them"""
+    st = sg.surround51_setup()
+    for rs in st.residues[:2]:
+        rs.books = [[-1] * 8 for _ in rs.books]
+    return st
+
+
 HOST_SETUPS = dict(SETUPS, stereo_single_entry=lambda: sg.stereo_setup(single_entry_book=True),
-                   stereo_spill_t1=lambda: spill_setup(1), stereo_spill_t2=lambda: spill_setup(2))
+                   stereo_spill_t1=lambda: spill_setup(1), stereo_spill_t2=lambda: spill_setup(2),
+                   surround51_bookless=bookless_submap_setup)
 # floor type 0 (SURVEY 8f row f4): curve evaluated by the host stage, multiplied on the GPU
 FLOOR0_SETUPS = {
     "floor0": lambda: sg.floor0_setup(),

@@ -188,7 +188,8 @@ def imdct_wave(X, img):
 
 
 def floor_lane_model(rec, xs, img_inv_db):
-    """Per-bin floor through the segment table the kernel builds (trunc((t*dy +- 0.5) * (1/adx)) form)."""
+    """Per-bin floor through the segment table the kernel builds (k_long's floor_table / floor_bin): entry {dy, c0, 1/adx, w},
+    y(k) = ((bits(fma(fma(k, dy, c0), 1/adx, w)) & 0x7fc) >> 2) - 1 with w = 2^21 + 1 + y_base."""
     Fp = len(xs)
     act = np.array([(rec[i] & 0x8000) != 0 for i in range(Fp)])
     y = np.array([int(rec[i] & 0xFF) for i in range(Fp)])
@@ -200,17 +201,25 @@ def floor_lane_model(rec, xs, img_inv_db):
         his = [i for i in range(s + 1, Fp) if act[i]]
         if his:
             hi = his[0]
-            x0, y0, dy, adx = xs[lo], y[lo], y[hi] - y[lo], xs[hi] - xs[lo]
+            x0, x1, y0, y1, adx = xs[lo], xs[hi], y[lo], y[hi], xs[hi] - xs[lo]
         else:
-            x0, y0, dy, adx = xs[lo], y[lo], 0, 1
+            x0, x1, y0, y1, adx = xs[lo], xs[lo], y[lo], y[lo], 1
+        dy = y1 - y0
         sel = k[sid == s]
         if len(sel) == 0:
             continue
         rinv = F(1.0) / F(adx)
-        tf = (sel - x0).astype(F)
-        zf = (tf * F(dy) + F(np.copysign(0.5, dy if dy != 0 else 1.0))).astype(F)  # exact: |t*dy| < 2^18
-        q = np.trunc((zf * rinv).astype(F)).astype(np.int64)
-        out[sel] = img_inv_db[y0 + q]
+        if dy < 0:
+            c0 = F(F(F(0.875) * F(adx)) - F(0.5)) - F(F(x1) * F(dy))
+            w = F(y1) + F(2097153.0)
+        else:
+            c0 = F(F(0.5) - F(F(0.125) * F(adx))) - F(F(x0) * F(dy))
+            w = F(y0) + F(2097153.0)
+        z = sel.astype(np.float64) * float(dy) + float(c0)          # fma: one rounding; the sum is exact in f32 anyway
+        assert np.array_equal(z.astype(F).astype(np.float64), z)
+        t = (z * float(rinv) + float(w)).astype(F)                   # fma (the f64 product is exact; see test_fast_model)
+        yk = ((t.view(np.uint32) & 0x7FC) >> 2).astype(np.int64) - 1
+        out[sel] = img_inv_db[yk]
     return out
 
 

@@ -101,6 +101,30 @@ def test_floor_division_by_reciprocal_is_exact():
             assert np.array_equal(q, want), (adx, rinv)
 
 
+def test_floor_by_two_fmas_and_a_mask_is_exact():
+    """k_long's floor_bin: y = ((bits(fma(fma(k, dy, c0), fl(1/adx), 2^21 + 1 + y_base)) & 0x7fc) >> 2) - 1 equals render_line's
+    y0 + trunc((k - x0) dy / adx) for EVERY segment the long-block kernel can meet: every dy in -255..255, every adx in
+    1..1024 (and some larger ones) with every offset inside it, at both ends of the y range the segment can sit in, and with
+    the reciprocal one ulp off either way (v_rcp_f32).  The f64 product z * rinv is exact (<= 22 + 24 bits) and the f64 sum is
+    rounded far below the quarter the f32 result is rounded to, so f32(f64 expression) is the fused multiply-add's result
+    except on exact quarter ties, which do not touch the integer part (see the kernel's comment)."""
+    dy = np.arange(-255, 256, dtype=np.int64)[:, None]
+    y0s = (np.where(dy >= 0, 0, -dy), np.where(dy >= 0, 255 - dy, 255))   # the lowest / highest y0 with y0, y0 + dy in 0..255
+    for adx in list(range(1, 1025)) + [1100, 2048, 4096]:
+        t = np.arange(0, min(adx, 1024), dtype=np.int64)[None, :]
+        off = np.sign(dy) * ((t * np.abs(dy)) // adx)
+        # (k - x0) = t: c0 carries - x0 dy (resp. - x1 dy), so the inner sum is t dy + 1/2 - adx/8 resp. (adx - t)|dy| + 7 adx/8 - 1/2
+        z = (np.where(dy >= 0, t * dy + 0.5, (adx - t) * np.abs(dy) + adx - 0.5) - adx / 8.0).astype(np.float64)
+        assert np.array_equal(z.astype(np.float32).astype(np.float64), z)
+        r0 = np.float32(1.0) / np.float32(adx)
+        for y0 in y0s:
+            w = (np.where(dy >= 0, y0, y0 + dy) + 2097153.0).astype(np.float64)
+            for rinv in (r0, np.nextafter(r0, np.float32(2)), np.nextafter(r0, np.float32(0))):
+                tt = (z * np.float64(rinv) + w).astype(np.float32)
+                got = ((tt.view(np.uint32) & 0x7FC) >> 2).astype(np.int64) - 1
+                assert np.array_equal(got, y0 + off), (adx, rinv)
+
+
 def test_packed_op_model_bit_exact():
     """The v_pk_mul/add formulation (op_sel / neg modifiers emulated in numpy) == oracle, incl. window/overlap-add."""
     blob, offs, _, _ = _image(SETUPS["stereo"]())

@@ -8,7 +8,7 @@ cp lewton_amd/_lib/liblewton_amd.so /tmp/keep.so
 for r in $(seq 1 $R); do
   for v in $V; do
     cp lewton_amd/_lib/variant_$v.so lewton_amd/_lib/liblewton_amd.so
-    python bench.py --no-cpu-baseline --steps $K --warmup 200 > gpurun_out/ab/$v$r.json 2>/dev/null
+    python bench.py --no-cpu-baseline --no-end-to-end --no-other-configs --steps $K --warmup 200 > gpurun_out/ab/$v$r.json 2>/dev/null
   done
 done
 cp /tmp/keep.so lewton_amd/_lib/liblewton_amd.so

@@ -9,6 +9,7 @@ the PCM the timed launches left for batch 0 is compared with the oracle, every p
 skips it).  The oracle is the checker only; nothing timed touches it.
     python tools/bench_configs.py [--steps 400] [--only 3,4]"""
 import argparse
+import dataclasses
 import ctypes as C
 import json
 import os
@@ -22,26 +23,22 @@ sys.path.insert(0, ROOT)
 from lewton_amd import audio, header, workloads as wl  # noqa: E402
 from lewton_amd.batch import Batch  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=400)
-ap.add_argument("--packets", type=int, default=4096)
-ap.add_argument("--only", default="", help="comma-separated config numbers (default: 3,4,5)")
-ap.add_argument("--no-verify", action="store_true")
-ap.add_argument("--force-generic", action="store_true")
-args = ap.parse_args()
-ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
 NB = 4
 
 
-def run(w):
+def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None):
+    """Time workload `w` (lewton_amd.workloads.Workload): `nb` rotated batches resident in HBM, one hipGraph of `nb` steps replayed,
+    HIP events; then (verify) every packet of timed batch 0 against the oracle.  Returns the result line as a dict."""
+    if distinct:
+        w = dataclasses.replace(w, distinct=distinct)
     setup = w.setup()
     idp, _, stp = setup.headers()
     ident = header.read_header_ident(idp)
     st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
-    dec = audio.decoder_for(ident, st, 0)
+    dec = audio.decoder_for(ident, st, torch.cuda.current_device())
     NP = w.n_streams * w.per_stream
     batches, outs, material = [], [], []
-    for b in range(NB):
+    for b in range(nb):
         pw = [audio.PreviousWindowRight() for _ in range(w.n_streams)]
         # every stream is primed with the packet that precedes its first timed one, so all timed packets yield samples
         seqs = wl.stream_material(w, setup, batch=b)
@@ -52,7 +49,7 @@ def run(w):
         prime.synth_to_host(None)
         prime.close()
         bt = Batch(dec, NP, "i16")
-        if args.force_generic:
+        if force_generic:
             bt.set_force_generic(True)
         bt.entropy(items, n_threads=0)
         bt.upload(None)
@@ -64,29 +61,30 @@ def run(w):
     stream = torch.cuda.current_stream()
 
     def step(k, sp):
-        bt = batches[k % NB][0]
-        bt.synth(C.c_void_p(outs[k % NB].data_ptr()), outs[k % NB].numel(), sp)
+        bt = batches[k % nb][0]
+        bt.synth(C.c_void_p(outs[k % nb].data_ptr()), outs[k % nb].numel(), sp)
 
-    for k in range(8):
+    for k in range(2 * nb):
         step(k, C.c_void_p(stream.cuda_stream))
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for k in range(NB):
+        for k in range(nb):
             step(k, cs)
     for _ in range(20):
         g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(1, steps // nb)
     e0.record()
-    for _ in range(args.steps // NB):
+    for _ in range(reps):
         g.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (args.steps // NB * NB)
+    us = e0.elapsed_time(e1) * 1e3 / (reps * nb)
     parity = "unchecked"
-    if not args.no_verify:
+    if verify:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from common import verify_workload_batch
@@ -94,15 +92,24 @@ def run(w):
             parity = ("timed batch 0: %d packets i16 bit-exact vs oracle" % NP) if bad == 0 else "MISMATCH: %d of %d packets" % (bad, NP)
         except Exception as e:  # the oracle is only a checker here
             parity = "unchecked: %r" % (e,)
-    res = {"config": w.name, "packets_per_launch": NP, "streams": w.n_streams, "us_per_launch": round(us, 2),
+    res = {"config": w.name, "packets_per_launch": NP, "streams": w.n_streams, "steps": reps * nb, "us_per_launch": round(us, 2),
            "M_packets_per_s": round(NP / us, 2), "algorithmic_bytes_per_launch": alg,
            "pct_of_8TBps": round(100 * alg / (us * 1e-6) / 8e12, 2), "kernels": batches[0][0].last_kernels, "parity": parity,
            "note": w.note}
-    print(json.dumps(res), flush=True)
     for bt, _ in batches:
         bt.close()
+    return res
 
 
-for w in wl.configs(args.packets):
-    if w.key in ONLY:
-        run(w)
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--packets", type=int, default=4096)
+    ap.add_argument("--only", default="", help="comma-separated config numbers (default: 3,4,5)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-generic", action="store_true")
+    args = ap.parse_args()
+    ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
+    for w in wl.configs(args.packets):
+        if w.key in ONLY:
+            print(json.dumps(measure(w, args.steps, NB, not args.no_verify, args.force_generic)), flush=True)
