@@ -58,6 +58,10 @@ def main():
                          "own default (CPUs this process may use: affinity and cgroup cpu.max) and 1.25 x that")
     ap.add_argument("--gate-us", type=float, default=0.0,
                     help="length of the spin kernel in front of the timed region (see the comment at ev0); 0 = none")
+    ap.add_argument("--graph-segments", default="",
+                    help="K <= 512: capture the timed steps as consecutive hipGraphs of these lengths plus one for the rest, e.g. "
+                         "'1,3' ('' = ONE graph, the default: measured at K = 20, every extra graph launch costs more -- ~0.7 us "
+                         "per step by HIP events -- than the earlier start of the first kernel saves; profiles/r04_submission.txt)")
     ap.add_argument("--no-active-wait", action="store_true",
                     help="leave the HIP runtime's completion wait on its default (interrupt after a short spin) instead of polling: "
                          "the host learns of the end of the K steps tens of microseconds later, all of it inside the wall-clock span")
@@ -150,22 +154,34 @@ def main():
     # One hipGraph holding N_BATCHES consecutive steps (launch-bound inner loop -> graph replay); the Python
     # interpreter would otherwise be the bottleneck at ~25 us per launch.
     graph = tail_graph = None
-    # K <= 512: ONE graph holds all K steps (one submission for the whole timed region); larger K: a graph of N_BATCHES steps
-    # replayed K // N_BATCHES times plus a tail graph (the submissions after the first hide behind queued work)
+    # K <= 512: ONE graph holds all K steps (one submission for the whole timed region; --graph-segments splits it for
+    # experiments).  Larger K: a graph of N_BATCHES steps replayed K // N_BATCHES times plus a tail graph (the submissions
+    # after the first hide behind queued work)
+    seg_graphs = []
     per_graph = args.steps if args.steps <= 512 else N_BATCHES
     n_tail = args.steps % per_graph
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for k in range(per_graph):
-                step(args.warmup + k, cs)
-        if n_tail:  # K is not a multiple of the graph length: the remainder is its own graph, not eager launches
-            tail_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(tail_graph):
+        def capture(first, count):
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
                 cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-                for k in range(n_tail):
+                for k in range(first, first + count):
                     step(args.warmup + k, cs)
+            return g_
+        if args.steps <= 512:
+            segs, done = [], 0
+            for tok in [t for t in args.graph_segments.split(",") if t.strip()]:
+                n_ = int(tok)
+                if n_ > 0 and done + n_ < args.steps:
+                    segs.append((done, n_))
+                    done += n_
+            segs.append((done, args.steps - done))
+            seg_graphs = [capture(a_, n_) for a_, n_ in segs]
+            graph = seg_graphs[-1]
+        else:
+            graph = capture(0, per_graph)
+            if n_tail:  # K is not a multiple of the graph length: the remainder is its own graph, not eager launches
+                tail_graph = capture(0, n_tail)
         torch.cuda.synchronize()
         # untimed: let the device clocks settle (DVFS reaches its steady state only after tens of ms of load, far
         # longer than W steps of 18 us); the timed region below is still exactly K steps
@@ -198,7 +214,11 @@ def main():
         torch.cuda._sleep(gate_ticks)
     ev0.record(stream)
     k = 0
-    if graph is not None:
+    if seg_graphs:
+        for g_ in seg_graphs:
+            g_.replay()
+        k = args.steps
+    elif graph is not None:
         while k + per_graph <= args.steps:
             graph.replay()
             k += per_graph
@@ -209,6 +229,7 @@ def main():
         step(args.warmup + k, sptr)
         k += 1
     ev1.record(stream)
+    ev1.synchronize()         # (waits on the one event; the device-wide synchronize the contract asks for then has nothing left to wait for)
     torch.cuda.synchronize()
     # this rank's own span ends HERE, before the closing barrier: at K = 20 the timed region is ~0.35 ms, and an RCCL
     # barrier (tens of microseconds plus rank skew) inside it would be charged to the kernels at N > 1 only.  The job's

@@ -379,21 +379,23 @@ float bark(float x)
 	return 13.1f * atanf(0.00074f * x) + 2.24f * atanf(0.0000000185f * x * x) + 0.0001f * x;
 }
 
-// header_cached.rs:142-158
-std::vector<float> bark_map_cos_omega(uint32_t n, uint16_t rate, uint16_t bms)
+// cos(omega) of every spectrum bin of a floor-0 curve (Vorbis I 6.2.3: map[i] = min(bark_map_size - 1, floor(bark(rate i / 2n)
+// bark_map_size / bark(rate / 2))), omega = pi map[i] / bark_map_size), without the spec's sentinel element n.  The f32
+// operation order is the reference's (header_cached.rs:142-158): Nyquist first, one Nyquist / n step per bin, one
+// bark_map_size / bark(Nyquist) scale -- any other association rounds differently and moves bins across map entries.
+std::vector<float> bark_map_cos_omega(uint32_t n, uint16_t rate, uint16_t bark_map_size)
 {
-	std::vector<float> res(n);
-	const float hfl = (float)rate / 2.0f;
-	const float hfl_dn = hfl / (float)n;
-	const float foobar_const_part = (float)bms / bark(hfl);
-	const float bms_m1 = (float)bms - 1.0f;
-	const float omega_factor = PI_F / (float)bms;
-	for (uint32_t i = 0; i < n; i++) {
-		const float foobar = floorf(bark((float)i * hfl_dn) * foobar_const_part);
-		const float map_elem = fminf(foobar, bms_m1);
-		res[i] = cosf(map_elem * omega_factor);
+	const float nyquist = (float)rate / 2.0f;
+	const float bin_hz = nyquist / (float)n;                    // frequency step of one bin
+	const float entries_per_bark = (float)bark_map_size / bark(nyquist);
+	const float last_entry = (float)bark_map_size - 1.0f;
+	const float omega_step = PI_F / (float)bark_map_size;
+	std::vector<float> cos_omega(n);
+	for (uint32_t bin = 0; bin < n; bin++) {
+		const float entry = fminf(floorf(bark((float)bin * bin_hz) * entries_per_bark), last_entry);
+		cos_omega[bin] = cosf(entry * omega_step);
 	}
-	return res;
+	return cos_omega;
 }
 
 // header.rs:771-918
