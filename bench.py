@@ -78,6 +78,11 @@ def main():
         # host side of the timed region: hipDeviceSynchronize polls the completion signal (up to 1 s) instead of sleeping on the
         # interrupt.  At the driver's K = 20 the region is ~0.3 ms, and the interrupt path's wake-up latency alone was ~5 % of it.
         os.environ.setdefault("ROC_ACTIVE_WAIT_TIMEOUT", "1000000")
+    # the staging rings of the end_to_end leg give every slot its own HIP stream; the runtime maps streams onto 4 hardware
+    # queues by default, and with the graph's queues in the same process two slots of a ring end up in ONE queue -- their
+    # upload / kernels / PCM copy then run one after the other instead of side by side (9.0 instead of 11.7 M packets/s,
+    # profiles/r04_e2e_ring.txt).  A process that runs rings next to other streams wants GPU_MAX_HW_QUEUES >= 8.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     import torch.distributed as dist

@@ -179,7 +179,7 @@ void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
  * wave per packet; lw_batch_entropy then only reads the prologues, copies the packets into pinned staging and plans the
  * batch, and the packets themselves (~0.5 KB instead of 8.3 KB of records per stereo long block) cross PCIe.  Records,
  * PCM and statuses are bit-identical to the host stage's.  Eligible streams: floor type 1, residue books with a vector
- * lookup of at most 64 dimensions, at most 8 channels and 16 coupling steps (`why` names the reason otherwise;
+ * lookup of at most 64 dimensions, at most 16 channels and 16 coupling steps (`why` names the reason otherwise;
  * LW_ERR_UNSUPPORTED from the setters). */
 int lw_decoder_supports_device_entropy(const lw_decoder *d, const char **why);
 int lw_batch_set_entropy_on_device(lw_batch *b, int on);
@@ -245,7 +245,12 @@ size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0
  * lw_sharder_collect waits for the OLDEST call: out = host memory for cap_elems elements (NULL: drop the samples); results[i] (status, n_samples,
  * out_offset = element offset of packet i's block in out) come back in the order of that call's pkts; blocks are laid out
  * shard by shard.  LW_ERR_CAPACITY: more than max_packets_per_shard packets for one shard, three calls already in flight
- * (submit), nothing in flight or out too small (collect: nothing is consumed).
+ * (submit), nothing in flight or out too small (collect).
+ * Which returns of lw_sharder_collect consume the call: LW_ERR_CAPACITY and LW_ERR_NULL_ARG come from the argument checks and
+ * consume NOTHING (call again); every other return -- LW_OK, or the error of a shard (LW_ERR_DEVICE) -- has taken the call out
+ * of the queue and freed its slots; the packets of a shard that failed carry LW_ERR_DEVICE in results[].  A shard whose ring
+ * saw a device error is started over (drained): parts of OLDER calls still in flight on that shard report LW_ERR_DEVICE when
+ * they are collected, newer submits run normally.
  * A submit that fails AFTER some shards have launched (a device error on one shard) still queues the call, so that the
  * slots those shards hold can be freed: collect it (its packets on the failed shard come back with LW_ERR_DEVICE).
  * lw_sharder_decode = submit + collect on an empty pipeline.
@@ -274,7 +279,9 @@ int lw_sharder_collect(lw_sharder *sh, void *out, size_t cap_elems, lw_packet_re
 size_t lw_sharder_in_flight(lw_sharder *sh); /* calls submitted and not yet collected */
 /* Zero-copy form of collect: the oldest call's PCM stays where the GPUs' copy engines put it, in the shards' pinned ring
  * buffers -- pcm[g] / elems[g] for shard g (arrays of lw_sharder_shards() entries); results[i].out_offset is relative to
- * the block of the shard that owns packet i (lw_sharder_shard_of).  Valid until lw_sharder_release, which frees the slots. */
+ * the block of the shard that owns packet i (lw_sharder_shard_of).  Valid until lw_sharder_release, which frees the slots.
+ * Both run on the caller's thread (no hand-over to the shards' workers).  After ANY return of lw_sharder_collect_pinned other
+ * than LW_ERR_CAPACITY / LW_ERR_NULL_ARG the call is held by the caller: lw_sharder_release takes it out of the queue. */
 int lw_sharder_collect_pinned(lw_sharder *sh, lw_packet_result *results, size_t n_results, const void **pcm, size_t *elems);
 int lw_sharder_release(lw_sharder *sh);
 

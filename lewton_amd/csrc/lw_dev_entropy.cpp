@@ -29,7 +29,7 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	const size_t n1 = (size_t)1 << id.bs1;
 	img.general = 0;
 	if (ch == 0 || ch > LW_ENT_MAX_CH) {
-		*why = "more than 8 channels";
+		*why = "more than 16 channels";
 		return false;
 	}
 	if (n1 * ch >= 65536) {

@@ -12,7 +12,7 @@
 // lw::DevEntropyImage) that lives in HBM.  The function produces exactly what the host stage writes into a batch's staging
 // -- floor records [ch][fstride] u16 and residue vectors [ch][n/2] f32 before inverse coupling -- so the synthesis kernels
 // run unchanged behind it.  Eligible setups only (lw::dev_entropy_build says why not): floor type 1, residue books whose
-// dimension divides the partition size, at most 8 channels.
+// dimension divides the partition size, at most 16 channels.
 // For those the packet status is decided by the prologue alone (the host reads it: mode number, window flags), so the
 // host's planning pass needs nothing back from the device.
 #pragma once
@@ -94,7 +94,8 @@ __device__ inline __attribute__((always_inline)) uint32_t lw_ent_mad24(uint32_t 
 #define LW_ENT_ACC(out, at) (out)[at]
 #endif
 
-#define LW_ENT_MAX_CH 8
+#define LW_ENT_MAX_CH 16 // (a submap's channel map travels as 16 four-bit entries of one 64-bit scalar: LW_ENT_CMAP)
+#define LW_ENT_CMAP(cmap, v) ((uint32_t)(((cmap) >> (4u * (v))) & 0xfu))
 #define LW_ENT_MAX_CLASSES 64
 #define LW_ENT_MAX_COUPLING 16
 #define LW_ENT_LINK 0x80000000u
@@ -813,7 +814,7 @@ LW_HD uint32_t lw_ent_place(uint32_t el, uint32_t deint, uint32_t half, uint64_t
 	if (DEINT == 0)
 		return el;
 	const uint32_t v = DEINT == 2 ? el & 1u : el % deint, q = DEINT == 2 ? el >> 1 : el / deint;
-	return (ident ? v : (uint32_t)((cmap >> (8u * v)) & 0xffu)) * half + q;
+	return (ident ? v : LW_ENT_CMAP(cmap, v)) * half + q;
 }
 
 // What the partitions of one residue vector share
@@ -1030,7 +1031,7 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 	V.ident = true;
 	if (general) // (a compile-time constant at both call sites: the one-submap kernel carries no channel map at all)
 		for (uint32_t v = 0, nv = DEINT ? deint_ch : nch; v < nv; v++)
-			V.ident &= ((cmap >> (8u * v)) & 0xffu) == v;
+			V.ident &= LW_ENT_CMAP(cmap, v) == v;
 	// (device) a single vector with an ordinary classbook whose digits are in the image: pass 0 reads its class words inside the
 	// asm statement of its partitions (lw_ent_partitions, cw)
 	LwEntCw cw = {classbook, T.digits + (digits_off != 0xFFFFFFFFu ? digits_off : 0u), cpc};
@@ -1078,7 +1079,7 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 					pc_end = parts;
 				if (!(dnd & 1u)) {
 					V.cls = cls;
-					V.base = (DEINT ? 0u : (V.ident ? 0u : (uint32_t)(cmap & 0xffu)) * half) + begin;
+					V.base = (DEINT ? 0u : (V.ident ? 0u : LW_ENT_CMAP(cmap, 0u)) * half) + begin;
 					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc_end, pass == 0u && own_cw, cw))
 						return;
 				}
@@ -1090,7 +1091,7 @@ LW_HD void lw_ent_residue(const LwEntTables &T, const LW_K LwEntResidue &rs, LwE
 					if ((dnd >> j) & 1u)
 						continue;
 					V.cls = cls + j * stride;
-					V.base = (DEINT ? 0u : (V.ident ? j : (uint32_t)((cmap >> (8u * j)) & 0xffu)) * half) + begin;
+					V.base = (DEINT ? 0u : (V.ident ? j : LW_ENT_CMAP(cmap, j)) * half) + begin;
 					if (!lw_ent_partitions<DEINT>(T, V, r, pend, pass, pc, pc + 1u, false, cw))
 						return;
 				}
@@ -1152,7 +1153,7 @@ LW_HD void lw_ent_decode_packet(const LwEntTables &T, const LW_K uint32_t *words
 			if (m.mux[c] == sm) {
 				dnd |= ((no_residue >> c) & 1u) << sub_ch;
 				any |= !((no_residue >> c) & 1u);
-				cmap |= (uint64_t)c << (8u * sub_ch);
+				cmap |= (uint64_t)c << (4u * sub_ch);
 				sub_ch++;
 			}
 		if (sub_ch == 0)

@@ -34,15 +34,18 @@ namespace {
 struct Part {
 	std::vector<size_t> idx;        // positions (in the caller's packet list) of this shard's packets, in list order
 	std::vector<lw_packet> pk;
+	size_t expect = 0;              // how many packets of the call are this shard's (counted by the caller; the worker gathers them)
 	size_t out_elems = 0, base = 0; // elements this shard produces / where its first block starts in the caller's buffer
 	int rc = LW_OK;
 	bool launched = false;          // a ring slot holds this part (must be collected and released)
+	uint64_t gen = 0;               // the shard's ring generation the slot belongs to (a drained ring starts a new one)
 };
 
 struct Call {
 	std::vector<Part> parts;        // one per shard
 	size_t n = 0, total_elems = 0;
 	int n_threads = 0;
+	const lw_shard_packet *pkts = nullptr; // the caller's list, valid while lw_sharder_submit runs (the workers gather their parts from it)
 	// collect phase
 	void *out = nullptr;
 	lw_packet_result *results = nullptr;
@@ -50,9 +53,14 @@ struct Call {
 	const void **pcm = nullptr;     // zero-copy collect: per shard, the pinned PCM of its slot
 	size_t *elems = nullptr;
 	bool collected = false;
+	// completion of the jobs handed to the workers for this call (one caller waits: its own mutex and condition variable,
+	// so that a finishing worker wakes that caller and nobody else)
+	std::mutex mu;
+	std::condition_variable cv;
+	size_t pending = 0;
 };
 
-enum JobKind { JOB_STAGE, JOB_COLLECT, JOB_RELEASE };
+enum JobKind { JOB_STAGE, JOB_COLLECT };
 
 struct Job {
 	JobKind kind;
@@ -65,7 +73,16 @@ struct Shard {
 	lw_decoder *dec = nullptr;
 	lw_ring *ring = nullptr;        // pinned records + pinned PCM per slot, H2D / kernels / D2H asynchronous on the slot's stream
 	std::thread worker;
-	std::deque<Job> jobs;           // guarded by lw_sharder::mu
+	// the worker's own queue, mutex and condition variable: a job for shard g wakes worker g only
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<Job> jobs;
+	bool quit = false;
+	// collect / release / drain of the ring exclude each other (the worker's stage + launch run beside them: the ring allows one
+	// staging and one collecting thread).  A drain -- after a failed launch or a failed collect -- frees every slot and resets
+	// the ring's cursors, so whatever older calls still hold on this ring is gone: `gen` tells their parts apart from new ones.
+	std::mutex ring_mu;
+	uint64_t gen = 0;               // under ring_mu
 };
 
 } // namespace
@@ -86,12 +103,48 @@ struct lw_sharder {
 	size_t max_packets = 0;
 	int fmt = 0;
 	size_t esz = 2;
-	std::mutex mu;
-	std::condition_variable cv;     // jobs arrive (workers) / jobs finish (callers)
-	bool quit = false;
-	size_t pending = 0;             // jobs of the call being waited for that have not finished
 	std::mutex call_mu;             // serialises the public calls
 	std::deque<std::unique_ptr<Call>> calls; // submitted and not yet collected, oldest first (guarded by call_mu)
+	std::vector<std::unique_ptr<Call>> spare; // consumed calls: their vectors keep their capacity for the next submit (call_mu)
+
+	std::unique_ptr<Call> fresh_call()
+	{
+		std::unique_ptr<Call> c;
+		if (!spare.empty()) {
+			c = std::move(spare.back());
+			spare.pop_back();
+		} else {
+			c = std::make_unique<Call>();
+			c->parts.resize(shards.size());
+		}
+		for (Part &p : c->parts) {
+			p.idx.clear();
+			p.pk.clear();
+			p.expect = p.out_elems = p.base = 0;
+			p.rc = LW_OK;
+			p.launched = false;
+		}
+		c->n = c->total_elems = 0;
+		c->out = nullptr;
+		c->results = nullptr;
+		c->keep = c->collected = false;
+		c->pcm = nullptr;
+		c->elems = nullptr;
+		c->pkts = nullptr;
+		return c;
+	}
+
+	void retire_front()
+	{
+		spare.push_back(std::move(calls.front()));
+		calls.pop_front();
+	}
+
+	void drain_locked(Shard &s) // (s.ring_mu held)
+	{
+		(void)lw_ring_drain(s.ring);
+		s.gen++;
+	}
 
 	void stage(Shard &s, Call &c)
 	{
@@ -99,26 +152,46 @@ struct lw_sharder {
 		p.rc = LW_OK;
 		p.out_elems = 0;
 		p.launched = false;
+		// this shard's packets of the call, in list order (every worker walks the caller's list for its own: the split runs on
+		// all shards at once instead of on the caller's thread)
+		p.idx.reserve(p.expect);
+		p.pk.reserve(p.expect);
+		for (size_t i = 0; i < c.n; i++) {
+			const lw_shard_stream *st = c.pkts[i].stream;
+			if (st->shard != s.index)
+				continue;
+			p.idx.push_back(i);
+			p.pk.push_back(lw_packet{c.pkts[i].data, c.pkts[i].len, st->pwr});
+		}
 		if (p.pk.empty())
 			return;
 		p.rc = lw_ring_stage(s.ring, p.pk.data(), p.pk.size(), c.n_threads);
 		if (p.rc != LW_OK)
 			return;
 		p.rc = lw_ring_launch(s.ring);
+		std::lock_guard<std::mutex> g(s.ring_mu);
 		if (p.rc != LW_OK) {
-			(void)lw_ring_drain(s.ring); // (a device failure: nothing of this shard survives it)
+			drain_locked(s); // a device failure: nothing of this shard survives it (older parts find their generation gone)
 			return;
 		}
 		p.launched = true;
+		p.gen = s.gen;
 		// sample counts and offsets are known once the batch is planned (lw_ring_stage): the sizes need no GPU
 		p.out_elems = lw_ring_last_staged_elems(s.ring);
 	}
 
+	// runs on the shard's worker (copy-out form: the shards copy in parallel) or on the caller's thread (zero-copy form)
 	void collect(Shard &s, Call &c)
 	{
 		Part &p = c.parts[s.index];
 		if (!p.launched)
 			return;
+		std::lock_guard<std::mutex> g(s.ring_mu);
+		if (p.gen != s.gen) { // the ring was drained after this part was launched: its slot and its PCM are gone
+			p.launched = false;
+			p.rc = LW_ERR_DEVICE;
+			return;
+		}
 		const lw_packet_result *r = nullptr;
 		const void *pcm = nullptr;
 		size_t n = 0, elems = 0;
@@ -136,17 +209,31 @@ struct lw_sharder {
 				c.elems[s.index] = elems;
 			} else {
 				rc = lw_ring_release(s.ring);
+				p.launched = false;
 			}
 		}
-		if (rc != LW_OK)
+		if (rc != LW_OK) { // the slot would stay LAUNCHED for ever and wedge the ring after a few calls: start the ring over
+			drain_locked(s);
+			p.launched = false;
 			p.rc = rc;
+		}
 	}
 
+	// caller's thread: lw_ring_release only moves the ring's cursors
 	void release(Shard &s, Call &c)
 	{
 		Part &p = c.parts[s.index];
-		if (p.launched && lw_ring_release(s.ring) != LW_OK && p.rc == LW_OK)
-			p.rc = LW_ERR_DEVICE;
+		if (!p.launched)
+			return;
+		std::lock_guard<std::mutex> g(s.ring_mu);
+		p.launched = false;
+		if (p.gen != s.gen)
+			return; // (drained meanwhile: nothing left to release)
+		if (lw_ring_release(s.ring) != LW_OK) {
+			drain_locked(s);
+			if (p.rc == LW_OK)
+				p.rc = LW_ERR_DEVICE;
+		}
 	}
 
 	void worker_main(Shard *s)
@@ -155,34 +242,49 @@ struct lw_sharder {
 		for (;;) {
 			Job j;
 			{
-				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&]() { return quit || !s->jobs.empty(); });
-				if (quit)
+				std::unique_lock<std::mutex> g(s->mu);
+				s->cv.wait(g, [&]() { return s->quit || !s->jobs.empty(); });
+				if (s->quit)
 					return;
 				j = s->jobs.front();
 				s->jobs.pop_front();
 			}
 			if (j.kind == JOB_STAGE)
 				stage(*s, *j.call);
-			else if (j.kind == JOB_COLLECT)
-				collect(*s, *j.call);
 			else
-				release(*s, *j.call);
-			std::unique_lock<std::mutex> g(mu);
-			pending--;
-			cv.notify_all();
+				collect(*s, *j.call);
+			std::lock_guard<std::mutex> g(j.call->mu);
+			if (--j.call->pending == 0)
+				j.call->cv.notify_one();
 		}
 	}
 
-	// one job per shard, wait for all of them
+	// one job per shard that has something to do, wait for all of them
 	void all_workers(JobKind kind, Call *c)
 	{
-		std::unique_lock<std::mutex> g(mu);
-		pending = shards.size();
-		for (auto &s : shards)
-			s->jobs.push_back(Job{kind, c});
-		cv.notify_all();
-		cv.wait(g, [&]() { return pending == 0; });
+		size_t n = 0;
+		for (auto &s : shards) {
+			const Part &p = c->parts[s->index];
+			n += kind == JOB_STAGE ? p.expect != 0 : p.launched;
+		}
+		if (n == 0)
+			return;
+		{
+			std::lock_guard<std::mutex> g(c->mu);
+			c->pending = n;
+		}
+		for (auto &s : shards) {
+			const Part &p = c->parts[s->index];
+			if (kind == JOB_STAGE ? p.expect == 0 : !p.launched)
+				continue;
+			{
+				std::lock_guard<std::mutex> g(s->mu);
+				s->jobs.push_back(Job{kind, c});
+			}
+			s->cv.notify_one();
+		}
+		std::unique_lock<std::mutex> g(c->mu);
+		c->cv.wait(g, [&]() { return c->pending == 0; });
 	}
 };
 
@@ -228,12 +330,12 @@ void lw_sharder_destroy(lw_sharder *sh)
 {
 	if (!sh)
 		return;
-	{
-		std::unique_lock<std::mutex> g(sh->mu);
-		sh->quit = true;
-		sh->cv.notify_all();
-	}
 	for (auto &s : sh->shards) {
+		{
+			std::lock_guard<std::mutex> g(s->mu);
+			s->quit = true;
+		}
+		s->cv.notify_all();
 		if (s->worker.joinable())
 			s->worker.join();
 		if (s->ring) {
@@ -316,18 +418,21 @@ static int submit_locked(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, 
 {
 	if (sh->calls.size() >= LW_SHARD_SLOTS)
 		return LW_ERR_CAPACITY; // collect the oldest call first
-	auto c = std::make_unique<Call>();
-	c->parts.resize(sh->shards.size());
+	// (a cheap pass on the caller's thread: owners and per-shard counts, so that a bad list is refused before anything is staged)
+	std::unique_ptr<Call> c = sh->fresh_call();
 	c->n = n;
-	for (size_t i = 0; i < n; i++) {
+	c->pkts = pkts;
+	int bad = LW_OK;
+	for (size_t i = 0; i < n && bad == LW_OK; i++) {
 		const lw_shard_stream *st = pkts[i].stream;
 		if (!st || st->owner != sh)
-			return LW_ERR_STATE_MISMATCH;
-		Part &p = c->parts[st->shard];
-		if (p.idx.size() == sh->max_packets)
-			return LW_ERR_CAPACITY;
-		p.idx.push_back(i);
-		p.pk.push_back(lw_packet{pkts[i].data, pkts[i].len, st->pwr});
+			bad = LW_ERR_STATE_MISMATCH;
+		else if (++c->parts[st->shard].expect > sh->max_packets)
+			bad = LW_ERR_CAPACITY;
+	}
+	if (bad != LW_OK) {
+		sh->spare.push_back(std::move(c));
+		return bad;
 	}
 	// all shards run their host entropy stage at once (the worker pool serves their parallel regions side by side): by
 	// default they share the CPUs this process may use
@@ -345,6 +450,7 @@ static int submit_locked(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, 
 	c->total_elems = total;
 	if (out_elems)
 		*out_elems = total;
+	c->pkts = nullptr;
 	// (on an error the shards that did launch still hold a slot each: the call stays in the queue so that a collect frees them)
 	sh->calls.push_back(std::move(c));
 	return rc;
@@ -370,7 +476,7 @@ static int collect_locked(lw_sharder *sh, void *out, size_t cap_elems, lw_packet
 	for (Part &p : c.parts)
 		if (p.rc != LW_OK)
 			rc = p.rc;
-	sh->calls.pop_front();
+	sh->retire_front();
 	return rc;
 }
 
@@ -397,7 +503,8 @@ int lw_sharder_collect_pinned(lw_sharder *sh, lw_packet_result *results, size_t 
 	}
 	for (size_t i = 0; i < c.n; i++)
 		results[i] = lw_packet_result{LW_ERR_DEVICE, 0, 0};
-	sh->all_workers(JOB_COLLECT, &c);
+	for (auto &s : sh->shards) // nothing to copy: the caller's thread waits for every shard's slot itself (no hand-over to the workers)
+		sh->collect(*s, c);
 	c.collected = true;
 	int rc = LW_OK;
 	for (Part &p : c.parts)
@@ -414,12 +521,13 @@ int lw_sharder_release(lw_sharder *sh)
 	if (sh->calls.empty() || !sh->calls.front()->collected)
 		return LW_ERR_CAPACITY;
 	Call &c = *sh->calls.front();
-	sh->all_workers(JOB_RELEASE, &c);
+	for (auto &s : sh->shards)
+		sh->release(*s, c);
 	int rc = LW_OK;
 	for (Part &p : c.parts)
 		if (p.rc != LW_OK)
 			rc = p.rc;
-	sh->calls.pop_front();
+	sh->retire_front();
 	return rc;
 }
 
@@ -459,7 +567,7 @@ int lw_sharder_decode(lw_sharder *sh, const lw_shard_packet *pkts, size_t n, int
 		c.out = nullptr;
 		c.results = scratch.data();
 		sh->all_workers(JOB_COLLECT, &c);
-		sh->calls.pop_front();
+		sh->retire_front();
 		return rc;
 	}
 	return collect_locked(sh, out, cap_elems, results, n);

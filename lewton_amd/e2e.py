@@ -16,7 +16,7 @@ from .ring import Ring
 
 
 def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots=3, callers=1, seed=1,
-            samples="i16", warm=4, device_entropy=False):
+            samples="i16", warm=8, device_entropy=False):
     """Returns a dict: packets/s, H2D / D2H GB/s, host entropy stage alone, kernels used.
     Every caller thread owns a ring and `streams` independent streams, each contributing packets/streams consecutive
     packets per batch (the bench workload, BASELINE configs[1])."""
@@ -94,7 +94,7 @@ def measure(dec, pool, n_batches=32, packets=4096, streams=256, threads=0, slots
 
 
 def measure_sharder(ident, setup, pool, devices, n_calls=32, packets_per_shard=4096, streams_per_shard=256, threads=0,
-                    samples="i16", device_entropy=False, seed=1, warm=4, copy_out=False):
+                    samples="i16", device_entropy=False, seed=1, warm=8, copy_out=False):
     """End-to-end rate of the one-process multi-device path (lw_sharder_*): packets of len(devices) x streams_per_shard
     streams per call, stream_id mod G onto the shards, every shard on its own staging ring; up to three calls in flight.
     Returns a dict like measure()."""

@@ -160,8 +160,12 @@ class Sharder:
             self._res = (N.PacketResult * max(1, n))()
             self._res_cap = n
         res = self._res
+        before = N.lw_sharder_in_flight(self._h)
         rc = N.lw_sharder_collect(self._h, out.ctypes.data_as(C.c_void_p), out.size, res, n)
         if rc:
+            # the argument checks (LW_ERR_CAPACITY / LW_ERR_NULL_ARG) consume nothing; a shard's error has consumed the call
+            if N.lw_sharder_in_flight(self._h) < before:
+                self._pending.pop(0)
             raise RuntimeError("lw_sharder_collect: %d %s" % (rc, N.device_error()))
         self._pending.pop(0)
         if not want_results:
@@ -182,6 +186,10 @@ class Sharder:
         el = (C.c_size_t * G)()
         rc = N.lw_sharder_collect_pinned(self._h, self._res, n, pcm, el)
         if rc:
+            # a shard's error leaves the call held by the caller (see lewton_amd.h): give it back so that the C queue and
+            # self._pending stay in step; the argument checks hold nothing and release() then refuses harmlessly
+            if N.lw_sharder_release(self._h) == 0:
+                self._pending.pop(0)
             raise RuntimeError("lw_sharder_collect_pinned: %d %s" % (rc, N.device_error()))
         dt = np.float32 if self.fmt == N.FMT_F32_PLANAR else np.int16
         views = []

@@ -572,6 +572,31 @@ def surround51_setup(sample_rate: int = 48000, bs0: int = 8, bs1: int = 11) -> S
                        [Mode(0, 0), Mode(1, 1)])
 
 
+def multichannel_setup(channels: int = 12, sample_rate: int = 48000, bs0: int = 8, bs1: int = 11) -> StreamSetup:
+    """`channels` (> 8, e.g. 7.1.4 = 12) channels: submap 0 = all but the last channel (one floor, type-2 residue interleaving
+    channels - 1 vectors), submap 1 = the last channel (own floor, type-1 residue); coupling steps on pairs (0,1), (2,3), ...
+    of the main channels.  blocksize_1 * channels stays below 65536 (the reference's u16 product, audio.rs:745)."""
+    assert 2 < channels <= 16 and (1 << bs1) * channels < 65536
+    books, ix = _std_books()
+    n0h, n1h = (1 << bs0) // 2, (1 << bs1) // 2
+    main = channels - 1
+    fl_short = _floor1(_scale_x(SHORT_X, 128, n0h), bs0 - 1, 4, ix["y16"], ix["master8"], ix["y16"])
+    fl_long = _floor1(_scale_x(LONG_X, 1024, n1h), bs1 - 1, 2, ix["y16"], ix["master8"], ix["y32"])
+    fl_lfe_s = _floor1([16, 64, 32], bs0 - 1, 1, ix["y32"], ix["master8"], ix["y16"])
+    fl_lfe_l = _floor1([64, 16, 256, 128, 32, 512], bs1 - 1, 1, ix["y32"], ix["master8"], ix["y16"])
+    rs = [
+        Residue(2, 0, main * (n0h * 13 // 16), 16, 4, ix["class16"], _res_books(ix)),   # short main
+        Residue(2, 0, main * 600 * n1h // 1024, 32, 4, ix["class16"], _res_books(ix)),  # long main
+        Residue(1, 0, n0h // 4, 8, 4, ix["class16"], _res_books(ix)),                   # short last channel
+        Residue(1, 0, n1h // 8, 32, 4, ix["class16"], _res_books(ix)),                  # long last channel
+    ]
+    mux = [0] * main + [1]
+    coupling = [(c, c + 1) for c in range(0, main - 1, 2)]
+    maps = [Mapping(coupling, mux, [0, 2], [0, 2]), Mapping(coupling, mux, [1, 3], [1, 3])]
+    return StreamSetup(channels, sample_rate, bs0, bs1, books, [fl_short, fl_long, fl_lfe_s, fl_lfe_l], rs, maps,
+                       [Mode(0, 0), Mode(1, 1)])
+
+
 def mono_setup(bs0: int = 6, bs1: int = 9, sample_rate: int = 8000) -> StreamSetup:
     """1 ch, small blocks, residue types 0 and 1, a begin offset, dims not dividing the partition size."""
     books, ix = _std_books()

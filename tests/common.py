@@ -50,7 +50,9 @@ def bookless_submap_setup():
 
 HOST_SETUPS = dict(SETUPS, stereo_single_entry=lambda: sg.stereo_setup(single_entry_book=True),
                    stereo_spill_t1=lambda: spill_setup(1), stereo_spill_t2=lambda: spill_setup(2),
-                   surround51_bookless=bookless_submap_setup)
+                   surround51_bookless=bookless_submap_setup,
+                   # more than 8 channels (7.1.4): the device entropy stage's channel map holds 16
+                   multichannel12=lambda: sg.multichannel_setup(12))
 # floor type 0: curve evaluated by the host stage, multiplied on the GPU
 FLOOR0_SETUPS = {
     "floor0": lambda: sg.floor0_setup(),

@@ -30,6 +30,8 @@ struct Side {
 	std::vector<lw_shard_stream *> st;
 };
 
+#include <atomic>
+extern std::atomic<int> lw_standin_fail_launch; // hip_standins.inc
 #define CHECK(c, ...)                  \
 	do {                               \
 		if (!(c)) {                    \
@@ -48,6 +50,7 @@ int main(int argc, char **argv)
 		return 2;
 	const size_t G = (size_t)atoi(argv[2]), S = (size_t)atoi(argv[3]), per = (size_t)atoi(argv[4]), calls = (size_t)atoi(argv[5]);
 	const bool dev_entropy = argc > 6 && atoi(argv[6]) != 0;
+	const bool fail_mode = argc > 7 && atoi(argv[7]) != 0;
 	uint32_t nc, npk;
 	std::vector<uint8_t> idp, stp;
 	if (!rd(f, nc) || !rdv(f, idp) || !rdv(f, stp) || !rd(f, npk))
@@ -88,6 +91,63 @@ int main(int argc, char **argv)
 	std::vector<std::vector<lw_packet_result>> resA(calls, std::vector<lw_packet_result>(n_call)), resB(calls, std::vector<lw_packet_result>(n_call));
 	std::vector<size_t> elemsA(calls), elemsB(calls);
 	std::vector<lw_shard_packet> pk(n_call);
+	if (fail_mode) {
+		// ---- a launch failure on ONE shard while older calls are in flight on it: the shard's ring is started
+		// over, the older calls' parts on that shard come back LW_ERR_DEVICE (never another call's data), the other shards'
+		// parts are intact, and the shard works again afterwards
+		CHECK(G >= 2 && calls >= 4, "fail mode wants >= 2 shards and >= 4 calls");
+		auto fill = [&](size_t c) {
+			for (size_t s = 0; s < S; s++)
+				for (size_t k = 0; k < per; k++) {
+					const auto &p = packet_of(c, s, k);
+					pk[s * per + k] = lw_shard_packet{A.st[s], p.data(), p.size()};
+				}
+		};
+		for (size_t c = 0; c < 2; c++) {
+			fill(c);
+			CHECK(lw_sharder_submit(A.sh, pk.data(), n_call, 2, &elemsA[c]) == LW_OK, "submit %zu", c);
+		}
+		lw_standin_fail_launch.store(1); // the next launch of whichever shard gets there first
+		fill(2);
+		CHECK(lw_sharder_submit(A.sh, pk.data(), n_call, 2, &elemsA[2]) == LW_ERR_DEVICE, "the submit with the failing launch has to say so");
+		CHECK(lw_sharder_in_flight(A.sh) == 3, "the failed call stays queued so that the other shards' slots can be freed");
+		size_t dead_shard = G;
+		for (size_t c = 0; c < 3; c++) {
+			const int rc = lw_sharder_collect(A.sh, outA.data(), cap, resA[c].data(), n_call);
+			CHECK(rc == LW_ERR_DEVICE, "collect %zu after the failure: %d", c, rc);
+			for (size_t i = 0; i < n_call; i++) {
+				const size_t g = lw_sharder_shard_of(A.sh, 1000 + 7 * (i / per));
+				if (resA[c][i].status == LW_ERR_DEVICE) {
+					CHECK(dead_shard == G || dead_shard == g, "packets of two shards failed: %zu and %zu", dead_shard, g);
+					dead_shard = g;
+				}
+			}
+			CHECK(dead_shard != G, "no packet of call %zu carries the device error", c);
+			for (size_t i = 0; i < n_call; i++) // every packet of the failed shard, and only those
+				if (lw_sharder_shard_of(A.sh, 1000 + 7 * (i / per)) == dead_shard)
+					CHECK(resA[c][i].status == LW_ERR_DEVICE, "call %zu packet %zu of the failed shard: status %d", c, i, resA[c][i].status);
+				else
+					CHECK(resA[c][i].status != LW_ERR_DEVICE, "call %zu packet %zu of a healthy shard: device error", c, i);
+		}
+		CHECK(lw_sharder_in_flight(A.sh) == 0, "every call is consumed by its collect");
+		for (size_t c = 3; c < calls; c++) { // the shard works again (the streams' states on it are whatever the failed calls left)
+			fill(c);
+			CHECK(lw_sharder_submit(A.sh, pk.data(), n_call, 2, &elemsA[c]) == LW_OK, "submit after the failure");
+			CHECK(lw_sharder_collect(A.sh, outA.data(), cap, resA[c].data(), n_call) == LW_OK, "collect after the failure");
+			for (size_t i = 0; i < n_call; i++)
+				CHECK(resA[c][i].status != LW_ERR_DEVICE, "call %zu packet %zu after the restart: device error", c, i);
+		}
+		for (auto *s : A.st)
+			lw_sharder_stream_close(s);
+		for (auto *s : B.st)
+			lw_sharder_stream_close(s);
+		lw_sharder_destroy(A.sh);
+		lw_sharder_destroy(B.sh);
+		lw_setup_free(setup);
+		lw_ident_free(id);
+		printf("sharder failure ok: shard %zu of %zu restarted, older calls reported, %zu calls\n", dead_shard, G, calls);
+		return 0;
+	}
 	// ---- B: call by call
 	for (size_t c = 0; c < calls; c++) {
 		for (size_t s = 0; s < S; s++)

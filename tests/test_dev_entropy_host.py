@@ -38,7 +38,7 @@ def _case(path, setup, pattern, count, **kw):
 
 @pytest.mark.parametrize("name,pattern", [("stereo", "LLSSLSL"), ("stereo_t1", "LSL"), ("mono_small", "LSSLL"), ("stereo_9_12", "LSL"),
                                           ("stereo_7_7", "LSL"), ("stereo_single_entry", "LLS"), ("surround51", "LLSL"),
-                                          ("stereo_spill_t1", "LSLL"), ("stereo_spill_t2", "LLSL"), ("surround51_bookless", "LLSL")])
+                                          ("stereo_spill_t1", "LSLL"), ("stereo_spill_t2", "LLSL"), ("surround51_bookless", "LLSL"), ("multichannel12", "LLSL")])
 def test_device_algorithm_equals_host_stage(harness, tmp_path, name, pattern):
     case = str(tmp_path / "case.bin")
     _case(case, HOST_SETUPS[name](), pattern, 60, seed=11, p_floor_unused=0.15)

@@ -35,7 +35,7 @@ def _damage(pk, rng):
 @pytest.mark.parametrize("name,pattern", [("stereo", "L"), ("stereo", "LLSSSSLLSL"), ("stereo_t1", "LSL"), ("mono_small", "LSSLL"),
                                           ("stereo_9_12", "LLS"), ("stereo_7_7", "LSL"), ("surround51", "LLSL"), ("stereo_6_13", "LSL"),
                                           ("stereo_spill_t1", "LSLL"), ("stereo_spill_t2", "LLSL"), ("stereo_single_entry", "LLS"),
-                                          ("surround51_bookless", "LLSL")])
+                                          ("surround51_bookless", "LLSL"), ("multichannel12", "LSL")])
 def test_ring_with_device_entropy_matches_oracle(name, pattern):
     from lewton_amd.ring import Ring
     setup = HOST_SETUPS[name]()

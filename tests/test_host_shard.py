@@ -64,3 +64,15 @@ def test_pipelined_shards_agree_with_one_shard_call_by_call(harness, tmp_path, n
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "sharder ok: %d shards, %d calls of %d packets" % (shards, calls, streams * per) in out.stdout, out.stdout
+
+
+def test_a_failed_launch_restarts_one_shard_and_older_calls_say_so(harness, tmp_path):
+    """a launch failure on one shard with older calls in flight on it -- the older calls' packets of that shard
+    come back LW_ERR_DEVICE (not another call's data), the other shards' are intact, every collect consumes its call, and the
+    shard decodes again afterwards (stand-in failure injection, ThreadSanitizer)"""
+    case = str(tmp_path / "case.bin")
+    _case(case, SETUPS["stereo"](), "L", 60, seed=7)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    out = subprocess.run([harness, case, "3", "9", "4", "6", "0", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "sharder failure ok" in out.stdout, out.stdout
