@@ -174,6 +174,8 @@ void lw_batch_set_force_generic(lw_batch *b, int on);
 /* Test hook: rounds per workgroup of the specialised long-block kernel for this batch's next lw_batch_entropy (1..16;
  * 0 = the planner decides).  Exercises the hand-over of window state across rounds and workgroups on small batches. */
 void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
+/* test hook: 0 = never run a mixed short / long batch as one k_mix launch (two launches: k_long<EDGE>, k_short), -1 = where it applies */
+void lw_debug_batch_set_mix(lw_batch *b, int mode);
 /* Entropy stage on the device (csrc/lw_dev_entropy.h, k_entropy): the bit-serial half of read_audio_packet_generic
  * (audio.rs:921-986: floor-1 decode :215-251 + amplitude unwrap :391-435, residue decode :587-760) runs on the GPU, one
  * wave per packet; lw_batch_entropy then only reads the prologues, copies the packets into pinned staging and plans the

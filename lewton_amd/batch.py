@@ -79,6 +79,10 @@ class Batch:
     def set_force_generic(self, on):
         N.lw_batch_set_force_generic(self._h, 1 if on else 0)
 
+    def debug_set_mix(self, mode):
+        """test hook (lw_debug_batch_set_mix): 0 = two launches for a mixed short / long batch, -1 = k_mix where it applies"""
+        N.lw_debug_batch_set_mix(self._h, int(mode))
+
     def debug_set_rounds(self, rounds):
         """test hook (lw_debug_batch_set_rounds): rounds per workgroup of the specialised kernel, 0 = planner's choice"""
         N.lw_debug_batch_set_rounds(self._h, int(rounds))

@@ -124,6 +124,12 @@ void lw_batch_set_force_generic(lw_batch *b, int on)
 		b->force_generic = on != 0;
 }
 
+void lw_debug_batch_set_mix(lw_batch *b, int mode)
+{
+	if (b)
+		b->mix_mode = mode;
+}
+
 void lw_debug_batch_set_rounds(lw_batch *b, int rounds)
 {
 	if (b)
@@ -731,6 +737,10 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	if (b->n == 0)
 		return LW_OK;
 	b->ent_done = false;
+	if (b->d_edge) { // k_mix's flags: an edge written for a reader that a NEW plan no longer has must not look ready
+		const size_t entries = b->max_packets * 2 * ch;
+		HIP_TRY(hipMemsetAsync(b->d_edge + entries * LW_EDGE_VALUES, 0, entries * sizeof(uint32_t), st));
+	}
 	if (b->dev_entropy) {
 		HIP_TRY(hipMemcpyAsync(b->d_pk, b->h_pk, b->n * sizeof(LwEntPacket), hipMemcpyHostToDevice, st));
 		if (b->pool_words)
@@ -792,8 +802,11 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	const bool run_generic = b->has_generic || all_generic;
 	const bool run_fast = b->has_fast && !all_generic;
 	const bool run_short = (b->n_tasks[0] > 0 || b->n_tasks[1] > 0) && !all_generic;
-	if (b->edge_mode && (run_fast || run_short) && !b->d_edge)
-		HIP_TRY(hipMalloc((void **)&b->d_edge, b->max_packets * 2 * d->T.ch * LW_EDGE_VALUES * sizeof(float)));
+	if (b->edge_mode && (run_fast || run_short) && !b->d_edge) {
+		const size_t entries = b->max_packets * 2 * d->T.ch; // raw edges, and one flag each for k_mix (zero between launches)
+		HIP_TRY(hipMalloc((void **)&b->d_edge, entries * (LW_EDGE_VALUES * sizeof(float) + sizeof(uint32_t))));
+		HIP_TRY(hipMemsetAsync(b->d_edge + entries * LW_EDGE_VALUES, 0, entries * sizeof(uint32_t), st));
+	}
 	if (run_short && (b->has_generic || all_generic) && !b->d_td) { // (k_short may read / write td blocks next to generic packets)
 		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
 		HIP_TRY(hipMalloc((void **)&b->d_td, 2 * maxres * sizeof(float)));
@@ -843,8 +856,8 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		HIP_TRY(lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic));
 		b->last_kernels += d->any_coupling && (!d->T.pair_coupling || tap) ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 	}
+	LwFastLaunch L{};
 	if (run_fast) {
-		LwFastLaunch L{};
 		L.off = d->fast.off;
 		L.d_image = d->d_fast_image;
 		L.d_items = b->d_items;
@@ -864,24 +877,41 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		for (size_t i = 0; i < units.size() && i < LW_FAST_WAVES; i++)
 			L.units[i] = units[i];
 		L.d_halo = b->d_halo;
+	}
+	auto short_launch = [&](int cls) {
+		const LwShortPlan &bp = d->blkp[cls];
+		LwShortLaunch S{};
+		S.d_image = d->d_blk_image[cls];
+		S.d_slots = b->d_slots[cls];
+		S.lanes = bp.lanes;
+		S.passes = b->blk_passes[cls];
+		S.n_tasks = (uint32_t)b->n_tasks[cls];
+		S.n_units = (uint32_t)bp.units.size();
+		for (size_t i = 0; i < bp.units.size() && i < LW_FAST_WAVES; i++)
+			S.units[i] = bp.units[i];
+		S.d_edge = b->d_edge;
+		return S;
+	};
+	// a mixed short / long batch small enough for the chip to hold at once: both kernels' work in ONE launch (k_mix)
+	bool mixed = false;
+	if (run_fast && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
+		const LwShortLaunch S = short_launch(0);
+		if (lw_mix_applicable(L, S, d->n_cus)) {
+			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * LW_EDGE_VALUES);
+			HIP_TRY(lw_launch_mix(d->T, B, L, S, flags, d_out, b->fmt, st));
+			b->last_kernels += b->n_halo_items ? "k_long<halo>,k_mix," : "k_mix,";
+			mixed = true;
+		}
+	}
+	if (run_fast && !mixed) {
 		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
 	}
-	if (run_short)
+	if (run_short && !mixed)
 		for (int cls = 1; cls >= 0; cls--) { // (the two classes never touch: generic packets lie between them)
 			if (!b->n_tasks[cls])
 				continue;
-			const LwShortPlan &bp = d->blkp[cls];
-			LwShortLaunch S{};
-			S.d_image = d->d_blk_image[cls];
-			S.d_slots = b->d_slots[cls];
-			S.lanes = bp.lanes;
-			S.passes = b->blk_passes[cls];
-			S.n_tasks = (uint32_t)b->n_tasks[cls];
-			S.n_units = (uint32_t)bp.units.size();
-			for (size_t i = 0; i < bp.units.size() && i < LW_FAST_WAVES; i++)
-				S.units[i] = bp.units[i];
-			S.d_edge = b->d_edge;
+			const LwShortLaunch S = short_launch(cls);
 			HIP_TRY(lw_launch_short(d->T, B, S, d_out, b->fmt, st));
 			b->last_kernels += "k_short,";
 		}

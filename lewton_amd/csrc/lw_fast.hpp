@@ -213,6 +213,11 @@ static_assert(sizeof(LwShortSlot) == 48, "LwShortSlot is 48 bytes");
 // floats per packet in the edge buffer: [side: 0 = left edge pa(448..511), 1 = right edge pb(448..511)][ch][64]
 #define LW_EDGE_VALUES 64u
 
+// k_mix (a mixed short / long batch in ONE launch, lw_kernels_long.hip): the last LW_MIX_SHORT_WAVES waves of every workgroup run
+// k_short's work while the first LW_FAST_WAVES - 6 run k_long's (a sparse launch leaves them idle anyway)
+#define LW_MIX_SHORT_WAVES 4u
+#define LW_MIX_LONG_WAVES (LW_FAST_WAVES - 6u)
+
 struct LwShortLaunch {
 	const uint8_t *d_image;
 	const LwShortSlot *d_slots; // [n_tasks][passes][64 / lanes]

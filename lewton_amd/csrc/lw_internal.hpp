@@ -98,7 +98,8 @@ struct lw_batch {
 	size_t max_tasks[2] = {0, 0}, n_tasks[2] = {0, 0}; // (max_tasks: capacity in SLOTS)
 	uint32_t blk_passes[2] = {1, 1}; // passes per wave of this batch (lw_fast.hpp)
 	bool edge_mode = false;  // short blocks in k_short, long blocks with short slopes in k_long<EDGE>
-	float *d_edge = nullptr; // [max_packets][2][ch][64]
+	float *d_edge = nullptr; // [max_packets][2][ch][64], and behind it the flags of k_mix: [max_packets][2][ch] dwords
+	int mix_mode = -1;       // lw_debug_batch_set_mix: -1 = k_mix where it applies, 0 = never (two launches)
 	std::vector<uint32_t> blk_idx[2], blk_slot[2];
 	std::vector<int32_t> succ; // per packet: the next packet of the same stream in this batch, or -1
 	// entropy stage on the device: the packets themselves go up (word-aligned, zero padded) with one descriptor each

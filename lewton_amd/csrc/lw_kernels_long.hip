@@ -1327,322 +1327,9 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t byte_addr, uint32_t need)
 template <int FMT, bool RIGHT_ONLY, bool TD = false, bool EDGE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const uint32_t lane_id = threadIdx.x & 63u;
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	LW_STAMP_DECL;
-	LW_STAMP(0);
-	const uint32_t n_units = F.n_units, per_round = F.per_round, rounds = F.rounds;
-	// this wave's unit and packet slot: one 8-byte scalar load from the kernel-argument segment, requested together with ...
-	LwFastUnit un;
-#if defined(__HIP_DEVICE_COMPILE__)
-	typedef const unsigned long long __attribute__((address_space(4))) *ka_ptr;
-	const unsigned long long unit_word = ((ka_ptr)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(LwFastArgs, waves) / 8 + wave];
-#else
-	const unsigned long long unit_word = 0;
-#endif
-	// ... every scalar the first HBM loads depend on: ONE batch of kernel-argument loads behind one wait (the compiler
-	// would otherwise load them one by one, each behind its own s_waitcnt, on the critical path to the first load)
-	asm volatile("" ::"s"(F.residue), "s"(F.floors), "s"(F.n_items), "s"(n_units), "s"(per_round), "s"(rounds), "s"(F.dense),
-			"s"(F.late_from), "s"(F.ch), "s"(F.fstride), "s"(F.image), "s"(unit_word));
-	__builtin_memcpy(&un, &unit_word, 8);
-	const uint32_t slot = un.slot, uidx = wave - slot * n_units; // packet slot of the round, unit of the packet
-	const bool active = slot < per_round;
-	const uint32_t item0 = blockIdx.x * per_round * rounds + slot;      // item of round j = item0 + j * per_round
-	const bool two = !SPLIT && un.ch_b >= 0; // (SPLIT: every unit is one channel; ch_b, if any, is the coupling partner whose residues are loaded)
-	const int chn[2] = {un.ch_a, two ? un.ch_b : un.ch_a};
-#define LW_PRE_WAVES 2 // waves that queue their HBM loads before the barrier (waves 0-3 can: the others stage the image);
-                       // measured: 1 -> 17.33, 2 -> 17.0-17.16, 4 -> 17.73 us; releasing the next wave of the chain before
-                       // (18.0) or half-way through (17.17) the own loads is slower than after them
-	const bool late = !RIGHT_ONLY && wave >= (F.late_from > LW_PRE_WAVES ? F.late_from : (uint32_t)LW_PRE_WAVES);
-
-	// ---- round 0: table image (L2-resident) and residues/floors (HBM); early waves queue their HBM loads first
-	ItemRegs it{};
-	Pref pf{};
-	bool valid = active && item0 < F.n_items;
-	if (valid) {
-		if (F.dense)
-			dense_offsets(F, item0, it);
-		else
-			it = load_item(F.items, item0);
-	}
-	// Waves 0-3 (the first pacing group) only queue their HBM loads; waves 4-15 stage the table image (1536 x 16 bytes =
-	// 2 per thread, no tail) and clear the hand-over counters.  A wave that waits for image data therefore never has
-	// residue loads in flight (s_waitcnt vmcnt counts in order), and the first group's loads are issued ~1 us after launch.
-	static_assert(LWI_TOTAL / 16 == 2 * (LW_WG - 256), "image staging: 12 waves x 2 x 16 bytes per thread");
-	static_assert(LW_FLOOR_FIRST_FROM >= 4, "floor-first waves request their floor records after staging the image");
-	const bool floor_first = late && two && F.late_from < LW_FAST_WAVES && wave >= LW_FLOOR_FIRST_FROM;
-	if (wave < 4) {
-		if (valid && !late)
-			issue_loads(F, it, un, lane_id, pf);
-	} else {
-		const uint32_t t = threadIdx.x - 256u;
-		const uint4 *src = reinterpret_cast<const uint4 *>(F.image) + t;
-		uint4 *dst = reinterpret_cast<uint4 *>(smem) + t;
-		const uint4 v0 = src[0], v1 = src[LW_WG - 256];
-		if (t < 3 * LW_FAST_WAVES)
-			lds_store_u32(LW_CNT_BASE + 4u * t, 0u);
-		dst[0] = v0;
-		dst[LW_WG - 256] = v1;
-		lds_fence();
-		if (valid && !late)
-			issue_loads(F, it, un, lane_id, pf);
-		// a floor-first wave (below) asks for its floor records now, 58 bytes per channel: behind the image data it just
-		// waited for (loads return in order), ahead of every residue it will request
-		if (valid && floor_first)
-			issue_floor_loads(F, it, un, lane_id, pf);
-	}
-	__syncthreads();
-	const char *img = smem;
-	LW_STAMP(2);
-	char *sc = smem + LWI_TOTAL + wave * LW_SCR_BYTES;
-	char *pub0 = smem + LWI_TOTAL + LW_FAST_WAVES * LW_SCR_BYTES; // [wave][LW_PUB_BYTES]
-	char *pub = pub0 + wave * LW_PUB_BYTES;
-	// A wave far enough back in the load queue builds its floor curve NOW, before its turn to request residues comes (the
-	// queue advances by one wave per ~0.6 us; the floor stage is ~1.8 us of LDS round trips with the VALU mostly idle):
-	// when its residues land, only inverse coupling, one multiply per bin and the IMDCT are left.  The first waves of the
-	// queue request their residues first (the queue must not wait for them) and build the curve afterwards.
-#define LW_PACE_VMCNT 63
-	// Order the HBM queue: wave w issues its loads when wave w - late_from has issued its own (LW_PACE_VMCNT = 63) or
-	// has all but LW_PACE_VMCNT of them back.  Requests of one CU are served in issue order, so the data arrives
-	// wave by wave instead of all at the end of the burst: the first waves compute while the later waves' data is
-	// still in flight (issue order, one wave at a time, measured best: 18.7 us vs 27 us unpaced).
-	const bool paced = !RIGHT_ONLY && F.late_from < LW_FAST_WAVES;
-	// ---- round 0 up to the spectrum (floor x residue) in the residue registers
-	// (the lane id is laundered, as in the loop below: with its known bits visible hipcc turns every `4 lane + const` of the
-	// floor stage into an integer OR plus a conversion, two instructions per bin instead of one addition)
-	uint32_t lane0 = lane_id;
-	asm volatile("" : "+v"(lane0));
-	if (valid && floor_first) {
-		// (one block, so that no residue register is live during the floor stage and no floor register after it)
-		float4_t fl[2][4]; // floor value of every bin this lane holds
-		floor_phase<2>(F, img, sc, lane0, un, pf.fe, fl);
-		LW_STAMP(1);
-		__builtin_amdgcn_s_setprio(LW_PRIO_PACE);
-		lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
-		issue_residue_loads<true>(F, it, un, lane_id, pf);
-		LW_STAMP(15);
-		if (wave + F.late_from < LW_FAST_WAVES) {
-			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW_PACE_VMCNT) : "memory");
-			lds_store_u32(LW_CNT_LANDED(wave), 1u);
-		}
-		if (F.dense)
-			it = load_item(F.items, item0); // the rest of the item (phase 2); its latency hides behind the residues'
-		__builtin_amdgcn_s_setprio(LW_PRIO_READY);
-		LW_STAMP_W(3);
-		spectrum_ready(un, pf, fl);
-		__builtin_amdgcn_s_setprio(0);
-		LW_STAMP(4);
-	} else {
-		if (paced) {
-			__builtin_amdgcn_s_setprio(LW_PRIO_PACE);
-			if (late) {
-				lds_wait_ge(LW_CNT_LANDED(wave - F.late_from), 1u);
-				if (valid)
-					issue_loads(F, it, un, lane_id, pf);
-			}
-			LW_STAMP(15);
-			if (wave + F.late_from < LW_FAST_WAVES) {
-				asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW_PACE_VMCNT) : "memory");
-				lds_store_u32(LW_CNT_LANDED(wave), 1u);
-			}
-			__builtin_amdgcn_s_setprio(0);
-		}
-		if (valid && F.dense)
-			it = load_item(F.items, item0); // the rest of the item (phase 2); its latency hides behind the residues'
-		LW_STAMP_W(3);
-		if (valid) {
-			if (two)
-				spectrum_fused<2>(F, img, sc, lane0, un, pf);
-			else
-				spectrum_fused<1, SPLIT>(F, img, sc, lane0, un, pf);
-		}
-		LW_STAMP(4);
-	}
-	uint32_t n_pub_used = 0; // hand-overs published by this wave (only those a successor reads are published)
-	uint32_t n_got = 0;      // hand-overs consumed from the predecessor wave
-	// predecessor waves: same round (slot > 0) / previous round (slot == 0)
-	const uint32_t wprev = slot != 0 ? wave - n_units : (per_round - 1) * n_units + uidx;
-
-	for (uint32_t j = 0; j < rounds; j++) {
-		// launder the lane id once per round: everything derived from it (LDS addresses, bin numbers as floats) is
-		// recomputed where it is used instead of being hoisted out of the loop and kept in registers
-		uint32_t lane = lane_id;
-		asm volatile("" : "+v"(lane));
-		float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb) at q_k(m' = 2 lane + c2): un-windowed left / right halves
-		const uint32_t item_n = item0 + (j + 1) * per_round;
-		const bool valid_n = active && j + 1 < rounds && item_n < F.n_items;
-		ItemRegs itn{};
-		if (valid_n && !F.dense)
-			itn = load_item(F.items, item_n);
-		if (valid) {
-			if (two)
-				long_imdct<2>(F, img, sc, lane, pf, R);
-			else
-				long_imdct<1>(F, img, sc, lane, pf, R);
-			if (j == 0)
-				LW_STAMP(8);
-		}
-		if (valid) {
-			if (RIGHT_ONLY) {
-#pragma unroll
-				for (int c = 0; c < 2; c++)
-					if (c == 0 || two) {
-						float *dst = F.halo + ((size_t)it.halo_out * F.ch + chn[c]) * 512u;
-						*reinterpret_cast<float4_t *>(dst + 4u * lane) = LW_PB_LO0(c);
-						*reinterpret_cast<float4_t *>(dst + 508u - 4u * lane) = LW_PB_LO1(c);
-					}
-			} else {
-				__builtin_amdgcn_s_setprio(LW_PRIO_FINISH); // finish: hand-over, overlap-add, stores
-				// EDGE kernels: geometry of a long block with a short slope on the left (window starts at 448, the first 128
-				// samples are k_short's) and / or on the right (samples up to 1472, 128-sample right part)
-				const bool edge_l = EDGE && (it.flags & LW_IF_EDGE_L), edge_r = EDGE && (it.flags & LW_IF_EDGE_R);
-				const uint32_t e_ls = edge_l ? 448u : 0u, e_m = EDGE ? (edge_r ? 1472u : 1024u) - e_ls : 1024u;
-				// ---- publish my right half: wait until the previous one has been read, write, bump the counter
-				if (it.flags & LW_IF_NEXT_LDS) {
-					lds_wait_ge(LW_CNT_ACK(wave), n_pub_used);
-					if (two)
-						publish<2>(pub, lane, R);
-					else
-						publish<1>(pub, lane, R);
-					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-					n_pub_used++;
-					lds_store_u32(LW_CNT_PUB(wave), n_pub_used);
-				}
-				// ---- the previous packet's right half: from my predecessor wave through LDS, or (chunk starts) from the
-				//      stream's state slot / the halo buffer / a generic predecessor's time-domain block; then window,
-				//      overlap-add, conversion and stores, one channel at a time (register pressure)
-				if (it.src_kind != LW_SRC_NONE) {
-					const float *g = nullptr;
-					uint32_t cstride = 0;
-					const char *src = nullptr;
-					if (it.src_kind == LW_SRC_LDS) {
-						++n_got;
-						lds_wait_ge(LW_CNT_PUB(wprev), n_got);
-						src = pub0 + wprev * LW_PUB_BYTES;
-					} else if (it.src_kind == LW_SRC_STATE) {
-						const uint32_t pin = (it.flags & LW_RF_PARITY_IN) ? 1u : 0u;
-						g = F.state + ((size_t)it.src_arg * 2 + pin) * F.state_stride;
-						cstride = F.state_chan_stride;
-					} else if (it.src_kind == LW_SRC_HALO) {
-						g = F.halo + (size_t)it.src_arg * F.ch * 512u;
-						cstride = 512u;
-					} else { // LW_SRC_TD: second half of the predecessor's [ch][2048] time-domain block
-						g = F.td + (size_t)it.src_arg + 1024u;
-						cstride = 2048u;
-					}
-					if (j == 0)
-						LW_STAMP(9);
-					if (FMT == LW_OUT_I16_ITL_STEREO) {
-						// 2-channel stream decoded as one channel pair: both channels of a sample position leave in one 16-byte store
-						uint32_t D[2][4][2];
-#pragma unroll
-						for (int c = 0; c < 2; c++) {
-							PrevHalf ph;
-							if (src)
-								prev_from_lds(src + 2048 * c, lane, ph);
-							else
-								prev_from_global(g + (uint32_t)chn[c] * cstride, lane, ph);
-							ola_pack_i16(img, lane, R[c], ph, D[c]);
-						}
-						if (chn[0] == 0)
-							store_interleaved2(F, lane, it.out_off, D[0], D[1]);
-						else
-							store_interleaved2(F, lane, it.out_off, D[1], D[0]);
-					} else {
-#pragma unroll
-						for (int c = 0; c < 2; c++)
-							if (c == 0 || two) {
-								PrevHalf ph;
-								if (src)
-									prev_from_lds(src + 2048 * c, lane, ph);
-								else
-									prev_from_global(g + (uint32_t)chn[c] * cstride, lane, ph);
-								ola_store<FMT>(F, img, lane, chn[c], it.out_off, R[c], ph, e_m);
-							}
-					}
-					if (src) {
-						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						lds_store_u32(LW_CNT_ACK(wprev), n_got);
-					}
-				}
-				if (EDGE && (edge_l || edge_r)) {
-					// ---- short slopes: the un-windowed samples past them, the raw edges for k_short, the 128-sample state
-#pragma unroll
-					for (int c = 0; c < 2; c++)
-						if (c == 0 || two) {
-							const bool inner = lane >= 16u; // this lane's q in [508 - 4 lane, +4) lies below 448
-							const bool sound = !(it.flags & LW_IF_SILENT); // (the first packet of a stream yields no samples at all)
-							float *edge = F.edge + ((size_t)it.pkt * 2u * F.ch + (uint32_t)chn[c]) * LW_EDGE_VALUES;
-							if (edge_l) {
-								// cur[1023 - q] = -pa(q) for q < 448 (imdct.rs:589-658), positions 576..1023 -> samples 128..575
-								const float4_t lo0 = LW_PA_LO0(c), lo1 = LW_PA_LO1(c);
-								store_quad<FMT>(F, chn[c], it.out_off, e_m, 1020u - 4u * lane - 448u, float4_t{-lo0.w, -lo0.z, -lo0.y, -lo0.x}, sound);
-								store_quad<FMT>(F, chn[c], it.out_off, e_m, 512u + 4u * lane - 448u, float4_t{-lo1.w, -lo1.z, -lo1.y, -lo1.x}, sound && inner);
-								if (!inner) // raw left edge pa(448 + i), i = 60 - 4 lane ..
-									store16_wt(edge + 60u - 4u * lane, lo1);
-							}
-							if (edge_r) {
-								// cur[1024 + q] = pb(q) for q < 448: positions 1024..1471
-								const float4_t lo0 = LW_PB_LO0(c), lo1 = LW_PB_LO1(c);
-								store_quad<FMT>(F, chn[c], it.out_off, e_m, 1024u + 4u * lane - e_ls, lo0, sound);
-								store_quad<FMT>(F, chn[c], it.out_off, e_m, 1532u - 4u * lane - e_ls, lo1, sound && inner);
-								if (!inner) { // raw right part cur[1472 .. 1600): pb(448 + i), then mirrored
-									store16_wt(edge + (size_t)F.ch * LW_EDGE_VALUES + 60u - 4u * lane, lo1);
-									if (it.state_out >= 0) {
-										float *dst = F.state + ((size_t)it.state_out * 2 + ((it.flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride +
-											(uint32_t)chn[c] * F.state_chan_stride;
-										store16_wt(dst + 60u - 4u * lane, lo1);
-										store16_wt(dst + 64u + 4u * lane, float4_t{lo1.w, lo1.z, lo1.y, lo1.x});
-									}
-								}
-							}
-						}
-				}
-				// ---- raw right half to the stream's state slot and/or to the td block a generic successor reads
-				const bool to_state = it.state_out >= 0 && !edge_r, to_td = (it.flags & LW_RF_WRITE_TD) != 0;
-				if (to_state || to_td) {
-#pragma unroll
-					for (int c = 0; c < 2; c++)
-						if (c == 0 || two) {
-							const float4_t lo0 = LW_PB_LO0(c), lo1 = LW_PB_LO1(c);
-							if (to_state) {
-								const uint32_t pout = (it.flags & LW_RF_PARITY_OUT) ? 1u : 0u;
-								store_right_half(F.state + ((size_t)it.state_out * 2 + pout) * F.state_stride +
-										(uint32_t)chn[c] * F.state_chan_stride, lane, lo0, lo1);
-							}
-							if (to_td)
-								store_right_half(F.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u + 1024u, lane, lo0, lo1);
-							if (TD && (it.flags & LW_IF_TDONLY)) // the un-windowed left half too: cur[q] = pa(q), cur[1023 - q] = -pa(q)
-								store_left_half(F.td + 2u * (size_t)it.res_off + (uint32_t)chn[c] * 2048u, lane, LW_PA_LO0(c), LW_PA_LO1(c));
-						}
-				}
-			}
-		}
-		if (j == 0)
-			LW_STAMP(10);
-		__builtin_amdgcn_s_setprio(0);
-		// ---- HBM loads of the next round
-		if (valid_n) {
-			if (F.dense) {
-				dense_offsets(F, item_n, itn);
-				issue_loads(F, itn, un, lane, pf);
-				itn = load_item(F.items, item_n);
-			} else {
-				issue_loads(F, itn, un, lane, pf);
-			}
-			// ... and its spectrum (waits for them; the stage sits here, not at the top of the loop, so that round 0 can
-			// enter the loop with its spectrum already built on either of the two paths above)
-			if (two)
-				spectrum_fused<2>(F, img, sc, lane, un, pf);
-			else
-				spectrum_fused<1, SPLIT>(F, img, sc, lane, un, pf);
-		}
-		it = itn;
-		valid = valid_n;
-	}
-	LW_STAMP_W(11);
-	LW_STAMP_FLUSH;
+	constexpr bool MIXF = false;
+	uint32_t *const edge_flags = nullptr;
+#include "lw_long_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1675,15 +1362,18 @@ struct LwBlkLds { // compile-time facts of the LDS layout: [table image][gather]
 
 // LDS of a wave behind the image.  Every area sits at a compile-time offset (ds offsets fold into the instructions: sizing the
 // floor areas for the stream's real post count at run time saved 3 KB per wave and cost 8 % at 16 384 packets per launch).
-template <int L>
+// ONE: the areas of one channel and one pass only (k_mix: the waves finish one channel each, 13 of them share a workgroup's LDS)
+template <int L, bool ONE = false>
 struct LwBlkWave {
-	static constexpr uint32_t SLOTS = 64u / L, POSTS = LW_BLK_MAX_POSTS(L);
+	static constexpr uint32_t SLOTS = 64u / L, POSTS = LW_BLK_MAX_POSTS(L), CH = ONE ? 1u : 2u;
 	static constexpr uint32_t SCR = 0;                              // bit-reverse gather of one channel: [slot][8 L] pairs
 	static constexpr uint32_t PUB = 4096u;                          // right parts [pass parity][slot][channel][c2][l] float4
-	static constexpr uint32_t REC = PUB + 8192u;                    // floor records [slot][channel][POSTS] u16
-	static constexpr uint32_t TAB = REC + SLOTS * 2u * POSTS * 2u;  // interval entries [slot][channel][POSTS] x 16 bytes
-	static constexpr uint32_t BYTES = TAB + SLOTS * 2u * POSTS * 16u;
+	static constexpr uint32_t PUB_PASS = SLOTS * CH * 2u * L * 16u; // ... of one pass (4 KB; ONE: 2 KB)
+	static constexpr uint32_t REC = PUB + (ONE ? 1u : 2u) * PUB_PASS; // floor records [slot][channel][POSTS] u16
+	static constexpr uint32_t TAB = REC + SLOTS * CH * POSTS * 2u;  // interval entries [slot][channel][POSTS] x 16 bytes
+	static constexpr uint32_t BYTES = TAB + SLOTS * CH * POSTS * 16u;
 };
+static_assert(LwBlkWave<8>::PUB_PASS == 4096u && LwBlkWave<32>::PUB_PASS == 4096u, "right parts of one pass: 4 KB");
 
 struct LwShortArgs {
 	const float *residue;
@@ -1961,186 +1651,94 @@ __device__ __forceinline__ void short_store_right(float *dst, uint32_t l, const 
 	store16_wt(dst + 16u * L - 4u - 4u * l, float4_t{lo0.w, lo0.z, lo0.y, lo0.x});
 }
 
+// 16-byte load that sees what another workgroup's wave has written through (sc1) in this very launch (k_mix: the raw edges)
+__device__ __forceinline__ Half8 load_half8_coherent(const float *src, uint32_t l, uint32_t L8)
+{
+	Half8 h;
+	asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+	             : "=&v"(h.lo), "=&v"(h.hi) : "v"(src + 4u * l), "v"(src + (L8 - 4u) - 4u * l) : "memory");
+	return h;
+}
+
+__device__ __forceinline__ uint32_t load_flag_coherent(const uint32_t *p)
+{
+	uint32_t v;
+	asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+	return v;
+}
+
 template <int FMT, int L>
 __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 {
-	typedef LwBlkLayout<L> Y;
-	typedef LwBlkLds<L> D;
-	constexpr int PT = D::PT;
 	__shared__ __attribute__((aligned(16))) char smem_all[LwBlkLayout<L>::TOTAL + LwBlkWave<L>::BYTES];
-	const uint32_t lane = threadIdx.x, g = lane / L, l_id = lane % L;
-	const uint32_t wid = blockIdx.x;                                   // this wave's (task, unit)
-	const uint32_t task = wid / F.n_units, uidx = wid - task * F.n_units;
-	const LwFastUnit un = F.units[uidx];
-	const bool two = un.ch_b >= 0;
-	const uint32_t chn[2] = {(uint32_t)un.ch_a, (uint32_t)(two ? un.ch_b : un.ch_a)};
-	// Small launches split a channel pair over two waves (un.slot = the one channel this wave finishes, 0xFF = both): the
-	// launch lasts as long as one wave's dependent chain, and past the inverse coupling the channels need nothing from each
-	// other.  Both waves load both residue vectors (a coupled pair) and decouple; each does floor, transform and samples
-	// of its own channel only.
-	const uint32_t only = un.slot;
-	const bool mine[2] = {only != 1u, two && only != 0u};
-	// ---- the table image (L2-resident), staged by the wave that uses it.  (Workgroups of 8-12 waves sharing one image were
-	// measured 6-17 % slower on every shape: their waves start together and move through the memory- and compute-bound
-	// phases in lock step, and a CU takes the next workgroup only when the whole previous one is done; single waves are
-	// dispatched one by one and interleave.)
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(F.image);
-		uint4 *dst = reinterpret_cast<uint4 *>(smem_all);
-		static_assert(Y::TOTAL % 1024u == 0, "whole rows of 64 lanes x 16 bytes");
-		constexpr uint32_t ROUNDS = Y::TOTAL / 1024u;
-		uint4 v[ROUNDS]; // all loads in flight at once: one L2 round trip for the whole image
-#pragma unroll
-		for (uint32_t k = 0; k < ROUNDS; k++)
-			v[k] = src[lane + 64u * k];
-#pragma unroll
-		for (uint32_t k = 0; k < ROUNDS; k++)
-			dst[lane + 64u * k] = v[k];
+	char *const smem = smem_all + LwBlkLayout<L>::TOTAL; // the wave's working areas
+	const uint32_t wid = blockIdx.x, lane = threadIdx.x;     // this wave's (task, unit)
+	constexpr int ONLY = -1;
+	constexpr bool STAGE = true;
+	uint32_t *const edge_flags = nullptr;
+#include "lw_short_body.inc"
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mix: a mixed short / long batch in ONE launch
+// ---------------------------------------------------------------------------------------------
+// BASELINE configs[2] at 4096 packets is two sparse launches -- k_long<EDGE, SPLIT> for the long blocks, k_short<8> behind it for the
+// short ones -- and each lasts about as long as ONE wave's dependent chain plus 3 us of start-up: 8.3 + 7.2 us for 18 MB.  The
+// short blocks need two things from the long ones, the raw edges either side of a run of short blocks; everything else they do
+// (records, floor curves, transforms) is independent.  And the sparse long-block launch leaves waves idle: five packets per
+// workgroup, one channel per wave, are ten of its sixteen.  k_mix is k_long's launch (the same grid, the same body, textually)
+// in which the last LW_MIX_SHORT_WAVES waves of every workgroup, once the table image is staged, turn to k_short's work: wave
+// 12 + i of workgroup g is k_short wave 4 g + i (one channel per wave, known at compile time: 108 registers; the compact areas of
+// LwBlkWave<8, true> laid into the LDS of the idle waves 10..15, the short blocks' 5 KB image behind the workgroup's own
+// areas).  A long block's wave sets a flag in HBM behind each raw edge it has written through; a short wave runs up to its
+// overlap-add and only then waits for the flags of its two edges.  No deadlock: long-block waves wait for nobody, and every
+// workgroup of the grid is resident (the planner never makes more workgroups than CUs for a sparse launch, one per CU).
+static_assert(2u * LwBlkWave<8, true>::BYTES <= 6u * LW_SCR_BYTES && 2u * LwBlkWave<8, true>::BYTES <= 6u * LW_PUB_BYTES,
+		"two short waves' areas fit the transpose buffers of the six idle waves, two more their hand-over buffers");
+#define LW_MIX_IMG_OFF ((LW_LDS_BYTES + 15u) & ~15u) // the short blocks' image behind k_long's own LDS
+#define LW_MIX_LDS_BYTES (LW_MIX_IMG_OFF + LwBlkLayout<8>::TOTAL)
+static_assert(LW_MIX_LDS_BYTES <= 160u * 1024u, "k_long's areas and the short blocks' image fit a CU's LDS");
+
+struct LwMixArgs {
+	uint32_t *flags;     // [packet][side][ch] of the batch, zero between launches (every flag is cleared by its one reader)
+	uint32_t pad[2];
+};
+
+template <int FMT>
+__device__ __forceinline__ void mix_short_role(const LwShortArgs &F, uint32_t *edge_flags, char *smem_dyn, uint32_t wave, uint32_t lane)
+{
+	constexpr int L = 8;
+	const uint32_t i = wave - (LW_FAST_WAVES - LW_MIX_SHORT_WAVES);
+	const uint32_t wid = blockIdx.x * LW_MIX_SHORT_WAVES + i; // this wave's (task, unit half)
+	if (wid >= F.n_waves)
+		return;
+	char *const smem_all = smem_dyn + LW_MIX_IMG_OFF; // every short wave of the workgroup writes the same image there before it reads it
+	// waves 10..15 of a k_mix workgroup have no long-block work: their transpose buffers (24 KB in a row) and their hand-over
+	// buffers (24 KB in a row) hold two short waves' areas each
+	char *const smem = smem_dyn + LWI_TOTAL + (i < 2u ? 0u : LW_FAST_WAVES * LW_SCR_BYTES) + LW_MIX_LONG_WAVES * LW_SCR_BYTES +
+		(i & 1u) * LwBlkWave<L, true>::BYTES;
+	constexpr bool STAGE = true;
+	if (__builtin_amdgcn_readfirstlane((uint32_t)F.units[wid % F.n_units].slot) == 0u) {
+		constexpr int ONLY = 0;
+#include "lw_short_body.inc"
+	} else {
+		constexpr int ONLY = 1;
+#include "lw_short_body.inc"
 	}
-	char *smem = smem_all + Y::TOTAL; // the wave's working areas
-	typedef LwBlkWave<L> W;
-	constexpr uint32_t OFF_SCR = W::SCR, OFF_PUB = W::PUB, OFF_REC = W::REC, OFF_TAB = W::TAB, POSTS_ = W::POSTS;
-	for (uint32_t pass = 0; pass < F.passes; pass++) {
-	// launder the lane index once per pass: everything derived from it (table addresses, twiddles) is recomputed where it is
-	// used instead of being hoisted out of the loop and kept in ~70 registers
-	uint32_t l = l_id;
-	asm volatile("" : "+v"(l));
-	// ---- slot descriptor (all lanes of a group read the same 48 bytes)
-	const uint4 *sp = reinterpret_cast<const uint4 *>(F.slots + (((size_t)task * F.passes + pass) * D::SLOTS + g));
-	const uint4 d0 = sp[0], d1 = sp[1], d2 = sp[2];
-	const uint32_t res_off = d0.x, floor_off = d0.y, out_off = d0.z, prev_arg = d0.w;
-	const int32_t state_out = (int32_t)d1.x;
-	const uint32_t next_edge = d1.y, next_out = d1.z, next_m = d1.w;
-	const uint32_t prev_stride = d2.x & 0xffffu, kind = (d2.x >> 16) & 0xffu, prev_kind = d2.x >> 24, flags = d2.y;
-	const bool has_block = kind == LW_SS_BLOCK || kind == LW_SS_HALO;
-	// ---- HBM loads, all at once: floor records, residues, the previous right part and the successor's left edge
-	uint32_t fe[2][PT];
-	float4_t r[2][4];
-	Half8 prv[2], nxt[2];
-#pragma unroll
-	for (int c = 0; c < 2; c++) {
-		const bool on = mine[c];
-		const bool need_res = (c == 0 || two) && (on || un.coupled); // (the partner's vector: for the inverse coupling only)
-		const uint32_t Fp = c == 0 ? un.F_a : un.F_b;
-		const uint16_t *f = F.floors + floor_off + chn[c] * F.fstride;
-#pragma unroll
-		for (int t = 0; t < PT; t++) {
-			const uint32_t i = l + L * (uint32_t)t;
-			fe[c][t] = on && has_block && i < Fp ? (uint32_t)f[i] : 0u;
-		}
-		const float4_t *s = reinterpret_cast<const float4_t *>(F.residue + res_off + chn[c] * (16u * L));
-#pragma unroll
-		for (int x = 0; x < 4; x++)
-			r[c][x] = need_res && has_block ? __builtin_nontemporal_load(&s[L * x + l]) : float4_t{0.0f, 0.0f, 0.0f, 0.0f};
-		const float *pbase = F.state;
-		uint32_t poff = 0;
-		if (prev_kind == LW_SP_STATE) {
-			poff = (prev_arg * 2u + ((flags & LW_RF_PARITY_IN) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride;
-		} else if (prev_kind == LW_SP_EDGE) {
-			pbase = F.edge;
-			poff = ((prev_arg * 2u + 1u) * F.ch + chn[c]) * LW_EDGE_VALUES;
-		} else if (prev_kind == LW_SP_TD) {
-			pbase = F.td;
-			poff = prev_arg + chn[c] * prev_stride;
-		}
-		prv[c].lo = prv[c].hi = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
-		if (on && prev_kind >= LW_SP_STATE)
-			prv[c] = load_half8<L>(pbase + poff, l);
-		nxt[c].lo = nxt[c].hi = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
-		if (L == 8 && on && next_edge != 0xFFFFFFFFu)
-			nxt[c] = load_half8<L>(F.edge + ((size_t)next_edge * 2u * F.ch + chn[c]) * LW_EDGE_VALUES, l);
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(LW_WG) k_mix(LwFastArgs F, LwShortArgs FS, LwMixArgs M)
+{
+	constexpr bool RIGHT_ONLY = false, TD = false, EDGE = true, SPLIT = true, MIXF = true;
+	uint32_t *const edge_flags = M.flags;
+#define LW_LONG_BODY_AFTER_STAGE                                                  \
+	if (wave >= LW_FAST_WAVES - LW_MIX_SHORT_WAVES) {                            \
+		mix_short_role<FMT>(FS, edge_flags, smem, wave, lane_id);                 \
+		return;                                                                   \
 	}
-	const char *img = smem_all;
-	char *scr = smem + OFF_SCR, *pub = smem + OFF_PUB + 4096u * (pass & 1u);
-	// (the previous slot of group 0 is the last slot of the pass before: the other half of the double buffer)
-	const char *pub_prev = g != 0 ? pub + 16u * ((g - 1u) * 4u * L) : smem + OFF_PUB + 4096u * ((pass & 1u) ^ 1u) + 16u * ((D::SLOTS - 1u) * 4u * L);
-	lds_fence();
-	// ---- floor curves (interval entries by lanes = posts), inverse coupling, floor x residue
-	bool unused[2] = {true, true};
-#pragma unroll
-	for (int c = 0; c < 2; c++) {
-		if (!mine[c])
-			continue;
-		char *rec = smem + OFF_REC + (g * 2u + c) * (POSTS_ * 2u);
-		char *tab = smem + OFF_TAB + (g * 2u + c) * (POSTS_ * 16u);
-		unused[c] = short_floor_table<L>(img, rec, tab, g, l, fe[c], c == 0 ? un.floor_a : un.floor_b, c == 0 ? un.F_a : un.F_b, has_block);
-	}
-	lds_fence();
-	if (two && un.coupled) {
-#pragma unroll
-		for (int x = 0; x < 4; x++) {
-			float m[4] = {r[0][x].x, r[0][x].y, r[0][x].z, r[0][x].w};
-			float a[4] = {r[1][x].x, r[1][x].y, r[1][x].z, r[1][x].w};
-			decouple4(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
-			r[0][x] = float4_t{m[0], m[1], m[2], m[3]};
-			r[1][x] = float4_t{a[0], a[1], a[2], a[3]};
-		}
-	}
-	float2_t R[2][2][4]; // [channel][c2][k] = (pa, pb)
-#pragma unroll
-	for (int c = 0; c < 2; c++) {
-		if (!mine[c])
-			continue;
-		const char *tab = smem + OFF_TAB + (g * 2u + c) * (POSTS_ * 16u);
-		short_spectrum<L>(img, tab, l, c == 0 ? un.floor_a : un.floor_b, unused[c], r[c]);
-		short_imdct<L>(img, scr, g, l, r[c], R[c]);
-		if (L == 8 && kind == LW_SS_EDGE) { // no block of its own: the stored right part stands in for it (feeds the successor's left edge)
-			R[c][0][3].y = prv[c].lo.x, R[c][0][2].y = prv[c].lo.y, R[c][1][3].y = prv[c].lo.z, R[c][1][2].y = prv[c].lo.w;
-			R[c][1][1].y = prv[c].hi.x, R[c][1][0].y = prv[c].hi.y, R[c][0][1].y = prv[c].hi.z, R[c][0][0].y = prv[c].hi.w;
-		}
-		// right part for the next slot of the wave: [slot][channel][c2][l] float4 = pb at k = 0..3
-#pragma unroll
-		for (int c2 = 0; c2 < 2; c2++)
-			*reinterpret_cast<float4_t *>(pub + 16u * (((g * 2u + c) * 2u + c2) * L + l)) =
-				float4_t{R[c][c2][0].y, R[c][c2][1].y, R[c][c2][2].y, R[c][c2][3].y};
-	}
-	lds_fence();
-	// ---- window / overlap-add / stores of the slot's own samples; state; the successor's left edge
-	const uint32_t esz_stride = FMT == LW_OUT_I16_INTERLEAVED ? F.ch : 1u;
-#pragma unroll
-	for (int c = 0; c < 2; c++) {
-		if (!mine[c])
-			continue;
-		if (kind == LW_SS_BLOCK && prev_kind != LW_SP_NONE) {
-			PrevHalf ph;
-			if (prev_kind == LW_SP_LANE) {
-#pragma unroll
-				for (int c2 = 0; c2 < 2; c2++) {
-					const float4_t v = *reinterpret_cast<const float4_t *>(pub_prev + 16u * ((c * 2u + c2) * L + l));
-					ph.pp[c2][0] = float2_t{v.x, v.y};
-					ph.pp[c2][1] = float2_t{v.z, v.w};
-				}
-			} else {
-				prev_from_half8(prv[c], ph);
-			}
-			const uint32_t e0 = FMT == LW_OUT_I16_INTERLEAVED ? out_off + chn[c] : out_off + chn[c] * (16u * L);
-			short_ola_store<FMT, L>(img, l, F.out, e0, esz_stride, R[c], ph);
-		}
-		if (kind == LW_SS_BLOCK && state_out >= 0)
-			short_store_right<L>(F.state + ((size_t)state_out * 2u + ((flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride +
-					chn[c] * F.state_chan_stride, l, R[c]);
-		if (kind == LW_SS_BLOCK && (flags & LW_SF_WRITE_TD))
-			short_store_right<L>(F.td + 2u * (size_t)res_off + chn[c] * (32u * L) + 16u * L, l, R[c]);
-		if (L == 8 && next_edge != 0xFFFFFFFFu && (kind == LW_SS_BLOCK || kind == LW_SS_EDGE)) {
-			// the long successor's first 128 samples: its raw left edge pa(448 + i) against this slot's right part, short slope
-			float2_t Rn[2][4];
-			Rn[0][3].x = nxt[c].lo.x, Rn[0][2].x = nxt[c].lo.y, Rn[1][3].x = nxt[c].lo.z, Rn[1][2].x = nxt[c].lo.w;
-			Rn[1][1].x = nxt[c].hi.x, Rn[1][0].x = nxt[c].hi.y, Rn[0][1].x = nxt[c].hi.z, Rn[0][0].x = nxt[c].hi.w;
-			PrevHalf ph;
-#pragma unroll
-			for (int c2 = 0; c2 < 2; c2++) {
-#pragma unroll
-				for (int k = 0; k < 4; k++)
-					Rn[c2][k].y = 0.0f;
-				ph.pp[c2][0] = float2_t{R[c][c2][0].y, R[c][c2][1].y};
-				ph.pp[c2][1] = float2_t{R[c][c2][2].y, R[c][c2][3].y};
-			}
-			const uint32_t e0 = FMT == LW_OUT_I16_INTERLEAVED ? next_out + chn[c] : next_out + chn[c] * next_m;
-			short_ola_store<FMT, L>(img, l, F.out, e0, esz_stride, Rn, ph);
-		}
-	}
-	lds_fence(); // (the next pass re-uses the record / table / gather areas)
-	} // pass
+#include "lw_long_body.inc"
+#undef LW_LONG_BODY_AFTER_STAGE
 }
 
 template <int L>
@@ -2156,11 +1754,9 @@ static hipError_t launch_short(LwShortArgs &F, int fmt, hipStream_t st)
 	return lw_launch_k(k_short<LW_OUT_F32_PLANAR, L>, grid, block, 0, st, F);
 }
 
-hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st)
+// the kernel arguments of a k_short launch (also the short role of k_mix)
+static void short_prepare(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, LwShortArgs &F)
 {
-	if (L.n_tasks == 0)
-		return hipSuccess;
-	LwShortArgs F{};
 	F.residue = B.residue;
 	F.floors = B.floors;
 	F.slots = L.d_slots;
@@ -2190,6 +1786,14 @@ hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwSh
 	}
 	F.n_units = nu;
 	F.n_waves = L.n_tasks * nu;
+}
+
+hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st)
+{
+	if (L.n_tasks == 0)
+		return hipSuccess;
+	LwShortArgs F{};
+	short_prepare(T, B, L, out, F);
 	if (L.lanes == 8)
 		return launch_short<8>(F, fmt, st);
 	if (L.lanes == 16)
@@ -2202,9 +1806,10 @@ hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwSh
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
-hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st)
+// per-device attributes, the halo pre-pass, and the kernel arguments + grid of the main pass (also the long role of k_mix)
+static hipError_t long_prepare(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, hipStream_t st, LwFastArgs &F,
+		uint32_t &grid)
 {
-	LwFastArgs F{};
 	F.image = L.d_image;
 	F.residue = B.residue;
 	F.floors = B.floors;
@@ -2236,7 +1841,8 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 			(const void *)k_long<LW_OUT_I16_PLANAR, true, false, false, true>,
 			(const void *)k_long<LW_OUT_I16_PLANAR, false, false, false, true>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, false, true>,
 			(const void *)k_long<LW_OUT_F32_PLANAR, false, false, false, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, false, true, true>,
-			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true, true>};
+			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true, true>,
+			(const void *)k_mix<LW_OUT_I16_PLANAR>, (const void *)k_mix<LW_OUT_I16_INTERLEAVED>, (const void *)k_mix<LW_OUT_F32_PLANAR>};
 		for (const void *f : fns) {
 			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			if (e != hipSuccess)
@@ -2257,6 +1863,7 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 		if (e != hipSuccess)
 			return e;
 	}
+	grid = 0;
 	if (L.n_items) {
 		F.items = L.d_items;
 		F.n_items = L.n_items;
@@ -2264,8 +1871,21 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 		F.rounds = L.rounds;
 		F.dense = L.dense;
 		const uint32_t chunk = L.per_round * L.rounds;
-		const uint32_t grid = (L.n_items + chunk - 1) / chunk;
+		grid = (L.n_items + chunk - 1) / chunk;
 		F.late_from = L.late_from;
+	}
+	return hipSuccess;
+}
+
+hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st)
+{
+	LwFastArgs F{};
+	uint32_t grid = 0;
+	const hipError_t pe = long_prepare(T, B, L, out, st, F, grid);
+	if (pe != hipSuccess)
+		return pe;
+	const size_t lds = LW_LDS_BYTES + LW_STAMP_LDS_EXTRA;
+	if (L.n_items) {
 #define LW_LAUNCH_MAIN(F_)                                                                                     \
 	do {                                                                                                      \
 		if (L.split && !L.has_tdonly) { /* sparse launch: one channel per wave (generic interleaved stores: a wave has one channel) */ \
@@ -2293,4 +1913,43 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 #undef LW_LAUNCH_MAIN
 	}
 	return hipSuccess;
+}
+
+// ---- k_mix: can this pair of launches run as one, and the launch itself
+// (the long blocks' launch is the sparse one-channel-per-wave form with raw edges, the short blocks' is 256-point blocks in one pass
+// with every unit a channel pair split over two waves, and the whole grid is resident at once: one workgroup per CU)
+bool lw_mix_applicable(const LwFastLaunch &LL, const LwShortLaunch &LS, int n_cus)
+{
+	if (!LL.n_items || !LL.split || !LL.edge_mode || LL.has_tdonly || !LS.n_tasks || LS.lanes != 8 || LS.passes > 1)
+		return false;
+	if ((size_t)LS.n_tasks * LS.n_units > LW_SHORT_SPLIT_BELOW || 2 * LS.n_units > LW_FAST_WAVES)
+		return false;
+	for (uint32_t u = 0; u < LS.n_units; u++)
+		if (LS.units[u].ch_b < 0)
+			return false;
+	if (LL.per_round * LL.n_units > LW_MIX_LONG_WAVES) // (the long blocks' waves: 0 .. LW_MIX_LONG_WAVES - 1)
+		return false;
+	const uint32_t chunk = LL.per_round * LL.rounds;
+	const size_t n_wg = (LL.n_items + chunk - 1) / chunk;
+	return n_wg <= (size_t)std::max(1, n_cus) && (size_t)LS.n_tasks * LS.n_units * 2 <= n_wg * LW_MIX_SHORT_WAVES;
+}
+
+hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &LL, const LwShortLaunch &LS, uint32_t *d_flags,
+		void *out, int fmt, hipStream_t st)
+{
+	LwFastArgs F{};
+	uint32_t grid = 0;
+	const hipError_t pe = long_prepare(T, B, LL, out, st, F, grid);
+	if (pe != hipSuccess)
+		return pe;
+	LwShortArgs FS{};
+	short_prepare(T, B, LS, out, FS);
+	LwMixArgs M{};
+	M.flags = d_flags;
+	const size_t lds = LW_MIX_LDS_BYTES + LW_STAMP_LDS_EXTRA;
+	if (fmt == LW_OUT_I16_PLANAR)
+		return lw_launch_k(k_mix<LW_OUT_I16_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M);
+	if (fmt == LW_OUT_I16_INTERLEAVED)
+		return lw_launch_k(k_mix<LW_OUT_I16_INTERLEAVED>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M);
+	return lw_launch_k(k_mix<LW_OUT_F32_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M);
 }

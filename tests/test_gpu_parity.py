@@ -319,7 +319,7 @@ def test_long_mixed_single_stream_in_one_batch(name, pattern, fmt):
     res = b.entropy([(p, pwr) for p in pk], n_threads=4)
     b.upload()
     got = b.split(b.synth_to_host(), ch)
-    assert "k_long" in b.last_kernels and "k_short" in b.last_kernels and "generic" not in b.last_kernels
+    assert ("k_mix" in b.last_kernels or ("k_long" in b.last_kernels and "k_short" in b.last_kernels)) and "generic" not in b.last_kernels
     for i, p in enumerate(pk):
         want = po.read_audio_packet(o_id, o_st, p, o_pwr, fmt)
         assert res[i][0] == 0 and got[i].shape == want.shape, i

@@ -53,7 +53,7 @@ def _run_dense(key, fmt="i16", packets=4096):
 def test_configs2_mixed_short_long_bench_shape(fmt):
     bad, kernels, n = _run_dense("3", fmt)
     assert n == 4096 and bad == 0, (bad, kernels)
-    assert kernels == "k_long,k_short"      # two launches, no generic kernel, no time-domain block through HBM
+    assert kernels == "k_mix"               # ONE launch (the chip holds the whole grid), no generic kernel, no time-domain block through HBM
 
 
 @pytest.mark.parametrize("fmt", ["i16", "f32"])
@@ -234,7 +234,7 @@ def test_mixed_streams_one_packet_per_launch(name, fmt):
                 assert np.array_equal(got[s].reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32)), (t, s, bt.last_kernels)
             else:
                 assert np.array_equal(got[s].reshape(-1), want.reshape(-1)), (t, s, bt.last_kernels)
-    assert "k_short" in seen and "k_long" in seen and not any("generic" in k for k in seen), seen
+    assert ("k_mix" in seen or ("k_short" in seen and "k_long" in seen)) and not any("generic" in k for k in seen), seen
     for s in range(n_streams):
         assert np.array_equal(pwrs[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32)), s
     bt.close()
@@ -279,3 +279,35 @@ def test_many_short_blocks_one_wave_per_channel_pair():
     for s in range(0, n_streams, 17):
         assert np.array_equal(pwrs[s].data().view(np.uint32), expect[s % distinct][1].data(2).view(np.uint32))
     bt.close()
+
+
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+@pytest.mark.parametrize("name", ["stereo", "surround51"])
+def test_mixed_batch_as_one_launch_equals_two_launches(name, fmt):
+    """k_mix (long and short blocks of a mixed batch in ONE launch, the short blocks' waves waiting for the long blocks' raw edges
+    through flags in HBM) against the same batch as two launches (k_long<EDGE>, k_short): identical bytes, identical state,
+    also when the same uploaded batch is launched again (the flags are back to zero) and after a re-plan of the same Batch."""
+    from lewton_amd.batch import Batch
+    from common import SETUPS
+    setup = SETUPS[name]()
+    audio, dec = _decoder(setup)
+    n_streams, per = 24, 22
+    streams = [sg.make_stream(setup, "LLSSSSSSSSLLSSLSL", 2 * per, seed=700 + s, p_floor_unused=0.05) for s in range(n_streams)]
+    outs = {}
+    for mode in (-1, 0):
+        pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+        bt = Batch(dec, n_streams * per, fmt)
+        bt.debug_set_mix(mode)
+        flats = []
+        for half in range(2):                      # the second half re-plans the same Batch object (other window shapes, same buffers)
+            bt.entropy([(streams[s][half * per + t], pwrs[s]) for s in range(n_streams) for t in range(per)], n_threads=2)
+            bt.upload()
+            flats.append(bt.synth_to_host().copy())
+            assert ("k_mix" in bt.last_kernels) == (mode == -1), bt.last_kernels
+            again = bt.synth_to_host()             # launching an uploaded batch again is idempotent (state parity, flags cleared)
+            assert np.array_equal(again.view(np.uint8), flats[-1].view(np.uint8))
+        outs[mode] = (flats, [p.data().copy() for p in pwrs])
+    for a, b in zip(outs[-1][0], outs[0][0]):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    for a, b in zip(outs[-1][1], outs[0][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
