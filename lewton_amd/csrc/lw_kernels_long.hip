@@ -1712,12 +1712,12 @@ __device__ __forceinline__ void mix_short_role(const LwShortArgs &F, uint32_t *e
 	const uint32_t wid = blockIdx.x * LW_MIX_SHORT_WAVES + i; // this wave's (task, unit half)
 	if (wid >= F.n_waves)
 		return;
-	char *const smem_all = smem_dyn + LW_MIX_IMG_OFF; // every short wave of the workgroup writes the same image there before it reads it
+	char *const smem_all = smem_dyn + LW_MIX_IMG_OFF; // (staged by the workgroup's last four waves together with k_long's image)
 	// waves 10..15 of a k_mix workgroup have no long-block work: their transpose buffers (24 KB in a row) and their hand-over
 	// buffers (24 KB in a row) hold two short waves' areas each
 	char *const smem = smem_dyn + LWI_TOTAL + (i < 2u ? 0u : LW_FAST_WAVES * LW_SCR_BYTES) + LW_MIX_LONG_WAVES * LW_SCR_BYTES +
 		(i & 1u) * LwBlkWave<L, true>::BYTES;
-	constexpr bool STAGE = true;
+	constexpr bool STAGE = false;
 	if (__builtin_amdgcn_readfirstlane((uint32_t)F.units[wid % F.n_units].slot) == 0u) {
 		constexpr int ONLY = 0;
 #include "lw_short_body.inc"
@@ -1737,8 +1737,26 @@ __global__ void __launch_bounds__(LW_WG) k_mix(LwFastArgs F, LwShortArgs FS, LwM
 		mix_short_role<FMT>(FS, edge_flags, smem, wave, lane_id);                 \
 		return;                                                                   \
 	}
+	// the short blocks' image (5 KB = 320 x 16 bytes) goes up with k_long's, by the threads of the last four waves
+	static_assert(LwBlkLayout<8>::TOTAL / 16u <= 256u + 64u, "one 16-byte row per thread of four waves, a second one for the first 64");
+#define LW_LONG_BODY_STAGE_LOAD                                                                       \
+	const bool s_on = t >= 512u, s_two = s_on && t - 512u < LwBlkLayout<8>::TOTAL / 16u - 256u;       \
+	const uint4 *s_src = reinterpret_cast<const uint4 *>(FS.image) + (s_on ? t - 512u : 0u);          \
+	uint4 s_v0 = make_uint4(0, 0, 0, 0), s_v1 = s_v0;                                                 \
+	if (s_on)                                                                                         \
+		s_v0 = s_src[0];                                                                              \
+	if (s_two)                                                                                        \
+		s_v1 = s_src[256];
+#define LW_LONG_BODY_STAGE_STORE                                                                      \
+	uint4 *s_dst = reinterpret_cast<uint4 *>(smem + LW_MIX_IMG_OFF) + (s_on ? t - 512u : 0u);         \
+	if (s_on)                                                                                         \
+		s_dst[0] = s_v0;                                                                              \
+	if (s_two)                                                                                        \
+		s_dst[256] = s_v1;
 #include "lw_long_body.inc"
 #undef LW_LONG_BODY_AFTER_STAGE
+#undef LW_LONG_BODY_STAGE_LOAD
+#undef LW_LONG_BODY_STAGE_STORE
 }
 
 template <int L>
