@@ -971,15 +971,16 @@ __device__ __forceinline__ void spectrum_ready(const LwFastUnit &un, Pref &pf, c
 // ---- IMDCT of the unit's spectrum up to the un-windowed halves (pa, pb) (wave-private).  Both channels of a pair advance
 // through the stages together (shared twiddles); their transposes go through ONE 4 KB buffer one after the other (LDS
 // operations of a wave execute in order).
-template <int NCH>
+// UP (k_mix): the long blocks' waves share their SIMDs with short blocks' waves that will wait for them: one priority level up
+template <int NCH, int UP = 0>
 __device__ __forceinline__ void long_imdct(const LwFastArgs &F, const char *img, char *sc, uint32_t lane, Pref &pf,
 		float2_t (&R)[2][2][4])
 {
 	// the last waves to get their data (the launch ends when they do) run the IMDCT one priority level up
 	if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= LW_IMDCT_PRIO_LATE)
-		__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT + 1);
+		__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT + 1 + UP);
 	else
-		__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT);
+		__builtin_amdgcn_s_setprio(LW_PRIO_IMDCT + UP);
 	if (NCH == 2) {
 		imdct_pair(img, sc, lane, pf.r, R);
 		return;
@@ -1938,7 +1939,7 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 // with every unit a channel pair split over two waves, and the whole grid is resident at once: one workgroup per CU)
 bool lw_mix_applicable(const LwFastLaunch &LL, const LwShortLaunch &LS, int n_cus)
 {
-	if (!LL.n_items || !LL.split || !LL.edge_mode || LL.has_tdonly || !LS.n_tasks || LS.lanes != 8 || LS.passes > 1)
+	if (!LL.n_items || !LL.split || !LL.edge_mode || LL.has_tdonly || LL.rounds != 1 || !LS.n_tasks || LS.lanes != 8 || LS.passes > 1)
 		return false;
 	if ((size_t)LS.n_tasks * LS.n_units > LW_SHORT_SPLIT_BELOW || 2 * LS.n_units > LW_FAST_WAVES)
 		return false;
