@@ -46,21 +46,12 @@ struct lw_ring {
 	// FIFO cursors (slot indices advance modulo slots.size()): next to stage, next to launch, next to collect / release
 	size_t i_stage = 0, i_launch = 0, i_collect = 0;
 	hipEvent_t last_kernels = nullptr; // kernels_done of the most recent launch (null before the first)
+	hipEvent_t last_all_done = nullptr; // all_done of the most recent launch: the PCM copies run one at a time, in order
 	std::mutex mu;
 	std::condition_variable cv;
 };
 
 namespace {
-
-// The PCM copy of the most recent launch on each device, over ALL rings of the process (two logical shards on one GPU, several
-// callers with a ring each): the copies to the host run one at a time per device, in launch order (see lw_ring_launch).
-std::mutex g_copy_mu;
-struct DevCopy {
-	int device;
-	hipEvent_t done;
-	const lw_ring *owner;
-};
-std::vector<DevCopy> g_last_copy;
 
 bool ok(hipError_t e)
 {
@@ -119,12 +110,6 @@ void lw_ring_destroy(lw_ring *r)
 	if (!r)
 		return;
 	(void)hipSetDevice(r->device);
-	{
-		std::lock_guard<std::mutex> cg(g_copy_mu); // (this ring's events are about to go: nobody may wait for them any more)
-		for (DevCopy &c : g_last_copy)
-			if (c.owner == r)
-				c.done = nullptr, c.owner = nullptr;
-	}
 	for (Slot &s : r->slots) {
 		if (s.stream)
 			(void)hipStreamSynchronize(s.stream);
@@ -228,33 +213,20 @@ int lw_ring_launch(lw_ring *r)
 	// flight share the link, finish together, the caller (first-in first-out) refills all slots at once, and the batches then
 	// move through upload / entropy / synthesis / copy in lock step -- the copy engine idle while the kernels run and the
 	// other way round (measured: every third collect waiting 1.2 ms, 7.2 M packets/s; staggered 13 M, profiles/r04_e2e_ring.txt)
-	// (per DEVICE, not per ring: two rings on one GPU would otherwise fall into the same lock step with each other)
-	{
-		std::lock_guard<std::mutex> cg(g_copy_mu);
-		DevCopy *dc = nullptr;
-		for (DevCopy &c : g_last_copy)
-			if (c.device == r->device)
-				dc = &c;
-		if (rc == LW_OK && s->out_elems && dc && dc->done && !ok(hipStreamWaitEvent(s->stream, dc->done, 0)))
-			rc = LW_ERR_DEVICE;
-		if (rc == LW_OK && s->out_elems &&
-				!ok(hipMemcpyAsync(s->h_out, s->d_out, s->out_elems * r->esz, hipMemcpyDeviceToHost, s->stream)))
-			rc = LW_ERR_DEVICE;
-		if (rc == LW_OK && !ok(hipEventRecord(s->all_done, s->stream)))
-			rc = LW_ERR_DEVICE;
-		if (rc == LW_OK && s->out_elems) {
-			if (!dc) {
-				g_last_copy.push_back(DevCopy{r->device, nullptr, nullptr});
-				dc = &g_last_copy.back();
-			}
-			dc->done = s->all_done;
-			dc->owner = r;
-		}
-	}
+	// (per ring: the same order over ALL rings of a device was measured as well -- two logical shards on one GPU then made 6-7
+	// instead of 8.3 M packets/s, profiles/r04_e2e_ring.txt)
+	if (rc == LW_OK && s->out_elems && r->last_all_done && !ok(hipStreamWaitEvent(s->stream, r->last_all_done, 0)))
+		rc = LW_ERR_DEVICE;
+	if (rc == LW_OK && s->out_elems &&
+			!ok(hipMemcpyAsync(s->h_out, s->d_out, s->out_elems * r->esz, hipMemcpyDeviceToHost, s->stream)))
+		rc = LW_ERR_DEVICE;
+	if (rc == LW_OK && !ok(hipEventRecord(s->all_done, s->stream)))
+		rc = LW_ERR_DEVICE;
 	std::lock_guard<std::mutex> g(r->mu);
 	if (rc != LW_OK)
 		return rc; // the slot stays STAGED (its host-side bookkeeping is done): the caller may retry or drop the ring
 	r->last_kernels = s->kernels_done;
+	r->last_all_done = s->all_done;
 	s->state = SLOT_LAUNCHED;
 	r->i_launch = (r->i_launch + 1) % r->slots.size();
 	return LW_OK;

@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace(" ", "")
-        name = "k_short" if "k_short" in k else "k_long<EDGE>" if "k_long" in k and k.split("(")[0].endswith("true>") else None
+        name = "k_mix" if "k_mix" in k else "k_short" if "k_short" in k else "k_long<EDGE>" if "k_long" in k and k.split("(")[0].endswith("true>") else None
         if name:
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
@@ -31,8 +31,11 @@ for name, cs in agg.items():
     if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
         d["hbm_read_bytes_per_launch"] = 2.0 * pm["FETCH_SIZE"] * 1024   # gfx950: FETCH_SIZE counts half of a wide read
         d["hbm_write_bytes_per_launch"] = pm["WRITE_SIZE"] * 1024
-        tot_r += d["hbm_read_bytes_per_launch"]
-        tot_w += d["hbm_write_bytes_per_launch"]
+        # (a step's kernels are launched dozens of times; the few launches of another kernel are the priming of the streams)
+        if d["launches_per_counter"] >= 16:
+            tot_r += d["hbm_read_bytes_per_launch"]
+            tot_w += d["hbm_write_bytes_per_launch"]
+            d["kernel_of_the_step"] = True
     out[name] = d
 out["total_hbm_bytes_per_step"] = tot_r + tot_w
 json.dump(out, open("$OUT/../pmc_mixed.json", "w"), indent=1, sort_keys=True)
