@@ -67,7 +67,7 @@ def main():
                          "the host learns of the end of the K steps tens of microseconds later, all of it inside the wall-clock span")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other_configs object (BASELINE configs[2], [3], [4]-stepping, blocksize_1 = 10 / 12 / 13)")
-    ap.add_argument("--other-steps", type=int, default=200, help="timed launches per entry of other_configs")
+    ap.add_argument("--other-steps", type=int, default=400, help="timed launches per entry of other_configs")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group also for one process (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--streams", type=int, default=256,

@@ -26,7 +26,7 @@ from lewton_amd.batch import Batch  # noqa: E402
 NB = 4
 
 
-def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None):
+def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0):
     """Time workload `w` (lewton_amd.workloads.Workload): `nb` rotated batches resident in HBM, one hipGraph of `nb` steps replayed,
     HIP events; then (verify) every packet of timed batch 0 against the oracle.  Returns the result line as a dict."""
     if distinct:
@@ -72,9 +72,14 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
         cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for k in range(nb):
             step(k, cs)
-    for _ in range(20):
-        g.replay()
-    torch.cuda.synchronize()
+    import time
+    t_settle = time.perf_counter()   # untimed: tens of milliseconds of load until the device clocks have settled (as bench.py does)
+    while True:
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t_settle) * 1e3 >= settle_ms:
+            break
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(1, steps // nb)
     e0.record()
