@@ -29,6 +29,7 @@
 // equal to the reference's integer render_line for every reachable segment (tests/test_fast_model.py).
 #include <algorithm>
 #include <cstddef>
+#include <mutex>
 
 #include "lw_fast.hpp"
 #include "lw_kernels.hpp"
@@ -1966,9 +1967,44 @@ hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFast
 	LwMixArgs M{};
 	M.flags = d_flags;
 	const size_t lds = LW_MIX_LDS_BYTES + LW_STAMP_LDS_EXTRA;
+	// ONE k_mix grid per device at a time.  Its short blocks' waves wait for long blocks' waves of other workgroups, which is safe
+	// because the whole grid is resident -- two such grids on one device (two decoders, two rings, logical shards; different
+	// streams) could each hold the CUs the other one's missing workgroups are waiting for.  Every launch therefore waits for the
+	// previous k_mix launch of this device, whatever its stream, through one event per device.  (Not while a stream is being
+	// captured: a graph's launches are ordered by the graph, and an event from outside a capture cannot be waited for inside.)
+	struct PerDev {
+		hipEvent_t done = nullptr;
+		bool recorded = false;
+	};
+	static std::mutex mix_mu;
+	static PerDev mix_dev[64];
+	int dev = 0;
+	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+	const bool ordered = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 &&
+		hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+	std::unique_lock<std::mutex> mix_lock(mix_mu, std::defer_lock);
+	if (ordered) {
+		mix_lock.lock();
+		PerDev &pd = mix_dev[dev];
+		if (!pd.done && hipEventCreateWithFlags(&pd.done, hipEventDisableTiming) != hipSuccess)
+			return hipErrorOutOfMemory;
+		if (pd.recorded) {
+			const hipError_t we = hipStreamWaitEvent(st, pd.done, 0);
+			if (we != hipSuccess)
+				return we;
+		}
+	}
+	auto launched = [&](hipError_t e) {
+		if (e == hipSuccess && ordered) {
+			PerDev &pd = mix_dev[dev];
+			e = hipEventRecord(pd.done, st);
+			pd.recorded = e == hipSuccess;
+		}
+		return e;
+	};
 	if (fmt == LW_OUT_I16_PLANAR)
-		return lw_launch_k(k_mix<LW_OUT_I16_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M);
+		return launched(lw_launch_k(k_mix<LW_OUT_I16_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M));
 	if (fmt == LW_OUT_I16_INTERLEAVED)
-		return lw_launch_k(k_mix<LW_OUT_I16_INTERLEAVED>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M);
-	return lw_launch_k(k_mix<LW_OUT_F32_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M);
+		return launched(lw_launch_k(k_mix<LW_OUT_I16_INTERLEAVED>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M));
+	return launched(lw_launch_k(k_mix<LW_OUT_F32_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M));
 }

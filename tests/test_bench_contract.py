@@ -9,7 +9,7 @@ from common import ROOT
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json"])
+@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json", "r04_bench.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).readline()
     d = json.loads(line)
@@ -44,6 +44,15 @@ def test_committed_bench_line_has_the_contract_fields(name):
         assert c["synthesis_only"]["value"] > c["value"]
         sh = d["end_to_end"]["sharder"]
         assert sh["unit"] == "packets/s" and sh["shards"] >= 2 and sh["value"] > 0
+    if name >= "r04":
+        # round 4: every quoted shape under the same clock, each with the oracle check of its timed batch (never `value`)
+        oc = d["other_configs"]
+        assert len(oc) >= 6
+        for label, e in oc.items():
+            assert "bit-exact" in e["parity"], label
+            assert e["us_per_launch"] > 0 and 0 < e["frac"] < 1
+            assert abs(e["frac"] - e["algorithmic_bytes_per_launch"] / (e["us_per_launch"] * 1e-6) / 8e12) < 2e-3, label
+        assert any("k_mix" in e["kernels"] for e in oc.values())
 
 
 def test_device_code_is_the_measured_build():
