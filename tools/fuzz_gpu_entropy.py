@@ -3,7 +3,7 @@
 intact, truncated and bit-flipped packets go through the staging ring twice -- host stage, then k_entropy -- and every
 packet's status and every PCM sample must be identical.  (Both sides are product code; the oracle comparison of either
 path is tests/test_gpu_*.py.)
-    python tools/fuzz_gpu_entropy.py [--packets 200000] [--seed 1] [--setup stereo|stereo_t1|mono_small|surround51|surround51_bookless|spill_t1|spill_t2|real]"""
+    python tools/fuzz_gpu_entropy.py [--packets 200000] [--seed 1] [--setup stereo|stereo_t1|mono_small|surround51|surround51_bookless|multichannel12|spill_t1|spill_t2|real]"""
 import argparse
 import os
 import sys
@@ -36,7 +36,7 @@ if args.setup == "real":
     pattern_len = len(base)
 else:
     setups = {"stereo": sg.stereo_setup, "stereo_t1": lambda: sg.stereo_setup(residue_type=1), "mono_small": sg.mono_setup,
-              "surround51": sg.surround51_setup, "spill_t1": lambda: spill_setup(1), "spill_t2": lambda: spill_setup(2), "surround51_bookless": bookless_submap_setup}
+              "surround51": sg.surround51_setup, "spill_t1": lambda: spill_setup(1), "spill_t2": lambda: spill_setup(2), "surround51_bookless": bookless_submap_setup, "multichannel12": lambda: sg.multichannel_setup(12)}
     setup = setups[args.setup]()
     idp, _, stp = setup.headers()
     base = sg.make_stream(setup, "LLSLSSLL", 400, seed=args.seed, p_floor_unused=0.1)
