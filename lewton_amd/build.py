@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblewton_amd.so")
-SOURCES = ["lw_headers.cpp", "lw_entropy.cpp", "lw_dev_entropy.cpp", "lw_pool.cpp", "lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_fast.cpp", "lw_ring.cpp", "lw_shard.cpp", "lw_ogg.cpp", "lw_capi.cpp", "lw_kernels.hip", "lw_kernels_long.hip", "lw_kernels_entropy.hip"]
+SOURCES = ["lw_headers.cpp", "lw_entropy.cpp", "lw_dev_entropy.cpp", "lw_pool.cpp", "lw_runtime.cpp", "lw_batch.cpp", "lw_packet.cpp", "lw_fast.cpp", "lw_ring.cpp", "lw_shard.cpp", "lw_ogg.cpp", "lw_capi.cpp", "lw_kernels.hip", "lw_kernels_long.hip", "lw_kernels_big.hip", "lw_kernels_entropy.hip"]
 ARCH = os.environ.get("LW_OFFLOAD_ARCH", "gfx950")  # e.g. gfx950:xnack- for an experiment
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall",
          "-Wno-unused-result", "-pthread"]

@@ -57,7 +57,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 	for (int cls = 0; cls < 2; cls++)
 		if (d->blkp[cls].eligible) {
 			// (sized in slots: at most three per packet plus one task of padding, whatever the passes per task)
-			const size_t per_wave = 64 / d->blkp[cls].lanes;
+			const size_t per_wave = std::max<size_t>(1, 64 / d->blkp[cls].lanes); // (k_big: one slot per pass)
 			max_tasks[cls] = 3 * max_packets + 2 * per_wave * d->blkp[cls].passes;
 			o_slots[cls] = slice(max_tasks[cls] * sizeof(LwShortSlot));
 		}
@@ -479,10 +479,11 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			// passes per wave: more slots per recomputed predecessor -- but only while the launch keeps the waves the chip holds
 			// at a time (five per CU: LDS) (a wave's passes run one after the other: 4096 blocks of 1024 points in 820 waves of 3
 			// passes were slower than in 4096 waves of one)
-			const size_t per_wave = 64 / d->blkp[cls].lanes;
-			uint32_t passes = 1;
+			const bool big = d->blkp[cls].lanes > 64; // k_big: a workgroup per task, one slot per pass, at least two (halo + block)
+			const size_t per_wave = big ? 1 : 64 / d->blkp[cls].lanes;
+			uint32_t passes = big ? 2 : 1;
 			while (passes < d->blkp[cls].passes &&
-					b->blk_idx[cls].size() / (per_wave * (passes + 1) - 1) >= 5 * (size_t)std::max(1, d->n_cus))
+					b->blk_idx[cls].size() / (per_wave * (passes + 1) - 1) >= (big ? 4 : 5) * (size_t)std::max(1, d->n_cus))
 				passes++;
 			b->blk_passes[cls] = passes;
 			const size_t per_task = per_wave * passes;
@@ -773,7 +774,7 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	for (int cls = 0; cls < 2; cls++)
 		if (b->n_tasks[cls])
 			HIP_TRY(hipMemcpyAsync(b->d_slots[cls], b->h_slots[cls],
-						b->n_tasks[cls] * (64 / b->dec->blkp[cls].lanes * b->blk_passes[cls]) * sizeof(LwShortSlot),
+						b->n_tasks[cls] * (std::max(1u, 64 / b->dec->blkp[cls].lanes) * b->blk_passes[cls]) * sizeof(LwShortSlot),
 						hipMemcpyHostToDevice, st));
 	if (b->n_items)
 		HIP_TRY(hipMemcpyAsync(b->d_items, b->h_items, b->n_items * sizeof(LwFastItem), hipMemcpyHostToDevice, st));
@@ -890,6 +891,8 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		for (size_t i = 0; i < bp.units.size() && i < LW_FAST_WAVES; i++)
 			S.units[i] = bp.units[i];
 		S.d_edge = b->d_edge;
+		for (uint32_t i = 0; i < LW_FAST_MAX_FLOORS; i++)
+			S.fl_of[i] = bp.fl_of[i];
 		return S;
 	};
 	// a mixed short / long batch small enough for the chip to hold at once: both kernels' work in ONE launch (k_mix)
@@ -912,8 +915,13 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 			if (!b->n_tasks[cls])
 				continue;
 			const LwShortLaunch S = short_launch(cls);
-			HIP_TRY(lw_launch_short(d->T, B, S, d_out, b->fmt, st));
-			b->last_kernels += "k_short,";
+			if (S.lanes > 64) {
+				HIP_TRY(lw_launch_big(d->T, B, S, d_out, b->fmt, st));
+				b->last_kernels += "k_big,";
+			} else {
+				HIP_TRY(lw_launch_short(d->T, B, S, d_out, b->fmt, st));
+				b->last_kernels += "k_short,";
+			}
 		}
 	if (run_generic) {
 		lw_launch_generic_ola(d->T, B, d_out, b->fmt, st, all_generic);

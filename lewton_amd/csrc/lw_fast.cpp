@@ -366,22 +366,30 @@ void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFas
 		plan.why_not = "blocksize_1 = blocksize_0: the two block classes are neighbours with full overlap (generic kernels)";
 		return;
 	}
-	if (bs < LW_BLK_MIN_BS || bs > LW_BLK_MAX_BS) {
-		plan.why_not = "block size outside 256 .. 1024";
+	const bool big = blockflag && bs >= LW_BIG_MIN_BS && bs <= LW_BIG_MAX_BS; // k_big<BS>: a workgroup of n / 32 threads per block
+	if ((bs < LW_BLK_MIN_BS || bs > LW_BLK_MAX_BS) && !big) {
+		plan.why_not = "block size outside 256 .. 1024 (long blocks: and not 4096 / 8192)";
 		return;
 	}
 	plan.bs = bs;
 	plan.lanes = 1u << (bs - 5);
-	plan.passes = plan.lanes == 32 ? 3 : plan.lanes == 16 ? 2 : 1;
+	plan.passes = big ? LW_BIG_MAX_PASSES : plan.lanes == 32 ? 3 : plan.lanes == 16 ? 2 : 1;
 	UnitPlan up;
-	if (const char *why = plan_units(id, s, blockflag, LW_BLK_MAX_POSTS(plan.lanes), up)) {
+	if (const char *why = plan_units(id, s, blockflag, big ? 65 : LW_BLK_MAX_POSTS(plan.lanes), up)) {
 		plan.why_not = why;
 		return;
 	}
+	for (size_t fl = 0; fl < up.floor_slot.size(); fl++)
+		if (up.floor_slot[fl] >= 0)
+			plan.fl_of[up.floor_slot[fl]] = (uint32_t)fl;
 	std::memcpy(plan.short_mode_mask, up.mode_mask, sizeof(plan.short_mode_mask));
 	plan.units = up.units;
 	plan.n_staged_floors = up.n_staged;
 	std::memcpy(plan.staged_floor_F, up.staged_F, sizeof(plan.staged_floor_F));
+	if (big) { // (no LDS image: the tables of the block size stay in HBM / L2)
+		plan.eligible = true;
+		return;
+	}
 	const BlocksizeTables &t = id.tab[blockflag ? 1 : 0];
 	if (plan.lanes == 8)
 		fill_blk_image<8>(t, s, up.floor_slot, plan.image);

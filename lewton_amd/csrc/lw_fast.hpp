@@ -141,6 +141,11 @@ struct LwFastLaunch {
 #define LW_BLK_MIN_BS 8         // block sizes the kernel is instantiated for: 2^8 .. 2^10
 #define LW_BLK_MAX_BS 10
 #define LW_BLK_MAX_SLOTS 8      // blocks per wave: 64 / L
+// k_big<BS> (lw_kernels_big.hip) takes the same slot descriptors for the long blocks of 4096 / 8192 points: one workgroup of
+// L = n / 32 = 128 / 256 threads per task, one slot per pass, no table image
+#define LW_BIG_MIN_BS 12
+#define LW_BIG_MAX_BS 13
+#define LW_BIG_MAX_PASSES 8u    // consecutive blocks of a stream per workgroup (one of them a recomputed predecessor inside a stream)
 #define LW_BLK_MAX_POSTS(L) ((L) >= 16 ? 64 : 32) // floor-1 posts per channel of a block: 4 per lane (L = 8, 16), 2 per lane (L = 32)
 
 // byte offsets inside the LDS image of k_short<L> (compile-time layout; build_blk_plan writes the same)
@@ -176,6 +181,7 @@ struct LwShortPlan {
 	std::vector<LwFastUnit> units;
 	uint32_t n_staged_floors = 0;
 	uint8_t staged_floor_F[LW_FAST_MAX_FLOORS] = {0};
+	uint32_t fl_of[LW_FAST_MAX_FLOORS] = {0}; // floor index (header order) of each staged floor slot (k_big reads the posts' x from T.floor_x)
 };
 
 // what a slot of k_short is
@@ -227,6 +233,7 @@ struct LwShortLaunch {
 	uint32_t n_units;
 	LwFastUnit units[LW_FAST_WAVES];
 	float *d_edge;
+	uint32_t fl_of[LW_FAST_MAX_FLOORS]; // k_big: see LwShortPlan
 };
 
 static inline uint32_t lw_blk_inv_db_offset(uint32_t lanes)

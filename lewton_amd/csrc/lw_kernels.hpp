@@ -107,6 +107,8 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 // Short blocks of such streams (k_short, same translation unit); runs after lw_launch_long (it reads the edge buffer).
 struct LwShortLaunch;
 hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st);
+// Long blocks of 4096 / 8192 points (k_big, lw_kernels_big.hip): the same slot descriptors, L.lanes = 128 / 256
+hipError_t lw_launch_big(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st);
 // Both in ONE launch (k_mix, same translation unit) where lw_mix_applicable says so; d_flags: [packets][2][ch] dwords, zero.
 bool lw_mix_applicable(const LwFastLaunch &LL, const LwShortLaunch &LS, int n_cus);
 hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &LL, const LwShortLaunch &LS, uint32_t *d_flags,

@@ -301,7 +301,8 @@ size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, int blockflag
 	lw::build_blk_plan(*id->p, *s->p, blockflag != 0, fast, plan);
 	if (!plan.eligible)
 		return 0;
-	std::memcpy(plan.image.data() + lw_blk_inv_db_offset(plan.lanes), kInverseDbTable, sizeof(float) * 256);
+	if (!plan.image.empty())
+		std::memcpy(plan.image.data() + lw_blk_inv_db_offset(plan.lanes), kInverseDbTable, sizeof(float) * 256);
 	if (dst)
 		std::memcpy(dst, plan.image.data(), std::min(cap, plan.image.size()));
 	if (units8 && n_units) {
@@ -533,7 +534,7 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	for (int cls = 0; cls < 2; cls++) {
 		LwShortPlan &bp = d->blkp[cls];
 		lw::build_blk_plan(id, s, cls != 0, d->fast, bp);
-		if (!bp.eligible)
+		if (!bp.eligible || bp.image.empty()) // (k_big: no image)
 			continue;
 		std::memcpy(bp.image.data() + lw_blk_inv_db_offset(bp.lanes), kInverseDbTable, sizeof(float) * 256);
 		if (!lw_hip_ok(hipMalloc((void **)&d->d_blk_image[cls], bp.image.size()), "hipMalloc(block kernel image)") ||

@@ -1,0 +1,217 @@
+"""Thread-level numpy model of the big-block kernel k_big<BS> (lw_kernels_big.hip), n = 2^BS = 4096 / 8192.
+
+One workgroup of T = n / 32 threads transforms one (block, channel) at a time; every per-thread register is a numpy array of
+shape [T].  The n/4 complex pairs of the transform (imdct.rs:291-659; pair q = floats (2q, 2q + 1) of the reference's work
+array) live in LDS between the passes, addressed by q' = n/4 - 1 - q and padded by one pair per eight (pad()); a thread holds
+eight pairs per pass and runs up to three butterfly stages on them in registers:
+  P0  step 1 (imdct.rs:337-371) of j = t + T i (i < 4): the pairs q' = j and n/8 + j, then the stage of distance n/8 (step 2,
+      :385-430) and, n = 8192, the stage of distance 512
+  P1  distances 256, 128, 64      q' = 512 (t / 64) + t % 64 + 64 i
+  P2  distances 32, 16, 8         q' = 64 (t / 8) + t % 8 + 8 i
+  P3  the fused last three stages (:234-288) on q' = 8 t + i
+  E   m = t + T e (e < 2): bit-reverse gather (:490-528), step 7 (:533-580), step 8 (:589-658) -> (pa, pb) at
+      p = 2m, 2m + 1, n/4 - 2 - 2m, n/4 - 1 - 2m; window / overlap-add (audio.rs:1116-1118) of the samples n/4 - 1 - p and
+      n/4 + p with the predecessor's pb(p), which the same thread holds
+Every stage of distance D is the reference's butterfly (hi = q', lo = q' + D, twiddle A[r n / (2 D)], r = q' mod 2D < D): step 2
+is the stage of distance n/8.  All arithmetic is single f32 operations in the reference's order (no contraction); the model
+must reproduce the oracle bit for bit (tests/test_big_model.py)."""
+import numpy as np
+
+F = np.float32
+
+
+def pad(q):
+    return q + (q >> 3)
+
+
+def bfly(V, hi, lo, t0, t1):
+    """imdct.rs:445-477 on pairs (x = even float, y = odd float): hi <- hi + lo, lo <- (hi - lo) * twiddle"""
+    k00 = V[hi][1] - V[lo][1]
+    k01 = V[hi][0] - V[lo][0]
+    h = (V[hi][0] + V[lo][0], V[hi][1] + V[lo][1])
+    l = (k01 * t0 + k00 * t1, k00 * t0 - k01 * t1)
+    V[hi], V[lo] = h, l
+
+
+def radix8(V, q0, A, n, D, stages=3):
+    """V: list of 8 (x, y) register pairs of the pairs q' = q0 + (D / 4) i ... for three stages D, D/2, D/4 (or the first `stages`)"""
+    step = D // 4
+    off = q0 % step if stages == 3 else None
+    for s in range(stages):
+        d = D >> s                      # distance of this stage
+        k1 = n // (2 * d)
+        span = d // step                # register distance
+        for i in range(8):
+            if (i // span) % 2 == 0:
+                r = (q0 + step * i) % (2 * d)
+                assert np.all(r < d)
+                bfly(V, i, i + span, A[r * k1], A[r * k1 + 1])
+
+
+def iter54(w):
+    k00 = w[7] - w[3]
+    y0 = w[7] + w[3]
+    y2 = w[5] + w[1]
+    k22 = w[5] - w[1]
+    k33 = w[4] - w[0]
+    k11 = w[6] - w[2]
+    y1 = w[6] + w[2]
+    y3 = w[4] + w[0]
+    return [k11 + k22, k00 - k33, k11 - k22, k00 + k33, y1 - y3, y0 - y2, y1 + y3, y0 + y2]
+
+
+def last3(z, a2):
+    """imdct.rs:234-288 on z[0..16) (z[15 - k] is the reference's z![-k])"""
+    z = list(z)
+    k00 = z[15] - z[7]
+    k11 = z[14] - z[6]
+    z[15] = z[15] + z[7]
+    z[14] = z[14] + z[6]
+    z[7] = k00
+    z[6] = k11
+    k00 = z[13] - z[5]
+    k11 = z[12] - z[4]
+    z[13] = z[13] + z[5]
+    z[12] = z[12] + z[4]
+    z[5] = (k00 + k11) * a2
+    z[4] = (k11 - k00) * a2
+    k00 = z[3] - z[11]
+    k11 = z[10] - z[2]
+    z[11] = z[11] + z[3]
+    z[10] = z[10] + z[2]
+    z[3] = k11
+    z[2] = k00
+    k00 = z[1] - z[9]
+    k11 = z[8] - z[0]
+    z[9] = z[9] + z[1]
+    z[8] = z[8] + z[0]
+    z[1] = (k00 + k11) * a2
+    z[0] = (k00 - k11) * a2
+    z[8:16] = iter54(z[8:16])
+    z[0:8] = iter54(z[0:8])
+    return z
+
+
+def block(spec, bs, tabs, prev_pb=None):
+    """spec: n/2 f32 (floor x residue of one channel).  Returns (time-domain block n f32, overlap-added samples n/2 f32 or None,
+    pb[n/4] as the threads hold it, indexed by p)."""
+    A, B, Cc, W, br = tabs
+    n = 1 << bs
+    n2, n4, n8, T = n // 2, n // 4, n // 8, n // 32
+    t = np.arange(T)
+    U = np.asarray(spec, F)
+    lds = np.zeros((pad(n4 - 1) + 1, 2), F)
+
+    def put(q, v):
+        lds[pad(q), 0], lds[pad(q), 1] = v[0], v[1]
+
+    def get(q):
+        return (lds[pad(q), 0].copy(), lds[pad(q), 1].copy())
+
+    # ---- P0
+    V = [None] * 8
+    for i in range(4):
+        j = t + T * i
+        x0, x2 = U[4 * j], U[4 * j + 2]
+        V[i] = (x0 * A[2 * j + 1] + x2 * A[2 * j], x0 * A[2 * j] - x2 * A[2 * j + 1])
+        e, a = n2 - 3 - 4 * j, n4 + 2 * j
+        me2, me0 = -U[e + 2], -U[e]
+        V[4 + i] = (me2 * A[a + 1] + me0 * A[a], me2 * A[a] - me0 * A[a + 1])
+    for i in range(4):                      # distance n/8 (step 2): r = j, k1 = 4
+        j = t + T * i
+        bfly(V, i, 4 + i, A[4 * j], A[4 * j + 1])
+    if bs == 13:                            # distance 512: (j, j + 512) in both halves, r = j (< 512), k1 = 8
+        for i in (0, 1, 4, 5):
+            j = t + T * (i & 1)
+            bfly(V, i, i + 2, A[8 * j], A[8 * j + 1])
+    for i in range(4):
+        put(t + T * i, V[i])
+        put(n8 + t + T * i, V[4 + i])
+    # ---- P1, P2
+    for D in (256, 32):
+        step = D // 4
+        q0 = (t // step) * (2 * D) + t % step
+        V = [get(q0 + step * i) for i in range(8)]
+        radix8(V, q0, A, n, D)
+        for i in range(8):
+            put(q0 + step * i, V[i])
+    # ---- P3: z[2k], z[2k+1] = pair q' = 8t + 7 - k
+    z = [None] * 16
+    for k in range(8):
+        z[2 * k], z[2 * k + 1] = get(8 * t + 7 - k)
+    z = last3(z, A[n8])
+    for k in range(8):
+        put(8 * t + 7 - k, (z[2 * k], z[2 * k + 1]))
+    # ---- E
+    td = np.zeros(n, F)
+    ola = None if prev_pb is None else np.zeros(n2, F)
+    pb_out = np.zeros(n4, F)
+
+    def pair_of_float(k):                   # the pair holding floats (k, k + 1) of the reference's array, k even
+        return get(n4 - 1 - k // 2)
+    for e_ in range(2):
+        m = t + T * e_
+        t0 = n // 16 - 1 - m
+        k1, k1p, k0, k0p = br[2 * m], br[2 * m + 1], br[2 * t0], br[2 * t0 + 1]
+        Pa, Pb, Pc, Pd = pair_of_float(k1), pair_of_float(k1p), pair_of_float(k0 + 2), pair_of_float(k0p + 2)
+        d = 4 * m
+        ve = [Pb[1], Pb[0], Pa[1], Pa[0]]   # v[e .. e+3], e = n/2 - 4 - 4m
+        vd = [Pd[1], Pd[0], Pc[1], Pc[0]]   # v[d .. d+3]
+        C0, C1, C2, C3 = Cc[d], Cc[d + 1], Cc[d + 2], Cc[d + 3]
+        a02 = vd[0] - ve[2]
+        a11 = vd[1] + ve[3]
+        b0 = C1 * a02 + C0 * a11
+        b1 = C1 * a11 - C0 * a02
+        b2 = vd[0] + ve[2]
+        b3 = vd[1] - ve[3]
+        vd[0], vd[1], ve[2], ve[3] = b2 + b0, b3 + b1, b2 - b0, b1 - b3
+        a02 = vd[2] - ve[0]
+        a11 = vd[3] + ve[1]
+        b0 = C3 * a02 + C2 * a11
+        b1 = C3 * a11 - C2 * a02
+        b2 = vd[2] + ve[0]
+        b3 = vd[3] - ve[1]
+        vd[2], vd[3], ve[0], ve[1] = b2 + b0, b3 + b1, b2 - b0, b1 - b3
+        for p, w0, w1 in ((2 * m, vd[0], vd[1]), (2 * m + 1, vd[2], vd[3]), (n4 - 2 - 2 * m, ve[0], ve[1]), (n4 - 1 - 2 * m, ve[2], ve[3])):
+            pa = w0 * B[2 * p + 1] - w1 * B[2 * p]
+            pb = (-w0) * B[2 * p] - w1 * B[2 * p + 1]
+            q = n4 - 1 - p
+            td[q], td[n2 - 1 - q], td[n2 + q], td[n - 1 - q] = pa, -pa, pb, pb
+            pb_out[p] = pb
+            if prev_pb is not None:
+                pp = prev_pb[p]
+                ola[q] = (pa * W[q]) + (pp * W[n2 - 1 - q])
+                ola[n2 - 1 - q] = ((-pa) * W[n2 - 1 - q]) + (pp * W[q])
+    return td, ola, pb_out
+
+
+def floor_group(posts_x, posts_y, K, k0):
+    """the four floor values y of bins k0 .. k0+3 as a thread computes them: binary search for the interval of k0, at most one
+    step forward per bin (the posts' x are distinct integers), render_line's closed form (audio.rs:503-524) with the integer
+    division done by a reciprocal and a correction.  posts_x / posts_y: the ACTIVE posts in ascending x."""
+    lo, hi = 0, K - 1
+    while lo < hi:
+        mid = (lo + hi + 1) >> 1
+        if posts_x[mid] <= k0:
+            lo = mid
+        else:
+            hi = mid - 1
+    ys = []
+    for k in range(k0, k0 + 4):
+        if lo + 1 < K and posts_x[lo + 1] <= k:
+            lo += 1
+        if lo == K - 1:
+            ys.append(int(posts_y[lo]))
+            continue
+        x0, x1, y0, y1 = int(posts_x[lo]), int(posts_x[lo + 1]), int(posts_y[lo]), int(posts_y[lo + 1])
+        dy, adx = y1 - y0, x1 - x0
+        ady = abs(dy)
+        num = ady * (k - x0)
+        q = int(F(F(num) * (F(1.0) / F(adx))))          # (the kernel: v_rcp_f32, 1 ulp; any error below one unit is corrected)
+        rem = num - q * adx
+        if rem < 0:
+            q -= 1
+        elif rem >= adx:
+            q += 1
+        ys.append(y0 - q if dy < 0 else y0 + q)
+    return ys

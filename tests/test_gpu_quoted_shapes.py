@@ -70,10 +70,20 @@ def test_uncoupled_pair_and_single_channel_units_bench_shape(key):
     assert kernels == "k_long"
 
 
-@pytest.mark.parametrize("key", ["11", "12"])
+@pytest.mark.parametrize("key", ["11", "12", "13"])
 def test_other_long_block_sizes_bench_shape(key):
     bad, kernels, n = _run_dense(key, packets=1024)
     assert n == 1024 and bad == 0, (bad, kernels)
+    assert kernels == ("k_short" if key == "12" else "k_big")
+
+
+@pytest.mark.parametrize("key,fmt", [("11", "i16"), ("11", "f32"), ("13", "i16_interleaved")])
+def test_long_blocks_of_4096_and_8192_points_dense_bench_shape(key, fmt):
+    """256 streams x 16 long blocks in one launch through k_big: runs of consecutive blocks per workgroup (right parts stay in
+    the threads' registers), a recomputed predecessor where a run starts inside a stream"""
+    bad, kernels, n = _run_dense(key, fmt, packets=4096)
+    assert n == 4096 and bad == 0, (bad, kernels)
+    assert kernels == "k_big"
 
 
 @pytest.mark.parametrize("tier,pattern", [("host", "L"), ("device", "L"), ("host", "LLSSSSSSSSL"), ("device", "LLSSSSSSSSL")])
@@ -137,7 +147,12 @@ MIXED_SETUPS = {"stereo": lambda: sg.stereo_setup(44100, 8, 11), "surround51": l
 
 BLK_SETUPS = {"stereo_9_10": lambda: sg.stereo_setup(22050, 9, 10), "stereo_8_10": lambda: sg.stereo_setup(22050, 8, 10, residue_type=1),
               "stereo_8_9": lambda: sg.stereo_setup(11025, 8, 9),
-              "stereo_9_11": lambda: sg.stereo_setup(44100, 9, 11), "stereo_10_12": lambda: sg.stereo_setup(44100, 10, 12)}
+              "stereo_9_11": lambda: sg.stereo_setup(44100, 9, 11), "stereo_10_12": lambda: sg.stereo_setup(44100, 10, 12),
+              # 4096 / 8192-point long blocks: k_big<12 / 13> (two long slopes), the generic kernels next to short blocks
+              "stereo_9_12": lambda: sg.stereo_setup(44100, 9, 12), "stereo_6_13": lambda: sg.stereo_setup(44100, 6, 13),
+              "stereo_8_13_t1": lambda: sg.stereo_setup(44100, 8, 13, residue_type=1),
+              "surround51_9_12": lambda: sg.surround51_setup(48000, 9, 12), "mono_7_12": lambda: sg.mono_setup(7, 12, 44100)}
+BIG = {"stereo_10_12", "stereo_9_12", "stereo_6_13", "stereo_8_13_t1", "surround51_9_12", "mono_7_12"}
 
 
 @pytest.mark.parametrize("name", sorted(BLK_SETUPS))
@@ -179,7 +194,7 @@ def test_block_kernel_streams_state_round_trip_and_runs(name, fmt):
         check(b1, [(s, t) for s in range(n_streams)])
     b2 = Batch(dec, n_streams * tail, fmt)
     check(b2, [(s, steps + t) for s in range(n_streams) for t in range(tail)])
-    assert "k_short" in seen, seen
+    assert ("k_big" in seen) if name in BIG else ("k_short" in seen), seen
     for s in range(n_streams):
         assert np.array_equal(pwrs[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32)), s
     b1.close()
