@@ -482,8 +482,16 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			const bool big = d->blkp[cls].lanes > 64; // k_big: a workgroup per task, one slot per pass, at least two (halo + block)
 			const size_t per_wave = big ? 1 : 64 / d->blkp[cls].lanes;
 			uint32_t passes = big ? 2 : 1;
+			if (big) {
+				// k_big holds two waves per SIMD (its registers): 8 waves = 8 / (lanes / 64) workgroups per CU.  The fewest passes with
+				// which the whole launch is resident at once (a second round of workgroups would double the launch's duration);
+				// a task of p slots takes p - 1 blocks when it starts with a recomputed predecessor
+				const size_t cap = (size_t)std::max(1, d->n_cus) * (8 / (d->blkp[cls].lanes / 64));
+				while (passes < d->blkp[cls].passes && (b->blk_idx[cls].size() + passes - 2) / (passes - 1) > cap)
+					passes++;
+			} else
 			while (passes < d->blkp[cls].passes &&
-					b->blk_idx[cls].size() / (per_wave * (passes + 1) - 1) >= (big ? 4 : 5) * (size_t)std::max(1, d->n_cus))
+					b->blk_idx[cls].size() / (per_wave * (passes + 1) - 1) >= 5 * (size_t)std::max(1, d->n_cus))
 				passes++;
 			b->blk_passes[cls] = passes;
 			const size_t per_task = per_wave * passes;

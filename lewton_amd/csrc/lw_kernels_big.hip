@@ -63,20 +63,13 @@ __device__ __forceinline__ void bfly2(float2_t &H, float2_t &L, const float2_t t
 __device__ __forceinline__ float2_t ld2(const float *p) { return *reinterpret_cast<const float2_t *>(p); }
 __device__ __forceinline__ float4_t ld4(const float *p) { return *reinterpret_cast<const float4_t *>(p); }
 
-// three stages of distances D, D/2, D/4 on the pairs q' = q0 + (D/4) i
-template <uint32_t D, uint32_t N>
-__device__ __forceinline__ void pass3(float2_t *V, uint32_t t, const float *A)
+// three stages of distances D, D/2, D/4 on the pairs q' = q0 + (D/4) i; twiddles of the thread (loaded once per workgroup):
+// ta[i] = A[(off + (D/4) i) N / (2D) ..], tb[i] = A[(off + (D/4) i) N / D ..], tc = A[off 2N / D ..], off = t % (D/4)
+template <uint32_t D>
+__device__ __forceinline__ void pass3(float2_t *V, uint32_t t, const float2_t (&ta)[4], const float2_t (&tb)[2], const float2_t tc)
 {
 	constexpr uint32_t STEP = D / 4;
-	const uint32_t off = t % STEP, q0 = (t / STEP) * (2u * D) + off;
-	float2_t ta[4], tb[2], tc;
-#pragma unroll
-	for (uint32_t i = 0; i < 4; i++)
-		ta[i] = ld2(A + (off + STEP * i) * (N / (2u * D)));
-#pragma unroll
-	for (uint32_t i = 0; i < 2; i++)
-		tb[i] = ld2(A + (off + STEP * i) * (N / D));
-	tc = ld2(A + off * (2u * N / D));
+	const uint32_t q0 = (t / STEP) * (2u * D) + t % STEP;
 	float2_t R[8];
 #pragma unroll
 	for (uint32_t i = 0; i < 8; i++)
@@ -150,83 +143,61 @@ __device__ __forceinline__ void last3(float *z, const float a2)
 	iter54(z);
 }
 
-// audio.rs:762-777
+// audio.rs:762-777.  With c = (m > 0), d = (a > 0) the reference's four cases are v = m + ((c == d) ? -a : a) and
+// (new_m, new_a) = d ? (m, v) : (v, m)   (x - y and x + (-y) are the same operation): no branches
 __device__ __forceinline__ void decouple(float &m, float &a)
 {
-	float nm, na;
-	if (m > 0.0f) {
-		if (a > 0.0f) {
-			nm = m;
-			na = m - a;
-		} else {
-			nm = m + a;
-			na = m;
-		}
-	} else {
-		if (a > 0.0f) {
-			nm = m;
-			na = m + a;
-		} else {
-			nm = m - a;
-			na = m;
-		}
-	}
+	const bool c = m > 0.0f, d = a > 0.0f;
+	const float v = m + ((c == d) ? -a : a);
+	const float nm = d ? m : v, na = d ? v : m;
 	m = nm;
 	a = na;
 }
 
-// samples.rs:92-103: x * 32768, clamp to [-32768, 32767], truncate toward zero; NaN -> 0
-__device__ __forceinline__ int16_t to_i16(float x)
+// Floor curve (audio.rs:526-555), the way k_long does it (lw_kernels_long.hip: floor_table / floor_bin): one 16-byte entry
+// {dy, c0, 1/adx, w} per STATIC interval of the floor configuration (between consecutive posts in ascending x), describing the
+// ACTIVE segment that covers it; the floor value of bin k is inverse_db[y(k)] with
+//     y(k) = ((bits(fma(fma(k, dy, c0), 1/adx, w)) & 0x7fc) >> 2) - 1,       w = 2^21 + 1 + y_base
+// -- two fused multiply-adds and one AND per bin.  render_line (audio.rs:503-524) is y = y0 + trunc((k - x0) dy / adx); both
+// signs are written as a FLOOR of something non-negative:
+//     dy >= 0:  y = y0 + floor(((k - x0) dy + 1/2) / adx)            c0 = 1/2 - x0 dy - adx/8,      y_base = y0
+//     dy <  0:  y = y1 + floor(((x1 - k) |dy| + adx - 1/2) / adx)    c0 = 7 adx/8 - 1/2 - x1 dy,    y_base = y1
+// The numerators are integers + 1/2, so the quotient's fraction lies in [1/(2 adx), 1 - 1/(2 adx)]; the - adx/8 moves it to
+// [-1/8 + 1/(2 adx), 7/8 - 1/(2 adx)], which rounds to a multiple of 1/4 (one ulp in [2^21, 2^22)) in [0, 3/4]: the integer part
+// is never touched.  Both inner sums are exact in f32 up to adx = 4096 (multiples of 1/8 below 2^21); the outer product's error
+// is below 256 * 2^-23 < 1/(2 * 4096).  tests/test_big_model.py checks every adx <= 4096 with every offset inside it, with the
+// reciprocal one ulp off either way, as v_rcp_f32 may be.
+#define LW_BIG_FLOOR_W0 2097153.0f // 2^21 + 1
+#define LW_BIG_FLOOR_MASK 0x7fcu
+
+// posts: x | y << 16 | active << 31 of the floor's posts in ascending x; the entry of the static interval behind post s
+__device__ __forceinline__ float4_t floor_entry(const uint32_t *posts, uint32_t s, uint32_t Fp)
 {
-	const float t = x * 32768.0f;
-	if (t > 32767.0f)
-		return 32767;
-	if (t < -32768.0f)
-		return -32768;
-	return (int16_t)(int)t;
+	uint32_t lo = s;
+	while (!(posts[lo] >> 31)) // (post 0 is always active)
+		lo--;
+	uint32_t hi = s + 1u;
+	while (hi < Fp && !(posts[hi] >> 31))
+		hi++;
+	const bool above = hi < Fp; // otherwise: flat to n/2 behind the last active post (audio.rs:546-548)
+	const uint32_t pl = posts[lo], ph = posts[above ? hi : lo];
+	const float xlo = (float)(pl & 0xffffu), xhi = (float)(ph & 0xffffu);
+	const int ylo = (int)((pl >> 16) & 0xffu), yhi = (int)((ph >> 16) & 0xffu);
+	const float dy = (float)(yhi - ylo);
+	const float adx = above ? xhi - xlo : 1.0f;
+	const bool down = yhi < ylo;
+	float4_t ent;
+	ent.x = dy;
+	ent.y = down ? (0.875f * adx - 0.5f) - xhi * dy : (0.5f - 0.125f * adx) - xlo * dy;
+	ent.z = above ? __builtin_amdgcn_rcpf(adx) : 1.0f;
+	ent.w = (float)(down ? yhi : ylo) + LW_BIG_FLOOR_W0;
+	return ent;
 }
 
-// The floor values (indices into the inverse-dB table) of the bins k0 .. k0 + 3: the interval of k0 by binary search over the
-// K active posts (ascending x; entry = x | y << 16), at most one step forward per bin (the x are distinct integers), and
-// render_line's closed form y0 +- (|dy| (k - x0)) / adx (audio.rs:503-524) with the integer division by a
-// reciprocal and a correction: |dy| (k - x0) < 2^21 is exact in f32 and v_rcp_f32 is good to 1 ulp, so the truncated product
-// is off by at most one.
-__device__ __forceinline__ void floor_group(const uint32_t *pxy, int K, uint32_t k0, int (&y)[4])
+__device__ __forceinline__ float floor_bin(const float *inv_s, float kf, float4_t ent)
 {
-	int lo = 0, hi = K - 1;
-	while (lo < hi) {
-		const int mid = (lo + hi + 1) >> 1;
-		if ((pxy[mid] & 0xffffu) <= k0)
-			lo = mid;
-		else
-			hi = mid - 1;
-	}
-	uint32_t cur = pxy[lo], nxt = pxy[lo + 1 < K ? lo + 1 : lo];
-#pragma unroll
-	for (uint32_t j = 0; j < 4; j++) {
-		const uint32_t k = k0 + j;
-		if (lo + 1 < K && (nxt & 0xffffu) <= k) {
-			lo++;
-			cur = nxt;
-			nxt = pxy[lo + 1 < K ? lo + 1 : lo];
-		}
-		const int x0 = (int)(cur & 0xffffu), y0 = (int)(cur >> 16);
-		if (lo == K - 1) {
-			y[j] = y0; // flat extension to n/2, audio.rs:546-548
-		} else {
-			const int x1 = (int)(nxt & 0xffffu), y1 = (int)(nxt >> 16);
-			const int dy = y1 - y0, adx = x1 - x0;
-			const int ady = dy < 0 ? -dy : dy;
-			const int num = ady * ((int)k - x0);
-			int q = (int)((float)num * __builtin_amdgcn_rcpf((float)adx));
-			const int rem = num - q * adx;
-			if (rem < 0)
-				q--;
-			else if (rem >= adx)
-				q++;
-			y[j] = dy < 0 ? y0 - q : y0 + q;
-		}
-	}
+	const float t = __builtin_fmaf(__builtin_fmaf(kf, ent.x, ent.y), ent.z, ent.w);
+	return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(inv_s) + ((__float_as_uint(t) & LW_BIG_FLOOR_MASK) - 4u));
 }
 
 template <int FMT>
@@ -234,36 +205,105 @@ __device__ __forceinline__ void store_pair(void *out, uint32_t elem0, uint32_t p
 {
 	if (FMT == LW_OUT_F32_PLANAR) {
 		*reinterpret_cast<float2_t *>(reinterpret_cast<float *>(out) + elem0 + pos) = float2_t{a, b};
-	} else if (FMT == LW_OUT_I16_PLANAR) {
-		*reinterpret_cast<uint32_t *>(reinterpret_cast<int16_t *>(out) + elem0 + pos) =
-			(uint32_t)(uint16_t)to_i16(a) | ((uint32_t)(uint16_t)to_i16(b) << 16);
 	} else {
+		// samples.rs:92-103: x * 32768, truncate toward zero (v_cvt_i32_f32: saturating, NaN -> 0), clamp to i16 by the saturating
+		// pack (clamping the integer = clamping the float first: the bounds are integers)
+		typedef short short2_t __attribute__((ext_vector_type(2)));
+		union {
+			short2_t s;
+			uint32_t u;
+		} v;
+		v.s = __builtin_amdgcn_cvt_pk_i16((int)(a * 32768.0f), (int)(b * 32768.0f));
 		int16_t *o = reinterpret_cast<int16_t *>(out) + elem0;
-		o[pos * stride] = to_i16(a);
-		o[(pos + 1u) * stride] = to_i16(b);
+		if (FMT == LW_OUT_I16_PLANAR) {
+			*reinterpret_cast<uint32_t *>(o + pos) = v.u;
+		} else {
+			o[pos * stride] = v.s.x;
+			o[(pos + 1u) * stride] = v.s.y;
+		}
 	}
 }
 
 } // namespace
 
-template <int FMT, int BS>
-__global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
+// the fields of a slot descriptor the kernel uses (the same for every thread: kept in scalar registers)
+struct BigSlot {
+	uint32_t res_off, floor_off, out_off, prev_arg, prev_stride, kind, prev_kind, flags;
+	int32_t state_out;
+};
+
+__device__ __forceinline__ BigSlot load_slot(const LwShortSlot *p)
 {
-	constexpr uint32_t n = 1u << BS, n2 = n / 2, n4 = n / 4, n8 = n / 8, T = n / 32;
+	const uint4 *sp = reinterpret_cast<const uint4 *>(p);
+	const uint4 d0 = sp[0], d1 = sp[1], d2 = sp[2];
+	BigSlot s;
+	s.res_off = __builtin_amdgcn_readfirstlane(d0.x);
+	s.floor_off = __builtin_amdgcn_readfirstlane(d0.y);
+	s.out_off = __builtin_amdgcn_readfirstlane(d0.z);
+	s.prev_arg = __builtin_amdgcn_readfirstlane(d0.w);
+	s.state_out = (int32_t)__builtin_amdgcn_readfirstlane(d1.x);
+	const uint32_t x = __builtin_amdgcn_readfirstlane(d2.x);
+	s.prev_stride = x & 0xffffu;
+	s.kind = (x >> 16) & 0xffu;
+	s.prev_kind = x >> 24;
+	s.flags = __builtin_amdgcn_readfirstlane(d2.y);
+	return s;
+}
+
+template <int FMT, int BS>
+__global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per_eu(2, 2))) k_big(LwBigArgs F)
+{
+	constexpr uint32_t n = 1u << BS, n2 = n / 2, n4 = n / 4, n8 = n / 8, T = n / 32, NPAD = n4 + n4 / 8;
 	__shared__ __attribute__((aligned(16))) float U[n2];
-	__shared__ __attribute__((aligned(16))) float2_t V[n4 + n4 / 8];
+	__shared__ __attribute__((aligned(16))) float2_t V[NPAD];
 	__shared__ float inv_s[256];
-	__shared__ uint32_t pxy[2][68];
-	__shared__ uint8_t act[2][68];
-	__shared__ int Kp[2];
-	const uint32_t tid = threadIdx.x;
+	__shared__ __attribute__((aligned(16))) float4_t tab[2][68]; // floor segment entry of every static interval, per channel
+	__shared__ uint32_t posts[2][68];                            // x | y << 16 | active << 31 of the floor posts, per channel
+	__shared__ int unused_s[2];
+	const uint32_t t = threadIdx.x;
 	const uint32_t task = blockIdx.x / F.n_units, uidx = blockIdx.x - task * F.n_units;
 	const LwFastUnit un = F.units[uidx];
 	const bool two = un.ch_b >= 0;
 	const uint32_t chn[2] = {(uint32_t)un.ch_a, (uint32_t)(two ? un.ch_b : un.ch_a)};
 	const uint32_t nch = two ? 2u : 1u;
-	for (uint32_t i = tid; i < 256u; i += T)
+	const uint32_t Fp[2] = {un.F_a, two ? un.F_b : 0u};
+	for (uint32_t i = t; i < 256u; i += T)
 		inv_s[i] = F.inv_db[i];
+	const float *A = F.A;
+	// ---- once per workgroup: the x of the thread's floor post and the static floor interval (largest post index s with
+	// x[s] <= k among ALL posts of the floor configuration) of each of its 16 bins, one byte each
+	uint32_t my_x[2] = {0u, 0u}, sid[2][4];
+#pragma unroll
+	for (uint32_t c = 0; c < 2; c++) {
+#pragma unroll
+		for (uint32_t i = 0; i < 4; i++)
+			sid[c][i] = 0u;
+		if (c >= nch)
+			continue;
+		const uint16_t *fx = F.floor_x + F.fl_of[c == 0 ? un.floor_a : un.floor_b] * LW_XSTRIDE;
+		if (t < Fp[c])
+			my_x[c] = fx[t];
+#pragma unroll
+		for (uint32_t i = 0; i < 4; i++) {
+			const uint32_t k0 = 4u * (t + T * i);
+			int lo = 0, hi = (int)Fp[c] - 1;
+			while (lo < hi) {
+				const int mid = (lo + hi + 1) >> 1;
+				if (fx[mid] <= k0)
+					lo = mid;
+				else
+					hi = mid - 1;
+			}
+			uint32_t w = (uint32_t)lo;
+#pragma unroll
+			for (uint32_t j = 1; j < 4; j++) { // (the x are distinct integers: at most one post per bin)
+				if (lo + 1 < (int)Fp[c] && fx[lo + 1] <= k0 + j)
+					lo++;
+				w |= (uint32_t)lo << (8u * j);
+			}
+			sid[c][i] = w;
+		}
+	}
 	// the previous block's right part as this thread needs it: pb(p) at p = 2m, 2m + 1, n/4 - 2 - 2m, n/4 - 1 - 2m, m = t + T e
 	float pbp[2][2][4];
 #pragma unroll
@@ -273,22 +313,16 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 				pbp[c][e][k] = 0.0f;
+	const LwShortSlot *slots = F.slots + (size_t)task * F.passes;
+	BigSlot nxt = load_slot(slots);
 	for (uint32_t pass = 0; pass < F.passes; pass++) {
-		// launder the thread index once per slot: the table addresses derived from it are recomputed where they are used instead
-		// of being hoisted out of the loop and kept in registers
-		uint32_t t = tid;
-		asm volatile("" : "+v"(t));
-		const uint4 *sp = reinterpret_cast<const uint4 *>(F.slots + ((size_t)task * F.passes + pass));
-		const uint4 d0 = sp[0], d1 = sp[1], d2 = sp[2];
-		const uint32_t res_off = d0.x, floor_off = d0.y, out_off = d0.z, prev_arg = d0.w;
-		const int32_t state_out = (int32_t)d1.x;
-		const uint32_t prev_stride = d2.x & 0xffffu, kind = (d2.x >> 16) & 0xffu, prev_kind = d2.x >> 24, flags = d2.y;
-		if (kind != LW_SS_BLOCK && kind != LW_SS_HALO)
+		const BigSlot cur = nxt;
+		nxt = load_slot(slots + (pass + 1u < F.passes ? pass + 1u : pass)); // (in scalar registers by the time the next slot starts)
+		if (cur.kind != LW_SS_BLOCK && cur.kind != LW_SS_HALO)
 			continue; // (the same for every thread of the workgroup)
 		// ---- HBM loads, all at once: residues, floor records, the stored right part in front of the first block of a run
 		float4_t r[2][4];
-		uint32_t my_e[2] = {0u, 0u}, my_x[2] = {0u, 0u};
-		bool unused[2] = {true, true};
+		uint32_t my_e[2] = {0u, 0u};
 #pragma unroll
 		for (uint32_t c = 0; c < 2; c++) {
 			if (c >= nch) {
@@ -297,25 +331,19 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 					r[c][i] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
 				continue;
 			}
-			const float4_t *s = reinterpret_cast<const float4_t *>(F.residue + res_off + chn[c] * n2);
+			const float4_t *src = reinterpret_cast<const float4_t *>(F.residue + cur.res_off + chn[c] * n2);
 #pragma unroll
 			for (uint32_t i = 0; i < 4; i++)
-				r[c][i] = __builtin_nontemporal_load(&s[t + T * i]);
-			const uint16_t *frec = F.floors + floor_off + chn[c] * F.fstride;
-			const uint32_t fl = F.fl_of[c == 0 ? un.floor_a : un.floor_b], Fp = c == 0 ? un.F_a : un.F_b;
-			unused[c] = frec[0] == LW_FLOOR_UNUSED;
-			if (t < Fp) {
-				my_e[c] = frec[t];
-				my_x[c] = F.floor_x[fl * LW_XSTRIDE + t];
-			}
-			if (kind == LW_SS_BLOCK && (prev_kind == LW_SP_STATE || prev_kind == LW_SP_TD)) {
-				const float *src = prev_kind == LW_SP_STATE
-					? F.state + ((size_t)prev_arg * 2u + ((flags & LW_RF_PARITY_IN) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride
-					: F.td + prev_arg + chn[c] * prev_stride;
+				r[c][i] = __builtin_nontemporal_load(&src[t + T * i]);
+			my_e[c] = t < Fp[c] ? (uint32_t)F.floors[cur.floor_off + chn[c] * F.fstride + t] : 0u;
+			if (cur.kind == LW_SS_BLOCK && (cur.prev_kind == LW_SP_STATE || cur.prev_kind == LW_SP_TD)) {
+				const float *ps = cur.prev_kind == LW_SP_STATE
+					? F.state + ((size_t)cur.prev_arg * 2u + ((cur.flags & LW_RF_PARITY_IN) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride
+					: F.td + cur.prev_arg + chn[c] * cur.prev_stride;
 #pragma unroll
 				for (uint32_t e = 0; e < 2; e++) { // pb(p) = right part at n/4 - 1 - p
 					const uint32_t m = t + T * e;
-					const float2_t a = ld2(src + (n4 - 2u - 2u * m)), b = ld2(src + 2u * m);
+					const float2_t a = ld2(ps + (n4 - 2u - 2u * m)), b = ld2(ps + 2u * m);
 					pbp[c][e][0] = a.y;
 					pbp[c][e][1] = a.x;
 					pbp[c][e][2] = b.y;
@@ -323,29 +351,23 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 				}
 			}
 		}
-		// ---- active floor posts in ascending x (audio.rs:536-545 walks exactly these): one thread per post
+		// ---- floor segment table (audio.rs:536-548 walks the active posts in ascending x): one thread per post
 #pragma unroll
 		for (uint32_t c = 0; c < 2; c++) {
-			const uint32_t Fc = (c >= nch || unused[c]) ? 0u : (c == 0 ? un.F_a : un.F_b);
-			if (t < Fc)
-				act[c][t] = (my_e[c] & LW_POST_ACTIVE) ? 1 : 0;
+			if (c >= nch)
+				continue;
+			if (t < Fp[c])
+				posts[c][t] = my_x[c] | ((my_e[c] & 0xffu) << 16) | ((my_e[c] & LW_POST_ACTIVE) ? 0x80000000u : 0u);
+			if (t == 0u)
+				unused_s[c] = my_e[c] == LW_FLOOR_UNUSED;
 		}
 		__syncthreads();
 #pragma unroll
 		for (uint32_t c = 0; c < 2; c++) {
-			const uint32_t Fc = (c >= nch || unused[c]) ? 0u : (c == 0 ? un.F_a : un.F_b);
-			if (t < Fc) {
-				int rank = 0;
-				for (uint32_t u = 0; u < t; u++)
-					rank += act[c][u];
-				const bool on = (my_e[c] & LW_POST_ACTIVE) != 0;
-				if (on)
-					pxy[c][rank] = my_x[c] | ((my_e[c] & 0xffu) << 16);
-				if (t == Fc - 1u)
-					Kp[c] = rank + (on ? 1 : 0);
-			}
-			if (Fc == 0u && t == 0u)
-				Kp[c] = 0;
+			if (c >= nch)
+				continue;
+			if (t < Fp[c] && !unused_s[c])
+				tab[c][t] = floor_entry(posts[c], t, Fp[c]);
 		}
 		__syncthreads();
 		// ---- inverse coupling (audio.rs:762-777): ch_a = magnitude, ch_b = angle
@@ -364,49 +386,69 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 		for (uint32_t c = 0; c < 2; c++) { // (unrolled: everything indexed by the channel stays in registers)
 			if (c >= nch)
 				continue;
+			// (the thread index behind an opaque copy, once per channel: the table values are then re-read per channel and block
+			// -- each phase requests the next one's -- instead of being kept in ~100 registers across the whole loop)
+			uint32_t tl = t;
+			asm volatile("" : "+v"(tl));
+			// The tables of the block size (A, B, C, window: 28 / 56 KB) stay in L2: every phase REQUESTS what the next one needs
+			// before it starts on its own LDS traffic, so that the values are there behind the barrier.
 			// ---- spectrum = floor x residue (audio.rs:1035-1037; zero floor of an unused channel :1021-1024) -> U
+			float2_t p0a0[4], p0a1[4], p0tw[4], p0tw2[2];
+#pragma unroll
+			for (uint32_t i = 0; i < 4; i++) {
+				const uint32_t j = tl + T * i;
+				p0a0[i] = ld2(A + 2u * j);
+				p0a1[i] = ld2(A + n4 + 2u * j);
+				p0tw[i] = ld2(A + 4u * j);
+			}
+			if (BS == 13) {
+#pragma unroll
+				for (uint32_t i = 0; i < 2; i++)
+					p0tw2[i] = ld2(A + 8u * (tl + T * i));
+			}
 			{
-				const int K = Kp[c];
+				const bool unused = unused_s[c] != 0;
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++) {
 					const uint32_t k0 = 4u * (t + T * i);
 					float f[4];
-					if (unused[c]) {
-						f[0] = f[1] = f[2] = f[3] = 0.0f;
-					} else {
-						int y[4];
-						floor_group(pxy[c], K, k0, y);
 #pragma unroll
-						for (int j = 0; j < 4; j++)
-							f[j] = inv_s[y[j]];
-					}
+					for (uint32_t j = 0; j < 4; j++)
+						f[j] = unused ? 0.0f : floor_bin(inv_s, (float)(k0 + j), tab[c][(sid[c][i] >> (8u * j)) & 0xffu]);
 					const float4_t rr = r[c][i];
 					*reinterpret_cast<float4_t *>(U + k0) = float4_t{f[0] * rr.x, f[1] * rr.y, f[2] * rr.z, f[3] * rr.w};
 				}
 			}
 			__syncthreads();
 			// ---- P0: step 1 (imdct.rs:337-371) of j = t + T i, the stage of distance n/8 (step 2, :385-430), n = 8192: of distance 512
+			float2_t p1a[4], p1b[2], p1c;
+#pragma unroll
+			for (uint32_t i = 0; i < 4; i++)
+				p1a[i] = ld2(A + (tl % 64u + 64u * i) * (n / 512u));
+#pragma unroll
+			for (uint32_t i = 0; i < 2; i++)
+				p1b[i] = ld2(A + (tl % 64u + 64u * i) * (n / 256u));
+			p1c = ld2(A + (tl % 64u) * (n / 128u));
 			{
 				float2_t H[4], Lo[4];
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++) {
 					const uint32_t j = t + T * i;
-					const float2_t a0 = ld2(F.A + 2u * j), a1 = ld2(F.A + n4 + 2u * j);
 					const float4_t x = *reinterpret_cast<const float4_t *>(U + 4u * j);             // x0 = .x, x2 = .z
 					const float4_t y = *reinterpret_cast<const float4_t *>(U + (n2 - 4u - 4u * j)); // u[e] = .y, u[e + 2] = .w
+					const float2_t a0 = p0a0[i], a1 = p0a1[i];
 					H[i] = float2_t{x.x * a0.y + x.z * a0.x, x.x * a0.x - x.z * a0.y};
 					const float me2 = -y.w, me0 = -y.y;
 					Lo[i] = float2_t{me2 * a1.y + me0 * a1.x, me2 * a1.x - me0 * a1.y};
 				}
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++)
-					bfly2(H[i], Lo[i], ld2(F.A + 4u * (t + T * i)));
+					bfly2(H[i], Lo[i], p0tw[i]);
 				if (BS == 13) {
 #pragma unroll
 					for (uint32_t i = 0; i < 2; i++) {
-						const float2_t tw = ld2(F.A + 8u * (t + T * i));
-						bfly2(H[i], H[i + 2], tw);
-						bfly2(Lo[i], Lo[i + 2], tw);
+						bfly2(H[i], H[i + 2], p0tw2[i]);
+						bfly2(Lo[i], Lo[i + 2], p0tw2[i]);
 					}
 				}
 #pragma unroll
@@ -416,14 +458,43 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 				}
 			}
 			__syncthreads();
-			pass3<256, n>(V, t, F.A);
+			float2_t p2a[4], p2b[2], p2c;
+#pragma unroll
+			for (uint32_t i = 0; i < 4; i++)
+				p2a[i] = ld2(A + (tl % 8u + 8u * i) * (n / 64u));
+#pragma unroll
+			for (uint32_t i = 0; i < 2; i++)
+				p2b[i] = ld2(A + (tl % 8u + 8u * i) * (n / 32u));
+			p2c = ld2(A + (tl % 8u) * (n / 16u));
+			pass3<256>(V, t, p1a, p1b, p1c);
 			__syncthreads();
-			pass3<32, n>(V, t, F.A);
+			float4_t Cq[2], Bl[2], Bh[2];
+#pragma unroll
+			for (uint32_t e = 0; e < 2; e++) {
+				const uint32_t m = tl + T * e;
+				Cq[e] = ld4(F.C + 4u * m);
+				Bl[e] = ld4(F.Bt + 4u * m);
+				Bh[e] = ld4(F.Bt + (n2 - 4u - 4u * m));
+			}
+			const float a2 = A[n8];
+			pass3<32>(V, t, p2a, p2b, p2c);
 			__syncthreads();
 			// ---- P3: imdct.rs:234-288 on the pairs q' = 8t .. 8t + 7 (z[2k], z[2k + 1] = pair 8t + 7 - k)
+			const bool samples = cur.kind == LW_SS_BLOCK && cur.prev_kind != LW_SP_NONE;
+			float2_t wA[2], wB[2], wC[2], wD[2];
+#pragma unroll
+			for (uint32_t e = 0; e < 2; e++) {
+				const uint32_t m = tl + T * e;
+				wA[e] = wB[e] = wC[e] = wD[e] = float2_t{0.0f, 0.0f};
+				if (samples) {
+					wA[e] = ld2(F.window + (n4 - 2u - 2u * m));
+					wB[e] = ld2(F.window + (n4 + 2u * m));
+					wC[e] = ld2(F.window + 2u * m);
+					wD[e] = ld2(F.window + (n2 - 2u - 2u * m));
+				}
+			}
 			{
 				float z[16];
-				const float a2 = F.A[n8];
 #pragma unroll
 				for (uint32_t k = 0; k < 8; k++) {
 					const float2_t v = V[pad8(8u * t + 7u - k)];
@@ -437,26 +508,26 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 			}
 			__syncthreads();
 			// ---- E: bit-reverse gather (imdct.rs:490-528), step 7 (:533-580), step 8 (:589-658), window / overlap-add, stores
-			const uint32_t elem0 = FMT == LW_OUT_I16_INTERLEAVED ? out_off + chn[c] : out_off + chn[c] * n2;
+			const uint32_t elem0 = FMT == LW_OUT_I16_INTERLEAVED ? cur.out_off + chn[c] : cur.out_off + chn[c] * n2;
 			const uint32_t stride = FMT == LW_OUT_I16_INTERLEAVED ? F.ch : 1u;
-			float *st_dst = (kind == LW_SS_BLOCK && state_out >= 0)
-				? F.state + ((size_t)state_out * 2u + ((flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride
+			float *st_dst = (cur.kind == LW_SS_BLOCK && cur.state_out >= 0)
+				? F.state + ((size_t)cur.state_out * 2u + ((cur.flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride
 				: nullptr;
-			float *td_dst = (kind == LW_SS_BLOCK && (flags & LW_SF_WRITE_TD)) ? F.td + 2u * (size_t)res_off + chn[c] * n + n2 : nullptr;
-			const bool samples = kind == LW_SS_BLOCK && prev_kind != LW_SP_NONE;
+			float *td_dst = (cur.kind == LW_SS_BLOCK && (cur.flags & LW_SF_WRITE_TD)) ? F.td + 2u * (size_t)cur.res_off + chn[c] * n + n2 : nullptr;
 #pragma unroll
 			for (uint32_t e = 0; e < 2; e++) {
 				const uint32_t m = t + T * e, m0 = n / 16u - 1u - m;
-				const uint2 b1 = *reinterpret_cast<const uint2 *>(F.bitrev + 2u * m), b0 = *reinterpret_cast<const uint2 *>(F.bitrev + 2u * m0);
-				const float4_t Cq = ld4(F.C + 4u * m), Bl = ld4(F.Bt + 4u * m), Bh = ld4(F.Bt + (n2 - 4u - 4u * m));
-				// the pair holding floats (k, k + 1) of the reference's array: q' = n/4 - 1 - k/2
-				const float2_t Pa = V[pad8(n4 - 1u - b1.x / 2u)], Pb = V[pad8(n4 - 1u - b1.y / 2u)];
-				const float2_t Pc = V[pad8(n4 - 2u - b0.x / 2u)], Pd = V[pad8(n4 - 2u - b0.y / 2u)];
+				// header_cached.rs:104-108: bitrev[i] = (reverse of i's 32 bits >> (32 - ld n + 3)) << 2; the pair holding floats
+				// (k, k + 1) of the reference's array: q' = n/4 - 1 - k/2
+				const uint32_t k1 = (__brev(2u * m) >> (35 - BS)) << 1, k1p = (__brev(2u * m + 1u) >> (35 - BS)) << 1;
+				const uint32_t k0 = (__brev(2u * m0) >> (35 - BS)) << 1, k0p = (__brev(2u * m0 + 1u) >> (35 - BS)) << 1;
+				const float2_t Pa = V[pad8(n4 - 1u - k1)], Pb = V[pad8(n4 - 1u - k1p)];
+				const float2_t Pc = V[pad8(n4 - 2u - k0)], Pd = V[pad8(n4 - 2u - k0p)];
 				float ve[4] = {Pb.y, Pb.x, Pa.y, Pa.x}; // v[e .. e + 3], e = n/2 - 4 - 4m
 				float vd[4] = {Pd.y, Pd.x, Pc.y, Pc.x}; // v[d .. d + 3], d = 4m
 				{
 					const float a02 = vd[0] - ve[2], a11 = vd[1] + ve[3];
-					const float b0_ = Cq.y * a02 + Cq.x * a11, b1_ = Cq.y * a11 - Cq.x * a02;
+					const float b0_ = Cq[e].y * a02 + Cq[e].x * a11, b1_ = Cq[e].y * a11 - Cq[e].x * a02;
 					const float b2 = vd[0] + ve[2], b3 = vd[1] - ve[3];
 					vd[0] = b2 + b0_;
 					vd[1] = b3 + b1_;
@@ -465,7 +536,7 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 				}
 				{
 					const float a02 = vd[2] - ve[0], a11 = vd[3] + ve[1];
-					const float b0_ = Cq.w * a02 + Cq.z * a11, b1_ = Cq.w * a11 - Cq.z * a02;
+					const float b0_ = Cq[e].w * a02 + Cq[e].z * a11, b1_ = Cq[e].w * a11 - Cq[e].z * a02;
 					const float b2 = vd[2] + ve[0], b3 = vd[3] - ve[1];
 					vd[2] = b2 + b0_;
 					vd[3] = b3 + b1_;
@@ -474,26 +545,24 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 				}
 				// step 8 at p = 2m, 2m + 1 (B[4m ..]) and n/4 - 2 - 2m, n/4 - 1 - 2m (B[n/2 - 4 - 4m ..])
 				float pa[4], pb[4];
-				pa[0] = vd[0] * Bl.y - vd[1] * Bl.x;
-				pb[0] = (-vd[0]) * Bl.x - vd[1] * Bl.y;
-				pa[1] = vd[2] * Bl.w - vd[3] * Bl.z;
-				pb[1] = (-vd[2]) * Bl.z - vd[3] * Bl.w;
-				pa[2] = ve[0] * Bh.y - ve[1] * Bh.x;
-				pb[2] = (-ve[0]) * Bh.x - ve[1] * Bh.y;
-				pa[3] = ve[2] * Bh.w - ve[3] * Bh.z;
-				pb[3] = (-ve[2]) * Bh.z - ve[3] * Bh.w;
+				pa[0] = vd[0] * Bl[e].y - vd[1] * Bl[e].x;
+				pb[0] = (-vd[0]) * Bl[e].x - vd[1] * Bl[e].y;
+				pa[1] = vd[2] * Bl[e].w - vd[3] * Bl[e].z;
+				pb[1] = (-vd[2]) * Bl[e].z - vd[3] * Bl[e].w;
+				pa[2] = ve[0] * Bh[e].y - ve[1] * Bh[e].x;
+				pb[2] = (-ve[0]) * Bh[e].x - ve[1] * Bh[e].y;
+				pa[3] = ve[2] * Bh[e].w - ve[3] * Bh[e].z;
+				pb[3] = (-ve[2]) * Bh[e].z - ve[3] * Bh[e].w;
 				if (samples) {
 					// audio.rs:1116-1118: sample i = cur[i] * w[i] + prev_right[i] * w[n/2 - 1 - i]; with q = n/4 - 1 - p the block's
 					// left half is pa(p) at q and -pa(p) at n/2 - 1 - q, the predecessor's right part pb'(p) at both
-					const float2_t wA = ld2(F.window + (n4 - 2u - 2u * m)), wB = ld2(F.window + (n4 + 2u * m));
-					const float2_t wC = ld2(F.window + 2u * m), wD = ld2(F.window + (n2 - 2u - 2u * m));
 					const float *pp = pbp[c][e];
 					// p = 2m: q = n/4 - 1 - 2m (w = wA.y, mirror wB.x); p = 2m + 1: q = n/4 - 2 - 2m (wA.x, wB.y)
-					const float s0 = (pa[0] * wA.y) + (pp[0] * wB.x), s0m = ((-pa[0]) * wB.x) + (pp[0] * wA.y);
-					const float s1 = (pa[1] * wA.x) + (pp[1] * wB.y), s1m = ((-pa[1]) * wB.y) + (pp[1] * wA.x);
+					const float s0 = (pa[0] * wA[e].y) + (pp[0] * wB[e].x), s0m = ((-pa[0]) * wB[e].x) + (pp[0] * wA[e].y);
+					const float s1 = (pa[1] * wA[e].x) + (pp[1] * wB[e].y), s1m = ((-pa[1]) * wB[e].y) + (pp[1] * wA[e].x);
 					// p = n/4 - 2 - 2m: q = 2m + 1 (wC.y, mirror wD.x); p = n/4 - 1 - 2m: q = 2m (wC.x, wD.y)
-					const float s2 = (pa[2] * wC.y) + (pp[2] * wD.x), s2m = ((-pa[2]) * wD.x) + (pp[2] * wC.y);
-					const float s3 = (pa[3] * wC.x) + (pp[3] * wD.y), s3m = ((-pa[3]) * wD.y) + (pp[3] * wC.x);
+					const float s2 = (pa[2] * wC[e].y) + (pp[2] * wD[e].x), s2m = ((-pa[2]) * wD[e].x) + (pp[2] * wC[e].y);
+					const float s3 = (pa[3] * wC[e].x) + (pp[3] * wD[e].y), s3m = ((-pa[3]) * wD[e].y) + (pp[3] * wC[e].x);
 					store_pair<FMT>(F.out, elem0, n4 - 2u - 2u * m, stride, s1, s0);
 					store_pair<FMT>(F.out, elem0, n4 + 2u * m, stride, s0m, s1m);
 					store_pair<FMT>(F.out, elem0, 2u * m, stride, s3, s2);
@@ -514,7 +583,8 @@ __global__ void __launch_bounds__(1 << (BS - 5)) k_big(LwBigArgs F)
 				for (int k = 0; k < 4; k++)
 					pbp[c][e][k] = pb[k];
 			}
-			// (the next channel's spectrum goes to U, last read in P0 two barriers ago; its P0 writes V behind one more barrier)
+			// (the next channel's spectrum goes to U, last read in P0; its P0 writes V behind the barrier that follows the spectrum;
+			// the next slot's floor tables were last read in the spectrum phase, barriers ago)
 		}
 	}
 }
