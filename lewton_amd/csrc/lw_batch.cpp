@@ -483,10 +483,11 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			const size_t per_wave = big ? 1 : 64 / d->blkp[cls].lanes;
 			uint32_t passes = big ? 2 : 1;
 			if (big) {
-				// k_big holds two waves per SIMD (its registers): 8 waves = 8 / (lanes / 64) workgroups per CU.  The fewest passes with
-				// which the whole launch is resident at once (a second round of workgroups would double the launch's duration);
-				// a task of p slots takes p - 1 blocks when it starts with a recomputed predecessor
-				const size_t cap = (size_t)std::max(1, d->n_cus) * (8 / (d->blkp[cls].lanes / 64));
+				// k_big holds three waves per SIMD (its registers): 12 waves = 12 / (lanes / 64) workgroups per CU.  The fewest passes
+				// with which the whole launch is resident at once (the launch lasts passes x ~15 us whatever the number of
+				// workgroups, and a second round of them would double it; measured: profiles/r04_k_big_variants.txt); a task of p
+				// slots takes p - 1 blocks when it starts with a recomputed predecessor
+				const size_t cap = (size_t)std::max(1, d->n_cus) * (12 / (d->blkp[cls].lanes / 64));
 				while (passes < d->blkp[cls].passes && (b->blk_idx[cls].size() + passes - 2) / (passes - 1) > cap)
 					passes++;
 			} else

@@ -42,6 +42,7 @@ struct LwBigArgs {
 	const uint32_t *bitrev;
 	const uint16_t *floor_x;
 	uint32_t n_units, ch, fstride, state_stride, state_chan_stride, passes;
+	uint32_t n_wg; // tasks x units = workgroups
 	uint32_t fl_of[LW_FAST_MAX_FLOORS]; // floor index (header order) of each staged floor slot of the units
 	LwFastUnit units[LW_FAST_WAVES];
 };
@@ -49,6 +50,11 @@ struct LwBigArgs {
 namespace {
 
 __device__ __forceinline__ uint32_t pad8(uint32_t q) { return q + (q >> 3); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence over every address space: it would
+// wait for the block's sample stores (and for the residue loads of the next block) at each of the ~13 barriers of a slot.
+// Nothing the waves of a workgroup exchange goes through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // imdct.rs:445-477 on pairs (x = even float, y = odd float)
 __device__ __forceinline__ void bfly2(float2_t &H, float2_t &L, const float2_t tw)
@@ -170,16 +176,15 @@ __device__ __forceinline__ void decouple(float &m, float &a)
 #define LW_BIG_FLOOR_W0 2097153.0f // 2^21 + 1
 #define LW_BIG_FLOOR_MASK 0x7fcu
 
-// posts: x | y << 16 | active << 31 of the floor's posts in ascending x; the entry of the static interval behind post s
-__device__ __forceinline__ float4_t floor_entry(const uint32_t *posts, uint32_t s, uint32_t Fp)
+// posts: x | y << 16 of the floor's posts in ascending x, `active`: bit s = post s is used by this packet (bit 64 in `a64`); the
+// entry of the static interval behind post s: from the last active post at or below it to the next active one above it
+__device__ __forceinline__ float4_t floor_entry(const uint32_t *posts, unsigned long long active, bool a64, uint32_t s)
 {
-	uint32_t lo = s;
-	while (!(posts[lo] >> 31)) // (post 0 is always active)
-		lo--;
-	uint32_t hi = s + 1u;
-	while (hi < Fp && !(posts[hi] >> 31))
-		hi++;
-	const bool above = hi < Fp; // otherwise: flat to n/2 behind the last active post (audio.rs:546-548)
+	const unsigned long long lowmask = s >= 63u ? ~0ull : (2ull << s) - 1ull;
+	const unsigned long long below = active & lowmask, above_m = s >= 63u ? 0ull : active & ~lowmask;
+	const uint32_t lo = (s == 64u && a64) ? 64u : 63u - (uint32_t)__builtin_clzll(below); // (post 0 is always active)
+	const bool above = above_m != 0ull || (a64 && s < 64u); // otherwise: flat to n/2 behind the last active post (audio.rs:546-548)
+	const uint32_t hi = above_m ? (uint32_t)__builtin_ctzll(above_m) : 64u;
 	const uint32_t pl = posts[lo], ph = posts[above ? hi : lo];
 	const float xlo = (float)(pl & 0xffffu), xhi = (float)(ph & 0xffffu);
 	const int ylo = (int)((pl >> 16) & 0xffu), yhi = (int)((ph >> 16) & 0xffu);
@@ -250,16 +255,22 @@ __device__ __forceinline__ BigSlot load_slot(const LwShortSlot *p)
 	return s;
 }
 
+// Three waves per SIMD (168 registers: no spills with the table values re-read where they are used) = six / three workgroups per CU
 template <int FMT, int BS>
-__global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per_eu(2, 2))) k_big(LwBigArgs F)
+__global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per_eu(3, 3))) k_big(LwBigArgs F)
 {
 	constexpr uint32_t n = 1u << BS, n2 = n / 2, n4 = n / 4, n8 = n / 8, T = n / 32, NPAD = n4 + n4 / 8;
-	__shared__ __attribute__((aligned(16))) float U[n2];
-	__shared__ __attribute__((aligned(16))) float2_t V[NPAD];
-	__shared__ float inv_s[256];
+	__shared__ __attribute__((aligned(16))) float U[n2];         // floor x residue of the channel in work
+	__shared__ __attribute__((aligned(16))) float2_t V[NPAD];    // the transform's pairs
 	__shared__ __attribute__((aligned(16))) float4_t tab[2][68]; // floor segment entry of every static interval, per channel
-	__shared__ uint32_t posts[2][68];                            // x | y << 16 | active << 31 of the floor posts, per channel
-	__shared__ int unused_s[2];
+	__shared__ float inv_s[256];
+	__shared__ uint32_t posts[2][68];       // x | y << 16 of the floor posts, per channel
+	__shared__ unsigned long long amask[2]; // bit s: post s is active (posts 0 .. 63: a ballot of the first wave)
+	__shared__ int unused_s[2], a64_s[2];   // the floor is unused / post 64 is active
+	// The tables of the block size (header_cached.rs:34-110; 28 / 56 KB) stay in L2.  (Staged in LDS per workgroup they cost the
+	// residency they were meant to pay for: 78.8 us per 4096 blocks of 4096 points instead of 77.7; kept in ~100 registers per
+	// thread the rest of the code was serialised or spilled: 133 us -- profiles/r04_k_big_variants.txt.)
+	const float *const At = F.A, *const Bs = F.Bt, *const Cs = F.C, *const Ws = F.window;
 	const uint32_t t = threadIdx.x;
 	const uint32_t task = blockIdx.x / F.n_units, uidx = blockIdx.x - task * F.n_units;
 	const LwFastUnit un = F.units[uidx];
@@ -269,41 +280,41 @@ __global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per
 	const uint32_t Fp[2] = {un.F_a, two ? un.F_b : 0u};
 	for (uint32_t i = t; i < 256u; i += T)
 		inv_s[i] = F.inv_db[i];
-	const float *A = F.A;
 	// ---- once per workgroup: the x of the thread's floor post and the static floor interval (largest post index s with
 	// x[s] <= k among ALL posts of the floor configuration) of each of its 16 bins, one byte each
 	uint32_t my_x[2] = {0u, 0u}, sid[2][4];
 #pragma unroll
 	for (uint32_t c = 0; c < 2; c++) {
+		if (c < nch && t < Fp[c]) {
+			my_x[c] = F.floor_x[F.fl_of[c == 0 ? un.floor_a : un.floor_b] * LW_XSTRIDE + t];
+			posts[c][t] = my_x[c]; // (through LDS: every thread walks all the posts, without a chain of dependent HBM loads)
+		}
+	}
+	lds_barrier();
 #pragma unroll
-		for (uint32_t i = 0; i < 4; i++)
-			sid[c][i] = 0u;
-		if (c >= nch)
-			continue;
-		const uint16_t *fx = F.floor_x + F.fl_of[c == 0 ? un.floor_a : un.floor_b] * LW_XSTRIDE;
-		if (t < Fp[c])
-			my_x[c] = fx[t];
+	for (uint32_t c = 0; c < 2; c++) {
+		uint32_t cnt[4] = {1u, 1u, 1u, 1u}; // posts at or below the first bin of each group (post 0 has x = 0)
+		const uint32_t Fc = c < nch ? Fp[c] : 0u;
+		for (uint32_t s_ = 1; s_ < Fc; s_++) {
+			const uint32_t x = posts[c][s_];
+#pragma unroll
+			for (uint32_t i = 0; i < 4; i++)
+				cnt[i] += x <= 4u * (t + T * i) ? 1u : 0u;
+		}
 #pragma unroll
 		for (uint32_t i = 0; i < 4; i++) {
 			const uint32_t k0 = 4u * (t + T * i);
-			int lo = 0, hi = (int)Fp[c] - 1;
-			while (lo < hi) {
-				const int mid = (lo + hi + 1) >> 1;
-				if (fx[mid] <= k0)
-					lo = mid;
-				else
-					hi = mid - 1;
-			}
-			uint32_t w = (uint32_t)lo;
+			uint32_t lo = cnt[i] - 1u, w = lo;
 #pragma unroll
 			for (uint32_t j = 1; j < 4; j++) { // (the x are distinct integers: at most one post per bin)
-				if (lo + 1 < (int)Fp[c] && fx[lo + 1] <= k0 + j)
+				if (lo + 1u < Fc && posts[c][lo + 1u] <= k0 + j)
 					lo++;
-				w |= (uint32_t)lo << (8u * j);
+				w |= lo << (8u * j);
 			}
 			sid[c][i] = w;
 		}
 	}
+	lds_barrier();
 	// the previous block's right part as this thread needs it: pb(p) at p = 2m, 2m + 1, n/4 - 2 - 2m, n/4 - 1 - 2m, m = t + T e
 	float pbp[2][2][4];
 #pragma unroll
@@ -318,19 +329,17 @@ __global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per
 	for (uint32_t pass = 0; pass < F.passes; pass++) {
 		const BigSlot cur = nxt;
 		nxt = load_slot(slots + (pass + 1u < F.passes ? pass + 1u : pass)); // (in scalar registers by the time the next slot starts)
-		if (cur.kind != LW_SS_BLOCK && cur.kind != LW_SS_HALO)
-			continue; // (the same for every thread of the workgroup)
+		const bool block = cur.kind == LW_SS_BLOCK || cur.kind == LW_SS_HALO; // (the same for every thread of the workgroup)
 		// ---- HBM loads, all at once: residues, floor records, the stored right part in front of the first block of a run
 		float4_t r[2][4];
 		uint32_t my_e[2] = {0u, 0u};
 #pragma unroll
 		for (uint32_t c = 0; c < 2; c++) {
-			if (c >= nch) {
 #pragma unroll
-				for (uint32_t i = 0; i < 4; i++)
-					r[c][i] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+			for (uint32_t i = 0; i < 4; i++)
+				r[c][i] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+			if (c >= nch || !block)
 				continue;
-			}
 			const float4_t *src = reinterpret_cast<const float4_t *>(F.residue + cur.res_off + chn[c] * n2);
 #pragma unroll
 			for (uint32_t i = 0; i < 4; i++)
@@ -354,24 +363,33 @@ __global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per
 		// ---- floor segment table (audio.rs:536-548 walks the active posts in ascending x): one thread per post
 #pragma unroll
 		for (uint32_t c = 0; c < 2; c++) {
-			if (c >= nch)
+			if (c >= nch || !block)
 				continue;
+			const bool on = t < Fp[c] && (my_e[c] & LW_POST_ACTIVE) != 0;
 			if (t < Fp[c])
-				posts[c][t] = my_x[c] | ((my_e[c] & 0xffu) << 16) | ((my_e[c] & LW_POST_ACTIVE) ? 0x80000000u : 0u);
-			if (t == 0u)
-				unused_s[c] = my_e[c] == LW_FLOOR_UNUSED;
+				posts[c][t] = my_x[c] | ((my_e[c] & 0xffu) << 16);
+			if (t < 64u) {
+				const unsigned long long m = __ballot(on);
+				if (t == 0u) {
+					amask[c] = m;
+					unused_s[c] = my_e[c] == LW_FLOOR_UNUSED;
+					if (Fp[c] <= 64u)
+						a64_s[c] = 0;
+				}
+			} else if (t == 64u && Fp[c] > 64u) {
+				a64_s[c] = on ? 1 : 0;
+			}
 		}
-		__syncthreads();
+		lds_barrier();
 #pragma unroll
 		for (uint32_t c = 0; c < 2; c++) {
-			if (c >= nch)
+			if (c >= nch || !block)
 				continue;
 			if (t < Fp[c] && !unused_s[c])
-				tab[c][t] = floor_entry(posts[c], t, Fp[c]);
+				tab[c][t] = floor_entry(posts[c], amask[c], a64_s[c] != 0, t);
 		}
-		__syncthreads();
 		// ---- inverse coupling (audio.rs:762-777): ch_a = magnitude, ch_b = angle
-		if (two && un.coupled) {
+		if (block && two && un.coupled) {
 #pragma unroll
 			for (uint32_t i = 0; i < 4; i++) {
 				float m[4] = {r[0][i].x, r[0][i].y, r[0][i].z, r[0][i].w}, a[4] = {r[1][i].x, r[1][i].y, r[1][i].z, r[1][i].w};
@@ -382,206 +400,189 @@ __global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per
 				r[1][i] = float4_t{a[0], a[1], a[2], a[3]};
 			}
 		}
+		lds_barrier();
 #pragma unroll
-		for (uint32_t c = 0; c < 2; c++) { // (unrolled: everything indexed by the channel stays in registers)
-			if (c >= nch)
-				continue;
-			// (the thread index behind an opaque copy, once per channel: the table values are then re-read per channel and block
-			// -- each phase requests the next one's -- instead of being kept in ~100 registers across the whole loop)
+		for (uint32_t c = 0; c < 2; c++) { // (unrolled: everything indexed by the channel stays in registers; a single-channel unit
+		                                   // passes the second channel's barriers idle -- a barrier inside a skipped body would hang)
+			const bool work = block && c < nch;
+			// (the thread index behind an opaque copy, refreshed before every phase's table reads: the factors are then re-read from
+			// LDS where they are used instead of being hoisted out of the loop and kept in ~100 registers)
 			uint32_t tl = t;
 			asm volatile("" : "+v"(tl));
-			// The tables of the block size (A, B, C, window: 28 / 56 KB) stay in L2: every phase REQUESTS what the next one needs
-			// before it starts on its own LDS traffic, so that the values are there behind the barrier.
 			// ---- spectrum = floor x residue (audio.rs:1035-1037; zero floor of an unused channel :1021-1024) -> U
-			float2_t p0a0[4], p0a1[4], p0tw[4], p0tw2[2];
-#pragma unroll
-			for (uint32_t i = 0; i < 4; i++) {
-				const uint32_t j = tl + T * i;
-				p0a0[i] = ld2(A + 2u * j);
-				p0a1[i] = ld2(A + n4 + 2u * j);
-				p0tw[i] = ld2(A + 4u * j);
-			}
-			if (BS == 13) {
-#pragma unroll
-				for (uint32_t i = 0; i < 2; i++)
-					p0tw2[i] = ld2(A + 8u * (tl + T * i));
-			}
-			{
+			if (work) {
 				const bool unused = unused_s[c] != 0;
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++) {
-					const uint32_t k0 = 4u * (t + T * i);
+					const uint32_t k0 = 4u * (tl + T * i);
+					float4_t ent[4];
+#pragma unroll
+					for (uint32_t j = 0; j < 4; j++) // (the four entries first, then the four table values: two LDS round trips per group)
+						ent[j] = tab[c][(sid[c][i] >> (8u * j)) & 0xffu];
 					float f[4];
 #pragma unroll
 					for (uint32_t j = 0; j < 4; j++)
-						f[j] = unused ? 0.0f : floor_bin(inv_s, (float)(k0 + j), tab[c][(sid[c][i] >> (8u * j)) & 0xffu]);
+						f[j] = unused ? 0.0f : floor_bin(inv_s, (float)(k0 + j), ent[j]);
 					const float4_t rr = r[c][i];
 					*reinterpret_cast<float4_t *>(U + k0) = float4_t{f[0] * rr.x, f[1] * rr.y, f[2] * rr.z, f[3] * rr.w};
 				}
 			}
-			__syncthreads();
+			lds_barrier();
 			// ---- P0: step 1 (imdct.rs:337-371) of j = t + T i, the stage of distance n/8 (step 2, :385-430), n = 8192: of distance 512
-			float2_t p1a[4], p1b[2], p1c;
-#pragma unroll
-			for (uint32_t i = 0; i < 4; i++)
-				p1a[i] = ld2(A + (tl % 64u + 64u * i) * (n / 512u));
-#pragma unroll
-			for (uint32_t i = 0; i < 2; i++)
-				p1b[i] = ld2(A + (tl % 64u + 64u * i) * (n / 256u));
-			p1c = ld2(A + (tl % 64u) * (n / 128u));
-			{
+			if (work) {
 				float2_t H[4], Lo[4];
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++) {
-					const uint32_t j = t + T * i;
+					const uint32_t j = tl + T * i;
 					const float4_t x = *reinterpret_cast<const float4_t *>(U + 4u * j);             // x0 = .x, x2 = .z
 					const float4_t y = *reinterpret_cast<const float4_t *>(U + (n2 - 4u - 4u * j)); // u[e] = .y, u[e + 2] = .w
-					const float2_t a0 = p0a0[i], a1 = p0a1[i];
+					const float2_t a0 = ld2(At + 2u * j), a1 = ld2(At + n4 + 2u * j);
 					H[i] = float2_t{x.x * a0.y + x.z * a0.x, x.x * a0.x - x.z * a0.y};
 					const float me2 = -y.w, me0 = -y.y;
 					Lo[i] = float2_t{me2 * a1.y + me0 * a1.x, me2 * a1.x - me0 * a1.y};
 				}
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++)
-					bfly2(H[i], Lo[i], p0tw[i]);
+					bfly2(H[i], Lo[i], ld2(At + 4u * (tl + T * i)));
 				if (BS == 13) {
 #pragma unroll
 					for (uint32_t i = 0; i < 2; i++) {
-						bfly2(H[i], H[i + 2], p0tw2[i]);
-						bfly2(Lo[i], Lo[i + 2], p0tw2[i]);
+						const float2_t tw = ld2(At + 8u * (tl + T * i));
+						bfly2(H[i], H[i + 2], tw);
+						bfly2(Lo[i], Lo[i + 2], tw);
 					}
 				}
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++) {
-					V[pad8(t + T * i)] = H[i];
-					V[pad8(n8 + t + T * i)] = Lo[i];
+					V[pad8(tl + T * i)] = H[i];
+					V[pad8(n8 + tl + T * i)] = Lo[i];
 				}
 			}
-			__syncthreads();
-			float2_t p2a[4], p2b[2], p2c;
+			lds_barrier();
+			asm volatile("" : "+v"(tl));
+			if (work) {
+				float2_t ta[4], tb[2];
 #pragma unroll
-			for (uint32_t i = 0; i < 4; i++)
-				p2a[i] = ld2(A + (tl % 8u + 8u * i) * (n / 64u));
+				for (uint32_t i = 0; i < 4; i++)
+					ta[i] = ld2(At + (tl % 64u + 64u * i) * (n / 512u));
 #pragma unroll
-			for (uint32_t i = 0; i < 2; i++)
-				p2b[i] = ld2(A + (tl % 8u + 8u * i) * (n / 32u));
-			p2c = ld2(A + (tl % 8u) * (n / 16u));
-			pass3<256>(V, t, p1a, p1b, p1c);
-			__syncthreads();
-			float4_t Cq[2], Bl[2], Bh[2];
-#pragma unroll
-			for (uint32_t e = 0; e < 2; e++) {
-				const uint32_t m = tl + T * e;
-				Cq[e] = ld4(F.C + 4u * m);
-				Bl[e] = ld4(F.Bt + 4u * m);
-				Bh[e] = ld4(F.Bt + (n2 - 4u - 4u * m));
+				for (uint32_t i = 0; i < 2; i++)
+					tb[i] = ld2(At + (tl % 64u + 64u * i) * (n / 256u));
+				pass3<256>(V, tl, ta, tb, ld2(At + (tl % 64u) * (n / 128u)));
 			}
-			const float a2 = A[n8];
-			pass3<32>(V, t, p2a, p2b, p2c);
-			__syncthreads();
+			lds_barrier();
+			asm volatile("" : "+v"(tl));
+			if (work) {
+				float2_t ta[4], tb[2];
+#pragma unroll
+				for (uint32_t i = 0; i < 4; i++)
+					ta[i] = ld2(At + (tl % 8u + 8u * i) * (n / 64u));
+#pragma unroll
+				for (uint32_t i = 0; i < 2; i++)
+					tb[i] = ld2(At + (tl % 8u + 8u * i) * (n / 32u));
+				pass3<32>(V, tl, ta, tb, ld2(At + (tl % 8u) * (n / 16u)));
+			}
+			lds_barrier();
 			// ---- P3: imdct.rs:234-288 on the pairs q' = 8t .. 8t + 7 (z[2k], z[2k + 1] = pair 8t + 7 - k)
-			const bool samples = cur.kind == LW_SS_BLOCK && cur.prev_kind != LW_SP_NONE;
-			float2_t wA[2], wB[2], wC[2], wD[2];
-#pragma unroll
-			for (uint32_t e = 0; e < 2; e++) {
-				const uint32_t m = tl + T * e;
-				wA[e] = wB[e] = wC[e] = wD[e] = float2_t{0.0f, 0.0f};
-				if (samples) {
-					wA[e] = ld2(F.window + (n4 - 2u - 2u * m));
-					wB[e] = ld2(F.window + (n4 + 2u * m));
-					wC[e] = ld2(F.window + 2u * m);
-					wD[e] = ld2(F.window + (n2 - 2u - 2u * m));
-				}
-			}
-			{
+			asm volatile("" : "+v"(tl));
+			if (work) {
 				float z[16];
 #pragma unroll
 				for (uint32_t k = 0; k < 8; k++) {
-					const float2_t v = V[pad8(8u * t + 7u - k)];
+					const float2_t v = V[pad8(8u * tl + 7u - k)];
 					z[2 * k] = v.x;
 					z[2 * k + 1] = v.y;
 				}
-				last3(z, a2);
+				last3(z, At[n8]);
 #pragma unroll
 				for (uint32_t k = 0; k < 8; k++)
-					V[pad8(8u * t + 7u - k)] = float2_t{z[2 * k], z[2 * k + 1]};
+					V[pad8(8u * tl + 7u - k)] = float2_t{z[2 * k], z[2 * k + 1]};
 			}
-			__syncthreads();
+			lds_barrier();
+			asm volatile("" : "+v"(tl));
 			// ---- E: bit-reverse gather (imdct.rs:490-528), step 7 (:533-580), step 8 (:589-658), window / overlap-add, stores
-			const uint32_t elem0 = FMT == LW_OUT_I16_INTERLEAVED ? cur.out_off + chn[c] : cur.out_off + chn[c] * n2;
-			const uint32_t stride = FMT == LW_OUT_I16_INTERLEAVED ? F.ch : 1u;
-			float *st_dst = (cur.kind == LW_SS_BLOCK && cur.state_out >= 0)
-				? F.state + ((size_t)cur.state_out * 2u + ((cur.flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride
-				: nullptr;
-			float *td_dst = (cur.kind == LW_SS_BLOCK && (cur.flags & LW_SF_WRITE_TD)) ? F.td + 2u * (size_t)cur.res_off + chn[c] * n + n2 : nullptr;
+			if (work) {
+				const bool samples = cur.kind == LW_SS_BLOCK && cur.prev_kind != LW_SP_NONE;
+				const uint32_t elem0 = FMT == LW_OUT_I16_INTERLEAVED ? cur.out_off + chn[c] : cur.out_off + chn[c] * n2;
+				const uint32_t stride = FMT == LW_OUT_I16_INTERLEAVED ? F.ch : 1u;
+				float *st_dst = (cur.kind == LW_SS_BLOCK && cur.state_out >= 0)
+					? F.state + ((size_t)cur.state_out * 2u + ((cur.flags & LW_RF_PARITY_OUT) ? 1u : 0u)) * F.state_stride + chn[c] * F.state_chan_stride
+					: nullptr;
+				float *td_dst = (cur.kind == LW_SS_BLOCK && (cur.flags & LW_SF_WRITE_TD)) ? F.td + 2u * (size_t)cur.res_off + chn[c] * n + n2 : nullptr;
 #pragma unroll
-			for (uint32_t e = 0; e < 2; e++) {
-				const uint32_t m = t + T * e, m0 = n / 16u - 1u - m;
-				// header_cached.rs:104-108: bitrev[i] = (reverse of i's 32 bits >> (32 - ld n + 3)) << 2; the pair holding floats
-				// (k, k + 1) of the reference's array: q' = n/4 - 1 - k/2
-				const uint32_t k1 = (__brev(2u * m) >> (35 - BS)) << 1, k1p = (__brev(2u * m + 1u) >> (35 - BS)) << 1;
-				const uint32_t k0 = (__brev(2u * m0) >> (35 - BS)) << 1, k0p = (__brev(2u * m0 + 1u) >> (35 - BS)) << 1;
-				const float2_t Pa = V[pad8(n4 - 1u - k1)], Pb = V[pad8(n4 - 1u - k1p)];
-				const float2_t Pc = V[pad8(n4 - 2u - k0)], Pd = V[pad8(n4 - 2u - k0p)];
-				float ve[4] = {Pb.y, Pb.x, Pa.y, Pa.x}; // v[e .. e + 3], e = n/2 - 4 - 4m
-				float vd[4] = {Pd.y, Pd.x, Pc.y, Pc.x}; // v[d .. d + 3], d = 4m
-				{
-					const float a02 = vd[0] - ve[2], a11 = vd[1] + ve[3];
-					const float b0_ = Cq[e].y * a02 + Cq[e].x * a11, b1_ = Cq[e].y * a11 - Cq[e].x * a02;
-					const float b2 = vd[0] + ve[2], b3 = vd[1] - ve[3];
-					vd[0] = b2 + b0_;
-					vd[1] = b3 + b1_;
-					ve[2] = b2 - b0_;
-					ve[3] = b1_ - b3;
-				}
-				{
-					const float a02 = vd[2] - ve[0], a11 = vd[3] + ve[1];
-					const float b0_ = Cq[e].w * a02 + Cq[e].z * a11, b1_ = Cq[e].w * a11 - Cq[e].z * a02;
-					const float b2 = vd[2] + ve[0], b3 = vd[3] - ve[1];
-					vd[2] = b2 + b0_;
-					vd[3] = b3 + b1_;
-					ve[0] = b2 - b0_;
-					ve[1] = b1_ - b3;
-				}
-				// step 8 at p = 2m, 2m + 1 (B[4m ..]) and n/4 - 2 - 2m, n/4 - 1 - 2m (B[n/2 - 4 - 4m ..])
-				float pa[4], pb[4];
-				pa[0] = vd[0] * Bl[e].y - vd[1] * Bl[e].x;
-				pb[0] = (-vd[0]) * Bl[e].x - vd[1] * Bl[e].y;
-				pa[1] = vd[2] * Bl[e].w - vd[3] * Bl[e].z;
-				pb[1] = (-vd[2]) * Bl[e].z - vd[3] * Bl[e].w;
-				pa[2] = ve[0] * Bh[e].y - ve[1] * Bh[e].x;
-				pb[2] = (-ve[0]) * Bh[e].x - ve[1] * Bh[e].y;
-				pa[3] = ve[2] * Bh[e].w - ve[3] * Bh[e].z;
-				pb[3] = (-ve[2]) * Bh[e].z - ve[3] * Bh[e].w;
-				if (samples) {
-					// audio.rs:1116-1118: sample i = cur[i] * w[i] + prev_right[i] * w[n/2 - 1 - i]; with q = n/4 - 1 - p the block's
-					// left half is pa(p) at q and -pa(p) at n/2 - 1 - q, the predecessor's right part pb'(p) at both
-					const float *pp = pbp[c][e];
-					// p = 2m: q = n/4 - 1 - 2m (w = wA.y, mirror wB.x); p = 2m + 1: q = n/4 - 2 - 2m (wA.x, wB.y)
-					const float s0 = (pa[0] * wA[e].y) + (pp[0] * wB[e].x), s0m = ((-pa[0]) * wB[e].x) + (pp[0] * wA[e].y);
-					const float s1 = (pa[1] * wA[e].x) + (pp[1] * wB[e].y), s1m = ((-pa[1]) * wB[e].y) + (pp[1] * wA[e].x);
-					// p = n/4 - 2 - 2m: q = 2m + 1 (wC.y, mirror wD.x); p = n/4 - 1 - 2m: q = 2m (wC.x, wD.y)
-					const float s2 = (pa[2] * wC[e].y) + (pp[2] * wD[e].x), s2m = ((-pa[2]) * wD[e].x) + (pp[2] * wC[e].y);
-					const float s3 = (pa[3] * wC[e].x) + (pp[3] * wD[e].y), s3m = ((-pa[3]) * wD[e].y) + (pp[3] * wC[e].x);
-					store_pair<FMT>(F.out, elem0, n4 - 2u - 2u * m, stride, s1, s0);
-					store_pair<FMT>(F.out, elem0, n4 + 2u * m, stride, s0m, s1m);
-					store_pair<FMT>(F.out, elem0, 2u * m, stride, s3, s2);
-					store_pair<FMT>(F.out, elem0, n2 - 2u - 2u * m, stride, s2m, s3m);
-				}
-				// the raw right part (audio.rs:1121, :1142-1147): pb(p) at n/4 - 1 - p and mirrored at n/4 + p
-#pragma unroll
-				for (int w = 0; w < 2; w++) {
-					float *dst = w == 0 ? st_dst : td_dst;
-					if (dst) {
-						*reinterpret_cast<float2_t *>(dst + (n4 - 2u - 2u * m)) = float2_t{pb[1], pb[0]};
-						*reinterpret_cast<float2_t *>(dst + (n4 + 2u * m)) = float2_t{pb[0], pb[1]};
-						*reinterpret_cast<float2_t *>(dst + 2u * m) = float2_t{pb[3], pb[2]};
-						*reinterpret_cast<float2_t *>(dst + (n2 - 2u - 2u * m)) = float2_t{pb[2], pb[3]};
+				for (uint32_t e = 0; e < 2; e++) {
+					const uint32_t m = tl + T * e, m0 = n / 16u - 1u - m;
+					// header_cached.rs:104-108: bitrev[i] = (reverse of i's 32 bits >> (32 - ld n + 3)) << 2; the pair holding floats
+					// (k, k + 1) of the reference's array: q' = n/4 - 1 - k/2
+					const uint32_t k1 = (__brev(2u * m) >> (35 - BS)) << 1, k1p = (__brev(2u * m + 1u) >> (35 - BS)) << 1;
+					const uint32_t k0 = (__brev(2u * m0) >> (35 - BS)) << 1, k0p = (__brev(2u * m0 + 1u) >> (35 - BS)) << 1;
+					const float2_t Pa = V[pad8(n4 - 1u - k1)], Pb = V[pad8(n4 - 1u - k1p)];
+					const float2_t Pc = V[pad8(n4 - 2u - k0)], Pd = V[pad8(n4 - 2u - k0p)];
+					const float4_t Cq = ld4(Cs + 4u * m), Bl = ld4(Bs + 4u * m), Bh = ld4(Bs + (n2 - 4u - 4u * m));
+					float ve[4] = {Pb.y, Pb.x, Pa.y, Pa.x}; // v[e .. e + 3], e = n/2 - 4 - 4m
+					float vd[4] = {Pd.y, Pd.x, Pc.y, Pc.x}; // v[d .. d + 3], d = 4m
+					{
+						const float a02 = vd[0] - ve[2], a11 = vd[1] + ve[3];
+						const float b0_ = Cq.y * a02 + Cq.x * a11, b1_ = Cq.y * a11 - Cq.x * a02;
+						const float b2 = vd[0] + ve[2], b3 = vd[1] - ve[3];
+						vd[0] = b2 + b0_;
+						vd[1] = b3 + b1_;
+						ve[2] = b2 - b0_;
+						ve[3] = b1_ - b3;
 					}
-				}
+					{
+						const float a02 = vd[2] - ve[0], a11 = vd[3] + ve[1];
+						const float b0_ = Cq.w * a02 + Cq.z * a11, b1_ = Cq.w * a11 - Cq.z * a02;
+						const float b2 = vd[2] + ve[0], b3 = vd[3] - ve[1];
+						vd[2] = b2 + b0_;
+						vd[3] = b3 + b1_;
+						ve[0] = b2 - b0_;
+						ve[1] = b1_ - b3;
+					}
+					// step 8 at p = 2m, 2m + 1 (B[4m ..]) and n/4 - 2 - 2m, n/4 - 1 - 2m (B[n/2 - 4 - 4m ..])
+					float pa[4], pb[4];
+					pa[0] = vd[0] * Bl.y - vd[1] * Bl.x;
+					pb[0] = (-vd[0]) * Bl.x - vd[1] * Bl.y;
+					pa[1] = vd[2] * Bl.w - vd[3] * Bl.z;
+					pb[1] = (-vd[2]) * Bl.z - vd[3] * Bl.w;
+					pa[2] = ve[0] * Bh.y - ve[1] * Bh.x;
+					pb[2] = (-ve[0]) * Bh.x - ve[1] * Bh.y;
+					pa[3] = ve[2] * Bh.w - ve[3] * Bh.z;
+					pb[3] = (-ve[2]) * Bh.z - ve[3] * Bh.w;
+					if (samples) {
+						// audio.rs:1116-1118: sample i = cur[i] * w[i] + prev_right[i] * w[n/2 - 1 - i]; with q = n/4 - 1 - p the block's
+						// left half is pa(p) at q and -pa(p) at n/2 - 1 - q, the predecessor's right part pb'(p) at both
+						const float2_t wA = ld2(Ws + (n4 - 2u - 2u * m)), wB = ld2(Ws + (n4 + 2u * m));
+						const float2_t wC = ld2(Ws + 2u * m), wD = ld2(Ws + (n2 - 2u - 2u * m));
+						const float *pp = pbp[c][e];
+						// p = 2m: q = n/4 - 1 - 2m (w = wA.y, mirror wB.x); p = 2m + 1: q = n/4 - 2 - 2m (wA.x, wB.y)
+						const float s0 = (pa[0] * wA.y) + (pp[0] * wB.x), s0m = ((-pa[0]) * wB.x) + (pp[0] * wA.y);
+						const float s1 = (pa[1] * wA.x) + (pp[1] * wB.y), s1m = ((-pa[1]) * wB.y) + (pp[1] * wA.x);
+						// p = n/4 - 2 - 2m: q = 2m + 1 (wC.y, mirror wD.x); p = n/4 - 1 - 2m: q = 2m (wC.x, wD.y)
+						const float s2 = (pa[2] * wC.y) + (pp[2] * wD.x), s2m = ((-pa[2]) * wD.x) + (pp[2] * wC.y);
+						const float s3 = (pa[3] * wC.x) + (pp[3] * wD.y), s3m = ((-pa[3]) * wD.y) + (pp[3] * wC.x);
+						const uint32_t mt = tl + T * e;
+						store_pair<FMT>(F.out, elem0, n4 - 2u - 2u * mt, stride, s1, s0);
+						store_pair<FMT>(F.out, elem0, n4 + 2u * mt, stride, s0m, s1m);
+						store_pair<FMT>(F.out, elem0, 2u * mt, stride, s3, s2);
+						store_pair<FMT>(F.out, elem0, n2 - 2u - 2u * mt, stride, s2m, s3m);
+					}
+					// the raw right part (audio.rs:1121, :1142-1147): pb(p) at n/4 - 1 - p and mirrored at n/4 + p
 #pragma unroll
-				for (int k = 0; k < 4; k++)
-					pbp[c][e][k] = pb[k];
+					for (int w = 0; w < 2; w++) {
+						float *dst = w == 0 ? st_dst : td_dst;
+						if (dst) {
+							const uint32_t mt = tl + T * e;
+							*reinterpret_cast<float2_t *>(dst + (n4 - 2u - 2u * mt)) = float2_t{pb[1], pb[0]};
+							*reinterpret_cast<float2_t *>(dst + (n4 + 2u * mt)) = float2_t{pb[0], pb[1]};
+							*reinterpret_cast<float2_t *>(dst + 2u * mt) = float2_t{pb[3], pb[2]};
+							*reinterpret_cast<float2_t *>(dst + (n2 - 2u - 2u * mt)) = float2_t{pb[2], pb[3]};
+						}
+					}
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						pbp[c][e][k] = pb[k];
+				}
 			}
 			// (the next channel's spectrum goes to U, last read in P0; its P0 writes V behind the barrier that follows the spectrum;
 			// the next slot's floor tables were last read in the spectrum phase, barriers ago)
@@ -590,9 +591,9 @@ __global__ void __launch_bounds__(1 << (BS - 5)) __attribute__((amdgpu_waves_per
 }
 
 template <int BS>
-static hipError_t launch_big(const LwBigArgs &F, uint32_t n_wg, int fmt, hipStream_t st)
+static hipError_t launch_big(const LwBigArgs &F, int fmt, hipStream_t st)
 {
-	const dim3 g(n_wg), b(1u << (BS - 5));
+	const dim3 g(F.n_wg), b(1u << (BS - 5));
 	LwBigArgs A = F;
 	if (fmt == LW_OUT_I16_PLANAR)
 		return lw_launch_k(k_big<LW_OUT_I16_PLANAR, BS>, g, b, 0, st, A);
@@ -632,5 +633,6 @@ hipError_t lw_launch_big(const LwDevTables &T, const LwBatchDev &B, const LwShor
 		F.fl_of[i] = L.fl_of[i];
 	for (uint32_t u = 0; u < L.n_units && u < LW_FAST_WAVES; u++)
 		F.units[u] = L.units[u];
-	return L.lanes == 128 ? launch_big<12>(F, L.n_tasks * L.n_units, fmt, st) : launch_big<13>(F, L.n_tasks * L.n_units, fmt, st);
+	F.n_wg = L.n_tasks * L.n_units;
+	return L.lanes == 128 ? launch_big<12>(F, fmt, st) : launch_big<13>(F, fmt, st);
 }
