@@ -185,33 +185,33 @@ def block(spec, bs, tabs, prev_pb=None):
     return td, ola, pb_out
 
 
-def floor_group(posts_x, posts_y, K, k0):
-    """the four floor values y of bins k0 .. k0+3 as a thread computes them: binary search for the interval of k0, at most one
-    step forward per bin (the posts' x are distinct integers), render_line's closed form (audio.rs:503-524) with the integer
-    division done by a reciprocal and a correction.  posts_x / posts_y: the ACTIVE posts in ascending x."""
-    lo, hi = 0, K - 1
-    while lo < hi:
-        mid = (lo + hi + 1) >> 1
-        if posts_x[mid] <= k0:
-            lo = mid
-        else:
-            hi = mid - 1
-    ys = []
-    for k in range(k0, k0 + 4):
-        if lo + 1 < K and posts_x[lo + 1] <= k:
-            lo += 1
-        if lo == K - 1:
-            ys.append(int(posts_y[lo]))
-            continue
-        x0, x1, y0, y1 = int(posts_x[lo]), int(posts_x[lo + 1]), int(posts_y[lo]), int(posts_y[lo + 1])
-        dy, adx = y1 - y0, x1 - x0
-        ady = abs(dy)
-        num = ady * (k - x0)
-        q = int(F(F(num) * (F(1.0) / F(adx))))          # (the kernel: v_rcp_f32, 1 ulp; any error below one unit is corrected)
-        rem = num - q * adx
-        if rem < 0:
-            q -= 1
-        elif rem >= adx:
-            q += 1
-        ys.append(y0 - q if dy < 0 else y0 + q)
-    return ys
+def floor_entries(xs, ys, active):
+    """k_big's floor segment table (floor_entry in lw_kernels_big.hip): one entry {dy, c0, 1/adx, w} per STATIC interval (behind post
+    s of the floor configuration, ascending x), describing the ACTIVE segment that covers it."""
+    Fp = len(xs)
+    ent = np.zeros((Fp, 4), F)
+    for s in range(Fp):
+        lo = max(i for i in range(s + 1) if active[i])
+        above = [i for i in range(s + 1, Fp) if active[i]]
+        hi = above[0] if above else lo
+        xlo, xhi, ylo, yhi = F(xs[lo]), F(xs[hi]), int(ys[lo]), int(ys[hi])
+        dy = F(yhi - ylo)
+        adx = xhi - xlo if above else F(1.0)
+        down = yhi < ylo
+        ent[s, 0] = dy
+        ent[s, 1] = (F(0.875) * adx - F(0.5)) - xhi * dy if down else (F(0.5) - F(0.125) * adx) - xlo * dy
+        ent[s, 2] = F(1.0) / adx if above else F(1.0)
+        ent[s, 3] = F(yhi if down else ylo) + F(2097153.0)
+    return ent
+
+
+def floor_bins(xs, ent, n2):
+    """y of every bin: the static interval of the bin (largest s with xs[s] <= k), its entry, two fused multiply-adds and a mask
+    (floor_bin).  The f64 evaluation rounds far below the quarter the f32 result is rounded to (see tests/test_big_model.py)."""
+    k = np.arange(n2)
+    sid = np.searchsorted(np.asarray(xs), k, side="right") - 1
+    e = ent[sid].astype(np.float64)
+    inner = (k * e[:, 0] + e[:, 1])
+    assert np.array_equal(inner.astype(np.float32).astype(np.float64), inner)
+    t = (inner * e[:, 2] + e[:, 3]).astype(np.float32)
+    return ((t.view(np.uint32) & 0x7FC) >> 2).astype(np.int64) - 1

@@ -22,10 +22,15 @@ from oracle import pyoracle as po  # noqa: E402  (the checker)
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--big", action="store_true", help="streams with 4096 / 8192-point long blocks (k_big) instead of the 2048-point ones")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 SETUPS = {"stereo": lambda: sg.stereo_setup(44100, 8, 11), "stereo_t1": lambda: sg.stereo_setup(44100, 8, 11, residue_type=1),
           "surround51": lambda: sg.surround51_setup(48000, 8, 11), "mono": wl.mono, "uncoupled": wl.uncoupled_stereo}
+if args.big:
+    SETUPS = {"stereo_9_12": lambda: sg.stereo_setup(44100, 9, 12), "stereo_6_13_t1": lambda: sg.stereo_setup(44100, 6, 13, residue_type=1),
+              "surround51_9_12": lambda: sg.surround51_setup(48000, 9, 12), "mono_7_12": lambda: sg.mono_setup(7, 12, 44100),
+              "stereo_10_12": lambda: sg.stereo_setup(44100, 10, 12), "stereo_8_13": lambda: sg.stereo_setup(44100, 8, 13)}
 FMTS = ["i16", "f32", "i16_interleaved"]
 OFMT = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}
 made = {}
