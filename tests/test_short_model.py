@@ -41,7 +41,7 @@ def test_image_eligibility_and_units():
     assert blob51 is not None and len(units51) == 3                                # two coupled pairs + one uncoupled pair
     assert _image(SETUPS["stereo"](), 1)[0] is None                                # its long blocks are k_long's
     assert _image(SETUPS["mono_small"]())[0] is None                               # 64-point blocks -> generic kernels
-    assert _image(SETUPS["stereo_9_12"](), 0)[2] == 16 and _image(SETUPS["stereo_9_12"](), 1)[0] is None   # 4096: generic
+    assert _image(SETUPS["stereo_9_12"](), 0)[2] == 16 and _image(SETUPS["stereo_9_12"](), 1)[0] is None   # 4096: k_big (no LDS image)
     assert _image(SETUPS["stereo_7_7"](), 1)[0] is None
     for name, (mk, flag, L) in CASES.items():
         blob, _, lanes, _, _ = _image(mk(), flag)
