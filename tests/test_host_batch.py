@@ -37,7 +37,8 @@ def harness(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("name,pattern", [("stereo", "L"), ("stereo", "LLSSLSL"), ("surround51", "LLSL"), ("mono_small", "LSSLL")])
+@pytest.mark.parametrize("name,pattern", [("stereo", "L"), ("stereo", "LLSSLSL"), ("surround51", "LLSL"), ("mono_small", "LSSLL"),
+                                          ("stereo_9_12", "LLLLLSLLL"), ("stereo_6_13", "L")])   # (the last two: k_big's slot planner)
 def test_batch_entropy_threads_agree_under_tsan(harness, tmp_path, name, pattern):
     from common import SETUPS
     case = str(tmp_path / "case.bin")
