@@ -4,11 +4,12 @@
 // kernels, ~16 barrier-separated radix-2 stages in LDS + a round trip of the time-domain block through HBM).
 //
 //   reference                                   here
-//   src/audio.rs:526-555, :503-524 (floor 1)    floor_group(): interval search + render_line's closed form
+//   src/audio.rs:526-555, :503-524 (floor 1)    floor_entry() / floor_bin(): a segment table per static interval, two FMAs per bin
 //   src/audio.rs:762-777 (inverse coupling)     decouple()
 //   src/imdct.rs:291-659 (inverse MDCT)         passes P0 .. P3 + E below
 //   src/audio.rs:1082-1154 (overlap-add, state) phase E of the kernel
-//   src/samples.rs:92-103 (conversion)          to_i16()
+//   src/samples.rs:92-103 (conversion)          store_pair()
+//   src/header_cached.rs:104-108 (bit reversal) computed (v_bfrev_b32) in phase E
 //
 // One workgroup of T = n / 32 threads (2 / 4 waves) works through the `passes` consecutive slots of one task (the block kernel's
 // slot descriptors, lw_fast.hpp: the planner of lw_batch.cpp places consecutive blocks of a stream in consecutive slots and a
@@ -39,7 +40,7 @@ struct LwBigArgs {
 	float *state, *td;
 	void *out;
 	const float *A, *Bt, *C, *window, *inv_db;
-	const uint32_t *bitrev;
+	const uint32_t *bitrev; // (not read: phase E computes the bit reversal)
 	const uint16_t *floor_x;
 	uint32_t n_units, ch, fstride, state_stride, state_chan_stride, passes;
 	uint32_t n_wg; // tasks x units = workgroups
