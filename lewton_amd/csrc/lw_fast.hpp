@@ -145,7 +145,7 @@ struct LwFastLaunch {
 // L = n / 32 = 128 / 256 threads per task, one slot per pass, no table image
 #define LW_BIG_MIN_BS 12
 #define LW_BIG_MAX_BS 13
-#define LW_BIG_MAX_PASSES 16u   // consecutive blocks of a stream per workgroup (one of them a recomputed predecessor inside a stream)
+#define LW_BIG_MAX_PASSES 64u   // consecutive blocks of a stream per workgroup (one of them a recomputed predecessor inside a stream)
 #define LW_BLK_MAX_POSTS(L) ((L) >= 16 ? 64 : 32) // floor-1 posts per channel of a block: 4 per lane (L = 8, 16), 2 per lane (L = 32)
 
 // byte offsets inside the LDS image of k_short<L> (compile-time layout; build_blk_plan writes the same)
