@@ -215,3 +215,89 @@ def floor_bins(xs, ent, n2):
     assert np.array_equal(inner.astype(np.float32).astype(np.float64), inner)
     t = (inner * e[:, 2] + e[:, 3]).astype(np.float32)
     return ((t.view(np.uint32) & 0x7FC) >> 2).astype(np.int64) - 1
+
+
+def block_wave(spec, bs=12):
+    """NOT built yet -- the index maps of the next design: ONE wave per channel of a 4096-point block, 16 pairs per
+    lane, no barrier.  Lane l holds j = l + 64 i (i < 8): step 1 gives it the pairs q' = j and 512 + j, and the stages of distance
+    512, 256, 128 and 64 all pair registers of the SAME lane (i with the mirrored set, i with i + 4, i + 2, i + 1): four stages
+    before the first LDS round trip.  Then two units of the workgroup kernel's P2 / P3 / E per lane (virtual threads l and l + 64
+    of block() with T = 128): three LDS round trips per channel instead of five, ordered by the wave's own LDS ordering.
+    Returns the time-domain block (compared with the oracle in tests/test_big_model.py)."""
+    from common import po
+    assert bs == 12
+    A, B, Cc, W, br = po.tables(bs)
+    n = 1 << bs
+    n2, n4, n8 = n // 2, n // 4, n // 8
+    l = np.arange(64)
+    U = np.asarray(spec, F)
+    lds = np.zeros((pad(n4 - 1) + 1, 2), F)
+
+    def put(q, v):
+        lds[pad(q), 0], lds[pad(q), 1] = v[0], v[1]
+
+    def get(q):
+        return (lds[pad(q), 0].copy(), lds[pad(q), 1].copy())
+
+    # ---- P0: step 1 + distances 512, 256, 128, 64 in registers; H[i] = pair j_i, L[i] = pair 512 + j_i
+    H, L = [None] * 8, [None] * 8
+    for i in range(8):
+        j = l + 64 * i
+        x0, x2 = U[4 * j], U[4 * j + 2]
+        H[i] = (x0 * A[2 * j + 1] + x2 * A[2 * j], x0 * A[2 * j] - x2 * A[2 * j + 1])
+        e, a = n2 - 3 - 4 * j, n4 + 2 * j
+        me2, me0 = -U[e + 2], -U[e]
+        L[i] = (me2 * A[a + 1] + me0 * A[a], me2 * A[a] - me0 * A[a + 1])
+    R = H + L                                   # registers 0..7 = q' = j_i, 8..15 = 512 + j_i
+    for i in range(8):                          # distance 512 (step 2): r = j
+        j = l + 64 * i
+        bfly(R, i, 8 + i, A[4 * j], A[4 * j + 1])
+    for D, span in ((256, 4), (128, 2), (64, 1)):
+        k1 = n // (2 * D)
+        for half in (0, 8):
+            for i in range(8):
+                if (i // span) % 2 == 0:
+                    r = (l + 64 * i) % (2 * D)
+                    assert np.all(r < D)
+                    bfly(R, half + i, half + i + span, A[r * k1], A[r * k1 + 1])
+    for i in range(8):
+        put(l + 64 * i, R[i])
+        put(n8 + l + 64 * i, R[8 + i])
+    # ---- the rest: block()'s P2, P3, E with two virtual threads per lane
+    T = 128
+    t = np.arange(T)
+    step = 8
+    q0 = (t // step) * 64 + t % step
+    V = [get(q0 + step * i) for i in range(8)]
+    radix8(V, q0, A, n, 32)
+    for i in range(8):
+        put(q0 + step * i, V[i])
+    z = [None] * 16
+    for k in range(8):
+        z[2 * k], z[2 * k + 1] = get(8 * t + 7 - k)
+    z = last3(z, A[n8])
+    for k in range(8):
+        put(8 * t + 7 - k, (z[2 * k], z[2 * k + 1]))
+    td = np.zeros(n, F)
+    for e_ in range(2):
+        m = t + T * e_
+        t0 = n // 16 - 1 - m
+        k1, k1p, k0, k0p = br[2 * m], br[2 * m + 1], br[2 * t0], br[2 * t0 + 1]
+        Pa, Pb = get(n4 - 1 - k1 // 2), get(n4 - 1 - k1p // 2)
+        Pc, Pd = get(n4 - 2 - k0 // 2), get(n4 - 2 - k0p // 2)
+        d = 4 * m
+        ve = [Pb[1], Pb[0], Pa[1], Pa[0]]
+        vd = [Pd[1], Pd[0], Pc[1], Pc[0]]
+        C0, C1, C2, C3 = Cc[d], Cc[d + 1], Cc[d + 2], Cc[d + 3]
+        a02, a11 = vd[0] - ve[2], vd[1] + ve[3]
+        b0, b1, b2, b3 = C1 * a02 + C0 * a11, C1 * a11 - C0 * a02, vd[0] + ve[2], vd[1] - ve[3]
+        vd[0], vd[1], ve[2], ve[3] = b2 + b0, b3 + b1, b2 - b0, b1 - b3
+        a02, a11 = vd[2] - ve[0], vd[3] + ve[1]
+        b0, b1, b2, b3 = C3 * a02 + C2 * a11, C3 * a11 - C2 * a02, vd[2] + ve[0], vd[3] - ve[1]
+        vd[2], vd[3], ve[0], ve[1] = b2 + b0, b3 + b1, b2 - b0, b1 - b3
+        for p, w0, w1 in ((2 * m, vd[0], vd[1]), (2 * m + 1, vd[2], vd[3]), (n4 - 2 - 2 * m, ve[0], ve[1]), (n4 - 1 - 2 * m, ve[2], ve[3])):
+            pa = w0 * B[2 * p + 1] - w1 * B[2 * p]
+            pb = (-w0) * B[2 * p] - w1 * B[2 * p + 1]
+            q = n4 - 1 - p
+            td[q], td[n2 - 1 - q], td[n2 + q], td[n - 1 - q] = pa, -pa, pb, pb
+    return td

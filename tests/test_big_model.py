@@ -99,3 +99,14 @@ def test_floor_by_two_fmas_and_a_mask_is_exact_up_to_4096_bins():
                 tt = (z * np.float64(rinv) + w).astype(np.float32)
                 got = ((tt.view(np.uint32) & 0x7FC) >> 2).astype(np.int64) - 1
                 assert np.array_equal(got, y0 + off), (adx, rinv)
+
+
+def test_wave_level_index_maps_of_the_next_design_bit_exact():
+    """one wave per 4096-point channel, 16 pairs per lane, four stages before the first LDS round trip (not built
+    yet; the maps are pinned here so that the kernel can be written against them)"""
+    rng = np.random.default_rng(5)
+    for trial in range(2):
+        x = (rng.standard_normal(2048) * 0.3).astype(np.float32)
+        got = bm.block_wave(x, 12)
+        want = po.inverse_mdct(x, 12)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), trial
