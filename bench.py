@@ -67,7 +67,7 @@ def main():
                          "the host learns of the end of the K steps tens of microseconds later, all of it inside the wall-clock span")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other_configs object (BASELINE configs[2], [3], [4]-stepping, blocksize_1 = 10 / 12 / 13)")
-    ap.add_argument("--other-steps", type=int, default=400, help="timed launches per entry of other_configs")
+    ap.add_argument("--other-steps", type=int, default=600, help="timed launches per entry of other_configs (at least)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group also for one process (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--streams", type=int, default=256,
@@ -380,12 +380,17 @@ def main():
             from lewton_amd import workloads as wl
             for key, label in (("3", "configs[2] mixed short/long"), ("4", "configs[3] 5.1 @ 48 kHz"),
                                ("10", "configs[4] stepping on one GPU: 10 000 streams x 4 packets"),
-                               ("12", "blocksize_1 = 10"), ("11", "blocksize_1 = 12"), ("13", "blocksize_1 = 13")):
+                               ("12", "blocksize_1 = 10"), ("11", "blocksize_1 = 12"), ("13", "blocksize_1 = 13"),
+                               ("14", "mixed 512/1024 (blocksize 9 / 10, LLLSSSLLLL)"),
+                               ("15", "mixed 256/1024 (blocksize 8 / 10, LLLSSSLLLL)")):
                 try:
                     w_ = wl.by_key(key)
-                    r_ = bc.measure(w_, steps=args.other_steps, nb=2, verify=True, distinct=16)
+                    # nb=None: as many rotated batches as put >= 0.5 GiB of algorithmic bytes into one rotation (twice the 256 MiB
+                    # Infinity Cache), at least 8 while that stays below 1.5 GiB -- the rule the headline follows
+                    r_ = bc.measure(w_, steps=args.other_steps, nb=None, verify=True, distinct=16)
                     other[label] = {"us_per_launch": r_["us_per_launch"], "packets_per_launch": r_["packets_per_launch"],
                                     "M_packets_per_s": r_["M_packets_per_s"], "algorithmic_bytes_per_launch": r_["algorithmic_bytes_per_launch"],
+                                    "batches_rotated": r_["batches_rotated"], "footprint_bytes": r_["footprint_bytes"],
                                     "frac": round(r_["pct_of_8TBps"] / 100.0, 4), "kernels": r_["kernels"], "parity": r_["parity"],
                                     "steps": r_["steps"]}
                 except Exception as e:

@@ -176,6 +176,19 @@ void lw_batch_set_force_generic(lw_batch *b, int on);
 void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
 /* test hook: 0 = never run a mixed short / long batch as one k_mix launch (two launches: k_long<EDGE>, k_short), -1 = where it applies */
 void lw_debug_batch_set_mix(lw_batch *b, int mode);
+/* test hook: 0 = the long blocks of a blocksize_1 = 10 stream through the block kernel k_short<32> instead of k_long10, -1 = k_long10 */
+void lw_debug_batch_set_long10(lw_batch *b, int mode);
+/* Device-side failures of a batch's launches (audio.rs:27-41: every failure is a status, never wrong samples).  Call once the
+ * work lw_batch_synth queued has COMPLETED (after synchronising its stream); lw_batch_synth_to_host and lw_ring_collect call it
+ * themselves.  LW_OK, or LW_ERR_DEVICE: a kernel raised the batch's error word (k_mix: a short block's wave never saw the raw
+ * edges its long neighbours' waves of the same launch were to write -- the grid was not resident at once, e.g. under a CU mask or
+ * next to another process's kernels).  Then every packet's result carries LW_ERR_DEVICE with 0 samples, the PCM written by this
+ * batch must not be used, and the window state of the batch's streams is undefined: reset their PreviousWindowRight (or restore
+ * a snapshot, lw_pwr_snapshot) before decoding on.  The word and the launch's leftovers are cleared: the batch can run again. */
+int lw_batch_device_status(lw_batch *b);
+/* test hook: spin != 0 = the long blocks' waves of the next k_mix launches never signal their edges, and the short blocks' waves
+ * give up after `spin` polls (lw_batch_device_status then reports LW_ERR_DEVICE); 0 = normal operation */
+void lw_debug_batch_break_mix(lw_batch *b, unsigned spin);
 /* Entropy stage on the device (csrc/lw_dev_entropy.h, k_entropy): the bit-serial half of read_audio_packet_generic
  * (audio.rs:921-986: floor-1 decode :215-251 + amplitude unwrap :391-435, residue decode :587-760) runs on the GPU, one
  * wave per packet; lw_batch_entropy then only reads the prologues, copies the packets into pinned staging and plans the
@@ -202,7 +215,8 @@ const char *lw_batch_last_kernels(const lw_batch *b);
  *                    (ordered behind the previous launch's kernels: consecutive batches may carry the same streams'
  *                    window state) and D2H of the PCM into the slot's pinned buffer
  *   lw_ring_submit   = stage + launch: returns while the GPU works, so the next submit's entropy decode overlaps it
- *   lw_ring_collect  waits for the oldest launched slot; results / PCM stay valid until lw_ring_release
+ *   lw_ring_collect  waits for the oldest launched slot; results / PCM stay valid until lw_ring_release.  LW_ERR_DEVICE with
+ *                    the slot collected all the same (release it as usual): lw_batch_device_status of that batch
  *   lw_ring_release  frees that slot
  *   lw_ring_drain    waits for everything in flight and frees all slots (their results are dropped)
  * stage may run on another thread than launch / collect / release (one thread each).  Every PreviousWindowRight sees its
@@ -251,8 +265,11 @@ size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0
  * Which returns of lw_sharder_collect consume the call: LW_ERR_CAPACITY and LW_ERR_NULL_ARG come from the argument checks and
  * consume NOTHING (call again); every other return -- LW_OK, or the error of a shard (LW_ERR_DEVICE) -- has taken the call out
  * of the queue and freed its slots; the packets of a shard that failed carry LW_ERR_DEVICE in results[].  A shard whose ring
- * saw a device error is started over (drained): parts of OLDER calls still in flight on that shard report LW_ERR_DEVICE when
- * they are collected, newer submits run normally.
+ * saw a device error is started over (drained): EVERY part that was in flight on that shard at that moment -- of older calls and
+ * of newer ones already submitted (up to two) -- reports LW_ERR_DEVICE when it is collected; calls submitted after the drain run
+ * normally.  The dropped batches had already advanced the host halves of their streams' window states, so the drain resets the
+ * PreviousWindowRight of every stream opened on that shard (lw_sharder_stream_reset): the first packet of each of them after the
+ * failure yields 0 samples (audio.rs:1140-1152), never samples overlapped with a stale right part.
  * A submit that fails AFTER some shards have launched (a device error on one shard) still queues the call, so that the
  * slots those shards hold can be freed: collect it (its packets on the failed shard come back with LW_ERR_DEVICE).
  * lw_sharder_decode = submit + collect on an empty pipeline.
@@ -282,7 +299,8 @@ size_t lw_sharder_in_flight(lw_sharder *sh); /* calls submitted and not yet coll
 /* Zero-copy form of collect: the oldest call's PCM stays where the GPUs' copy engines put it, in the shards' pinned ring
  * buffers -- pcm[g] / elems[g] for shard g (arrays of lw_sharder_shards() entries); results[i].out_offset is relative to
  * the block of the shard that owns packet i (lw_sharder_shard_of).  Valid until lw_sharder_release, which frees the slots.
- * Both run on the caller's thread (no hand-over to the shards' workers).  After ANY return of lw_sharder_collect_pinned other
+ * Both run on the caller's thread (no hand-over to the shards' workers) and leave the caller's current HIP device as they found
+ * it.  After ANY return of lw_sharder_collect_pinned other
  * than LW_ERR_CAPACITY / LW_ERR_NULL_ARG the call is held by the caller: lw_sharder_release takes it out of the queue. */
 int lw_sharder_collect_pinned(lw_sharder *sh, lw_packet_result *results, size_t n_results, const void **pcm, size_t *elems);
 int lw_sharder_release(lw_sharder *sh);

@@ -83,6 +83,19 @@ class Batch:
         """test hook (lw_debug_batch_set_mix): 0 = two launches for a mixed short / long batch, -1 = k_mix where it applies"""
         N.lw_debug_batch_set_mix(self._h, int(mode))
 
+    def debug_set_long10(self, mode):
+        """test hook (lw_debug_batch_set_long10): 0 = long blocks of a blocksize_1 = 10 stream through k_short<32>, -1 = k_long10"""
+        N.lw_debug_batch_set_long10(self._h, int(mode))
+
+    def debug_break_mix(self, spin):
+        """test hook (lw_debug_batch_break_mix): the long blocks' waves of k_mix never signal; the short blocks' waves give up after
+        `spin` polls and the batch fails with LW_ERR_DEVICE (0 = normal operation)"""
+        N.lw_debug_batch_break_mix(self._h, int(spin))
+
+    def device_status(self):
+        """lw_batch_device_status: 0, or LW_ERR_DEVICE when a kernel of the completed launches raised the batch's error word"""
+        return N.lw_batch_device_status(self._h)
+
     def debug_set_rounds(self, rounds):
         """test hook (lw_debug_batch_set_rounds): rounds per workgroup of the specialised kernel, 0 = planner's choice"""
         N.lw_debug_batch_set_rounds(self._h, int(rounds))

@@ -84,6 +84,12 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		if (d->any_floor0)
 			b->h_fcurve = (float *)H(o_fc), b->d_fcurve = (float *)D(o_fc);
 	}
+	if (ok) { // the device error word (lw_batch_device_status)
+		ok = lw_hip_ok(hipHostMalloc((void **)&b->h_err, 64, hipHostMallocMapped), "hipHostMalloc(error word)") &&
+			lw_hip_ok(hipHostGetDevicePointer((void **)&b->d_err, b->h_err, 0), "hipHostGetDevicePointer(error word)");
+		if (ok)
+			*b->h_err = 0;
+	}
 	if (!ok) {
 		*err = LW_ERR_DEVICE;
 		lw_batch_destroy(b.release());
@@ -107,6 +113,8 @@ void lw_batch_destroy(lw_batch *b)
 		(void)hipHostFree(b->h_pk);
 	if (b->h_pool)
 		(void)hipHostFree(b->h_pool);
+	if (b->h_err)
+		(void)hipHostFree(b->h_err);
 	void *ent[] = {b->d_pk, b->d_pool};
 	for (void *p : ent)
 		if (p)
@@ -128,6 +136,41 @@ void lw_debug_batch_set_mix(lw_batch *b, int mode)
 {
 	if (b)
 		b->mix_mode = mode;
+}
+
+void lw_debug_batch_set_long10(lw_batch *b, int mode)
+{
+	if (b)
+		b->l10_mode = mode;
+}
+
+void lw_debug_batch_break_mix(lw_batch *b, unsigned spin)
+{
+	if (b)
+		b->mix_break_spin = spin;
+}
+
+/* After the launches of lw_batch_synth have COMPLETED (the caller has synchronised the stream): LW_OK, or LW_ERR_DEVICE when a
+ * kernel raised the batch's device error word -- the PCM of this batch must not be used.  Clears the word and what the failed
+ * launch may have left behind (k_mix's edge flags), so that the batch can be launched again. */
+int lw_batch_device_status(lw_batch *b)
+{
+	if (!b)
+		return LW_ERR_NULL_ARG;
+	if (!b->h_err || __atomic_load_n(b->h_err, __ATOMIC_ACQUIRE) == 0)
+		return LW_OK;
+	__atomic_store_n(b->h_err, 0u, __ATOMIC_RELEASE);
+	lw_set_device_error("k_mix: a short block's wave never saw the raw edges of its long neighbours (grid not resident?); batch dropped");
+	if (lw_decoder_set_device(b->dec) == LW_OK && b->d_edge) {
+		const size_t entries = b->max_packets * 2 * b->dec->T.ch;
+		(void)lw_hip_ok(hipMemset(b->d_edge + entries * LW_EDGE_VALUES, 0, entries * sizeof(uint32_t)), "hipMemset(edge flags)");
+	}
+	for (size_t i = 0; i < b->n; i++)
+		if (b->results[i].status == LW_OK) {
+			b->results[i].status = LW_ERR_DEVICE;
+			b->results[i].n_samples = 0;
+		}
+	return LW_ERR_DEVICE;
 }
 
 void lw_debug_batch_set_rounds(lw_batch *b, int rounds)
@@ -448,6 +491,16 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
 				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
 		}
+	// blocksize_1 = 10: the class-1 blocks (long blocks with two long slopes) go to k_long10 on k_long's work list (below) instead
+	// of k_short<32>'s slots
+	b->use_l10 = blk_ok[1] && d->blkp[1].lanes == 32 && b->l10_mode != 0 && !d->fast.eligible &&
+		d->blkp[1].units.size() <= LW_FAST_WAVES;
+	if (b->use_l10) {
+		b->fast_idx.swap(b->blk_idx[1]);
+		b->fast_slot.swap(b->blk_slot[1]);
+		b->blk_idx[1].clear();
+		b->blk_slot[1].clear();
+	}
 	// ---- slots of k_short<L> (lw_fast.hpp), per block class: the blocks sorted by stream so that consecutive blocks of a stream sit
 	// in consecutive slots of a wave and hand their right part over through LDS; a block whose predecessor of the same class is
 	// not the slot in front of it (wave boundary) gets that predecessor recomputed in the slot in front (LW_SS_HALO).
@@ -474,7 +527,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		};
 		std::vector<Ev> ev;
 		for (int cls = 0; cls < 2; cls++) {
-			if (!blk_ok[cls])
+			if (!blk_ok[cls] || (cls == 1 && b->use_l10))
 				continue;
 			// passes per wave: more slots per recomputed predecessor -- but only while the launch keeps the waves the chip holds
 			// at a time (five per CU: LDS) (a wave's passes run one after the other: 4096 blocks of 1024 points in 820 waves of 3
@@ -512,8 +565,16 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			std::stable_sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &c) { return a.slot != c.slot ? a.slot < c.slot : a.idx < c.idx; });
 			LwShortSlot *slots = b->h_slots[cls];
 			size_t n_slots = 0; // slots used so far (tasks are consecutive groups of per_task)
+			// capacity (lw_batch_create sizes the list for three slots per packet plus padding): every event below takes at most two
+			// slots and at most one task's worth of padding in front of them
+			const size_t slot_cap = b->max_tasks[cls];
+			bool slots_full = false;
 			auto room = [&](size_t want) { // the next `want` slots lie in one task
 				const size_t used = n_slots % per_task;
+				if (n_slots + per_task + want > slot_cap) {
+					slots_full = true;
+					return;
+				}
 				if (used + want > per_task)
 					while (n_slots % per_task) {
 						std::memset(&slots[n_slots], 0, sizeof(LwShortSlot));
@@ -567,9 +628,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			};
 			int64_t last_pkt = -1; // packet of the slot placed last (a block or a halo), -1 after anything else
 			for (const Ev &e : ev) {
+				if (slots_full)
+					break;
 				const LwPacketRec &r = b->h_recs[e.idx];
 				if (is_long_fast(r)) { // LW_SS_EDGE
 					room(1);
+					if (slots_full)
+						break;
 					LwShortSlot &sl = blank(e.idx, LW_SS_EDGE);
 					outside_prev(r, sl);
 					sl.next_edge = e.idx;
@@ -582,10 +647,14 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				bool lane = pred_same && last_pkt == (int64_t)r.prev && (n_slots % per_task) != 0;
 				if (pred_same && !lane) { // recompute the predecessor in the slot in front
 					room(2);
+					if (slots_full)
+						break;
 					blank((uint32_t)r.prev, LW_SS_HALO);
 					lane = true;
-				} else if (!lane) {
-					room(1);
+				} else {
+					room(1); // (a slot behind its predecessor in the same task: only the capacity check)
+					if (slots_full)
+						break;
 				}
 				LwShortSlot &sl = blank(e.idx, LW_SS_BLOCK);
 				if (lane)
@@ -599,7 +668,16 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				set_next(e.idx, sl);
 				last_pkt = (int64_t)e.idx;
 			}
-			room(per_task + 1); // pad the last task
+			if (slots_full) { // (cannot happen while lw_batch_create's bound holds; never write past the list)
+				lw_set_device_error("block kernel: slot list capacity exceeded");
+				return LW_ERR_CAPACITY;
+			}
+			while (n_slots % per_task) { // pad the last task
+				std::memset(&slots[n_slots], 0, sizeof(LwShortSlot));
+				slots[n_slots].next_edge = 0xFFFFFFFFu;
+				slots[n_slots].state_out = -1;
+				n_slots++;
+			}
 			b->n_tasks[cls] = n_slots / per_task;
 		}
 	}
@@ -661,7 +739,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		if (!std::is_sorted(b->fast_slot.begin(), b->fast_slot.end())) // (callers usually list their streams one after the other)
 			std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
 					[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
-		uint32_t per_round = LW_FAST_WAVES / (uint32_t)d->fast.units.size();
+		const size_t n_fast_units = b->use_l10 ? d->blkp[1].units.size() : d->fast.units.size();
+		uint32_t per_round = LW_FAST_WAVES / (uint32_t)n_fast_units;
 		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
 		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
@@ -678,7 +757,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		}
 		// a sparse launch (one round, at most half of a workgroup's waves in use) lasts as long as ONE wave's dependent chain:
 		// split every channel pair over two waves (LW_UNIT_SPLIT_*) -- each half does one channel's floor, transform and samples
-		b->fast_split = !b->forced_rounds && !b->has_tdonly && rounds == 1 && d->fast.units_split.size() > d->fast.units.size() &&
+		b->fast_split = !b->use_l10 && !b->forced_rounds && !b->has_tdonly && rounds == 1 && d->fast.units_split.size() > d->fast.units.size() &&
 			per_round * d->fast.units_split.size() <= LW_FAST_WAVES;
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
@@ -874,7 +953,9 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.n_items = (uint32_t)b->n_items;
 		L.d_halo_items = b->d_halo_items;
 		L.n_halo_items = (uint32_t)b->n_halo_items;
-		const std::vector<LwFastUnit> &units = b->fast_split ? d->fast.units_split : d->fast.units;
+		const std::vector<LwFastUnit> &units = b->use_l10 ? d->blkp[1].units : b->fast_split ? d->fast.units_split : d->fast.units;
+		if (b->use_l10)
+			L.d_image = d->d_blk_image[1];
 		L.n_units = (uint32_t)units.size();
 		L.per_round = b->fast_per_round;
 		L.rounds = b->fast_rounds;
@@ -906,16 +987,19 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	};
 	// a mixed short / long batch small enough for the chip to hold at once: both kernels' work in ONE launch (k_mix)
 	bool mixed = false;
-	if (run_fast && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
+	if (run_fast && !b->use_l10 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
 		const LwShortLaunch S = short_launch(0);
 		if (lw_mix_applicable(L, S, d->n_cus)) {
 			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * LW_EDGE_VALUES);
-			HIP_TRY(lw_launch_mix(d->T, B, L, S, flags, d_out, b->fmt, st));
+			HIP_TRY(lw_launch_mix(d->T, B, L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
 			b->last_kernels += b->n_halo_items ? "k_long<halo>,k_mix," : "k_mix,";
 			mixed = true;
 		}
 	}
-	if (run_fast && !mixed) {
+	if (run_fast && b->use_l10) {
+		HIP_TRY(lw_launch_long10(d->T, B, L, d_out, b->fmt, st));
+		b->last_kernels += b->n_halo_items ? "k_long10<halo>,k_long10," : "k_long10,";
+	} else if (run_fast && !mixed) {
 		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
 	}
@@ -991,7 +1075,7 @@ int lw_batch_synth_to_host(lw_batch *b, void *h_out, size_t out_capacity_elems, 
 	if (b->out_elems)
 		HIP_TRY(hipMemcpyAsync(h_out, b->d_out, b->out_elems * lw_elem_size(b->fmt), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	return LW_OK;
+	return lw_batch_device_status(b);
 }
 
 int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats)

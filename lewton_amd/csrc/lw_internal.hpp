@@ -100,6 +100,10 @@ struct lw_batch {
 	bool edge_mode = false;  // short blocks in k_short, long blocks with short slopes in k_long<EDGE>
 	float *d_edge = nullptr; // [max_packets][2][ch][64], and behind it the flags of k_mix: [max_packets][2][ch] dwords
 	int mix_mode = -1;       // lw_debug_batch_set_mix: -1 = k_mix where it applies, 0 = never (two launches)
+	// device error word: one dword of pinned host memory the kernels can write (k_mix: a wave whose producer never signalled);
+	// lw_batch_device_status reads it once the launches have completed
+	uint32_t *h_err = nullptr, *d_err = nullptr;
+	uint32_t mix_break_spin = 0; // lw_debug_batch_break_mix: != 0 = the long blocks' waves of k_mix never signal, give up after this many polls
 	std::vector<uint32_t> blk_idx[2], blk_slot[2];
 	std::vector<int32_t> succ; // per packet: the next packet of the same stream in this batch, or -1
 	// entropy stage on the device: the packets themselves go up (word-aligned, zero padded) with one descriptor each
@@ -121,6 +125,10 @@ struct lw_batch {
 	std::vector<uint32_t> fast_idx, fast_slot, fast_order;
 	uint32_t fast_per_round = 1, fast_rounds = 1, fast_dense = 0, fast_late_from = 1;
 	bool fast_split = false; // the specialised kernel runs one channel per wave (sparse launch)
+	// blocksize_1 = 10: the long blocks with two long slopes (block class 1, 32 lanes per block) run through k_long10 -- k_long's
+	// work list, units and launch shape on the block kernel's table image -- instead of k_short<32>
+	bool use_l10 = false;
+	int l10_mode = -1;       // lw_debug_batch_set_long10: -1 = k_long10 where it applies, 0 = never (k_short<32>)
 	int forced_rounds = 0; // lw_debug_batch_set_rounds: rounds per workgroup of the specialised kernel (0 = the planner decides)
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 
 // hipFuncSetAttribute is per DEVICE, and launchers are entered from several host threads (one decoder per GPU in one
 // process; the sharder's workers; the Ogg staging thread next to the caller): `run(set)` calls
@@ -31,9 +32,15 @@ struct LwPerDeviceOnce {
 };
 
 // Kernel launch that RETURNS the launch status (hipLaunchKernelGGL drops it; hipGetLastError would also pick up an earlier
-// hipErrorNotReady of a polled event): the arguments are passed by address, in the kernel's parameter order.
-template <class K, class... A> static inline hipError_t lw_launch_k(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A &...a)
+// hipErrorNotReady of a polled event): the arguments are passed by address, in the kernel's parameter order -- and hipLaunchKernel
+// reads sizeof(parameter) bytes behind each address, so every argument must BE the parameter's type (a bool or a size_t handed in
+// for an int parameter would be read as garbage without a diagnostic): checked against the kernel's signature at compile time.
+template <class... P, class... A>
+static inline hipError_t lw_launch_k(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, A &...a)
 {
+	static_assert(sizeof...(P) == sizeof...(A), "lw_launch_k: one argument per kernel parameter");
+	static_assert((std::is_same<typename std::remove_cv<A>::type, typename std::remove_cv<P>::type>::value && ...),
+			"lw_launch_k: every argument must have exactly its kernel parameter's type");
 	void *args[] = {(void *)&a...};
 	return hipLaunchKernel((const void *)kernel, grid, block, args, lds, st);
 }
@@ -104,6 +111,9 @@ void lw_launch_generic_ola(const LwDevTables &T, const LwBatchDev &B, void *out,
 // Specialised long-block path (lw_kernels_long.hip): optional halo pre-pass + main pass.
 struct LwFastLaunch;
 hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
+// The same design for blocksize_1 = 10 (k_long10, lw_long10.inc): L.d_image = the block kernel's image for 32 lanes per block
+// (LwBlkLayout<32>), the work list and the halo pre-pass as for k_long with 512-value residue vectors.
+hipError_t lw_launch_long10(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
 // Short blocks of such streams (k_short, same translation unit); runs after lw_launch_long (it reads the edge buffer).
 struct LwShortLaunch;
 hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st);
@@ -111,5 +121,7 @@ hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwSh
 hipError_t lw_launch_big(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st);
 // Both in ONE launch (k_mix, same translation unit) where lw_mix_applicable says so; d_flags: [packets][2][ch] dwords, zero.
 bool lw_mix_applicable(const LwFastLaunch &LL, const LwShortLaunch &LS, int n_cus);
+// d_err: the batch's device error word (device-visible host memory): a short block's wave that does not see its edge flags within
+// `spin` polls (0 = the default, about a second) raises it and stores nothing.  drop_flags: test hook, no producer signals.
 hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &LL, const LwShortLaunch &LS, uint32_t *d_flags,
-		void *out, int fmt, hipStream_t st);
+		uint32_t *d_err, uint32_t spin, bool drop_flags, void *out, int fmt, hipStream_t st);

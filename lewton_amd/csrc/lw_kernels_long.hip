@@ -1329,7 +1329,7 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t byte_addr, uint32_t need)
 template <int FMT, bool RIGHT_ONLY, bool TD = false, bool EDGE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 {
-	constexpr bool MIXF = false;
+	constexpr bool MIXF = false, mix_drop_flags = false;
 	uint32_t *const edge_flags = nullptr;
 #include "lw_long_body.inc"
 }
@@ -1662,6 +1662,12 @@ __device__ __forceinline__ Half8 load_half8_coherent(const float *src, uint32_t 
 	return h;
 }
 
+// the batch's device error word lives in host memory (lw_batch_device_status reads it once the launch has completed)
+__device__ __forceinline__ void raise_device_error(uint32_t *err)
+{
+	__hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ uint32_t load_flag_coherent(const uint32_t *p)
 {
 	uint32_t v;
@@ -1677,7 +1683,8 @@ __global__ void __launch_bounds__(64) k_short(LwShortArgs F)
 	const uint32_t wid = blockIdx.x, lane = threadIdx.x;     // this wave's (task, unit)
 	constexpr int ONLY = -1;
 	constexpr bool STAGE = true;
-	uint32_t *const edge_flags = nullptr;
+	uint32_t *const edge_flags = nullptr, *const mix_err = nullptr;
+	constexpr uint32_t mix_spin = 0;
 #include "lw_short_body.inc"
 }
 
@@ -1701,14 +1708,19 @@ static_assert(2u * LwBlkWave<8, true>::BYTES <= 6u * LW_SCR_BYTES && 2u * LwBlkW
 #define LW_MIX_LDS_BYTES (LW_MIX_IMG_OFF + LwBlkLayout<8>::TOTAL)
 static_assert(LW_MIX_LDS_BYTES <= 160u * 1024u, "k_long's areas and the short blocks' image fit a CU's LDS");
 
+#define LW_MIX_SPIN (1u << 20) // polls of a short block's wave for its edge flags before it gives the batch up (~1 s)
 struct LwMixArgs {
 	uint32_t *flags;     // [packet][side][ch] of the batch, zero between launches (every flag is cleared by its one reader)
-	uint32_t pad[2];
+	uint32_t *err;       // the batch's device error word (host memory, mapped): set by a short block's wave whose flags never came
+	uint32_t spin;       // polls before giving up (LW_MIX_SPIN; the test hook shortens it)
+	uint32_t drop_flags; // test hook (lw_debug_batch_break_mix): the long blocks' waves never signal
 };
 
 template <int FMT>
-__device__ __forceinline__ void mix_short_role(const LwShortArgs &F, uint32_t *edge_flags, char *smem_dyn, uint32_t wave, uint32_t lane)
+__device__ __forceinline__ void mix_short_role(const LwShortArgs &F, const LwMixArgs &M, char *smem_dyn, uint32_t wave, uint32_t lane)
 {
+	uint32_t *const edge_flags = M.flags, *const mix_err = M.err;
+	const uint32_t mix_spin = M.spin;
 	constexpr int L = 8;
 	const uint32_t i = wave - (LW_FAST_WAVES - LW_MIX_SHORT_WAVES);
 	const uint32_t wid = blockIdx.x * LW_MIX_SHORT_WAVES + i; // this wave's (task, unit half)
@@ -1734,9 +1746,10 @@ __global__ void __launch_bounds__(LW_WG) k_mix(LwFastArgs F, LwShortArgs FS, LwM
 {
 	constexpr bool RIGHT_ONLY = false, TD = false, EDGE = true, SPLIT = true, MIXF = true;
 	uint32_t *const edge_flags = M.flags;
+	const bool mix_drop_flags = M.drop_flags != 0;
 #define LW_LONG_BODY_AFTER_STAGE                                                  \
 	if (wave >= LW_FAST_WAVES - LW_MIX_SHORT_WAVES) {                            \
-		mix_short_role<FMT>(FS, edge_flags, smem, wave, lane_id);                 \
+		mix_short_role<FMT>(FS, M, smem, wave, lane_id);                          \
 		return;                                                                   \
 	}
 	// the short blocks' image (5 KB = 320 x 16 bytes) goes up with k_long's, by the threads of the last four waves
@@ -1955,7 +1968,7 @@ bool lw_mix_applicable(const LwFastLaunch &LL, const LwShortLaunch &LS, int n_cu
 }
 
 hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &LL, const LwShortLaunch &LS, uint32_t *d_flags,
-		void *out, int fmt, hipStream_t st)
+		uint32_t *d_err, uint32_t spin, bool drop_flags, void *out, int fmt, hipStream_t st)
 {
 	LwFastArgs F{};
 	uint32_t grid = 0;
@@ -1966,6 +1979,9 @@ hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFast
 	short_prepare(T, B, LS, out, FS);
 	LwMixArgs M{};
 	M.flags = d_flags;
+	M.err = d_err;
+	M.spin = spin ? spin : LW_MIX_SPIN;
+	M.drop_flags = drop_flags ? 1u : 0u;
 	const size_t lds = LW_MIX_LDS_BYTES + LW_STAMP_LDS_EXTRA;
 	// ONE k_mix grid per device at a time.  Its short blocks' waves wait for long blocks' waves of other workgroups, which is safe
 	// because the whole grid is resident -- two such grids on one device (two decoders, two rings, logical shards; different
@@ -2008,3 +2024,8 @@ hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFast
 		return launched(lw_launch_k(k_mix<LW_OUT_I16_INTERLEAVED>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M));
 	return launched(lw_launch_k(k_mix<LW_OUT_F32_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M));
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_long10: this file's design for blocksize_1 = 10 (n = 1024)
+// ---------------------------------------------------------------------------------------------
+#include "lw_long10.inc"

@@ -252,9 +252,13 @@ int lw_ring_collect(lw_ring *r, const lw_packet_result **results, size_t *n, con
 			return LW_ERR_CAPACITY; // nothing launched
 		wait = s->state == SLOT_LAUNCHED; // (collect is idempotent until release)
 	}
+	int dev_rc = LW_OK;
 	if (wait) {
 		if (!ok(hipSetDevice(r->device)) || !ok(hipEventSynchronize(s->all_done)))
 			return LW_ERR_DEVICE;
+		// a kernel of this batch raised its device error word: the batch's results carry LW_ERR_DEVICE, its PCM is void; the
+		// slot is COLLECTED all the same (release it as usual)
+		dev_rc = lw_batch_device_status(s->batch);
 		std::lock_guard<std::mutex> g(r->mu);
 		s->state = SLOT_COLLECTED;
 	}
@@ -266,7 +270,7 @@ int lw_ring_collect(lw_ring *r, const lw_packet_result **results, size_t *n, con
 		*pcm = s->h_out;
 	if (pcm_elems)
 		*pcm_elems = s->out_elems;
-	return LW_OK;
+	return dev_rc;
 }
 
 int lw_ring_release(lw_ring *r)

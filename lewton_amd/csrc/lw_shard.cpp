@@ -83,6 +83,9 @@ struct Shard {
 	// the ring's cursors, so whatever older calls still hold on this ring is gone: `gen` tells their parts apart from new ones.
 	std::mutex ring_mu;
 	uint64_t gen = 0;               // under ring_mu
+	// the streams opened on this shard (lw_sharder_stream_open / _close): a drain resets their window state
+	std::mutex streams_mu;
+	std::vector<lw_shard_stream *> streams;
 };
 
 } // namespace
@@ -140,11 +143,27 @@ struct lw_sharder {
 		calls.pop_front();
 	}
 
-	void drain_locked(Shard &s) // (s.ring_mu held)
+	// Starts a shard's ring over after a device failure.  Everything in flight on the shard is gone with it -- parts of OLDER and
+	// of NEWER calls alike report LW_ERR_DEVICE when they are collected (`gen`) -- and the host halves of the shard's window states
+	// have advanced past batches that never completed: every stream of the shard is reset (`PreviousWindowRight::new()`), so that
+	// its next packet yields no samples (audio.rs:1140-1152) instead of samples overlapped with a stale right part.
+	// (s.ring_mu held; the public calls are serialised by call_mu, so no stage of this shard runs beside this)
+	void drain_locked(Shard &s)
 	{
 		(void)lw_ring_drain(s.ring);
 		s.gen++;
+		std::lock_guard<std::mutex> g(s.streams_mu);
+		for (lw_shard_stream *st : s.streams)
+			lw_pwr_reset(st->pwr);
 	}
+
+	// the calling thread's current HIP device, restored when a public call that ran ring operations on the caller's thread returns
+	// (lw_ring_collect / lw_ring_drain select the shard's device; the caller's own HIP code must not find another device current)
+	struct KeepDevice {
+		int dev = -1;
+		KeepDevice() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+		~KeepDevice() { if (dev >= 0) (void)hipSetDevice(dev); }
+	};
 
 	void stage(Shard &s, Call &c)
 	{
@@ -389,6 +408,9 @@ lw_shard_stream *lw_sharder_stream_open(lw_sharder *sh, uint64_t stream_id)
 		delete st;
 		return nullptr;
 	}
+	Shard &s = *sh->shards[st->shard];
+	std::lock_guard<std::mutex> g(s.streams_mu);
+	s.streams.push_back(st);
 	return st;
 }
 
@@ -396,6 +418,11 @@ void lw_sharder_stream_close(lw_shard_stream *st)
 {
 	if (!st)
 		return;
+	if (st->owner && st->shard < st->owner->shards.size()) {
+		Shard &s = *st->owner->shards[st->shard];
+		std::lock_guard<std::mutex> g(s.streams_mu);
+		s.streams.erase(std::remove(s.streams.begin(), s.streams.end(), st), s.streams.end());
+	}
 	lw_pwr_free(st->pwr);
 	delete st;
 }
@@ -485,6 +512,7 @@ int lw_sharder_collect_pinned(lw_sharder *sh, lw_packet_result *results, size_t 
 	if (!sh || !pcm || !elems)
 		return LW_ERR_NULL_ARG;
 	std::lock_guard<std::mutex> call(sh->call_mu);
+	lw_sharder::KeepDevice keep_dev;
 	if (sh->calls.empty())
 		return LW_ERR_CAPACITY;
 	Call &c = *sh->calls.front();
@@ -518,6 +546,7 @@ int lw_sharder_release(lw_sharder *sh)
 	if (!sh)
 		return LW_ERR_NULL_ARG;
 	std::lock_guard<std::mutex> call(sh->call_mu);
+	lw_sharder::KeepDevice keep_dev;
 	if (sh->calls.empty() || !sh->calls.front()->collected)
 		return LW_ERR_CAPACITY;
 	Call &c = *sh->calls.front();

@@ -187,8 +187,12 @@ class Sharder:
         rc = N.lw_sharder_collect_pinned(self._h, self._res, n, pcm, el)
         if rc:
             # a shard's error leaves the call held by the caller (see lewton_amd.h): give it back so that the C queue and
-            # self._pending stay in step; the argument checks hold nothing and release() then refuses harmlessly
-            if N.lw_sharder_release(self._h) == 0:
+            # self._pending stay in step.  lw_sharder_release RETIRES the call and returns that part's status (LW_ERR_DEVICE
+            # again, not 0), so whether the call left the queue is read off lw_sharder_in_flight, as collect() does; after a
+            # failed argument check nothing is held and the release retires nothing
+            before = N.lw_sharder_in_flight(self._h)
+            N.lw_sharder_release(self._h)
+            if N.lw_sharder_in_flight(self._h) < before:
                 self._pending.pop(0)
             raise RuntimeError("lw_sharder_collect_pinned: %d %s" % (rc, N.device_error()))
         dt = np.float32 if self.fmt == N.FMT_F32_PLANAR else np.int16
@@ -203,10 +207,13 @@ class Sharder:
         return views, res
 
     def release(self):
+        # (a shard's error is returned by the release that retires the call: the queues stay in step either way)
+        before = self._N.lw_sharder_in_flight(self._h)
         rc = self._N.lw_sharder_release(self._h)
+        if rc == 0 or self._N.lw_sharder_in_flight(self._h) < before:
+            self._pending.pop(0)
         if rc:
             raise RuntimeError("lw_sharder_release: %d" % rc)
-        self._pending.pop(0)
 
     def close(self):
         if getattr(self, "_h", None):

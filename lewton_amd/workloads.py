@@ -67,6 +67,12 @@ def configs(packets: int = 4096) -> List[Workload]:
                  "blocksize_1 = 10"),
         Workload("13", "stereo long blocks n = 8192", lambda: sg.stereo_setup(44100, 6, 13), "L", 256, per,
                  "blocksize_1 = 13"),
+        # mixed short/long streams at the block sizes libvorbis writes at 16-22 kHz (audio.rs:1056-1073: the four window shapes of a
+        # long block next to short ones)
+        Workload("14", "mixed 512/1024", lambda: sg.stereo_setup(22050, 9, 10), "LLLSSSLLLL", 256, per,
+                 "blocksize 9 / 10; long blocks with short slopes on either side of every run of short blocks"),
+        Workload("15", "mixed 256/1024", lambda: sg.stereo_setup(22050, 8, 10), "LLLSSSLLLL", 256, per,
+                 "blocksize 8 / 10"),
     ]
 
 

@@ -1,0 +1,162 @@
+"""k_long10 -- k_long's design for blocksize_1 = 10 (1024-point long blocks, lw_long10.inc) -- against the ORACLE, and against the
+block kernel k_short<32> on the very same batches (-m gpu).
+
+Covered: dense launches (256 streams x 16 packets, the bench shape; 48 packets per stream = three rounds per workgroup), streams
+cut across rounds and workgroups (hand-over through LDS inside a round, from round to round, and through the halo pre-pass at
+chunk starts), one packet per stream per launch (every right part through the state pool), 5.1 (two coupled pairs + one
+uncoupled pair = three units per packet), mono (single-channel units: half a wave idle), stereo without coupling, residue
+types 1 and 2, unused floors, truncated packets, the three sample formats, and mixed short/long streams whose transition blocks
+go through the generic kernels (time-domain blocks exchanged both ways)."""
+import numpy as np
+import pytest
+
+from common import oracle_headers, po, sg
+
+pytestmark = pytest.mark.gpu
+
+
+def _uncoupled_8_10():
+    st = sg.stereo_setup(22050, 8, 10, residue_type=1)
+    for m in st.mappings:
+        m.coupling = []
+    return st
+
+
+L10_SETUPS = {
+    "stereo_9_10": lambda: sg.stereo_setup(22050, 9, 10),
+    "stereo_8_10_t1": lambda: sg.stereo_setup(22050, 8, 10, residue_type=1),
+    "surround51_8_10": lambda: sg.surround51_setup(48000, 8, 10),
+    "mono_7_10": lambda: sg.mono_setup(7, 10, 16000),
+    "uncoupled_8_10": _uncoupled_8_10,
+}
+
+
+def _decoder(setup):
+    from lewton_amd import audio, header
+    idp, _, stp = setup.headers()
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    return audio, audio.decoder_for(ident, st)
+
+
+def _decode(dec, audio, streams, cuts, fmt, l10=-1, rounds=0):
+    """streams[s] = packets; cuts = batch boundaries in packets-per-stream ([0, 3, 10, ...]): every batch holds packets cuts[k] ..
+    cuts[k+1] of every stream, stream-major.  Returns (per packet arrays, kernels seen, final window states)."""
+    from lewton_amd.batch import Batch
+    ch = dec.ident.audio_channels
+    pwrs = [audio.PreviousWindowRight() for _ in streams]
+    out = [[None] * len(s) for s in streams]
+    seen = set()
+    cap = max(b - a for a, b in zip(cuts[:-1], cuts[1:])) * len(streams)
+    bt = Batch(dec, cap, fmt)
+    bt.debug_set_long10(l10)
+    if rounds:
+        bt.debug_set_rounds(rounds)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        items = [(s, t) for s in range(len(streams)) for t in range(a, min(b, len(streams[s])))]
+        res = bt.entropy([(streams[s][t], pwrs[s]) for s, t in items], n_threads=2)
+        bt.upload()
+        got = bt.split(bt.synth_to_host(), ch)
+        seen.update(bt.last_kernels.split(","))
+        for (s, t), r, g in zip(items, res, got):
+            out[s][t] = (r[0], None if g is None else g.copy())
+    states = [p.data().copy() for p in pwrs]
+    bt.close()
+    return out, seen, states
+
+
+def _oracle(setup, streams, fmt):
+    o_id, o_st = oracle_headers(setup)
+    ofmt = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}[fmt]
+    out, states = [], []
+    for pk in streams:
+        opw = po.Pwr()
+        row = []
+        for p in pk:
+            try:
+                row.append((0, np.asarray(po.read_audio_packet(o_id, o_st, p, opw, ofmt))))
+            except po.OracleError as e:
+                row.append((e.code, None))
+        out.append(row)
+        states.append(opw.data(setup.channels))
+    return out, states
+
+
+def _same(a, b, fmt):
+    if a is None or b is None:
+        return a is None and b is None
+    a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+    if a.size != b.size:
+        return False
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32)) if fmt == "f32" else np.array_equal(a, b)
+
+
+def _compare(got, want, fmt, tag):
+    for s, (gr, wr) in enumerate(zip(got, want)):
+        for t, ((gs, g), (ws, w)) in enumerate(zip(gr, wr)):
+            assert gs == ws, (tag, s, t, gs, ws)
+            assert _same(g, w, fmt), (tag, s, t)
+
+
+@pytest.mark.parametrize("name", sorted(L10_SETUPS))
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_long10_all_long_streams_vs_oracle_and_block_kernel(name, fmt):
+    setup = L10_SETUPS[name]()
+    audio, dec = _decoder(setup)
+    n_streams = 37                      # not a multiple of anything: chunks cut streams, the last workgroup is partly idle
+    streams = [sg.make_stream(setup, "L", 23 + (s % 5), seed=4100 + s, p_floor_unused=0.08) for s in range(n_streams)]
+    streams[3][7] = streams[3][7][: len(streams[3][7]) // 2]      # a truncated packet (end of packet inside the residue)
+    want, wstates = _oracle(setup, streams, fmt)
+    cuts = [0, 1, 2, 9, 28]             # one packet per stream per launch twice (state pool), then runs
+    got, seen, states = _decode(dec, audio, streams, cuts, fmt)
+    assert "k_long10" in seen and not any(k.startswith("k_short") for k in seen), seen
+    _compare(got, want, fmt, name)
+    for s in range(n_streams):
+        assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
+    # the block kernel on the same batches: identical bytes
+    got2, seen2, states2 = _decode(dec, audio, streams, cuts, fmt, l10=0)
+    assert "k_short" in seen2 and "k_long10" not in seen2, seen2
+    _compare(got2, want, fmt, name + " (k_short<32>)")
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 3, 5])
+def test_long10_forced_rounds_hand_over_paths(rounds):
+    """the same streams with 1 / 2 / 3 / 5 rounds per workgroup: right halves through LDS inside a round and from the last wave of a
+    round to the first of the next, through the halo pre-pass where a chunk starts inside a stream, through the state pool between
+    launches"""
+    setup = L10_SETUPS["stereo_9_10"]()
+    audio, dec = _decoder(setup)
+    streams = [sg.make_stream(setup, "L", 40 + 3 * (s % 4), seed=4300 + s) for s in range(11)]
+    want, wstates = _oracle(setup, streams, "i16")
+    got, seen, states = _decode(dec, audio, streams, [0, 5, 52], "i16", rounds=rounds)
+    assert "k_long10" in seen, seen
+    if rounds < 5:
+        assert "k_long10<halo>" in seen, seen
+    _compare(got, want, "i16", "rounds=%d" % rounds)
+    for s in range(len(streams)):
+        assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
+
+
+@pytest.mark.parametrize("name", ["stereo_9_10", "stereo_8_10_t1", "surround51_8_10"])
+@pytest.mark.parametrize("fmt", ["i16", "f32"])
+def test_long10_next_to_short_blocks_through_the_generic_kernels(name, fmt):
+    """mixed short/long streams: the long blocks with two long slopes in k_long10, the short blocks in k_short, the long blocks next
+    to short ones in the generic kernels -- right halves cross between all three through time-domain blocks and the state pool"""
+    setup = L10_SETUPS[name]()
+    audio, dec = _decoder(setup)
+    pats = ["LLLSSSLLLL", "LLSLLLSSLLLLL", "LSSSSSSLLL", "LLLLLLLSL"]
+    streams = [sg.make_stream(setup, pats[s % 4], 30 + s % 3, seed=4500 + s, p_floor_unused=0.05) for s in range(13)]
+    want, wstates = _oracle(setup, streams, fmt)
+    got, seen, states = _decode(dec, audio, streams, [0, 2, 3, 17, 33], fmt)
+    assert "k_long10" in seen and "k_short" in seen, seen
+    _compare(got, want, fmt, name)
+    for s in range(len(streams)):
+        assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
+
+
+def test_long10_dense_bench_shapes():
+    """the shapes tools/bench_configs.py times for blocksize_1 = 10: 256 streams x 16 (one round) and x 48 (three rounds)"""
+    from test_gpu_quoted_shapes import _run_dense
+    for packets in (4096, 12288):
+        bad, kernels, n = _run_dense("12", "i16", packets=packets)
+        assert n == packets and bad == 0 and kernels == "k_long10", (bad, kernels)

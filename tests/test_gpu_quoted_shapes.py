@@ -25,7 +25,7 @@ def _decoder(setup):
     return audio, audio.decoder_for(ident, st)
 
 
-def _run_dense(key, fmt="i16", packets=4096):
+def _run_dense(key, fmt="i16", packets=4096, l10=-1):
     from lewton_amd import workloads as wl
     from lewton_amd.batch import Batch
     w = wl.by_key(key, packets)
@@ -40,6 +40,7 @@ def _run_dense(key, fmt="i16", packets=4096):
     prime.synth_to_host()
     prime.close()
     bt = Batch(dec, len(items), fmt)
+    bt.debug_set_long10(l10)
     res = bt.entropy(items, n_threads=4)
     bt.upload()
     flat = bt.synth_to_host()
@@ -74,7 +75,7 @@ def test_uncoupled_pair_and_single_channel_units_bench_shape(key):
 def test_other_long_block_sizes_bench_shape(key):
     bad, kernels, n = _run_dense(key, packets=1024)
     assert n == 1024 and bad == 0, (bad, kernels)
-    assert kernels == ("k_short" if key == "12" else "k_big")
+    assert kernels == ("k_long10" if key == "12" else "k_big")
 
 
 @pytest.mark.parametrize("key,fmt", [("11", "i16"), ("11", "f32"), ("13", "i16_interleaved")])
@@ -195,24 +196,27 @@ def test_block_kernel_streams_state_round_trip_and_runs(name, fmt):
     b2 = Batch(dec, n_streams * tail, fmt)
     check(b2, [(s, steps + t) for s in range(n_streams) for t in range(tail)])
     assert ("k_big" in seen) if name in BIG else ("k_short" in seen), seen
+    if name in ("stereo_9_10", "stereo_8_10"):
+        assert "k_long10" in seen, seen        # their long blocks with two long slopes (lw_long10.inc)
     for s in range(n_streams):
         assert np.array_equal(pwrs[s].data().view(np.uint32), opws[s].data(ch).view(np.uint32)), s
     b1.close()
     b2.close()
 
 
-def test_long_blocks_of_1024_points_dense_bench_shape():
-    """blocksize_1 = 10 (what libvorbis writes at 16-22 kHz): 256 streams x 16 long blocks in one launch, all through
-    k_short<32> (a block's predecessor recomputed in the slot in front: two slots per wave)"""
-    bad, kernels, n = _run_dense("12", "i16", packets=4096)
+def test_long_blocks_of_1024_points_dense_bench_shape_block_kernel():
+    """blocksize_1 = 10 (what libvorbis writes at 16-22 kHz): 256 streams x 16 long blocks in one launch through the block kernel
+    k_short<32> (a block's predecessor recomputed in the slot in front: two slots per wave) -- the default path for this shape is
+    k_long10 (tests/test_gpu_long10.py); the block kernel stays as the independent second implementation"""
+    bad, kernels, n = _run_dense("12", "i16", packets=4096, l10=0)
     assert n == 4096 and bad == 0, (bad, kernels)
     assert kernels == "k_short"
 
 
 def test_long_blocks_of_1024_points_three_passes_per_wave():
-    """a launch with enough blocks that a wave works through three passes of two slots (one recomputed predecessor per five
-    blocks, right parts handed from pass to pass through the double-buffered LDS area): 256 streams x 48 blocks"""
-    bad, kernels, n = _run_dense("12", "i16", packets=12288)
+    """a launch with enough blocks that a wave of k_short<32> works through three passes of two slots (one recomputed predecessor
+    per five blocks, right parts handed from pass to pass through the double-buffered LDS area): 256 streams x 48 blocks"""
+    bad, kernels, n = _run_dense("12", "i16", packets=12288, l10=0)
     assert n == 12288 and bad == 0, (bad, kernels)
     assert kernels == "k_short"
 
@@ -326,3 +330,44 @@ def test_mixed_batch_as_one_launch_equals_two_launches(name, fmt):
         assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
     for a, b in zip(outs[-1][1], outs[0][1]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_mix_launch_without_producers_is_an_error_not_samples():
+    """k_mix's short blocks' waves wait for the raw edges of their long neighbours through flags in HBM.  A wave whose flags never come
+    (here: the test hook makes every long block's wave skip its flags; in the field: a grid that is not resident at once) must end in a
+    STATUS -- LW_ERR_DEVICE for the whole batch, every packet result marked, audio.rs:27-41 -- not in PCM computed from whatever the
+    edge buffer held.  Afterwards the very same Batch object decodes correctly again (the error word and the flags are cleared)."""
+    from lewton_amd import _native as N
+    from lewton_amd.batch import Batch
+    setup = sg.stereo_setup()
+    audio, dec = _decoder(setup)
+    n_streams, per = 24, 22
+    streams = [sg.make_stream(setup, "LLSSSSSSSSLLSSLSL", per, seed=900 + s) for s in range(n_streams)]
+    o_id = po.Ident(setup.headers()[0])
+    o_st = po.Setup(setup.headers()[2], o_id)
+    bt = Batch(dec, n_streams * per, "i16")
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    bt.entropy([(streams[s][t], pwrs[s]) for s in range(n_streams) for t in range(per)], n_threads=2)
+    bt.upload()
+    bt.debug_break_mix(2000)                 # ~2000 polls of a few hundred ns: milliseconds, not the default second
+    with pytest.raises(RuntimeError) as ei:
+        bt.synth_to_host()
+    assert "lw_batch_synth_to_host: %d" % N.ERR_DEVICE in str(ei.value) and "k_mix" in bt.last_kernels
+    assert all(r[0] == N.ERR_DEVICE and r[1] == 0 for r in bt.results())
+    assert bt.device_status() == 0           # the word was consumed by the failing call
+    # normal operation again, same Batch: fresh window states (those of the failed batch are undefined by contract)
+    bt.debug_break_mix(0)
+    pwrs = [audio.PreviousWindowRight() for _ in range(n_streams)]
+    res = bt.entropy([(streams[s][t], pwrs[s]) for s in range(n_streams) for t in range(per)], n_threads=2)
+    bt.upload()
+    flat = bt.synth_to_host()
+    assert "k_mix" in bt.last_kernels
+    k = 0
+    for s in range(n_streams):
+        opw = po.Pwr()
+        for t in range(per):
+            want = np.asarray(po.read_audio_packet(o_id, o_st, streams[s][t], opw, "i16")).reshape(-1)
+            status, m, off = res[k]
+            assert status == 0 and m * 2 == want.size and np.array_equal(flat[off:off + m * 2], want), (s, t)
+            k += 1
+    bt.close()

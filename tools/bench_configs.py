@@ -3,7 +3,7 @@
   3: mixed short/long stream(s), block pattern L L S S S S S S S S L with overlap-add state carry
   4: 5.1-channel 48 kHz long blocks with channel coupling
   5: many independent stereo streams, ONE packet per stream per launch (state round trip through HBM every launch)
-  (6-12: design probes, see lewton_amd/workloads.py)
+  (6-15: design probes and other block sizes, see lewton_amd/workloads.py)
 Same method as bench.py: records resident in HBM, hipGraph replay of rotated batches, HIP events -- and, like bench.py,
 the PCM the timed launches left for batch 0 is compared with the oracle, every packet (`parity` of each line; --no-verify
 skips it).  The oracle is the checker only; nothing timed touches it.
@@ -23,12 +23,23 @@ sys.path.insert(0, ROOT)
 from lewton_amd import audio, header, workloads as wl  # noqa: E402
 from lewton_amd.batch import Batch  # noqa: E402
 
-NB = 4
+NB = None           # batches rotated: None = by footprint (rotation_batches below)
+MALL_BYTES = 256 << 20   # MI355X Infinity Cache (MI355X_MICROARCH.md): a rotation that fits it is timed out of the cache, not HBM
+
+
+def rotation_batches(alg_bytes):
+    """Batches to rotate so that a timed rotation touches >= 0.5 GiB of algorithmic bytes (twice the 256 MiB Infinity Cache,
+    SURVEY 7 "Measuring HBM, not Infinity Cache"), and at least 8 of them while that stays below 1.5 GiB."""
+    need = -(-(2 * MALL_BYTES) // max(1, alg_bytes))
+    return max(2, need, min(8, (3 * (1 << 29)) // max(1, alg_bytes)))
 
 
 def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0):
-    """Time workload `w` (lewton_amd.workloads.Workload): `nb` rotated batches resident in HBM, one hipGraph of `nb` steps replayed,
-    HIP events; then (verify) every packet of timed batch 0 against the oracle.  Returns the result line as a dict."""
+    """Time workload `w` (lewton_amd.workloads.Workload): `nb` rotated batches resident in HBM (default: as many as
+    rotation_batches() asks for -- a footprint of at least 0.5 GiB), one hipGraph of `nb` steps replayed, HIP events; then
+    (verify) every packet of timed batch 0 against the oracle.  Returns the result line as a dict.
+    Batch b holds the same packet sequences as batch 0 with the stream -> sequence assignment rotated by b (its own
+    records, its own PCM buffer: what defeats the cache is the footprint, not the values)."""
     if distinct:
         w = dataclasses.replace(w, distinct=distinct)
     setup = w.setup()
@@ -38,10 +49,13 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
     dec = audio.decoder_for(ident, st, torch.cuda.current_device())
     NP = w.n_streams * w.per_stream
     batches, outs, material = [], [], []
-    for b in range(nb):
+    seqs0 = wl.stream_material(w, setup, batch=0)
+    b = 0
+    while nb is None or b < nb:
         pw = [audio.PreviousWindowRight() for _ in range(w.n_streams)]
         # every stream is primed with the packet that precedes its first timed one, so all timed packets yield samples
-        seqs = wl.stream_material(w, setup, batch=b)
+        r_ = b % len(seqs0)
+        seqs = seqs0[r_:] + seqs0[:r_]
         prime_items, items = wl.items_of(w, seqs, pw)
         prime = Batch(dec, w.n_streams, "i16")
         prime.entropy(prime_items, n_threads=0)
@@ -56,6 +70,9 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
         outs.append(torch.empty(max(1, bt.out_elems), dtype=torch.int16, device="cuda"))
         batches.append((bt, pw))
         material.append(seqs)
+        if nb is None:
+            nb = rotation_batches(bt.algorithmic_bytes)
+        b += 1
     torch.cuda.synchronize()
     alg = batches[0][0].algorithmic_bytes
     stream = torch.cuda.current_stream()
@@ -81,7 +98,7 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
         if (time.perf_counter() - t_settle) * 1e3 >= settle_ms:
             break
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(1, steps // nb)
+    reps = max(2, -(-steps // nb))
     e0.record()
     for _ in range(reps):
         g.replay()
@@ -99,6 +116,7 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
             parity = "unchecked: %r" % (e,)
     res = {"config": w.name, "packets_per_launch": NP, "streams": w.n_streams, "steps": reps * nb, "us_per_launch": round(us, 2),
            "M_packets_per_s": round(NP / us, 2), "algorithmic_bytes_per_launch": alg,
+           "batches_rotated": nb, "footprint_bytes": nb * alg,
            "pct_of_8TBps": round(100 * alg / (us * 1e-6) / 8e12, 2), "kernels": batches[0][0].last_kernels, "parity": parity,
            "note": w.note}
     for bt, _ in batches:
@@ -113,8 +131,9 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="", help="comma-separated config numbers (default: 3,4,5)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
+    ap.add_argument("--nb", type=int, default=0, help="batches rotated (0 = by footprint: >= 0.5 GiB per rotation)")
     args = ap.parse_args()
     ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
     for w in wl.configs(args.packets):
         if w.key in ONLY:
-            print(json.dumps(measure(w, args.steps, NB, not args.no_verify, args.force_generic)), flush=True)
+            print(json.dumps(measure(w, args.steps, args.nb or None, not args.no_verify, args.force_generic)), flush=True)

@@ -3,7 +3,7 @@
 # + stats of the bench command, PMC passes (headline kernel; the two kernels of the mixed configuration), the other BASELINE
 # configs with their oracle check, the device entropy stage (kernel duration, counters, differential runs), the end-to-end
 # rates of ring and sharder, the host's CPU limits.  Everything lands in gpurun_out/r04_final/;
-# tools/r04_collect.sh copies the summaries into profiles/.
+# tools/sessions/r04_collect.sh copies the summaries into profiles/.
 D=gpurun_out/r04_final
 mkdir -p $D
 bash tools/host_limits.sh > $D/gpu_box_host.txt 2>&1
