@@ -176,7 +176,9 @@ void lw_batch_set_force_generic(lw_batch *b, int on);
 void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
 /* test hook: 0 = never run a mixed short / long batch as one k_mix launch (two launches: k_long<EDGE>, k_short), -1 = where it applies */
 void lw_debug_batch_set_mix(lw_batch *b, int mode);
-/* test hook: 0 = the long blocks of a blocksize_1 = 10 stream through the block kernel k_short<32> instead of k_long10, -1 = k_long10 */
+/* test hook for blocksize_1 = 10 streams: -1 = k_long10 (long blocks next to short ones in its EDGE form where the short blocks run
+ * through k_short), 1 = k_long10 for the long blocks with two long slopes only (the others through the generic kernels), 0 = the
+ * block kernel k_short<32> instead of k_long10 */
 void lw_debug_batch_set_long10(lw_batch *b, int mode);
 /* Device-side failures of a batch's launches (audio.rs:27-41: every failure is a status, never wrong samples).  Call once the
  * work lw_batch_synth queued has COMPLETED (after synchronising its stream); lw_batch_synth_to_host and lw_ring_collect call it

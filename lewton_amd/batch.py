@@ -84,7 +84,8 @@ class Batch:
         N.lw_debug_batch_set_mix(self._h, int(mode))
 
     def debug_set_long10(self, mode):
-        """test hook (lw_debug_batch_set_long10): 0 = long blocks of a blocksize_1 = 10 stream through k_short<32>, -1 = k_long10"""
+        """test hook (lw_debug_batch_set_long10) for blocksize_1 = 10 streams: -1 = k_long10 incl. its EDGE form, 1 = k_long10 without
+        the EDGE form (long blocks next to short ones through the generic kernels), 0 = k_short<32>"""
         N.lw_debug_batch_set_long10(self._h, int(mode))
 
     def debug_break_mix(self, spin):

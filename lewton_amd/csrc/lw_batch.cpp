@@ -13,6 +13,12 @@
 // packets a worker claims at a time: small enough that 64 threads share a 4096-packet batch evenly to the end
 #define LW_ENTROPY_CHUNK 4
 
+// floats per raw edge in the edge buffer (lw_fast.hpp): blocksize_0 / 4 = 8 x the lanes of a short block of k_short (64 next to k_long)
+static inline size_t lw_edge_values(const lw_decoder *d)
+{
+	return d->blkp[0].eligible && d->blkp[0].lanes <= 16 ? 8u * d->blkp[0].lanes : LW_EDGE_VALUES;
+}
+
 extern "C" {
 
 // ---- batches ----------------------------------------------------------------------------------
@@ -163,7 +169,7 @@ int lw_batch_device_status(lw_batch *b)
 	lw_set_device_error("k_mix: a short block's wave never saw the raw edges of its long neighbours (grid not resident?); batch dropped");
 	if (lw_decoder_set_device(b->dec) == LW_OK && b->d_edge) {
 		const size_t entries = b->max_packets * 2 * b->dec->T.ch;
-		(void)lw_hip_ok(hipMemset(b->d_edge + entries * LW_EDGE_VALUES, 0, entries * sizeof(uint32_t)), "hipMemset(edge flags)");
+		(void)lw_hip_ok(hipMemset(b->d_edge + entries * lw_edge_values(b->dec), 0, entries * sizeof(uint32_t)), "hipMemset(edge flags)");
 	}
 	for (size_t i = 0; i < b->n; i++)
 		if (b->results[i].status == LW_OK) {
@@ -363,8 +369,13 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	// k_short<L> covers the short blocks (class 0) and, where k_long does not apply, the long blocks with two long slopes (class 1)
 	const bool blk_ok[2] = {d->blkp[0].eligible && !b->force_generic, d->blkp[1].eligible && !b->force_generic};
-	// short blocks of 256 points next to k_long: long blocks with short slopes stay in k_long<EDGE> (lw_fast.hpp)
-	const bool short_ok = d->fast.eligible && blk_ok[0] && d->blkp[0].bs == 8;
+	// blocksize_1 = 10: the class-1 blocks go to k_long10 on k_long's work list (below) instead of k_short<32>'s slots
+	b->use_l10 = blk_ok[1] && d->blkp[1].lanes == 32 && b->l10_mode != 0 && !d->fast.eligible &&
+		d->blkp[1].units.size() <= LW_FAST_WAVES;
+	// short blocks of 256 points next to k_long, of 256 / 512 points next to k_long10: long blocks with short slopes stay in the
+	// long-block kernel's EDGE form (lw_fast.hpp)
+	const bool short_ok10 = b->use_l10 && b->l10_mode != 1 && blk_ok[0] && (d->blkp[0].bs == 8 || d->blkp[0].bs == 9);
+	const bool short_ok = (d->fast.eligible && blk_ok[0] && d->blkp[0].bs == 8) || short_ok10;
 	b->edge_mode = false; // set when the batch has a long block with a short slope (an all-(1,1) batch keeps the plain k_long)
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
 	for (size_t i = 0; i < n; i++) {
@@ -441,9 +452,16 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				b->fast_idx.push_back((uint32_t)i);
 				b->fast_slot.push_back((uint32_t)pw->slot);
 			}
-		} else if (blk_ok[1] && p.blockflag && p.prev_flag && p.next_flag &&
-				(d->blkp[1].short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) && (r.prev == -1 || r.plen == n1h)) {
-			r.flags |= LW_RF_FAST; // (a long block of a stream without k_long: k_short<L>, class 1; other window shapes: generic)
+		} else if (blk_ok[1] && p.blockflag && (d->blkp[1].short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) &&
+				(short_ok10 ? (r.prev == -1 || r.plen == (p.prev_flag ? n1h : n0h))
+				            : (p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h)))) {
+			// a long block of a stream without k_long: k_short<L> (class 1) or k_long10, two long slopes; other window shapes go to
+			// the generic kernels -- unless the stream's short blocks run through k_short next to k_long10: then as above (EDGE)
+			r.flags |= LW_RF_FAST;
+			if (short_ok10) {
+				r.xflags = (uint8_t)((p.prev_flag ? 0u : LW_XF_EDGE_L) | (p.next_flag ? 0u : LW_XF_EDGE_R));
+				b->edge_mode |= r.xflags != 0;
+			}
 			b->blk_idx[1].push_back((uint32_t)i);
 			b->blk_slot[1].push_back((uint32_t)pw->slot);
 		} else if (blk_ok[0] && !p.blockflag && (d->blkp[0].short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) &&
@@ -491,11 +509,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
 				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
 		}
-	// blocksize_1 = 10: the class-1 blocks (long blocks with two long slopes) go to k_long10 on k_long's work list (below) instead
-	// of k_short<32>'s slots
-	b->use_l10 = blk_ok[1] && d->blkp[1].lanes == 32 && b->l10_mode != 0 && !d->fast.eligible &&
-		d->blkp[1].units.size() <= LW_FAST_WAVES;
-	if (b->use_l10) {
+	if (b->use_l10) { // (k_long10: its packets on the specialised kernel's lists from here on)
 		b->fast_idx.swap(b->blk_idx[1]);
 		b->fast_slot.swap(b->blk_slot[1]);
 		b->blk_idx[1].clear();
@@ -512,7 +526,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		for (size_t i = 0; i < n; i++)
 			if (!(b->h_recs[i].flags & LW_RF_SKIP) && b->h_recs[i].prev >= 0)
 				b->succ[b->h_recs[i].prev] = (int32_t)i;
-		const bool klong = d->fast.eligible;
+		const bool klong = d->fast.eligible || b->use_l10;
 		// a packet of k_long / a block of k_short<L> of class `cls`
 		auto is_long_fast = [&](const LwPacketRec &r) {
 			return klong && (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == (LW_RF_FAST | LW_RF_LONG);
@@ -828,7 +842,7 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	b->ent_done = false;
 	if (b->d_edge) { // k_mix's flags: an edge written for a reader that a NEW plan no longer has must not look ready
 		const size_t entries = b->max_packets * 2 * ch;
-		HIP_TRY(hipMemsetAsync(b->d_edge + entries * LW_EDGE_VALUES, 0, entries * sizeof(uint32_t), st));
+		HIP_TRY(hipMemsetAsync(b->d_edge + entries * lw_edge_values(b->dec), 0, entries * sizeof(uint32_t), st));
 	}
 	if (b->dev_entropy) {
 		HIP_TRY(hipMemcpyAsync(b->d_pk, b->h_pk, b->n * sizeof(LwEntPacket), hipMemcpyHostToDevice, st));
@@ -893,8 +907,8 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	const bool run_short = (b->n_tasks[0] > 0 || b->n_tasks[1] > 0) && !all_generic;
 	if (b->edge_mode && (run_fast || run_short) && !b->d_edge) {
 		const size_t entries = b->max_packets * 2 * d->T.ch; // raw edges, and one flag each for k_mix (zero between launches)
-		HIP_TRY(hipMalloc((void **)&b->d_edge, entries * (LW_EDGE_VALUES * sizeof(float) + sizeof(uint32_t))));
-		HIP_TRY(hipMemsetAsync(b->d_edge + entries * LW_EDGE_VALUES, 0, entries * sizeof(uint32_t), st));
+		HIP_TRY(hipMalloc((void **)&b->d_edge, entries * (lw_edge_values(d) * sizeof(float) + sizeof(uint32_t))));
+		HIP_TRY(hipMemsetAsync(b->d_edge + entries * lw_edge_values(d), 0, entries * sizeof(uint32_t), st));
 	}
 	if (run_short && (b->has_generic || all_generic) && !b->d_td) { // (k_short may read / write td blocks next to generic packets)
 		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
@@ -965,6 +979,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.split = b->fast_split ? 1u : 0u;
 		L.edge_mode = b->edge_mode ? 1u : 0u;
 		L.d_edge = b->d_edge;
+		L.edge_n = (uint32_t)lw_edge_values(d);
 		for (size_t i = 0; i < units.size() && i < LW_FAST_WAVES; i++)
 			L.units[i] = units[i];
 		L.d_halo = b->d_halo;
@@ -990,7 +1005,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	if (run_fast && !b->use_l10 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
 		const LwShortLaunch S = short_launch(0);
 		if (lw_mix_applicable(L, S, d->n_cus)) {
-			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * LW_EDGE_VALUES);
+			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * lw_edge_values(d));
 			HIP_TRY(lw_launch_mix(d->T, B, L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
 			b->last_kernels += b->n_halo_items ? "k_long<halo>,k_mix," : "k_mix,";
 			mixed = true;

@@ -123,7 +123,8 @@ struct LwFastLaunch {
 	uint32_t has_tdonly; // some item is LW_IF_TDONLY
 	uint32_t split;      // the units are LW_UNIT_SPLIT_* halves (sparse launch): SPLIT instantiation
 	uint32_t edge_mode;  // the stream's short blocks run through k_short: EDGE instantiation, d_edge valid
-	float *d_edge;       // [packet][side][ch][64]
+	float *d_edge;       // [packet][side][ch][edge_n]
+	uint32_t edge_n;     // values per raw edge = blocksize_0 / 4 (LW_EDGE_VALUES next to k_long)
 	LwFastUnit units[LW_FAST_WAVES];
 	float *d_halo;
 };
@@ -216,7 +217,9 @@ struct LwShortSlot {
 };
 static_assert(sizeof(LwShortSlot) == 48, "LwShortSlot is 48 bytes");
 
-// floats per packet in the edge buffer: [side: 0 = left edge pa(448..511), 1 = right edge pb(448..511)][ch][64]
+// floats per packet in the edge buffer: [side: 0 = left edge pa(448..511), 1 = right edge pb(448..511)][ch][64] next to k_long
+// (256-point short blocks).  In general a raw edge holds blocksize_0 / 4 = 8 L values, L = lanes per short block: the top of the
+// long block's pa / pb (k_long10 next to 256- / 512-point short blocks: 64 / 128 values)
 #define LW_EDGE_VALUES 64u
 
 // k_mix (a mixed short / long batch in ONE launch, lw_kernels_long.hip): the last LW_MIX_SHORT_WAVES waves of every workgroup run

@@ -128,7 +128,9 @@ struct lw_batch {
 	// blocksize_1 = 10: the long blocks with two long slopes (block class 1, 32 lanes per block) run through k_long10 -- k_long's
 	// work list, units and launch shape on the block kernel's table image -- instead of k_short<32>
 	bool use_l10 = false;
-	int l10_mode = -1;       // lw_debug_batch_set_long10: -1 = k_long10 where it applies, 0 = never (k_short<32>)
+	int l10_mode = -1;       // lw_debug_batch_set_long10: -1 = k_long10 where it applies (long blocks next to short ones in its EDGE
+	                         // form when the short blocks run through k_short), 1 = k_long10 without the EDGE form (those blocks through
+	                         // the generic kernels), 0 = never (k_short<32>)
 	int forced_rounds = 0; // lw_debug_batch_set_rounds: rounds per workgroup of the specialised kernel (0 = the planner decides)
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;

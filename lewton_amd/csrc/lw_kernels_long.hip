@@ -69,6 +69,7 @@ struct LwFastArgs {
 	float *edge;               // EDGE kernels: [packet][side][ch][64] raw edges of long blocks with short slopes (lw_fast.hpp)
 	void *out;
 	uint32_t state_stride, state_chan_stride;
+	uint32_t edge_n;           // k_long10<EDGE>: values per raw edge = blocksize_0 / 4 (k_long: always LW_EDGE_VALUES)
 };
 static_assert(offsetof(LwFastArgs, waves) == 48, "kernel reads waves[] through the kernarg segment pointer");
 

@@ -22,10 +22,16 @@ def _uncoupled_8_10():
     return st
 
 
+def _surround51_8_10():
+    st = sg.surround51_setup(48000, 8, 10)
+    st.floors[3].x_rest = [64, 16, 256, 128, 32, 384]   # (the generator's LFE floor has a post at x = 512 = the implied end post for bs 10)
+    return st
+
+
 L10_SETUPS = {
     "stereo_9_10": lambda: sg.stereo_setup(22050, 9, 10),
     "stereo_8_10_t1": lambda: sg.stereo_setup(22050, 8, 10, residue_type=1),
-    "surround51_8_10": lambda: sg.surround51_setup(48000, 8, 10),
+    "surround51_8_10": _surround51_8_10,
     "mono_7_10": lambda: sg.mono_setup(7, 10, 16000),
     "uncoupled_8_10": _uncoupled_8_10,
 }
@@ -137,19 +143,26 @@ def test_long10_forced_rounds_hand_over_paths(rounds):
         assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
 
 
-@pytest.mark.parametrize("name", ["stereo_9_10", "stereo_8_10_t1", "surround51_8_10"])
-@pytest.mark.parametrize("fmt", ["i16", "f32"])
-def test_long10_next_to_short_blocks_through_the_generic_kernels(name, fmt):
-    """mixed short/long streams: the long blocks with two long slopes in k_long10, the short blocks in k_short, the long blocks next
-    to short ones in the generic kernels -- right halves cross between all three through time-domain blocks and the state pool"""
+@pytest.mark.parametrize("name", ["stereo_9_10", "stereo_8_10_t1", "surround51_8_10", "uncoupled_8_10"])
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+@pytest.mark.parametrize("mode", [-1, 1])
+def test_long10_mixed_short_long_streams(name, fmt, mode):
+    """mixed short/long streams (512/1024 and 256/1024 points), mode -1: the long blocks in k_long10 -- those with a short slope in
+    its EDGE form, which leaves the raw edges for k_short -- and the short blocks in k_short<8 / 16>, no generic kernel, no time-domain
+    block through HBM; mode 1: the long blocks next to short ones through the generic kernels instead (right halves cross between
+    all three paths through time-domain blocks and the state pool).  Batch cuts put every window shape at a launch boundary (the
+    short state written by one path, read by another)."""
     setup = L10_SETUPS[name]()
     audio, dec = _decoder(setup)
-    pats = ["LLLSSSLLLL", "LLSLLLSSLLLLL", "LSSSSSSLLL", "LLLLLLLSL"]
-    streams = [sg.make_stream(setup, pats[s % 4], 30 + s % 3, seed=4500 + s, p_floor_unused=0.05) for s in range(13)]
+    pats = ["LLLSSSLLLL", "LLSLLLSSLLLLL", "LSSSSSSLLL", "LLLLLLLSL", "SLSLLSSL"]
+    streams = [sg.make_stream(setup, pats[s % 5], 30 + s % 3, seed=4500 + s, p_floor_unused=0.05) for s in range(13)]
+    streams[5][9] = streams[5][9][: len(streams[5][9]) // 3]
     want, wstates = _oracle(setup, streams, fmt)
-    got, seen, states = _decode(dec, audio, streams, [0, 2, 3, 17, 33], fmt)
+    cuts = [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 33]
+    got, seen, states = _decode(dec, audio, streams, cuts, fmt, l10=mode)
     assert "k_long10" in seen and "k_short" in seen, seen
-    _compare(got, want, fmt, name)
+    assert any("generic" in k for k in seen) == (mode == 1), seen
+    _compare(got, want, fmt, "%s mode %d" % (name, mode))
     for s in range(len(streams)):
         assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
 
