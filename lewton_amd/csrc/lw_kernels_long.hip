@@ -1518,6 +1518,27 @@ __device__ __forceinline__ void blk_t2(float2_t (&P)[8])
 	}
 }
 
+// Where pair p of block g lies in a wave's bit-reverse gather area (8-byte slots; a bijection of (g, p) onto 0 .. 511, linear over
+// GF(2): slot(g, p ^ q) = slot(g, p) ^ slot(0, q)).  The gather is written in layout D' (ds_write_b64: a wave's lanes are served in four
+// groups of 16 on 32 banks; a group's lanes differ in the pair bits above the register's three) and read at the pairs 2v, 2v + P/2,
+// P/2 - 1 - 2v, P - 1 - 2v, v = bit-reversed m' (ds_read_b64: two groups of 32 lanes on 64 banks).  In the plain order slot = P g + p
+// a group's writes fall on two to four bank pairs (8-way conflicts) and its reads on half of the banks (2- to 4-way): 36-49 % of
+// the block kernel's LDS cycles were bank conflicts (profiles/r03_pmc_mixed.json).  These maps put the bits that vary inside a
+// write group into the slot's low four bits and those that vary inside a read group into its low five, xor-ing in the bits
+// the other access holds fixed: no conflict on either side (tests/test_short_model.py simulates the banks).
+template <int L>
+__host__ __device__ constexpr uint32_t blk_slot(uint32_t g, uint32_t p)
+{
+#define LW_PB(k) ((p >> (k)) & 1u)
+	return L == 8 ? (LW_PB(3) | (g & 1u) << 1 | (LW_PB(4) ^ LW_PB(1)) << 2 | (LW_PB(5) ^ LW_PB(2)) << 3 | ((g >> 1) & 1u) << 4 | LW_PB(1) << 5 |
+	                 LW_PB(2) << 6 | LW_PB(0) << 7 | ((g >> 2) & 1u) << 8)
+	     : L == 16 ? (LW_PB(3) | LW_PB(4) << 1 | (LW_PB(5) ^ LW_PB(1)) << 2 | (LW_PB(6) ^ LW_PB(2)) << 3 | (g & 1u) << 4 | LW_PB(1) << 5 |
+	                  LW_PB(2) << 6 | LW_PB(0) << 7 | ((g >> 1) & 1u) << 8)
+	               : (LW_PB(3) | LW_PB(4) << 1 | LW_PB(5) << 2 | (LW_PB(1) ^ LW_PB(7)) << 3 | LW_PB(2) << 4 | LW_PB(0) << 5 | LW_PB(6) << 6 |
+	                  LW_PB(7) << 7 | (g & 1u) << 8);
+#undef LW_PB
+}
+
 // the transform of one channel of the wave's blocks: spectrum r (load layout) -> R[c2][k] = (pa, pb) at
 // q = 8L-1 - 2m', 8L-2 - 2m', 1 + 2m', 2m' for m' = 2 l + c2 (imdct.rs:291-659)
 template <int L>
@@ -1577,17 +1598,21 @@ __device__ __forceinline__ void short_imdct(const char *img, char *scr, uint32_t
 		hi = ((l >> 2) & 1u) << 3 | ((l >> 1) & 1u) << 2 | ((l >> 3) & 1u) << 1 | (l & 1u); // (p6, p5, p4, p3) = lane bits (2, 1, 3, 0)
 	else
 		hi = ((l >> 2) & 1u) << 4 | ((l >> 4) & 1u) << 3 | ((l >> 3) & 1u) << 2 | ((l >> 1) & 1u) << 1 | (l & 1u); // (p7 .. p3) = lane bits (2, 4, 3, 1, 0)
-	char *blk = scr + 8u * P * g;
+	// (slots through blk_slot: the pair index is lane bits xor constants, and the map is linear, so every address is one of two lane
+	// terms xor a compile-time constant)
+	const uint32_t wbase = 8u * blk_slot<L>(g, 8u * hi);
 #pragma unroll
 	for (int zz = 0; zz < 8; zz++)
-		*reinterpret_cast<float2_t *>(blk + 8u * (8u * hi + zz)) = Q[zz];
+		*reinterpret_cast<float2_t *>(scr + (wbase ^ (8u * blk_slot<L>(0, zz)))) = Q[zz];
 	lds_fence();
 	constexpr int VB = (L == 8 ? 4 : L == 16 ? 5 : 6); // bits of m' = 2 l + c2
+	const uint32_t rbase = 8u * blk_slot<L>(g, 2u * (__builtin_bitreverse32(2u * l) >> (32 - VB))); // pair 2v of c2 = 0
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) { // bit-reverse gather (imdct.rs:490-528), step 7 (:533-580), step 8 (:589-658)
-		const uint32_t v = __builtin_bitreverse32(2u * l + c2) >> (32 - VB);
-		const float2_t pq = lds2(blk, 8u * (2u * v)), pqh = lds2(blk, 8u * (2u * v + P / 2));
-		const float2_t ph = lds2(blk, 8u * (P / 2 - 1u - 2u * v)), pf = lds2(blk, 8u * (P - 1u - 2u * v));
+		// v = rev(2 l + c2) = rev(2 l) ^ c2 << (VB - 1); the pairs 2v, 2v + P/2, P/2 - 1 - 2v, P - 1 - 2v = 2v ^ 0, P/2, P/2 - 1, P - 1
+		const uint32_t kc = (uint32_t)c2 << VB;
+		const float2_t pq = lds2(scr, rbase ^ (8u * blk_slot<L>(0, kc))), pqh = lds2(scr, rbase ^ (8u * blk_slot<L>(0, kc ^ (P / 2))));
+		const float2_t ph = lds2(scr, rbase ^ (8u * blk_slot<L>(0, kc ^ (P / 2 - 1u)))), pf = lds2(scr, rbase ^ (8u * blk_slot<L>(0, kc ^ (P - 1u))));
 		const float4_t Cq = lds4(img + Y::C4, 16u * (L * c2 + l));
 		const float4_t Bl = lds4(img + Y::B_LO, 16u * (L * c2 + l)), Bh = lds4(img + Y::B_HI, 16u * (L * c2 + l));
 		step78_block(pf, pq, ph, pqh, Cq, Bl, Bh, R[c2]);

@@ -66,6 +66,58 @@ def xchg(Q, regbit, lanebit):
     return out
 
 
+def blk_slot(L, g, p):
+    """8-byte slot of pair p of block g in a wave's bit-reverse gather area (blk_slot<L> in lw_kernels_long.hip): a bijection of
+    (g, p) onto 0 .. 511, linear over GF(2), free of bank conflicts for the kernel's writes and reads (gather_bank_cycles)"""
+    pb = lambda k: (p >> k) & 1
+    gb = lambda k: (g >> k) & 1
+    if L == 8:
+        return pb(3) | gb(0) << 1 | (pb(4) ^ pb(1)) << 2 | (pb(5) ^ pb(2)) << 3 | gb(1) << 4 | pb(1) << 5 | pb(2) << 6 | pb(0) << 7 | gb(2) << 8
+    if L == 16:
+        return pb(3) | pb(4) << 1 | (pb(5) ^ pb(1)) << 2 | (pb(6) ^ pb(2)) << 3 | gb(0) << 4 | pb(1) << 5 | pb(2) << 6 | pb(0) << 7 | gb(1) << 8
+    return pb(3) | pb(4) << 1 | pb(5) << 2 | (pb(1) ^ pb(7)) << 3 | pb(2) << 4 | pb(0) << 5 | pb(6) << 6 | pb(7) << 7 | gb(0) << 8
+
+
+def lane_hi(L, l):
+    """pair bits above the register's three held by lane l of a block in layout D'"""
+    b = lambda k: (l >> k) & 1
+    if L == 8:
+        return l
+    if L == 16:
+        return b(2) << 3 | b(1) << 2 | b(3) << 1 | b(0)
+    return b(2) << 4 | b(4) << 3 | b(3) << 2 | b(1) << 1 | b(0)
+
+
+def gather_bank_cycles(L, slot=None):
+    """LDS-array cycles of the gather's 8 ds_write_b64 and 8 ds_read_b64 of one wave under MI355X's banking rules
+    (MI355X_MICROARCH.md: ds_write_b64 is served in four groups of 16 contiguous lanes on 32 banks of 4 bytes, ds_read_b64 in two
+    groups of 32 lanes on 64 banks; a group costs as many cycles as its busiest bank has distinct dwords).  Conflict-free: (32, 16)."""
+    slot = slot or (lambda g, p: blk_slot(L, g, p))
+    P, vb = 8 * L, {8: 4, 16: 5, 32: 6}[L]
+
+    def cycles(addrs, group, banks):
+        tot = 0
+        for g0 in range(0, 64, group):
+            busy = {}
+            for lane in range(g0, g0 + group):
+                for d in range(2):
+                    a = addrs[lane] + 4 * d
+                    busy.setdefault((a // 4) % banks, set()).add(a // 4)
+            tot += max(len(v) for v in busy.values())
+        return tot
+
+    w = sum(cycles([8 * slot(lane // L, 8 * lane_hi(L, lane % L) + zz) for lane in range(64)], 16, 32) for zz in range(8))
+    r = 0
+    for c in range(2):
+        for kind in range(4):
+            addrs = []
+            for lane in range(64):
+                q = 2 * int(rev_bits(np.array([2 * (lane % L) + c]), vb)[0])
+                addrs.append(8 * slot(lane // L, [q, q + P // 2, P // 2 - 1 - q, P - 1 - q][kind]))
+            r += cycles(addrs, 32, 64)
+    return w, r
+
+
 def imdct_wave(X, img, prev_pb=None):
     """X: [64 / L][16 L] spectra (one channel of the wave's blocks).  Returns the [64 / L][32 L] time-domain blocks; with prev_pb
     ([64 / L][8 L]: right part pb(q) of each block's predecessor) also the overlap-added samples (audio.rs:1116-1118) and pb."""
@@ -124,11 +176,19 @@ def imdct_wave(X, img, prev_pb=None):
         hi = b(2) << 3 | b(1) << 2 | b(3) << 1 | b(0)
     else:
         hi = b(2) << 4 | b(4) << 3 | b(3) << 2 | b(1) << 1 | b(0)
-    # ---- bit-reverse gather through LDS
-    lds = np.zeros((S * P, 2), F)
+    # ---- bit-reverse gather through LDS (the wave's 512 pairs in blk_slot order; the reads below go through the same map)
+    assert hi.tolist() == [lane_hi(L, int(l)) for l in Ln]
+    slot_of = np.array([[blk_slot(L, g, p) for p in range(P)] for g in range(S)])
+    assert sorted(slot_of.reshape(-1).tolist()) == list(range(S * P))
+    lds_raw = np.zeros((S * P, 2), F)
     for zz in range(8):
-        lds[P * G + 8 * hi + zz] = Z[zz].T
-    assert len(set((P * G + 8 * hi).tolist())) == 64
+        lds_raw[slot_of[G, 8 * hi + zz]] = Z[zz].T
+
+    class _View:          # lds[P * g + p] = pair p of block g
+        def __getitem__(self, idx):
+            idx = np.asarray(idx)
+            return lds_raw[slot_of[idx // P, idx % P]]
+    lds = _View()
     pa = np.zeros((S, N4), F)
     pb = np.zeros((S, N4), F)
     out_ola = np.zeros((S, N2), F)

@@ -115,3 +115,17 @@ def test_floor_curve_model_equals_render_line(case):
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, c)
                 n += 1
     assert n >= 24
+
+
+@pytest.mark.parametrize("L", [8, 16, 32])
+def test_gather_slots_are_free_of_bank_conflicts(L):
+    """the bit-reverse gather of the block kernels (k_short<L>, and k_long10 with L = 32 per half-wave): in the plain order a wave's
+    writes are 8-way and its reads 2- to 4-way bank-conflicted; blk_slot's order costs the conflict-free minimum on both sides"""
+    plain = sm.gather_bank_cycles(L, lambda g, p: 8 * L * g + p)
+    assert plain[0] == 256 and plain[1] >= 32, plain
+    assert sm.gather_bank_cycles(L) == (32, 16)
+    # linear over GF(2) (the kernel forms every address as a lane term xor a compile-time constant)
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        g, p, q = int(rng.integers(0, 64 // L)), int(rng.integers(0, 8 * L)), int(rng.integers(0, 8 * L))
+        assert sm.blk_slot(L, g, p ^ q) == sm.blk_slot(L, g, p) ^ sm.blk_slot(L, 0, q)

@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--big", action="store_true", help="streams with 4096 / 8192-point long blocks (k_big) instead of the 2048-point ones")
+ap.add_argument("--mid", action="store_true", help="streams with 1024- / 512-point long blocks (k_long10 incl. its EDGE form, k_short<16 / 32>)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 SETUPS = {"stereo": lambda: sg.stereo_setup(44100, 8, 11), "stereo_t1": lambda: sg.stereo_setup(44100, 8, 11, residue_type=1),
@@ -31,6 +32,20 @@ if args.big:
     SETUPS = {"stereo_9_12": lambda: sg.stereo_setup(44100, 9, 12), "stereo_6_13_t1": lambda: sg.stereo_setup(44100, 6, 13, residue_type=1),
               "surround51_9_12": lambda: sg.surround51_setup(48000, 9, 12), "mono_7_12": lambda: sg.mono_setup(7, 12, 44100),
               "stereo_10_12": lambda: sg.stereo_setup(44100, 10, 12), "stereo_8_13": lambda: sg.stereo_setup(44100, 8, 13)}
+if args.mid:
+    def _s51():
+        st = sg.surround51_setup(48000, 8, 10)
+        st.floors[3].x_rest = [64, 16, 256, 128, 32, 384]   # (the generator's LFE floor repeats the implied end post at x = 512 for bs 10)
+        return st
+
+    def _unc():
+        st = sg.stereo_setup(22050, 8, 10, residue_type=1)
+        for m in st.mappings:
+            m.coupling = []
+        return st
+    SETUPS = {"stereo_9_10": lambda: sg.stereo_setup(22050, 9, 10), "stereo_8_10_t1": lambda: sg.stereo_setup(22050, 8, 10, residue_type=1),
+              "surround51_8_10": _s51, "mono_7_10": lambda: sg.mono_setup(7, 10, 16000), "uncoupled_8_10": _unc,
+              "stereo_8_9": lambda: sg.stereo_setup(11025, 8, 9)}
 FMTS = ["i16", "f32", "i16_interleaved"]
 OFMT = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}
 made = {}
