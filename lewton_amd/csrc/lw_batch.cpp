@@ -372,6 +372,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	// blocksize_1 = 10: the class-1 blocks go to k_long10 on k_long's work list (below) instead of k_short<32>'s slots
 	b->use_l10 = blk_ok[1] && d->blkp[1].lanes == 32 && b->l10_mode != 0 && !d->fast.eligible &&
 		d->blkp[1].units.size() <= LW_FAST_WAVES;
+	// blocksize_1 = 12: likewise to k_long12 (one wave per channel: the split units) instead of k_big<12>
+	b->use_l12 = blk_ok[1] && d->blkp[1].lanes == 128 && !d->blkp[1].units_split.empty() && !d->blkp[1].image.empty() &&
+		b->l10_mode != 0 && !d->fast.eligible;
 	// short blocks of 256 points next to k_long, of 256 / 512 points next to k_long10: long blocks with short slopes stay in the
 	// long-block kernel's EDGE form (lw_fast.hpp)
 	const bool short_ok10 = b->use_l10 && b->l10_mode != 1 && blk_ok[0] && (d->blkp[0].bs == 8 || d->blkp[0].bs == 9);
@@ -509,7 +512,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
 				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
 		}
-	if (b->use_l10) { // (k_long10: its packets on the specialised kernel's lists from here on)
+	if (b->use_l10 || b->use_l12) { // (k_long10 / k_long12: their packets on the specialised kernel's lists from here on)
 		b->fast_idx.swap(b->blk_idx[1]);
 		b->fast_slot.swap(b->blk_slot[1]);
 		b->blk_idx[1].clear();
@@ -526,7 +529,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		for (size_t i = 0; i < n; i++)
 			if (!(b->h_recs[i].flags & LW_RF_SKIP) && b->h_recs[i].prev >= 0)
 				b->succ[b->h_recs[i].prev] = (int32_t)i;
-		const bool klong = d->fast.eligible || b->use_l10;
+		const bool klong = d->fast.eligible || b->use_l10 || b->use_l12;
 		// a packet of k_long / a block of k_short<L> of class `cls`
 		auto is_long_fast = [&](const LwPacketRec &r) {
 			return klong && (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == (LW_RF_FAST | LW_RF_LONG);
@@ -541,7 +544,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		};
 		std::vector<Ev> ev;
 		for (int cls = 0; cls < 2; cls++) {
-			if (!blk_ok[cls] || (cls == 1 && b->use_l10))
+			if (!blk_ok[cls] || (cls == 1 && (b->use_l10 || b->use_l12)))
 				continue;
 			// passes per wave: more slots per recomputed predecessor -- but only while the launch keeps the waves the chip holds
 			// at a time (five per CU: LDS) (a wave's passes run one after the other: 4096 blocks of 1024 points in 820 waves of 3
@@ -753,7 +756,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		if (!std::is_sorted(b->fast_slot.begin(), b->fast_slot.end())) // (callers usually list their streams one after the other)
 			std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
 					[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
-		const size_t n_fast_units = b->use_l10 ? d->blkp[1].units.size() : d->fast.units.size();
+		const size_t n_fast_units = b->use_l10 ? d->blkp[1].units.size() : b->use_l12 ? d->blkp[1].units_split.size() : d->fast.units.size();
 		uint32_t per_round = LW_FAST_WAVES / (uint32_t)n_fast_units;
 		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
@@ -771,7 +774,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		}
 		// a sparse launch (one round, at most half of a workgroup's waves in use) lasts as long as ONE wave's dependent chain:
 		// split every channel pair over two waves (LW_UNIT_SPLIT_*) -- each half does one channel's floor, transform and samples
-		b->fast_split = !b->use_l10 && !b->forced_rounds && !b->has_tdonly && rounds == 1 && d->fast.units_split.size() > d->fast.units.size() &&
+		b->fast_split = !b->use_l10 && !b->use_l12 && !b->forced_rounds && !b->has_tdonly && rounds == 1 && d->fast.units_split.size() > d->fast.units.size() &&
 			per_round * d->fast.units_split.size() <= LW_FAST_WAVES;
 		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
@@ -928,7 +931,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 			b->d_halo = nullptr;
 		}
 		const size_t cap = std::max<size_t>(b->n_halo_items, 64);
-		HIP_TRY(hipMalloc((void **)&b->d_halo, cap * d->T.ch * 512 * sizeof(float)));
+		HIP_TRY(hipMalloc((void **)&b->d_halo, cap * d->T.ch * std::max<size_t>(512, d->T.state_chan_stride / 2) * sizeof(float))); // [slots][ch][n1 / 4]
 		b->halo_cap = cap;
 	}
 	LwBatchDev B{};
@@ -967,9 +970,11 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.n_items = (uint32_t)b->n_items;
 		L.d_halo_items = b->d_halo_items;
 		L.n_halo_items = (uint32_t)b->n_halo_items;
-		const std::vector<LwFastUnit> &units = b->use_l10 ? d->blkp[1].units : b->fast_split ? d->fast.units_split : d->fast.units;
-		if (b->use_l10)
+		const std::vector<LwFastUnit> &units = b->use_l10 ? d->blkp[1].units : b->use_l12 ? d->blkp[1].units_split
+			: b->fast_split ? d->fast.units_split : d->fast.units;
+		if (b->use_l10 || b->use_l12)
 			L.d_image = d->d_blk_image[1];
+		L.d_sid12 = d->d_l12_sid;
 		L.n_units = (uint32_t)units.size();
 		L.per_round = b->fast_per_round;
 		L.rounds = b->fast_rounds;
@@ -1002,7 +1007,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	};
 	// a mixed short / long batch small enough for the chip to hold at once: both kernels' work in ONE launch (k_mix)
 	bool mixed = false;
-	if (run_fast && !b->use_l10 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
+	if (run_fast && !b->use_l10 && !b->use_l12 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
 		const LwShortLaunch S = short_launch(0);
 		if (lw_mix_applicable(L, S, d->n_cus)) {
 			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * lw_edge_values(d));
@@ -1014,6 +1019,9 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	if (run_fast && b->use_l10) {
 		HIP_TRY(lw_launch_long10(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long10<halo>,k_long10," : "k_long10,";
+	} else if (run_fast && b->use_l12) {
+		HIP_TRY(lw_launch_long12(d->T, B, L, d_out, b->fmt, st));
+		b->last_kernels += b->n_halo_items ? "k_long12<halo>,k_long12," : "k_long12,";
 	} else if (run_fast && !mixed) {
 		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";

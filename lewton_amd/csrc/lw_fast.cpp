@@ -354,6 +354,104 @@ void fill_blk_image(const BlocksizeTables &t, const Setup &s, const std::vector<
 }
 } // namespace
 
+namespace {
+// one channel per wave: every channel pair of `units` as two LW_UNIT_SPLIT_* halves (see build_fast_plan)
+void split_units(const std::vector<LwFastUnit> &units, std::vector<LwFastUnit> &out)
+{
+	out.clear();
+	for (const LwFastUnit &u : units) {
+		if (u.ch_b < 0) {
+			out.push_back(u);
+			continue;
+		}
+		LwFastUnit a = u, b = u;
+		a.coupled = u.coupled ? LW_UNIT_SPLIT_MAG : 0; // ch_a stays; ch_b only as the partner of the coupling step
+		if (!u.coupled)
+			a.ch_b = -1;
+		b.ch_a = u.ch_b;
+		b.ch_b = u.coupled ? u.ch_a : (int8_t)-1;
+		b.coupled = u.coupled ? LW_UNIT_SPLIT_ANG : 0;
+		b.floor_a = u.floor_b;
+		b.F_a = u.F_b;
+		b.floor_b = u.floor_a;
+		b.F_b = u.F_a;
+		out.push_back(a);
+		out.push_back(b);
+	}
+}
+
+// the LDS image and the HBM interval table of k_long12 (LwL12Layout)
+void fill_l12_image(const BlocksizeTables &t, const Setup &s, const std::vector<int> &floor_slot, std::vector<uint8_t> &image,
+		std::vector<uint8_t> &sid)
+{
+	typedef LwL12Layout Y;
+	const uint32_t n = 4096, n2 = n / 2, n8 = n / 8;
+	const float *A = t.A.data(), *B = t.B.data(), *C = t.C.data(), *W = t.window.data();
+	image.assign(Y::TOTAL, 0);
+	sid.assign(Y::SID_BYTES, 0);
+	auto f = [&](uint32_t off) { return reinterpret_cast<float *>(image.data() + off); };
+	auto put = [&](uint32_t off, uint32_t idx, uint32_t a) { // float2 number idx of a table <- (A[a], A[a + 1])
+		f(off)[2 * idx] = A[a];
+		f(off)[2 * idx + 1] = A[a + 1];
+	};
+	for (uint32_t x = 0; x < 8; x++)
+		for (uint32_t l = 0; l < 64; l++)
+			put(Y::TW_S2, 64 * x + l, n2 - 4 - 4 * (64 * x + l)); // imdct.rs:385-430
+	// stages l (imdct.rs:445-477): twiddle A[(8 << l) r], r = the complement of the pair bits below the butterfly's bit
+	for (uint32_t y = 0; y < 4; y++)
+		for (uint32_t l = 0; l < 64; l++)
+			put(Y::TW_L0, 64 * y + l, 8 * (255 - (64 * y + l)));
+	for (uint32_t b = 0; b < 2; b++)
+		for (uint32_t l = 0; l < 64; l++)
+			put(Y::TW_L1, 64 * b + l, 16 * (127 - (64 * b + l)));
+	for (uint32_t l = 0; l < 64; l++)
+		put(Y::TW_L2, l, 32 * (63 - l));
+	for (uint32_t yy = 0; yy < 4; yy++)
+		for (uint32_t lo3 = 0; lo3 < 8; lo3++)
+			put(Y::TW_L3, 8 * yy + lo3, 64 * (31 - (8 * yy + lo3)));
+	for (uint32_t b = 0; b < 2; b++)
+		for (uint32_t lo3 = 0; lo3 < 8; lo3++)
+			put(Y::TW_L4, 8 * b + lo3, 128 * (15 - (8 * b + lo3)));
+	for (uint32_t lo3 = 0; lo3 < 8; lo3++)
+		put(Y::TW_L5, lo3, 256 * (7 - lo3));
+	f(Y::A2)[0] = A[n8];
+	for (uint32_t k4 = 0; k4 < 4; k4++)
+		for (uint32_t l = 0; l < 64; l++) {
+			const uint32_t mp = 128 * (k4 >> 1) + 2 * l + (k4 & 1), e = 64 * k4 + l;
+			for (uint32_t j = 0; j < 4; j++) {
+				f(Y::C4)[4 * e + j] = C[4 * mp + j];
+				f(Y::B_LO)[4 * e + j] = B[4 * mp + j];
+				f(Y::B_HI)[4 * e + j] = B[4 * (511 - mp) + j];
+			}
+			const uint32_t q[4] = {1023 - 2 * mp, 1022 - 2 * mp, 1 + 2 * mp, 2 * mp};
+			for (uint32_t k = 0; k < 4; k++) {
+				f(Y::WIN)[8 * e + 2 * k] = W[q[k]];
+				f(Y::WIN)[8 * e + 2 * k + 1] = W[n2 - 1 - q[k]];
+			}
+		}
+	// (INV_DB is filled by the runtime: it owns the spec table)
+	uint16_t *h = reinterpret_cast<uint16_t *>(sid.data());
+	for (size_t fl = 0; fl < s.floors.size(); fl++) {
+		const int slot = floor_slot[fl];
+		if (slot < 0)
+			continue;
+		const Floor1 &f1 = s.floors[fl].f1;
+		const size_t F = f1.sorted_x.size();
+		for (size_t i = 0; i < 64; i++)
+			f(Y::XSF)[64 * slot + i] = i < F ? (float)f1.sorted_x[i] : std::numeric_limits<float>::infinity();
+		for (uint32_t x = 0; x < 8; x++)
+			for (uint32_t l = 0; l < 64; l++)
+				for (uint32_t j = 0; j < 4; j++) {
+					const uint32_t k = 4 * (64 * x + l) + j;
+					size_t sidx = 0; // largest s with xs[s] <= k (xs[0] = 0)
+					while (sidx + 1 < F && f1.sorted_x[sidx + 1] <= k)
+						sidx++;
+					h[((slot * 8 + x) * 64 + l) * 4 + j] = (uint16_t)(16 * sidx);
+				}
+	}
+}
+} // namespace
+
 void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFastPlan &fast, LwShortPlan &plan)
 {
 	plan = LwShortPlan();
@@ -386,7 +484,17 @@ void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFas
 	plan.units = up.units;
 	plan.n_staged_floors = up.n_staged;
 	std::memcpy(plan.staged_floor_F, up.staged_F, sizeof(plan.staged_floor_F));
-	if (big) { // (no LDS image: the tables of the block size stay in HBM / L2)
+	if (big) { // (k_big: no LDS image, the tables of the block size stay in HBM / L2)
+		if (bs == 12) { // k_long12: a floor's posts are lanes of ONE wave (at most 64), one channel per wave
+			bool posts_ok = true;
+			for (uint32_t i = 0; i < up.n_staged; i++)
+				posts_ok = posts_ok && up.staged_F[i] <= 64;
+			split_units(up.units, plan.units_split);
+			if (posts_ok && plan.units_split.size() <= LW_FAST_WAVES)
+				fill_l12_image(id.tab[1], s, up.floor_slot, plan.image, plan.sid12);
+			else
+				plan.units_split.clear();
+		}
 		plan.eligible = true;
 		return;
 	}

@@ -125,6 +125,7 @@ struct LwFastLaunch {
 	uint32_t edge_mode;  // the stream's short blocks run through k_short: EDGE instantiation, d_edge valid
 	float *d_edge;       // [packet][side][ch][edge_n]
 	uint32_t edge_n;     // values per raw edge = blocksize_0 / 4 (LW_EDGE_VALUES next to k_long)
+	const uint16_t *d_sid12; // k_long12: static interval table of the staged floors (HBM)
 	LwFastUnit units[LW_FAST_WAVES];
 	float *d_halo;
 };
@@ -170,6 +171,35 @@ struct LwBlkLayout {
 	static constexpr uint32_t TOTAL = (END + 1023u) & ~1023u; // whole 1 KB rows: 64 lanes x 16 bytes per staging step
 };
 
+// ---------------------------------------------------------------------------------------------
+// k_long12 (lw_long12.inc): k_long's design for blocksize_1 = 12 (n = 4096): one wave per CHANNEL of a packet, 16 complex pairs per
+// lane.  After step 1 and step 2 (pair bit 9) the 1024 pairs of a channel are two independent 512-pair problems (p9 = 0 / 1) that go
+// through k_long's register layouts B -> C -> D with one more stage in front (l = 0 .. 2 in layout B, l = 3 .. 5 in layout C, the fused
+// last three in layout D) and meet again in the bit-reverse gather (8 KB of LDS per wave); a lane then finishes m' = 128 h + 2 lane + c2
+// for (h, c2) = k4 = 2 h + c2 in 0 .. 3.  LDS image (byte offsets, all 16-byte aligned; the step-1 twiddles come from the A table in
+// HBM / L2 and the static interval indices of the floor from `sid12`, both read once per wave):
+// ---------------------------------------------------------------------------------------------
+struct LwL12Layout {
+	static constexpr uint32_t TW_S2 = 0;        // float2[8][64]   step 2 twiddle of lower pair p = 64 x + lane: A[n/2 - 4 - 4p ..]
+	static constexpr uint32_t TW_L0 = 4096;     // float2[4][64]   stage l = 0: A[8 r ..],   r = 255 - (64 y + lane)
+	static constexpr uint32_t TW_L1 = 6144;     // float2[2][64]   stage l = 1: A[16 r ..],  r = 127 - (64 b + lane)
+	static constexpr uint32_t TW_L2 = 7168;     // float2[64]      stage l = 2: A[32 r ..],  r = 63 - lane
+	static constexpr uint32_t TW_L3 = 7680;     // float2[4][8]    stage l = 3: A[64 r ..],  r = 31 - (8 yy + lo3)
+	static constexpr uint32_t TW_L4 = 7936;     // float2[2][8]    stage l = 4: A[128 r ..], r = 15 - (8 b + lo3)
+	static constexpr uint32_t TW_L5 = 8064;     // float2[8]       stage l = 5: A[256 r ..], r = 7 - lo3
+	static constexpr uint32_t A2 = 8128;        // float           A[n/8]
+	static constexpr uint32_t C4 = 8144;        // float4[4][64]   C[4m' .. 4m'+3], m' = 128 h + 2 lane + c2 at [2 h + c2][lane]
+	static constexpr uint32_t B_LO = 12240;     // float4[4][64]   B[4m' .. 4m'+3]
+	static constexpr uint32_t B_HI = 16336;     // float4[4][64]   B[4(511 - m') .. +3]
+	static constexpr uint32_t WIN = 20432;      // float[4][64][8] window slope pairs (s[q], s[2047 - q]) for q = 1023-2m', 1022-2m', 1+2m', 2m'
+	static constexpr uint32_t INV_DB = 28624;   // float[256]
+	static constexpr uint32_t XSF = 29648;      // float[LW_FAST_MAX_FLOORS][64]  ascending post x of each staged floor (padded with +inf)
+	static constexpr uint32_t END = 30160;
+	static constexpr uint32_t TOTAL = 30208;    // whole 16-byte rows
+	// sid12 (HBM): u16[LW_FAST_MAX_FLOORS][8][64][4]  16 * (static interval index) of bin 4 (64 x + lane) + j
+	static constexpr uint32_t SID_BYTES = LW_FAST_MAX_FLOORS * 8u * 64u * 4u * 2u;
+};
+
 struct LwShortPlan {
 	bool eligible = false;
 	const char *why_not = "";
@@ -183,6 +213,10 @@ struct LwShortPlan {
 	uint32_t n_staged_floors = 0;
 	uint8_t staged_floor_F[LW_FAST_MAX_FLOORS] = {0};
 	uint32_t fl_of[LW_FAST_MAX_FLOORS] = {0}; // floor index (header order) of each staged floor slot (k_big reads the posts' x from T.floor_x)
+	// blocksize 12 (k_long12): its LDS image (LwL12Layout; goes where the other block sizes' image does), the static interval table
+	// kept in HBM, and the units with every channel pair split over two waves (LW_UNIT_SPLIT_*)
+	std::vector<uint8_t> sid12;
+	std::vector<LwFastUnit> units_split;
 };
 
 // what a slot of k_short is
@@ -241,7 +275,7 @@ struct LwShortLaunch {
 
 static inline uint32_t lw_blk_inv_db_offset(uint32_t lanes)
 {
-	return lanes == 8 ? LwBlkLayout<8>::INV_DB : lanes == 16 ? LwBlkLayout<16>::INV_DB : LwBlkLayout<32>::INV_DB;
+	return lanes == 8 ? LwBlkLayout<8>::INV_DB : lanes == 16 ? LwBlkLayout<16>::INV_DB : lanes == 128 ? LwL12Layout::INV_DB : LwBlkLayout<32>::INV_DB;
 }
 
 namespace lw {

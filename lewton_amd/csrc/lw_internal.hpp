@@ -63,6 +63,7 @@ struct lw_decoder {
 	LwFastUnit *d_fast_units = nullptr;
 	LwShortPlan blkp[2];           // block kernel k_short<L>: [0] the short blocks, [1] the long blocks where k_long does not apply
 	uint8_t *d_blk_image[2] = {nullptr, nullptr};
+	uint16_t *d_l12_sid = nullptr; // k_long12: the static interval table of its floors (LwL12Layout::SID_BYTES, HBM)
 	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
 	void *one_out = nullptr; // pinned host output for the single-packet path
 	size_t one_out_bytes = 0;
@@ -128,6 +129,7 @@ struct lw_batch {
 	// blocksize_1 = 10: the long blocks with two long slopes (block class 1, 32 lanes per block) run through k_long10 -- k_long's
 	// work list, units and launch shape on the block kernel's table image -- instead of k_short<32>
 	bool use_l10 = false;
+	bool use_l12 = false;    // blocksize_1 = 12: the same for k_long12 (one wave per channel) instead of k_big<12>; l10_mode 0 switches it off too
 	int l10_mode = -1;       // lw_debug_batch_set_long10: -1 = k_long10 where it applies (long blocks next to short ones in its EDGE
 	                         // form when the short blocks run through k_short), 1 = k_long10 without the EDGE form (those blocks through
 	                         // the generic kernels), 0 = never (k_short<32>)

@@ -114,6 +114,8 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 // The same design for blocksize_1 = 10 (k_long10, lw_long10.inc): L.d_image = the block kernel's image for 32 lanes per block
 // (LwBlkLayout<32>), the work list and the halo pre-pass as for k_long with 512-value residue vectors.
 hipError_t lw_launch_long10(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
+// ... and for blocksize_1 = 12 (k_long12, lw_long12.inc): one wave per channel (L.units = the split units), L.d_image = LwL12Layout
+hipError_t lw_launch_long12(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
 // Short blocks of such streams (k_short, same translation unit); runs after lw_launch_long (it reads the edge buffer).
 struct LwShortLaunch;
 hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st);

@@ -70,6 +70,8 @@ struct LwFastArgs {
 	void *out;
 	uint32_t state_stride, state_chan_stride;
 	uint32_t edge_n;           // k_long10<EDGE>: values per raw edge = blocksize_0 / 4 (k_long: always LW_EDGE_VALUES)
+	const float *tabA;         // k_long12: the block size's A table (header_cached.rs:64-99) in HBM, read as pairs by step 1
+	const uint16_t *sid12;     // k_long12: static interval indices of the staged floors (LwL12Layout)
 };
 static_assert(offsetof(LwFastArgs, waves) == 48, "kernel reads waves[] through the kernarg segment pointer");
 
@@ -2055,3 +2057,8 @@ hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFast
 // k_long10: this file's design for blocksize_1 = 10 (n = 1024)
 // ---------------------------------------------------------------------------------------------
 #include "lw_long10.inc"
+
+// ---------------------------------------------------------------------------------------------
+// k_long12: this file's design for blocksize_1 = 12 (n = 4096), one wave per channel
+// ---------------------------------------------------------------------------------------------
+#include "lw_long12.inc"

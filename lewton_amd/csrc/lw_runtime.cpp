@@ -544,6 +544,13 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			lw_decoder_destroy(d.release());
 			return nullptr;
 		}
+		if (!bp.sid12.empty() && (!lw_hip_ok(hipMalloc((void **)&d->d_l12_sid, bp.sid12.size()), "hipMalloc(k_long12 interval table)") ||
+					!lw_hip_ok(hipMemcpy(d->d_l12_sid, bp.sid12.data(), bp.sid12.size(), hipMemcpyHostToDevice),
+						"hipMemcpy(k_long12 interval table)"))) {
+			*err = LW_ERR_DEVICE;
+			lw_decoder_destroy(d.release());
+			return nullptr;
+		}
 	}
 	return d.release();
 }
@@ -571,6 +578,8 @@ void lw_decoder_destroy(lw_decoder *d)
 	for (uint8_t *p : d->d_blk_image)
 		if (p)
 			(void)hipFree(p);
+	if (d->d_l12_sid)
+		(void)hipFree(d->d_l12_sid);
 	delete d;
 }
 

@@ -75,14 +75,15 @@ def test_uncoupled_pair_and_single_channel_units_bench_shape(key):
 def test_other_long_block_sizes_bench_shape(key):
     bad, kernels, n = _run_dense(key, packets=1024)
     assert n == 1024 and bad == 0, (bad, kernels)
-    assert kernels == ("k_long10" if key == "12" else "k_big")
+    assert kernels == {"12": "k_long10", "11": "k_long12", "13": "k_big"}[key]
 
 
 @pytest.mark.parametrize("key,fmt", [("11", "i16"), ("11", "f32"), ("13", "i16_interleaved")])
 def test_long_blocks_of_4096_and_8192_points_dense_bench_shape(key, fmt):
     """256 streams x 16 long blocks in one launch through k_big: runs of consecutive blocks per workgroup (right parts stay in
-    the threads' registers), a recomputed predecessor where a run starts inside a stream"""
-    bad, kernels, n = _run_dense(key, fmt, packets=4096)
+    the threads' registers), a recomputed predecessor where a run starts inside a stream (4096 points: the default path is
+    k_long12, tests/test_gpu_long12.py; k_big<12> stays as the independent second implementation)"""
+    bad, kernels, n = _run_dense(key, fmt, packets=4096, l10=0)
     assert n == 4096 and bad == 0, (bad, kernels)
     assert kernels == "k_big"
 
@@ -195,7 +196,10 @@ def test_block_kernel_streams_state_round_trip_and_runs(name, fmt):
         check(b1, [(s, t) for s in range(n_streams)])
     b2 = Batch(dec, n_streams * tail, fmt)
     check(b2, [(s, steps + t) for s in range(n_streams) for t in range(tail)])
-    assert ("k_big" in seen) if name in BIG else ("k_short" in seen), seen
+    if name in BIG:
+        assert ("k_big" if "13" in name else "k_long12") in seen, seen   # 8192 points: the workgroup pipeline; 4096: one wave per channel
+    else:
+        assert "k_short" in seen, seen
     if name in ("stereo_9_10", "stereo_8_10"):
         assert "k_long10" in seen, seen        # their long blocks with two long slopes (lw_long10.inc)
     for s in range(n_streams):

@@ -41,7 +41,10 @@ def test_image_eligibility_and_units():
     assert blob51 is not None and len(units51) == 3                                # two coupled pairs + one uncoupled pair
     assert _image(SETUPS["stereo"](), 1)[0] is None                                # its long blocks are k_long's
     assert _image(SETUPS["mono_small"]())[0] is None                               # 64-point blocks -> generic kernels
-    assert _image(SETUPS["stereo_9_12"](), 0)[2] == 16 and _image(SETUPS["stereo_9_12"](), 1)[0] is None   # 4096: k_big (no LDS image)
+    assert _image(SETUPS["stereo_9_12"](), 0)[2] == 16
+    b12, _, l12, _, _ = _image(SETUPS["stereo_9_12"](), 1)
+    assert l12 == 128 and len(b12) == 30208            # 4096: k_long12's image (LwL12Layout; tests/test_long12_model.py)
+    assert _image(SETUPS["stereo_6_13"](), 1)[0] is None or len(_image(SETUPS["stereo_6_13"](), 1)[0]) == 0   # 8192: k_big (no LDS image)
     assert _image(SETUPS["stereo_7_7"](), 1)[0] is None
     for name, (mk, flag, L) in CASES.items():
         blob, _, lanes, _, _ = _image(mk(), flag)
