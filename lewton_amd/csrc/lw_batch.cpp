@@ -1016,7 +1016,18 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 			mixed = true;
 		}
 	}
-	if (run_fast && b->use_l10) {
+	if (run_fast && b->use_l10 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
+		const LwShortLaunch S = short_launch(0);
+		if (lw_mix10_applicable(L, S, d->n_cus)) { // a mixed batch the chip holds at once: long and short blocks in ONE launch (k_mix10)
+			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * lw_edge_values(d));
+			HIP_TRY(lw_launch_mix10(d->T, B, L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
+			b->last_kernels += b->n_halo_items ? "k_long10<halo>,k_mix10," : "k_mix10,";
+			mixed = true;
+		}
+	}
+	if (run_fast && b->use_l10 && mixed) {
+		// (done above)
+	} else if (run_fast && b->use_l10) {
 		HIP_TRY(lw_launch_long10(d->T, B, L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long10<halo>,k_long10," : "k_long10,";
 	} else if (run_fast && b->use_l12) {

@@ -116,6 +116,11 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 hipError_t lw_launch_long10(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
 // ... and for blocksize_1 = 12 (k_long12, lw_long12.inc): one wave per channel (L.units = the split units), L.d_image = LwL12Layout
 hipError_t lw_launch_long12(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &L, void *out, int fmt, hipStream_t st);
+// k_mix10: k_long10<EDGE> and k_short<8 / 16> in one launch (arguments as lw_launch_mix)
+struct LwShortLaunch;
+bool lw_mix10_applicable(const LwFastLaunch &LL, const LwShortLaunch &LS, int n_cus);
+hipError_t lw_launch_mix10(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &LL, const LwShortLaunch &LS, uint32_t *d_flags,
+		uint32_t *d_err, uint32_t spin, bool drop_flags, void *out, int fmt, hipStream_t st);
 // Short blocks of such streams (k_short, same translation unit); runs after lw_launch_long (it reads the edge buffer).
 struct LwShortLaunch;
 hipError_t lw_launch_short(const LwDevTables &T, const LwBatchDev &B, const LwShortLaunch &L, void *out, int fmt, hipStream_t st);

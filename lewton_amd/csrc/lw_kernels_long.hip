@@ -1995,6 +1995,55 @@ bool lw_mix_applicable(const LwFastLaunch &LL, const LwShortLaunch &LS, int n_cu
 	return n_wg <= (size_t)std::max(1, n_cus) && (size_t)LS.n_tasks * LS.n_units * 2 <= n_wg * LW_MIX_SHORT_WAVES;
 }
 
+// ONE mixed grid (k_mix, k_mix10) per device at a time.  Its short blocks' waves wait for long blocks' waves of other workgroups, which
+// is safe because the whole grid is resident -- two such grids on one device (two decoders, two rings, logical shards; different
+// streams) could each hold the CUs the other one's missing workgroups are waiting for.  Every launch therefore waits for the previous
+// mixed launch of this device, whatever its stream, through one event per device.  (Not while a stream is being captured: a graph's
+// launches are ordered by the graph, and an event from outside a capture cannot be waited for inside.)
+struct LwMixOrder {
+	struct PerDev {
+		hipEvent_t done = nullptr;
+		bool recorded = false;
+	};
+	static std::mutex &mu()
+	{
+		static std::mutex m;
+		return m;
+	}
+	static PerDev *devs()
+	{
+		static PerDev d[64];
+		return d;
+	}
+	std::unique_lock<std::mutex> lock;
+	int dev = 0;
+	bool ordered = false;
+	hipError_t begin(hipStream_t st)
+	{
+		hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+		ordered = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && hipStreamIsCapturing(st, &cap) == hipSuccess &&
+			cap == hipStreamCaptureStatusNone;
+		if (!ordered)
+			return hipSuccess;
+		lock = std::unique_lock<std::mutex>(mu());
+		PerDev &pd = devs()[dev];
+		if (!pd.done && hipEventCreateWithFlags(&pd.done, hipEventDisableTiming) != hipSuccess)
+			return hipErrorOutOfMemory;
+		if (pd.recorded)
+			return hipStreamWaitEvent(st, pd.done, 0);
+		return hipSuccess;
+	}
+	hipError_t end(hipError_t e, hipStream_t st) // after the launch: its completion is what the next mixed launch of the device waits for
+	{
+		if (e == hipSuccess && ordered) {
+			PerDev &pd = devs()[dev];
+			e = hipEventRecord(pd.done, st);
+			pd.recorded = e == hipSuccess;
+		}
+		return e;
+	}
+};
+
 hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFastLaunch &LL, const LwShortLaunch &LS, uint32_t *d_flags,
 		uint32_t *d_err, uint32_t spin, bool drop_flags, void *out, int fmt, hipStream_t st)
 {
@@ -2011,41 +2060,11 @@ hipError_t lw_launch_mix(const LwDevTables &T, const LwBatchDev &B, const LwFast
 	M.spin = spin ? spin : LW_MIX_SPIN;
 	M.drop_flags = drop_flags ? 1u : 0u;
 	const size_t lds = LW_MIX_LDS_BYTES + LW_STAMP_LDS_EXTRA;
-	// ONE k_mix grid per device at a time.  Its short blocks' waves wait for long blocks' waves of other workgroups, which is safe
-	// because the whole grid is resident -- two such grids on one device (two decoders, two rings, logical shards; different
-	// streams) could each hold the CUs the other one's missing workgroups are waiting for.  Every launch therefore waits for the
-	// previous k_mix launch of this device, whatever its stream, through one event per device.  (Not while a stream is being
-	// captured: a graph's launches are ordered by the graph, and an event from outside a capture cannot be waited for inside.)
-	struct PerDev {
-		hipEvent_t done = nullptr;
-		bool recorded = false;
-	};
-	static std::mutex mix_mu;
-	static PerDev mix_dev[64];
-	int dev = 0;
-	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-	const bool ordered = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 &&
-		hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
-	std::unique_lock<std::mutex> mix_lock(mix_mu, std::defer_lock);
-	if (ordered) {
-		mix_lock.lock();
-		PerDev &pd = mix_dev[dev];
-		if (!pd.done && hipEventCreateWithFlags(&pd.done, hipEventDisableTiming) != hipSuccess)
-			return hipErrorOutOfMemory;
-		if (pd.recorded) {
-			const hipError_t we = hipStreamWaitEvent(st, pd.done, 0);
-			if (we != hipSuccess)
-				return we;
-		}
-	}
-	auto launched = [&](hipError_t e) {
-		if (e == hipSuccess && ordered) {
-			PerDev &pd = mix_dev[dev];
-			e = hipEventRecord(pd.done, st);
-			pd.recorded = e == hipSuccess;
-		}
-		return e;
-	};
+	LwMixOrder order;
+	const hipError_t oe = order.begin(st);
+	if (oe != hipSuccess)
+		return oe;
+	auto launched = [&](hipError_t e) { return order.end(e, st); };
 	if (fmt == LW_OUT_I16_PLANAR)
 		return launched(lw_launch_k(k_mix<LW_OUT_I16_PLANAR>, dim3(grid), dim3(LW_WG), lds, st, F, FS, M));
 	if (fmt == LW_OUT_I16_INTERLEAVED)

@@ -45,7 +45,7 @@ def _decoder(setup):
     return audio, audio.decoder_for(ident, st)
 
 
-def _decode(dec, audio, streams, cuts, fmt, l10=-1, rounds=0):
+def _decode(dec, audio, streams, cuts, fmt, l10=-1, rounds=0, mix=-1):
     """streams[s] = packets; cuts = batch boundaries in packets-per-stream ([0, 3, 10, ...]): every batch holds packets cuts[k] ..
     cuts[k+1] of every stream, stream-major.  Returns (per packet arrays, kernels seen, final window states)."""
     from lewton_amd.batch import Batch
@@ -56,6 +56,7 @@ def _decode(dec, audio, streams, cuts, fmt, l10=-1, rounds=0):
     cap = max(b - a for a, b in zip(cuts[:-1], cuts[1:])) * len(streams)
     bt = Batch(dec, cap, fmt)
     bt.debug_set_long10(l10)
+    bt.debug_set_mix(mix)
     if rounds:
         bt.debug_set_rounds(rounds)
     for a, b in zip(cuts[:-1], cuts[1:]):
@@ -160,7 +161,7 @@ def test_long10_mixed_short_long_streams(name, fmt, mode):
     want, wstates = _oracle(setup, streams, fmt)
     cuts = [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 33]
     got, seen, states = _decode(dec, audio, streams, cuts, fmt, l10=mode)
-    assert "k_long10" in seen and "k_short" in seen, seen
+    assert seen & {"k_long10", "k_mix10"} and seen & {"k_short", "k_mix10"}, seen   # (k_mix10: both roles in one launch where the chip holds it)
     assert any("generic" in k for k in seen) == (mode == 1), seen
     _compare(got, want, fmt, "%s mode %d" % (name, mode))
     for s in range(len(streams)):
@@ -173,3 +174,48 @@ def test_long10_dense_bench_shapes():
     for packets in (4096, 12288):
         bad, kernels, n = _run_dense("12", "i16", packets=packets)
         assert n == packets and bad == 0 and kernels == "k_long10", (bad, kernels)
+
+
+@pytest.mark.parametrize("name", ["stereo_9_10", "stereo_8_10_t1", "surround51_8_10"])
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_mix10_one_launch_equals_two_launches(name, fmt):
+    """k_mix10 (the long and the short blocks of a mixed blocksize_1 = 10 batch in ONE launch, the short blocks' waves waiting for the
+    long blocks' raw edges through flags in HBM) against the same batches as two launches (k_long10<EDGE>, k_short<8 / 16>) and
+    against the oracle: identical samples and states, also across re-planned batches of the same Batch object"""
+    setup = L10_SETUPS[name]()
+    audio, dec = _decoder(setup)
+    pats = ["LLLSSSLLLL", "LLSLLLSSLLLLL", "LSSSSSSLLL", "LLLLLLLSL", "SLSLLSSL"]
+    streams = [sg.make_stream(setup, pats[s % 5], 40, seed=4700 + s, p_floor_unused=0.05) for s in range(24)]
+    want, wstates = _oracle(setup, streams, fmt)
+    cuts = [0, 1, 14, 27, 40]
+    got1, seen1, st1 = _decode(dec, audio, streams, cuts, fmt)
+    got2, seen2, st2 = _decode(dec, audio, streams, cuts, fmt, mix=0)
+    assert "k_mix10" in seen1 and "k_mix10" not in seen2 and {"k_long10", "k_short"} <= seen2, (seen1, seen2)
+    _compare(got1, want, fmt, name + " (k_mix10)")
+    _compare(got2, want, fmt, name + " (two launches)")
+    for s in range(len(streams)):
+        assert np.array_equal(st1[s].view(np.uint32), wstates[s].view(np.uint32)) and np.array_equal(st2[s].view(np.uint32), wstates[s].view(np.uint32)), s
+
+
+def test_mix10_bench_shapes_and_error_exit():
+    """the two mixed lines of the bench (256 streams x 16 packets of LLLSSSLLLL at 512/1024 and 256/1024 points) are ONE launch each;
+    and a k_mix10 launch whose producers never signal ends in LW_ERR_DEVICE for the batch, not in samples"""
+    from lewton_amd import _native as N
+    from lewton_amd.batch import Batch
+    from test_gpu_quoted_shapes import _run_dense
+    for key in ("14", "15"):
+        bad, kernels, n = _run_dense(key, "i16", packets=4096)
+        assert n == 4096 and bad == 0 and kernels == "k_mix10", (key, bad, kernels)
+    setup = L10_SETUPS["stereo_9_10"]()
+    audio, dec = _decoder(setup)
+    streams = [sg.make_stream(setup, "LLLSSSLLLL", 20, seed=4900 + s) for s in range(16)]
+    pwrs = [audio.PreviousWindowRight() for _ in streams]
+    bt = Batch(dec, 16 * 20, "i16")
+    bt.entropy([(streams[s][t], pwrs[s]) for s in range(16) for t in range(20)], n_threads=2)
+    bt.upload()
+    bt.debug_break_mix(2000)
+    with pytest.raises(RuntimeError) as ei:
+        bt.synth_to_host()
+    assert "lw_batch_synth_to_host: %d" % N.ERR_DEVICE in str(ei.value) and "k_mix10" in bt.last_kernels
+    assert all(r[0] == N.ERR_DEVICE and r[1] == 0 for r in bt.results())
+    bt.close()
