@@ -372,12 +372,25 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	// blocksize_1 = 10: the class-1 blocks go to k_long10 on k_long's work list (below) instead of k_short<32>'s slots
 	b->use_l10 = blk_ok[1] && d->blkp[1].lanes == 32 && b->l10_mode != 0 && !d->fast.eligible &&
 		d->blkp[1].units.size() <= LW_FAST_WAVES;
+	b->l10_cls = 1;
+	if (!b->use_l10 && blk_ok[0] && d->blkp[0].lanes == 32 && id.bs0 == id.bs1 && b->l10_mode != 0 && !d->fast.eligible &&
+			d->blkp[0].units.size() <= LW_FAST_WAVES) {
+		// blocksize_0 = blocksize_1 = 10 and no mode with the block flag (what libvorbis writes for equal block sizes is ONE mode,
+		// flag 0): every block is a 1024-point block with two full slopes -- k_long10's shape, on the "short" class's units and image
+		bool any_long = false;
+		for (const lw::Mode &m : s.modes)
+			any_long = any_long || m.blockflag;
+		if (!any_long) {
+			b->use_l10 = true;
+			b->l10_cls = 0;
+		}
+	}
 	// blocksize_1 = 12: likewise to k_long12 (one wave per channel: the split units) instead of k_big<12>
 	b->use_l12 = blk_ok[1] && d->blkp[1].lanes == 128 && !d->blkp[1].units_split.empty() && !d->blkp[1].image.empty() &&
 		b->l10_mode != 0 && !d->fast.eligible;
 	// short blocks of 256 points next to k_long, of 256 / 512 points next to k_long10: long blocks with short slopes stay in the
 	// long-block kernel's EDGE form (lw_fast.hpp)
-	const bool short_ok10 = b->use_l10 && b->l10_mode != 1 && blk_ok[0] && (d->blkp[0].bs == 8 || d->blkp[0].bs == 9);
+	const bool short_ok10 = b->use_l10 && b->l10_cls == 1 && b->l10_mode != 1 && blk_ok[0] && (d->blkp[0].bs == 8 || d->blkp[0].bs == 9);
 	const bool short_ok = (d->fast.eligible && blk_ok[0] && d->blkp[0].bs == 8) || short_ok10;
 	b->edge_mode = false; // set when the batch has a long block with a short slope (an all-(1,1) batch keeps the plain k_long)
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
@@ -512,11 +525,14 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			if (!(r.flags & LW_RF_SKIP) && ola_generic && r.prev >= 0 && (b->h_recs[r.prev].flags & LW_RF_FAST))
 				b->h_recs[r.prev].flags |= LW_RF_WRITE_TD;
 		}
+	const int wave_cls = b->use_l12 ? 1 : b->l10_cls; // the block class whose packets k_long10 / k_long12 take
+	// what marks a packet of the specialised wave-pipeline kernel in rec.flags (the single-class case: its blocks carry no block flag)
+	const uint32_t fast_mark = (b->use_l10 && b->l10_cls == 0) ? (uint32_t)LW_RF_FAST : (uint32_t)(LW_RF_FAST | LW_RF_LONG);
 	if (b->use_l10 || b->use_l12) { // (k_long10 / k_long12: their packets on the specialised kernel's lists from here on)
-		b->fast_idx.swap(b->blk_idx[1]);
-		b->fast_slot.swap(b->blk_slot[1]);
-		b->blk_idx[1].clear();
-		b->blk_slot[1].clear();
+		b->fast_idx.swap(b->blk_idx[wave_cls]);
+		b->fast_slot.swap(b->blk_slot[wave_cls]);
+		b->blk_idx[wave_cls].clear();
+		b->blk_slot[wave_cls].clear();
 	}
 	// ---- slots of k_short<L> (lw_fast.hpp), per block class: the blocks sorted by stream so that consecutive blocks of a stream sit
 	// in consecutive slots of a wave and hand their right part over through LDS; a block whose predecessor of the same class is
@@ -532,7 +548,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		const bool klong = d->fast.eligible || b->use_l10 || b->use_l12;
 		// a packet of k_long / a block of k_short<L> of class `cls`
 		auto is_long_fast = [&](const LwPacketRec &r) {
-			return klong && (r.flags & (LW_RF_FAST | LW_RF_LONG | LW_RF_SKIP)) == (LW_RF_FAST | LW_RF_LONG);
+			return klong && (r.flags & (fast_mark | LW_RF_SKIP)) == fast_mark;
 		};
 		auto is_blk = [&](const LwPacketRec &r, int cls) {
 			if ((r.flags & (LW_RF_FAST | LW_RF_SKIP)) != LW_RF_FAST || is_long_fast(r))
@@ -544,7 +560,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		};
 		std::vector<Ev> ev;
 		for (int cls = 0; cls < 2; cls++) {
-			if (!blk_ok[cls] || (cls == 1 && (b->use_l10 || b->use_l12)))
+			if (!blk_ok[cls] || (cls == wave_cls && (b->use_l10 || b->use_l12)))
 				continue;
 			// passes per wave: more slots per recomputed predecessor -- but only while the launch keeps the waves the chip holds
 			// at a time (five per CU: LDS) (a wave's passes run one after the other: 4096 blocks of 1024 points in 820 waves of 3
@@ -756,7 +772,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		if (!std::is_sorted(b->fast_slot.begin(), b->fast_slot.end())) // (callers usually list their streams one after the other)
 			std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
 					[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
-		const size_t n_fast_units = b->use_l10 ? d->blkp[1].units.size() : b->use_l12 ? d->blkp[1].units_split.size() : d->fast.units.size();
+		const size_t n_fast_units = b->use_l10 ? d->blkp[b->l10_cls].units.size() : b->use_l12 ? d->blkp[1].units_split.size() : d->fast.units.size();
 		uint32_t per_round = LW_FAST_WAVES / (uint32_t)n_fast_units;
 		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
 		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
@@ -810,7 +826,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			} else if (r.prev <= -2) {
 				it.src_kind = LW_SRC_STATE;
 				it.src_arg = (uint32_t)(-(r.prev + 2));
-			} else if ((b->h_recs[r.prev].flags & (LW_RF_FAST | LW_RF_LONG)) == (LW_RF_FAST | LW_RF_LONG)) {
+			} else if ((b->h_recs[r.prev].flags & fast_mark) == fast_mark) {
 				if ((k % chunk) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev) {
 					it.src_kind = LW_SRC_LDS;
 					b->h_items[k - 1].flags |= LW_IF_NEXT_LDS;
@@ -970,10 +986,10 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		L.n_items = (uint32_t)b->n_items;
 		L.d_halo_items = b->d_halo_items;
 		L.n_halo_items = (uint32_t)b->n_halo_items;
-		const std::vector<LwFastUnit> &units = b->use_l10 ? d->blkp[1].units : b->use_l12 ? d->blkp[1].units_split
+		const std::vector<LwFastUnit> &units = b->use_l10 ? d->blkp[b->l10_cls].units : b->use_l12 ? d->blkp[1].units_split
 			: b->fast_split ? d->fast.units_split : d->fast.units;
 		if (b->use_l10 || b->use_l12)
-			L.d_image = d->d_blk_image[1];
+			L.d_image = d->d_blk_image[b->use_l12 ? 1 : b->l10_cls];
 		L.d_sid12 = d->d_l12_sid;
 		L.n_units = (uint32_t)units.size();
 		L.per_round = b->fast_per_round;

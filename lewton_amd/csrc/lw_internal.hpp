@@ -129,6 +129,8 @@ struct lw_batch {
 	// blocksize_1 = 10: the long blocks with two long slopes (block class 1, 32 lanes per block) run through k_long10 -- k_long's
 	// work list, units and launch shape on the block kernel's table image -- instead of k_short<32>
 	bool use_l10 = false;
+	int l10_cls = 1;         // the block class k_long10 serves: 1 = the long blocks; 0 = a stream whose ONLY mode is a 1024-point mode
+	                         // without the block flag (blocksize_0 = blocksize_1 = 10: libvorbis at 16 / 22 kHz, lowest quality)
 	bool use_l12 = false;    // blocksize_1 = 12: the same for k_long12 (one wave per channel) instead of k_big<12>; l10_mode 0 switches it off too
 	int l10_mode = -1;       // lw_debug_batch_set_long10: -1 = k_long10 where it applies (long blocks next to short ones in its EDGE
 	                         // form when the short blocks run through k_short), 1 = k_long10 without the EDGE form (those blocks through

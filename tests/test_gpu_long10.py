@@ -219,3 +219,24 @@ def test_mix10_bench_shapes_and_error_exit():
     assert "lw_batch_synth_to_host: %d" % N.ERR_DEVICE in str(ei.value) and "k_mix10" in bt.last_kernels
     assert all(r[0] == N.ERR_DEVICE and r[1] == 0 for r in bt.results())
     bt.close()
+
+
+@pytest.mark.parametrize("fmt", ["i16", "i16_interleaved"])
+def test_long10_single_mode_stream_with_equal_block_sizes(fmt):
+    """blocksize_0 = blocksize_1 = 10 with ONE mode (no block flag): what libvorbis writes at 16 / 22 kHz, lowest quality.  Every block is
+    a 1024-point block with two full slopes: k_long10 on the "short" class's units and image (the block kernel k_short<32> when
+    switched off)"""
+    setup = sg.stereo_setup(22050, 10, 10)
+    setup.modes = [sg.Mode(0, 0)]
+    audio, dec = _decoder(setup)
+    streams = []
+    for s in range(19):
+        pw = sg.PacketWriter(setup, 4950 + s, p_floor_unused=0.05)
+        streams.append([pw.packet(0) for _ in range(21 + s % 4)])
+    want, wstates = _oracle(setup, streams, fmt)
+    for l10, kernel in ((-1, "k_long10"), (0, "k_short")):
+        got, seen, states = _decode(dec, audio, streams, [0, 1, 2, 11, 25], fmt, l10=l10)
+        assert kernel in seen and not any("generic" in k for k in seen), (l10, seen)
+        _compare(got, want, fmt, "single mode, l10=%d" % l10)
+        for s in range(len(streams)):
+            assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
