@@ -9,7 +9,7 @@ from common import ROOT
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json", "r04_bench.json"])
+@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json", "r04_bench.json", "r05_bench.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).readline()
     d = json.loads(line)
@@ -53,6 +53,17 @@ def test_committed_bench_line_has_the_contract_fields(name):
             assert e["us_per_launch"] > 0 and 0 < e["frac"] < 1
             assert abs(e["frac"] - e["algorithmic_bytes_per_launch"] / (e["us_per_launch"] * 1e-6) / 8e12) < 2e-3, label
         assert any("k_mix" in e["kernels"] for e in oc.values())
+    if name >= "r05":
+        # round 5: every entry is timed on a footprint the 256 MiB Infinity Cache cannot hold (>= 0.5 GiB of algorithmic bytes per
+        # rotation), the two mixed block-size pairs of low-rate Vorbis are there, and the wave-pipeline kernels serve 1024 / 4096 points
+        oc = d["other_configs"]
+        assert len(oc) >= 8
+        for label, e in oc.items():
+            assert e["footprint_bytes"] >= 5e8 and e["footprint_bytes"] == e["batches_rotated"] * e["algorithmic_bytes_per_launch"], label
+        ks = {e["kernels"] for e in oc.values()}
+        assert {"k_long10", "k_long12", "k_mix10", "k_mix"} <= ks, ks
+        assert not any("generic" in k for k in ks)
+        assert "r05_pmc_summary" in d["roofline"]["traffic_unit"] or "r04_pmc_summary" in d["roofline"]["traffic_unit"]
 
 
 def test_device_code_is_the_measured_build():

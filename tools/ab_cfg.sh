@@ -17,7 +17,7 @@ import json, glob, sys
 o = sys.argv[1]
 for v in sys.argv[2:]:
     xs = []
-    for f in sorted(glob.glob("%s/%s[0-9]*.json" % (o, v))):
+    for f in sorted(glob.glob("%s/%s[0-9].json" % (o, v))):
         for l in open(f):
             if l.startswith("{"):
                 xs.append(json.loads(l)["us_per_launch"])
