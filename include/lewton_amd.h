@@ -238,6 +238,11 @@ size_t lw_ring_in_flight(lw_ring *r); /* slots staged, launched or collected and
 size_t lw_ring_last_staged_elems(lw_ring *r); /* elements the batch staged last will produce (known after lw_ring_stage) */
 int lw_ring_set_entropy_on_device(lw_ring *r, int on); /* lw_batch_set_entropy_on_device for every slot (ring must be idle) */
 const char *lw_ring_last_kernels(const lw_ring *r);
+/* measurement hook, process-wide, read by lw_ring_create: -1 (default) = by the ring's decoder -- a tenant's ring
+ * (lw_decoder_set_cu_share) runs its launches' kernels one launch after the other, and its PCM copies are issued by one copier
+ * thread per device once their kernels have finished (a copy queued behind its kernels blocks the copy engine for the other
+ * tenants' ready copies); else bit 0 = kernels in launch order per ring, bit 1 = copies by the device's copier */
+void lw_debug_ring_policy(int bits);
 /* The host half of a PreviousWindowRight (whether a right part is stored, its length, which of the two device buffers
  * holds it).  lw_batch_entropy / lw_ring_stage advance it when they plan a batch; a caller that drops a staged batch (or
  * one launched batch: a launch writes the OTHER device buffer) restores the state it saved before staging. */
@@ -248,6 +253,23 @@ typedef struct {
 void lw_pwr_get_state(const lw_pwr *p, lw_pwr_state *out);
 void lw_pwr_set_state(lw_pwr *p, const lw_pwr_state *in);
 int lw_decoder_device(const lw_decoder *d);
+/* Several decoders on ONE GPU (tenants; nothing in the reference corresponds: lewton decodes one stream on one thread).
+ * lw_decoder_set_shared_device(d, 1): other decoders' rings run on d's GPU as well.  The rings created for d AFTERWARDS then hand
+ * their PCM copies to one copier thread per device, which issues each copy once its kernels have finished -- a copy queued
+ * behind its kernels blocks the copy engine for every other ring's ready copies (measured: two rings on one GPU 8.6-9.0 M
+ * packets/s, with the copier 11.1-12.4 M, the rate of one ring) -- and run their launches' kernels in launch order.
+ * lw_sharder_create does this by itself when devices[] names a device several times.
+ * lw_decoder_set_cu_share: in addition, decoder `part` of `parts` launches on the slice [32 part / parts, 32 (part + 1) / parts)
+ * of the 32 CUs of EVERY XCD only (a HIP queue has to keep CUs on all eight; tenants share the L2s, never a CU): the rings
+ * created AFTERWARDS launch on CU-masked HIP streams and its batches are planned for that many CUs; parts = 1 gives the device
+ * back.  The wave-pipeline kernels take whole compute units, so without a share a 15 us launch next to another tenant's
+ * long-running kernel waits for CUs to drain (130-700 us measured; 28 us flat on a half-device share).  Throughput is the
+ * same either way (the PCIe link is the bound), so the sharder leaves it off.  Batches launched on a caller's own stream
+ * (lw_batch_synth) are planned for the share but run wherever that stream runs.  LW_ERR_UNSUPPORTED: parts > 32. */
+int lw_decoder_set_shared_device(lw_decoder *d, int on);
+int lw_decoder_set_cu_share(lw_decoder *d, unsigned part, unsigned parts);
+int lw_decoder_cu_count(const lw_decoder *d); /* compute units this decoder's launches are planned for */
+int lw_decoder_device_cu_count(const lw_decoder *d); /* compute units of its device */
 size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0) / 4: the largest block a packet yields */
 
 /* ---- independent streams sharded over the GPUs of a node, one process (BASELINE configs[4]) ----------------
@@ -275,6 +297,8 @@ size_t lw_decoder_max_block_elems(const lw_decoder *d); /* channels * (3 n1 - n0
  * A submit that fails AFTER some shards have launched (a device error on one shard) still queues the call, so that the
  * slots those shards hold can be freed: collect it (its packets on the failed shard come back with LW_ERR_DEVICE).
  * lw_sharder_decode = submit + collect on an empty pipeline.
+ * Logical shards (a device named several times) are tenants of that GPU (lw_decoder_set_shared_device): their PCM copies go
+ * through the device's copier thread, ready copies only, one at a time.
  * The process-per-GPU form of the same rule is lewton_amd/shard.py + bench.py under torch.distributed.run. */
 typedef struct lw_sharder lw_sharder;
 typedef struct lw_shard_stream lw_shard_stream; /* one logical stream: its PreviousWindowRight lives on the owning shard */
@@ -287,6 +311,10 @@ lw_sharder *lw_sharder_create(const lw_ident *id, const lw_setup *setup, const i
 		size_t max_packets_per_shard, int fmt, int *err);
 void lw_sharder_destroy(lw_sharder *sh); /* close the streams first */
 size_t lw_sharder_shards(const lw_sharder *sh);
+int lw_sharder_shard_cus(const lw_sharder *sh, size_t shard); /* compute units shard's launches run on (its lw_decoder_cu_count) */
+/* measurement hook, process-wide, read by lw_sharder_create: 1 = logical shards of one device also get a CU share each
+ * (lw_decoder_set_cu_share); 0 (default) = they share all its CUs */
+void lw_debug_sharder_share_cus(int on);
 int lw_sharder_set_entropy_on_device(lw_sharder *sh, int on); /* every shard's entropy stage on its own GPU (k_entropy) */
 size_t lw_sharder_shard_of(const lw_sharder *sh, uint64_t stream_id);
 int lw_sharder_device_of(const lw_sharder *sh, size_t shard);

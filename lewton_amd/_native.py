@@ -155,6 +155,13 @@ SYMBOLS = {
     "lw_pwr_get_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
     "lw_pwr_set_state": (None, [C.c_void_p, C.POINTER(PwrState)]),
     "lw_decoder_device": (C.c_int, [C.c_void_p]),
+    "lw_decoder_set_cu_share": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint]),
+    "lw_decoder_cu_count": (C.c_int, [C.c_void_p]),
+    "lw_decoder_set_shared_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "lw_debug_sharder_share_cus": (None, [C.c_int]),
+    "lw_debug_ring_policy": (None, [C.c_int]),
+    "lw_decoder_device_cu_count": (C.c_int, [C.c_void_p]),
+    "lw_sharder_shard_cus": (C.c_int, [C.c_void_p, C.c_size_t]),
     "lw_decoder_max_block_elems": (C.c_size_t, [C.c_void_p]),
     "lw_ogg_reader_open_memory": (C.c_void_p, [C.c_char_p, C.c_size_t, C.c_int]),
     "lw_ogg_reader_open_file": (C.c_void_p, [C.c_char_p, intp]),

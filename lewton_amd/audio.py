@@ -36,6 +36,14 @@ class Decoder:
         if not self._h:
             raise RuntimeError("lw_decoder_create failed (%d): %s" % (err.value, N.device_error()))
 
+    def set_cu_share(self, part, parts):
+        """several decoders on one GPU: this one launches on CUs [32 part / parts, 32 (part + 1) / parts) of every XCD only (the
+        rings made for it afterwards; lw_decoder_set_cu_share).  Returns the compute units its batches are planned for."""
+        rc = N.lw_decoder_set_cu_share(self._h, part, parts)
+        if rc:
+            raise ValueError("lw_decoder_set_cu_share(%d, %d): %d" % (part, parts, rc))
+        return N.lw_decoder_cu_count(self._h)
+
     def close(self):
         if getattr(self, "_h", None):
             N.lw_decoder_destroy(self._h)

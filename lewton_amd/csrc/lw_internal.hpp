@@ -25,6 +25,8 @@ void lw_set_device_error(const std::string &msg);
 			return LW_ERR_DEVICE;            \
 	} while (0)
 
+#define LW_XCDS 8u // accelerator dies of an MI355X, each with 32 CUs and its own L2; CU mask bit i of a queue = CU i / 8 of XCD i % 8
+
 struct lw_ident {
 	std::shared_ptr<lw::Ident> p;
 };
@@ -39,7 +41,10 @@ struct lw_decoder {
 	std::shared_ptr<lw::Ident> id;
 	std::shared_ptr<lw::Setup> setup;
 	int device = 0;
-	int n_cus = 256;
+	int n_cus = 256;                // compute units this decoder's launches are planned for (its share of the device)
+	int n_cus_device = 256;
+	std::vector<uint32_t> cu_mask;  // lw_decoder_set_cu_share: the mask of the streams made for this decoder (empty = all CUs)
+	bool shares_device = false;     // lw_decoder_set_shared_device: other decoders' rings run on this GPU as well
 	LwDevTables T{};
 	void *d_blob = nullptr; // one allocation holding every table
 	bool any_coupling = false;
@@ -68,6 +73,8 @@ struct lw_decoder {
 	void *one_out = nullptr; // pinned host output for the single-packet path
 	size_t one_out_bytes = 0;
 };
+
+hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s);
 
 struct lw_pwr {
 	lw_decoder *dec = nullptr;

@@ -13,15 +13,24 @@
 // Slots are used strictly first-in first-out, so every PreviousWindowRight sees its packets in submission order
 // (audio.rs:919 touches only its own pwr).  stage() and launch()/collect()/release() may be called from two different
 // threads (the Ogg reader's producer thread stages while the caller's thread launches and collects).
+//
+// Tenants (several decoders on one GPU: lw_decoder_set_shared_device, lw_decoder_set_cu_share): a tenant's ring runs its
+// launches' kernels one launch after the other, and its PCM copies are issued by the device's COPIER thread once their kernels
+// have finished, on one copy stream for all tenants of the device (see Copier below for the measurement behind it).
 #include "../../include/lewton_amd.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
+
+#define LW_RING_MAX_DEVICES 64
 
 namespace {
 
@@ -34,7 +43,10 @@ struct Slot {
 	hipEvent_t kernels_done = nullptr, all_done = nullptr;
 	SlotState state = SLOT_FREE;
 	size_t n = 0, out_elems = 0;
+	bool copy_queued = false, copy_failed = false; // (copier rings) the PCM copy is still to be issued / could not be issued
 };
+
+struct Copier;
 
 } // namespace
 
@@ -47,11 +59,16 @@ struct lw_ring {
 	size_t i_stage = 0, i_launch = 0, i_collect = 0;
 	hipEvent_t last_kernels = nullptr; // kernels_done of the most recent launch (null before the first)
 	hipEvent_t last_all_done = nullptr; // all_done of the most recent launch: the PCM copies run one at a time, in order
+	bool kernels_fifo = false; // a tenant's ring: the kernels of launch k+1 (k_entropy included) wait for those of launch k
+	bool masked = false;       // its slots' streams carry a CU mask (lw_decoder_set_cu_share)
+	Copier *copier = nullptr;  // a tenant's ring: the device's copier issues the PCM copies (null: on the slot's own stream)
 	std::mutex mu;
 	std::condition_variable cv;
 };
 
 namespace {
+
+std::atomic<int> g_policy{-1}; // lw_debug_ring_policy
 
 bool ok(hipError_t e)
 {
@@ -61,7 +78,110 @@ bool ok(hipError_t e)
 	return false;
 }
 
+// The PCM copies of the tenants of one device.  A device-to-host copy that is queued BEHIND ITS KERNELS on the slot's stream
+// sits in the SDMA engine's queue until those kernels are done, and every copy issued after it -- another ring's, long ready
+// -- waits behind it (tools/micro/d2h_streams.hip: a ready 0.31 ms copy on another stream completes 0.3 ms after the END of
+// the first stream's kernel, however long that runs).  One ring never notices: its copies are in launch order anyway.  Two
+// rings on one device stall each other every few launches (1.3 ms copies in the trace, every third collect of the sharder
+// waiting 1.0-1.4 ms: 8.6-9.0 M packets/s where the link allows 12.5 M; profiles/r05_tenants.txt), and ordering the copies
+// by events across the rings only makes the queue longer (6.4-7.1 M).  So for tenants the copy is issued by a host thread
+// when its kernels HAVE finished: one copier per device, jobs in launch order, one copy stream -- the engine's queue holds
+// ready copies only (two logical shards: 11.1-12.4 M packets/s, the rate of ONE ring with the same packets per call).
+struct Copier {
+	int device = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<std::pair<lw_ring *, Slot *>> jobs;
+	bool quit = false;
+	int users = 0; // rings holding it (under g_copiers_mu)
+	hipStream_t own_stream = nullptr; // the copies of rings on ordinary streams; a ring on CU-masked streams copies on its slots' own
+	std::thread th;
+
+	void main()
+	{
+		(void)hipSetDevice(device);
+		for (;;) {
+			std::pair<lw_ring *, Slot *> j;
+			{
+				std::unique_lock<std::mutex> g(mu);
+				cv.wait(g, [&]() { return quit || !jobs.empty(); });
+				if (jobs.empty())
+					return;
+				j = jobs.front();
+				jobs.pop_front();
+			}
+			lw_ring *r = j.first;
+			Slot *s = j.second;
+			hipStream_t on = r->masked ? s->stream : own_stream;
+			const bool good = ok(hipEventSynchronize(s->kernels_done)) &&
+				ok(hipMemcpyAsync(s->h_out, s->d_out, s->out_elems * r->esz, hipMemcpyDeviceToHost, on)) &&
+				ok(hipEventRecord(s->all_done, on));
+			std::lock_guard<std::mutex> g(r->mu); // (the ring waits for copy_queued of all its slots before it goes away)
+			s->copy_failed = !good;
+			s->copy_queued = false;
+			r->cv.notify_all();
+		}
+	}
+};
+std::mutex g_copiers_mu;
+Copier *g_copiers[LW_RING_MAX_DEVICES];
+
+Copier *copier_acquire(int device, bool own_stream)
+{
+	if (device < 0 || device >= LW_RING_MAX_DEVICES)
+		return nullptr;
+	std::lock_guard<std::mutex> g(g_copiers_mu);
+	Copier *&c = g_copiers[device];
+	if (!c) {
+		// Kept for the life of the process, and so is its stream: all tenants' copies on ONE stream of the copier's made 11.1-12.4 M
+		// packets/s where the same copies issued on the slots' own streams made 8.0-10.6 M (two logical shards; same box, same
+		// minute).  Next to CU-MASKED streams that stream is not used: destroying it, leaving it to the runtime's teardown, or even
+		// _exit() then hung one run in three (the queues of the process never drained) -- a ring on masked streams copies on them.
+		c = new Copier();
+		c->device = device;
+	}
+	if (own_stream && !c->own_stream && !ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)))
+		return nullptr;
+	if (c->users++ == 0) {
+		c->quit = false;
+		c->th = std::thread([p = c]() { p->main(); });
+	}
+	return c;
+}
+
+void copier_release(Copier *c)
+{
+	if (!c)
+		return;
+	std::lock_guard<std::mutex> g(g_copiers_mu);
+	if (--c->users > 0)
+		return;
+	{
+		std::lock_guard<std::mutex> q(c->mu);
+		c->quit = true;
+	}
+	c->cv.notify_all();
+	c->th.join();
+}
+
+// every copy the copier still has to issue for this ring has been issued (or has failed)
+void wait_copies_issued(lw_ring *r)
+{
+	std::unique_lock<std::mutex> g(r->mu);
+	r->cv.wait(g, [&]() {
+		for (const Slot &s : r->slots)
+			if (s.copy_queued)
+				return false;
+		return true;
+	});
+}
+
 } // namespace
+
+hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s); // lw_runtime.cpp: non-blocking, on the decoder's CU share
+extern "C" int lw_decoder_cu_count(const lw_decoder *d);
+extern "C" int lw_decoder_device_cu_count(const lw_decoder *d);
+extern "C" int lw_decoder_shares_device(const lw_decoder *d);
 
 extern "C" {
 
@@ -87,13 +207,21 @@ lw_ring *lw_ring_create(lw_decoder *d, size_t n_slots, size_t max_packets, int f
 	r->cap_elems = max_packets * lw_decoder_max_block_elems(d);
 	r->slots.resize(n_slots);
 	bool good = ok(hipSetDevice(r->device));
+	{
+		r->masked = lw_decoder_cu_count(d) < lw_decoder_device_cu_count(d);
+		const bool tenant = r->masked || lw_decoder_shares_device(d);
+		const int pol = g_policy.load();
+		r->kernels_fifo = pol < 0 ? tenant : (pol & 1) != 0;
+		if (good && (pol < 0 ? tenant : (pol & 2) != 0))
+			good = (r->copier = copier_acquire(r->device, !r->masked)) != nullptr;
+	}
 	for (Slot &s : r->slots) {
 		if (!good)
 			break;
 		int e = 0;
 		s.batch = lw_batch_create(d, max_packets, fmt, &e);
 		good = s.batch && ok(hipMalloc(&s.d_out, r->cap_elems * r->esz)) && ok(hipHostMalloc(&s.h_out, r->cap_elems * r->esz)) &&
-			ok(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) &&
+			ok(lw_decoder_stream_create(d, &s.stream)) &&
 			ok(hipEventCreateWithFlags(&s.kernels_done, hipEventDisableTiming)) &&
 			ok(hipEventCreateWithFlags(&s.all_done, hipEventDisableTiming));
 	}
@@ -110,6 +238,8 @@ void lw_ring_destroy(lw_ring *r)
 	if (!r)
 		return;
 	(void)hipSetDevice(r->device);
+	if (r->copier)
+		wait_copies_issued(r);
 	for (Slot &s : r->slots) {
 		if (s.stream)
 			(void)hipStreamSynchronize(s.stream);
@@ -126,6 +256,7 @@ void lw_ring_destroy(lw_ring *r)
 		if (s.stream)
 			(void)hipStreamDestroy(s.stream);
 	}
+	copier_release(r->copier);
 	delete r;
 }
 
@@ -200,28 +331,48 @@ int lw_ring_launch(lw_ring *r)
 	}
 	if (!ok(hipSetDevice(r->device)))
 		return LW_ERR_DEVICE;
+	const bool kernels_fifo = r->kernels_fifo;
 	int rc = lw_batch_upload(s->batch, s->stream);
+	// A tenant's kernels run one launch after the other: on its share of the CUs the next launch's k_entropy would take the
+	// CUs this launch's whole-CU workgroups are waiting for (k_long 28 -> 300-700 us, measured) and gain nothing
+	if (rc == LW_OK && kernels_fifo && r->last_kernels && !ok(hipStreamWaitEvent(s->stream, r->last_kernels, 0)))
+		rc = LW_ERR_DEVICE;
 	if (rc == LW_OK) // entropy stage on the device: no stream state involved, so it runs beside the previous launches' kernels
 		rc = lw_batch_device_entropy(s->batch, s->stream);
-	if (rc == LW_OK && r->last_kernels && !ok(hipStreamWaitEvent(s->stream, r->last_kernels, 0)))
+	if (rc == LW_OK && !kernels_fifo && r->last_kernels && !ok(hipStreamWaitEvent(s->stream, r->last_kernels, 0)))
 		rc = LW_ERR_DEVICE;
 	if (rc == LW_OK)
 		rc = lw_batch_synth(s->batch, s->d_out, r->cap_elems, s->stream);
 	if (rc == LW_OK && !ok(hipEventRecord(s->kernels_done, s->stream)))
 		rc = LW_ERR_DEVICE;
-	// The PCM copies of consecutive launches run ONE AT A TIME, in launch order: left to themselves the copies of all slots in
-	// flight share the link, finish together, the caller (first-in first-out) refills all slots at once, and the batches then
-	// move through upload / entropy / synthesis / copy in lock step -- the copy engine idle while the kernels run and the
-	// other way round (measured: every third collect waiting 1.2 ms, 7.2 M packets/s; staggered 13 M, profiles/r04_e2e_ring.txt)
-	// (per ring: the same order over ALL rings of a device was measured as well -- two logical shards on one GPU then made 6-7
-	// instead of 8.3 M packets/s, profiles/r04_e2e_ring.txt)
-	if (rc == LW_OK && s->out_elems && r->last_all_done && !ok(hipStreamWaitEvent(s->stream, r->last_all_done, 0)))
-		rc = LW_ERR_DEVICE;
-	if (rc == LW_OK && s->out_elems &&
-			!ok(hipMemcpyAsync(s->h_out, s->d_out, s->out_elems * r->esz, hipMemcpyDeviceToHost, s->stream)))
-		rc = LW_ERR_DEVICE;
-	if (rc == LW_OK && !ok(hipEventRecord(s->all_done, s->stream)))
-		rc = LW_ERR_DEVICE;
+	if (r->copier && s->out_elems) {
+		// a tenant's ring: the device's copier issues the copy once the kernels are done (see Copier)
+		if (rc == LW_OK) {
+			{
+				std::lock_guard<std::mutex> g(r->mu);
+				s->copy_queued = true;
+				s->copy_failed = false;
+			}
+			{
+				std::lock_guard<std::mutex> q(r->copier->mu);
+				r->copier->jobs.emplace_back(r, s);
+			}
+			r->copier->cv.notify_one();
+		}
+	} else {
+		// The PCM copies of consecutive launches run ONE AT A TIME, in launch order: left to themselves the copies of all slots
+		// in flight share the link, finish together, the caller (first-in first-out) refills all slots at once, and the batches
+		// then move through upload / entropy / synthesis / copy in lock step -- the copy engine idle while the kernels run and
+		// the other way round (measured: every third collect waiting 1.2 ms, 7.2 M packets/s; staggered 13 M,
+		// profiles/r04_e2e_ring.txt)
+		if (rc == LW_OK && s->out_elems && r->last_all_done && !ok(hipStreamWaitEvent(s->stream, r->last_all_done, 0)))
+			rc = LW_ERR_DEVICE;
+		if (rc == LW_OK && s->out_elems &&
+				!ok(hipMemcpyAsync(s->h_out, s->d_out, s->out_elems * r->esz, hipMemcpyDeviceToHost, s->stream)))
+			rc = LW_ERR_DEVICE;
+		if (rc == LW_OK && !ok(hipEventRecord(s->all_done, s->stream)))
+			rc = LW_ERR_DEVICE;
+	}
 	std::lock_guard<std::mutex> g(r->mu);
 	if (rc != LW_OK)
 		return rc; // the slot stays STAGED (its host-side bookkeeping is done): the caller may retry or drop the ring
@@ -254,6 +405,12 @@ int lw_ring_collect(lw_ring *r, const lw_packet_result **results, size_t *n, con
 	}
 	int dev_rc = LW_OK;
 	if (wait) {
+		if (r->copier) { // the copier issues this slot's copy once its kernels are done: all_done is recorded only then
+			std::unique_lock<std::mutex> g(r->mu);
+			r->cv.wait(g, [&]() { return !s->copy_queued; });
+			if (s->copy_failed)
+				return LW_ERR_DEVICE;
+		}
 		if (!ok(hipSetDevice(r->device)) || !ok(hipEventSynchronize(s->all_done)))
 			return LW_ERR_DEVICE;
 		// a kernel of this batch raised its device error word: the batch's results carry LW_ERR_DEVICE, its PCM is void; the
@@ -297,6 +454,8 @@ int lw_ring_drain(lw_ring *r)
 	if (!ok(hipSetDevice(r->device)))
 		return LW_ERR_DEVICE;
 	int rc = LW_OK;
+	if (r->copier)
+		wait_copies_issued(r);
 	for (Slot &s : r->slots)
 		if (!ok(hipStreamSynchronize(s.stream)))
 			rc = LW_ERR_DEVICE;
@@ -306,6 +465,13 @@ int lw_ring_drain(lw_ring *r)
 	r->i_stage = r->i_launch = r->i_collect = 0;
 	r->cv.notify_all();
 	return rc;
+}
+
+// measurement hook, process-wide, read by lw_ring_create: -1 = by the ring's decoder (a tenant: kernels in order per ring, copies
+// by the device's copier), else bit 0 = kernels of a ring one launch after the other, bit 1 = copies by the device's copier
+void lw_debug_ring_policy(int bits)
+{
+	g_policy.store(bits);
 }
 
 const char *lw_ring_last_kernels(const lw_ring *r)

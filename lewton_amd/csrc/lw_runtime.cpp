@@ -378,6 +378,7 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	d->device = device;
 	if (hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || d->n_cus <= 0)
 		d->n_cus = 256;
+	d->n_cus_device = d->n_cus;
 
 	// ---- build one blob with all tables
 	std::vector<uint8_t> blob;
@@ -587,6 +588,80 @@ int lw_decoder_device(const lw_decoder *d)
 {
 	return d ? d->device : -1;
 }
+
+// Several decoders on ONE GPU.  k_long / k_long10 / k_long12 / k_mix* take a whole compute unit per workgroup (152 KB of its
+// 160 KB LDS and all of its vector registers), so next to another tenant's long-running kernel (k_entropy: 196 us per 4096
+// packets) a 15 us launch waits for whole CUs to drain: 130-150 us.  With a share, the streams made for this
+// decoder carry a CU mask and the planner sizes this decoder's launches for its own CUs.  A queue's mask bit i is CU i / 8 of
+// XCD i % 8, and a queue must keep CUs on EVERY XCD -- its workgroups go round the XCDs whatever the mask says; a mask that
+// empties an XCD is ignored as a whole (both measured: tools/micro/cumask.hip, profiles/r05_cumask.txt) -- so a share is the
+// same CUs [n j / k, n (j + 1) / k) of each XCD's n = 32, not whole XCDs: tenants never meet on a CU, they do share the L2s.
+int lw_decoder_set_cu_share(lw_decoder *d, unsigned part, unsigned parts)
+{
+	if (!d || parts == 0 || part >= parts)
+		return LW_ERR_NULL_ARG;
+	const unsigned per_xcd = (unsigned)d->n_cus_device / LW_XCDS;
+	if (parts > per_xcd)
+		return LW_ERR_UNSUPPORTED;
+	std::lock_guard<std::mutex> g(d->mu);
+	d->cu_mask.clear();
+	d->n_cus = d->n_cus_device;
+	if (parts == 1)
+		return LW_OK;
+	d->cu_mask.assign((size_t)(d->n_cus_device + 31) / 32, 0u);
+	int mine = 0;
+	for (unsigned i = 0; i < per_xcd * LW_XCDS; i++)
+		if ((i / LW_XCDS) * parts / per_xcd == part) {
+			d->cu_mask[i / 32] |= 1u << (i % 32);
+			mine++;
+		}
+	d->n_cus = std::max(1, mine);
+	return LW_OK;
+}
+
+int lw_decoder_cu_count(const lw_decoder *d)
+{
+	return d ? d->n_cus : 0;
+}
+
+int lw_decoder_device_cu_count(const lw_decoder *d)
+{
+	return d ? d->n_cus_device : 0;
+}
+
+// Other decoders' rings run on this decoder's GPU as well (lw_sharder_create with a device named several times, or several
+// lewton-style decoders in one process): the rings made for it AFTERWARDS hand their PCM copies to the device's copier
+// thread and run their launches' kernels in launch order (lw_ring.cpp: Copier).
+int lw_decoder_set_shared_device(lw_decoder *d, int on)
+{
+	if (!d)
+		return LW_ERR_NULL_ARG;
+	std::lock_guard<std::mutex> g(d->mu);
+	d->shares_device = on != 0;
+	return LW_OK;
+}
+
+int lw_decoder_shares_device(const lw_decoder *d)
+{
+	return d && d->shares_device;
+}
+
+} // extern "C"
+
+// a stream for this decoder's launches: non-blocking, on the decoder's share of the device
+hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s)
+{
+	std::vector<uint32_t> mask;
+	{
+		std::lock_guard<std::mutex> g(d->mu);
+		mask = d->cu_mask;
+	}
+	if (mask.empty())
+		return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+	return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+
+extern "C" {
 
 size_t lw_decoder_max_block_elems(const lw_decoder *d)
 {

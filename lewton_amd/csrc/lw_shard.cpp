@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -307,7 +308,15 @@ struct lw_sharder {
 	}
 };
 
+static std::atomic<int> g_share_cus{0};
+
 extern "C" {
+
+// measurement hook: 1 = logical shards of one device get their own CUs of every XCD each (tools/probe/sharder_probe.py)
+void lw_debug_sharder_share_cus(int on)
+{
+	g_share_cus.store(on);
+}
 
 lw_sharder *lw_sharder_create(const lw_ident *id, const lw_setup *setup, const int *devices, size_t n_shards,
 		size_t max_packets_per_shard, int fmt, int *err)
@@ -330,6 +339,20 @@ lw_sharder *lw_sharder_create(const lw_ident *id, const lw_setup *setup, const i
 		s->device = devices[g];
 		int e = 0;
 		s->dec = lw_decoder_create(id, setup, devices[g], &e);
+		// logical shards on one device are tenants of that GPU (lw_decoder_set_shared_device): their rings hand the PCM copies to the
+		// device's copier.  With the measurement hook each also gets its own CUs of every XCD (lw_decoder_set_cu_share: a shard's
+		// whole-CU workgroups then never queue behind the other shard's entropy kernel -- k_long 28 us flat instead of 130-700 --
+		// at the same packets/s, the link being the bound; not the default: profiles/r05_tenants.txt).
+		unsigned same = 0, before = 0;
+		for (size_t k = 0; k < n_shards; k++)
+			if (devices[k] == devices[g]) {
+				same++;
+				before += k < g;
+			}
+		if (s->dec && same > 1)
+			(void)lw_decoder_set_shared_device(s->dec, 1);
+		if (s->dec && same > 1 && same <= 32 && g_share_cus.load())
+			(void)lw_decoder_set_cu_share(s->dec, before, same);
 		if (s->dec)
 			s->ring = lw_ring_create(s->dec, LW_SHARD_SLOTS, max_packets_per_shard, fmt, &e);
 		const bool ok = s->dec && s->ring;
@@ -383,6 +406,11 @@ int lw_sharder_set_entropy_on_device(lw_sharder *sh, int on)
 size_t lw_sharder_shards(const lw_sharder *sh)
 {
 	return sh ? sh->shards.size() : 0;
+}
+
+int lw_sharder_shard_cus(const lw_sharder *sh, size_t shard)
+{
+	return sh && shard < sh->shards.size() ? lw_decoder_cu_count(sh->shards[shard]->dec) : 0;
 }
 
 size_t lw_sharder_shard_of(const lw_sharder *sh, uint64_t stream_id)

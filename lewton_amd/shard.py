@@ -38,7 +38,9 @@ class Sharder:
     opened through the sharder and live on shard stream_id mod G.  decode() is synchronous; submit() / collect() keep up to
     three calls in flight so that every shard's host stage overlaps the GPU work of the call before."""
 
-    def __init__(self, ident, setup, devices, max_packets_per_shard, samples="i16"):
+    def __init__(self, ident, setup, devices, max_packets_per_shard, samples="i16", share_cus=False):
+        """share_cus: logical shards (a device named several times) each launch on their own CUs of every XCD
+        (lw_decoder_set_cu_share; measurement hook, tools/probe/sharder_probe.py); False = all of them on the whole device"""
         import ctypes as C
         from . import _native as N
         from .audio import _FMT
@@ -46,7 +48,9 @@ class Sharder:
         self.ident, self.fmt = ident, _FMT[samples]
         arr = (C.c_int * len(devices))(*devices)
         err = C.c_int(0)
+        N.lw_debug_sharder_share_cus(1 if share_cus else 0)
         self._h = N.lw_sharder_create(ident._h, setup._h, arr, len(devices), max_packets_per_shard, self.fmt, C.byref(err))
+        N.lw_debug_sharder_share_cus(0)
         if not self._h:
             raise RuntimeError("lw_sharder_create failed (%d): %s" % (err.value, N.device_error()))
         self._streams = {}
@@ -54,6 +58,10 @@ class Sharder:
     @property
     def shards(self):
         return self._N.lw_sharder_shards(self._h)
+
+    def shard_cus(self, shard):
+        """compute units the shard's launches run on"""
+        return self._N.lw_sharder_shard_cus(self._h, shard)
 
     def shard_of(self, stream_id):
         return self._N.lw_sharder_shard_of(self._h, stream_id)

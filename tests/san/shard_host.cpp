@@ -74,6 +74,24 @@ int main(int argc, char **argv)
 	CHECK(A.sh, "sharder(G): %d", err);
 	B.sh = lw_sharder_create(id, setup, one.data(), 1, n_call, LW_FMT_I16_PLANAR, &err);
 	CHECK(B.sh, "sharder(1): %d", err);
+	{ // logical shards share the device's CUs unless the measurement hook gives each its own (checked below on a third sharder)
+		for (size_t g = 0; g < G; g++)
+			CHECK(lw_sharder_shard_cus(A.sh, g) == 256, "shard %zu of %zu plans for %d CUs", g, G, lw_sharder_shard_cus(A.sh, g));
+		CHECK(lw_sharder_shard_cus(B.sh, 0) == 256 && lw_sharder_shard_cus(B.sh, 1) == 0, "CUs of the lone shard");
+		lw_debug_sharder_share_cus(1); // CUs [32 j / G, 32 (j + 1) / G) of each of the 8 XCDs
+		lw_sharder *C = lw_sharder_create(id, setup, devs.data(), G, n_call, LW_FMT_I16_PLANAR, &err);
+		lw_debug_sharder_share_cus(0);
+		CHECK(C, "sharder(G, CU shares): %d", err);
+		int sum = 0;
+		for (size_t g = 0; g < G; g++) {
+			const int want = G == 1 || G > 32 ? 256 : 8 * (int)((32 * (g + 1) + G - 1) / G - (32 * g + G - 1) / G);
+			CHECK(lw_sharder_shard_cus(C, g) == want, "shard %zu of %zu plans for %d CUs, expected %d", g, G,
+			      lw_sharder_shard_cus(C, g), want);
+			sum += want;
+		}
+		CHECK(G > 32 || sum == 256, "CU shares add up to %d", sum);
+		lw_sharder_destroy(C);
+	}
 	if (dev_entropy) {
 		CHECK(lw_sharder_set_entropy_on_device(A.sh, 1) == LW_OK && lw_sharder_set_entropy_on_device(B.sh, 1) == LW_OK,
 		      "stream not eligible for the device entropy stage");
