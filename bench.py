@@ -391,7 +391,10 @@ def main():
                     other[label] = {"us_per_launch": r_["us_per_launch"], "packets_per_launch": r_["packets_per_launch"],
                                     "M_packets_per_s": r_["M_packets_per_s"], "algorithmic_bytes_per_launch": r_["algorithmic_bytes_per_launch"],
                                     "batches_rotated": r_["batches_rotated"], "footprint_bytes": r_["footprint_bytes"],
-                                    "frac": round(r_["pct_of_8TBps"] / 100.0, 4), "kernels": r_["kernels"], "parity": r_["parity"],
+                                    "frac": round(r_["pct_of_8TBps"] / 100.0, 4),
+                                    "state_bytes_per_launch": r_["state_bytes_per_launch"],
+                                    "frac_incl_state": round(r_["pct_of_8TBps_incl_state"] / 100.0, 4),
+                                    "kernels": r_["kernels"], "parity": r_["parity"],
                                     "steps": r_["steps"]}
                 except Exception as e:
                     other[label] = {"error": repr(e)}
@@ -436,7 +439,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/%s)" % os.path.basename(pmc_file),
-                         "kernel": kernels, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": kernels, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         # informational, not in `frac`: window state of the batch's streams crossing HBM at the launch boundary
+                         "state_bytes_per_launch": batches[0].state_bytes},
             "cpu_baseline": cpu,
             "end_to_end": e2e_obj,
             "other_configs": other,

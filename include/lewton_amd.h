@@ -166,6 +166,10 @@ size_t lw_batch_out_elems(const lw_batch *b);
 const lw_packet_result *lw_batch_results(const lw_batch *b);
 /* bytes the device stage reads+writes for this batch by the SURVEY 8(d) definition */
 uint64_t lw_batch_algorithmic_bytes(const lw_batch *b);
+/* bytes of PreviousWindowRight that have to cross HBM because of the launch boundary, NOT part of the 8(d) figure: the stored
+ * right part of every stream whose first packet of the batch has one (read from the state pool) and the right part every
+ * stream's last packet leaves behind (written to it), channels * length * 4 each.  Inside a launch the state passes through LDS. */
+uint64_t lw_batch_state_bytes(const lw_batch *b);
 /* Debug taps: copy one intermediate of packet `idx` to host after running the generic kernels.
  * dst: [ch][n/2] floats ([ch][n] for LW_TAP_POST_MDCT). */
 int lw_batch_tap(lw_batch *b, size_t idx, int tap, float *dst, size_t cap_floats);

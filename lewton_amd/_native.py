@@ -112,6 +112,7 @@ SYMBOLS = {
     "lw_batch_out_elems": (C.c_size_t, [C.c_void_p]),
     "lw_batch_results": (C.POINTER(PacketResult), [C.c_void_p]),
     "lw_batch_algorithmic_bytes": (C.c_uint64, [C.c_void_p]),
+    "lw_batch_state_bytes": (C.c_uint64, [C.c_void_p]),
     "lw_batch_tap": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, f32p, C.c_size_t]),
     "lw_batch_set_force_generic": (None, [C.c_void_p, C.c_int]),
     "lw_debug_batch_set_rounds": (None, [C.c_void_p, C.c_int]),

@@ -73,6 +73,11 @@ class Batch:
         return N.lw_batch_algorithmic_bytes(self._h)
 
     @property
+    def state_bytes(self):
+        """window state that crosses HBM at the launch boundary (not part of algorithmic_bytes; lw_batch_state_bytes)"""
+        return N.lw_batch_state_bytes(self._h)
+
+    @property
     def last_kernels(self):
         return (N.lw_batch_last_kernels(self._h) or b"").decode()
 

@@ -228,6 +228,11 @@ uint64_t lw_batch_algorithmic_bytes(const lw_batch *b)
 	return b ? b->alg_bytes : 0;
 }
 
+uint64_t lw_batch_state_bytes(const lw_batch *b)
+{
+	return b ? b->state_bytes : 0;
+}
+
 const char *lw_batch_last_kernels(const lw_batch *b)
 {
 	return b ? b->last_kernels.c_str() : "";
@@ -357,7 +362,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->fast_idx.clear();
 	b->fast_slot.clear();
 	size_t out_off = 0;
-	uint64_t alg = 0;
+	uint64_t alg = 0, state = 0;
 	const size_t esz = lw_elem_size(b->fmt);
 	b->has_generic = b->has_fast = false;
 	b->n_gen_small = b->n_gen_large = b->n_gen_ola = 0;
@@ -435,6 +440,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				r.prev = last;
 			} else {
 				r.prev = -(pw->slot + 2);
+				state += (uint64_t)ch * pw->len * 4; // the stream's stored right part comes in from the state pool
 				if (pw->parity)
 					r.flags |= LW_RF_PARITY_IN;
 			}
@@ -509,6 +515,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 		if (last >= 0) {
 			LwPacketRec &r = b->h_recs[last];
 			r.state_out = pw->slot;
+			state += (uint64_t)ch * pw->len * 4; // ... and the new one goes out to it
 			const uint8_t outp = pw->parity ^ 1;
 			if (outp)
 				r.flags |= LW_RF_PARITY_OUT;
@@ -518,6 +525,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	}
 	b->out_elems = out_off;
 	b->alg_bytes = alg;
+	b->state_bytes = state;
 	if (!b->fast_idx.empty() || !b->blk_idx[0].empty() || !b->blk_idx[1].empty())
 		for (size_t i = 0; i < n; i++) { // generic successors of packets of the specialised kernels read the td block
 			const LwPacketRec &r = b->h_recs[i];

@@ -148,6 +148,7 @@ struct lw_batch {
 	bool has_generic = false, has_fast = false, force_generic = false;
 	std::vector<lw_packet_result> results;
 	uint64_t alg_bytes = 0;
+	uint64_t state_bytes = 0; // window state crossing HBM at the launch boundary (lw_batch_state_bytes)
 	std::string last_kernels;
 	std::vector<lw::Prologue> prologues;
 	std::vector<int> status;

@@ -75,6 +75,7 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
         b += 1
     torch.cuda.synchronize()
     alg = batches[0][0].algorithmic_bytes
+    state = batches[0][0].state_bytes
     stream = torch.cuda.current_stream()
 
     def step(k, sp):
@@ -117,7 +118,11 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
     res = {"config": w.name, "packets_per_launch": NP, "streams": w.n_streams, "steps": reps * nb, "us_per_launch": round(us, 2),
            "M_packets_per_s": round(NP / us, 2), "algorithmic_bytes_per_launch": alg,
            "batches_rotated": nb, "footprint_bytes": nb * alg,
-           "pct_of_8TBps": round(100 * alg / (us * 1e-6) / 8e12, 2), "kernels": batches[0][0].last_kernels, "parity": parity,
+           "pct_of_8TBps": round(100 * alg / (us * 1e-6) / 8e12, 2),
+           # informational: the streams' window state has to cross HBM at a launch boundary (stored right parts in, new ones out);
+           # SURVEY 8(d)'s figure does not count it, so shapes with few packets per stream and launch look slower than the chip runs
+           "state_bytes_per_launch": state, "pct_of_8TBps_incl_state": round(100 * (alg + state) / (us * 1e-6) / 8e12, 2),
+           "kernels": batches[0][0].last_kernels, "parity": parity,
            "note": w.note}
     for bt, _ in batches:
         bt.close()
