@@ -60,6 +60,9 @@ def test_dense_bench_batch_every_packet_vs_oracle(fmt):
     assert bt.last_kernels == "k_long"
     assert all(r[0] == 0 and r[1] == 1024 for r in res) and flat.size == S * per * 2 * 1024
     assert bt.algorithmic_bytes == S * per * (12420 + (4096 if fmt == "f32" else 0))
+    # every stream's stored right part comes in from the state pool and the new one goes out: 2 channels x 1024 floats each way;
+    # the priming batch had nothing to read
+    assert bt.state_bytes == S * 2 * (2 * 1024 * 4) and prime.state_bytes == S * (2 * 1024 * 4)
     bad = 0
     for s in range(S):
         opw = po.Pwr()
