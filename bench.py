@@ -357,10 +357,11 @@ def main():
             except Exception as e:
                 e2e_obj["device_entropy"] = {"error": repr(e)}
             try:   # one process, every GPU of the node (lw_sharder_*: a staging ring per device, streams sharded stream_id mod G,
-                   # no collective); a one-GPU box runs two logical shards on the same device
+                   # no collective); a one-GPU box runs two logical shards on the same device.  As many packets in all as the
+                   # single ring above decodes (e2e_batches x 4096), so that fill and drain weigh the same in both
                 ndev = max(1, N_.lw_device_count())
                 devs = list(range(ndev)) if ndev > 1 else [0, 0]
-                r_ = e2e_mod.measure_sharder(ident, st, pool, devs, n_calls=max(8, args.e2e_batches // 4), packets_per_shard=PACKETS_PER_BATCH,
+                r_ = e2e_mod.measure_sharder(ident, st, pool, devs, n_calls=max(8, args.e2e_batches // len(devs)), packets_per_shard=PACKETS_PER_BATCH,
                                              streams_per_shard=S, threads=0, samples=args.format, device_entropy=True)
                 e2e_obj["sharder"] = r_
             except Exception as e:

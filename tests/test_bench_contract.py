@@ -9,7 +9,8 @@ from common import ROOT
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json", "r04_bench.json", "r05_bench.json"])
+@pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json", "r04_bench.json", "r05_bench.json",
+                                  "r05_bench_closing.json", "r05_bench_closing_box2.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).readline()
     d = json.loads(line)
@@ -64,6 +65,15 @@ def test_committed_bench_line_has_the_contract_fields(name):
         assert {"k_long10", "k_long12", "k_mix10", "k_mix"} <= ks, ks
         assert not any("generic" in k for k in ks)
         assert "r05_pmc_summary" in d["roofline"]["traffic_unit"] or "r04_pmc_summary" in d["roofline"]["traffic_unit"]
+    if name >= "r05_bench_closing":
+        # the round's closing tree: the window state crossing HBM at the launch boundary rides along (never in `frac`), and two
+        # logical shards on one GPU reach the rate of one ring (the copier thread of tenants' rings)
+        assert d["roofline"]["state_bytes_per_launch"] == 256 * 2 * (2 * 1024 * 4)
+        for label, e in d["other_configs"].items():
+            want = (e["algorithmic_bytes_per_launch"] + e["state_bytes_per_launch"]) / (e["us_per_launch"] * 1e-6) / 8e12
+            assert e["frac"] <= e["frac_incl_state"] < 1 and abs(e["frac_incl_state"] - want) < 2e-3, label
+        e2e = d["end_to_end"]
+        assert e2e["sharder"]["value"] >= 0.9 * e2e["device_entropy"]["value"] and e2e["sharder"]["value"] >= 11e6
 
 
 def test_device_code_is_the_measured_build():
