@@ -34,7 +34,7 @@ def rotation_batches(alg_bytes):
     return max(2, need, min(8, (3 * (1 << 29)) // max(1, alg_bytes)))
 
 
-def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0):
+def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0, mix=None):
     """Time workload `w` (lewton_amd.workloads.Workload): `nb` rotated batches resident in HBM (default: as many as
     rotation_batches() asks for -- a footprint of at least 0.5 GiB), one hipGraph of `nb` steps replayed, HIP events; then
     (verify) every packet of timed batch 0 against the oracle.  Returns the result line as a dict.
@@ -63,6 +63,8 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
         prime.synth_to_host(None)
         prime.close()
         bt = Batch(dec, NP, "i16")
+        if mix is not None:
+            bt.debug_set_mix(mix)   # lw_debug_batch_set_mix: 0 = mixed batches as two launches, -1 = as one where k_mix applies
         if force_generic:
             bt.set_force_generic(True)
         bt.entropy(items, n_threads=0)
@@ -137,8 +139,9 @@ if __name__ == "__main__":
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--nb", type=int, default=0, help="batches rotated (0 = by footprint: >= 0.5 GiB per rotation)")
+    ap.add_argument("--mix", type=int, default=None, help="lw_debug_batch_set_mix: 0 = mixed batches as two launches, -1 = as one where k_mix applies (default)")
     args = ap.parse_args()
     ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
     for w in wl.configs(args.packets):
         if w.key in ONLY:
-            print(json.dumps(measure(w, args.steps, args.nb or None, not args.no_verify, args.force_generic)), flush=True)
+            print(json.dumps(measure(w, args.steps, args.nb or None, not args.no_verify, args.force_generic, mix=args.mix)), flush=True)
