@@ -164,16 +164,20 @@ void copier_release(Copier *c)
 	c->th.join();
 }
 
-// every copy the copier still has to issue for this ring has been issued (or has failed)
-void wait_copies_issued(lw_ring *r)
+// every copy the copier still had to issue for this ring has been issued (or has failed) AND has completed: the ring's buffers
+// are no longer read or written by the copier's stream
+bool wait_copies_done(lw_ring *r)
 {
-	std::unique_lock<std::mutex> g(r->mu);
-	r->cv.wait(g, [&]() {
-		for (const Slot &s : r->slots)
-			if (s.copy_queued)
-				return false;
-		return true;
-	});
+	{
+		std::unique_lock<std::mutex> g(r->mu);
+		r->cv.wait(g, [&]() {
+			for (const Slot &s : r->slots)
+				if (s.copy_queued)
+					return false;
+			return true;
+		});
+	}
+	return r->masked || !r->copier->own_stream || ok(hipStreamSynchronize(r->copier->own_stream)); // (masked: the slots' own streams)
 }
 
 } // namespace
@@ -239,7 +243,7 @@ void lw_ring_destroy(lw_ring *r)
 		return;
 	(void)hipSetDevice(r->device);
 	if (r->copier)
-		wait_copies_issued(r);
+		(void)wait_copies_done(r);
 	for (Slot &s : r->slots) {
 		if (s.stream)
 			(void)hipStreamSynchronize(s.stream);
@@ -454,8 +458,8 @@ int lw_ring_drain(lw_ring *r)
 	if (!ok(hipSetDevice(r->device)))
 		return LW_ERR_DEVICE;
 	int rc = LW_OK;
-	if (r->copier)
-		wait_copies_issued(r);
+	if (r->copier && !wait_copies_done(r))
+		rc = LW_ERR_DEVICE;
 	for (Slot &s : r->slots)
 		if (!ok(hipStreamSynchronize(s.stream)))
 			rc = LW_ERR_DEVICE;
