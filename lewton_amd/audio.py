@@ -36,6 +36,14 @@ class Decoder:
         if not self._h:
             raise RuntimeError("lw_decoder_create failed (%d): %s" % (err.value, N.device_error()))
 
+    def set_shared_device(self, on=True):
+        """other decoders' rings (of this process or another) run on this decoder's GPU as well: the rings made for it afterwards
+        hand their PCM copies to the device's copier thread and run their launches' kernels in launch order
+        (lw_decoder_set_shared_device)"""
+        rc = N.lw_decoder_set_shared_device(self._h, 1 if on else 0)
+        if rc:
+            raise ValueError("lw_decoder_set_shared_device: %d" % rc)
+
     def set_cu_share(self, part, parts):
         """several decoders on one GPU: this one launches on CUs [32 part / parts, 32 (part + 1) / parts) of every XCD only (the
         rings made for it afterwards; lw_decoder_set_cu_share).  Returns the compute units its batches are planned for."""

@@ -18,6 +18,9 @@ ap.add_argument("--streams", type=int, default=256)
 ap.add_argument("--slots", type=int, default=3)
 ap.add_argument("--callers", type=int, default=1, help="host threads, each with its own ring and its own streams")
 ap.add_argument("--device-entropy", action="store_true", help="ship the packets, entropy stage in k_entropy")
+ap.add_argument("--shared-device", action="store_true",
+                help="lw_decoder_set_shared_device: several rings on this GPU (--callers > 1, or other processes): copies by the copier thread")
+ap.add_argument("--start-at", type=float, default=0.0, help="unix time to start the timed part at (two processes side by side)")
 args = ap.parse_args()
 
 setup = sg.stereo_setup(44100, 8, 11)
@@ -26,6 +29,12 @@ ident = header.read_header_ident(idp)
 st = header.read_header_setup(stp, 2, (8, 11))
 dec = audio.decoder_for(ident, st, 0)
 pool = sg.make_stream(setup, "L", 512, seed=9)
+if args.shared_device:
+    dec.set_shared_device(True)
+if args.start_at:
+    import time
+    e2e.measure(dec, pool, 16, args.packets, args.streams, args.threads, args.slots, args.callers, device_entropy=args.device_entropy)
+    time.sleep(max(0.0, args.start_at - time.time()))
 r = e2e.measure(dec, pool, args.batches, args.packets, args.streams, args.threads, args.slots, args.callers,
                 device_entropy=args.device_entropy)
 print(json.dumps(r))
