@@ -269,7 +269,10 @@ int lw_decoder_device(const lw_decoder *d);
  * back.  The wave-pipeline kernels take whole compute units, so without a share a 15 us launch next to another tenant's
  * long-running kernel waits for CUs to drain (130-700 us measured; 28 us flat on a half-device share).  Throughput is the
  * same either way (the PCIe link is the bound), so the sharder leaves it off.  Batches launched on a caller's own stream
- * (lw_batch_synth) are planned for the share but run wherever that stream runs.  LW_ERR_UNSUPPORTED: parts > 32. */
+ * (lw_batch_synth) are planned for the share but run wherever that stream runs.  LW_ERR_UNSUPPORTED: parts > 32.
+ * Known hazard of the HIP runtime this was measured on (ROCm 7.2): a process that has BOTH copied on the copier's own stream (a
+ * flagged decoder without a share) AND run CU-masked streams was seen not to exit, one run in three; keep the two kinds of
+ * decoder in different processes. */
 int lw_decoder_set_shared_device(lw_decoder *d, int on);
 int lw_decoder_set_cu_share(lw_decoder *d, unsigned part, unsigned parts);
 int lw_decoder_cu_count(const lw_decoder *d); /* compute units this decoder's launches are planned for */
