@@ -48,6 +48,13 @@ def test_batch_entropy_threads_agree_under_tsan(harness, tmp_path, name, pattern
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "check ok: 384 packets" in out.stdout
+    if (name, pattern) == ("stereo", "L"):
+        # lw_batch_algorithmic_bytes / lw_batch_state_bytes: 12 streams x 32 long packets, the first of each without a previous
+        # window (no samples, audio.rs:1140-1152); nothing stored comes in, every stream leaves 2 x 1024 floats behind.  Floor
+        # bytes: 2 + 2 per post used (21 posts here), an unused floor still costs its record
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("bytes ")][0].split()
+        assert int(line[2]) == 12 * 2 * 1024 * 4
+        assert int(line[1]) == 384 * (8192 + 132) + (384 - 12) * 4096
 
 
 @pytest.mark.parametrize("name,pattern", [("stereo", "LLSSLSL"), ("surround51", "LSSLL"), ("mono_small", "SLLSL"),

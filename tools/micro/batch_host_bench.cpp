@@ -96,6 +96,9 @@ int main(int argc, char **argv)
 		};
 		Snap ref;
 		snap(1, ref);
+		// SURVEY 8(d) bytes of the batch, and the window state crossing HBM at its launch boundary (every stream was reset: nothing
+		// comes in, every stream whose last packet decoded leaves its right part behind)
+		printf("bytes %llu %llu\n", (unsigned long long)lw_batch_algorithmic_bytes(b), (unsigned long long)lw_batch_state_bytes(b));
 		if (getenv("LW_HOST_BENCH_DUMP"))
 			for (size_t k = 0; k < NP; k++)
 				printf("R %d %u %llu\n", ref.res[k].status, ref.res[k].n_samples, (unsigned long long)ref.res[k].out_offset);
