@@ -228,7 +228,7 @@ def test_two_tenants_on_one_gpu():
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tenants_worker.py")
     p = subprocess.Popen([sys.executable, worker, "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        out, err = p.communicate(timeout=240)
+        out, err = p.communicate(timeout=90)
     except subprocess.TimeoutExpired:
         p.kill()
         out, err = p.communicate()
