@@ -469,6 +469,11 @@ size_t lw_debug_fast_image(const lw_ident *id, const lw_setup *s, uint8_t *dst, 
 size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, int blockflag, uint8_t *dst, size_t cap, uint8_t *units8,
 		size_t *n_units, uint32_t *lanes);
 
+/* Census hook (host only, no GPU needed): which synthesis kernels the blocks of this stream shape are routed to, and the reason
+ * where a faster one does not apply, as one line of text: "long=<kernel> | short=<kernel> | transitions=<how long blocks with a short
+ * slope are done> | entropy=<device | host (why)>".  Returns the length of the whole text; copies at most cap - 1 characters. */
+size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, size_t cap);
+
 /* Library/version introspection */
 const char *lw_version(void);
 /* Host threads the entropy stage uses when a call passes n_threads <= 0: the CPUs this process may run on (hardware

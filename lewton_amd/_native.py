@@ -101,6 +101,7 @@ SYMBOLS = {
     "lw_huffman_check": (C.c_int, [u8p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, szp]),
     "lw_debug_imdct": (C.c_int, [C.c_void_p, C.c_int, f32p, f32p]),
     "lw_debug_fast_image": (C.c_size_t, [C.c_void_p, C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "lw_debug_plan_census": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]),
     "lw_debug_short_image": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_int, u8p, C.c_size_t, u8p, szp, C.POINTER(C.c_uint32)]),
     "lw_batch_create": (C.c_void_p, [C.c_void_p, C.c_size_t, C.c_int, intp]),
     "lw_batch_destroy": (None, [C.c_void_p]),

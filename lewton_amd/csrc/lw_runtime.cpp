@@ -316,6 +316,73 @@ size_t lw_debug_short_image(const lw_ident *id, const lw_setup *s, int blockflag
 	return plan.image.size();
 }
 
+size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, size_t cap)
+{
+	if (!id || !s)
+		return 0;
+	const lw::Ident &I = *id->p;
+	const lw::Setup &S = *s->p;
+	LwFastPlan fast;
+	lw::build_fast_plan(I, S, fast);
+	LwShortPlan blk[2];
+	lw::build_blk_plan(I, S, false, fast, blk[0]);
+	lw::build_blk_plan(I, S, true, fast, blk[1]);
+	bool any_long = false, any_short = false;
+	for (const lw::Mode &m : S.modes)
+		(m.blockflag ? any_long : any_short) = true;
+	auto blk_name = [](const LwShortPlan &p) -> std::string {
+		if (p.lanes > 64)
+			return p.lanes == 128 ? "k_big<12>" : "k_big<13>";
+		return "k_short<" + std::to_string(p.lanes) + ">";
+	};
+	// the routing of lw_batch_entropy (csrc/lw_batch.cpp), per block class
+	std::string lng, sht, edge = "none";
+	bool use_l10 = false;
+	if (!any_long)
+		lng = "none";
+	else if (fast.eligible)
+		lng = "k_long";
+	else if (blk[1].eligible) {
+		if (blk[1].lanes == 32 && blk[1].units.size() <= LW_FAST_WAVES) {
+			lng = "k_long10";
+			use_l10 = true;
+		} else if (blk[1].lanes == 128 && !blk[1].units_split.empty() && !blk[1].image.empty())
+			lng = "k_long12";
+		else
+			lng = blk_name(blk[1]);
+	} else
+		lng = std::string("generic (") + (I.bs1 == LW_FAST_BS ? fast.why_not : blk[1].why_not) + ")";
+	if (!any_short)
+		sht = "none";
+	else if (blk[0].eligible) {
+		if (!any_long && blk[0].lanes == 32 && I.bs0 == I.bs1 && !fast.eligible && blk[0].units.size() <= LW_FAST_WAVES)
+			sht = "k_long10";
+		else
+			sht = blk_name(blk[0]);
+	} else
+		sht = std::string("generic (") + blk[0].why_not + ")";
+	if (any_long && any_short) { // long blocks with a short slope
+		const bool short_ok10 = use_l10 && blk[0].eligible && (blk[0].bs == 8 || blk[0].bs == 9);
+		if ((fast.eligible && blk[0].eligible && blk[0].bs == 8) || short_ok10)
+			edge = "edge form";
+		else if (fast.eligible)
+			edge = "k_long + k_ola_generic";
+		else
+			edge = "generic";
+	}
+	lw::DevEntropyImage img;
+	const char *why = "";
+	const bool dev = lw::dev_entropy_build(I, S, floor_stride_of(S), img, &why);
+	const std::string out = "long=" + lng + " | short=" + sht + " | transitions=" + edge + " | entropy=" +
+		(dev ? std::string("device") : std::string("host (") + why + ")");
+	if (dst && cap) {
+		const size_t n = std::min(cap - 1, out.size());
+		std::memcpy(dst, out.data(), n);
+		dst[n] = 0;
+	}
+	return out.size();
+}
+
 int lw_huffman_check(const uint8_t *lengths, size_t n_entries, const uint8_t *bits, size_t bits_len, uint32_t *syms,
 		size_t max_syms, size_t *n_syms)
 {

@@ -879,3 +879,482 @@ def ogg_stream(setup: StreamSetup, audio_packets: Sequence[bytes], sample_counts
         out.append(ogg_page(chunk, serial, seq, gp - (final_trim if last else 0), eos=last))
         seq += 1
     return b"".join(out)
+
+
+# --------------------------------------------------------------------------------------------
+# random setup headers (round 6): draws from the whole space src/header.rs accepts -- floors :771-918 (2 .. 65 posts, any
+# distinct x list, multipliers 1-4, class / subclass structures with and without master books, floor 0 mixed in), residues
+# :922-981 (types 0/1/2, begin > 0, end below / above the vector, partition sizes that the books' dimensions do not divide,
+# class books of 1-4 words, sparse cascades), mappings :985-1058 (any coupling list incl. a channel in several steps and
+# chains, 1-3 submaps), modes :1060-1080 (several long / short modes with their own mappings), codebooks :673-768 (ordered
+# and sparse length lists, lookup types 1 and 2, sequence_p, entry counts that are no power of the lookup values, one-entry
+# books).  Every draw is legal: a setup the product's parser rejects is a finding, not noise.
+# --------------------------------------------------------------------------------------------
+
+
+def _rand_lengths(rng, weights, max_len):
+    n = len(weights)
+    if n == 1:
+        return [1]
+    need = int(np.ceil(np.log2(n))) + 1
+    return huffman_lengths(np.asarray(weights, np.float64) + 1e-300, max(max_len, need))
+
+
+def _finish_book(rng, cb: Codebook, allow_sparse=True) -> Codebook:
+    """Randomise how the length list is coded: ordered (lengths sorted ascending -- any order of a complete set of lengths is a
+    complete tree), sparse with unused entries, or plain."""
+    r = rng.random()
+    n = len(cb.lengths)
+    if r < 0.15 and n >= 2:
+        cb.lengths = sorted(cb.lengths)
+        cb.ordered = True
+    elif r < 0.25 and allow_sparse:
+        cb.sparse = True          # the sparse flag with every entry used
+    return cb
+
+
+def random_scalar_book(rng, entries: int, max_len: int = 0, sparse_ok: bool = False) -> Codebook:
+    """A book that is only read for its entry NUMBER (floor-1 Y values, floor class master books, residue class words)."""
+    entries = max(1, int(entries))
+    max_len = max_len or int(rng.choice([6, 10, 16, 24, 32]))
+    used = np.ones(entries, bool)
+    if sparse_ok and entries >= 4 and rng.random() < 0.3:
+        used = rng.random(entries) < 0.7
+        used[int(rng.integers(0, entries))] = True
+        if used.sum() < 2:
+            used[:2] = True
+    shape = rng.random()
+    if shape < 0.6:
+        w = np.exp(-np.arange(entries) / max(0.7, entries * float(rng.uniform(0.08, 0.5))))
+    elif shape < 0.85:
+        w = np.ones(entries)
+    else:
+        w = rng.random(entries) ** 4 + 1e-4
+    ls = np.zeros(entries, int)
+    ls[used] = _rand_lengths(rng, w[used], max_len)
+    cb = Codebook(dims=int(rng.choice([1, 1, 1, 2, 3])), lengths=[int(x) for x in ls])
+    if not used.all():
+        cb.sparse = True
+        return cb
+    return _finish_book(rng, cb)
+
+
+def random_vq_book(rng, small: bool = False) -> Codebook:
+    """A book with a vector lookup (residue passes, floor-0 coefficients)."""
+    max_len = int(rng.choice([8, 12, 16, 20, 32]))
+    if rng.random() < 0.04:                              # one entry: one bit per codeword, either value (huffman_tree.rs:202-217)
+        dims = int(rng.choice([1, 2, 4, 8]))
+        return Codebook(dims=dims, lengths=[1], lookup_type=2, minimum=-1.0, delta=0.5, value_bits=3,
+                        multiplicands=[int(x) for x in rng.integers(0, 5, dims)])
+    cap = 600 if small else 4096
+    if rng.random() < 0.7:
+        dims = int(rng.choice([1, 2, 2, 2, 4, 4, 4, 8, 8, 3, 5, 6, 12]))
+        nv_max = max(1, int(np.floor(cap ** (1.0 / dims) + 1e-9)))
+        while (nv_max + 1) ** dims <= cap:
+            nv_max += 1
+        nv = int(rng.integers(max(1, min(2, nv_max)), min(nv_max, 17) + 1))
+        entries = nv ** dims
+        if rng.random() < 0.25 and nv >= 2 and (nv + 1) ** dims - entries > 1:   # more entries than lookup_values ^ dims: the index wraps (header.rs:504)
+            entries += int(rng.integers(1, min(9, (nv + 1) ** dims - entries)))
+        delta = float(rng.choice([1.0, 1.0, 0.5, 0.25, 2.0]))
+        order = np.arange(nv)
+        if rng.random() < 0.2:
+            rng.shuffle(order)
+        seq = rng.random() < 0.12
+        vmin = -delta * (nv // 2) if not seq else -delta * float(rng.integers(0, 3))
+        if rng.random() < 0.15:
+            vmin += delta * float(rng.integers(-2, 3))
+        vals = vmin + order * delta
+        e = np.arange(entries)
+        l1 = np.zeros(entries)
+        for d in range(dims):
+            l1 += np.abs(vals[(e // (nv ** d)) % nv])
+        w = np.exp(-l1 / (delta * float(rng.uniform(0.6, 2.5))))
+        cb = Codebook(dims=dims, lengths=_rand_lengths(rng, w, max_len), lookup_type=1, minimum=float(vmin), delta=delta,
+                      value_bits=max(1, ilog(int(order.max()))) + int(rng.integers(0, 3)), sequence_p=seq,
+                      multiplicands=[int(x) for x in order])
+        return _finish_book(rng, cb)
+    dims = int(rng.choice([1, 2, 3, 4, 8]))
+    entries = int(rng.integers(2, 257 if not small else 65))
+    delta = float(rng.choice([1.0, 0.5, 0.25]))
+    table = rng.integers(-8, 9, (entries, dims)) * delta
+    if rng.random() < 0.5:
+        table = np.where(rng.random((entries, dims)) < 0.5, 0.0, table)
+    vmin = float(table.min())
+    mult = np.rint((table - vmin) / delta).astype(int).reshape(-1)
+    used = np.ones(entries, bool)
+    if entries >= 4 and rng.random() < 0.25:
+        used = rng.random(entries) < 0.75
+        used[:2] = True
+    w = np.exp(-np.abs(table).sum(axis=1) / (delta * 3.0))
+    ls = np.zeros(entries, int)
+    ls[used] = _rand_lengths(rng, w[used], max_len)
+    cb = Codebook(dims=dims, lengths=[int(x) for x in ls], lookup_type=2, minimum=vmin, delta=delta,
+                  value_bits=max(1, ilog(int(mult.max()))), multiplicands=[int(m) for m in mult])
+    if not used.all():
+        cb.sparse = True
+        return cb
+    return _finish_book(rng, cb)
+
+
+def _random_x_rest(rng, count: int, rangebits: int) -> List[int]:
+    hi = (1 << rangebits) - 1            # legal values 1 .. hi, all distinct (header.rs:885-900)
+    assert count <= hi
+    if count == 0:
+        return []
+    if rng.random() < 0.5 or count * 3 > hi:
+        xs = rng.choice(np.arange(1, hi + 1), size=count, replace=False)
+    else:                                # dense at the low end, like an encoder's lists
+        seen = set()
+        while len(seen) < count:
+            v = int(np.exp(rng.uniform(0.0, np.log(hi + 0.999))))
+            if 1 <= v <= hi:
+                seen.add(v)
+        xs = np.array(sorted(seen))
+        rng.shuffle(xs)
+    return [int(x) for x in xs]
+
+
+def random_floor1(rng, books: List[Codebook], bs: int, posts: Optional[int] = None) -> Floor1:
+    """`books` is appended to.  `posts`: total post count F (2 .. 65); default random."""
+    if posts is None:
+        r = rng.random()
+        posts = int(2 if r < 0.04 else rng.integers(3, 9) if r < 0.2 else rng.integers(9, 33) if r < 0.65 else
+                    rng.integers(33, 65) if r < 0.93 else 65)
+    rest = posts - 2
+    dims_list = []
+    while rest > 0:
+        lo = max(1, rest - 8 * (30 - len(dims_list)))      # at most 31 partitions (5-bit count)
+        d = int(rng.integers(lo, min(8, rest) + 1))
+        dims_list.append(d)
+        rest -= d
+    mult = int(rng.integers(1, 5))
+    range_ = [256, 128, 86, 64][mult - 1]
+    # classes: one or more per distinct dimension, at most 16
+    class_dim, class_sub, class_master, sub_books = [], [], [], []
+    by_dim = {}
+    for d in sorted(set(dims_list)):
+        for _ in range(int(rng.integers(1, 3)) if len(class_dim) + len(set(dims_list)) < 14 else 1):
+            if len(class_dim) == 16:
+                break
+            by_dim.setdefault(d, []).append(len(class_dim))
+            cbits = int(rng.choice([0, 0, 1, 1, 2, 3]))
+            class_dim.append(d)
+            class_sub.append(cbits)
+            if cbits:
+                ent = int(rng.choice([1 << min(8, cbits * d), int(rng.integers(1, 40))]))
+                class_master.append(len(books))
+                books.append(random_scalar_book(rng, max(1, ent), sparse_ok=True))
+            else:
+                class_master.append(0)
+            sb = []
+            for _j in range(1 << cbits):
+                if rng.random() < 0.25:
+                    sb.append(-1)
+                else:
+                    r = rng.random()
+                    ent = int(rng.choice([4, 8, 16, 32]) if r < 0.6 else range_ if r < 0.9 else rng.integers(range_, 2 * range_ + 40))
+                    sb.append(len(books))
+                    books.append(random_scalar_book(rng, ent, sparse_ok=True))
+            sub_books.append(sb)
+    perm = list(range(len(class_dim)))
+    rng.shuffle(perm)                                        # class numbers in no particular order
+    inv = {old: new for new, old in enumerate(perm)}
+    class_dim = [class_dim[o] for o in perm]
+    class_sub = [class_sub[o] for o in perm]
+    class_master = [class_master[o] for o in perm]
+    sub_books = [sub_books[o] for o in perm]
+    pcs = [inv[int(rng.choice(by_dim[d]))] for d in dims_list]
+    rb_min = max(1, ilog(posts - 2)) if posts > 2 else 0
+    r = rng.random()
+    rangebits = int(bs - 1 if r < 0.6 else rng.integers(rb_min, 16) if r < 0.8 else max(rb_min, bs - 2) if r < 0.9 else min(15, bs))
+    rangebits = max(rangebits, rb_min)
+    return Floor1(partition_class=pcs, class_dim=class_dim, class_sub=class_sub, class_master=class_master,
+                  sub_books=sub_books, multiplier=mult, rangebits=rangebits, x_rest=_random_x_rest(rng, posts - 2, rangebits))
+
+
+def random_floor0(rng, books: List[Codebook], bs: int, sample_rate: int) -> Floor0:
+    """Floor type 0 with coefficient books whose vectors ascend, so that the LSP angles stay inside (0, pi) for the order drawn
+    (audio.rs:131-147: the last element of a vector advances the running offset) and the curve stays finite."""
+    order = int(rng.integers(2, 17))
+    n_books = int(rng.integers(1, 4))
+    bl = []
+    for _ in range(n_books):
+        dims = int(rng.choice([1, 2, 3, 4]))
+        per_vec = 3.0 / max(1.0, np.ceil(order / dims) + 1.0)           # the offsets of ceil(order / dims) vectors stay below pi
+        ent = int(rng.integers(4, 65))
+        tab = np.round(np.sort(rng.uniform(0.2 * per_vec, per_vec, (ent, dims)), axis=1) * 64) / 64
+        bl.append(len(books))
+        books.append(vq_table_book(dims, tab, delta=1 / 64, max_len=int(rng.choice([8, 16]))))
+    half = (1 << bs) // 2
+    return Floor0(order=order, rate=sample_rate, bark_map_size=int(rng.choice([max(2, half // 4), max(2, half // 2), half, 2 * half, 37])),
+                  amplitude_bits=int(rng.integers(2, 9)), amplitude_offset=int(rng.integers(8, 40)), book_list=bl,
+                  amp_max=int(rng.integers(1, 4)))
+
+
+def random_residue(rng, books: List[Codebook], vq_pool: List[int], bs: int, ch_sub: int) -> Residue:
+    rtype = int(rng.choice([0, 1, 2, 2]))
+    size = ((1 << bs) // 2) * (ch_sub if rtype == 2 else 1)
+    r = rng.random()
+    begin = 0 if r < 0.6 else int(rng.integers(1, max(2, size // 4))) if r < 0.95 else size + int(rng.integers(0, 50))
+    r = rng.random()
+    end = (int(size * rng.uniform(0.4, 1.0)) if r < 0.6 else size if r < 0.7 else size + int(rng.integers(1, 5000)) if r < 0.85
+           else int(rng.integers(0, size + 1)) if r < 0.97 else (1 << 24) - 1)
+    end = max(end, begin)
+    if rng.random() < 0.03:
+        end = begin
+    r = rng.random()
+    psize = int(rng.choice([4, 8, 16, 32, 64]) if r < 0.6 else rng.integers(1, 65) if r < 0.93 else rng.integers(65, 400))
+    ncls = int(rng.choice([1, 2, 3, 4, 4, 5, 8, 10, 16]))
+    words = int(rng.choice([1, 2, 2, 3, 4]))
+    while ncls ** words > 4096:
+        words -= 1
+    ent = ncls ** words
+    r = rng.random()
+    if r < 0.15:
+        ent += int(rng.integers(1, 20))                    # entries above classifications ^ words: the digits still come out in range
+    elif r < 0.25 and ent > 2:
+        ent -= int(rng.integers(1, max(2, ent // 3)))
+    cbk = random_scalar_book(rng, ent)
+    cbk.dims = words
+    classbook = len(books)
+    books.append(cbk)
+    rows = []
+    p_bit = float(rng.choice([0.15, 0.3, 0.5]))
+    for _c in range(ncls):
+        row = [-1] * 8
+        if rng.random() > 0.2:                             # (a class without any book: a silent partition)
+            for p in range(7):
+                if rng.random() < p_bit / (1 + 0.5 * p):
+                    row[p] = int(rng.choice(vq_pool))
+            if rng.random() < 0.04 and books[0].lookup_type:
+                row[7] = 0                                 # the cascade's bit 7: no book number is read for it, book 0 is used (header.rs:449-466)
+        rows.append(row)
+    return Residue(rtype, begin, end, psize, ncls, classbook, rows)
+
+
+def random_coupling(rng, channels: int) -> List[Tuple[int, int]]:
+    if channels < 2:
+        return []
+    r = rng.random()
+    if r < 0.2:
+        return []
+    if r < 0.6:                                            # disjoint pairs, some channels left out
+        chans = list(range(channels))
+        rng.shuffle(chans)
+        n = int(rng.integers(1, channels // 2 + 1))
+        steps = [(chans[2 * i], chans[2 * i + 1]) for i in range(n)]
+        rng.shuffle(steps)
+        return [(int(m), int(a)) for m, a in steps]
+    if r < 0.75 and channels >= 3:                         # a chain: 0-1, 1-2, ...
+        n = int(rng.integers(2, channels))
+        return [(i, i + 1) if rng.random() < 0.5 else (i + 1, i) for i in range(n)]
+    steps = []
+    for _ in range(int(rng.integers(1, channels + 2))):   # anything legal: repeated pairs, a channel in several steps
+        m = int(rng.integers(0, channels))
+        a = int(rng.integers(0, channels - 1))
+        steps.append((m, a if a < m else a + 1))
+    return steps
+
+
+_RANDOM_BS = [(8, 11)] * 7 + [(8, 10), (9, 10), (8, 9), (9, 12), (10, 12), (8, 12), (8, 13), (6, 13), (7, 7), (6, 9), (6, 6), (11, 11),
+                              (10, 10), (9, 11), (10, 11), (7, 10), (6, 8), (13, 13), (12, 13), (7, 12)]
+
+
+def random_setup(rng, channels: Optional[int] = None, blocksizes: Optional[Tuple[int, int]] = None, allow_floor0: bool = True
+                 ) -> StreamSetup:
+    """One draw from the space of legal ident + setup headers (see the section comment).  `rng`: numpy Generator."""
+    bs0, bs1 = blocksizes if blocksizes else _RANDOM_BS[int(rng.integers(0, len(_RANDOM_BS)))]
+    if channels is None:
+        channels = int(rng.choice([1, 2, 2, 2, 2, 3, 4, 5, 6, 6, 7, 8]))
+    if channels * (1 << bs1) >= 65536:                     # audio.rs:745: blocksize * channels as u16 (type-2 residues)
+        channels = 65535 // (1 << bs1)
+    sample_rate = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
+    books: List[Codebook] = []
+    vq_pool = []
+    for _ in range(int(rng.integers(3, 9))):
+        vq_pool.append(len(books))
+        books.append(random_vq_book(rng))
+    n_modes = int(rng.choice([1, 2, 2, 2, 2, 3, 3, 4, 6]))
+    flags = [int(rng.integers(0, 2)) for _ in range(n_modes)]
+    if n_modes >= 2 and rng.random() < 0.85:
+        flags[0], flags[1] = (0, 1) if rng.random() < 0.7 else (1, 0)
+    if bs0 == bs1 and rng.random() < 0.5:
+        flags = [0] * n_modes                              # what libvorbis writes for equal block sizes
+    floors, residues, mappings, modes = [], [], [], []
+    floor_of_class = {0: [], 1: []}
+    res_of_class = {0: [], 1: []}
+
+    def new_floor(bf):
+        bs = bs1 if bf else bs0
+        if allow_floor0 and rng.random() < 0.06:
+            fl = random_floor0(rng, books, bs, sample_rate)
+        else:
+            fl = random_floor1(rng, books, bs)
+        floors.append(fl)
+        floor_of_class[bf].append(len(floors) - 1)
+        return len(floors) - 1
+
+    def new_residue(bf, ch_sub):
+        residues.append(random_residue(rng, books, vq_pool, bs1 if bf else bs0, max(1, ch_sub)))
+        res_of_class[bf].append(len(residues) - 1)
+        return len(residues) - 1
+
+    map_of_class = {0: [], 1: []}
+    for md in range(n_modes):
+        bf = flags[md]
+        if map_of_class[bf] and rng.random() < 0.45:       # several modes may share a mapping
+            modes.append(Mode(bf, int(rng.choice(map_of_class[bf]))))
+            continue
+        nsub = int(rng.choice([1, 1, 1, 2, 2, 3]))
+        nsub = min(nsub, 16)
+        mux = [int(rng.integers(0, nsub)) for _ in range(channels)] if nsub > 1 else [0] * channels
+        sf, sr = [], []
+        for sm in range(nsub):
+            ch_sub = sum(1 for c in mux if c == sm)
+            reuse_f = floor_of_class[bf] and rng.random() < 0.4 and len(floors) < 12
+            any_f = floors and rng.random() < 0.08        # (a floor made for the other block size: legal)
+            sf.append(int(rng.choice(floor_of_class[bf])) if reuse_f else int(rng.integers(0, len(floors))) if any_f else new_floor(bf))
+            reuse_r = res_of_class[bf] and rng.random() < 0.3
+            any_r = residues and rng.random() < 0.08
+            sr.append(int(rng.choice(res_of_class[bf])) if reuse_r else int(rng.integers(0, len(residues))) if any_r else new_residue(bf, ch_sub))
+        mappings.append(Mapping(random_coupling(rng, channels), mux, sf, sr))
+        map_of_class[bf].append(len(mappings) - 1)
+        modes.append(Mode(bf, len(mappings) - 1))
+    assert len(books) <= 256
+    return StreamSetup(channels, sample_rate, bs0, bs1, books, floors, residues, mappings, modes)
+
+
+class RandomPacketWriter(PacketWriter):
+    """PacketWriter for arbitrary setups: symbols are drawn from the USED entries of whatever book the setup names."""
+
+    def __init__(self, setup: StreamSetup, seed: int = 0, p_floor_unused: float = 0.05, p_zero_y: float = 0.6, loud: float = 1.0):
+        super().__init__(setup, seed, p_floor_unused=p_floor_unused, p_zero_y=p_zero_y)
+        self.loud = loud
+
+    def _draw_y(self, book: int):
+        cb = self.s.codebooks[book]
+        used = cb.used_entries()
+        if self.rng.random() < self.p_zero_y and cb.lengths[0] > 0:
+            return 0
+        if self.rng.random() < 0.9:
+            small = [e for e in used if e <= 12]
+            if small:
+                return int(self.rng.choice(small))
+        return int(self.rng.choice(used))
+
+    def _floor1(self, w: BitWriter, fl: Floor1) -> bool:
+        if self.rng.random() < self.p_unused:
+            w.write(0, 1)
+            return False
+        w.write(1, 1)
+        rng_ = [256, 128, 86, 64][fl.multiplier - 1]
+        b = ilog(rng_ - 1)
+        r = self.rng.random()
+        for _ in range(2):
+            if r < 0.9:
+                v = int(np.clip(self.rng.integers(45, 96) * rng_ / 128.0 * self.loud, 0, rng_ - 1))
+            else:
+                v = int(self.rng.integers(0, 1 << b))       # anything the field can hold (86 .. 127 with range 86: clamped at the end)
+            w.write(v, b)
+        for c in fl.partition_class:
+            cdim, cbits = fl.class_dim[c], fl.class_sub[c]
+            cval = 0
+            if cbits:
+                mb = fl.class_master[c]
+                cval = int(self.rng.choice(self.s.codebooks[mb].used_entries()))
+                self._huff(w, mb, cval)
+            for _ in range(cdim):
+                book = fl.sub_books[c][cval & ((1 << cbits) - 1)]
+                cval >>= cbits
+                if book >= 0:
+                    self._huff(w, book, self._draw_y(book))
+        return True
+
+    def _residue(self, w: BitWriter, rs: Residue, n: int, dnd: List[bool]):
+        ch = len(dnd)
+        if rs.type == 2:
+            if all(dnd):
+                return
+            n = (n * ch) & 0xFFFF                           # audio.rs:745
+            dnd = [False]
+            ch = 1
+        size = n // 2
+        begin, end = min(rs.begin, size), min(rs.end, size)
+        if end - begin == 0:
+            return
+        parts = (end - begin) // rs.partition_size
+        classbook = self.s.codebooks[rs.classbook]
+        cpc = classbook.dims
+        ncls = rs.classifications
+        cls = np.zeros((max(1, ch), parts + cpc), np.int64)
+        for p_ in range(8):
+            pc = 0
+            while pc < parts:
+                if p_ == 0:
+                    for j in range(ch):
+                        if dnd[j]:
+                            continue
+                        sym = int(self._draw_vq_entries(rs.classbook, 1)[0])
+                        t = sym
+                        for i in range(cpc - 1, -1, -1):
+                            cls[j, pc + i] = t % ncls
+                            t //= ncls
+                        self._huff(w, rs.classbook, sym)
+                for _ in range(cpc):
+                    if pc >= parts:
+                        break
+                    for j in range(ch):
+                        if dnd[j]:
+                            continue
+                        book = rs.books[int(cls[j, pc])][p_]
+                        if book >= 0:
+                            cb = self.s.codebooks[book]
+                            offs = begin + pc * rs.partition_size
+                            if rs.type == 0:
+                                cnt = rs.partition_size // cb.dims
+                            else:
+                                cnt, i = 0, 0
+                                while i < rs.partition_size:
+                                    cnt += 1
+                                    if i + cb.dims > size - offs:
+                                        break
+                                    i += cb.dims
+                            for e in self._draw_vq_entries(book, cnt):
+                                self._huff(w, book, int(e))
+                    pc += 1
+
+
+def random_stream(setup: StreamSetup, rng, count: int, seed: int = 0, p_floor_unused: float = 0.05, p_odd_flags: float = 0.03,
+                  p_damage: float = 0.0) -> List[bytes]:
+    """`count` audio packets of one stream of a random_setup(): runs of short and long blocks with window flags that fit the
+    neighbours (sometimes not: legal), the mode drawn among the setup's modes of that block flag; `p_damage`: share of packets
+    truncated or bit-flipped afterwards."""
+    pw = RandomPacketWriter(setup, seed, p_floor_unused=p_floor_unused)
+    by_flag = {0: [i for i, m in enumerate(setup.modes) if not m.blockflag], 1: [i for i, m in enumerate(setup.modes) if m.blockflag]}
+    kinds = [f for f in (0, 1) if by_flag[f]]
+    seq = []
+    while len(seq) < count:
+        f = int(rng.choice(kinds))
+        seq += [f] * int(rng.choice([1, 1, 2, 3, 5, 8, 9, 17]))
+    seq = seq[:count]
+    out = []
+    for i, f in enumerate(seq):
+        mode = int(rng.choice(by_flag[f]))
+        if not f:
+            out.append(pw.packet(mode))
+            continue
+        pf = 1 if (i == 0 or seq[i - 1]) else 0
+        nf = 1 if (i + 1 >= count or seq[i + 1]) else 0
+        if rng.random() < p_odd_flags:
+            pf, nf = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        out.append(pw.packet(mode, pf, nf))
+    for i in range(count):
+        r = rng.random()
+        if r < p_damage / 2 and len(out[i]) > 2:
+            out[i] = out[i][: int(rng.integers(1, len(out[i])))]
+        elif r < p_damage and len(out[i]):
+            p = bytearray(out[i])
+            p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8))
+            out[i] = bytes(p)
+    return out

@@ -38,6 +38,10 @@ class BadFormat(Exception):
     pass
 
 
+class IsHeader(BadFormat):
+    """the packet's first bit says "header packet" (AudioReadError::AudioIsHeader, audio.rs:923)"""
+
+
 class Bits:
     """LSb-first bit reader: the packet as one Python integer."""
 
@@ -212,7 +216,9 @@ class Residue:
             lo = b.read(3)
             hi = b.read(5) if b.bit() else 0
             casc.append(hi * 8 + lo)
-        self.books = [[(b.read(8) if (c >> p) & 1 else None) for p in range(8)] for c in casc]
+        # book numbers are coded for cascade bits 0..6 only; bit 7 set means "book 0" with nothing read (the reference's
+        # ResidueBook::read_book loops over 0..7 exclusive, header.rs:449-466 / SURVEY 9.7)
+        self.books = [[((b.read(8) if p < 7 else 0) if (c >> p) & 1 else None) for p in range(8)] for c in casc]
 
 
 class Stream:
@@ -338,7 +344,10 @@ def imdct(X, t):
         u[4 * i + hi] = p * A[a + t0] - q * A[a + t1]
         u[4 * i + lo] = q * A[a + t0] + p * A[a + t1]
     ld = n.bit_length() - 1
-    for l in range(0, ld - 6):
+    # stages l = 0 and 1 are called whatever the block size (imdct.rs:445-452; SURVEY 8c's caveat): 128-point blocks get both
+    # (one more than the ld - 6 of the transform's definition), 64-point blocks stage 0 only -- stage 1's loop handles four
+    # butterflies per turn and has n / 128 turns (imdct.rs:95: `lim >> 2`), none for n = 64.  This is what lewton computes.
+    for l in range(0, max(ld - 6, 1 if ld == 6 else 2)):
         k0, k1 = n >> (l + 2), 1 << (l + 3)
         s = np.arange(1 << (l + 1))[:, None]
         r = np.arange(n >> (l + 4))[None, :]
@@ -412,7 +421,7 @@ class Decoder:
         s = self.s
         b = Bits(packet)
         if b.bit():
-            raise BadFormat("header packet")
+            raise IsHeader("header packet")
         mode = b.read(ilog(len(s.modes) - 1))
         if mode >= len(s.modes):
             raise BadFormat("mode")

@@ -32,6 +32,8 @@ def _compare(ident_pkt, setup_pkt, packets, expect_errors=False):
             g_err = None
         except ind.EndOfPacket:
             g_err = po.AUDIO_END_OF_PACKET
+        except ind.IsHeader:
+            g_err = po.AUDIO_IS_HEADER
         except ind.BadFormat:
             g_err = po.AUDIO_BAD_FORMAT
         assert (o_err is None) == (g_err is None), (i, o_err, g_err)
