@@ -1074,22 +1074,23 @@ def random_floor1(rng, books: List[Codebook], bs: int, posts: Optional[int] = No
 
 
 def random_floor0(rng, books: List[Codebook], bs: int, sample_rate: int) -> Floor0:
-    """Floor type 0 with coefficient books whose vectors ascend, so that the LSP angles stay inside (0, pi) for the order drawn
-    (audio.rs:131-147: the last element of a vector advances the running offset) and the curve stays finite."""
+    """Floor type 0 with coefficient books made for its order: element i of a vector is (i + 1 +- 0.3) steps of pi / (order + 1),
+    and the last element of a vector advances the running offset (audio.rs:131-147), so the LSP angles ascend, stay inside
+    (0, pi) and the roots of P and Q interlace -- p + q stays away from zero and the curve finite, as for an encoder's streams."""
     order = int(rng.integers(2, 17))
+    step = np.pi / (order + 1)
     n_books = int(rng.integers(1, 4))
     bl = []
     for _ in range(n_books):
         dims = int(rng.choice([1, 2, 3, 4]))
-        per_vec = 3.0 / max(1.0, np.ceil(order / dims) + 1.0)           # the offsets of ceil(order / dims) vectors stay below pi
         ent = int(rng.integers(4, 65))
-        tab = np.round(np.sort(rng.uniform(0.2 * per_vec, per_vec, (ent, dims)), axis=1) * 64) / 64
+        tab = np.round((np.arange(1, dims + 1)[None, :] + rng.uniform(-0.3, 0.3, (ent, dims))) * step * 256) / 256
         bl.append(len(books))
-        books.append(vq_table_book(dims, tab, delta=1 / 64, max_len=int(rng.choice([8, 16]))))
+        books.append(vq_table_book(dims, tab, delta=1 / 256, max_len=int(rng.choice([8, 16]))))
     half = (1 << bs) // 2
     return Floor0(order=order, rate=sample_rate, bark_map_size=int(rng.choice([max(2, half // 4), max(2, half // 2), half, 2 * half, 37])),
-                  amplitude_bits=int(rng.integers(2, 9)), amplitude_offset=int(rng.integers(8, 40)), book_list=bl,
-                  amp_max=int(rng.integers(1, 4)))
+                  amplitude_bits=int(rng.integers(4, 9)), amplitude_offset=int(rng.integers(8, 21)), book_list=bl,
+                  amp_max=int(rng.integers(1, 3)))
 
 
 def random_residue(rng, books: List[Codebook], vq_pool: List[int], bs: int, ch_sub: int) -> Residue:

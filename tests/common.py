@@ -61,6 +61,15 @@ FLOOR0_SETUPS = {
 }
 
 
+def f32_identical(a, b):
+    """bit-identical f32 arrays, except that a NaN equals a NaN: sign and payload of a NaN an operation produces are not
+    fixed by IEEE 754 (x86 makes 0xFFC00000, gfx950 0x7FC00000), so lewton itself differs between platforms there"""
+    a, b = np.asarray(a, np.float32).reshape(-1), np.asarray(b, np.float32).reshape(-1)
+    if a.size != b.size:
+        return False
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
 def oracle_headers(setup):
     idp, cmt, stp = setup.headers()
     ident = po.Ident(idp)

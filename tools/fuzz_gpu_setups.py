@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+from common import f32_identical  # noqa: E402
+
 FMTS = ["i16", "f32", "i16_interleaved"]
 OFMT = {"i16": "i16", "f32": "f32", "i16_interleaved": "i16_itl"}
 DISTINCT = 3          # distinct packet sequences generated per setup (stream s carries sequence s % DISTINCT)
@@ -124,8 +126,7 @@ def run_setup(seed, ch, idp, stp, seqs, packets, rng, mods):
                     if rc:
                         continue
                     g = pcm[i]
-                    same = g.size == w.size and (np.array_equal(g.reshape(-1).view(np.uint32), w.reshape(-1).view(np.uint32))
-                                                 if fmt == "f32" else np.array_equal(g.reshape(-1), w.reshape(-1)))
+                    same = g.size == w.size and (f32_identical(g, w) if fmt == "f32" else np.array_equal(g.reshape(-1), w.reshape(-1)))
                     if not same:
                         bad = -1
                         if g.size == w.size:
@@ -139,7 +140,7 @@ def run_setup(seed, ch, idp, stp, seqs, packets, rng, mods):
         for name, _bt in paths:
             for s in range(n_streams):
                 o, g = want[s % DISTINCT][1], pws[name][s].data()
-                same = (o is None) == (g is None) and (o is None or np.array_equal(g.view(np.uint32), o.view(np.uint32)))
+                same = (o is None) == (g is None) and (o is None or f32_identical(g, o))
                 if not same:
                     print("STATE MISMATCH setup %d (%s path) stream %d\n  %s" % (seed, name, s, line))
                     raise SystemExit(1)
