@@ -303,6 +303,13 @@ bool dev_entropy_build(const Ident &id, const Setup &s, unsigned fstride, DevEnt
 	img.fstride = fstride;
 	img.ws_bytes = (uint32_t)((LW_ENT_POSTS_BYTES + cls_bytes + 15) & ~(size_t)15);
 	img.res_floats = (uint32_t)(ch * (n1 / 2));
+	// one wave = one packet with its accumulators, dump slots and work space in LDS (lw_launch_entropy): what does not fit a
+	// workgroup's 160 KB (many channels of 8192-point blocks, or residues cut into thousands of tiny partitions, whose class digits
+	// are the work space) keeps the host stage -- found by the random-setup campaign: the launch failed with "invalid argument"
+	if (((size_t)img.res_floats + LW_ENT_DUMP_FLOATS) * 4 + img.ws_bytes > LW_ENT_MAX_LDS) {
+		*why = "accumulators and class digits of a packet exceed a workgroup's LDS";
+		return false;
+	}
 	return true;
 }
 

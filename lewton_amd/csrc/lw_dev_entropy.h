@@ -72,6 +72,7 @@ typedef uint8_t *LwEntFlags;
 #define LW_K
 #endif
 #define LW_ENT_DUMP_FLOATS 64u // device: one dump slot per lane behind the accumulators
+#define LW_ENT_MAX_LDS (160u * 1024u - 64u) // dynamic LDS k_entropy may ask for (hipFuncAttributeMaxDynamicSharedMemorySize)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LW_ENT_ROW_UNIT 4u // a lane's place in a codeword's vector row is kept as a byte offset
 // a lane's accumulator is kept as its LDS byte address

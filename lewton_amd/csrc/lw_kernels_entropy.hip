@@ -60,9 +60,9 @@ hipError_t lw_launch_entropy(const LwEntTables &T, const LwEntPacket *d_pk, cons
 	static LwPerDeviceOnce once;
 	{
 		const hipError_t e = once.run([] {
-			hipError_t r = hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+			hipError_t r = hipFuncSetAttribute((const void *)k_entropy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LW_ENT_MAX_LDS);
 			if (r == hipSuccess)
-				r = hipFuncSetAttribute((const void *)k_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+				r = hipFuncSetAttribute((const void *)k_entropy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LW_ENT_MAX_LDS);
 			return r;
 		});
 		if (e != hipSuccess)

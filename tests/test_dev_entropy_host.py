@@ -78,3 +78,32 @@ def test_real_encoder_stream_is_eligible_and_identical(harness, tmp_path):
     out = subprocess.run([harness, case, "300", "9"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "device entropy algorithm == host entropy stage" in out.stdout, out.stdout
+
+
+def test_random_setups_device_algorithm_equals_host_stage(harness, tmp_path):
+    """round 6: setup headers drawn at random (streamgen.random_setup): wherever the device entropy stage is eligible its
+    per-packet algorithm must equal the host stage -- floors of 2..65 posts with any class structure, every residue shape, books
+    of both lookup types, sparse / ordered / one-entry books -- incl. cut and bit-flipped packets; ineligible setups say why."""
+    import numpy as np
+    n_eligible = 0
+    for seed in range(2000, 2040):
+        rng = np.random.default_rng(seed)
+        setup = sg.random_setup(rng)
+        idp, _, stp = setup.headers()
+        pk = sg.random_stream(setup, rng, 10, seed=seed)
+        case = str(tmp_path / "case.bin")
+        with open(case, "wb") as f:
+            f.write(struct.pack("<I", 1))
+            for b in (idp, stp):
+                f.write(struct.pack("<I", len(b)) + bytes(b))
+            f.write(struct.pack("<I", len(pk)))
+            for p in pk:
+                f.write(struct.pack("<I", len(p)) + bytes(p))
+        out = subprocess.run([harness, case, "4", str(seed)], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (seed, out.stdout[-2000:] + out.stderr[-4000:])
+        if "not eligible" in out.stdout:
+            assert any(isinstance(fl, sg.Floor0) for fl in setup.floors) or "LDS" in out.stdout, (seed, out.stdout)
+            continue
+        assert "device entropy algorithm == host entropy stage" in out.stdout, (seed, out.stdout)
+        n_eligible += 1
+    assert n_eligible >= 25

@@ -175,7 +175,11 @@ def main():
     by_field = {k: collections.Counter() for k in ("long", "short", "transitions", "entropy")}
     by_kernel = collections.Counter()
     for seed, ch, idp, stp, seqs in it:
-        checked, kernels, line, dev = run_setup(seed, ch, idp, stp, seqs, args.packets, rng, mods)
+        try:
+            checked, kernels, line, dev = run_setup(seed, ch, idp, stp, seqs, args.packets, rng, mods)
+        except RuntimeError as e:      # a library call failed: name the setup
+            print("ERROR setup %d: %s" % (seed, e), flush=True)
+            raise SystemExit(1)
         n_streams, length = shape_of(seed, args.packets)
         total += checked
         n_dev += dev
