@@ -54,7 +54,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		return at;
 	};
 	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
-	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(3 * max_packets * sizeof(uint32_t));
+	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(4 * max_packets * sizeof(uint32_t));
 	const size_t o_ola = slice(max_packets * sizeof(LwOlaDesc));
 	const size_t o_tasks = slice(max_packets * ch * sizeof(LwGenTask));
 	// k_short: at most two slots per short packet (a recomputed predecessor in front of it) plus one per long block with a
@@ -125,7 +125,7 @@ void lw_batch_destroy(lw_batch *b)
 	for (void *p : ent)
 		if (p)
 			(void)hipFree(p);
-	void *dev[] = {b->d_slab, b->d_edge, b->d_decoupled, b->d_td, b->d_tap, b->d_out, b->d_halo};
+	void *dev[] = {b->d_slab, b->d_edge, b->d_decoupled, b->d_floor_alt, b->d_td, b->d_tap, b->d_out, b->d_halo};
 	for (void *p : dev)
 		if (p)
 			(void)hipFree(p);
@@ -367,6 +367,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	b->has_generic = b->has_fast = false;
 	b->n_gen_small = b->n_gen_large = b->n_gen_ola = 0;
 	b->has_tdonly = false;
+	b->n_prep = 0;
 	for (int cls = 0; cls < 2; cls++) {
 		b->blk_idx[cls].clear();
 		b->blk_slot[cls].clear();
@@ -399,6 +400,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	const bool short_ok = (d->fast.eligible && blk_ok[0] && d->blkp[0].bs == 8) || short_ok10;
 	b->edge_mode = false; // set when the batch has a long block with a short slope (an all-(1,1) batch keeps the plain k_long)
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
+	// equal block sizes with a flagged mode: one block shape (full slopes on both sides whatever the flags say), one class -- every
+	// packet is planned as a long block between long blocks (lw_unified_classes)
+	const bool unified = lw::lw_unified_classes(id, s);
 	for (size_t i = 0; i < n; i++) {
 		LwPacketRec &r = b->h_recs[i];
 		lw_packet_result &res = b->results[i];
@@ -411,7 +415,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			continue;
 		}
 		lw_pwr *pw = pkts[i].pwr;
-		const lw::Prologue &p = b->prologues[i];
+		lw::Prologue &p = b->prologues[i];
+		if (unified)
+			p.blockflag = p.prev_flag = p.next_flag = true; // (same window geometry, same tables: window_info below)
 		const lw::WindowInfo w = lw::window_info(id, p.blockflag, p.prev_flag, p.next_flag);
 		r.bs = p.bs;
 		r.mode = p.mode;
@@ -492,6 +498,8 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			b->blk_idx[0].push_back((uint32_t)i);
 			b->blk_slot[0].push_back((uint32_t)pw->slot);
 		}
+		if ((r.flags & LW_RF_FAST) && d->h_prep_mode[p.mode]) // its stream shape goes through the canonicalising pre-pass first
+			b->h_gen[3 * b->max_packets + b->n_prep++] = (uint32_t)i;
 		pw->present = true;
 		pw->len = w.right_end - w.right_start;
 		b->slot_last[pw->slot] = (int32_t)i;
@@ -896,6 +904,9 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	if (b->n_gen_ola)
 		HIP_TRY(hipMemcpyAsync(b->d_gen + 2 * b->max_packets, b->h_gen + 2 * b->max_packets, b->n_gen_ola * sizeof(uint32_t),
 					hipMemcpyHostToDevice, st));
+	if (b->n_prep)
+		HIP_TRY(hipMemcpyAsync(b->d_gen + 3 * b->max_packets, b->h_gen + 3 * b->max_packets, b->n_prep * sizeof(uint32_t),
+					hipMemcpyHostToDevice, st));
 	if (b->n_gen_ola)
 		HIP_TRY(hipMemcpyAsync(b->d_ola, b->h_ola, b->n_gen_ola * sizeof(LwOlaDesc), hipMemcpyHostToDevice, st));
 	if (b->n_gen_small)
@@ -941,11 +952,14 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
 		HIP_TRY(hipMalloc((void **)&b->d_td, 2 * maxres * sizeof(float)));
 	}
-	if (run_generic) {
+	const bool run_prep = b->n_prep > 0 && !all_generic;
+	if (run_generic || run_prep) {
 		const size_t maxres = b->max_packets * d->T.ch * d->T.state_chan_stride;
-		if (d->any_coupling && !b->d_decoupled)
+		if (((run_generic && d->any_coupling) || run_prep) && !b->d_decoupled)
 			HIP_TRY(hipMalloc((void **)&b->d_decoupled, maxres * sizeof(float)));
-		if (!b->d_td)
+		if (run_prep && d->prep_floors && !b->d_floor_alt)
+			HIP_TRY(hipMalloc((void **)&b->d_floor_alt, b->max_packets * d->T.ch * d->T.fstride * sizeof(uint16_t)));
+		if (run_generic && !b->d_td)
 			HIP_TRY(hipMalloc((void **)&b->d_td, 2 * maxres * sizeof(float)));
 	}
 	if (run_fast && b->n_halo_items > b->halo_cap) {
@@ -982,6 +996,21 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 			return rc;
 		b->last_kernels = "k_entropy,";
 	}
+	// the block classes whose stream shape the specialised kernels do not take as it is: k_prep writes their packets' residues after
+	// every coupling step (x floor curve where the floor cannot be staged) and, if so, their floor records with the unit floor; those
+	// classes' kernels then read the second pair of buffers (Bc[class])
+	LwBatchDev Bc[2] = {B, B};
+	if (run_prep) {
+		HIP_TRY(lw_launch_prep(d->T, B, b->d_gen + 3 * b->max_packets, b->n_prep, d->d_prep_action, d->prep_floors ? b->d_floor_alt : nullptr, st));
+		b->last_kernels += "k_prep,";
+		for (int cls = 0; cls < 2; cls++)
+			if (d->prep_cls[cls]) {
+				Bc[cls].residue = b->d_decoupled;
+				if (d->prep_floors)
+					Bc[cls].floors = b->d_floor_alt;
+			}
+	}
+	const int fast_cls = b->use_l10 ? b->l10_cls : 1; // the block class of the wave-pipeline kernel's packets
 	if (run_generic) {
 		HIP_TRY(lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic));
 		b->last_kernels += d->any_coupling && (!d->T.pair_coupling || tap) ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
@@ -1031,20 +1060,21 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	};
 	// a mixed short / long batch small enough for the chip to hold at once: both kernels' work in ONE launch (k_mix)
 	bool mixed = false;
-	if (run_fast && !b->use_l10 && !b->use_l12 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
+	const bool same_bufs = !run_prep || d->prep_cls[0] == d->prep_cls[1]; // (one launch for both classes: one pair of buffers)
+	if (run_fast && !b->use_l10 && !b->use_l12 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge && same_bufs) {
 		const LwShortLaunch S = short_launch(0);
 		if (lw_mix_applicable(L, S, d->n_cus)) {
 			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * lw_edge_values(d));
-			HIP_TRY(lw_launch_mix(d->T, B, L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
+			HIP_TRY(lw_launch_mix(d->T, Bc[1], L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
 			b->last_kernels += b->n_halo_items ? "k_long<halo>,k_mix," : "k_mix,";
 			mixed = true;
 		}
 	}
-	if (run_fast && b->use_l10 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge) {
+	if (run_fast && b->use_l10 && run_short && b->mix_mode != 0 && !b->n_tasks[1] && b->n_tasks[0] && b->d_edge && same_bufs) {
 		const LwShortLaunch S = short_launch(0);
 		if (lw_mix10_applicable(L, S, d->n_cus)) { // a mixed batch the chip holds at once: long and short blocks in ONE launch (k_mix10)
 			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * lw_edge_values(d));
-			HIP_TRY(lw_launch_mix10(d->T, B, L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
+			HIP_TRY(lw_launch_mix10(d->T, Bc[1], L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
 			b->last_kernels += b->n_halo_items ? "k_long10<halo>,k_mix10," : "k_mix10,";
 			mixed = true;
 		}
@@ -1052,13 +1082,13 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	if (run_fast && b->use_l10 && mixed) {
 		// (done above)
 	} else if (run_fast && b->use_l10) {
-		HIP_TRY(lw_launch_long10(d->T, B, L, d_out, b->fmt, st));
+		HIP_TRY(lw_launch_long10(d->T, Bc[fast_cls], L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long10<halo>,k_long10," : "k_long10,";
 	} else if (run_fast && b->use_l12) {
-		HIP_TRY(lw_launch_long12(d->T, B, L, d_out, b->fmt, st));
+		HIP_TRY(lw_launch_long12(d->T, Bc[1], L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long12<halo>,k_long12," : "k_long12,";
 	} else if (run_fast && !mixed) {
-		HIP_TRY(lw_launch_long(d->T, B, L, d_out, b->fmt, st));
+		HIP_TRY(lw_launch_long(d->T, Bc[1], L, d_out, b->fmt, st));
 		b->last_kernels += b->n_halo_items ? "k_long<halo>,k_long," : "k_long,";
 	}
 	if (run_short && !mixed)
@@ -1067,10 +1097,10 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 				continue;
 			const LwShortLaunch S = short_launch(cls);
 			if (S.lanes > 64) {
-				HIP_TRY(lw_launch_big(d->T, B, S, d_out, b->fmt, st));
+				HIP_TRY(lw_launch_big(d->T, Bc[cls], S, d_out, b->fmt, st));
 				b->last_kernels += "k_big,";
 			} else {
-				HIP_TRY(lw_launch_short(d->T, B, S, d_out, b->fmt, st));
+				HIP_TRY(lw_launch_short(d->T, Bc[cls], S, d_out, b->fmt, st));
 				b->last_kernels += "k_short,";
 			}
 		}

@@ -22,62 +22,128 @@ struct Writer {
 };
 } // namespace
 
-// The unit list of the modes with `blockflag` (shared by k_long and k_short): every such mode must use the same mapping shape
-// (mux, floors, coupling), coupling steps must be disjoint channel pairs, at most LW_FAST_MAX_FLOORS distinct floor-1
-// configurations of at most max_posts posts.  Returns nullptr, or why the stream shape is not covered.
+// The unit list of the modes with `blockflag` (shared by every specialised kernel).  Native shape: every such mode uses the same
+// coupling list of disjoint channel pairs and the same floor per channel, at most LW_FAST_MAX_FLOORS distinct floor-1
+// configurations of at most max_posts posts -- the units then are the coupling steps plus the remaining channels two by two.
+// Every other shape gets the canonicalising pre-pass (LwPrepPlan, lw_fast.hpp): uncoupled units, the channels whose floor the
+// kernels cannot stage on the unit floor.  Returns nullptr, or why the stream shape is not covered at all.
 struct UnitPlan {
-	const Mapping *ref = nullptr;
 	std::vector<LwFastUnit> units;
 	std::vector<int> floor_slot; // per floor of the setup: staged slot or -1
-	uint32_t n_staged = 0;
+	uint32_t n_staged = 0;       // staged slots incl. the unit floor's
 	uint8_t staged_F[LW_FAST_MAX_FLOORS] = {0};
 	uint8_t mode_mask[32] = {0};
+	LwPrepPlan prep;
 };
+
+// blocksize_0 = blocksize_1 and a mode with the block flag: the two flags then name the same block shape (one size, full slopes on
+// both sides whatever the window flags say, audio.rs:1056-1073), and every mode of the stream is served as ONE class, the long one
+bool lw_unified_classes(const Ident &id, const Setup &s)
+{
+	if (id.bs0 != id.bs1)
+		return false;
+	for (const Mode &m : s.modes)
+		if (m.blockflag)
+			return true;
+	return false;
+}
 
 static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, size_t max_posts, UnitPlan &up)
 {
-	const size_t ch = id.channels;
-	// every covered mode must use the same mapping shape: same mux/floors/coupling
-	const Mapping *ref = nullptr;
-	for (size_t m = 0; m < s.modes.size() && m < 256; m++) {
-		if ((bool)s.modes[m].blockflag != blockflag)
-			continue;
-		const Mapping &mp = s.mappings[s.modes[m].mapping];
-		if (!ref)
-			ref = &mp;
-		else if (mp.mag != ref->mag || mp.ang != ref->ang || mp.mux != ref->mux || mp.submap_floor != ref->submap_floor)
-			return blockflag ? "long modes with different mappings" : "short modes with different mappings";
-		up.mode_mask[m >> 3] |= (uint8_t)(1u << (m & 7));
-	}
-	if (!ref)
+	const size_t ch = id.channels, nmodes = s.modes.size();
+	const bool unified = lw_unified_classes(id, s);
+	std::vector<size_t> modes;
+	for (size_t m = 0; m < nmodes && m < 256; m++)
+		if ((bool)s.modes[m].blockflag == blockflag || (unified && blockflag)) {
+			modes.push_back(m);
+			up.mode_mask[m >> 3] |= (uint8_t)(1u << (m & 7));
+		}
+	if (modes.empty())
 		return blockflag ? "no long mode" : "no short mode";
-	up.ref = ref;
-	// coupling steps must be disjoint pairs
+	if ((ch + 1) / 2 > LW_FAST_WAVES)
+		return "more units than waves in a workgroup";
+	const Mapping &ref = s.mappings[s.modes[modes[0]].mapping];
+	auto floor_of = [&](size_t m, size_t c) -> int {
+		const Mapping &mp = s.mappings[s.modes[m].mapping];
+		return (int)mp.submap_floor[mp.mux[c]];
+	};
+	// coupling: native when every covered mode has the reference list and its steps are disjoint pairs
+	const char *why = nullptr;
 	std::vector<int> partner(ch, -1), role(ch, 0);
-	for (size_t k = 0; k < ref->mag.size(); k++) {
-		const int m = ref->mag[k], a = ref->ang[k];
+	for (size_t k = 0; k < ref.mag.size() && !why; k++) {
+		const int m = ref.mag[k], a = ref.ang[k];
 		if (partner[m] != -1 || partner[a] != -1)
-			return "a channel takes part in more than one coupling step";
+			why = "a channel takes part in more than one coupling step";
 		partner[m] = a;
 		partner[a] = m;
 		role[m] = 1;
 		role[a] = 2;
 	}
-	// staged floors
-	up.floor_slot.assign(s.floors.size(), -1);
-	auto slot_of = [&](size_t c) -> int {
-		const uint8_t fl = ref->submap_floor[ref->mux[c]];
-		if (up.floor_slot[fl] < 0) {
-			if (up.n_staged == LW_FAST_MAX_FLOORS)
-				return -1;
-			const Floor1 &f1 = s.floors[fl].f1;
-			if (s.floors[fl].type != 1 || f1.sorted_x.size() > max_posts)
-				return -1;
-			up.floor_slot[fl] = (int)up.n_staged;
-			up.staged_F[up.n_staged++] = (uint8_t)f1.sorted_x.size();
+	for (size_t m : modes) {
+		const Mapping &mp = s.mappings[s.modes[m].mapping];
+		if (!why && (mp.mag != ref.mag || mp.ang != ref.ang))
+			why = blockflag ? "long modes with different coupling lists" : "short modes with different coupling lists";
+	}
+	// floors: a channel is native when all covered modes give it the same floor-1 configuration of at most max_posts posts
+	std::vector<int> native(ch, -1);
+	std::vector<size_t> use(s.floors.size(), 0);
+	bool all_native = true;
+	for (size_t c = 0; c < ch; c++) {
+		const int fl = floor_of(modes[0], c);
+		bool same = true;
+		for (size_t m : modes)
+			same = same && floor_of(m, c) == fl;
+		if (!same) {
+			if (!why)
+				why = blockflag ? "long modes with different floors per channel" : "short modes with different floors per channel";
+		} else if (s.floors[fl].type != 1) {
+			if (!why)
+				why = "floor type 0";
+		} else if (s.floors[fl].f1.sorted_x.size() > max_posts) {
+			if (!why)
+				why = "a floor with more posts than the kernel's lanes take";
+		} else {
+			native[c] = fl;
+			use[fl]++;
+			continue;
 		}
-		return up.floor_slot[fl];
-	};
+		all_native = false;
+	}
+	std::vector<int> staged; // floors by use, most used first
+	for (size_t f = 0; f < s.floors.size(); f++)
+		if (use[f])
+			staged.push_back((int)f);
+	std::stable_sort(staged.begin(), staged.end(), [&](int a, int b) { return use[a] > use[b]; });
+	const bool need_unit = !all_native || staged.size() > LW_FAST_MAX_FLOORS;
+	if (staged.size() > LW_FAST_MAX_FLOORS && !why)
+		why = "more distinct floor configurations than the kernel stages";
+	const size_t keep = need_unit ? LW_FAST_MAX_FLOORS - 1 : LW_FAST_MAX_FLOORS;
+	if (staged.size() > keep)
+		staged.resize(keep);
+	up.floor_slot.assign(s.floors.size(), -1);
+	for (int f : staged) {
+		up.floor_slot[f] = (int)up.n_staged;
+		up.staged_F[up.n_staged++] = (uint8_t)s.floors[f].f1.sorted_x.size();
+	}
+	if (need_unit) {
+		up.prep.unit_slot = (int)up.n_staged;
+		up.staged_F[up.n_staged++] = 2;
+	}
+	std::vector<int> slot(ch, -1);
+	for (size_t c = 0; c < ch; c++)
+		slot[c] = native[c] >= 0 && up.floor_slot[native[c]] >= 0 ? up.floor_slot[native[c]] : up.prep.unit_slot;
+	up.prep.on = why != nullptr;
+	up.prep.why = why ? why : "";
+	if (up.prep.on) {
+		up.prep.action.assign(nmodes * ch, LW_PREP_NONE);
+		for (size_t m : modes)
+			for (size_t c = 0; c < ch; c++) {
+				const bool pm = slot[c] == up.prep.unit_slot && up.prep.unit_slot >= 0;
+				up.prep.action[m * ch + c] = pm ? LW_PREP_PREMUL : LW_PREP_COPY;
+				up.prep.premul = up.prep.premul || pm;
+			}
+		std::fill(partner.begin(), partner.end(), -1); // every coupling step is k_prep's
+	}
 	// Units: a coupling step's two channels share a wave (the inverse coupling needs both); the channels that are in no step
 	// are paired up two by two as well, without coupling -- a wave works through two channels as one software pipeline, a
 	// single channel leaves half of it empty (5.1: two coupled pairs + one uncoupled pair = 3 waves per packet instead of 4).
@@ -111,10 +177,7 @@ static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, s
 			pending_single = -1;
 			done[c] = true;
 		}
-		const int sa = slot_of((size_t)u.ch_a), sb = u.ch_b >= 0 ? slot_of((size_t)u.ch_b) : 0;
-		if (sa < 0 || sb < 0)
-			return blockflag ? "more than two distinct floor configurations (or > 64 posts) in long blocks"
-			                 : "more than two distinct floor configurations (or > 32 posts) in short blocks";
+		const int sa = slot[(size_t)u.ch_a], sb = u.ch_b >= 0 ? slot[(size_t)u.ch_b] : 0;
 		u.floor_a = (uint8_t)sa;
 		u.floor_b = (uint8_t)sb;
 		u.F_a = up.staged_F[sa];
@@ -124,6 +187,15 @@ static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, s
 	if (up.units.size() > LW_FAST_WAVES)
 		return "more units than waves in a workgroup";
 	return nullptr;
+}
+
+// xsf / sid16 of the unit floor (LwPrepPlan): posts at x = 0 and x = n / 2, every bin in interval 0
+static void fill_unit_floor(float *xsf64, uint16_t *sid, size_t n_sid, uint32_t n2)
+{
+	for (size_t i = 0; i < 64; i++)
+		xsf64[i] = i == 0 ? 0.0f : i == 1 ? (float)n2 : std::numeric_limits<float>::infinity();
+	for (size_t i = 0; i < n_sid; i++)
+		sid[i] = 0;
 }
 
 void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
@@ -141,6 +213,7 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 	}
 	std::memcpy(plan.long_mode_mask, up.mode_mask, sizeof(plan.long_mode_mask));
 	plan.units = up.units;
+	plan.prep = up.prep;
 	// the same units with every channel pair split over two waves
 	for (const LwFastUnit &u : up.units) {
 		if (u.ch_b < 0) {
@@ -255,6 +328,8 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 					w.h(o.sid16)[((slot * 4 + x) * 64 + l) * 4 + j] = (uint16_t)(16 * sidx);
 				}
 	}
+	if (up.prep.unit_slot >= 0)
+		fill_unit_floor(w.f(o.xsf) + 64 * up.prep.unit_slot, w.h(o.sid16) + (size_t)up.prep.unit_slot * 4 * 64 * 4, 4 * 64 * 4, n2);
 	const size_t quantum = 1024;
 	o.total = (uint32_t)((plan.image.size() + quantum - 1) / quantum * quantum);
 	plan.image.resize(o.total, 0);
@@ -271,7 +346,7 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 namespace {
 // the LDS image of k_short<L> (index conventions of lw_fast.hpp: l = lane inside the block, 0 .. L-1)
 template <int L>
-void fill_blk_image(const BlocksizeTables &t, const Setup &s, const std::vector<int> &floor_slot, std::vector<uint8_t> &image)
+void fill_blk_image(const BlocksizeTables &t, const Setup &s, const std::vector<int> &floor_slot, int unit_slot, std::vector<uint8_t> &image)
 {
 	typedef LwBlkLayout<L> Y;
 	const uint32_t P = 8u * L, n = 4u * P, n2 = n / 2, n8 = n / 8;
@@ -351,6 +426,8 @@ void fill_blk_image(const BlocksizeTables &t, const Setup &s, const std::vector<
 					h(Y::SID16)[((slot * 4 + x) * L + l) * 4 + j] = (uint16_t)(16 * sidx);
 				}
 	}
+	if (unit_slot >= 0)
+		fill_unit_floor(f(Y::XSF) + 64 * unit_slot, h(Y::SID16) + (size_t)unit_slot * 4 * L * 4, 4 * L * 4, n2);
 }
 } // namespace
 
@@ -381,7 +458,7 @@ void split_units(const std::vector<LwFastUnit> &units, std::vector<LwFastUnit> &
 }
 
 // the LDS image and the HBM interval table of k_long12 (LwL12Layout)
-void fill_l12_image(const BlocksizeTables &t, const Setup &s, const std::vector<int> &floor_slot, std::vector<uint8_t> &image,
+void fill_l12_image(const BlocksizeTables &t, const Setup &s, const std::vector<int> &floor_slot, int unit_slot, std::vector<uint8_t> &image,
 		std::vector<uint8_t> &sid)
 {
 	typedef LwL12Layout Y;
@@ -449,6 +526,8 @@ void fill_l12_image(const BlocksizeTables &t, const Setup &s, const std::vector<
 					h[((slot * 8 + x) * 64 + l) * 4 + j] = (uint16_t)(16 * sidx);
 				}
 	}
+	if (unit_slot >= 0)
+		fill_unit_floor(f(Y::XSF) + 64 * unit_slot, h + (size_t)unit_slot * 8 * 64 * 4, 8 * 64 * 4, n2);
 }
 } // namespace
 
@@ -460,8 +539,8 @@ void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFas
 		plan.why_not = "long blocks run through k_long";
 		return;
 	}
-	if (blockflag && id.bs1 == id.bs0) {
-		plan.why_not = "blocksize_1 = blocksize_0: the two block classes are neighbours with full overlap (generic kernels)";
+	if (!blockflag && lw_unified_classes(id, s)) {
+		plan.why_not = "blocksize_0 = blocksize_1: served with the long blocks";
 		return;
 	}
 	const bool big = blockflag && bs >= LW_BIG_MIN_BS && bs <= LW_BIG_MAX_BS; // k_big<BS>: a workgroup of n / 32 threads per block
@@ -473,13 +552,17 @@ void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFas
 	plan.lanes = 1u << (bs - 5);
 	plan.passes = big ? LW_BIG_MAX_PASSES : plan.lanes == 32 ? 3 : plan.lanes == 16 ? 2 : 1;
 	UnitPlan up;
-	if (const char *why = plan_units(id, s, blockflag, big ? 65 : LW_BLK_MAX_POSTS(plan.lanes), up)) {
+	// (4096 points: k_long12 takes a floor's posts as the lanes of one wave, at most 64 -- a floor of 65 goes on the unit floor)
+	if (const char *why = plan_units(id, s, blockflag, big ? (bs == 12 ? 64 : 65) : LW_BLK_MAX_POSTS(plan.lanes), up)) {
 		plan.why_not = why;
 		return;
 	}
+	plan.prep = up.prep;
 	for (size_t fl = 0; fl < up.floor_slot.size(); fl++)
 		if (up.floor_slot[fl] >= 0)
 			plan.fl_of[up.floor_slot[fl]] = (uint32_t)fl;
+	if (up.prep.unit_slot >= 0) // (k_big reads the posts' x from T.floor_x: the unit floors are rows n_floors + block class there)
+		plan.fl_of[up.prep.unit_slot] = (uint32_t)(s.floors.size() + (blockflag ? 1 : 0));
 	std::memcpy(plan.short_mode_mask, up.mode_mask, sizeof(plan.short_mode_mask));
 	plan.units = up.units;
 	plan.n_staged_floors = up.n_staged;
@@ -491,7 +574,7 @@ void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFas
 				posts_ok = posts_ok && up.staged_F[i] <= 64;
 			split_units(up.units, plan.units_split);
 			if (posts_ok && plan.units_split.size() <= LW_FAST_WAVES)
-				fill_l12_image(id.tab[1], s, up.floor_slot, plan.image, plan.sid12);
+				fill_l12_image(id.tab[1], s, up.floor_slot, up.prep.unit_slot, plan.image, plan.sid12);
 			else
 				plan.units_split.clear();
 		}
@@ -500,11 +583,11 @@ void build_blk_plan(const Ident &id, const Setup &s, bool blockflag, const LwFas
 	}
 	const BlocksizeTables &t = id.tab[blockflag ? 1 : 0];
 	if (plan.lanes == 8)
-		fill_blk_image<8>(t, s, up.floor_slot, plan.image);
+		fill_blk_image<8>(t, s, up.floor_slot, up.prep.unit_slot, plan.image);
 	else if (plan.lanes == 16)
-		fill_blk_image<16>(t, s, up.floor_slot, plan.image);
+		fill_blk_image<16>(t, s, up.floor_slot, up.prep.unit_slot, plan.image);
 	else
-		fill_blk_image<32>(t, s, up.floor_slot, plan.image);
+		fill_blk_image<32>(t, s, up.floor_slot, up.prep.unit_slot, plan.image);
 	plan.eligible = true;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "lw_host.hpp"
+#include "lw_records.h"
 
 #include <cstdint>
 #include <vector>
@@ -67,9 +68,27 @@ struct LwFastUnit {
 };
 static_assert(sizeof(LwFastUnit) == 8, "LwFastUnit is loaded as one 8-byte scalar");
 
+// Canonicalising pre-pass (k_prep, lw_kernels.hip; round 6).  The wave-pipeline and block kernels take a stream shape in which every
+// covered mode has the same coupling list of disjoint channel pairs and the same floor per channel, at most LW_FAST_MAX_FLOORS distinct
+// floor-1 configurations of a bounded post count.  Every other legal shape (header.rs:985-1058: any coupling list; :1060-1080: modes
+// with their own mappings; :771-918: floor 0, 65 posts, many floor configurations) is brought to that form per packet by k_prep,
+// which writes a second residue buffer -- ALL coupling steps applied (audio.rs:990-1002), and, for the channels marked
+// LW_PREP_PREMUL, already multiplied with their floor curve (audio.rs:1035-1037) -- and a second floor buffer in which those
+// channels carry the UNIT floor (two posts at inverse-dB index 255 = 1.0: the kernel's own multiply is then exact), a synthetic
+// configuration staged next to the native ones.  The kernels run unchanged on units of uncoupled channel pairs.
+// (LW_PREP_*: lw_records.h)
+struct LwPrepPlan {
+	bool on = false;              // the class's packets go through k_prep
+	bool premul = false;          // some channel of some covered mode is LW_PREP_PREMUL: the kernels read the second floor buffer
+	int unit_slot = -1;           // staged slot of the unit floor, or -1
+	std::vector<uint8_t> action;  // [n_modes][ch] LW_PREP_*; rows of modes outside the class are LW_PREP_NONE
+	const char *why = "";         // what made the pre-pass necessary (census)
+};
+
 struct LwFastPlan {
 	bool eligible = false;
 	const char *why_not = "";
+	LwPrepPlan prep;
 	std::vector<uint8_t> image;
 	LwFastImage off{};
 	uint8_t long_mode_mask[32] = {0};        // bit m set: mode m is a long mode covered by the plan
@@ -203,6 +222,7 @@ struct LwL12Layout {
 struct LwShortPlan {
 	bool eligible = false;
 	const char *why_not = "";
+	LwPrepPlan prep;
 	uint32_t lanes = 0;            // L: lanes per block = 2^(bs - 5)
 	uint32_t passes = 1;           // most passes of 64 / L slots a wave may work through (more slots per recomputed predecessor where
 	                               // a wave holds few blocks: L = 32 -> 3, L = 16 -> 2); the planner picks per batch
@@ -279,6 +299,8 @@ static inline uint32_t lw_blk_inv_db_offset(uint32_t lanes)
 }
 
 namespace lw {
+// blocksize_0 = blocksize_1 and some mode has the block flag: all modes are planned (and routed, lw_batch.cpp) as the long class
+bool lw_unified_classes(const Ident &id, const Setup &s);
 // Decide whether the stream shape is covered by the specialised kernel and build its LDS image.
 void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan);
 // The same for k_short<L>: the blocks of the modes with `blockflag` (0: the short blocks; 1: the long blocks of a stream

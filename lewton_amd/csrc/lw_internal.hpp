@@ -69,6 +69,11 @@ struct lw_decoder {
 	LwShortPlan blkp[2];           // block kernel k_short<L>: [0] the short blocks, [1] the long blocks where k_long does not apply
 	uint8_t *d_blk_image[2] = {nullptr, nullptr};
 	uint16_t *d_l12_sid = nullptr; // k_long12: the static interval table of its floors (LwL12Layout::SID_BYTES, HBM)
+	// canonicalising pre-pass k_prep (LwPrepPlan): which block classes' packets go through it, the merged [n_modes][ch] action table
+	bool prep_cls[2] = {false, false};
+	bool prep_floors = false;      // some channel is LW_PREP_PREMUL: k_prep also writes the second floor buffer, the kernels read it
+	std::vector<uint8_t> h_prep_action, h_prep_mode;
+	uint8_t *d_prep_action = nullptr;
 	lw_batch *one = nullptr; // internal batch for lw_read_audio_packet
 	void *one_out = nullptr; // pinned host output for the single-packet path
 	size_t one_out_bytes = 0;
@@ -96,7 +101,7 @@ struct lw_batch {
 	float *h_fcurve = nullptr, *d_fcurve = nullptr; // explicit floor curves (floor 0), layout of the residues
 	// packets of the generic kernels, by size class (block size <= / > 2^9): dense launch grids instead of 8192
 	// workgroups that mostly find out they have nothing to do
-	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [3][max_packets]: small blocks, large blocks, k_ola_generic's packets
+	uint32_t *h_gen = nullptr, *d_gen = nullptr; // [4][max_packets]: small blocks, large blocks, k_ola_generic's packets, k_prep's packets
 	uint32_t n_gen_small = 0, n_gen_large = 0, n_gen_ola = 0;
 	LwGenTask *h_tasks = nullptr, *d_tasks = nullptr; // [max_packets * ch] tasks of the short-block transform kernel
 	LwOlaDesc *h_ola = nullptr, *d_ola = nullptr; // [max_packets] descriptors of k_ola_generic's tasks (order of the third list)
@@ -124,6 +129,8 @@ struct lw_batch {
 	uint16_t *d_floor = nullptr;
 	float *d_res = nullptr;
 	float *d_decoupled = nullptr, *d_td = nullptr, *d_tap = nullptr;
+	uint16_t *d_floor_alt = nullptr; // k_prep's floor records (layout of d_floor)
+	uint32_t n_prep = 0;             // packets of k_prep: the fourth list of h_gen / d_gen
 	void *d_out = nullptr;
 	size_t d_out_elems = 0;
 	LwFastItem *h_items = nullptr, *d_items = nullptr;           // [max_packets] main pass

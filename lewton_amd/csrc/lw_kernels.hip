@@ -83,6 +83,132 @@ __global__ void __launch_bounds__(LW_BLOCK) k_decouple(LwDevTables T, LwBatchDev
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_prep: the canonicalising pre-pass of the specialised kernels (LwPrepPlan, lw_fast.hpp; round 6).  One workgroup per listed
+// packet.  Out: B.decoupled = the packet's residue vectors after ALL coupling steps of its mode (audio.rs:990-1002, reverse
+// order), and for the channels whose action is LW_PREP_PREMUL already multiplied with their floor curve (audio.rs:1035-1037:
+// floor-1 curve by the closed form of render_line, SURVEY 9.3, or the host-evaluated floor-0 curve of B.fcurve);
+// floors_out (if given) = the packet's floor records with the UNIT floor (posts 0 and 1 active at inverse-dB index 255 = 1.0)
+// for those channels, a copy for the others.  An unused floor (audio.rs:1021-1024) stays marked: the kernels zero the channel.
+// Every thread owns the bins tid, tid + 256, ...: no synchronisation between the coupling and the multiply.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LW_ELEMENTWISE_BLOCK) k_prep(LwDevTables T, LwBatchDev B, const uint32_t *list, const uint8_t *action,
+		uint16_t *floors_out)
+{
+	__shared__ uint16_t px[LW_XSTRIDE];
+	__shared__ uint8_t py[LW_XSTRIDE + 2];
+	__shared__ uint8_t act[LW_XSTRIDE + 2];
+	__shared__ int s_K;
+	const uint32_t pkt = list[blockIdx.x];
+	const LwPacketRec rec = B.recs[pkt];
+	if (rec.flags & LW_RF_SKIP)
+		return;
+	const uint32_t tid = threadIdx.x, n2 = (1u << rec.bs) >> 1;
+	const uint32_t s0 = T.couple_off[rec.mode], s1 = T.couple_off[rec.mode + 1];
+	const float *src = B.residue + rec.res_off;
+	float *dst = B.decoupled + rec.res_off;
+	for (uint32_t k = tid; k < n2; k += blockDim.x) {
+		for (uint32_t c = 0; c < T.ch; c++)
+			dst[c * n2 + k] = src[c * n2 + k];
+		for (uint32_t s = s1; s-- > s0;) { // reverse step order, audio.rs:991-992
+			const uint32_t mi = T.couple[2 * s] * n2 + k, ai = T.couple[2 * s + 1] * n2 + k;
+			const float m = dst[mi], a = dst[ai];
+			float nm, na;
+			if (m > 0.0f) {
+				if (a > 0.0f) {
+					nm = m;
+					na = m - a;
+				} else {
+					nm = m + a;
+					na = m;
+				}
+			} else {
+				if (a > 0.0f) {
+					nm = m;
+					na = m + a;
+				} else {
+					nm = m - a;
+					na = m;
+				}
+			}
+			dst[mi] = nm;
+			dst[ai] = na;
+		}
+	}
+	const uint8_t *arow = action + (size_t)rec.mode * T.ch;
+	for (uint32_t c = 0; c < T.ch; c++) { // (every condition below is the same for all threads of the workgroup)
+		const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
+		uint16_t *fout = floors_out ? floors_out + rec.floor_off + c * T.fstride : nullptr;
+		const uint16_t e0 = frec[0];
+		if (arow[c] != LW_PREP_PREMUL || e0 == LW_FLOOR_UNUSED) {
+			if (fout)
+				for (uint32_t i = tid; i < T.fstride; i += blockDim.x)
+					fout[i] = frec[i];
+			continue;
+		}
+		float *v = dst + c * n2;
+		if (e0 == LW_FLOOR_EXPLICIT) { // floor 0: the curve evaluated by the host stage (audio.rs:160-212)
+			const float *fc = B.fcurve + rec.res_off + c * n2;
+			for (uint32_t k = tid; k < n2; k += blockDim.x)
+				v[k] = fc[k] * v[k];
+		} else {
+			// active posts in ascending x (audio.rs:536-545 walks exactly these), one thread per post
+			const uint32_t fl = T.mode_floor[rec.mode * T.ch + c], F = T.floor_F[fl];
+			uint16_t my_e = 0;
+			if (tid < F) {
+				my_e = frec[tid];
+				act[tid] = (my_e & LW_POST_ACTIVE) ? 1 : 0;
+			}
+			__syncthreads();
+			if (tid < F) {
+				int rank = 0;
+				for (uint32_t t = 0; t < tid; t++)
+					rank += act[t];
+				if (my_e & LW_POST_ACTIVE) {
+					px[rank] = T.floor_x[fl * LW_XSTRIDE + tid];
+					py[rank] = (uint8_t)(my_e & 0xff);
+				}
+				if (tid == F - 1)
+					s_K = rank + ((my_e & LW_POST_ACTIVE) ? 1 : 0);
+			}
+			__syncthreads();
+			const int K = s_K;
+			for (uint32_t k = tid; k < n2; k += blockDim.x) {
+				int lo = 0, hi = K - 1; // largest i with px[i] <= k
+				while (lo < hi) {
+					const int mid = (lo + hi + 1) >> 1;
+					if (px[mid] <= k)
+						lo = mid;
+					else
+						hi = mid - 1;
+				}
+				int y;
+				if (lo == K - 1) {
+					y = py[lo]; // flat extension to n/2, audio.rs:546-548
+				} else {
+					const int x0 = px[lo], x1 = px[lo + 1], y0 = py[lo], y1 = py[lo + 1];
+					const int dy = y1 - y0, adx = x1 - x0;
+					const int ady = dy < 0 ? -dy : dy;
+					const int off = (ady * ((int)k - x0)) / adx; // closed form of render_line
+					y = dy < 0 ? y0 - off : y0 + off;
+				}
+				v[k] = T.inv_db[y] * v[k];
+			}
+			__syncthreads(); // (px / py are rebuilt for the next channel)
+		}
+		if (fout && tid < 2)
+			fout[tid] = (uint16_t)(LW_POST_ACTIVE | 255u);
+	}
+}
+
+hipError_t lw_launch_prep(const LwDevTables &T, const LwBatchDev &B, const uint32_t *d_list, uint32_t n_list, const uint8_t *d_action,
+		uint16_t *d_floors_out, hipStream_t st)
+{
+	if (n_list == 0)
+		return hipSuccess;
+	return lw_launch_k(k_prep, dim3(n_list), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T, B, d_list, d_action, d_floors_out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // floor curve + multiply + IMDCT, one workgroup per (packet, channel)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bfly(float *u, uint32_t hi, uint32_t lo, float t0, float t1)

@@ -101,6 +101,11 @@ struct LwBatchDev {
 // (the launchers that opt a kernel into a large dynamic LDS segment return the result of that call)
 hipError_t lw_launch_generic_imdct(const LwDevTables &T, const LwBatchDev &B, float *tap_spec, hipStream_t st, uint32_t max_n,
 		bool any_coupling, bool include_fast);
+// Canonicalising pre-pass of the specialised kernels (k_prep, lw_kernels.hip; LwPrepPlan in lw_fast.hpp): for the n_list packets of
+// d_list, B.decoupled = residues after every coupling step (x floor curve for the channels d_action marks), d_floors_out (may be
+// null) = their floor records with the unit floor for those channels.
+hipError_t lw_launch_prep(const LwDevTables &T, const LwBatchDev &B, const uint32_t *d_list, uint32_t n_list, const uint8_t *d_action,
+		uint16_t *d_floors_out, hipStream_t st);
 // entropy stage on the device (lw_kernels_entropy.hip): floor records and residue vectors of n packets from their raw bytes
 struct LwEntTables;
 struct LwEntPacket;

@@ -21,6 +21,11 @@
 #define LW_FLOOR_EXPLICIT 0xFFFEu
 #define LW_POST_ACTIVE 0x8000u
 
+// per (mode, channel) action of the canonicalising pre-pass k_prep (LwPrepPlan, lw_fast.hpp)
+#define LW_PREP_NONE 0u    // the packet's mode is not one of a pre-passed block class
+#define LW_PREP_COPY 1u    // channel: residue after inverse coupling; its floor record as it is (evaluated by the kernel)
+#define LW_PREP_PREMUL 2u  // channel: residue after inverse coupling x floor curve; unit floor record
+
 // rec.flags
 #define LW_RF_LONG 1u          // mode blockflag
 #define LW_RF_SLOPE_BS1 2u     // overlap window slope comes from blocksize_1 (left_n_use_bs1, audio.rs:1058-1064)

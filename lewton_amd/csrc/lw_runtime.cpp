@@ -330,6 +330,8 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 	bool any_long = false, any_short = false;
 	for (const lw::Mode &m : S.modes)
 		(m.blockflag ? any_long : any_short) = true;
+	if (lw::lw_unified_classes(I, S))
+		any_short = false; // (equal block sizes: every mode is planned with the long blocks)
 	auto blk_name = [](const LwShortPlan &p) -> std::string {
 		if (p.lanes > 64)
 			return p.lanes == 128 ? "k_big<12>" : "k_big<13>";
@@ -352,6 +354,11 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 			lng = blk_name(blk[1]);
 	} else
 		lng = std::string("generic (") + (I.bs1 == LW_FAST_BS ? fast.why_not : blk[1].why_not) + ")";
+	{ // stream shapes the kernel takes only behind the canonicalising pre-pass (LwPrepPlan)
+		const LwPrepPlan *pp = fast.eligible ? &fast.prep : blk[1].eligible ? &blk[1].prep : nullptr;
+		if (any_long && pp && pp->on)
+			lng += std::string(" + k_prep (") + pp->why + ")";
+	}
 	if (!any_short)
 		sht = "none";
 	else if (blk[0].eligible) {
@@ -361,6 +368,8 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 			sht = blk_name(blk[0]);
 	} else
 		sht = std::string("generic (") + blk[0].why_not + ")";
+	if (any_short && blk[0].eligible && blk[0].prep.on)
+		sht += std::string(" + k_prep (") + blk[0].prep.why + ")";
 	if (any_long && any_short) { // long blocks with a short slope
 		const bool short_ok10 = use_l10 && blk[0].eligible && (blk[0].bs == 8 || blk[0].bs == 9);
 		if ((fast.eligible && blk[0].eligible && blk[0].bs == 8) || short_ok10)
@@ -475,8 +484,13 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			d->mode_floor_bytes[m] += fl.type == 0 ? half * 4 + 2 : (uint64_t)fl.f1.x_list.size() * 2; // explicit curve | posts
 		}
 	}
-	std::vector<uint16_t> fx(nfl * LW_XSTRIDE, 0);
-	std::vector<uint8_t> fF(nfl, 0);
+	// (rows nfl, nfl + 1: the unit floors of the two block classes, LwPrepPlan -- posts at x = 0 and x = n / 2)
+	std::vector<uint16_t> fx((nfl + 2) * LW_XSTRIDE, 0);
+	std::vector<uint8_t> fF(nfl + 2, 0);
+	for (size_t cls = 0; cls < 2; cls++) {
+		fx[(nfl + cls) * LW_XSTRIDE + 1] = (uint16_t)((1u << (cls ? id.bs1 : id.bs0)) / 2);
+		fF[nfl + cls] = 2;
+	}
 	for (size_t f = 0; f < nfl; f++) {
 		if (s.floors[f].type == 0)
 			d->any_floor0 = true;
@@ -620,6 +634,33 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 			return nullptr;
 		}
 	}
+	// canonicalising pre-pass (k_prep): the (mode, channel) actions of the block classes that need it, one merged table
+	{
+		const LwPrepPlan *pp[2] = {d->blkp[0].eligible ? &d->blkp[0].prep : nullptr,
+			d->fast.eligible ? &d->fast.prep : d->blkp[1].eligible ? &d->blkp[1].prep : nullptr};
+		d->h_prep_action.assign(nmodes * ch, LW_PREP_NONE);
+		d->h_prep_mode.assign(nmodes, 0);
+		for (int cls = 0; cls < 2; cls++) {
+			if (!pp[cls] || !pp[cls]->on)
+				continue;
+			d->prep_cls[cls] = true;
+			d->prep_floors = d->prep_floors || pp[cls]->premul;
+			for (size_t m = 0; m < nmodes; m++)
+				for (size_t c = 0; c < ch; c++)
+					if (pp[cls]->action[m * ch + c] != LW_PREP_NONE) {
+						d->h_prep_action[m * ch + c] = pp[cls]->action[m * ch + c];
+						d->h_prep_mode[m] = 1;
+					}
+		}
+		if ((d->prep_cls[0] || d->prep_cls[1]) &&
+				(!lw_hip_ok(hipMalloc((void **)&d->d_prep_action, d->h_prep_action.size()), "hipMalloc(pre-pass actions)") ||
+				 !lw_hip_ok(hipMemcpy(d->d_prep_action, d->h_prep_action.data(), d->h_prep_action.size(), hipMemcpyHostToDevice),
+					 "hipMemcpy(pre-pass actions)"))) {
+			*err = LW_ERR_DEVICE;
+			lw_decoder_destroy(d.release());
+			return nullptr;
+		}
+	}
 	return d.release();
 }
 
@@ -648,6 +689,8 @@ void lw_decoder_destroy(lw_decoder *d)
 			(void)hipFree(p);
 	if (d->d_l12_sid)
 		(void)hipFree(d->d_l12_sid);
+	if (d->d_prep_action)
+		(void)hipFree(d->d_prep_action);
 	delete d;
 }
 

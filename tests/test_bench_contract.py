@@ -77,7 +77,7 @@ def test_committed_bench_line_has_the_contract_fields(name):
 
 
 def test_device_code_is_the_measured_build():
-    """profiles/r05_device_code.sha256 identifies the kernels the round's GPU parity run, bench line and rocprof summaries were
+    """profiles/r06_device_code.sha256 identifies the kernels the round's GPU parity run, bench line and rocprof summaries were
     taken on (sha256 of the gfx950 disassembly, tools/device_code_id.sh).  Host-side work done without a GPU at hand must
     not change them: a kernel edit has to go through the GPU tests again and refresh the file together with the profiles."""
     import shutil
@@ -87,5 +87,5 @@ def test_device_code_is_the_measured_build():
         pytest.skip("binutils / ROCm LLVM tools not installed")
     import lewton_amd  # noqa: F401  (makes sure the library is built)
     out = subprocess.check_output([os.path.join(ROOT, "tools", "device_code_id.sh")], cwd=ROOT, text=True)
-    want = open(os.path.join(ROOT, "profiles", "r05_device_code.sha256")).read()
+    want = open(os.path.join(ROOT, "profiles", "r06_device_code.sha256")).read()
     assert out.split() == want.split()

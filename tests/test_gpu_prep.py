@@ -1,0 +1,119 @@
+"""The canonicalising pre-pass k_prep (round 6; LwPrepPlan in csrc/lw_fast.hpp): stream shapes the specialised kernels do not take
+as they are -- a channel in several coupling steps (libvorbis' own 5.1 and 3-channel mappings), modes of one block size with
+different mappings, a floor of 65 posts, three floor configurations in one mapping, floor 0 -- must leave the generic kernels for
+k_prep + the specialised kernel of their block size and stay bit-exact against the oracle and against the generic kernels
+(/root/reference/src/audio.rs:990-1002 any coupling list, :926-938 any mode, :1006-1039 floor x residue)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from common import ROOT, po, sg
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fuzz_gpu_setups as fz  # noqa: E402
+
+
+def surround51_libvorbis_coupling(bs0=8, bs1=11):
+    """5.1 with the four coupling steps libvorbis writes for it: (0,2), (3,4), (0,1), (0,3) -- channel 0 is in three of them"""
+    st = sg.surround51_setup(48000, bs0, bs1)
+    if bs1 == 10:
+        st.floors[3].x_rest = [64, 16, 256, 128, 32, 384]   # (the generator's LFE floor repeats the implied end post at x = 512)
+    for m in st.mappings:
+        m.coupling = [(0, 2), (3, 4), (0, 1), (0, 3)]
+    return st
+
+
+def three_channels(bs0=8, bs1=11):
+    """L / C / R: coupling steps (0,2), (0,1)"""
+    st = sg.stereo_setup(44100, bs0, bs1, residue_type=1)
+    st.channels = 3
+    st.mappings = [sg.Mapping([(0, 2), (0, 1)], [0, 0, 0], [0], [0]), sg.Mapping([(0, 2), (0, 1)], [0, 0, 0], [1], [1])]
+    return st
+
+
+def two_long_modes(bs0=8, bs1=11):
+    """two long modes with their own mappings: another floor, another coupling list"""
+    st = sg.stereo_setup(44100, bs0, bs1)
+    rng = np.random.default_rng(5)
+    st.floors.append(sg.random_floor1(rng, st.codebooks, bs1, posts=40))
+    st.mappings.append(sg.Mapping([], [0, 0], [2], [1]))
+    st.modes.append(sg.Mode(1, 2))
+    return st
+
+
+def floor_of_65_posts(bs0=8, bs1=11):
+    st = sg.stereo_setup(44100, bs0, bs1)
+    st.floors[1] = sg.random_floor1(np.random.default_rng(6), st.codebooks, bs1, posts=65)
+    return st
+
+
+def three_floor_configurations(bs0=8, bs1=11):
+    """4 channels in three submaps, each with its own floor: more configurations than the kernels stage"""
+    st = sg.stereo_setup(44100, bs0, bs1, residue_type=1)
+    rng = np.random.default_rng(7)
+    st.channels = 4
+    st.floors += [sg.random_floor1(rng, st.codebooks, bs1, posts=12), sg.random_floor1(rng, st.codebooks, bs1, posts=31)]
+    st.mappings = [sg.Mapping([(0, 1)], [0, 0, 0, 0], [0], [0]), sg.Mapping([(0, 1)], [0, 0, 1, 2], [1, 2, 3], [1, 1, 1])]
+    return st
+
+
+CASES = {
+    "surround51_libvorbis_coupling": (surround51_libvorbis_coupling, "a channel takes part in more than one coupling step"),
+    "surround51_libvorbis_coupling_9_12": (lambda: surround51_libvorbis_coupling(9, 12), "a channel takes part"),
+    "surround51_libvorbis_coupling_8_10": (lambda: surround51_libvorbis_coupling(8, 10), "a channel takes part"),
+    "surround51_libvorbis_coupling_8_13": (lambda: surround51_libvorbis_coupling(8, 13), "a channel takes part"),
+    "three_channels": (three_channels, "a channel takes part"),
+    "two_long_modes": (two_long_modes, "long modes with different"),
+    "floor_of_65_posts": (floor_of_65_posts, "more posts"),
+    "three_floor_configurations": (three_floor_configurations, "floor"),
+    "floor0_long_blocks": (lambda: sg.floor0_setup(8, 11, 44100, mixed=True), "floor type 0"),
+    # blocksize_0 = blocksize_1 with a flagged and an unflagged mode: one block shape, every mode planned as the long class; the two
+    # modes have their own floors, so the class goes through k_prep
+    "equal_sizes_8": (lambda: sg.stereo_setup(8000, 8, 8), "long modes with different floors"),
+    "equal_sizes_9": (lambda: sg.stereo_setup(8000, 9, 9), "long modes with different floors"),
+    "equal_sizes_10": (lambda: sg.stereo_setup(16000, 10, 10), "long modes with different floors"),
+    "equal_sizes_11": (lambda: sg.stereo_setup(44100, 11, 11), "long modes with different floors"),
+    "equal_sizes_12": (lambda: sg.stereo_setup(44100, 12, 12), "long modes with different floors"),
+    "equal_sizes_13": (lambda: sg.stereo_setup(44100, 13, 13, residue_type=1), "long modes with different floors"),
+}
+
+
+def _census(setup):
+    from lewton_amd import _native as N
+    from lewton_amd import header
+    idp, _cmt, stp = setup.headers()
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    buf = C.create_string_buffer(2048)
+    N.lib.lw_debug_plan_census(ident._h, st._h, buf, 2048)
+    return dict(x.split("=", 1) for x in buf.value.decode().split(" | "))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_plan_sends_the_shape_through_k_prep_not_the_generic_kernels(name):
+    make, why = CASES[name]
+    parts = _census(make())
+    assert parts["long"].startswith("k_") and "k_prep" in parts["long"] and why in parts["long"], parts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("fmt_seed", [0, 1, 2])
+def test_k_prep_shapes_three_ways(name, fmt_seed):
+    from lewton_amd import _native as N
+    from lewton_amd import audio, header
+    from lewton_amd.batch import Batch
+    setup = CASES[name][0]()
+    rng = np.random.default_rng(fmt_seed)
+    seqs = [sg.random_stream(setup, rng, 24, seed=100 * fmt_seed + q, p_floor_unused=0.1, p_damage=0.04) for q in range(fz.DISTINCT)]
+    idp, _cmt, stp = setup.headers()
+    # (the seed only picks the sample format and the stream count of run_setup: 3 k + fmt_seed -> format fmt_seed)
+    checked, kernels, line, _dev = fz.run_setup(3 * 7 + fmt_seed, setup.channels, idp, stp, seqs, 24 * 10, rng,
+                                                (audio, header, Batch, po, N), length=24)
+    assert checked > 150 and "k_prep" in kernels, (kernels, line)
+    assert kernels & {"k_long", "k_long10", "k_long12", "k_big", "k_short", "k_mix", "k_mix10"}, kernels
+    if name.startswith("equal_sizes"):
+        assert "k_imdct_generic" not in kernels, kernels      # (no packet of such a stream is left to the generic kernels)

@@ -64,8 +64,9 @@ def census_line(N, ident, st):
     return buf.value.decode()
 
 
-def run_setup(seed, ch, idp, stp, seqs, packets, rng, mods):
-    """returns (packets checked, kernels seen, census line); raises SystemExit on the first difference"""
+def run_setup(seed, ch, idp, stp, seqs, packets, rng, mods, length=None):
+    """returns (packets checked, kernels seen, census line, k_entropy eligible); raises SystemExit on the first difference.
+    `length`: packets per sequence when the caller made `seqs` itself (default: shape_of(seed, packets))"""
     audio, header, Batch, po, N = mods
     ident = header.read_header_ident(idp)
     st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
@@ -74,7 +75,10 @@ def run_setup(seed, ch, idp, stp, seqs, packets, rng, mods):
     line = census_line(N, ident, st)
     dec = audio.Decoder(ident, st, 0)
     fmt = FMTS[seed % 3]
-    n_streams, length = shape_of(seed, packets)
+    if length is None:
+        n_streams, length = shape_of(seed, packets)
+    else:
+        n_streams = max(1, min(64, packets // length))
     # the oracle once per distinct sequence
     want = []
     for q in range(DISTINCT):
