@@ -91,7 +91,151 @@ __global__ void __launch_bounds__(LW_BLOCK) k_decouple(LwDevTables T, LwBatchDev
 // for those channels, a copy for the others.  An unused floor (audio.rs:1021-1024) stays marked: the kernels zero the channel.
 // Every thread owns the bins tid, tid + 256, ...: no synchronisation between the coupling and the multiply.
 // ---------------------------------------------------------------------------------------------
+// floor-1 value of bin k from the active posts (px ascending, py = final_y * multiplier): closed form of render_line
+__device__ __forceinline__ int prep_floor_y(const uint16_t *px, const uint8_t *py, int K, uint32_t k)
+{
+	int lo = 0, hi = K - 1; // largest i with px[i] <= k
+	while (lo < hi) {
+		const int mid = (lo + hi + 1) >> 1;
+		if (px[mid] <= k)
+			lo = mid;
+		else
+			hi = mid - 1;
+	}
+	if (lo == K - 1)
+		return py[lo]; // flat extension to n/2, audio.rs:546-548
+	const int x0 = px[lo], x1 = px[lo + 1], y0 = py[lo], y1 = py[lo + 1];
+	const int dy = y1 - y0, adx = x1 - x0;
+	const int ady = dy < 0 ? -dy : dy;
+	const int off = (ady * ((int)k - x0)) / adx;
+	return dy < 0 ? y0 - off : y0 + off;
+}
+
+__device__ __forceinline__ void prep_couple(float &m, float &a) // audio.rs:762-777
+{
+	float nm, na;
+	if (m > 0.0f) {
+		if (a > 0.0f) {
+			nm = m;
+			na = m - a;
+		} else {
+			nm = m + a;
+			na = m;
+		}
+	} else {
+		if (a > 0.0f) {
+			nm = m;
+			na = m + a;
+		} else {
+			nm = m - a;
+			na = m;
+		}
+	}
+	m = nm;
+	a = na;
+}
+
+// LDS: every thread keeps four consecutive bins of every channel in its own column col[c][tid] (16-byte accesses of consecutive
+// lanes: conflict-free, and private -- no synchronisation between the coupling steps); the floors' active posts per channel behind them
+#define LW_PREP_MAX_CH 16u
 __global__ void __launch_bounds__(LW_ELEMENTWISE_BLOCK) k_prep(LwDevTables T, LwBatchDev B, const uint32_t *list, const uint8_t *action,
+		uint16_t *floors_out)
+{
+	extern __shared__ __attribute__((aligned(16))) char prep_smem[];
+	float4 *col = reinterpret_cast<float4 *>(prep_smem); // [ch][256]
+	__shared__ uint16_t px[LW_XSTRIDE];
+	__shared__ uint8_t py[LW_XSTRIDE + 2];
+	__shared__ uint8_t act[LW_XSTRIDE + 2];
+	__shared__ int s_K;
+	const uint32_t pkt = list[blockIdx.x];
+	const LwPacketRec rec = B.recs[pkt];
+	if (rec.flags & LW_RF_SKIP)
+		return;
+	const uint32_t tid = threadIdx.x, n2 = (1u << rec.bs) >> 1, ch = T.ch;
+	const uint32_t s0 = T.couple_off[rec.mode], s1 = T.couple_off[rec.mode + 1];
+	const float *src = B.residue + rec.res_off;
+	float *dst = B.decoupled + rec.res_off;
+	const uint8_t *arow = action + (size_t)rec.mode * ch;
+	// ---- floor records out (and which channels are multiplied here)
+	for (uint32_t c = 0; c < ch && floors_out; c++) {
+		const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
+		uint16_t *fout = floors_out + rec.floor_off + c * T.fstride;
+		if (arow[c] != LW_PREP_PREMUL || frec[0] == LW_FLOOR_UNUSED) {
+			for (uint32_t i = tid; i < T.fstride; i += blockDim.x)
+				fout[i] = frec[i];
+		} else if (tid < 2) {
+			fout[tid] = (uint16_t)(LW_POST_ACTIVE | 255u);
+		}
+	}
+	for (uint32_t k0 = 0; k0 < n2; k0 += 4u * blockDim.x) { // (n2 >= 32: whole float4s; threads beyond the block idle)
+		const uint32_t k = k0 + 4u * tid;
+		const bool on = k < n2;
+		// ---- all channels of my four bins into my column, every coupling step there (reverse order, audio.rs:991-992)
+		if (on) {
+			for (uint32_t c = 0; c < ch; c++)
+				col[c * blockDim.x + tid] = *reinterpret_cast<const float4 *>(src + c * n2 + k);
+			for (uint32_t s = s1; s-- > s0;) {
+				float4 &m = col[T.couple[2 * s] * blockDim.x + tid], &a = col[T.couple[2 * s + 1] * blockDim.x + tid];
+				float4 mv = m, av = a;
+				prep_couple(mv.x, av.x);
+				prep_couple(mv.y, av.y);
+				prep_couple(mv.z, av.z);
+				prep_couple(mv.w, av.w);
+				m = mv;
+				a = av;
+			}
+		}
+		// ---- x floor curve for the channels the kernels cannot stage (audio.rs:1035-1037), and out
+		for (uint32_t c = 0; c < ch; c++) { // (every condition below is the same for all threads of the workgroup)
+			const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
+			const uint16_t e0 = frec[0];
+			float4 v = on ? col[c * blockDim.x + tid] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+			if (arow[c] == LW_PREP_PREMUL && e0 == LW_FLOOR_EXPLICIT) { // floor 0: the curve evaluated by the host stage (audio.rs:160-212)
+				if (on) {
+					const float4 f = *reinterpret_cast<const float4 *>(B.fcurve + rec.res_off + c * n2 + k);
+					v.x = f.x * v.x;
+					v.y = f.y * v.y;
+					v.z = f.z * v.z;
+					v.w = f.w * v.w;
+				}
+			} else if (arow[c] == LW_PREP_PREMUL && e0 != LW_FLOOR_UNUSED) {
+				// active posts in ascending x (audio.rs:536-545 walks exactly these), one thread per post
+				const uint32_t fl = T.mode_floor[rec.mode * ch + c], F = T.floor_F[fl];
+				uint16_t my_e = 0;
+				__syncthreads(); // (the previous channel's / block's evaluation is done with px / py)
+				if (tid < F) {
+					my_e = frec[tid];
+					act[tid] = (my_e & LW_POST_ACTIVE) ? 1 : 0;
+				}
+				__syncthreads();
+				if (tid < F) {
+					int rank = 0;
+					for (uint32_t t = 0; t < tid; t++)
+						rank += act[t];
+					if (my_e & LW_POST_ACTIVE) {
+						px[rank] = T.floor_x[fl * LW_XSTRIDE + tid];
+						py[rank] = (uint8_t)(my_e & 0xff);
+					}
+					if (tid == F - 1)
+						s_K = rank + ((my_e & LW_POST_ACTIVE) ? 1 : 0);
+				}
+				__syncthreads();
+				if (on) {
+					const int K = s_K;
+					v.x = T.inv_db[prep_floor_y(px, py, K, k)] * v.x;
+					v.y = T.inv_db[prep_floor_y(px, py, K, k + 1)] * v.y;
+					v.z = T.inv_db[prep_floor_y(px, py, K, k + 2)] * v.z;
+					v.w = T.inv_db[prep_floor_y(px, py, K, k + 3)] * v.w;
+				}
+			}
+			if (on)
+				*reinterpret_cast<float4 *>(dst + c * n2 + k) = v;
+		}
+	}
+}
+
+// the same for more channels than the columns hold (LW_PREP_MAX_CH): through B.decoupled itself, one bin per thread and turn
+__global__ void __launch_bounds__(LW_ELEMENTWISE_BLOCK) k_prep_wide(LwDevTables T, LwBatchDev B, const uint32_t *list, const uint8_t *action,
 		uint16_t *floors_out)
 {
 	__shared__ uint16_t px[LW_XSTRIDE];
@@ -109,30 +253,8 @@ __global__ void __launch_bounds__(LW_ELEMENTWISE_BLOCK) k_prep(LwDevTables T, Lw
 	for (uint32_t k = tid; k < n2; k += blockDim.x) {
 		for (uint32_t c = 0; c < T.ch; c++)
 			dst[c * n2 + k] = src[c * n2 + k];
-		for (uint32_t s = s1; s-- > s0;) { // reverse step order, audio.rs:991-992
-			const uint32_t mi = T.couple[2 * s] * n2 + k, ai = T.couple[2 * s + 1] * n2 + k;
-			const float m = dst[mi], a = dst[ai];
-			float nm, na;
-			if (m > 0.0f) {
-				if (a > 0.0f) {
-					nm = m;
-					na = m - a;
-				} else {
-					nm = m + a;
-					na = m;
-				}
-			} else {
-				if (a > 0.0f) {
-					nm = m;
-					na = m + a;
-				} else {
-					nm = m - a;
-					na = m;
-				}
-			}
-			dst[mi] = nm;
-			dst[ai] = na;
-		}
+		for (uint32_t s = s1; s-- > s0;) // reverse step order, audio.rs:991-992
+			prep_couple(dst[T.couple[2 * s] * n2 + k], dst[T.couple[2 * s + 1] * n2 + k]);
 	}
 	const uint8_t *arow = action + (size_t)rec.mode * T.ch;
 	for (uint32_t c = 0; c < T.ch; c++) { // (every condition below is the same for all threads of the workgroup)
@@ -146,12 +268,11 @@ __global__ void __launch_bounds__(LW_ELEMENTWISE_BLOCK) k_prep(LwDevTables T, Lw
 			continue;
 		}
 		float *v = dst + c * n2;
-		if (e0 == LW_FLOOR_EXPLICIT) { // floor 0: the curve evaluated by the host stage (audio.rs:160-212)
+		if (e0 == LW_FLOOR_EXPLICIT) {
 			const float *fc = B.fcurve + rec.res_off + c * n2;
 			for (uint32_t k = tid; k < n2; k += blockDim.x)
 				v[k] = fc[k] * v[k];
 		} else {
-			// active posts in ascending x (audio.rs:536-545 walks exactly these), one thread per post
 			const uint32_t fl = T.mode_floor[rec.mode * T.ch + c], F = T.floor_F[fl];
 			uint16_t my_e = 0;
 			if (tid < F) {
@@ -172,27 +293,8 @@ __global__ void __launch_bounds__(LW_ELEMENTWISE_BLOCK) k_prep(LwDevTables T, Lw
 			}
 			__syncthreads();
 			const int K = s_K;
-			for (uint32_t k = tid; k < n2; k += blockDim.x) {
-				int lo = 0, hi = K - 1; // largest i with px[i] <= k
-				while (lo < hi) {
-					const int mid = (lo + hi + 1) >> 1;
-					if (px[mid] <= k)
-						lo = mid;
-					else
-						hi = mid - 1;
-				}
-				int y;
-				if (lo == K - 1) {
-					y = py[lo]; // flat extension to n/2, audio.rs:546-548
-				} else {
-					const int x0 = px[lo], x1 = px[lo + 1], y0 = py[lo], y1 = py[lo + 1];
-					const int dy = y1 - y0, adx = x1 - x0;
-					const int ady = dy < 0 ? -dy : dy;
-					const int off = (ady * ((int)k - x0)) / adx; // closed form of render_line
-					y = dy < 0 ? y0 - off : y0 + off;
-				}
-				v[k] = T.inv_db[y] * v[k];
-			}
+			for (uint32_t k = tid; k < n2; k += blockDim.x)
+				v[k] = T.inv_db[prep_floor_y(px, py, K, k)] * v[k];
 			__syncthreads(); // (px / py are rebuilt for the next channel)
 		}
 		if (fout && tid < 2)
@@ -205,7 +307,18 @@ hipError_t lw_launch_prep(const LwDevTables &T, const LwBatchDev &B, const uint3
 {
 	if (n_list == 0)
 		return hipSuccess;
-	return lw_launch_k(k_prep, dim3(n_list), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T, B, d_list, d_action, d_floors_out);
+	if (T.ch > LW_PREP_MAX_CH)
+		return lw_launch_k(k_prep_wide, dim3(n_list), dim3(LW_ELEMENTWISE_BLOCK), 0, st, T, B, d_list, d_action, d_floors_out);
+	static LwPerDeviceOnce once;
+	{
+		const hipError_t e = once.run([] {
+			return hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LW_PREP_MAX_CH * LW_ELEMENTWISE_BLOCK * 16));
+		});
+		if (e != hipSuccess)
+			return e;
+	}
+	return lw_launch_k(k_prep, dim3(n_list), dim3(LW_ELEMENTWISE_BLOCK), (size_t)T.ch * LW_ELEMENTWISE_BLOCK * 16, st, T, B, d_list, d_action,
+			d_floors_out);
 }
 
 // ---------------------------------------------------------------------------------------------

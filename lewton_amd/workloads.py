@@ -28,6 +28,17 @@ def mono():
     return st
 
 
+def surround51_libvorbis_coupling(bs0: int = 8, bs1: int = 11):
+    """5.1 @ 48 kHz with the four coupling steps libvorbis writes for six channels -- (0,2), (3,4), (0,1), (0,3): channel 0 takes
+    part in three of them, channel 3 in two -- so the stream shape reaches k_long only behind the canonicalising pre-pass k_prep"""
+    st = sg.surround51_setup(48000, bs0, bs1)
+    if bs1 == 10:
+        st.floors[3].x_rest = [64, 16, 256, 128, 32, 384]   # (the generator's LFE floor repeats the implied end post at x = 512)
+    for m in st.mappings:
+        m.coupling = [(0, 2), (3, 4), (0, 1), (0, 3)]
+    return st
+
+
 @dataclass
 class Workload:
     key: str
@@ -73,6 +84,14 @@ def configs(packets: int = 4096) -> List[Workload]:
                  "blocksize 9 / 10; long blocks with short slopes on either side of every run of short blocks"),
         Workload("15", "mixed 256/1024", lambda: sg.stereo_setup(22050, 8, 10), "LLLSSSLLLL", 256, per,
                  "blocksize 8 / 10"),
+        # round 6: a stream shape behind the canonicalising pre-pass; SURVEY 8(d) config 3 as written (ONE stream, state carried
+        # through the whole launch: audio.rs:1082-1154, examples/perf.rs:35-44) and its all-long counterpart
+        Workload("16", "5.1 @ 48 kHz long blocks, libvorbis' coupling steps (a channel in three steps)", surround51_libvorbis_coupling,
+                 "L", 256, per, "k_prep applies every coupling step, k_long runs uncoupled channel pairs"),
+        Workload("17", "3b ONE stream x %d consecutive packets, LLSSSSSSSSL" % packets, lambda: sg.stereo_setup(44100, 8, 11),
+                 "LLSSSSSSSSL", 1, packets, "a single stream cut over the chip's workgroups: halo pre-pass at every chunk start", 1),
+        Workload("18", "ONE stream x %d consecutive long packets" % packets, lambda: sg.stereo_setup(44100, 8, 11), "L", 1, packets,
+                 "a single stream cut over the chip's workgroups: halo pre-pass at every chunk start", 1),
     ]
 
 

@@ -16,14 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import fuzz_gpu_setups as fz  # noqa: E402
 
 
-def surround51_libvorbis_coupling(bs0=8, bs1=11):
-    """5.1 with the four coupling steps libvorbis writes for it: (0,2), (3,4), (0,1), (0,3) -- channel 0 is in three of them"""
-    st = sg.surround51_setup(48000, bs0, bs1)
-    if bs1 == 10:
-        st.floors[3].x_rest = [64, 16, 256, 128, 32, 384]   # (the generator's LFE floor repeats the implied end post at x = 512)
-    for m in st.mappings:
-        m.coupling = [(0, 2), (3, 4), (0, 1), (0, 3)]
-    return st
+from lewton_amd.workloads import surround51_libvorbis_coupling  # noqa: E402
 
 
 def three_channels(bs0=8, bs1=11):
