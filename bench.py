@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--other-steps", type=int, default=600, help="timed launches per entry of other_configs (at least)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group also for one process (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--device-of-rank", default="",
+                    help="TEST ONLY: comma-separated device ordinal per local rank (e.g. 0,0: two ranks on the one GPU of a test box, "
+                         "with LW_BENCH_BACKEND=gloo -- RCCL cannot form a group of two ranks on one device); default: device = LOCAL_RANK")
     ap.add_argument("--streams", type=int, default=256,
                     help="logical streams per 4096-packet batch (each contributes 4096/streams consecutive packets)")
     args = ap.parse_args()
@@ -91,12 +94,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
-    torch.cuda.set_device(local_rank)
+    device = int(args.device_of_rank.split(",")[local_rank]) if args.device_of_rank else local_rank
+    torch.cuda.set_device(device)
+    # "nccl" IS RCCL on ROCm: the driver's 1/2/4/8-GPU runs.  LW_BENCH_BACKEND=gloo (test only) carries the same barrier and MAX
+    # all-reduce over TCP, so that the N > 1 code of this file (per-rank seeds, rank 0's line, cpu_baseline: null, the MAX over
+    # the ranks' spans) also runs where the ranks have to share a device
+    backend = os.environ.get("LW_BENCH_BACKEND", "nccl")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1 or args.force_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # host threads for the (untimed) entropy stage that prepares the records: an equal share of the cores per rank
     from lewton_amd import _native as N
@@ -110,7 +122,7 @@ def main():
     idp, _, stp = setup.headers()
     ident = header.read_header_ident(idp)
     st = header.read_header_setup(stp, 2, (8, 11))
-    dec = audio.decoder_for(ident, st, local_rank)
+    dec = audio.decoder_for(ident, st, device)
     pool = sg.make_stream(setup, "L", UNIQUE_PACKETS, seed=1000 + rank)
     rng = np.random.default_rng(77 + rank)
 
@@ -246,10 +258,11 @@ def main():
     torch.cuda.synchronize()
     from lewton_amd import shard
     if args.force_dist and world == 1:  # run the collective of the N > 1 path once
-        chk = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        chk = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(chk, op=dist.ReduceOp.MAX)
         assert float(chk.item()) == elapsed
-    elapsed = shard.max_elapsed(elapsed, dist if dist.is_initialized() else None, "cuda")
+    own_elapsed = elapsed
+    elapsed = shard.max_elapsed(elapsed, dist if dist.is_initialized() else None, red_dev)
     # device time of the K steps on the launch stream (HIP events), per step
     launch_ms = ev0.elapsed_time(ev1) / args.steps
 
@@ -258,7 +271,7 @@ def main():
     #      primed state (the oracle decodes the priming packet first, exactly as the GPU stream did)
     parity = None
     kernels = batches[0].last_kernels
-    if rank == 0:
+    if rank == 0 or world > 1:   # (N > 1: every rank checks the bytes it timed; rank 0 reports all of them, `ranks` below)
         try:
             from oracle import pyoracle as po
             o_id = po.Ident(idp)
@@ -281,6 +294,11 @@ def main():
         except Exception as e:  # the oracle is only a checker here
             parity = "unchecked: %r" % (e,)
 
+    per_rank = None
+    if world > 1:   # what each rank decoded and found: seeds, its own span, its parity string
+        mine = {"rank": rank, "device": device, "pool_seed": 1000 + rank, "order_seed": 77 + rank, "elapsed_s": own_elapsed, "parity": parity}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (the contract: rank 0 at N=1 only; null in the N>1 lines)
         from oracle import pyoracle as po
@@ -379,16 +397,29 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs as bc
             from lewton_amd import workloads as wl
-            for key, label in (("3", "configs[2] mixed short/long"), ("4", "configs[3] 5.1 @ 48 kHz"),
-                               ("10", "configs[4] stepping on one GPU: 10 000 streams x 4 packets"),
-                               ("12", "blocksize_1 = 10"), ("11", "blocksize_1 = 12"), ("13", "blocksize_1 = 13"),
-                               ("14", "mixed 512/1024 (blocksize 9 / 10, LLLSSSLLLL)"),
-                               ("15", "mixed 256/1024 (blocksize 8 / 10, LLLSSSLLLL)")):
+            # (key, label, packets per launch, through the generic kernels only)
+            for key, label, pk_, gen_ in (
+                    ("3", "configs[2] mixed short/long", 4096, False), ("4", "configs[3] 5.1 @ 48 kHz", 4096, False),
+                    ("10", "configs[4] stepping on one GPU: 10 000 streams x 4 packets", 4096, False),
+                    ("12", "blocksize_1 = 10", 4096, False), ("11", "blocksize_1 = 12", 4096, False), ("13", "blocksize_1 = 13", 4096, False),
+                    ("14", "mixed 512/1024 (blocksize 9 / 10, LLLSSSLLLL)", 4096, False),
+                    ("15", "mixed 256/1024 (blocksize 8 / 10, LLLSSSLLLL)", 4096, False),
+                    # round 6: SURVEY 8(d) config 3 as written (ONE stream), its all-long counterpart, a stream shape behind the
+                    # canonicalising pre-pass (libvorbis' 5.1 coupling steps), the fallback every specialised kernel is measured
+                    # against, and the mixed shapes at the batch size the library's own staging ring runs with
+                    ("17", "configs[2] as SURVEY 8(d) words it: ONE stream x 4096 packets, LLSSSSSSSSL", 4096, False),
+                    ("18", "ONE stream x 4096 long packets", 4096, False),
+                    ("16", "5.1 @ 48 kHz with libvorbis' coupling steps (k_prep + k_long)", 4096, False),
+                    ("9", "generic fallback (stereo 8/11 long blocks, forced)", 4096, True),
+                    ("3", "configs[2] mixed short/long, 16 384 packets per launch", 16384, False),
+                    ("14", "mixed 512/1024, 16 384 packets per launch", 16384, False),
+                    ("15", "mixed 256/1024, 16 384 packets per launch", 16384, False)):
                 try:
-                    w_ = wl.by_key(key)
+                    w_ = wl.by_key(key, pk_ // 2 if key == "9" else pk_)
                     # nb=None: as many rotated batches as put >= 0.5 GiB of algorithmic bytes into one rotation (twice the 256 MiB
                     # Infinity Cache), at least 8 while that stays below 1.5 GiB -- the rule the headline follows
-                    r_ = bc.measure(w_, steps=args.other_steps, nb=None, verify=True, distinct=16)
+                    r_ = bc.measure(w_, steps=args.other_steps, nb=None, verify=True, distinct=16 if w_.n_streams > 1 else 1,
+                                    force_generic=gen_)
                     other[label] = {"us_per_launch": r_["us_per_launch"], "packets_per_launch": r_["packets_per_launch"],
                                     "M_packets_per_s": r_["M_packets_per_s"], "algorithmic_bytes_per_launch": r_["algorithmic_bytes_per_launch"],
                                     "batches_rotated": r_["batches_rotated"], "footprint_bytes": r_["footprint_bytes"],
@@ -447,6 +478,8 @@ def main():
             "end_to_end": e2e_obj,
             "other_configs": other,
         }
+        if per_rank is not None:
+            line["ranks"] = per_rank
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()
