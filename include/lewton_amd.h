@@ -195,6 +195,8 @@ int lw_batch_device_status(lw_batch *b);
 /* test hook: spin != 0 = the long blocks' waves of the next k_mix launches never signal their edges, and the short blocks' waves
  * give up after `spin` polls (lw_batch_device_status then reports LW_ERR_DEVICE); 0 = normal operation */
 void lw_debug_batch_break_mix(lw_batch *b, unsigned spin);
+/* ... and process-wide, for the batches a ring, a sharder or an Ogg stream reader owns: every batch launched while spin != 0 */
+void lw_debug_break_mix(unsigned spin);
 /* Entropy stage on the device (csrc/lw_dev_entropy.h, k_entropy): the bit-serial half of read_audio_packet_generic
  * (audio.rs:921-986: floor-1 decode :215-251 + amplitude unwrap :391-435, residue decode :587-760) runs on the GPU, one
  * wave per packet; lw_batch_entropy then only reads the prologues, copies the packets into pinned staging and plans the
@@ -270,9 +272,15 @@ int lw_decoder_device(const lw_decoder *d);
  * long-running kernel waits for CUs to drain (130-700 us measured; 28 us flat on a half-device share).  Throughput is the
  * same either way (the PCIe link is the bound), so the sharder leaves it off.  Batches launched on a caller's own stream
  * (lw_batch_synth) are planned for the share but run wherever that stream runs.  LW_ERR_UNSUPPORTED: parts > 32.
- * Known hazard of the HIP runtime this was measured on (ROCm 7.2): a process that has BOTH copied on the copier's own stream (a
- * flagged decoder without a share) AND run CU-masked streams was seen not to exit, one run in three; keep the two kinds of
- * decoder in different processes. */
+ * LW_ERR_UNSUPPORTED also: a device that is not the one the mask layout was measured on (gfx950, eight XCDs of equally many CUs).
+ * The two kinds of tenant stream never meet in one process.  With the HIP runtime this was measured on (ROCm 7.2) a process that
+ * had BOTH copied on the copier's own stream (the ring of a flagged decoder without a share) AND run CU-masked streams was seen
+ * not to exit, one run in three.  The library therefore keeps a latch per device and process:
+ *   - once a ring has made the copier's own stream on a device, lw_decoder_set_cu_share(parts > 1) on that device and
+ *     lw_ring_create for a decoder that already has a share return LW_ERR_UNSUPPORTED;
+ *   - once a CU-masked stream exists on a device, the copier of later rings issues their copies on the slots' own streams
+ *     instead of a stream of its own (the same results; 9-10 instead of 11-12 M packets/s for two tenants).
+ * A deployment picks one of the two modes per process: CU shares for tenants, or none. */
 int lw_decoder_set_shared_device(lw_decoder *d, int on);
 int lw_decoder_set_cu_share(lw_decoder *d, unsigned part, unsigned parts);
 int lw_decoder_cu_count(const lw_decoder *d); /* compute units this decoder's launches are planned for */

@@ -156,6 +156,13 @@ void lw_debug_batch_break_mix(lw_batch *b, unsigned spin)
 		b->mix_break_spin = spin;
 }
 
+static std::atomic<unsigned> g_break_mix_spin{0}; // lw_debug_break_mix: the same for every batch launched while it is set
+
+void lw_debug_break_mix(unsigned spin)
+{
+	g_break_mix_spin.store(spin);
+}
+
 /* After the launches of lw_batch_synth have COMPLETED (the caller has synchronised the stream): LW_OK, or LW_ERR_DEVICE when a
  * kernel raised the batch's device error word -- the PCM of this batch must not be used.  Clears the word and what the failed
  * launch may have left behind (k_mix's edge flags), so that the batch can be launched again. */
@@ -168,8 +175,12 @@ int lw_batch_device_status(lw_batch *b)
 	__atomic_store_n(b->h_err, 0u, __ATOMIC_RELEASE);
 	lw_set_device_error("k_mix: a short block's wave never saw the raw edges of its long neighbours (grid not resident?); batch dropped");
 	if (lw_decoder_set_device(b->dec) == LW_OK && b->d_edge) {
+		// on the stream the failed launch ran on (completed by now; a re-launch on it comes behind this) -- not the NULL stream, with
+		// which CU-masked (blocking) streams of every tenant in the process would synchronise
 		const size_t entries = b->max_packets * 2 * b->dec->T.ch;
-		(void)lw_hip_ok(hipMemset(b->d_edge + entries * lw_edge_values(b->dec), 0, entries * sizeof(uint32_t)), "hipMemset(edge flags)");
+		(void)lw_hip_ok(hipMemsetAsync(b->d_edge + entries * lw_edge_values(b->dec), 0, entries * sizeof(uint32_t), (hipStream_t)b->last_stream),
+				"hipMemsetAsync(edge flags)");
+		(void)lw_hip_ok(hipStreamSynchronize((hipStream_t)b->last_stream), "hipStreamSynchronize(edge flags)");
 	}
 	for (size_t i = 0; i < b->n; i++)
 		if (b->results[i].status == LW_OK) {
@@ -875,6 +886,8 @@ int lw_batch_upload(lw_batch *b, void *hip_stream)
 	if (b->n == 0)
 		return LW_OK;
 	b->ent_done = false;
+	if (b->h_err) // a new upload starts clean: an error nobody asked about (lw_batch_synth without lw_batch_device_status) is not the next launch's
+		__atomic_store_n(b->h_err, 0u, __ATOMIC_RELEASE);
 	if (b->d_edge) { // k_mix's flags: an edge written for a reader that a NEW plan no longer has must not look ready
 		const size_t entries = b->max_packets * 2 * ch;
 		HIP_TRY(hipMemsetAsync(b->d_edge + entries * lw_edge_values(b->dec), 0, entries * sizeof(uint32_t), st));
@@ -938,6 +951,7 @@ static int device_entropy(lw_batch *b, hipStream_t st)
 static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_generic, float *tap)
 {
 	lw_decoder *d = b->dec;
+	b->last_stream = (void *)st;
 	if (b->n == 0)
 		return LW_OK;
 	const bool run_generic = b->has_generic || all_generic;
@@ -972,6 +986,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		HIP_TRY(hipMalloc((void **)&b->d_halo, cap * d->T.ch * std::max<size_t>(512, d->T.state_chan_stride / 2) * sizeof(float))); // [slots][ch][n1 / 4]
 		b->halo_cap = cap;
 	}
+	const uint32_t break_spin = b->mix_break_spin ? b->mix_break_spin : g_break_mix_spin.load(); // (test hooks)
 	LwBatchDev B{};
 	B.recs = b->d_recs;
 	B.floors = b->d_floor;
@@ -1065,7 +1080,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		const LwShortLaunch S = short_launch(0);
 		if (lw_mix_applicable(L, S, d->n_cus)) {
 			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * lw_edge_values(d));
-			HIP_TRY(lw_launch_mix(d->T, Bc[1], L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
+			HIP_TRY(lw_launch_mix(d->T, Bc[1], L, S, flags, b->d_err, break_spin, break_spin != 0, d_out, b->fmt, st));
 			b->last_kernels += b->n_halo_items ? "k_long<halo>,k_mix," : "k_mix,";
 			mixed = true;
 		}
@@ -1074,7 +1089,7 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		const LwShortLaunch S = short_launch(0);
 		if (lw_mix10_applicable(L, S, d->n_cus)) { // a mixed batch the chip holds at once: long and short blocks in ONE launch (k_mix10)
 			uint32_t *flags = (uint32_t *)(b->d_edge + b->max_packets * 2 * d->T.ch * lw_edge_values(d));
-			HIP_TRY(lw_launch_mix10(d->T, Bc[1], L, S, flags, b->d_err, b->mix_break_spin, b->mix_break_spin != 0, d_out, b->fmt, st));
+			HIP_TRY(lw_launch_mix10(d->T, Bc[1], L, S, flags, b->d_err, break_spin, break_spin != 0, d_out, b->fmt, st));
 			b->last_kernels += b->n_halo_items ? "k_long10<halo>,k_mix10," : "k_mix10,";
 			mixed = true;
 		}

@@ -43,6 +43,7 @@ struct lw_decoder {
 	int device = 0;
 	int n_cus = 256;                // compute units this decoder's launches are planned for (its share of the device)
 	int n_cus_device = 256;
+	bool is_gfx950 = false;         // the device the CU-mask layout of lw_decoder_set_cu_share was measured on
 	std::vector<uint32_t> cu_mask;  // lw_decoder_set_cu_share: the mask of the streams made for this decoder (empty = all CUs)
 	bool shares_device = false;     // lw_decoder_set_shared_device: other decoders' rings run on this GPU as well
 	LwDevTables T{};
@@ -80,6 +81,11 @@ struct lw_decoder {
 };
 
 hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s);
+// the kinds of tenant stream this process has made on a device (process-wide latch; see "Known hazard" in include/lewton_amd.h)
+#define LW_TENANT_COPIER_STREAM 1  // the copier thread's own copy stream (a tenant's ring without a CU share)
+#define LW_TENANT_MASKED_STREAMS 2 // CU-masked streams (a ring of a decoder with a CU share)
+int lw_tenant_streams(int device);
+void lw_tenant_streams_note(int device, int kind);
 
 struct lw_pwr {
 	lw_decoder *dec = nullptr;
@@ -116,6 +122,7 @@ struct lw_batch {
 	// device error word: one dword of pinned host memory the kernels can write (k_mix: a wave whose producer never signalled);
 	// lw_batch_device_status reads it once the launches have completed
 	uint32_t *h_err = nullptr, *d_err = nullptr;
+	void *last_stream = nullptr; // the HIP stream of the most recent launch (lw_batch_device_status clears the edge flags on it)
 	uint32_t mix_break_spin = 0; // lw_debug_batch_break_mix: != 0 = the long blocks' waves of k_mix never signal, give up after this many polls
 	std::vector<uint32_t> blk_idx[2], blk_slot[2];
 	std::vector<int32_t> succ; // per packet: the next packet of the same stream in this batch, or -1

@@ -1129,8 +1129,15 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 	const lw_packet_result *res = nullptr;
 	const void *pcm = nullptr;
 	size_t n = 0, total = 0;
-	if (int rc = lw_ring_collect(s->ring, &res, &n, &pcm, &total))
+	if (int rc = lw_ring_collect(s->ring, &res, &n, &pcm, &total)) {
+		// LW_ERR_DEVICE: the batch's samples are void and the batches behind it were planned on window states it never produced.
+		// Nothing of it is handed out: the stream goes back to what the caller has been given -- packets re-queued in order,
+		// PreviousWindowRight restored from the snapshot taken before this batch, ring drained -- and the next call stages and
+		// decodes the same packets again.  Never wrong samples under LW_OK.
+		if (rc == LW_ERR_DEVICE)
+			s->rollback();
 		return rc;
+	}
 	if (total > cap_elems)
 		return LW_ERR_CAPACITY; // nothing consumed: the batch stays at the head of the pipeline for a larger buffer
 	// the next batch goes to the GPU now, while this one is copied out (at most one launched batch is ever undelivered)

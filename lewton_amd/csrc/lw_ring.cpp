@@ -30,6 +30,12 @@
 #include <thread>
 #include <vector>
 
+// lw_runtime.cpp: the kinds of tenant stream this process has made on a device (see "Known hazard" in include/lewton_amd.h)
+#define LW_TENANT_COPIER_STREAM 1
+#define LW_TENANT_MASKED_STREAMS 2
+int lw_tenant_streams(int device);
+void lw_tenant_streams_note(int device, int kind);
+
 #define LW_RING_MAX_DEVICES 64
 
 namespace {
@@ -44,6 +50,7 @@ struct Slot {
 	SlotState state = SLOT_FREE;
 	size_t n = 0, out_elems = 0;
 	bool copy_queued = false, copy_failed = false; // (copier rings) the PCM copy is still to be issued / could not be issued
+	int dev_rc = LW_OK; // lw_batch_device_status of the launch, latched by the first collect: every collect until the release reports it
 };
 
 struct Copier;
@@ -61,6 +68,7 @@ struct lw_ring {
 	hipEvent_t last_all_done = nullptr; // all_done of the most recent launch: the PCM copies run one at a time, in order
 	bool kernels_fifo = false; // a tenant's ring: the kernels of launch k+1 (k_entropy included) wait for those of launch k
 	bool masked = false;       // its slots' streams carry a CU mask (lw_decoder_set_cu_share)
+	bool copy_on_slot = false; // the copier issues this ring's copies on the slots' own streams (CU-masked streams in the process)
 	Copier *copier = nullptr;  // a tenant's ring: the device's copier issues the PCM copies (null: on the slot's own stream)
 	std::mutex mu;
 	std::condition_variable cv;
@@ -92,19 +100,21 @@ struct Copier {
 	std::mutex mu;
 	std::condition_variable cv;
 	std::deque<std::pair<lw_ring *, Slot *>> jobs;
-	bool quit = false;
+	// the thread of generation g serves until stop_gen >= g: the last ring to let go raises stop_gen and joins that thread OUTSIDE the
+	// table's lock, while a new first ring may already have started generation g + 1 (both under mu)
+	uint64_t start_gen = 0, stop_gen = 0;
 	int users = 0; // rings holding it (under g_copiers_mu)
 	hipStream_t own_stream = nullptr; // the copies of rings on ordinary streams; a ring on CU-masked streams copies on its slots' own
 	std::thread th;
 
-	void main()
+	void main(uint64_t gen)
 	{
 		(void)hipSetDevice(device);
 		for (;;) {
 			std::pair<lw_ring *, Slot *> j;
 			{
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&]() { return quit || !jobs.empty(); });
+				cv.wait(g, [&]() { return stop_gen >= gen || !jobs.empty(); });
 				if (jobs.empty())
 					return;
 				j = jobs.front();
@@ -112,7 +122,7 @@ struct Copier {
 			}
 			lw_ring *r = j.first;
 			Slot *s = j.second;
-			hipStream_t on = r->masked ? s->stream : own_stream;
+			hipStream_t on = r->copy_on_slot || !own_stream ? s->stream : own_stream;
 			const bool good = ok(hipEventSynchronize(s->kernels_done)) &&
 				ok(hipMemcpyAsync(s->h_out, s->d_out, s->out_elems * r->esz, hipMemcpyDeviceToHost, on)) &&
 				ok(hipEventRecord(s->all_done, on));
@@ -129,7 +139,7 @@ Copier *g_copiers[LW_RING_MAX_DEVICES];
 Copier *copier_acquire(int device, bool own_stream)
 {
 	if (device < 0 || device >= LW_RING_MAX_DEVICES)
-		return nullptr;
+		return nullptr; // (the caller falls back to copies queued on the slots' own streams)
 	std::lock_guard<std::mutex> g(g_copiers_mu);
 	Copier *&c = g_copiers[device];
 	if (!c) {
@@ -140,11 +150,18 @@ Copier *copier_acquire(int device, bool own_stream)
 		c = new Copier();
 		c->device = device;
 	}
-	if (own_stream && !c->own_stream && !ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)))
-		return nullptr;
+	if (own_stream && !c->own_stream) {
+		if (!ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)))
+			return nullptr;
+		lw_tenant_streams_note(device, LW_TENANT_COPIER_STREAM);
+	}
 	if (c->users++ == 0) {
-		c->quit = false;
-		c->th = std::thread([p = c]() { p->main(); });
+		uint64_t gen;
+		{
+			std::lock_guard<std::mutex> q(c->mu);
+			gen = ++c->start_gen;
+		}
+		c->th = std::thread([p = c, gen]() { p->main(gen); });
 	}
 	return c;
 }
@@ -153,15 +170,22 @@ void copier_release(Copier *c)
 {
 	if (!c)
 		return;
-	std::lock_guard<std::mutex> g(g_copiers_mu);
-	if (--c->users > 0)
-		return;
+	// the thread is joined OUTSIDE the table's lock: it may still be inside a long hipEventSynchronize of the ring that is going
+	// away, and creating or destroying a ring on any other device must not wait for that
+	std::thread done;
 	{
-		std::lock_guard<std::mutex> q(c->mu);
-		c->quit = true;
+		std::lock_guard<std::mutex> g(g_copiers_mu);
+		if (--c->users > 0)
+			return;
+		{
+			std::lock_guard<std::mutex> q(c->mu);
+			c->stop_gen = c->start_gen;
+		}
+		c->cv.notify_all();
+		done = std::move(c->th);
 	}
-	c->cv.notify_all();
-	c->th.join();
+	if (done.joinable())
+		done.join();
 }
 
 // every copy the copier still had to issue for this ring has been issued (or has failed) AND has completed: the ring's buffers
@@ -177,12 +201,12 @@ bool wait_copies_done(lw_ring *r)
 			return true;
 		});
 	}
-	return r->masked || !r->copier->own_stream || ok(hipStreamSynchronize(r->copier->own_stream)); // (masked: the slots' own streams)
+	return r->copy_on_slot || !r->copier->own_stream || ok(hipStreamSynchronize(r->copier->own_stream)); // (else: the slots' own streams)
 }
 
 } // namespace
 
-hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s); // lw_runtime.cpp: non-blocking, on the decoder's CU share
+hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s); // lw_runtime.cpp: on the decoder's CU share
 extern "C" int lw_decoder_cu_count(const lw_decoder *d);
 extern "C" int lw_decoder_device_cu_count(const lw_decoder *d);
 extern "C" int lw_decoder_shares_device(const lw_decoder *d);
@@ -216,8 +240,18 @@ lw_ring *lw_ring_create(lw_decoder *d, size_t n_slots, size_t max_packets, int f
 		const bool tenant = r->masked || lw_decoder_shares_device(d);
 		const int pol = g_policy.load();
 		r->kernels_fifo = pol < 0 ? tenant : (pol & 1) != 0;
+		// The two kinds of tenant stream must not meet in one process (include/lewton_amd.h: a process that had copied on the
+		// copier's own stream AND run CU-masked streams was seen not to exit): CU-masked streams are refused once the copier's
+		// stream exists on this device; the other way round the copier simply issues its copies on the slots' own streams.
+		if (good && r->masked && (lw_tenant_streams(r->device) & LW_TENANT_COPIER_STREAM)) {
+			*err = LW_ERR_UNSUPPORTED;
+			lw_ring_destroy(r);
+			return nullptr;
+		}
+		const bool own = !r->masked && !(lw_tenant_streams(r->device) & LW_TENANT_MASKED_STREAMS);
 		if (good && (pol < 0 ? tenant : (pol & 2) != 0))
-			good = (r->copier = copier_acquire(r->device, !r->masked)) != nullptr;
+			r->copier = copier_acquire(r->device, own); // (null -- device ordinal beyond the table, no stream to be had: copies behind the kernels, as for a lone ring)
+		r->copy_on_slot = r->masked || !own;
 	}
 	for (Slot &s : r->slots) {
 		if (!good)
@@ -421,7 +455,10 @@ int lw_ring_collect(lw_ring *r, const lw_packet_result **results, size_t *n, con
 		// slot is COLLECTED all the same (release it as usual)
 		dev_rc = lw_batch_device_status(s->batch);
 		std::lock_guard<std::mutex> g(r->mu);
+		s->dev_rc = dev_rc;
 		s->state = SLOT_COLLECTED;
+	} else {
+		dev_rc = s->dev_rc; // (a second collect of the same slot: the same verdict, not LW_OK over a failed batch's samples)
 	}
 	if (results)
 		*results = lw_batch_results(s->batch);

@@ -455,6 +455,10 @@ lw_decoder *lw_decoder_create(const lw_ident *idh, const lw_setup *sh, int devic
 	if (hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || d->n_cus <= 0)
 		d->n_cus = 256;
 	d->n_cus_device = d->n_cus;
+	{
+		hipDeviceProp_t prop;
+		d->is_gfx950 = hipGetDeviceProperties(&prop, device) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+	}
 
 	// ---- build one blob with all tables
 	std::vector<uint8_t> blob;
@@ -704,7 +708,7 @@ int lw_decoder_device(const lw_decoder *d)
 // packets) a 15 us launch waits for whole CUs to drain: 130-150 us.  With a share, the streams made for this
 // decoder carry a CU mask and the planner sizes this decoder's launches for its own CUs.  A queue's mask bit i is CU i / 8 of
 // XCD i % 8, and a queue must keep CUs on EVERY XCD -- its workgroups go round the XCDs whatever the mask says; a mask that
-// empties an XCD is ignored as a whole (both measured: tools/micro/cumask.hip, profiles/r05_cumask.txt) -- so a share is the
+// empties an XCD is ignored as a whole (both measured: tools/micro/cumask.hip, profiles/r06_cumask.txt) -- so a share is the
 // same CUs [n j / k, n (j + 1) / k) of each XCD's n = 32, not whole XCDs: tenants never meet on a CU, they do share the L2s.
 int lw_decoder_set_cu_share(lw_decoder *d, unsigned part, unsigned parts)
 {
@@ -712,6 +716,14 @@ int lw_decoder_set_cu_share(lw_decoder *d, unsigned part, unsigned parts)
 		return LW_ERR_NULL_ARG;
 	const unsigned per_xcd = (unsigned)d->n_cus_device / LW_XCDS;
 	if (parts > per_xcd)
+		return LW_ERR_UNSUPPORTED;
+	// the mask layout (bit i = CU i / 8 of XCD i % 8; a queue keeps CUs on every XCD) was measured on MI355X = gfx950 with eight
+	// XCDs of equally many CUs (tools/micro/cumask.hip, profiles/r06_cumask.txt): anything else gets no share
+	if (parts > 1 && (!d->is_gfx950 || (unsigned)d->n_cus_device % LW_XCDS != 0))
+		return LW_ERR_UNSUPPORTED;
+	// ... and none once this process has copied on the device's copier stream (a tenant's ring without a share): the two kinds of
+	// stream in one process were seen to keep it from exiting (include/lewton_amd.h)
+	if (parts > 1 && (lw_tenant_streams(d->device) & LW_TENANT_COPIER_STREAM))
 		return LW_ERR_UNSUPPORTED;
 	std::lock_guard<std::mutex> g(d->mu);
 	d->cu_mask.clear();
@@ -758,7 +770,25 @@ int lw_decoder_shares_device(const lw_decoder *d)
 
 } // extern "C"
 
-// a stream for this decoder's launches: non-blocking, on the decoder's share of the device
+// Which kinds of tenant stream this process has made on each device (include/lewton_amd.h, "Known hazard"): once set, never cleared
+static std::atomic<int> g_tenant_streams[256];
+
+int lw_tenant_streams(int device)
+{
+	return device >= 0 && device < 256 ? g_tenant_streams[device].load() : 0;
+}
+
+void lw_tenant_streams_note(int device, int kind)
+{
+	if (device >= 0 && device < 256)
+		g_tenant_streams[device].fetch_or(kind);
+}
+
+// A stream for this decoder's launches, on the decoder's share of the device.  Without a share: a non-blocking stream.  With one:
+// hipExtStreamCreateWithCUMask takes no flags and makes a DEFAULT (blocking) stream -- a CU-masked stream synchronises implicitly
+// with the NULL stream, so any null-stream work in the process (a synchronous hipMemcpy, torch's legacy default stream) orders
+// itself against every such tenant's launches; the library keeps its own null-stream calls off the rings' paths
+// (lw_batch_device_status clears the edge flags on the batch's own stream).
 hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s)
 {
 	std::vector<uint32_t> mask;
@@ -768,6 +798,9 @@ hipError_t lw_decoder_stream_create(lw_decoder *d, hipStream_t *s)
 	}
 	if (mask.empty())
 		return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+	if (lw_tenant_streams(d->device) & LW_TENANT_COPIER_STREAM)
+		return hipErrorNotSupported; // (lw_ring_create checks first and says LW_ERR_UNSUPPORTED)
+	lw_tenant_streams_note(d->device, LW_TENANT_MASKED_STREAMS);
 	return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
 }
 
