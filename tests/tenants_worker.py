@@ -20,6 +20,10 @@ def run(share):
     o_id, o_st = oracle_headers(setup)
     dec = audio.Decoder(ident, st, 0)
     total = N.lw_decoder_cu_count(dec._h)
+    if share:   # the share of a lone decoder: CUs [32 j / k, 32 (j + 1) / k) of each of the eight XCDs
+        assert total == 256 and [dec.set_cu_share(j, 3) for j in range(3)] == [88, 88, 80]
+        assert dec.set_cu_share(0, 1) == total and dec.set_cu_share(31, 32) == 8
+        assert N.lw_decoder_set_cu_share(dec._h, 0, 33) == N.ERR_UNSUPPORTED and N.lw_decoder_set_cu_share(dec._h, 2, 2) != 0
     dec.close()
     S, per, n_calls = 512, 16, 5
     streams = [sg.make_stream(setup, "L", n_calls * per, seed=900 + s) for s in range(16)]
