@@ -409,7 +409,8 @@ def main():
                     # against, and the mixed shapes at the batch size the library's own staging ring runs with
                     ("17", "configs[2] as SURVEY 8(d) words it: ONE stream x 4096 packets, LLSSSSSSSSL", 4096, False),
                     ("18", "ONE stream x 4096 long packets", 4096, False),
-                    ("16", "5.1 @ 48 kHz with libvorbis' coupling steps (k_prep + k_long)", 4096, False),
+                    ("16", "5.1 @ 48 kHz with libvorbis' coupling steps (a channel in three steps: evaluated inside k_long's waves)", 4096, False),
+                    ("19", "stereo, two long modes with their own mappings (k_prep + k_long)", 4096, False),
                     ("9", "generic fallback (stereo 8/11 long blocks, forced)", 4096, True),
                     ("3", "configs[2] mixed short/long, 16 384 packets per launch", 16384, False),
                     ("14", "mixed 512/1024, 16 384 packets per launch", 16384, False),

@@ -1056,6 +1056,11 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 		for (size_t i = 0; i < units.size() && i < LW_FAST_WAVES; i++)
 			L.units[i] = units[i];
 		L.d_halo = b->d_halo;
+		if (!b->use_l10 && !b->use_l12 && !d->fast.pre.empty()) { // k_long<..., PRE>: the units' own coupling programs
+			L.pre_on = 1;
+			for (size_t i = 0; i < d->fast.pre.size() && i < LW_FAST_WAVES; i++)
+				L.pre[i] = d->fast.pre[i];
+		}
 	}
 	auto short_launch = [&](int cls) {
 		const LwShortPlan &bp = d->blkp[cls];

@@ -3,8 +3,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <string>
 
 namespace lw {
 
@@ -28,6 +30,7 @@ struct Writer {
 // Every other shape gets the canonicalising pre-pass (LwPrepPlan, lw_fast.hpp): uncoupled units, the channels whose floor the
 // kernels cannot stage on the unit floor.  Returns nullptr, or why the stream shape is not covered at all.
 struct UnitPlan {
+	std::vector<uint32_t> pre;   // (allow_pre) per unit: coupling steps evaluated inside the wave (LwFastPlan::pre), or empty
 	std::vector<LwFastUnit> units;
 	std::vector<int> floor_slot; // per floor of the setup: staged slot or -1
 	uint32_t n_staged = 0;       // staged slots incl. the unit floor's
@@ -48,7 +51,79 @@ bool lw_unified_classes(const Ident &id, const Setup &s)
 	return false;
 }
 
-static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, size_t max_posts, UnitPlan &up)
+// ---- coupling steps inside the waves (LwFastPlan::pre): the values the channels have after the steps BEHIND the disjoint prefix
+// (applied first, last step of the list first), as expression strings over the raw vectors: R<c>, M(e,e), A(e,e)
+static void pre_exprs(const Mapping &mp, size_t ch, size_t prefix, std::vector<std::string> &expr)
+{
+	expr.resize(ch);
+	for (size_t c = 0; c < ch; c++)
+		expr[c] = "R" + std::to_string(c);
+	for (size_t k = mp.mag.size(); k-- > prefix;) {
+		const size_t m = mp.mag[k], a = mp.ang[k];
+		const std::string nm = "M(" + expr[m] + "," + expr[a] + ")", na = "A(" + expr[m] + "," + expr[a] + ")";
+		expr[m] = nm;
+		expr[a] = na;
+	}
+}
+
+// the program of one unit: registers r0 = raw channel a, r1 = raw channel b, t0 / t1 = up to two more raw channels; up to
+// LW_PRE_MAX_OPS steps (m_reg, a_reg) in place until r0 (and r1) hold the wanted expressions.  False: not expressible that way.
+static bool pre_program(const std::vector<std::string> &expr, int ch_a, int ch_b, uint32_t &prog)
+{
+	const std::string &want_a = expr[(size_t)ch_a];
+	const std::string want_b = ch_b >= 0 ? expr[(size_t)ch_b] : std::string();
+	// the raw channels the two expressions mention, besides the unit's own
+	std::vector<int> extra;
+	for (const std::string *e : {&want_a, &want_b})
+		for (size_t i = 0; i < e->size(); i++)
+			if ((*e)[i] == 'R') {
+				const int c = std::atoi(e->c_str() + i + 1);
+				if (c != ch_a && c != ch_b && std::find(extra.begin(), extra.end(), c) == extra.end())
+					extra.push_back(c);
+			}
+	if (extra.size() > 2)
+		return false;
+	struct State {
+		std::string r[4];
+		uint8_t ops[LW_PRE_MAX_OPS];
+		uint32_t n;
+	};
+	State s0;
+	s0.r[0] = "R" + std::to_string(ch_a);
+	s0.r[1] = ch_b >= 0 ? "R" + std::to_string(ch_b) : std::string();
+	s0.r[2] = extra.size() > 0 ? "R" + std::to_string(extra[0]) : std::string();
+	s0.r[3] = extra.size() > 1 ? "R" + std::to_string(extra[1]) : std::string();
+	s0.n = 0;
+	auto done = [&](const State &st) { return st.r[0] == want_a && (ch_b < 0 || st.r[1] == want_b); };
+	std::vector<State> level{s0};
+	for (uint32_t depth = 0; depth <= LW_PRE_MAX_OPS; depth++) {
+		for (const State &st : level)
+			if (done(st)) {
+				prog = (extra.size() > 0 ? (uint32_t)extra[0] : LW_PRE_NO_CH) | ((extra.size() > 1 ? (uint32_t)extra[1] : LW_PRE_NO_CH) << 8) | (st.n << 28);
+				for (uint32_t i = 0; i < st.n; i++)
+					prog |= (uint32_t)st.ops[i] << (16 + 4 * i);
+				return true;
+			}
+		if (depth == LW_PRE_MAX_OPS)
+			break;
+		std::vector<State> next;
+		for (const State &st : level)
+			for (int m = 0; m < 4; m++)
+				for (int a = 0; a < 4; a++) {
+					if (m == a || st.r[m].empty() || st.r[a].empty() || st.r[m].size() + st.r[a].size() > 200)
+						continue;
+					State nx = st;
+					nx.r[m] = "M(" + st.r[m] + "," + st.r[a] + ")";
+					nx.r[a] = "A(" + st.r[m] + "," + st.r[a] + ")";
+					nx.ops[nx.n++] = (uint8_t)((m << 2) | a);
+					next.push_back(std::move(nx));
+				}
+		level.swap(next);
+	}
+	return false;
+}
+
+static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, size_t max_posts, UnitPlan &up, bool allow_pre = false)
 {
 	const size_t ch = id.channels, nmodes = s.modes.size();
 	const bool unified = lw_unified_classes(id, s);
@@ -79,10 +154,14 @@ static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, s
 		role[m] = 1;
 		role[a] = 2;
 	}
+	bool coupling_same = true;
 	for (size_t m : modes) {
 		const Mapping &mp = s.mappings[s.modes[m].mapping];
-		if (!why && (mp.mag != ref.mag || mp.ang != ref.ang))
-			why = blockflag ? "long modes with different coupling lists" : "short modes with different coupling lists";
+		if (mp.mag != ref.mag || mp.ang != ref.ang) {
+			coupling_same = false;
+			if (!why)
+				why = blockflag ? "long modes with different coupling lists" : "short modes with different coupling lists";
+		}
 	}
 	// floors: a channel is native when all covered modes give it the same floor-1 configuration of at most max_posts posts
 	std::vector<int> native(ch, -1);
@@ -132,7 +211,29 @@ static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, s
 	std::vector<int> slot(ch, -1);
 	for (size_t c = 0; c < ch; c++)
 		slot[c] = native[c] >= 0 && up.floor_slot[native[c]] >= 0 ? up.floor_slot[native[c]] : up.prep.unit_slot;
-	up.prep.on = why != nullptr;
+	// A coupling list that is not disjoint pairs, everything else native (libvorbis' 5.1): the steps behind the disjoint prefix
+	// inside the waves, if every unit's channels can be had with a short program (LwFastPlan::pre) -- no pre-pass then
+	bool pre_on = false;
+	std::vector<std::string> expr;
+	if (allow_pre && why && !need_unit && coupling_same && !std::strcmp(why, "a channel takes part in more than one coupling step")) {
+		size_t prefix = 0;
+		std::vector<bool> seen(ch, false);
+		while (prefix < ref.mag.size() && !seen[ref.mag[prefix]] && !seen[ref.ang[prefix]]) {
+			seen[ref.mag[prefix]] = seen[ref.ang[prefix]] = true;
+			prefix++;
+		}
+		pre_exprs(ref, ch, prefix, expr);
+		std::fill(partner.begin(), partner.end(), -1);
+		std::fill(role.begin(), role.end(), 0);
+		for (size_t k = 0; k < prefix; k++) {
+			partner[ref.mag[k]] = ref.ang[k];
+			partner[ref.ang[k]] = ref.mag[k];
+			role[ref.mag[k]] = 1;
+			role[ref.ang[k]] = 2;
+		}
+		pre_on = true; // (withdrawn below if a unit's program does not exist)
+	}
+	up.prep.on = why != nullptr && !pre_on;
 	up.prep.why = why ? why : "";
 	if (up.prep.on) {
 		up.prep.action.assign(nmodes * ch, LW_PREP_NONE);
@@ -186,6 +287,18 @@ static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, s
 	}
 	if (up.units.size() > LW_FAST_WAVES)
 		return "more units than waves in a workgroup";
+	if (pre_on) {
+		for (const LwFastUnit &u : up.units) {
+			uint32_t prog = 0;
+			if (!pre_program(expr, u.ch_a, u.ch_b, prog)) {
+				// not with two more channels and three steps: the pre-pass after all (plan again without the attempt)
+				up = UnitPlan();
+				return plan_units(id, s, blockflag, max_posts, up, false);
+			}
+			up.pre.push_back(prog);
+		}
+		up.prep.why = why; // (census: what the waves do themselves)
+	}
 	return nullptr;
 }
 
@@ -207,13 +320,14 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 	}
 	const uint32_t n = 1u << id.bs1, n2 = n / 2, n8 = n / 8;
 	UnitPlan up;
-	if (const char *why = plan_units(id, s, true, 64, up)) {
+	if (const char *why = plan_units(id, s, true, 64, up, true)) {
 		plan.why_not = why;
 		return;
 	}
 	std::memcpy(plan.long_mode_mask, up.mode_mask, sizeof(plan.long_mode_mask));
 	plan.units = up.units;
 	plan.prep = up.prep;
+	plan.pre = up.pre;
 	// the same units with every channel pair split over two waves
 	for (const LwFastUnit &u : up.units) {
 		if (u.ch_b < 0) {
@@ -234,7 +348,7 @@ void build_fast_plan(const Ident &id, const Setup &s, LwFastPlan &plan)
 		plan.units_split.push_back(a);
 		plan.units_split.push_back(b);
 	}
-	if (plan.units_split.size() > LW_FAST_WAVES)
+	if (plan.units_split.size() > LW_FAST_WAVES || !plan.pre.empty()) // (PRE: whole pairs only)
 		plan.units_split.clear();
 	plan.n_staged_floors = up.n_staged;
 	std::memcpy(plan.staged_floor_F, up.staged_F, sizeof(plan.staged_floor_F));

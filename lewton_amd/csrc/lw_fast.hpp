@@ -85,10 +85,21 @@ struct LwPrepPlan {
 	const char *why = "";         // what made the pre-pass necessary (census)
 };
 
+// Coupling steps inside the waves (k_long<..., PRE>; round 6).  A coupling list that is not disjoint pairs -- libvorbis' own 5.1
+// mapping: (0,2), (3,4), (0,1), (0,3) -- splits into a PREFIX of disjoint pairs, which are the last steps the decoder applies
+// (audio.rs:990-1002 walks the list backwards) and stay the units' own steps, and the steps behind it, which come first.  Those a
+// unit evaluates itself for its own channels: it loads up to two more channels of the packet (t0, t1: the other readers of these
+// lines are waves of the same workgroup, they meet in L2) and runs up to three steps on the registers r0 = channel a, r1 = channel
+// b, t0, t1 -- each step (m, a) -> (m', a') in place, results nobody asked for simply stay unused -- before its own step.  One
+// dword per unit: t0 | t1 << 8 (channel, 0xFF none) | op0 << 16 | op1 << 20 | op2 << 24 | number of ops << 28, op = m_reg << 2 | a_reg.
+#define LW_PRE_NO_CH 0xFFu
+#define LW_PRE_MAX_OPS 3u
+
 struct LwFastPlan {
 	bool eligible = false;
 	const char *why_not = "";
 	LwPrepPlan prep;
+	std::vector<uint32_t> pre;               // per unit: its program (see above); empty: the stream needs none
 	std::vector<uint8_t> image;
 	LwFastImage off{};
 	uint8_t long_mode_mask[32] = {0};        // bit m set: mode m is a long mode covered by the plan
@@ -147,6 +158,8 @@ struct LwFastLaunch {
 	const uint16_t *d_sid12; // k_long12: static interval table of the staged floors (HBM)
 	LwFastUnit units[LW_FAST_WAVES];
 	float *d_halo;
+	uint32_t pre_on;              // k_long<..., PRE>: the units evaluate coupling steps themselves, pre[u] = unit u's program (LwFastPlan::pre)
+	uint32_t pre[LW_FAST_WAVES];
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -72,6 +72,7 @@ struct LwFastArgs {
 	uint32_t edge_n;           // k_long10<EDGE>: values per raw edge = blocksize_0 / 4 (k_long: always LW_EDGE_VALUES)
 	const float *tabA;         // k_long12: the block size's A table (header_cached.rs:64-99) in HBM, read as pairs by step 1
 	const uint16_t *sid12;     // k_long12: static interval indices of the staged floors (LwL12Layout)
+	uint32_t pre[LW_FAST_WAVES]; // k_long<..., PRE>: per wave, the coupling steps it evaluates itself (LwFastPlan::pre, lw_fast.hpp)
 };
 static_assert(offsetof(LwFastArgs, waves) == 48, "kernel reads waves[] through the kernarg segment pointer");
 
@@ -375,7 +376,8 @@ __device__ __forceinline__ void issue_floor_loads(const LwFastArgs &F, const Ite
 }
 
 // PAIR: the caller knows that the unit has two channels (every residue register is written: none stays live before the call)
-template <bool PAIR = false>
+// NT = false (k_long<..., PRE>): the vectors are read by several waves of the workgroup -- ordinary loads, the later readers meet them in L2
+template <bool PAIR = false, bool NT = true>
 __device__ __forceinline__ void issue_residue_loads(const LwFastArgs &F, const ItemRegs &it, const LwFastUnit &un,
 		uint32_t lane, Pref &p)
 {
@@ -384,20 +386,44 @@ __device__ __forceinline__ void issue_residue_loads(const LwFastArgs &F, const I
 	const float4_t *s0 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_a * 1024u);
 #pragma unroll
 	for (int x = 0; x < 4; x++)
-		p.r[0][x] = __builtin_nontemporal_load(&s0[64 * x + lane]);
+		p.r[0][x] = NT ? __builtin_nontemporal_load(&s0[64 * x + lane]) : s0[64 * x + lane];
 	if (PAIR || un.ch_b >= 0) {
 		const float4_t *s1 = reinterpret_cast<const float4_t *>(F.residue + it.res_off + (uint32_t)un.ch_b * 1024u);
 #pragma unroll
 		for (int x = 0; x < 4; x++)
-			p.r[1][x] = __builtin_nontemporal_load(&s1[64 * x + lane]);
+			p.r[1][x] = NT ? __builtin_nontemporal_load(&s1[64 * x + lane]) : s1[64 * x + lane];
 	}
 }
 
 // the ordinary order: residues first, the floor records behind them
+template <bool NT = true>
 __device__ __forceinline__ void issue_loads(const LwFastArgs &F, const ItemRegs &it, const LwFastUnit &un, uint32_t lane, Pref &p)
 {
-	issue_residue_loads(F, it, un, lane, p);
+	issue_residue_loads<false, NT>(F, it, un, lane, p);
 	issue_floor_loads(F, it, un, lane, p);
+}
+
+// ---- coupling steps inside the wave (k_long<..., PRE>; LwFastPlan::pre in lw_fast.hpp): up to two more raw channels of the packet ...
+struct PreRegs {
+	float4_t t[2][4]; // same lane layout as Pref::r
+};
+
+__device__ __forceinline__ void issue_pre_loads(const LwFastArgs &F, const ItemRegs &it, uint32_t prog, uint32_t lane, PreRegs &q)
+{
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const uint32_t c = (prog >> (8 * k)) & 0xffu;
+		if (c != LW_PRE_NO_CH) { // (wave-uniform)
+			const float4_t *s = reinterpret_cast<const float4_t *>(F.residue + it.res_off + c * 1024u);
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+				q.t[k][x] = s[64 * x + lane];
+		} else {
+#pragma unroll
+			for (int x = 0; x < 4; x++)
+				asm volatile("" : "=v"(q.t[k][x])); // (never read: defined, so that the previous round's values are not kept alive through the transform)
+		}
+	}
 }
 
 // ---- floor segment table of one channel (one 16-byte entry per static interval), built by lanes = posts:
@@ -914,6 +940,48 @@ __device__ __forceinline__ void decouple_pair(Pref &pf)
 	}
 }
 
+// ... and up to three inverse-coupling steps (audio.rs:762-777) on the registers r0 / r1 (the unit's channels) and t0 / t1, each
+// (magnitude, angle) -> (magnitude', angle') in place, before the unit's own step: op = magnitude register << 2 | angle register
+__device__ __forceinline__ void couple_quad(float4_t &M, float4_t &A)
+{
+	float m[4] = {M.x, M.y, M.z, M.w};
+	float a[4] = {A.x, A.y, A.z, A.w};
+	decouple4(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
+	M = float4_t{m[0], m[1], m[2], m[3]};
+	A = float4_t{a[0], a[1], a[2], a[3]};
+}
+
+// (quarter by quarter of the vectors: the program runs on 16 registers at a time -- with whole vectors under the switch the
+// compiler spilled 300-500 registers around it)
+__device__ __forceinline__ void apply_pre(uint32_t prog, Pref &pf, PreRegs &q)
+{
+	const uint32_t n = prog >> 28;
+#pragma unroll
+	for (int x = 0; x < 4; x++) {
+		float4_t v0 = pf.r[0][x], v1 = pf.r[1][x], v2 = q.t[0][x], v3 = q.t[1][x];
+#pragma nounroll
+		for (uint32_t i = 0; i < n; i++) { // (wave-uniform control: scalar branches)
+			switch ((prog >> (16u + 4u * i)) & 0xfu) {
+			case 0x1: couple_quad(v0, v1); break;
+			case 0x2: couple_quad(v0, v2); break;
+			case 0x3: couple_quad(v0, v3); break;
+			case 0x4: couple_quad(v1, v0); break;
+			case 0x6: couple_quad(v1, v2); break;
+			case 0x7: couple_quad(v1, v3); break;
+			case 0x8: couple_quad(v2, v0); break;
+			case 0x9: couple_quad(v2, v1); break;
+			case 0xb: couple_quad(v2, v3); break;
+			case 0xc: couple_quad(v3, v0); break;
+			case 0xd: couple_quad(v3, v1); break;
+			case 0xe: couple_quad(v3, v2); break;
+			default: break;
+			}
+		}
+		pf.r[0][x] = v0;
+		pf.r[1][x] = v1;
+	}
+}
+
 // ---- from the landed residues to the spectrum, floor stage included (the path of a wave whose residues were requested
 //      before it had time for the floor stage): segment tables, inverse coupling, floor x residue fused into the gathers
 template <int NCH, bool SPLIT = false>
@@ -1329,7 +1397,7 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t byte_addr, uint32_t need)
 // short slope are copied un-windowed (audio.rs:1119), the raw edges pa(448..511) / pb(448..511) go to the edge buffer.
 // SPLIT: sparse launches run one channel per wave (LW_UNIT_SPLIT_*, lw_fast.hpp); a separate instantiation, so that the dense
 // launches keep their register allocation.
-template <int FMT, bool RIGHT_ONLY, bool TD = false, bool EDGE = false, bool SPLIT = false>
+template <int FMT, bool RIGHT_ONLY, bool TD = false, bool EDGE = false, bool SPLIT = false, bool PRE = false>
 __global__ void __launch_bounds__(LW_WG) k_long(LwFastArgs F)
 {
 	constexpr bool MIXF = false, mix_drop_flags = false;
@@ -1772,7 +1840,7 @@ __device__ __forceinline__ void mix_short_role(const LwShortArgs &F, const LwMix
 template <int FMT>
 __global__ void __launch_bounds__(LW_WG) k_mix(LwFastArgs F, LwShortArgs FS, LwMixArgs M)
 {
-	constexpr bool RIGHT_ONLY = false, TD = false, EDGE = true, SPLIT = true, MIXF = true;
+	constexpr bool RIGHT_ONLY = false, TD = false, EDGE = true, SPLIT = true, MIXF = true, PRE = false;
 	uint32_t *const edge_flags = M.flags;
 	const bool mix_drop_flags = M.drop_flags != 0;
 #define LW_LONG_BODY_AFTER_STAGE                                                  \
@@ -1888,6 +1956,7 @@ static hipError_t long_prepare(const LwDevTables &T, const LwBatchDev &B, const 
 	for (uint32_t w = 0; w < LW_FAST_WAVES; w++) {
 		F.waves[w] = L.units[w % L.n_units];
 		F.waves[w].slot = (uint8_t)(w / L.n_units);
+		F.pre[w] = L.pre_on ? L.pre[w % L.n_units] : 0u;
 	}
 	F.late_from = 0xFFFFFFFFu;
 	// k_long needs its 152 KB of dynamic LDS opted in once per device (LwPerDeviceOnce, lw_kernels.hpp)
@@ -1903,7 +1972,15 @@ static hipError_t long_prepare(const LwDevTables &T, const LwBatchDev &B, const 
 			(const void *)k_long<LW_OUT_I16_PLANAR, false, false, false, true>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, false, true>,
 			(const void *)k_long<LW_OUT_F32_PLANAR, false, false, false, true>, (const void *)k_long<LW_OUT_I16_PLANAR, false, false, true, true>,
 			(const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true, true>, (const void *)k_long<LW_OUT_F32_PLANAR, false, false, true, true>,
-			(const void *)k_mix<LW_OUT_I16_PLANAR>, (const void *)k_mix<LW_OUT_I16_INTERLEAVED>, (const void *)k_mix<LW_OUT_F32_PLANAR>};
+			(const void *)k_mix<LW_OUT_I16_PLANAR>, (const void *)k_mix<LW_OUT_I16_INTERLEAVED>, (const void *)k_mix<LW_OUT_F32_PLANAR>,
+			// PRE (coupling steps inside the waves): halo pre-pass, plain, TD and EDGE forms in the three sample formats
+			(const void *)k_long<LW_OUT_I16_PLANAR, true, false, false, false, true>,
+			(const void *)k_long<LW_OUT_I16_PLANAR, false, false, false, false, true>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, false, false, true>,
+			(const void *)k_long<LW_OUT_F32_PLANAR, false, false, false, false, true>,
+			(const void *)k_long<LW_OUT_I16_PLANAR, false, true, false, false, true>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false, true, false, false, true>,
+			(const void *)k_long<LW_OUT_F32_PLANAR, false, true, false, false, true>,
+			(const void *)k_long<LW_OUT_I16_PLANAR, false, false, true, false, true>, (const void *)k_long<LW_OUT_I16_INTERLEAVED, false, false, true, false, true>,
+			(const void *)k_long<LW_OUT_F32_PLANAR, false, false, true, false, true>};
 		for (const void *f : fns) {
 			const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			if (e != hipSuccess)
@@ -1918,7 +1995,9 @@ static hipError_t long_prepare(const LwDevTables &T, const LwBatchDev &B, const 
 		F.n_items = L.n_halo_items;
 		F.per_round = 1; // spread the few halo packets over the whole chip: one packet per workgroup
 		F.rounds = 1;
-		const hipError_t e = L.split
+		const hipError_t e = L.pre_on
+			? lw_launch_k(k_long<LW_OUT_I16_PLANAR, true, false, false, false, true>, dim3(L.n_halo_items), dim3(LW_WG), lds, st, F)
+			: L.split
 			? lw_launch_k(k_long<LW_OUT_I16_PLANAR, true, false, false, true>, dim3(L.n_halo_items), dim3(LW_WG), lds, st, F)
 			: lw_launch_k(k_long<LW_OUT_I16_PLANAR, true>, dim3(L.n_halo_items), dim3(LW_WG), lds, st, F);
 		if (e != hipSuccess)
@@ -1949,6 +2028,14 @@ hipError_t lw_launch_long(const LwDevTables &T, const LwBatchDev &B, const LwFas
 	if (L.n_items) {
 #define LW_LAUNCH_MAIN(F_)                                                                                     \
 	do {                                                                                                      \
+		if (L.pre_on) { /* coupling steps inside the waves (never with split units, never the stereo frame stores) */ \
+			constexpr int FP = F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_;                      \
+			if (L.edge_mode)                                                                                  \
+				return lw_launch_k(k_long<FP, false, false, true, false, true>, dim3(grid), dim3(LW_WG), lds, st, F); \
+			if (L.has_tdonly)                                                                                 \
+				return lw_launch_k(k_long<FP, false, true, false, false, true>, dim3(grid), dim3(LW_WG), lds, st, F); \
+			return lw_launch_k(k_long<FP, false, false, false, false, true>, dim3(grid), dim3(LW_WG), lds, st, F); \
+		}                                                                                                     \
 		if (L.split && !L.has_tdonly) { /* sparse launch: one channel per wave (generic interleaved stores: a wave has one channel) */ \
 			if (L.edge_mode)                                                                                  \
 				return lw_launch_k(k_long<F_ == LW_OUT_I16_ITL_STEREO ? LW_OUT_I16_INTERLEAVED : F_, false, false, true, true>,  \

@@ -358,6 +358,8 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 		const LwPrepPlan *pp = fast.eligible ? &fast.prep : blk[1].eligible ? &blk[1].prep : nullptr;
 		if (any_long && pp && pp->on)
 			lng += std::string(" + k_prep (") + pp->why + ")";
+		else if (any_long && fast.eligible && !fast.pre.empty())
+			lng += std::string(", coupling steps inside the waves (") + fast.prep.why + ")";
 	}
 	if (!any_short)
 		sht = "none";

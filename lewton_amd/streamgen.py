@@ -1165,6 +1165,13 @@ _RANDOM_BS = [(8, 11)] * 7 + [(8, 10), (9, 10), (8, 9), (9, 12), (10, 12), (8, 1
 def random_setup(rng, channels: Optional[int] = None, blocksizes: Optional[Tuple[int, int]] = None, allow_floor0: bool = True
                  ) -> StreamSetup:
     """One draw from the space of legal ident + setup headers (see the section comment).  `rng`: numpy Generator."""
+    while True:
+        st = _random_setup_once(rng, channels, blocksizes, allow_floor0)
+        if len(st.codebooks) <= 256:       # (the codebook count is one byte, header.rs:1096; a draw with more books is drawn again)
+            return st
+
+
+def _random_setup_once(rng, channels, blocksizes, allow_floor0) -> StreamSetup:
     bs0, bs1 = blocksizes if blocksizes else _RANDOM_BS[int(rng.integers(0, len(_RANDOM_BS)))]
     if channels is None:
         channels = int(rng.choice([1, 2, 2, 2, 2, 3, 4, 5, 6, 6, 7, 8]))
@@ -1222,7 +1229,6 @@ def random_setup(rng, channels: Optional[int] = None, blocksizes: Optional[Tuple
         mappings.append(Mapping(random_coupling(rng, channels), mux, sf, sr))
         map_of_class[bf].append(len(mappings) - 1)
         modes.append(Mode(bf, len(mappings) - 1))
-    assert len(books) <= 256
     return StreamSetup(channels, sample_rate, bs0, bs1, books, floors, residues, mappings, modes)
 
 

@@ -30,12 +30,24 @@ def mono():
 
 def surround51_libvorbis_coupling(bs0: int = 8, bs1: int = 11):
     """5.1 @ 48 kHz with the four coupling steps libvorbis writes for six channels -- (0,2), (3,4), (0,1), (0,3): channel 0 takes
-    part in three of them, channel 3 in two -- so the stream shape reaches k_long only behind the canonicalising pre-pass k_prep"""
+    part in three of them, channel 3 in two.  The disjoint prefix (0,2), (3,4) stays the units' own step, the two steps behind it
+    (applied first) are evaluated inside k_long's waves (LwFastPlan::pre); other block sizes take the pre-pass k_prep"""
     st = sg.surround51_setup(48000, bs0, bs1)
     if bs1 == 10:
         st.floors[3].x_rest = [64, 16, 256, 128, 32, 384]   # (the generator's LFE floor repeats the implied end post at x = 512)
     for m in st.mappings:
         m.coupling = [(0, 2), (3, 4), (0, 1), (0, 3)]
+    return st
+
+
+def two_long_modes(bs0: int = 8, bs1: int = 11):
+    """the bench stream with a second long mode that has its own mapping (another floor, no coupling): legal (header.rs:1060-1080),
+    never written by an encoder -- the long blocks reach k_long behind the canonicalising pre-pass k_prep"""
+    import numpy as np
+    st = sg.stereo_setup(44100, bs0, bs1)
+    st.floors.append(sg.random_floor1(np.random.default_rng(5), st.codebooks, bs1, posts=40))
+    st.mappings.append(sg.Mapping([], [0, 0], [2], [1]))
+    st.modes.append(sg.Mode(1, 2))
     return st
 
 
@@ -87,7 +99,9 @@ def configs(packets: int = 4096) -> List[Workload]:
         # round 6: a stream shape behind the canonicalising pre-pass; SURVEY 8(d) config 3 as written (ONE stream, state carried
         # through the whole launch: audio.rs:1082-1154, examples/perf.rs:35-44) and its all-long counterpart
         Workload("16", "5.1 @ 48 kHz long blocks, libvorbis' coupling steps (a channel in three steps)", surround51_libvorbis_coupling,
-                 "L", 256, per, "k_prep applies every coupling step, k_long runs uncoupled channel pairs"),
+                 "L", 256, per, "the steps behind the disjoint prefix (0,2), (3,4) are evaluated inside k_long's waves"),
+        Workload("19", "stereo long blocks of a stream with two long modes (own mappings)", two_long_modes, "L", 256, per,
+                 "k_prep applies the coupling step and multiplies the channels' floors, k_long runs an uncoupled pair on the unit floor"),
         Workload("17", "3b ONE stream x %d consecutive packets, LLSSSSSSSSL" % packets, lambda: sg.stereo_setup(44100, 8, 11),
                  "LLSSSSSSSSL", 1, packets, "a single stream cut over the chip's workgroups: halo pre-pass at every chunk start", 1),
         Workload("18", "ONE stream x %d consecutive long packets" % packets, lambda: sg.stereo_setup(44100, 8, 11), "L", 1, packets,

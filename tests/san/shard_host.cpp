@@ -69,16 +69,9 @@ int main(int argc, char **argv)
 	CHECK(setup, "setup header: %d", err);
 	const size_t n_call = S * per, ch = info.audio_channels, n1 = (size_t)1 << info.blocksize_1;
 	std::vector<int> devs(G, 0), one(1, 0);
-	Side A, B; // A: G shards, pipelined; B: one shard, call by call
-	A.sh = lw_sharder_create(id, setup, devs.data(), G, n_call, LW_FMT_I16_PLANAR, &err);
-	CHECK(A.sh, "sharder(G): %d", err);
-	B.sh = lw_sharder_create(id, setup, one.data(), 1, n_call, LW_FMT_I16_PLANAR, &err);
-	CHECK(B.sh, "sharder(1): %d", err);
-	{ // logical shards share the device's CUs unless the measurement hook gives each its own (checked below on a third sharder)
-		for (size_t g = 0; g < G; g++)
-			CHECK(lw_sharder_shard_cus(A.sh, g) == 256, "shard %zu of %zu plans for %d CUs", g, G, lw_sharder_shard_cus(A.sh, g));
-		CHECK(lw_sharder_shard_cus(B.sh, 0) == 256 && lw_sharder_shard_cus(B.sh, 1) == 0, "CUs of the lone shard");
-		lw_debug_sharder_share_cus(1); // CUs [32 j / G, 32 (j + 1) / G) of each of the 8 XCDs
+	{ // with the measurement hook every logical shard gets its own CUs: [32 j / G, 32 (j + 1) / G) of each of the 8 XCDs.  FIRST in
+	  // this process: once a ring of an unshared tenant has made the device's copier stream, CU shares are refused (lewton_amd.h)
+		lw_debug_sharder_share_cus(1);
 		lw_sharder *C = lw_sharder_create(id, setup, devs.data(), G, n_call, LW_FMT_I16_PLANAR, &err);
 		lw_debug_sharder_share_cus(0);
 		CHECK(C, "sharder(G, CU shares): %d", err);
@@ -92,6 +85,15 @@ int main(int argc, char **argv)
 		CHECK(G > 32 || sum == 256, "CU shares add up to %d", sum);
 		lw_sharder_destroy(C);
 	}
+	Side A, B; // A: G shards, pipelined; B: one shard, call by call
+	A.sh = lw_sharder_create(id, setup, devs.data(), G, n_call, LW_FMT_I16_PLANAR, &err);
+	CHECK(A.sh, "sharder(G): %d", err);
+	B.sh = lw_sharder_create(id, setup, one.data(), 1, n_call, LW_FMT_I16_PLANAR, &err);
+	CHECK(B.sh, "sharder(1): %d", err);
+	// logical shards share the device's CUs unless the measurement hook gives each its own
+	for (size_t g = 0; g < G; g++)
+		CHECK(lw_sharder_shard_cus(A.sh, g) == 256, "shard %zu of %zu plans for %d CUs", g, G, lw_sharder_shard_cus(A.sh, g));
+	CHECK(lw_sharder_shard_cus(B.sh, 0) == 256 && lw_sharder_shard_cus(B.sh, 1) == 0, "CUs of the lone shard");
 	if (dev_entropy) {
 		CHECK(lw_sharder_set_entropy_on_device(A.sh, 1) == LW_OK && lw_sharder_set_entropy_on_device(B.sh, 1) == LW_OK,
 		      "stream not eligible for the device entropy stage");

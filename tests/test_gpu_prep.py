@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import fuzz_gpu_setups as fz  # noqa: E402
 
 
-from lewton_amd.workloads import surround51_libvorbis_coupling  # noqa: E402
+from lewton_amd.workloads import surround51_libvorbis_coupling, two_long_modes  # noqa: E402
 
 
 def three_channels(bs0=8, bs1=11):
@@ -24,16 +24,6 @@ def three_channels(bs0=8, bs1=11):
     st = sg.stereo_setup(44100, bs0, bs1, residue_type=1)
     st.channels = 3
     st.mappings = [sg.Mapping([(0, 2), (0, 1)], [0, 0, 0], [0], [0]), sg.Mapping([(0, 2), (0, 1)], [0, 0, 0], [1], [1])]
-    return st
-
-
-def two_long_modes(bs0=8, bs1=11):
-    """two long modes with their own mappings: another floor, another coupling list"""
-    st = sg.stereo_setup(44100, bs0, bs1)
-    rng = np.random.default_rng(5)
-    st.floors.append(sg.random_floor1(rng, st.codebooks, bs1, posts=40))
-    st.mappings.append(sg.Mapping([], [0, 0], [2], [1]))
-    st.modes.append(sg.Mode(1, 2))
     return st
 
 
@@ -89,7 +79,10 @@ def _census(setup):
 def test_plan_sends_the_shape_through_k_prep_not_the_generic_kernels(name):
     make, why = CASES[name]
     parts = _census(make())
-    assert parts["long"].startswith("k_") and "k_prep" in parts["long"] and why in parts["long"], parts
+    # (a coupling list that only needs a few more steps -- libvorbis' 5.1, three channels -- is evaluated inside k_long's waves)
+    assert parts["long"].startswith("k_") and ("k_prep" in parts["long"] or "inside the waves" in parts["long"]) and why in parts["long"], parts
+    if name in ("surround51_libvorbis_coupling", "three_channels"):
+        assert parts["long"].startswith("k_long, coupling steps inside the waves"), parts
 
 
 @pytest.mark.gpu
@@ -106,7 +99,7 @@ def test_k_prep_shapes_three_ways(name, fmt_seed):
     # (the seed only picks the sample format and the stream count of run_setup: 3 k + fmt_seed -> format fmt_seed)
     checked, kernels, line, _dev = fz.run_setup(3 * 7 + fmt_seed, setup.channels, idp, stp, seqs, 24 * 10, rng,
                                                 (audio, header, Batch, po, N), length=24)
-    assert checked > 150 and "k_prep" in kernels, (kernels, line)
+    assert checked > 150 and ("k_prep" in kernels or "inside the waves" in line), (kernels, line)
     assert kernels & {"k_long", "k_long10", "k_long12", "k_big", "k_short", "k_mix", "k_mix10"}, kernels
     if name.startswith("equal_sizes"):
         assert "k_imdct_generic" not in kernels, kernels      # (no packet of such a stream is left to the generic kernels)
