@@ -178,6 +178,10 @@ void lw_batch_set_force_generic(lw_batch *b, int on);
 /* Test hook: rounds per workgroup of the specialised long-block kernel for this batch's next lw_batch_entropy (1..16;
  * 0 = the planner decides).  Exercises the hand-over of window state across rounds and workgroups on small batches. */
 void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
+/* Test hook: how the wave-pipeline kernels get the right half of a predecessor that is not the item in front (a chunk of the work
+ * list that starts inside a stream): -1 (default) = the predecessor is recomputed inside the launch as an item of its own where
+ * that pays, 0 = always by the pre-pass launch (k_long<halo>) */
+void lw_debug_batch_set_halo(lw_batch *b, int mode);
 /* test hook: 0 = never run a mixed short / long batch as one k_mix launch (two launches: k_long<EDGE>, k_short), -1 = where it applies */
 void lw_debug_batch_set_mix(lw_batch *b, int mode);
 /* test hook for blocksize_1 = 10 streams: -1 = k_long10 (long blocks next to short ones in its EDGE form where the short blocks run

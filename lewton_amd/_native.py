@@ -120,6 +120,7 @@ SYMBOLS = {
     "lw_debug_batch_set_mix": (None, [C.c_void_p, C.c_int]),
     "lw_debug_batch_break_mix": (None, [C.c_void_p, C.c_uint]),
     "lw_debug_break_mix": (None, [C.c_uint]),
+    "lw_debug_batch_set_halo": (None, [C.c_void_p, C.c_int]),
     "lw_debug_batch_set_long10": (None, [C.c_void_p, C.c_int]),
     "lw_batch_device_status": (C.c_int, [C.c_void_p]),
     "lw_batch_last_kernels": (C.c_char_p, [C.c_void_p]),

@@ -102,6 +102,10 @@ class Batch:
         """lw_batch_device_status: 0, or LW_ERR_DEVICE when a kernel of the completed launches raised the batch's error word"""
         return N.lw_batch_device_status(self._h)
 
+    def debug_set_halo(self, mode):
+        """test hook (lw_debug_batch_set_halo): 0 = predecessors of chunk starts by the pre-pass launch, -1 = inside the launch (default)"""
+        N.lw_debug_batch_set_halo(self._h, int(mode))
+
     def debug_set_rounds(self, rounds):
         """test hook (lw_debug_batch_set_rounds): rounds per workgroup of the specialised kernel, 0 = planner's choice"""
         N.lw_debug_batch_set_rounds(self._h, int(rounds))

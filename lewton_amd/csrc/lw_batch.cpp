@@ -53,7 +53,7 @@ lw_batch *lw_batch_create(lw_decoder *d, size_t max_packets, int fmt, int *err)
 		off = (off + bytes + 255) & ~(size_t)255;
 		return at;
 	};
-	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice(max_packets * sizeof(LwFastItem));
+	const size_t o_recs = slice(rec_b), o_floor = slice(fl_b), o_items = slice((max_packets + max_packets / 2 + 64) * sizeof(LwFastItem));
 	const size_t o_halo = slice(max_packets * sizeof(LwFastItem)), o_gen = slice(4 * max_packets * sizeof(uint32_t));
 	const size_t o_ola = slice(max_packets * sizeof(LwOlaDesc));
 	const size_t o_tasks = slice(max_packets * ch * sizeof(LwGenTask));
@@ -194,6 +194,12 @@ void lw_debug_batch_set_rounds(lw_batch *b, int rounds)
 {
 	if (b)
 		b->forced_rounds = rounds > 0 ? rounds : 0;
+}
+
+void lw_debug_batch_set_halo(lw_batch *b, int mode)
+{
+	if (b)
+		b->halo_mode = mode;
 }
 
 /* Entropy stage on the device (lw_dev_entropy.h, k_entropy): lw_batch_entropy then only reads the packet prologues, copies
@@ -800,26 +806,73 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			std::stable_sort(b->fast_order.begin(), b->fast_order.end(),
 					[&](uint32_t a, uint32_t c) { return b->fast_slot[a] < b->fast_slot[c]; });
 		const size_t n_fast_units = b->use_l10 ? d->blkp[b->l10_cls].units.size() : b->use_l12 ? d->blkp[1].units_split.size() : d->fast.units.size();
-		uint32_t per_round = LW_FAST_WAVES / (uint32_t)n_fast_units;
-		// as few rounds per workgroup as two resident workgroups per CU allow: small batches spread over the whole
-		// chip; big batches get long chunks (LDS hand-over, few halo recomputations)
-		const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
-		uint32_t rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (nf + per_pass - 1) / per_pass));
-		if (b->forced_rounds) { // lw_debug_batch_set_rounds (tests: hand-over paths across rounds and workgroups)
-			rounds = (uint32_t)std::min<int>(LW_FAST_MAX_ROUNDS, b->forced_rounds);
-		} else {
-			// spread the packets evenly over the CUs: with fewer packets than one full round per CU (the long blocks of a mixed
-			// short/long batch, a small batch: 1 117 long packets in chunks of 16 kept 186 of 256 CUs idle) or a packets-per-round
-			// count that does not divide the batch (5.1 with three units per packet: 5 packets x 4 rounds = 20 per workgroup put
-			// 4096 packets on 205 of 256 CUs) a workgroup takes fewer packets per round instead
-			const size_t cus = (size_t)std::max(1, d->n_cus);
-			per_round = (uint32_t)std::min<size_t>(per_round, std::max<size_t>(1, (nf + cus * rounds - 1) / (cus * rounds)));
+		const uint32_t per_round_max = LW_FAST_WAVES / (uint32_t)n_fast_units;
+		uint32_t per_round = per_round_max, rounds = 1;
+		// launch shape for `n_it` items: as few rounds per workgroup as two resident workgroups per CU allow -- small batches spread
+		// over the whole chip; big batches get long chunks (LDS hand-over, few recomputed predecessors)
+		auto shape = [&](size_t n_it) {
+			per_round = per_round_max;
+			const size_t per_pass = (size_t)per_round * std::max(1, d->n_cus);
+			rounds = (uint32_t)std::min<size_t>(LW_FAST_MAX_ROUNDS, std::max<size_t>(1, (n_it + per_pass - 1) / per_pass));
+			if (b->forced_rounds) { // lw_debug_batch_set_rounds (tests: hand-over paths across rounds and workgroups)
+				rounds = (uint32_t)std::min<int>(LW_FAST_MAX_ROUNDS, b->forced_rounds);
+			} else {
+				// spread the packets evenly over the CUs: with fewer packets than one full round per CU (the long blocks of a mixed
+				// short/long batch, a small batch: 1 117 long packets in chunks of 16 kept 186 of 256 CUs idle) or a packets-per-round
+				// count that does not divide the batch (5.1 with three units per packet: 5 packets x 4 rounds = 20 per workgroup put
+				// 4096 packets on 205 of 256 CUs) a workgroup takes fewer packets per round instead
+				const size_t cus = (size_t)std::max(1, d->n_cus);
+				per_round = (uint32_t)std::min<size_t>(per_round, std::max<size_t>(1, (n_it + cus * rounds - 1) / (cus * rounds)));
+			}
+			return per_round * rounds;
+		};
+		auto pkt_of = [&](size_t k) { return b->fast_idx[b->fast_order[k]]; };
+		// does item k's previous right half come from another packet of this launch's kernel (then it has to sit in the item in front)?
+		auto needs_pred = [&](const LwPacketRec &r) {
+			return !(r.prev == -1 || (r.flags & LW_RF_TDONLY) || (r.xflags & LW_XF_EDGE_L)) && r.prev >= 0 &&
+				(b->h_recs[r.prev].flags & fast_mark) == fast_mark;
+		};
+		uint32_t chunk = shape(nf);
+		// A chunk that starts inside a stream needs its predecessor's right half.  Round 6: the predecessor is recomputed IN the launch,
+		// as an item of its own in front (no samples, no state: the form of a stream's first packet, whose right half goes to the next
+		// wave through LDS) -- one more wave-slot per chunk start instead of a pre-pass launch in front of every such launch (ONE
+		// stream x 4096 long packets: 255 chunk starts; the pre-pass cost 6 of the launch's 21 us).  The pre-pass (k_long<RIGHT_ONLY>,
+		// LW_SRC_HALO) remains for forced launch shapes (tests), one-item chunks and batches where every other item would be one.
+		size_t n_inline = 0;
+		bool inline_halo = b->halo_mode != 0 && !b->forced_rounds;
+		for (int iter = 0; inline_halo && iter < 4; iter++) {
+			size_t pos = 0, nh = 0;
+			int64_t last = -1;
+			for (size_t k = 0; k < nf; k++) {
+				const LwPacketRec &r = b->h_recs[pkt_of(k)];
+				if (needs_pred(r) && (pos % chunk == 0 || last != (int64_t)r.prev)) {
+					nh++;
+					pos++;
+				}
+				pos++;
+				last = (int64_t)pkt_of(k);
+			}
+			const uint32_t c2 = shape(nf + nh);
+			if (c2 < 2 || nh * 3 > nf || nf + nh > b->max_packets + b->max_packets / 2 + 64) {
+				inline_halo = false;
+				chunk = shape(nf);
+				break;
+			}
+			n_inline = nh;
+			if (c2 == chunk)
+				break;
+			chunk = c2; // (another chunk length moves the chunk starts: count again)
+			if (iter == 3) {
+				inline_halo = false;
+				chunk = shape(nf);
+			}
 		}
+		if (!inline_halo)
+			n_inline = 0;
 		// a sparse launch (one round, at most half of a workgroup's waves in use) lasts as long as ONE wave's dependent chain:
 		// split every channel pair over two waves (LW_UNIT_SPLIT_*) -- each half does one channel's floor, transform and samples
 		b->fast_split = !b->use_l10 && !b->use_l12 && !b->forced_rounds && !b->has_tdonly && rounds == 1 && d->fast.units_split.size() > d->fast.units.size() &&
 			per_round * d->fast.units_split.size() <= LW_FAST_WAVES;
-		const uint32_t chunk = per_round * rounds;
 		b->fast_per_round = per_round;
 		b->fast_rounds = rounds;
 		b->fast_dense = 1;
@@ -841,12 +894,23 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 			}
 			it.pkt = idx;
 		};
+		size_t pos = 0; // items placed so far
 		for (size_t k = 0; k < nf; k++) {
-			const uint32_t idx = b->fast_idx[b->fast_order[k]];
+			const uint32_t idx = pkt_of(k);
 			const LwPacketRec &r = b->h_recs[idx];
-			LwFastItem &it = b->h_items[k];
+			const bool pred_in_front = pos % chunk != 0 && pos > 0 && b->h_items[pos - 1].pkt == (uint32_t)r.prev;
+			if (inline_halo && needs_pred(r) && !pred_in_front) {
+				// the predecessor once more, for its right half only: no previous window (no samples), no state, no edges, no td block
+				LwFastItem &h = b->h_items[pos++];
+				fill(h, (uint32_t)r.prev);
+				h.state_out = -1;
+				h.src_kind = LW_SRC_NONE;
+				h.flags = LW_IF_SILENT;
+				b->fast_dense = 0;
+			}
+			LwFastItem &it = b->h_items[pos];
 			fill(it, idx);
-			if (it.res_off != (uint32_t)(k * ch * n1h) || it.floor_off != (uint32_t)(k * ch * fstride))
+			if (it.res_off != (uint32_t)(pos * ch * n1h) || it.floor_off != (uint32_t)(pos * ch * fstride))
 				b->fast_dense = 0;
 			if (r.prev == -1 || (r.flags & LW_RF_TDONLY) || (r.xflags & LW_XF_EDGE_L)) {
 				it.src_kind = LW_SRC_NONE; // (a TD-only packet is overlapped later, by k_ola_generic; a short left slope by k_short)
@@ -854,9 +918,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				it.src_kind = LW_SRC_STATE;
 				it.src_arg = (uint32_t)(-(r.prev + 2));
 			} else if ((b->h_recs[r.prev].flags & fast_mark) == fast_mark) {
-				if ((k % chunk) != 0 && b->h_items[k - 1].pkt == (uint32_t)r.prev) {
+				if ((pos % chunk) != 0 && b->h_items[pos - 1].pkt == (uint32_t)r.prev) {
 					it.src_kind = LW_SRC_LDS;
-					b->h_items[k - 1].flags |= LW_IF_NEXT_LDS;
+					b->h_items[pos - 1].flags |= LW_IF_NEXT_LDS;
 				} else {
 					it.src_kind = LW_SRC_HALO;
 					it.src_arg = (uint32_t)b->n_halo_items;
@@ -869,8 +933,11 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				it.src_kind = LW_SRC_TD;
 				it.src_arg = 2u * b->h_recs[r.prev].res_off;
 			}
+			pos++;
 		}
-		b->n_items = nf;
+		b->n_items = pos;
+		b->n_inline_halo = inline_halo ? pos - nf : 0;
+		(void)n_inline;
 	}
 	return LW_OK;
 }

@@ -157,6 +157,8 @@ struct lw_batch {
 	                         // form when the short blocks run through k_short), 1 = k_long10 without the EDGE form (those blocks through
 	                         // the generic kernels), 0 = never (k_short<32>)
 	int forced_rounds = 0; // lw_debug_batch_set_rounds: rounds per workgroup of the specialised kernel (0 = the planner decides)
+	int halo_mode = -1;    // lw_debug_batch_set_halo: -1 = predecessors of chunk starts recomputed inside the launch where that pays, 0 = by the pre-pass
+	size_t n_inline_halo = 0; // such items in the work list of the batch planned last
 	size_t n = 0, res_floats = 0, out_elems = 0;
 	uint32_t max_n = 0;
 	bool has_generic = false, has_fast = false, force_generic = false;

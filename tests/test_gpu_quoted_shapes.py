@@ -375,3 +375,48 @@ def test_mix_launch_without_producers_is_an_error_not_samples():
             assert status == 0 and m * 2 == want.size and np.array_equal(flat[off:off + m * 2], want), (s, t)
             k += 1
     bt.close()
+
+
+@pytest.mark.parametrize("key,kernel", [("18", "k_long"), ("17", "k_mix"), ("12", "k_long10"), ("11", "k_long12")])
+def test_one_stream_in_one_launch_halo_items_equal_the_pre_pass(key, kernel):
+    """SURVEY 8(d) config 3 as written -- ONE stream, thousands of consecutive packets in one launch -- cuts the stream over the
+    chip's workgroups; every chunk that starts inside the stream needs its predecessor's right half (audio.rs:1082-1154).  Round 6
+    recomputes that predecessor INSIDE the launch (an item of its own in front of the chunk: no samples, right half through LDS)
+    instead of in a pre-pass launch.  Both forms against the oracle and against each other, on the bench's single-stream shapes and
+    on one stream of 1024- / 4096-point long blocks."""
+    import dataclasses
+    from lewton_amd import audio, header
+    from lewton_amd import workloads as wl
+    from lewton_amd.batch import Batch
+    w = wl.by_key(key, 2048)
+    if w.n_streams != 1:
+        w = dataclasses.replace(w, n_streams=1, per_stream=2048, distinct=1)
+    setup = w.setup()
+    idp, _, stp = setup.headers()
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    dec = audio.Decoder(ident, st, 0)
+    seqs = wl.stream_material(w, setup)
+    flats = {}
+    for mode in (-1, 0):
+        pw = [audio.PreviousWindowRight()]
+        prime_items, items = wl.items_of(w, seqs, pw)
+        prime = Batch(dec, 1, "i16")
+        prime.entropy(prime_items, n_threads=1)
+        prime.upload()
+        prime.synth_to_host()
+        prime.close()
+        bt = Batch(dec, len(items), "i16")
+        bt.debug_set_halo(mode)
+        res = bt.entropy(items, n_threads=4)
+        bt.upload()
+        flat = bt.synth_to_host()
+        assert kernel in bt.last_kernels and ("<halo>" in bt.last_kernels) == (mode == 0), (mode, bt.last_kernels)
+        assert verify_workload_batch(w, setup, seqs, res, flat, "i16") == 0, mode
+        flats[mode] = flat.copy()
+        state = pw[0].data().copy()
+        flats[(mode, "state")] = state
+        bt.close()
+        pw.clear()
+    assert np.array_equal(flats[-1], flats[0]) and np.array_equal(flats[(-1, "state")].view(np.uint32), flats[(0, "state")].view(np.uint32))
+    dec.close()
