@@ -833,6 +833,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				(b->h_recs[r.prev].flags & fast_mark) == fast_mark;
 		};
 		uint32_t chunk = shape(nf);
+		const uint32_t rounds_plain = rounds;
 		// A chunk that starts inside a stream needs its predecessor's right half.  Round 6: the predecessor is recomputed IN the launch,
 		// as an item of its own in front (no samples, no state: the form of a stream's first packet, whose right half goes to the next
 		// wave through LDS) -- one more wave-slot per chunk start instead of a pre-pass launch in front of every such launch (ONE
@@ -853,7 +854,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				last = (int64_t)pkt_of(k);
 			}
 			const uint32_t c2 = shape(nf + nh);
-			if (c2 < 2 || nh * 3 > nf || nf + nh > b->max_packets + b->max_packets / 2 + 64) {
+			// (not where the extra items would cost every workgroup another round -- a batch that fills the chip's waves exactly:
+			// ONE stream x 8192 long packets took 37 us with them against 35 us with the pre-pass)
+			if (c2 < 2 || nh * 3 > nf || nf + nh > b->max_packets + b->max_packets / 2 + 64 || rounds > rounds_plain) {
 				inline_halo = false;
 				chunk = shape(nf);
 				break;

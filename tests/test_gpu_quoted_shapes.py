@@ -377,8 +377,8 @@ def test_mix_launch_without_producers_is_an_error_not_samples():
     bt.close()
 
 
-@pytest.mark.parametrize("key,kernel", [("18", "k_long"), ("17", "k_mix"), ("12", "k_long10"), ("11", "k_long12")])
-def test_one_stream_in_one_launch_halo_items_equal_the_pre_pass(key, kernel):
+@pytest.mark.parametrize("key,kernel,packets", [("18", "k_long", 1536), ("17", "k_mix", 4096), ("12", "k_long10", 1536), ("11", "k_long12", 1536)])
+def test_one_stream_in_one_launch_halo_items_equal_the_pre_pass(key, kernel, packets):
     """SURVEY 8(d) config 3 as written -- ONE stream, thousands of consecutive packets in one launch -- cuts the stream over the
     chip's workgroups; every chunk that starts inside the stream needs its predecessor's right half (audio.rs:1082-1154).  Round 6
     recomputes that predecessor INSIDE the launch (an item of its own in front of the chunk: no samples, right half through LDS)
@@ -388,9 +388,10 @@ def test_one_stream_in_one_launch_halo_items_equal_the_pre_pass(key, kernel):
     from lewton_amd import audio, header
     from lewton_amd import workloads as wl
     from lewton_amd.batch import Batch
-    w = wl.by_key(key, 2048)
+    # (sizes at which the planner does use the extra items: they must not cost every workgroup another round, nor be every third item)
+    w = wl.by_key(key, packets)
     if w.n_streams != 1:
-        w = dataclasses.replace(w, n_streams=1, per_stream=2048, distinct=1)
+        w = dataclasses.replace(w, n_streams=1, per_stream=packets, distinct=1)
     setup = w.setup()
     idp, _, stp = setup.headers()
     ident = header.read_header_ident(idp)

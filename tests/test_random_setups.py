@@ -124,6 +124,8 @@ def test_plan_census_names_a_kernel_for_every_block_class():
         assert set(parts) == {"long", "short", "transitions", "entropy"}
         any_long = any(m.blockflag for m in setup.modes)
         any_short = any(not m.blockflag for m in setup.modes)
+        if setup.bs0 == setup.bs1 and any_long:
+            any_short = False          # (equal block sizes: every mode is planned with the long blocks, lw_unified_classes)
         assert (parts["long"] == "none") == (not any_long) and (parts["short"] == "none") == (not any_short)
         assert parts["entropy"] == "device" or parts["entropy"].startswith("host (")
         seen.add(parts["long"].split(" ")[0])
