@@ -136,100 +136,180 @@ __device__ __forceinline__ void prep_couple(float &m, float &a) // audio.rs:762-
 }
 
 // LDS: every thread keeps four consecutive bins of every channel in its own column col[c][tid] (16-byte accesses of consecutive
-// lanes: conflict-free, and private -- no synchronisation between the coupling steps); the floors' active posts per channel behind them
+// lanes: conflict-free, and private -- no synchronisation between the coupling steps); behind the columns the inverse-dB table and,
+// per channel that is multiplied here, the active posts of its floor in ascending x -- all of them built up front behind ONE barrier
+// (a barrier and a dependent round trip per channel made this kernel 45 us for 4096 stereo packets: three times its traffic's worth)
 #define LW_PREP_MAX_CH 16u
+// Per multiplied channel: the active posts in ascending x and one entry {dy, c0, 1 / adx, w} per interval between them -- the
+// two-FMA form of render_line the wave-pipeline kernels use (floor_table / floor_bin in lw_kernels_long.hip: y(k) from the
+// mantissa of fma(fma(k, dy, c0), 1 / adx, w); proven equal to the integer form for every dy and every adx <= 4096 with the
+// reciprocal one ulp off either way, tests/test_fast_model.py, tests/test_big_model.py).  An interval longer than that (a post
+// far beyond the block: range bits up to 15) keeps the integer division (ent.z = 0 marks it).
+struct LwPrepPosts {
+	float4 ent[LW_XSTRIDE];
+	uint16_t px[LW_XSTRIDE];
+	uint8_t py[LW_XSTRIDE + 2];
+	int32_t K;
+	int32_t pad;
+};
+#define LW_PREP_W0 2097153.0f // 2^21 + 1
+#define LW_PREP_MASK 0x7fcu
+
+// floor value of bin k inside active interval r (px[r] <= k < px[r + 1], or r = K - 1: flat to the end, audio.rs:546-548)
+__device__ __forceinline__ float prep_floor_bin(const LwPrepPosts &P, const float *inv_db, int r, uint32_t k)
+{
+	const float4 e = P.ent[r];
+	if (e.z != 0.0f) {
+		const float t = __builtin_fmaf(__builtin_fmaf((float)k, e.x, e.y), e.z, e.w);
+		return inv_db[((__float_as_uint(t) & LW_PREP_MASK) >> 2) - 1u];
+	}
+	const int x0 = P.px[r], x1 = P.px[r + 1], y0 = P.py[r], y1 = P.py[r + 1];
+	const int dy = y1 - y0, adx = x1 - x0;
+	const int ady = dy < 0 ? -dy : dy;
+	const int off = (ady * ((int)k - x0)) / adx; // closed form of render_line
+	return inv_db[dy < 0 ? y0 - off : y0 + off];
+}
 __global__ void __launch_bounds__(LW_ELEMENTWISE_BLOCK) k_prep(LwDevTables T, LwBatchDev B, const uint32_t *list, const uint8_t *action,
 		uint16_t *floors_out)
 {
 	extern __shared__ __attribute__((aligned(16))) char prep_smem[];
+	const uint32_t tid = threadIdx.x, ch = T.ch, nthr = blockDim.x;
 	float4 *col = reinterpret_cast<float4 *>(prep_smem); // [ch][256]
-	__shared__ uint16_t px[LW_XSTRIDE];
-	__shared__ uint8_t py[LW_XSTRIDE + 2];
-	__shared__ uint8_t act[LW_XSTRIDE + 2];
-	__shared__ int s_K;
+	float *inv_db = reinterpret_cast<float *>(prep_smem + (size_t)ch * nthr * 16u); // [256]
+	LwPrepPosts *posts = reinterpret_cast<LwPrepPosts *>(inv_db + 256); // [ch]
 	const uint32_t pkt = list[blockIdx.x];
 	const LwPacketRec rec = B.recs[pkt];
 	if (rec.flags & LW_RF_SKIP)
 		return;
-	const uint32_t tid = threadIdx.x, n2 = (1u << rec.bs) >> 1, ch = T.ch;
+	const uint32_t n2 = (1u << rec.bs) >> 1;
 	const uint32_t s0 = T.couple_off[rec.mode], s1 = T.couple_off[rec.mode + 1];
 	const float *src = B.residue + rec.res_off;
 	float *dst = B.decoupled + rec.res_off;
 	const uint8_t *arow = action + (size_t)rec.mode * ch;
-	// ---- floor records out (and which channels are multiplied here)
-	for (uint32_t c = 0; c < ch && floors_out; c++) {
+	// ---- my four bins of every channel are requested first (the first turn of the loop below) ...
+	const uint32_t k_first = 4u * tid;
+	if (k_first < n2)
+		for (uint32_t c = 0; c < ch; c++)
+			col[c * nthr + tid] = *reinterpret_cast<const float4 *>(src + c * n2 + k_first);
+	// ---- ... then the tables: inverse dB, floor records out, and the active posts of the channels multiplied here, one WAVE per
+	//      channel in turn (lanes = posts: the rank of an active post is the number of active posts below it, a ballot)
+	inv_db[tid] = T.inv_db[tid];
+	const uint32_t wave = tid >> 6, lane = tid & 63u;
+	for (uint32_t c = wave; c < ch; c += nthr >> 6) {
+		// (everything that does not depend on another load is requested before anything is looked at: the kernel's time is the
+		// length of its chain of dependent round trips -- list -> record -> {residues, floor record, floor number} -> {posts' x})
 		const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
-		uint16_t *fout = floors_out + rec.floor_off + c * T.fstride;
-		if (arow[c] != LW_PREP_PREMUL || frec[0] == LW_FLOOR_UNUSED) {
-			for (uint32_t i = tid; i < T.fstride; i += blockDim.x)
-				fout[i] = frec[i];
-		} else if (tid < 2) {
-			fout[tid] = (uint16_t)(LW_POST_ACTIVE | 255u);
-		}
-	}
-	for (uint32_t k0 = 0; k0 < n2; k0 += 4u * blockDim.x) { // (n2 >= 32: whole float4s; threads beyond the block idle)
-		const uint32_t k = k0 + 4u * tid;
-		const bool on = k < n2;
-		// ---- all channels of my four bins into my column, every coupling step there (reverse order, audio.rs:991-992)
-		if (on) {
-			for (uint32_t c = 0; c < ch; c++)
-				col[c * blockDim.x + tid] = *reinterpret_cast<const float4 *>(src + c * n2 + k);
-			for (uint32_t s = s1; s-- > s0;) {
-				float4 &m = col[T.couple[2 * s] * blockDim.x + tid], &a = col[T.couple[2 * s + 1] * blockDim.x + tid];
-				float4 mv = m, av = a;
-				prep_couple(mv.x, av.x);
-				prep_couple(mv.y, av.y);
-				prep_couple(mv.z, av.z);
-				prep_couple(mv.w, av.w);
-				m = mv;
-				a = av;
+		const uint16_t e = lane < T.fstride ? frec[lane] : (uint16_t)0;
+		const uint16_t e64 = T.fstride > 64 ? frec[64] : (uint16_t)0;
+		const uint32_t act = arow[c];
+		const uint32_t fl = T.mode_floor[rec.mode * ch + c];
+		const uint32_t F = T.floor_F[fl];
+		const uint16_t x = T.floor_x[fl * LW_XSTRIDE + lane], x64 = T.floor_x[fl * LW_XSTRIDE + 64];
+		const uint16_t e0 = (uint16_t)__builtin_amdgcn_readfirstlane((uint32_t)e);
+		const bool premul = act == LW_PREP_PREMUL && e0 != LW_FLOOR_UNUSED;
+		if (floors_out) {
+			uint16_t *fout = floors_out + rec.floor_off + c * T.fstride;
+			if (!premul) {
+				if (lane < T.fstride)
+					fout[lane] = e;
+				for (uint32_t i = lane + 64u; i < T.fstride; i += 64u)
+					fout[i] = frec[i];
+			} else if (lane < 2) {
+				fout[lane] = (uint16_t)(LW_POST_ACTIVE | 255u);
 			}
 		}
+		if (premul && e0 != LW_FLOOR_EXPLICIT) { // (audio.rs:536-545 walks exactly these)
+			const bool on = lane < F && (e & LW_POST_ACTIVE);
+			const unsigned long long M = __ballot(on);
+			const int rank = __builtin_popcountll(M & ((1ull << lane) - 1ull));
+			if (on) {
+				posts[c].px[rank] = x;
+				posts[c].py[rank] = (uint8_t)(e & 0xff);
+			}
+			int K = __builtin_popcountll(M);
+			if (F > 64 && lane == 0 && (e64 & LW_POST_ACTIVE)) { // the 65th post (header.rs:873)
+				posts[c].px[K] = x64;
+				posts[c].py[K] = (uint8_t)(e64 & 0xff);
+				K++;
+			}
+			if (lane == 0)
+				posts[c].K = K;
+			// (the wave's own LDS stores above are visible to its loads below: in-order LDS, a compiler fence is enough)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			K = __builtin_amdgcn_readfirstlane(K);
+			for (int r = (int)lane; r < K; r += 64) {
+				const LwPrepPosts &P = posts[c];
+				const bool last = r == K - 1;
+				const float xlo = (float)P.px[r], ylo = (float)P.py[r];
+				const float xhi = last ? xlo + 1.0f : (float)P.px[r + 1], yhi = last ? ylo : (float)P.py[r + 1];
+				const float dy = yhi - ylo, adx = xhi - xlo;
+				const bool down = yhi < ylo;
+				float4 en;
+				en.x = dy;
+				en.y = down ? (0.875f * adx - 0.5f) - xhi * dy : (0.5f - 0.125f * adx) - xlo * dy; // exact (22 bits at most)
+				en.z = last ? 1.0f : adx <= 4096.0f ? __builtin_amdgcn_rcpf(adx) : 0.0f;
+				en.w = (down ? yhi : ylo) + LW_PREP_W0;
+				posts[c].ent[r] = en;
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t k0 = 0; k0 < n2; k0 += 4u * nthr) { // (n2 >= 32: whole float4s; threads beyond the block idle)
+		const uint32_t k = k0 + 4u * tid;
+		if (k >= n2)
+			break;
+		// ---- all channels of my four bins in my column, every coupling step there (reverse order, audio.rs:991-992)
+		if (k0)
+			for (uint32_t c = 0; c < ch; c++)
+				col[c * nthr + tid] = *reinterpret_cast<const float4 *>(src + c * n2 + k);
+		for (uint32_t s = s1; s-- > s0;) {
+			float4 &m = col[T.couple[2 * s] * nthr + tid], &a = col[T.couple[2 * s + 1] * nthr + tid];
+			float4 mv = m, av = a;
+			prep_couple(mv.x, av.x);
+			prep_couple(mv.y, av.y);
+			prep_couple(mv.z, av.z);
+			prep_couple(mv.w, av.w);
+			m = mv;
+			a = av;
+		}
 		// ---- x floor curve for the channels the kernels cannot stage (audio.rs:1035-1037), and out
-		for (uint32_t c = 0; c < ch; c++) { // (every condition below is the same for all threads of the workgroup)
-			const uint16_t *frec = B.floors + rec.floor_off + c * T.fstride;
-			const uint16_t e0 = frec[0];
-			float4 v = on ? col[c * blockDim.x + tid] : float4{0.0f, 0.0f, 0.0f, 0.0f};
-			if (arow[c] == LW_PREP_PREMUL && e0 == LW_FLOOR_EXPLICIT) { // floor 0: the curve evaluated by the host stage (audio.rs:160-212)
-				if (on) {
+		for (uint32_t c = 0; c < ch; c++) {
+			float4 v = col[c * nthr + tid];
+			if (arow[c] == LW_PREP_PREMUL) {
+				const uint16_t e0 = B.floors[rec.floor_off + c * T.fstride];
+				if (e0 == LW_FLOOR_EXPLICIT) { // floor 0: the curve evaluated by the host stage (audio.rs:160-212)
 					const float4 f = *reinterpret_cast<const float4 *>(B.fcurve + rec.res_off + c * n2 + k);
 					v.x = f.x * v.x;
 					v.y = f.y * v.y;
 					v.z = f.z * v.z;
 					v.w = f.w * v.w;
-				}
-			} else if (arow[c] == LW_PREP_PREMUL && e0 != LW_FLOOR_UNUSED) {
-				// active posts in ascending x (audio.rs:536-545 walks exactly these), one thread per post
-				const uint32_t fl = T.mode_floor[rec.mode * ch + c], F = T.floor_F[fl];
-				uint16_t my_e = 0;
-				__syncthreads(); // (the previous channel's / block's evaluation is done with px / py)
-				if (tid < F) {
-					my_e = frec[tid];
-					act[tid] = (my_e & LW_POST_ACTIVE) ? 1 : 0;
-				}
-				__syncthreads();
-				if (tid < F) {
-					int rank = 0;
-					for (uint32_t t = 0; t < tid; t++)
-						rank += act[t];
-					if (my_e & LW_POST_ACTIVE) {
-						px[rank] = T.floor_x[fl * LW_XSTRIDE + tid];
-						py[rank] = (uint8_t)(my_e & 0xff);
+				} else if (e0 != LW_FLOOR_UNUSED) {
+					const LwPrepPosts &P = posts[c];
+					const int K = P.K;
+					int lo = 0, hi = K - 1; // largest r with px[r] <= k: searched once, my other three bins step along
+					while (lo < hi) {
+						const int mid = (lo + hi + 1) >> 1;
+						if (P.px[mid] <= k)
+							lo = mid;
+						else
+							hi = mid - 1;
 					}
-					if (tid == F - 1)
-						s_K = rank + ((my_e & LW_POST_ACTIVE) ? 1 : 0);
-				}
-				__syncthreads();
-				if (on) {
-					const int K = s_K;
-					v.x = T.inv_db[prep_floor_y(px, py, K, k)] * v.x;
-					v.y = T.inv_db[prep_floor_y(px, py, K, k + 1)] * v.y;
-					v.z = T.inv_db[prep_floor_y(px, py, K, k + 2)] * v.z;
-					v.w = T.inv_db[prep_floor_y(px, py, K, k + 3)] * v.w;
+					float f[4];
+#pragma unroll
+					for (uint32_t j = 0; j < 4; j++) {
+						while (lo + 1 < K && P.px[lo + 1] <= k + j)
+							lo++;
+						f[j] = prep_floor_bin(P, inv_db, lo, k + j);
+					}
+					v.x = f[0] * v.x;
+					v.y = f[1] * v.y;
+					v.z = f[2] * v.z;
+					v.w = f[3] * v.w;
 				}
 			}
-			if (on)
-				*reinterpret_cast<float4 *>(dst + c * n2 + k) = v;
+			*reinterpret_cast<float4 *>(dst + c * n2 + k) = v;
 		}
 	}
 }
@@ -312,13 +392,13 @@ hipError_t lw_launch_prep(const LwDevTables &T, const LwBatchDev &B, const uint3
 	static LwPerDeviceOnce once;
 	{
 		const hipError_t e = once.run([] {
-			return hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LW_PREP_MAX_CH * LW_ELEMENTWISE_BLOCK * 16));
+			return hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LW_PREP_MAX_CH * (LW_ELEMENTWISE_BLOCK * 16 + sizeof(LwPrepPosts)) + 1024));
 		});
 		if (e != hipSuccess)
 			return e;
 	}
-	return lw_launch_k(k_prep, dim3(n_list), dim3(LW_ELEMENTWISE_BLOCK), (size_t)T.ch * LW_ELEMENTWISE_BLOCK * 16, st, T, B, d_list, d_action,
-			d_floors_out);
+	return lw_launch_k(k_prep, dim3(n_list), dim3(LW_ELEMENTWISE_BLOCK), (size_t)T.ch * (LW_ELEMENTWISE_BLOCK * 16 + sizeof(LwPrepPosts)) + 1024, st, T,
+			B, d_list, d_action, d_floors_out);
 }
 
 // ---------------------------------------------------------------------------------------------

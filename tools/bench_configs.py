@@ -34,7 +34,7 @@ def rotation_batches(alg_bytes):
     return max(2, need, min(8, (3 * (1 << 29)) // max(1, alg_bytes)))
 
 
-def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0, mix=None):
+def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0, mix=None, branches=1):
     """Time workload `w` (lewton_amd.workloads.Workload): `nb` rotated batches resident in HBM (default: as many as
     rotation_batches() asks for -- a footprint of at least 0.5 GiB), one hipGraph of `nb` steps replayed, HIP events; then
     (verify) every packet of timed batch 0 against the oracle.  Returns the result line as a dict.
@@ -88,10 +88,30 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
         step(k, C.c_void_p(stream.cuda_stream))
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for k in range(nb):
-            step(k, cs)
+    if branches > 1:
+        # experiment (profiles/r06_graph_branches.txt): the rotated batches are independent of each other, so the graph may run them
+        # as `branches` parallel chains -- the ramp of one sparse launch can then overlap the tail of another.  NOT for the one-launch
+        # mixed kernels (k_mix / k_mix10: two such grids at once can starve each other): pass mix=0 with it.
+        sides = [torch.cuda.Stream() for _ in range(branches)]
+        with torch.cuda.graph(g):
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            for sd in sides:
+                sd.wait_event(fork)
+            for k in range(nb):
+                sd = sides[k % branches]
+                with torch.cuda.stream(sd):
+                    step(k, C.c_void_p(sd.cuda_stream))
+            for sd in sides:
+                join = torch.cuda.Event()
+                join.record(sd)
+                main.wait_event(join)
+    else:
+        with torch.cuda.graph(g):
+            cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for k in range(nb):
+                step(k, cs)
     import time
     t_settle = time.perf_counter()   # untimed: tens of milliseconds of load until the device clocks have settled (as bench.py does)
     while True:
@@ -124,7 +144,7 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
            # informational: the streams' window state has to cross HBM at a launch boundary (stored right parts in, new ones out);
            # SURVEY 8(d)'s figure does not count it, so shapes with few packets per stream and launch look slower than the chip runs
            "state_bytes_per_launch": state, "pct_of_8TBps_incl_state": round(100 * (alg + state) / (us * 1e-6) / 8e12, 2),
-           "kernels": batches[0][0].last_kernels, "parity": parity,
+           "kernels": batches[0][0].last_kernels, "parity": parity, "graph_branches": branches,
            "note": w.note}
     for bt, _ in batches:
         bt.close()
@@ -139,9 +159,10 @@ if __name__ == "__main__":
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--nb", type=int, default=0, help="batches rotated (0 = by footprint: >= 0.5 GiB per rotation)")
+    ap.add_argument("--branches", type=int, default=1, help="experiment: the rotated batches as this many parallel chains of the graph (use --mix 0 with mixed shapes)")
     ap.add_argument("--mix", type=int, default=None, help="lw_debug_batch_set_mix: 0 = mixed batches as two launches, -1 = as one where k_mix applies (default)")
     args = ap.parse_args()
     ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
     for w in wl.configs(args.packets):
         if w.key in ONLY:
-            print(json.dumps(measure(w, args.steps, args.nb or None, not args.no_verify, args.force_generic, mix=args.mix)), flush=True)
+            print(json.dumps(measure(w, args.steps, args.nb or None, not args.no_verify, args.force_generic, mix=args.mix, branches=args.branches)), flush=True)
