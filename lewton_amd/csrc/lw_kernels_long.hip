@@ -344,6 +344,27 @@ __device__ __forceinline__ void decouple4(float &m0, float &a0, float &m1, float
 	      "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3), "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3));
 }
 
+// The same for the steps a k_long<..., PRE> wave runs under a switch on its program (apply_pre): `asm volatile`, so that the statement
+// cannot be speculated -- with the plain form the compiler executed ALL twelve cases of the switch and selected the results
+// (3 500 more VALU instructions per wave than the one case that runs)
+__device__ __forceinline__ void decouple4_branchy(float &m0, float &a0, float &m1, float &a1, float &m2, float &a2, float &m3, float &a3)
+{
+	float t0, t1, t2, t3;
+	unsigned long long c0, c1, c2, c3, d0, d1, d2, d3;
+	asm volatile("v_cmp_lt_f32_e64 %12, 0, %0\n\tv_cmp_lt_f32_e64 %13, 0, %2\n\tv_cmp_lt_f32_e64 %14, 0, %4\n\tv_cmp_lt_f32_e64 %15, 0, %6\n\t"
+	    "v_cmp_lt_f32_e64 %16, 0, %1\n\tv_cmp_lt_f32_e64 %17, 0, %3\n\tv_cmp_lt_f32_e64 %18, 0, %5\n\tv_cmp_lt_f32_e64 %19, 0, %7\n\t"
+	    "s_xnor_b64 %12, %12, %16\n\ts_xnor_b64 %13, %13, %17\n\ts_xnor_b64 %14, %14, %18\n\ts_xnor_b64 %15, %15, %19\n\t"
+	    "v_cndmask_b32_e64 %8, %1, -%1, %12\n\tv_cndmask_b32_e64 %9, %3, -%3, %13\n\t"
+	    "v_cndmask_b32_e64 %10, %5, -%5, %14\n\tv_cndmask_b32_e64 %11, %7, -%7, %15\n\t"
+	    "v_add_f32_e32 %8, %0, %8\n\tv_add_f32_e32 %9, %2, %9\n\tv_add_f32_e32 %10, %4, %10\n\tv_add_f32_e32 %11, %6, %11\n\t"
+	    "v_cndmask_b32_e64 %1, %0, %8, %16\n\tv_cndmask_b32_e64 %3, %2, %9, %17\n\t"
+	    "v_cndmask_b32_e64 %5, %4, %10, %18\n\tv_cndmask_b32_e64 %7, %6, %11, %19\n\t"
+	    "v_cndmask_b32_e64 %0, %8, %0, %16\n\tv_cndmask_b32_e64 %2, %9, %2, %17\n\t"
+	    "v_cndmask_b32_e64 %4, %10, %4, %18\n\tv_cndmask_b32_e64 %6, %11, %6, %19"
+	    : "+v"(m0), "+v"(a0), "+v"(m1), "+v"(a1), "+v"(m2), "+v"(a2), "+v"(m3), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
+	      "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3), "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-round register state
 // ---------------------------------------------------------------------------------------------
@@ -946,7 +967,7 @@ __device__ __forceinline__ void couple_quad(float4_t &M, float4_t &A)
 {
 	float m[4] = {M.x, M.y, M.z, M.w};
 	float a[4] = {A.x, A.y, A.z, A.w};
-	decouple4(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
+	decouple4_branchy(m[0], a[0], m[1], a[1], m[2], a[2], m[3], a[3]);
 	M = float4_t{m[0], m[1], m[2], m[3]};
 	A = float4_t{a[0], a[1], a[2], a[3]};
 }
