@@ -10,7 +10,7 @@ import pytest
 
 
 @pytest.mark.parametrize("name", ["r01_bench.json", "r02_bench.json", "r03_bench.json", "r04_bench.json", "r05_bench.json",
-                                  "r05_bench_closing.json", "r05_bench_closing_box2.json"])
+                                  "r05_bench_closing.json", "r05_bench_closing_box2.json", "r06_bench.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).readline()
     d = json.loads(line)
@@ -63,8 +63,22 @@ def test_committed_bench_line_has_the_contract_fields(name):
             assert e["footprint_bytes"] >= 5e8 and e["footprint_bytes"] == e["batches_rotated"] * e["algorithmic_bytes_per_launch"], label
         ks = {e["kernels"] for e in oc.values()}
         assert {"k_long10", "k_long12", "k_mix10", "k_mix"} <= ks, ks
-        assert not any("generic" in k for k in ks)
-        assert "r05_pmc_summary" in d["roofline"]["traffic_unit"] or "r04_pmc_summary" in d["roofline"]["traffic_unit"]
+        if name < "r06":
+            assert not any("generic" in k for k in ks)
+        assert any(("r0%d_pmc_summary" % n) in d["roofline"]["traffic_unit"] for n in (4, 5, 6))
+    if name >= "r06":
+        # round 6: the fallback every specialised kernel is measured against is ON the line (forced: the only entry on the generic
+        # kernels), SURVEY 8(d)'s config 3 as written (ONE stream) and its all-long counterpart, a stream shape behind the
+        # canonicalising pre-pass, libvorbis' 5.1 coupling inside k_long's waves at >= 30 %, the mixed shapes at 16 384 packets
+        oc = d["other_configs"]
+        gen = [label for label, e in oc.items() if "generic" in e["kernels"]]
+        assert gen == ["generic fallback (stereo 8/11 long blocks, forced)"] and oc[gen[0]]["frac"] < 0.08
+        one = [e for label, e in oc.items() if "ONE stream" in label]
+        assert len(one) == 2 and all(e["packets_per_launch"] == 4096 for e in one)
+        assert any(e["kernels"] == "k_prep,k_long" for e in oc.values())
+        lv = [e for label, e in oc.items() if "libvorbis" in label]
+        assert len(lv) == 1 and lv[0]["kernels"] == "k_long" and lv[0]["frac"] >= 0.30
+        assert sum(1 for e in oc.values() if e["packets_per_launch"] == 16384) == 3
     if name >= "r05_bench_closing":
         # the round's closing tree: the window state crossing HBM at the launch boundary rides along (never in `frac`), and two
         # logical shards on one GPU reach the rate of one ring (the copier thread of tenants' rings)
