@@ -103,3 +103,59 @@ def test_k_prep_shapes_three_ways(name, fmt_seed):
     assert kernels & {"k_long", "k_long10", "k_long12", "k_big", "k_short", "k_mix", "k_mix10"}, kernels
     if name.startswith("equal_sizes"):
         assert "k_imdct_generic" not in kernels, kernels      # (no packet of such a stream is left to the generic kernels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["surround51_libvorbis_coupling", "two_long_modes", "floor0_long_blocks", "equal_sizes_10"])
+def test_k_prep_shapes_packet_by_packet_and_through_the_ogg_reader(name):
+    """the same shapes through the drop-in single-packet call (audio::read_audio_packet: one-packet batches, state through the
+    pool) and through OggStreamReader's look-ahead queue (rings of batches), against the oracle's reader"""
+    from lewton_amd import audio, header
+    from lewton_amd import inside_ogg as IO
+    from lewton_amd import ogg
+    from oracle import pyogg
+    setup = CASES[name][0]()
+    rng = np.random.default_rng(11)
+    pk = sg.random_stream(setup, rng, 90, seed=5, p_floor_unused=0.05)
+    idp, cmt, stp = setup.headers()
+    ident = header.read_header_ident(idp)
+    st = header.read_header_setup(stp, ident.audio_channels, (ident.blocksize_0, ident.blocksize_1))
+    o_id = po.Ident(idp)
+    o_st = po.Setup(stp, o_id)
+    pwr, opw = audio.PreviousWindowRight(), po.Pwr()
+    for i, p in enumerate(pk[:60]):   # (contradicting window flags make some of them AudioBadFormat, audio.rs:1107-1111: same code then)
+        try:
+            want, o_rc = po.read_audio_packet(o_id, o_st, p, opw, "i16"), 0
+        except po.OracleError as e:
+            o_rc = e.code
+        try:
+            got, rc = audio.read_audio_packet(ident, st, p, pwr), 0
+        except audio.AudioReadError as e:
+            rc = e.code
+        assert rc == o_rc and pwr.is_empty() == opw.is_empty(), (i, rc, o_rc)
+        if rc == 0:
+            assert got.shape == want.shape and np.array_equal(got, want), i
+    w = ogg.PageWriter(0x99)
+    w.add_packet(idp, 0, flush=True)
+    w.add_packet(cmt, 0)
+    w.add_packet(stp, 0, flush=True)
+    gp = 0
+    for i, p in enumerate(pk):
+        gp += po.get_decoded_sample_count(o_id, o_st, p) if i else 0
+        w.add_packet(p, gp, flush=(i % 9 == 8), eos=(i == len(pk) - 1))
+    data = w.bytes()
+    s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data, "i16")
+    n = 0
+    while True:
+        got = s.read_dec_packets(32, "i16", 2)
+        if got is None:
+            break
+        for a in got:
+            try:
+                b = o.read_dec_packet()
+            except pyogg.VorbisError as e:
+                assert e.kind == "BadAudio" and isinstance(a, audio.AudioReadError) and a.code == e.inner, (n, a, e)
+            else:
+                assert b is not None and not isinstance(a, Exception) and np.array_equal(a, b), n
+            n += 1
+    assert n == len(pk) and o.read_dec_packet() is None
