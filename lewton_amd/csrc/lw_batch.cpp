@@ -411,9 +411,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	// blocksize_1 = 12: likewise to k_long12 (one wave per channel: the split units) instead of k_big<12>
 	b->use_l12 = blk_ok[1] && d->blkp[1].lanes == 128 && !d->blkp[1].units_split.empty() && !d->blkp[1].image.empty() &&
 		b->l10_mode != 0 && !d->fast.eligible;
-	// short blocks of 256 points next to k_long, of 256 / 512 points next to k_long10: long blocks with short slopes stay in the
-	// long-block kernel's EDGE form (lw_fast.hpp)
-	const bool short_ok10 = b->use_l10 && b->l10_cls == 1 && b->l10_mode != 1 && blk_ok[0] && (d->blkp[0].bs == 8 || d->blkp[0].bs == 9);
+	// short blocks of 256 points next to k_long, of 256 / 512 points next to k_long10 / k_long12: long blocks with short slopes stay
+	// in the long-block kernel's EDGE form (lw_fast.hpp)
+	const bool short_ok10 = ((b->use_l10 && b->l10_cls == 1) || b->use_l12) && b->l10_mode != 1 && blk_ok[0] && (d->blkp[0].bs == 8 || d->blkp[0].bs == 9);
 	const bool short_ok = (d->fast.eligible && blk_ok[0] && d->blkp[0].bs == 8) || short_ok10;
 	b->edge_mode = false; // set when the batch has a long block with a short slope (an all-(1,1) batch keeps the plain k_long)
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
@@ -501,7 +501,7 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				(short_ok10 ? (r.prev == -1 || r.plen == (p.prev_flag ? n1h : n0h))
 				            : (p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h)))) {
 			// a long block of a stream without k_long: k_short<L> (class 1) or k_long10, two long slopes; other window shapes go to
-			// the generic kernels -- unless the stream's short blocks run through k_short next to k_long10: then as above (EDGE)
+			// the generic kernels -- unless the stream's short blocks run through k_short next to k_long10 / k_long12: then as above (EDGE)
 			r.flags |= LW_RF_FAST;
 			if (short_ok10) {
 				r.xflags = (uint8_t)((p.prev_flag ? 0u : LW_XF_EDGE_L) | (p.next_flag ? 0u : LW_XF_EDGE_R));

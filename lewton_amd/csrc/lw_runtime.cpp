@@ -339,7 +339,7 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 	};
 	// the routing of lw_batch_entropy (csrc/lw_batch.cpp), per block class
 	std::string lng, sht, edge = "none";
-	bool use_l10 = false;
+	bool use_l10 = false, use_l12 = false;
 	if (!any_long)
 		lng = "none";
 	else if (fast.eligible)
@@ -348,9 +348,10 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 		if (blk[1].lanes == 32 && blk[1].units.size() <= LW_FAST_WAVES) {
 			lng = "k_long10";
 			use_l10 = true;
-		} else if (blk[1].lanes == 128 && !blk[1].units_split.empty() && !blk[1].image.empty())
+		} else if (blk[1].lanes == 128 && !blk[1].units_split.empty() && !blk[1].image.empty()) {
 			lng = "k_long12";
-		else
+			use_l12 = true;
+		} else
 			lng = blk_name(blk[1]);
 	} else
 		lng = std::string("generic (") + (I.bs1 == LW_FAST_BS ? fast.why_not : blk[1].why_not) + ")";
@@ -373,7 +374,7 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 	if (any_short && blk[0].eligible && blk[0].prep.on)
 		sht += std::string(" + k_prep (") + blk[0].prep.why + ")";
 	if (any_long && any_short) { // long blocks with a short slope
-		const bool short_ok10 = use_l10 && blk[0].eligible && (blk[0].bs == 8 || blk[0].bs == 9);
+		const bool short_ok10 = (use_l10 || use_l12) && blk[0].eligible && (blk[0].bs == 8 || blk[0].bs == 9);
 		if ((fast.eligible && blk[0].eligible && blk[0].bs == 8) || short_ok10)
 			edge = "edge form";
 		else if (fast.eligible)

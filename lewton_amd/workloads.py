@@ -96,6 +96,10 @@ def configs(packets: int = 4096) -> List[Workload]:
                  "blocksize 9 / 10; long blocks with short slopes on either side of every run of short blocks"),
         Workload("15", "mixed 256/1024", lambda: sg.stereo_setup(22050, 8, 10), "LLLSSSLLLL", 256, per,
                  "blocksize 8 / 10"),
+        # the block sizes libvorbis writes at 44.1 kHz for its lowest qualities (-1, 0: ~45-64 kbit/s): long blocks with short slopes in
+        # k_long12's EDGE form
+        Workload("20", "mixed 512/4096", lambda: sg.stereo_setup(44100, 9, 12), "LLLSSSLLLL", 256, per,
+                 "blocksize 9 / 12; long blocks with short slopes on either side of every run of short blocks"),
         # round 6: a stream shape behind the canonicalising pre-pass; SURVEY 8(d) config 3 as written (ONE stream, state carried
         # through the whole launch: audio.rs:1082-1154, examples/perf.rs:35-44) and its all-long counterpart
         Workload("16", "5.1 @ 48 kHz long blocks, libvorbis' coupling steps (a channel in three steps)", surround51_libvorbis_coupling,

@@ -5,8 +5,8 @@ Covered: dense launches (the bench shape: 256 streams x 16 packets = two rounds 
 workgroups (hand-over through LDS inside a round and from round to round -- the published right half shares the wave's gather
 area --, through the halo pre-pass at chunk starts, through the state pool between launches), 5.1 (two coupled pairs and two
 uncoupled channels = six waves per packet), mono, stereo without coupling, residue types 1 and 2, unused floors, truncated
-packets, the three sample formats, and mixed short/long streams (1024- / 512-point short blocks in k_short, long blocks next to
-short ones in the generic kernels: time-domain blocks exchanged both ways)."""
+packets, the three sample formats, and mixed short/long streams (short blocks in k_short; long blocks next to 256- / 512-point
+short ones in k_long12's EDGE form, next to 1024-point ones in the generic kernels: time-domain blocks exchanged both ways)."""
 import numpy as np
 import pytest
 
@@ -25,6 +25,7 @@ def _uncoupled_9_12():
 
 L12_SETUPS = {
     "stereo_9_12": lambda: sg.stereo_setup(44100, 9, 12),
+    "stereo_8_12": lambda: sg.stereo_setup(44100, 8, 12),
     "stereo_10_12_t1": lambda: sg.stereo_setup(44100, 10, 12, residue_type=1),
     "surround51_9_12": lambda: sg.surround51_setup(48000, 9, 12),
     "mono_7_12": lambda: sg.mono_setup(7, 12, 44100),
@@ -67,17 +68,43 @@ def test_long12_forced_rounds_hand_over_paths(rounds):
         assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
 
 
-@pytest.mark.parametrize("name", ["stereo_9_12", "stereo_10_12_t1", "surround51_9_12"])
-@pytest.mark.parametrize("fmt", ["i16", "f32"])
+@pytest.mark.parametrize("name", ["stereo_9_12", "stereo_8_12", "stereo_10_12_t1", "surround51_9_12", "uncoupled_9_12"])
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
 def test_long12_mixed_short_long_streams(name, fmt):
+    """short blocks of 256 / 512 points: long blocks with a short slope stay in k_long12 (its EDGE form: the raw edges go to
+    k_short<8 / 16> through the edge buffer) -- no packet of such a stream on the generic kernels; 1024-point short blocks
+    (k_short<32> has no edge form): those long blocks through the generic kernels, time-domain blocks exchanged both ways"""
     setup = L12_SETUPS[name]()
     audio, dec = _decoder(setup)
     pats = ["LLLSSSLLLL", "LLSLLLSSLLLLL", "LSSSSSSLLL", "LLLLLLLSL", "SLSLLSSL"]
     streams = [sg.make_stream(setup, pats[s % 5], 26 + s % 3, seed=5500 + s, p_floor_unused=0.05) for s in range(9)]
+    streams[2][11] = streams[2][11][: len(streams[2][11]) // 3]      # a truncated packet
     want, wstates = _oracle(setup, streams, fmt)
     got, seen, states = _decode(dec, audio, streams, [0, 1, 2, 3, 4, 5, 6, 17, 29], fmt)
-    assert "k_long12" in seen and "k_short" in seen and any("generic" in k for k in seen), seen
+    assert "k_long12" in seen and "k_short" in seen, seen
+    edge = setup.bs0 in (8, 9)
+    assert any("generic" in k for k in seen) == (not edge), seen
     _compare(got, want, fmt, name)
+    for s in range(len(streams)):
+        assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
+    if edge:    # the same batches with the edge form off (lw_debug_batch_set_long10(1)): the generic kernels' route, same bytes
+        got2, seen2, states2 = _decode(dec, audio, streams, [0, 1, 2, 3, 4, 5, 6, 17, 29], fmt, l10=1)
+        assert any("generic" in k for k in seen2), seen2
+        _compare(got2, want, fmt, name + " (edge form off)")
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 4])
+def test_long12_edge_form_across_rounds_and_launches(rounds):
+    """forced launch shapes: chunk starts right behind / in front of short runs, one packet per stream per launch (every raw edge and
+    short right part crosses the state pool), long runs (through LDS)"""
+    setup = L12_SETUPS["stereo_9_12"]()
+    audio, dec = _decoder(setup)
+    pats = ["LSLSLLSSL", "LLLLSSSSLLLLLLLL", "SSLLLLLLLS", "LLSLLLLLLLLLLLSLL"]
+    streams = [sg.make_stream(setup, pats[s % 4], 31 + s % 4, seed=5700 + s, p_floor_unused=0.05) for s in range(11)]
+    want, wstates = _oracle(setup, streams, "i16")
+    got, seen, states = _decode(dec, audio, streams, [0, 1, 2, 3, 4, 5, 6, 7, 8, 19, 40], "i16", rounds=rounds)
+    assert "k_long12" in seen and "k_short" in seen and not any("generic" in k for k in seen), seen
+    _compare(got, want, "i16", "rounds=%d" % rounds)
     for s in range(len(streams)):
         assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
 

@@ -34,7 +34,7 @@ def rotation_batches(alg_bytes):
     return max(2, need, min(8, (3 * (1 << 29)) // max(1, alg_bytes)))
 
 
-def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0, mix=None, branches=1):
+def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None, settle_ms=40.0, mix=None, branches=1, long10=None):
     """Time workload `w` (lewton_amd.workloads.Workload): `nb` rotated batches resident in HBM (default: as many as
     rotation_batches() asks for -- a footprint of at least 0.5 GiB), one hipGraph of `nb` steps replayed, HIP events; then
     (verify) every packet of timed batch 0 against the oracle.  Returns the result line as a dict.
@@ -67,6 +67,8 @@ def measure(w, steps=400, nb=NB, verify=True, force_generic=False, distinct=None
             bt.debug_set_mix(mix)   # lw_debug_batch_set_mix: 0 = mixed batches as two launches, -1 = as one where k_mix applies
         if force_generic:
             bt.set_force_generic(True)
+        if long10 is not None:
+            bt.debug_set_long10(long10)   # lw_debug_batch_set_long10: 1 = k_long10 / k_long12 without their EDGE form, 0 = k_short<32> / k_big<12>
         bt.entropy(items, n_threads=0)
         bt.upload(None)
         outs.append(torch.empty(max(1, bt.out_elems), dtype=torch.int16, device="cuda"))
@@ -160,9 +162,10 @@ if __name__ == "__main__":
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--nb", type=int, default=0, help="batches rotated (0 = by footprint: >= 0.5 GiB per rotation)")
     ap.add_argument("--branches", type=int, default=1, help="experiment: the rotated batches as this many parallel chains of the graph (use --mix 0 with mixed shapes)")
+    ap.add_argument("--long10", type=int, default=None, help="lw_debug_batch_set_long10: 1 = without the EDGE form (long blocks next to short ones on the generic kernels)")
     ap.add_argument("--mix", type=int, default=None, help="lw_debug_batch_set_mix: 0 = mixed batches as two launches, -1 = as one where k_mix applies (default)")
     args = ap.parse_args()
     ONLY = set(args.only.split(",")) if args.only else {"3", "4", "5"}
     for w in wl.configs(args.packets):
         if w.key in ONLY:
-            print(json.dumps(measure(w, args.steps, args.nb or None, not args.no_verify, args.force_generic, mix=args.mix, branches=args.branches)), flush=True)
+            print(json.dumps(measure(w, args.steps, args.nb or None, not args.no_verify, args.force_generic, mix=args.mix, branches=args.branches, long10=args.long10)), flush=True)
