@@ -26,8 +26,25 @@ def test_random_setups_three_ways(first):
     rng = np.random.default_rng(first + 77)
     total, kernels = 0, set()
     for seed in range(first, first + 10):
-        _seed, ch, idp, stp, seqs = fz.generate((seed, 120))
+        _seed, ch, idp, stp, seqs = fz.generate((seed, 120, None))
         checked, ks, _line, _dev = fz.run_setup(seed, ch, idp, stp, seqs, 120, rng, mods)
         total += checked
         kernels |= ks
     assert total > 600 and kernels
+
+
+def test_random_setups_at_512_4096_and_256_4096():
+    """the same with the block sizes pinned to 9 / 12 and 8 / 12 (streamgen's menu draws them for one setup in fourteen): random
+    setups whose long blocks with short slopes run through k_long12's EDGE form"""
+    from lewton_amd import _native as N
+    from lewton_amd import audio, header
+    from lewton_amd.batch import Batch
+    mods = (audio, header, Batch, po, N)
+    rng = np.random.default_rng(4242)
+    total, kernels = 0, set()
+    for seed in range(700, 712):
+        _seed, ch, idp, stp, seqs = fz.generate((seed, 120, [(9, 12), (8, 12)]))
+        checked, ks, _line, _dev = fz.run_setup(seed, ch, idp, stp, seqs, 120, rng, mods)
+        total += checked
+        kernels |= ks
+    assert total > 600 and "k_long12" in kernels, kernels

@@ -47,10 +47,10 @@ def shape_of(seed, packets):
 
 def generate(job):
     """(worker process, CPU only) the header packets and DISTINCT packet sequences of setup `seed`"""
-    seed, packets = job
+    seed, packets, sizes = job
     from lewton_amd import streamgen as sg
     rng = np.random.default_rng(seed)
-    setup = sg.random_setup(rng)
+    setup = sg.random_setup(rng, blocksizes=sizes[seed % len(sizes)] if sizes else None)
     _n_streams, length = shape_of(seed, packets)
     seqs = [sg.random_stream(setup, rng, length, seed=1000 * seed + q, p_floor_unused=float(rng.choice([0.0, 0.05, 0.3])),
                              p_damage=0.04) for q in range(DISTINCT)]
@@ -163,8 +163,10 @@ def main():
     ap.add_argument("--packets", type=int, default=250, help="packets per setup (streams x length)")
     ap.add_argument("--procs", type=int, default=12, help="generator processes (CPU only)")
     ap.add_argument("--quiet", action="store_true", help="no line per setup")
+    ap.add_argument("--blocksizes", default="", help="pin the block sizes: e.g. 9:12,8:12 (setup `seed` takes entry seed %% count); default: streamgen's menu")
     args = ap.parse_args()
-    jobs = [(s, args.packets) for s in range(args.seed, args.seed + args.setups)]
+    sizes = [tuple(int(v) for v in e.split(":")) for e in args.blocksizes.split(",") if e]
+    jobs = [(s, args.packets, sizes) for s in range(args.seed, args.seed + args.setups)]
     ctx = mp.get_context("fork")
     pool = ctx.Pool(args.procs)                      # forked BEFORE this process touches HIP
     it = pool.imap(generate, jobs, chunksize=2)

@@ -14,15 +14,16 @@ tail -6 $D/pytest.txt
 tail -4 $D/bench.err
 timeout 400 bash tools/prof.sh r06_final --steps 20 --warmup 5 --no-end-to-end --no-other-configs > $D/prof_summary.txt 2>&1
 timeout 600 bash tools/pmc.sh r06_final --no-end-to-end --no-other-configs > $D/pmc_stdout.txt 2>&1
-timeout 900 python tools/bench_configs.py --only 3,4,5,6,7,10,11,12,13,14,15,16,17,18,19 --steps 600 > $D/other_configs.jsonl 2> $D/other_configs.err
+timeout 900 python tools/bench_configs.py --only 3,4,5,6,7,10,11,12,13,14,15,16,17,18,19,20 --steps 600 > $D/other_configs.jsonl 2> $D/other_configs.err
 timeout 300 python tools/bench_configs.py --only 9 --packets 2048 --force-generic --steps 100 >> $D/other_configs.jsonl 2>> $D/other_configs.err
-timeout 400 python tools/bench_configs.py --only 3,11,12,14,15,16 --packets 16384 --steps 300 >> $D/other_configs.jsonl 2>> $D/other_configs.err
+timeout 400 python tools/bench_configs.py --only 3,11,12,14,15,16,20 --packets 16384 --steps 300 >> $D/other_configs.jsonl 2>> $D/other_configs.err
 timeout 400 python tools/bench_configs.py --only 3,12,14 --packets 65536 --steps 100 >> $D/other_configs.jsonl 2>> $D/other_configs.err
-for c in 16 17 18 19; do
+for c in 16 17 18 19 20; do
   timeout 200 bash tools/prof_cfg.sh $c 200 r06_final/prof_cfg$c > $D/prof_cfg$c.txt 2>&1
   timeout 400 bash tools/pmc_cfg.sh $c r06_final > $D/pmc_cfg$c.txt 2>&1
 done
 timeout 900 python tools/fuzz_gpu_setups.py --setups 3000 --seed 20000 --procs 14 --quiet > $D/fuzz_gpu_setups.txt 2>&1
+timeout 600 python tools/fuzz_gpu_setups.py --setups 2000 --seed 300000 --procs 14 --quiet --blocksizes 9:12,8:12 > $D/fuzz_gpu_setups_edge12.txt 2>&1
 timeout 600 python tools/fuzz_gpu_mixed.py --rounds 100 --seed 81 > $D/fuzz_gpu_mixed_full.txt 2>&1; tail -1 $D/fuzz_gpu_mixed_full.txt > $D/fuzz_gpu_mixed.txt
 timeout 600 python tools/fuzz_gpu_mixed.py --rounds 120 --seed 82 --mid > $D/fuzz_gpu_mid_full.txt 2>&1; tail -1 $D/fuzz_gpu_mid_full.txt > $D/fuzz_gpu_mid.txt
 timeout 600 python tools/fuzz_gpu_mixed.py --rounds 80 --seed 83 --big > $D/fuzz_gpu_big_full.txt 2>&1; tail -1 $D/fuzz_gpu_big_full.txt > $D/fuzz_gpu_big.txt
@@ -51,4 +52,4 @@ tail -2 $D/prof_summary.txt
 cut -c1-260 $D/other_configs.jsonl
 grep -v '^setup' $D/fuzz_gpu_setups.txt | head -60
 cat $D/single_stream.txt $D/end_to_end_sharder.txt $D/fuzz_gpu_mixed.txt $D/fuzz_gpu_mid.txt $D/fuzz_gpu_big.txt $D/fuzz_gpu_entropy.txt
-for c in 16 17 18 19; do tail -6 $D/prof_cfg$c.txt; done
+for c in 16 17 18 19 20; do tail -6 $D/prof_cfg$c.txt; done
