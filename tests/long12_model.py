@@ -139,6 +139,42 @@ def imdct_wave(X, img, A, prev_pb=None):
     return out
 
 
+def edge_form(pa, pb, E, edge_l, edge_r):
+    """k_long12<EDGE>'s stores of a block with a short slope (lw_long12.inc, finish phase), lane by lane: returns
+    (samples {index relative to the window start: value}, raw left edge [E] | None, raw right edge [E] | None, short state [2 E] | None).
+    A lane owns, per output half h, the raw quads lo = q in [256 h + 4 lane, +4) and hi = q in [1020 - 256 h - 4 lane, +4)."""
+    e_ls = 1024 - E if edge_l else 0
+    out, left, right, state = {}, None, None, None
+    if edge_l:
+        left = np.zeros(E, F)
+    if edge_r:
+        right, state = np.zeros(E, F), np.zeros(2 * E, F)
+    for lane in range(64):
+        inner = lane >= E // 4
+        for h in range(2):
+            qlo, qhi = 256 * h + 4 * lane, 1020 - 256 * h - 4 * lane
+            if edge_l:       # cur[2047 - q] = -pa(q): the quad reversed and negated
+                for j in range(4):
+                    out[2044 - 256 * h - 4 * lane - e_ls + j] = -pa[qlo + 3 - j]
+                    if h == 1 or inner:
+                        out[1024 + 256 * h + 4 * lane - e_ls + j] = -pa[qhi + 3 - j]
+            if edge_r:       # cur[2048 + q] = pb(q)
+                for j in range(4):
+                    out[2048 + 256 * h + 4 * lane - e_ls + j] = pb[qlo + j]
+                    if h == 1 or inner:
+                        out[3068 - 256 * h - 4 * lane - e_ls + j] = pb[qhi + j]
+        if not inner:
+            qhi = 1020 - 4 * lane
+            for j in range(4):
+                if edge_l:
+                    left[E - 4 - 4 * lane + j] = pa[qhi + j]
+                if edge_r:
+                    right[E - 4 - 4 * lane + j] = pb[qhi + j]
+                    state[E - 4 - 4 * lane + j] = pb[qhi + j]
+                    state[E + 4 * lane + j] = pb[qhi + 3 - j]
+    return out, left, right, state
+
+
 def gather_bank_cycles():
     """LDS-array cycles of the gather's 16 ds_write_b64 and 16 ds_read_b64 of one wave (short_model.gather_bank_cycles: banking rules
     of MI355X_MICROARCH.md).  Conflict-free: (64, 32)."""

@@ -56,3 +56,29 @@ def test_lane_model_imdct_and_overlap_add_bit_exact():
 def test_gather_is_free_of_bank_conflicts():
     assert sorted(lm.gather_slot(p) for p in range(lm.P)) == list(range(lm.P))
     assert lm.gather_bank_cycles() == (64, 32)
+
+
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("edge_l,edge_r", [(True, False), (False, True), (True, True)])
+def test_edge_form_geometry(E, edge_l, edge_r):
+    """k_long12<EDGE>: what a wave stores for a long block with short slopes (E = blocksize_0 / 4) against the block's time-domain
+    samples -- the un-windowed samples between the slopes (audio.rs:1119), the raw edges k_short overlaps, the short right part
+    that becomes the stream's state (audio.rs:1056-1073 for the bounds)."""
+    rng = np.random.default_rng(E + 2 * edge_l + edge_r)
+    x = (rng.standard_normal(lm.N2) * 0.3).astype(np.float32)
+    td = po.inverse_mdct(x, 12)
+    pa, pb = td[:lm.N4].copy(), td[lm.N2:lm.N2 + lm.N4].copy()
+    out, left, right, state = lm.edge_form(pa, pb, E, edge_l, edge_r)
+    ls = 1024 - E if edge_l else 0                  # window bounds of the block
+    rs = 3072 - E if edge_r else 2048
+    want = {}
+    if edge_l:                                      # past the short left slope: positions 1024 + E .. 2047
+        want.update({p - ls: td[p] for p in range(1024 + E, 2048)})
+        assert np.array_equal(left, td[1024 - E:1024])
+    if edge_r:                                      # up to the short right slope: positions 2048 .. 3071 - E
+        want.update({p - ls: td[p] for p in range(2048, rs)})
+        assert np.array_equal(right, td[3072 - E:3072])
+        assert np.array_equal(state, td[3072 - E:3072 + E])
+    assert set(out) == set(want)
+    assert all(np.float32(out[k]).view(np.uint32) == np.float32(want[k]).view(np.uint32) for k in want)
+    assert max(want) < rs - ls and min(want) >= (2 * E if edge_l else 2048)
