@@ -76,8 +76,11 @@ def test_committed_bench_line_has_the_contract_fields(name):
         one = [e for label, e in oc.items() if "ONE stream" in label]
         assert len(one) == 2 and all(e["packets_per_launch"] == 4096 for e in one)
         assert any(e["kernels"] == "k_prep,k_long" for e in oc.values())
-        lv = [e for label, e in oc.items() if "libvorbis" in label]
+        lv = [e for label, e in oc.items() if "libvorbis' coupling" in label]
         assert len(lv) == 1 and lv[0]["kernels"] == "k_long" and lv[0]["frac"] >= 0.30
+        # libvorbis' low-bitrate block sizes: the long blocks next to short ones in k_long12's EDGE form, none on the generic kernels
+        lo = [e for label, e in oc.items() if "512/4096" in label]
+        assert len(lo) == 1 and lo[0]["kernels"] == "k_long12,k_short" and lo[0]["frac"] >= 0.20
         assert sum(1 for e in oc.values() if e["packets_per_launch"] == 16384) == 3
     if name >= "r05_bench_closing":
         # the round's closing tree: the window state crossing HBM at the launch boundary rides along (never in `frac`), and two
