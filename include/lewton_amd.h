@@ -184,9 +184,9 @@ void lw_debug_batch_set_rounds(lw_batch *b, int rounds);
 void lw_debug_batch_set_halo(lw_batch *b, int mode);
 /* test hook: 0 = never run a mixed short / long batch as one k_mix launch (two launches: k_long<EDGE>, k_short), -1 = where it applies */
 void lw_debug_batch_set_mix(lw_batch *b, int mode);
-/* test hook for blocksize_1 = 10 streams: -1 = k_long10 (long blocks next to short ones in its EDGE form where the short blocks run
- * through k_short), 1 = k_long10 for the long blocks with two long slopes only (the others through the generic kernels), 0 = the
- * block kernel k_short<32> instead of k_long10 */
+/* test hook for blocksize_1 = 10 / 12 streams: -1 = k_long10 / k_long12 (long blocks next to short ones in their EDGE form where the
+ * short blocks run through k_short<8 / 16>), 1 = k_long10 / k_long12 for the long blocks with two long slopes only (the others
+ * through the generic kernels), 0 = the block kernels k_short<32> / k_big<12> instead */
 void lw_debug_batch_set_long10(lw_batch *b, int mode);
 /* Device-side failures of a batch's launches (audio.rs:27-41: every failure is a status, never wrong samples).  Call once the
  * work lw_batch_synth queued has COMPLETED (after synchronising its stream); lw_batch_synth_to_host and lw_ring_collect call it

@@ -89,8 +89,8 @@ class Batch:
         N.lw_debug_batch_set_mix(self._h, int(mode))
 
     def debug_set_long10(self, mode):
-        """test hook (lw_debug_batch_set_long10) for blocksize_1 = 10 streams: -1 = k_long10 incl. its EDGE form, 1 = k_long10 without
-        the EDGE form (long blocks next to short ones through the generic kernels), 0 = k_short<32>"""
+        """test hook (lw_debug_batch_set_long10) for blocksize_1 = 10 / 12 streams: -1 = k_long10 / k_long12 incl. their EDGE form,
+        1 = without the EDGE form (long blocks next to short ones through the generic kernels), 0 = k_short<32> / k_big<12>"""
         N.lw_debug_batch_set_long10(self._h, int(mode))
 
     def debug_break_mix(self, spin):
