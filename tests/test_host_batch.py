@@ -117,7 +117,52 @@ def test_batch_statuses_and_sample_counts_equal_the_oracle(harness, tmp_path, na
 def harness_asan(tmp_path_factory):
     if not os.path.isdir(os.path.join(HIP_INC, "hip")):
         pytest.skip("HIP headers not installed")
-    exe = str(tmp_path_factory.mktemp("hostbatch_asan") / "batch_host_bench_asan")
+    return build_harness_asan(str(tmp_path_factory.mktemp("hostbatch_asan") / "batch_host_bench_asan"))
+
+
+def random_setup_case(harness, seed, case, blocksizes=None, n_streams=6, per=14):
+    """one random setup (streamgen.random_setup, seed `seed`; `blocksizes` pins the block sizes) with damaged multi-stream batches
+    through the harness `harness`: statuses, samples per packet and output offsets against the oracle.  Returns the number of
+    packets the oracle rejected.  (also driven by tools/fuzz_host_setups.py over many seeds)"""
+    import numpy as np
+    from common import po
+    rng = np.random.default_rng(seed)
+    setup = sg.random_setup(rng, blocksizes=blocksizes)
+    streams = [sg.random_stream(setup, rng, per, seed=10 * seed + k, p_damage=0.15) for k in range(n_streams)]
+    idp, _, stp = setup.headers()
+    with open(case, "wb") as f:
+        f.write(struct.pack("<I", 1))
+        for b in (idp, stp):
+            f.write(struct.pack("<I", len(b)) + bytes(b))
+        f.write(struct.pack("<I", n_streams * per))
+        for st in streams:
+            for p in st:
+                f.write(struct.pack("<I", len(p)) + p)
+    env = dict(os.environ, LW_HOST_BENCH_CHECK="1", LW_HOST_BENCH_DUMP="1", LW_HOST_BENCH_FILE_ORDER="1",
+               ASAN_OPTIONS="detect_leaks=0")   # (the bench harness ends without tearing its decoder down)
+    out = subprocess.run([harness, case, str(n_streams * per), str(n_streams), "1", "0", "2"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, (seed, out.stdout[-2000:] + out.stderr[-4000:])
+    got = [tuple(int(v) for v in l.split()[1:]) for l in out.stdout.splitlines() if l.startswith("R ")]
+    o_id = po.Ident(idp)
+    o_st = po.Setup(stp, o_id)
+    ch = o_id.audio_channels
+    want, off, n_bad = [], 0, 0
+    for st in streams:
+        pwr = po.Pwr()
+        for p in st:
+            try:
+                n = po.read_audio_packet(o_id, o_st, p, pwr, "i16").shape[1]
+                want.append((0, n, off))
+                off += n * ch
+            except po.OracleError as e:
+                want.append((e.code, 0, off))
+                n_bad += 1
+    assert got == want, seed
+    return n_bad
+
+
+def build_harness_asan(exe):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
                            "-D__HIP_PLATFORM_AMD__", "-I" + HIP_INC] + SRC + ["-lpthread", "-o", exe])
     return exe
@@ -126,44 +171,14 @@ def harness_asan(tmp_path_factory):
 def test_random_setups_plan_and_statuses_under_asan(harness_asan, tmp_path):
     """round 6: setup headers drawn at random (streamgen.random_setup) through the product's host side under ASan / UBSan -- header
     parser, the planner of the block classes (plan_units: native units, coupling steps inside the waves, the canonicalising
-    pre-pass with the unit floor), the batch planner (work lists, halo items, slot lists, k_prep's packet list) -- with the kernels
-    as no-ops: statuses, samples per packet and output offsets of damaged multi-stream batches against the oracle."""
-    import numpy as np
-    from common import po
-    n_streams, per, n_bad = 6, 14, 0
-    for seed in range(3000, 3015):
-        rng = np.random.default_rng(seed)
-        setup = sg.random_setup(rng)
-        streams = [sg.random_stream(setup, rng, per, seed=10 * seed + k, p_damage=0.15) for k in range(n_streams)]
-        idp, _, stp = setup.headers()
-        case = str(tmp_path / "case.bin")
-        with open(case, "wb") as f:
-            f.write(struct.pack("<I", 1))
-            for b in (idp, stp):
-                f.write(struct.pack("<I", len(b)) + bytes(b))
-            f.write(struct.pack("<I", n_streams * per))
-            for st in streams:
-                for p in st:
-                    f.write(struct.pack("<I", len(p)) + p)
-        env = dict(os.environ, LW_HOST_BENCH_CHECK="1", LW_HOST_BENCH_DUMP="1", LW_HOST_BENCH_FILE_ORDER="1",
-                   ASAN_OPTIONS="detect_leaks=0")   # (the bench harness ends without tearing its decoder down)
-        out = subprocess.run([harness_asan, case, str(n_streams * per), str(n_streams), "1", "0", "2"], env=env, capture_output=True,
-                             text=True, timeout=600)
-        assert out.returncode == 0, (seed, out.stdout[-2000:] + out.stderr[-4000:])
-        got = [tuple(int(v) for v in l.split()[1:]) for l in out.stdout.splitlines() if l.startswith("R ")]
-        o_id = po.Ident(idp)
-        o_st = po.Setup(stp, o_id)
-        ch = o_id.audio_channels
-        want, off = [], 0
-        for st in streams:
-            pwr = po.Pwr()
-            for p in st:
-                try:
-                    n = po.read_audio_packet(o_id, o_st, p, pwr, "i16").shape[1]
-                    want.append((0, n, off))
-                    off += n * ch
-                except po.OracleError as e:
-                    want.append((e.code, 0, off))
-                    n_bad += 1
-        assert got == want, seed
+    pre-pass with the unit floor), the batch planner (work lists, halo items, slot lists, k_prep's packet list, the long-block
+    kernels' edge forms) -- with the kernels as no-ops: statuses, samples per packet and output offsets of damaged multi-stream
+    batches against the oracle.  Twelve draws from the generator's menu, three each pinned to 512/4096 and 256/1024 blocks."""
+    n_bad = 0
+    case = str(tmp_path / "case.bin")
+    for seed in range(3000, 3012):
+        n_bad += random_setup_case(harness_asan, seed, case)
+    for seed in range(3100, 3103):
+        n_bad += random_setup_case(harness_asan, seed, case, blocksizes=(9, 12))
+        n_bad += random_setup_case(harness_asan, seed + 50, case, blocksizes=(8, 10))
     assert n_bad >= 3
