@@ -5,6 +5,8 @@
  *   perf file.ogg            packet by packet, like `while let Some(pck) = srr.read_dec_packet()?`
  *   perf file.ogg K [T]      look-ahead queue: K packets per batch (one set of kernel launches), T host entropy threads
  *   perf file.ogg K T dev    the same with the entropy stage on the device (eligible streams; T is then of no consequence)
+ *   perf file.ogg K T host|dev ahead   the packet-by-packet loop of the first form, served from batches of K packets decoded ahead
+ *                            (lw_ogg_stream_set_read_ahead): the reference's loop unchanged, at the batched rate
  *
  * Build: cc -O2 -Iinclude examples/perf.c -Llewton_amd/_lib -llewton_amd -Wl,-rpath,$PWD/lewton_amd/_lib -o examples/perf
  */
@@ -27,9 +29,12 @@ int main(int argc, char **argv)
 		fprintf(stderr, "No arg found. Please specify a file to open.\n");
 		return 2;
 	}
-	const size_t K = argc > 2 ? (size_t)strtoul(argv[2], NULL, 10) : 0;
+	size_t K = argc > 2 ? (size_t)strtoul(argv[2], NULL, 10) : 0;
 	const int threads = argc > 3 ? atoi(argv[3]) : 0;
-	const int dev_entropy = argc > 4;
+	const int dev_entropy = argc > 4 && argv[4][0] == 'd';
+	const size_t read_ahead = argc > 5 ? K : 0;
+	if (read_ahead)
+		K = 0; /* the loop below is the packet-by-packet one */
 	int err = 0;
 	printf("Opening file: %s\n", argv[1]);
 	lw_ogg_reader *rdr = lw_ogg_reader_open_file(argv[1], &err);
@@ -44,6 +49,8 @@ int main(int argc, char **argv)
 	}
 	if (dev_entropy)
 		lw_ogg_stream_set_entropy_on_device(srr, 1);
+	if (read_ahead)
+		lw_ogg_stream_set_read_ahead(srr, read_ahead, threads);
 	lw_ident_info info;
 	lw_ident_get_info(lw_ogg_stream_ident(srr), &info);
 	printf("Sample rate: %u\n", info.audio_sample_rate);

@@ -446,6 +446,16 @@ int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t c
  * by the next call on the caller's thread, with its text republished through lw_last_device_error(). */
 int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out,
 		size_t cap_elems, uint32_t *n_samples, int32_t *status, size_t *n_packets);
+/* Read-ahead behind the packet-by-packet call: with max_packets > 0, lw_ogg_stream_read_dec_packet hands out, one per call, the
+ * packets of batches of up to max_packets that the look-ahead pipeline above decodes (n_threads host entropy threads; the entropy
+ * stage on the device if set) -- the reference's own loop `while let Some(p) = rdr.read_dec_packet()? { .. }` (examples/perf.rs:35-44)
+ * at the batched rate instead of one synchronous GPU round trip per packet, with no change to the loop.  What the caller observes is
+ * the packet-by-packet sequence, call for call: samples, AudioReadError codes at the packets they belong to, get_last_absgp() as of
+ * the packet just handed out, the last packet's truncation, LW_OGG_EOF, chain boundaries (crossed by the call itself).  Every other
+ * entry point first returns the packets not yet handed out and re-makes the PreviousWindowRight as of the last one that was (one
+ * synchronous decode of that packet: a decoded packet's right half depends on nothing before it, audio.rs:1125-1138).
+ * The threading and read-ahead contract above applies from the first call on.  0 turns it off (the default). */
+int lw_ogg_stream_set_read_ahead(lw_ogg_stream *s, size_t max_packets, int n_threads);
 /* Look-ahead batches with the entropy stage on the device (lw_ring_set_entropy_on_device) whenever the current logical
  * stream is eligible; other streams (and the packet-by-packet call) keep the host stage.  Results are identical. */
 int lw_ogg_stream_set_entropy_on_device(lw_ogg_stream *s, int on);

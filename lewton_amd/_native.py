@@ -187,6 +187,7 @@ SYMBOLS = {
     "lw_ogg_stream_last_absgp": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lw_ogg_stream_read_dec_packet": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, szp]),
     "lw_ogg_stream_set_entropy_on_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "lw_ogg_stream_set_read_ahead": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
     "lw_ogg_stream_read_dec_packets": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                                  C.POINTER(C.c_uint32), C.POINTER(C.c_int32), szp]),
     "lw_ogg_stream_skip_samples_linear": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, szp, szp,

@@ -465,10 +465,89 @@ struct lw_ogg_stream {
 	bool has_retry = false;
 	QueuedPacket retry;
 	std::vector<uint8_t> scratch;
+	// ---- read-ahead behind the packet-by-packet call (lw_ogg_stream_set_read_ahead): lw_ogg_stream_read_dec_packet hands out the
+	// packets of a batch the look-ahead pipeline has decoded, one per call.  `served` = that batch (packets, statuses, sample
+	// counts, the granule position as of each packet), served_next = the next one to hand out; the stream's running granule
+	// position is that of the END of the batch, the caller sees the one of the last packet handed out (view_*).
+	size_t ra_k = 0;
+	int ra_threads = 0;
+	struct Served {
+		QueuedPacket q;
+		int32_t status = 0;
+		uint32_t n = 0;     // samples per channel (after the truncation of the stream's last packet)
+		size_t off = 0;     // element offset of its block in ra_out
+		bool has_absgp = false;
+		uint64_t absgp = 0; // get_last_absgp() once this packet has been handed out
+	};
+	std::vector<Served> served;
+	size_t served_next = 0;
+	int served_fmt = -1;
+	std::vector<char> ra_out;
+	std::vector<uint32_t> ra_ns;
+	std::vector<int32_t> ra_st;
+	bool view_has_absgp = false;
+	uint64_t view_absgp = 0;
+	// What reproduces the PreviousWindowRight the caller's calls have led to: the last packet that decoded (a decoded packet
+	// leaves its own raw right half and nothing of what came before, audio.rs:1125-1138) followed by every packet that has
+	// failed since (a failure may or may not have emptied the state, :1083 / :1107-1111: decoding it again does the same);
+	// empty = a fresh state.  Kept by every delivery path; used when packets of a served batch go back (unserve).
+	std::vector<QueuedPacket> replay;
+
+	bool serving() const { return served_next < served.size(); }
+
+	void note(QueuedPacket &&q, int status)
+	{
+		if (status == LW_OK)
+			replay.clear();
+		else if (status != LW_AUDIO_END_OF_PACKET && status != LW_AUDIO_BAD_FORMAT && status != LW_AUDIO_IS_HEADER &&
+				status != LW_AUDIO_BUFFER_NOT_ADDRESSABLE)
+			return; // (not the packet's doing: a device or argument error changes nothing)
+		replay.push_back(std::move(q));
+	}
+
+	// the packets of the served batch that have not been handed out go back in front of everything else that was read ahead, and
+	// the stream stands where the caller's calls have led it: granule position of the last packet handed out, its
+	// PreviousWindowRight (re-made from `replay`: one synchronous decode, plus one per packet that failed since).  No-op otherwise.
+	void unserve()
+	{
+		if (!serving()) {
+			served.clear();
+			served_next = 0;
+			return;
+		}
+		rollback();
+		for (size_t i = served.size(); i-- > served_next;) {
+			Requeued r;
+			r.q = std::move(served[i].q);
+			requeue.push_front(std::move(r));
+		}
+		served.clear();
+		served_next = 0;
+		has_absgp = view_has_absgp;
+		cur_absgp = view_absgp;
+		std::vector<QueuedPacket> rp;
+		rp.swap(replay);
+		if (pwr)
+			lw_pwr_reset(pwr);
+		for (QueuedPacket &q : rp)
+			(void)decode_discard(q); // (notes the packet again: `replay` is what it was)
+	}
+
+	// every entry point but the two reading calls: back to exactly what the caller has been handed
+	void settle()
+	{
+		if (serving())
+			unserve();
+		else
+			rollback();
+	}
 
 	void drop_context()
 	{
 		rollback();
+		served.clear();
+		served_next = 0;
+		replay.clear();
 		if (ring)
 			lw_ring_destroy(ring);
 		ring = nullptr;
@@ -510,6 +589,7 @@ struct lw_ogg_stream {
 	{
 		if (pwr)
 			lw_pwr_reset(pwr);
+		replay.clear();
 	}
 
 	static void take(const lw_ogg_packet &k, QueuedPacket &q)
@@ -583,7 +663,9 @@ struct lw_ogg_stream {
 		}
 		if (int rc = ensure_decoder())
 			return rc;
-		return lw_read_audio_packet(dec, q.data.data(), q.data.size(), pwr, fmt, out, cap, m);
+		const int rc = lw_read_audio_packet(dec, q.data.data(), q.data.size(), pwr, fmt, out, cap, m);
+		note(QueuedPacket(q), rc);
+		return rc;
 	}
 
 	int decode_discard(const QueuedPacket &q) // "read the first audio packet to prime the pwr and discard the packet"
@@ -595,7 +677,9 @@ struct lw_ogg_stream {
 		size_t m = 0;
 		if (int rc = ensure_decoder())
 			return rc;
-		return lw_read_audio_packet(dec, q.data.data(), q.data.size(), pwr, LW_FMT_I16_PLANAR, scratch.data(), cap, &m);
+		const int rc = lw_read_audio_packet(dec, q.data.data(), q.data.size(), pwr, LW_FMT_I16_PLANAR, scratch.data(), cap, &m);
+		note(QueuedPacket(q), rc);
+		return rc;
 	}
 
 	// next packet of the physical stream: what a roll-back of the look-ahead pipeline handed back first, then the
@@ -1040,7 +1124,7 @@ lw_ogg_reader *lw_ogg_stream_into_inner(lw_ogg_stream *s)
 {
 	if (!s)
 		return nullptr;
-	s->rollback();
+	s->settle();
 	lw_ogg_reader *r = s->rdr; // (packets read ahead are dropped with the stream object, like the reference's queue)
 	s->rdr = nullptr;
 	lw_ogg_stream_close(s);
@@ -1055,18 +1139,93 @@ uint32_t lw_ogg_stream_link_index(const lw_ogg_stream *s) { return s ? s->link :
 
 int lw_ogg_stream_last_absgp(const lw_ogg_stream *s, uint64_t *absgp)
 {
-	if (!s || !s->has_absgp)
+	if (!s)
 		return 0;
-	if (absgp)
-		*absgp = s->cur_absgp;
-	return 1;
+	// (packets of a served batch waiting to be handed out: the position of the last one the caller has, not the batch's end)
+	const bool has = s->serving() ? s->view_has_absgp : s->has_absgp;
+	if (has && absgp)
+		*absgp = s->serving() ? s->view_absgp : s->cur_absgp;
+	return has ? 1 : 0;
+}
+
+static int read_batch(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out, size_t cap_elems, uint32_t *n_samples,
+		int32_t *status, size_t *n_packets, bool serve);
+
+int lw_ogg_stream_set_read_ahead(lw_ogg_stream *s, size_t max_packets, int n_threads)
+{
+	if (!s)
+		return LW_ERR_NULL_ARG;
+	if (max_packets != s->ra_k || n_threads != s->ra_threads)
+		s->settle(); // what was read ahead under the old setting goes back; the stream stands where the caller's calls have led it
+	s->ra_k = max_packets;
+	s->ra_threads = n_threads;
+	return LW_OK;
+}
+
+// lw_ogg_stream_read_dec_packet with the read-ahead on: the next packet of the served batch, fetching a batch when there is none.
+// Returns 1 when the call has to go the sequential way (in front of a chain boundary), else 0 with *rc = the call's result.
+static int read_ahead_packet(lw_ogg_stream *s, int fmt, void *out, size_t cap_elems, size_t *n_samples, int *rc)
+{
+	for (;;) {
+		if (s->serving() && s->served_fmt != fmt)
+			s->unserve();
+		lw_ident_info info;
+		lw_ident_get_info(s->ident, &info);
+		const size_t ch = std::max<size_t>(info.audio_channels, 1);
+		if (s->has_retry)
+			return 1; // (a packet the sequential path handed back for a larger buffer comes first, through that path)
+		if (cap_elems / ch < ((size_t)1 << info.blocksize_1)) { // the packet-by-packet call's own rule; nothing consumed
+			*rc = LW_ERR_CAPACITY;
+			return 0;
+		}
+		if (s->serving()) {
+			lw_ogg_stream::Served &e = s->served[s->served_next++];
+			const size_t es = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
+			const int st = e.status;
+			s->view_has_absgp = e.has_absgp;
+			s->view_absgp = e.absgp;
+			if (st == LW_OK) {
+				std::memcpy(out, s->ra_out.data() + e.off * es, (size_t)e.n * ch * es);
+				*n_samples = e.n;
+			}
+			s->note(std::move(e.q), st);
+			if (!s->serving()) {
+				s->served.clear();
+				s->served_next = 0;
+			}
+			*rc = st;
+			return 0;
+		}
+		// a batch through the look-ahead pipeline into the stream's own buffer
+		const size_t es = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
+		// (the longest packet is a long block with a long left and a short right slope: 3 n1 / 4 - n0 / 4 samples, audio.rs:1056-1073)
+		const size_t n0 = (size_t)1 << info.blocksize_0, n1 = (size_t)1 << info.blocksize_1;
+		const size_t cap = s->ra_k * ch * std::max(n1 / 2, 3 * n1 / 4 - n0 / 4);
+		s->ra_out.resize(cap * es);
+		s->ra_ns.resize(s->ra_k);
+		s->ra_st.resize(s->ra_k);
+		size_t np = 0;
+		s->served_fmt = fmt;
+		const int r = read_batch(s, fmt, s->ra_k, s->ra_threads, s->ra_out.data(), cap, s->ra_ns.data(), s->ra_st.data(), &np, true);
+		if (r != LW_OK) {
+			*rc = r;
+			return 0;
+		}
+		if (np == 0)
+			return 1; // in front of a chain boundary: the sequential call crosses it
+	}
 }
 
 int lw_ogg_stream_read_dec_packet(lw_ogg_stream *s, int fmt, void *out, size_t cap_elems, size_t *n_samples)
 {
 	if (!s || !out || !n_samples)
 		return LW_ERR_NULL_ARG;
-	s->rollback();
+	if (s->ra_k && fmt >= 0 && fmt <= 2) {
+		int rc = LW_OK;
+		if (!read_ahead_packet(s, fmt, out, cap_elems, n_samples, &rc))
+			return rc;
+	}
+	s->settle();
 	QueuedPacket q;
 	if (int rc = s->next_audio(q))
 		return rc;
@@ -1082,7 +1241,7 @@ int lw_ogg_stream_set_entropy_on_device(lw_ogg_stream *s, int on)
 	if (!s)
 		return LW_ERR_NULL_ARG;
 	if (s->want_dev_entropy != (on != 0)) {
-		s->rollback(); // the look-ahead restarts in the other mode from what the caller has been handed
+		s->settle(); // the look-ahead restarts in the other mode from what the caller has been handed
 		s->want_dev_entropy = on != 0;
 	}
 	return LW_OK;
@@ -1093,6 +1252,16 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 {
 	if (!s || !out || !n_samples || !status || !n_packets || max_packets == 0 || fmt < 0 || fmt > 2)
 		return LW_ERR_NULL_ARG;
+	if (s->serving())
+		s->unserve(); // (the two reading calls mixed with the read-ahead on: this one continues behind the last packet handed out)
+	return read_batch(s, fmt, max_packets, n_threads, out, cap_elems, n_samples, status, n_packets, false);
+}
+
+// one batch of the look-ahead pipeline, delivered into `out`; serve: its packets are kept in s->served for
+// lw_ogg_stream_read_dec_packet to hand out one by one (else they count as handed out by this call)
+static int read_batch(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out, size_t cap_elems, uint32_t *n_samples,
+		int32_t *status, size_t *n_packets, bool serve)
+{
 	*n_packets = 0;
 	if (s->pipe_active && (s->pipe_fmt != fmt || s->pipe_k != max_packets || s->pipe_threads != n_threads))
 		s->rollback(); // other batch geometry: what was read ahead is staged again under the new one
@@ -1157,6 +1326,13 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 	lw_ident_get_info(s->ident, &info);
 	const size_t es = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
 	size_t w = 0; // write cursor in elements
+	if (serve) {
+		s->served.clear();
+		s->served.reserve(n);
+		s->served_next = 0;
+		s->view_has_absgp = s->has_absgp; // (as of the last packet handed out: nothing of this batch yet)
+		s->view_absgp = s->cur_absgp;
+	}
 	for (size_t i = 0; i < n; i++) {
 		status[i] = res[i].status;
 		size_t m = 0;
@@ -1167,7 +1343,27 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
 		if (res[i].status == LW_OK)
 			m = s->account(ps->ahead[i], fmt, dst, res[i].n_samples);
 		n_samples[i] = (uint32_t)m;
+		if (serve) {
+			lw_ogg_stream::Served e;
+			e.q = std::move(ps->ahead[i]);
+			e.status = res[i].status;
+			e.n = (uint32_t)m;
+			e.off = w;
+			e.has_absgp = s->has_absgp;
+			e.absgp = s->cur_absgp;
+			s->served.push_back(std::move(e));
+		}
 		w += m * info.audio_channels;
+	}
+	if (!serve) { // handed out by this call: what the PreviousWindowRight now derives from (see `replay`)
+		size_t from = 0;
+		for (size_t i = n; i-- > 0;)
+			if (res[i].status == LW_OK) {
+				from = i;
+				break;
+			}
+		for (size_t i = from; i < n; i++)
+			s->note(std::move(ps->ahead[i]), res[i].status);
 	}
 	*n_packets = n;
 	(void)lw_ring_release(s->ring);
@@ -1186,7 +1382,7 @@ int lw_ogg_stream_skip_samples_linear(lw_ogg_stream *s, size_t to_skip, int fmt,
 		return LW_ERR_NULL_ARG;
 	*got_packet = 0;
 	*n_samples = 0;
-	s->rollback();
+	s->settle();
 	bool have_last = false;
 	QueuedPacket last, next;
 	for (;;) {
@@ -1231,7 +1427,7 @@ int lw_ogg_stream_seek_absgp_pg(lw_ogg_stream *s, uint64_t absgp)
 {
 	if (!s)
 		return LW_ERR_NULL_ARG;
-	s->rollback();
+	s->settle();
 	s->requeue.clear(); // everything read ahead is void after a seek
 	s->has_pending = false;
 	s->has_retry = false;

@@ -118,11 +118,11 @@ class OggStreamReader:
     def read_dec_packet_generic(self, samples="i16"):
         """Ok(None) -> None at the end of the stream."""
         m = C.c_size_t(0)
-        while True:
+        for _attempt in range(3):
             fmt, ch, cap, out = self._buffers(samples)
             rc = N.lw_ogg_stream_read_dec_packet(self._h, fmt, out.ctypes.data_as(C.c_void_p), out.size, C.byref(m))
             self._after_call()
-            if rc != N.ERR_CAPACITY:  # else: the next link of a chained file needs a larger buffer
+            if rc != N.ERR_CAPACITY:  # else: the next link of a chained file needs a larger buffer (at most once per call)
                 break
         if rc == N.OGG_EOF:
             return None
@@ -139,6 +139,13 @@ class OggStreamReader:
     def set_entropy_on_device(self, on=True):
         """look-ahead batches decode their floors and residues on the GPU (k_entropy) when the stream is eligible"""
         N.lw_ogg_stream_set_entropy_on_device(self._h, 1 if on else 0)
+
+    def set_read_ahead(self, max_packets, n_threads=0):
+        """read_dec_packet* hand out the packets of batches of up to max_packets decoded ahead by the look-ahead pipeline
+        (lw_ogg_stream_set_read_ahead): the same sequence of results, call for call, at the batched rate.  0 = off (default)."""
+        rc = N.lw_ogg_stream_set_read_ahead(self._h, int(max_packets), int(n_threads))
+        if rc:
+            raise VorbisError(rc)
 
     def read_dec_packets(self, max_packets, samples="i16", n_threads=0):
         """Look-ahead queue: up to max_packets packets with one batch.  Returns a list of (samples | AudioReadError);
@@ -165,7 +172,7 @@ class OggStreamReader:
     def skip_samples_linear(self, to_skip, samples="i16"):
         """inside_ogg.rs:244-283: (Some(packet) | None, leftover)."""
         m, left, got = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
-        while True:
+        for _attempt in range(3):   # (LW_ERR_CAPACITY: the next link of a chained file needs a larger buffer, at most once per call)
             fmt, ch, cap, out = self._buffers(samples)
             rc = N.lw_ogg_stream_skip_samples_linear(self._h, to_skip, fmt, out.ctypes.data_as(C.c_void_p), out.size,
                                                      C.byref(m), C.byref(left), C.byref(got))

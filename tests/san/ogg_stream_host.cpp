@@ -3,7 +3,8 @@
 // product sources linked against hip_standins.inc, so every sample VALUE is zero but every count, status, serial and
 // granule position is what the product decides on the host.  tests/test_host_ogg.py compares the trace printed here
 // with the oracle's OggStreamReader (oracle/pyogg.py) and runs mutated files through it under ASan/UBSan.
-//   usage: ogg_stream_host file.ogg seq | ahead K | skip N | seek G
+//   usage: ogg_stream_host file.ogg seq | ahead K | skip N | seek G | mix K singles skip goal | hop N
+//   environment: LW_OSH_DEVICE_ENTROPY=1, LW_OSH_READ_AHEAD=K (lw_ogg_stream_set_read_ahead)
 // trace lines:  P <n_samples> <status> <serial> <link> <absgp|->      (one per decoded packet)
 //               E <code>                                               (terminating error), "EOF" at a clean end
 #include "../../include/lewton_amd.h"
@@ -55,6 +56,8 @@ int main(int argc, char **argv)
 	}
 	if (getenv("LW_OSH_DEVICE_ENTROPY")) // look-ahead batches in device-entropy mode: the host side copies packets, plans, rolls back
 		lw_ogg_stream_set_entropy_on_device(s, 1);
+	if (getenv("LW_OSH_READ_AHEAD")) // the packet-by-packet calls served from batches decoded ahead: every trace must stay what it is
+		lw_ogg_stream_set_read_ahead(s, (size_t)atoi(getenv("LW_OSH_READ_AHEAD")), 2);
 	std::vector<int16_t> out(cap_for(s));
 	auto drain = [&]() {
 		for (;;) {
@@ -67,6 +70,10 @@ int main(int argc, char **argv)
 			if (rc == LW_OGG_EOF) {
 				printf("EOF\n");
 				return;
+			}
+			if (rc >= LW_AUDIO_END_OF_PACKET && rc <= LW_AUDIO_BUFFER_NOT_ADDRESSABLE && getenv("LW_OSH_GO_ON")) {
+				show(s, 0, rc); // BadAudio(code): the packet is consumed, the caller may go on (LW_OSH_GO_ON: the trace does)
+				continue;
 			}
 			if (rc != LW_OK) {
 				printf("E %d\n", rc);
@@ -198,6 +205,54 @@ int main(int argc, char **argv)
 			printf("K %d\n", rc);
 			if (rc == LW_OK)
 				batch();
+		}
+		if (!stop)
+			drain();
+	} else if (mode == "hop") {
+		// `arg` packet-by-packet calls, a skip of argv[4] samples, argv[5] more calls, a seek to argv[6] (or -1), then drain: with the
+		// read-ahead on, every one of these lands in the middle of a served batch
+		const size_t skip = argc > 4 ? strtoull(argv[4], nullptr, 10) : 0;
+		const size_t more = argc > 5 ? strtoull(argv[5], nullptr, 10) : 0;
+		const long long goal = argc > 6 ? atoll(argv[6]) : -1;
+		bool stop = false;
+		auto singles = [&](size_t cnt) {
+			for (size_t i = 0; i < cnt && !stop; i++) {
+				size_t n = 0;
+				int r1;
+				while ((r1 = lw_ogg_stream_read_dec_packet(s, LW_FMT_I16_PLANAR, out.data(), out.size(), &n)) == LW_ERR_CAPACITY)
+					out.resize(cap_for(s));
+				if (r1 == LW_OGG_EOF) {
+					printf("EOF\n");
+					stop = true;
+				} else if (r1 != LW_OK) {
+					printf("E %d\n", r1);
+					stop = true;
+				} else {
+					show(s, n, 0);
+				}
+			}
+		};
+		singles((size_t)arg);
+		if (!stop && skip) {
+			size_t left = skip, n = 0;
+			int got = 0, rc;
+			while ((rc = lw_ogg_stream_skip_samples_linear(s, left, LW_FMT_I16_PLANAR, out.data(), out.size(), &n, &left, &got)) ==
+					LW_ERR_CAPACITY)
+				out.resize(cap_for(s));
+			if (rc != LW_OK) {
+				printf("E %d\n", rc);
+				stop = true;
+			} else {
+				printf("S %d %zu %zu\n", got, got ? n : 0, left);
+				if (got)
+					show(s, n, 0);
+			}
+		}
+		singles(more);
+		if (!stop && goal >= 0) {
+			const int rc = lw_ogg_stream_seek_absgp_pg(s, (uint64_t)goal);
+			printf("K %d\n", rc);
+			stop = rc != LW_OK;
 		}
 		if (!stop)
 			drain();

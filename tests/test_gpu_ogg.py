@@ -271,3 +271,137 @@ def test_single_skip_seek_between_batched_calls_sample_values(k, singles, skip, 
         alive = batch()
     while alive:
         alive = batch()
+
+
+# ---- lw_ogg_stream_set_read_ahead: read_dec_packet served from batches decoded ahead
+def _damaged_stream(seed, count=90, p_bad=0.08):
+    """a stereo stream with some packets damaged (truncated / a header bit / flipped bits): several of them fail with an
+    AudioReadError, some of those after the previous window has been taken (audio.rs:1083, :1107-1111)"""
+    setup, pk, _ = _vorbis_stream("stereo", "LLSLLLSSL", count, seed=seed)
+    rng = np.random.default_rng(seed)
+    idp, cmt, stp = setup.headers()
+    o_id = po.Ident(idp)
+    o_st = po.Setup(stp, o_id)
+    w = ogg.PageWriter(0x77)
+    w.add_packet(idp, 0, flush=True)
+    w.add_packet(cmt, 0)
+    w.add_packet(stp, 0, flush=True)
+    gp = 0
+    for i, p in enumerate(pk):
+        if i and i + 1 < len(pk) and rng.random() < p_bad:
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                p = p[: max(1, len(p) // int(rng.integers(2, 9)))]
+            elif kind == 1:
+                p = bytes([p[0] | 1]) + p[1:]               # AudioIsHeader
+            else:
+                q = bytearray(p)
+                for _ in range(3):
+                    q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8))
+                p = bytes(q)
+        try:
+            gp += po.get_decoded_sample_count(o_id, o_st, p) if i else 0
+        except po.OracleError:
+            pass
+        w.add_packet(p, gp, flush=(i % 5 == 4), eos=(i == len(pk) - 1))
+    return w.bytes()
+
+
+def _one(s, o, fmt="i16"):
+    """one read_dec_packet on both readers: the same samples or the same BadAudio code; returns False at the end of the stream"""
+    ea = eb = a = b = None
+    try:
+        a = s.read_dec_packet_generic(fmt)
+    except IO.VorbisError as e:
+        ea = e
+    try:
+        b = o.read_dec_packet()
+    except pyogg.VorbisError as e:
+        eb = e
+    assert (ea is None) == (eb is None), (ea, eb)
+    if ea is not None:
+        assert ea.kind == eb.kind == "BadAudio" and ea.code == eb.inner, (ea, eb)
+    else:
+        assert (a is None) == (b is None)
+        if a is None:
+            return False
+        _same(a, b, fmt)
+    assert s.get_last_absgp() == o.get_last_absgp() and s.stream_serial() == o.stream_serial
+    return True
+
+
+@pytest.mark.parametrize("dev_entropy", [False, True])
+@pytest.mark.parametrize("k", [1, 5, 64, 1024])
+def test_read_ahead_serves_the_packet_by_packet_sequence(k, dev_entropy):
+    """every call's samples / error, granule position and serial, on a real file, a damaged stream, a trimmed one and a chained one"""
+    for data in (open(GOLDEN, "rb").read(), _damaged_stream(3), _vorbis_stream("surround51", "LLSSSL", 30, per_page=4, trim=37)[2].bytes(),
+                 _chained()):
+        s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data)
+        s.set_read_ahead(k, 2)
+        if dev_entropy:
+            s.set_entropy_on_device(True)
+        n = 0
+        while _one(s, o):
+            n += 1
+        assert n >= 20
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_read_ahead_under_a_random_call_script(seed):
+    """read_dec_packet (three formats), read_dec_packets, skip_samples_linear, seek_absgp_pg, set_read_ahead and set_entropy_on_device in
+    random order on a damaged stream: whatever lands in the middle of a served batch returns its packets and re-makes the
+    PreviousWindowRight of the last packet handed out -- incl. the packets that failed behind it -- so every sample that follows
+    equals the oracle reader's, which was driven packet by packet"""
+    rng = np.random.default_rng(100 + seed)
+    data = _damaged_stream(10 + seed, count=140, p_bad=0.12)
+    s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data)
+    s.set_read_ahead(int(rng.choice([2, 7, 33])), 2)
+    alive, calls = True, 0
+    while calls < 260:
+        calls += 1
+        r = rng.random()
+        if not alive:          # the end of the stream: somewhere else, on
+            r, alive = 0.88, True
+        if r < 0.70:
+            alive = _one(s, o)
+        elif r < 0.78:
+            kk = int(rng.integers(1, 9))
+            got = s.read_dec_packets(kk)
+            if got is None:
+                assert o.read_dec_packet() is None
+                alive = False
+                continue
+            for a in got:
+                try:
+                    b = o.read_dec_packet()
+                except pyogg.VorbisError as e:
+                    assert isinstance(a, Exception) and a.code == e.inner
+                else:
+                    assert not isinstance(a, Exception) and np.array_equal(a, b)
+            assert s.get_last_absgp() == o.get_last_absgp()
+        elif r < 0.86:
+            n = int(rng.choice([0, 1, 700, 3000]))
+            try:
+                a, la = s.skip_samples_linear(n)
+                ea = None
+            except IO.VorbisError as e:
+                ea = e
+            try:
+                b, lb = o.skip_samples_linear(n)
+                eb = None
+            except pyogg.VorbisError as e:
+                eb = e
+            assert (ea is None) == (eb is None), (ea, eb)
+            if ea is None:
+                assert la == lb and (a is None) == (b is None)
+                if a is not None:
+                    assert np.array_equal(a, b)
+                assert s.get_last_absgp() == o.get_last_absgp()
+        elif r < 0.90:
+            goal = int(rng.integers(0, 120000))
+            s.seek_absgp_pg(goal)
+            o.seek_absgp_pg(goal)
+        elif r < 0.95:
+            s.set_read_ahead(int(rng.choice([0, 1, 4, 50])), 2)
+        else:
+            s.set_entropy_on_device(bool(rng.integers(0, 2)))

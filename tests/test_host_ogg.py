@@ -47,11 +47,17 @@ def _files():
     }
 
 
-def _run(exe, tmp_path, data, *mode, dev_entropy=False):
+def _run(exe, tmp_path, data, *mode, dev_entropy=False, read_ahead=0, go_on=False):
     path = str(tmp_path / "in.ogg")
     with open(path, "wb") as f:
         f.write(data)
-    env = dict(os.environ, LW_OSH_DEVICE_ENTROPY="1") if dev_entropy else None
+    env = dict(os.environ)
+    if dev_entropy:
+        env["LW_OSH_DEVICE_ENTROPY"] = "1"
+    if read_ahead:
+        env["LW_OSH_READ_AHEAD"] = str(read_ahead)   # lw_ogg_stream_set_read_ahead(s, K, 2) right after the open
+    if go_on:
+        env["LW_OSH_GO_ON"] = "1"                    # a drain goes on behind a BadAudio packet (trace line P 0 <code> ...)
     out = subprocess.run([exe, path] + [str(m) for m in mode], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-4000:]
     return [l.split() for l in out.stdout.splitlines()]
@@ -278,3 +284,154 @@ def test_zero_length_packets_are_empty_packets_not_null_arguments(harness, tmp_p
     assert (e.value.kind, e.value.inner) == ("BadHeader", po.HDR_END_OF_PACKET)
     got = _run(harness, tmp_path, data, "seq")
     assert got == [["E", str(po.HDR_END_OF_PACKET)]]
+
+
+# ---- lw_ogg_stream_set_read_ahead: the packet-by-packet call served from batches decoded ahead.  Nothing the caller can observe
+#      may change: every trace above, with the read-ahead on, is the trace without it (= the oracle's).
+@pytest.mark.parametrize("k", [1, 3, 64])
+@pytest.mark.parametrize("name", ["golden", "trim", "surround", "mono_pages", "chained"])
+def test_read_ahead_packet_by_packet_trace_matches_oracle(harness, tmp_path, name, k):
+    data = _files()[name]
+    got = _run(harness, tmp_path, data, "seq", read_ahead=k)
+    want = _oracle_trace(pyogg.OggStreamReader(data))
+    assert want[-1] == ["EOF"] and got == want          # sample counts, serials, links AND the granule position after every call
+    assert _run(harness, tmp_path, data, "seq", read_ahead=k, dev_entropy=True) == got
+
+
+@pytest.mark.parametrize("k", [2, 5, 64])
+@pytest.mark.parametrize("first,skip,more,goal", [(3, 900, 4, -1), (1, 1, 0, 5000), (7, 3000, 2, 0), (10, 0, 0, 20000), (0, 128, 9, -1),
+                                                   (4, 10 ** 7, 3, -1), (66, 5000, 1, 100)])
+def test_read_ahead_other_calls_in_the_middle_of_a_served_batch(harness, tmp_path, k, first, skip, more, goal):
+    """skip_samples_linear and seek_absgp_pg (and the end of the stream) while packets of a served batch wait to be handed out: those
+    packets go back, the PreviousWindowRight is re-made as of the last packet handed out, and the stream stands exactly where the
+    packet-by-packet reader stands after the same calls (inside_ogg.rs:167-313)."""
+    data = _vorbis_stream("stereo", "LLSLLLSSL", 70, per_page=4, trim=123)[2].bytes()
+    got = _run(harness, tmp_path, data, "hop", first, skip, more, goal, read_ahead=k)
+    assert got == _run(harness, tmp_path, data, "hop", first, skip, more, goal)      # the sequential product path
+    o = pyogg.OggStreamReader(data)
+    want, stop = [], [False]
+
+    def singles(cnt):
+        for _ in range(cnt):
+            if stop[0]:
+                return
+            d = o.read_dec_packet()
+            if d is None:
+                want.append(["EOF"])
+                stop[0] = True
+            else:
+                want.append(["P", str(d.shape[1]), "0", str(o.stream_serial), "0", _gp(o.get_last_absgp())])
+
+    singles(first)
+    if not stop[0] and skip:
+        dec, left = o.skip_samples_linear(skip)
+        want.append(["S", "0" if dec is None else "1", "0" if dec is None else str(dec.shape[1]), str(left)])
+        if dec is not None:
+            want.append(["P", str(dec.shape[1]), "0", str(o.stream_serial), "0", _gp(o.get_last_absgp())])
+    singles(more)
+    if not stop[0] and goal >= 0:
+        o.seek_absgp_pg(goal)
+        want.append(["K", "0"])
+    if not stop[0]:
+        want += _oracle_trace(o)
+    assert got == want
+
+
+@pytest.mark.parametrize("k,singles,skip,goal", [(4, 2, 900, -1), (7, 0, 1, 5000), (3, 5, 3000, 0), (16, 3, 10 ** 7, -1)])
+def test_read_ahead_mixed_with_the_batched_call(harness, tmp_path, k, singles, skip, goal):
+    """the batched call and the served packet-by-packet call on one stream (a batched call continues behind the last packet handed
+    out, whatever was read ahead): the `mix` trace with the read-ahead on is the one without"""
+    data = _vorbis_stream("stereo", "LLSLLLSSL", 70, per_page=4, trim=123)[2].bytes()
+    want = _run(harness, tmp_path, data, "mix", k, singles, skip, goal)
+    for ra in (2, 9):
+        assert _run(harness, tmp_path, data, "mix", k, singles, skip, goal, read_ahead=ra) == want
+
+
+def test_read_ahead_mutated_files_under_sanitizers(harness, tmp_path):
+    """the mutated files of the test above through the served packet-by-packet call: the same trace as the sequential call, error
+    for error (audio errors at their packets, container errors behind the packets that precede them), nothing for ASan / UBSan"""
+    rng = np.random.default_rng(9)
+    files = _files()
+    ran = 0
+    for name in ("golden", "trim", "chained"):
+        base = files[name]
+        for trial in range(12):
+            d = bytearray(base)
+            kind = trial % 4
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 4))):
+                    d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                d = d[: int(rng.integers(28, len(d)))]
+            elif kind == 2:
+                a = int(rng.integers(0, len(d) - 64))
+                d[a:a + int(rng.integers(1, 64))] = b""
+            else:
+                a = bytes(d).find(b"OggS", int(rng.integers(0, len(d) // 2)))
+                b = bytes(d).find(b"OggS", a + 4)
+                if a >= 0 and b > a:
+                    d[a:a] = d[a:b]
+            want = _run(harness, tmp_path, bytes(d), "seq")
+            assert _run(harness, tmp_path, bytes(d), "seq", read_ahead=int(rng.choice([1, 4, 50]))) == want
+            ran += 1
+    assert ran == 36
+
+
+def _damaged(seed, count=60, p_bad=0.15):
+    """a stereo stream with damaged audio packets (cut, header bit set, flipped bits): several fail with an AudioReadError"""
+    from common import sg
+    from lewton_amd import ogg
+    from oracle import pyoracle as po
+    setup, pk, _ = _vorbis_stream("stereo", "LLSLLLSSL", count, seed=seed)
+    rng = np.random.default_rng(seed)
+    idp, cmt, stp = setup.headers()
+    o_id = po.Ident(idp)
+    o_st = po.Setup(stp, o_id)
+    w = ogg.PageWriter(0x77)
+    w.add_packet(idp, 0, flush=True)
+    w.add_packet(cmt, 0)
+    w.add_packet(stp, 0, flush=True)
+    gp = 0
+    for i, p in enumerate(pk):
+        if i and i + 1 < len(pk) and rng.random() < p_bad:
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                p = p[: max(1, len(p) // int(rng.integers(2, 9)))]
+            elif kind == 1:
+                p = bytes([p[0] | 1]) + p[1:]
+            else:
+                q = bytearray(p)
+                for _ in range(3):
+                    q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8))
+                p = bytes(q)
+        try:
+            gp += po.get_decoded_sample_count(o_id, o_st, p) if i else 0
+        except po.OracleError:
+            pass
+        w.add_packet(p, gp, flush=(i % 5 == 4), eos=(i == len(pk) - 1))
+    return w.bytes()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_read_ahead_damaged_packets_fail_at_their_call_and_the_stream_goes_on(harness, tmp_path, seed):
+    """AudioReadErrors in the middle of served batches: the code at the call of its packet, no samples, the granule position
+    untouched, the next call the next packet (sample counts as the oracle's reader gives them when it goes on behind an error)"""
+    data = _damaged(seed)
+    o = pyogg.OggStreamReader(data)
+    want, n_bad = [], 0
+    while True:
+        try:
+            d = o.read_dec_packet()
+        except pyogg.VorbisError as e:
+            assert e.kind == "BadAudio"
+            want.append(["P", "0", str(e.inner), str(o.stream_serial), "0", _gp(o.get_last_absgp())])
+            n_bad += 1
+            continue
+        if d is None:
+            want.append(["EOF"])
+            break
+        want.append(["P", str(d.shape[1]), "0", str(o.stream_serial), "0", _gp(o.get_last_absgp())])
+    assert n_bad >= 2
+    assert _run(harness, tmp_path, data, "seq", go_on=True) == want
+    for k in (1, 4, 25):
+        assert _run(harness, tmp_path, data, "seq", go_on=True, read_ahead=k) == want

@@ -35,6 +35,8 @@ timeout 600 python tools/fuzz_gpu_mixed.py --rounds 80 --seed 83 --big > $D/fuzz
   for K in 4096 16384; do
     echo "look-ahead K = $K, host entropy stage, 12 threads:"; timeout 300 ./examples/perf /tmp/long.ogg $K 12 2>&1 | tail -2
     echo "look-ahead K = $K, entropy stage on the device:"; timeout 300 ./examples/perf /tmp/long.ogg $K 2 dev 2>&1 | tail -2
+    echo "packet by packet with lw_ogg_stream_set_read_ahead($K), host entropy stage, 12 threads:"; timeout 300 ./examples/perf /tmp/long.ogg $K 12 host ahead 2>&1 | tail -2
+    echo "packet by packet with lw_ogg_stream_set_read_ahead($K), entropy stage on the device:"; timeout 300 ./examples/perf /tmp/long.ogg $K 2 dev ahead 2>&1 | tail -2
   done; } > $D/single_stream.txt 2>&1
 { echo "e2e_sharder: $(timeout 200 python tools/e2e_sharder.py 2>&1 | tail -1 | cut -c1-420)"
   echo "single ring, device entropy: $(timeout 200 python tools/e2e.py --batches 300 --device-entropy 2>&1 | tail -1 | cut -c1-300)"
