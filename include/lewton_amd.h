@@ -454,7 +454,8 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
  * the packet just handed out, the last packet's truncation, LW_OGG_EOF, chain boundaries (crossed by the call itself).  Every other
  * entry point first returns the packets not yet handed out and re-makes the PreviousWindowRight as of the last one that was (one
  * synchronous decode of that packet: a decoded packet's right half depends on nothing before it, audio.rs:1125-1138).
- * The threading and read-ahead contract above applies from the first call on.  0 turns it off (the default). */
+ * The threading and read-ahead contract above applies from the first call on.  0 turns it off (the default); more than 65 536
+ * packets: LW_ERR_CAPACITY. */
 int lw_ogg_stream_set_read_ahead(lw_ogg_stream *s, size_t max_packets, int n_threads);
 /* Look-ahead batches with the entropy stage on the device (lw_ring_set_entropy_on_device) whenever the current logical
  * stream is eligible; other streams (and the packet-by-packet call) keep the host stage.  Results are identical. */

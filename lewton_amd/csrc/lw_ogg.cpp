@@ -1155,6 +1155,8 @@ int lw_ogg_stream_set_read_ahead(lw_ogg_stream *s, size_t max_packets, int n_thr
 {
 	if (!s)
 		return LW_ERR_NULL_ARG;
+	if (max_packets > 65536)
+		return LW_ERR_CAPACITY; // (a batch's samples are held in host memory: 65 536 stereo packets are 0.4 GB already)
 	if (max_packets != s->ra_k || n_threads != s->ra_threads)
 		s->settle(); // what was read ahead under the old setting goes back; the stream stands where the caller's calls have led it
 	s->ra_k = max_packets;
