@@ -435,3 +435,33 @@ def test_read_ahead_damaged_packets_fail_at_their_call_and_the_stream_goes_on(ha
     assert _run(harness, tmp_path, data, "seq", go_on=True) == want
     for k in (1, 4, 25):
         assert _run(harness, tmp_path, data, "seq", go_on=True, read_ahead=k) == want
+
+
+@pytest.fixture(scope="module")
+def harness_tsan(tmp_path_factory):
+    if not os.path.isdir(os.path.join(HIP_INC, "hip")):
+        pytest.skip("HIP headers not installed")
+    exe = str(tmp_path_factory.mktemp("hostogg_tsan") / "ogg_stream_host_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__",
+                           "-I" + HIP_INC] + SRC + ["-lpthread", "-o", exe])
+    return exe
+
+
+def test_read_ahead_and_look_ahead_under_thread_sanitizer(harness, harness_tsan, tmp_path):
+    """the stream's two library threads (demultiplexer, entropy staging) against the caller's thread -- batches served packet by
+    packet, roll-backs by skip / seek / the batched call in the middle of them, chain boundaries, damaged packets: the same traces,
+    and no report from ThreadSanitizer"""
+    mix = _vorbis_stream("stereo", "LLSLLLSSL", 70, per_page=4, trim=123)[2].bytes()
+    cases = [(_damaged(2), ("seq",), dict(go_on=True)), (mix, ("hop", 5, 900, 4, 5000), {}), (mix, ("mix", 4, 2, 900, 3000), {}),
+             (_files()["chained"], ("seq",), {}), (mix, ("ahead", 6), {})]
+    for data, mode, kw in cases:
+        for k in (1, 7):
+            path = str(tmp_path / "in.ogg")
+            with open(path, "wb") as f:
+                f.write(data)
+            env = dict(os.environ, LW_OSH_READ_AHEAD=str(k), TSAN_OPTIONS="halt_on_error=0")
+            if kw.get("go_on"):
+                env["LW_OSH_GO_ON"] = "1"
+            out = subprocess.run([harness_tsan, path] + [str(m) for m in mode], capture_output=True, text=True, timeout=600, env=env)
+            assert out.returncode == 0 and "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+            assert [l.split() for l in out.stdout.splitlines()] == _run(harness, tmp_path, data, *mode, read_ahead=k, **kw)
