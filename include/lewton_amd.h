@@ -454,6 +454,7 @@ int lw_ogg_stream_read_dec_packets(lw_ogg_stream *s, int fmt, size_t max_packets
  * the packet just handed out, the last packet's truncation, LW_OGG_EOF, chain boundaries (crossed by the call itself).  Every other
  * entry point first returns the packets not yet handed out and re-makes the PreviousWindowRight as of the last one that was (one
  * synchronous decode of that packet: a decoded packet's right half depends on nothing before it, audio.rs:1125-1138).
+ * A served batch's samples stay in the staging ring's pinned memory and are copied once, into the caller's buffer, at the call.
  * The threading and read-ahead contract above applies from the first call on.  0 turns it off (the default); more than 65 536
  * packets: LW_ERR_CAPACITY. */
 int lw_ogg_stream_set_read_ahead(lw_ogg_stream *s, size_t max_packets, int n_threads);

@@ -474,15 +474,19 @@ struct lw_ogg_stream {
 	struct Served {
 		QueuedPacket q;
 		int32_t status = 0;
-		uint32_t n = 0;     // samples per channel (after the truncation of the stream's last packet)
-		size_t off = 0;     // element offset of its block in ra_out
+		uint32_t n = 0;     // samples per channel handed out (after the truncation of the stream's last packet)
+		uint32_t full = 0;  // samples per channel as decoded: the block [ch][full] (or [full][ch]) at element `off`
+		size_t off = 0;     // of the batch's PCM in the ring slot's pinned buffer (served_pcm)
 		bool has_absgp = false;
 		uint64_t absgp = 0; // get_last_absgp() once this packet has been handed out
 	};
 	std::vector<Served> served;
 	size_t served_next = 0;
 	int served_fmt = -1;
-	std::vector<char> ra_out;
+	// the served batch's samples stay where the GPU's copy put them: its ring slot is held (collected, not released) until the last
+	// packet has been handed out -- one copy per packet, straight into the caller's buffer
+	const void *served_pcm = nullptr;
+	bool slot_held = false;
 	std::vector<uint32_t> ra_ns;
 	std::vector<int32_t> ra_st;
 	bool view_has_absgp = false;
@@ -494,6 +498,17 @@ struct lw_ogg_stream {
 	std::vector<QueuedPacket> replay;
 
 	bool serving() const { return served_next < served.size(); }
+
+	void release_held()
+	{
+		if (!slot_held)
+			return;
+		(void)lw_ring_release(ring);
+		std::unique_lock<std::mutex> g(pmu);
+		slot_held = false;
+		served_pcm = nullptr;
+		pcv.notify_all(); // (the staging thread may have been waiting for the slot)
+	}
 
 	void note(QueuedPacket &&q, int status)
 	{
@@ -513,8 +528,10 @@ struct lw_ogg_stream {
 		if (!serving()) {
 			served.clear();
 			served_next = 0;
+			release_held();
 			return;
 		}
+		release_held(); // (before the ring is drained: the pipeline's own bookkeeping never sees a slot of ours)
 		rollback();
 		for (size_t i = served.size(); i-- > served_next;) {
 			Requeued r;
@@ -544,6 +561,7 @@ struct lw_ogg_stream {
 
 	void drop_context()
 	{
+		release_held();
 		rollback();
 		served.clear();
 		served_next = 0;
@@ -829,7 +847,8 @@ struct lw_ogg_stream {
 			Collected c;
 			{
 				std::unique_lock<std::mutex> g(pmu);
-				pcv.wait(g, [&]() { return p_stop || (!collected.empty() && staged.size() < 3); });
+				// (three ring slots: the batches staged or in flight, plus the one whose packets are being handed out one by one)
+				pcv.wait(g, [&]() { return p_stop || (!collected.empty() && staged.size() + (slot_held ? 1 : 0) < 3); });
 				if (p_stop)
 					break;
 				c = std::move(collected.front());
@@ -1151,6 +1170,29 @@ int lw_ogg_stream_last_absgp(const lw_ogg_stream *s, uint64_t *absgp)
 static int read_batch(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threads, void *out, size_t cap_elems, uint32_t *n_samples,
 		int32_t *status, size_t *n_packets, bool serve);
 
+// memcpy on up to n_threads threads (0 = four), pieces of at least 2 MB
+static void copy_out(char *dst, const char *src, size_t bytes, int n_threads)
+{
+	const size_t piece = (size_t)2 << 20;
+	size_t t = (size_t)std::min(std::max(n_threads > 0 ? n_threads : 4, 1), 8);
+	t = std::min(t, bytes / piece);
+	if (t <= 1) {
+		if (bytes)
+			std::memcpy(dst, src, bytes);
+		return;
+	}
+	const size_t per = ((bytes / t) + 63) & ~(size_t)63;
+	std::vector<std::thread> th;
+	for (size_t k = 1; k < t; k++) {
+		const size_t a = k * per, b = k + 1 == t ? bytes : std::min(bytes, (k + 1) * per);
+		if (a < b)
+			th.emplace_back([=]() { std::memcpy(dst + a, src + a, b - a); });
+	}
+	std::memcpy(dst, src, std::min(per, bytes));
+	for (std::thread &x : th)
+		x.join();
+}
+
 int lw_ogg_stream_set_read_ahead(lw_ogg_stream *s, size_t max_packets, int n_threads)
 {
 	if (!s)
@@ -1187,28 +1229,30 @@ static int read_ahead_packet(lw_ogg_stream *s, int fmt, void *out, size_t cap_el
 			s->view_has_absgp = e.has_absgp;
 			s->view_absgp = e.absgp;
 			if (st == LW_OK) {
-				std::memcpy(out, s->ra_out.data() + e.off * es, (size_t)e.n * ch * es);
+				const char *src = (const char *)s->served_pcm + e.off * es;
+				if (fmt == LW_FMT_I16_INTERLEAVED || e.n == e.full) {
+					std::memcpy(out, src, (size_t)e.n * ch * es);
+				} else { // the stream's last packet, truncated (inside_ogg.rs:219-227): the first n samples of every channel
+					for (size_t c = 0; c < ch; c++)
+						std::memcpy((char *)out + c * e.n * es, src + c * e.full * es, (size_t)e.n * es);
+				}
 				*n_samples = e.n;
 			}
 			s->note(std::move(e.q), st);
 			if (!s->serving()) {
 				s->served.clear();
 				s->served_next = 0;
+				s->release_held();
 			}
 			*rc = st;
 			return 0;
 		}
-		// a batch through the look-ahead pipeline into the stream's own buffer
-		const size_t es = fmt == LW_FMT_F32_PLANAR ? 4 : 2;
-		// (the longest packet is a long block with a long left and a short right slope: 3 n1 / 4 - n0 / 4 samples, audio.rs:1056-1073)
-		const size_t n0 = (size_t)1 << info.blocksize_0, n1 = (size_t)1 << info.blocksize_1;
-		const size_t cap = s->ra_k * ch * std::max(n1 / 2, 3 * n1 / 4 - n0 / 4);
-		s->ra_out.resize(cap * es);
+		// a batch through the look-ahead pipeline; its samples stay in the ring slot (served_pcm)
 		s->ra_ns.resize(s->ra_k);
 		s->ra_st.resize(s->ra_k);
 		size_t np = 0;
 		s->served_fmt = fmt;
-		const int r = read_batch(s, fmt, s->ra_k, s->ra_threads, s->ra_out.data(), cap, s->ra_ns.data(), s->ra_st.data(), &np, true);
+		const int r = read_batch(s, fmt, s->ra_k, s->ra_threads, nullptr, 0, s->ra_ns.data(), s->ra_st.data(), &np, true);
 		if (r != LW_OK) {
 			*rc = r;
 			return 0;
@@ -1309,7 +1353,7 @@ static int read_batch(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threa
 			s->rollback();
 		return rc;
 	}
-	if (total > cap_elems)
+	if (!serve && total > cap_elems)
 		return LW_ERR_CAPACITY; // nothing consumed: the batch stays at the head of the pipeline for a larger buffer
 	// the next batch goes to the GPU now, while this one is copied out (at most one launched batch is ever undelivered)
 	{
@@ -1335,13 +1379,18 @@ static int read_batch(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threa
 		s->view_has_absgp = s->has_absgp; // (as of the last packet handed out: nothing of this batch yet)
 		s->view_absgp = s->cur_absgp;
 	}
+	// the batched call: the whole batch out of pinned memory with one copy, on several threads when it is large (a single
+	// thread's memcpy, ~8 GB/s, was the bound of one stream: 4 KB per stereo packet); the blocks are already back to back, only a
+	// truncated packet (the last of its stream) makes what follows move up
+	if (!serve)
+		copy_out((char *)out, (const char *)pcm, total * es, n_threads);
 	for (size_t i = 0; i < n; i++) {
 		status[i] = res[i].status;
 		size_t m = 0;
 		const size_t full = res[i].status == LW_OK ? (size_t)res[i].n_samples * info.audio_channels : 0;
-		char *dst = (char *)out + w * es;
-		if (full)
-			std::memcpy(dst, (const char *)pcm + res[i].out_offset * es, full * es);
+		char *dst = serve ? nullptr : (char *)out + w * es;
+		if (!serve && full && w != res[i].out_offset)
+			std::memmove(dst, (const char *)out + res[i].out_offset * es, full * es);
 		if (res[i].status == LW_OK)
 			m = s->account(ps->ahead[i], fmt, dst, res[i].n_samples);
 		n_samples[i] = (uint32_t)m;
@@ -1350,7 +1399,8 @@ static int read_batch(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threa
 			e.q = std::move(ps->ahead[i]);
 			e.status = res[i].status;
 			e.n = (uint32_t)m;
-			e.off = w;
+			e.full = res[i].status == LW_OK ? res[i].n_samples : 0;
+			e.off = res[i].out_offset;
 			e.has_absgp = s->has_absgp;
 			e.absgp = s->cur_absgp;
 			s->served.push_back(std::move(e));
@@ -1368,6 +1418,14 @@ static int read_batch(lw_ogg_stream *s, int fmt, size_t max_packets, int n_threa
 			s->note(std::move(ps->ahead[i]), res[i].status);
 	}
 	*n_packets = n;
+	if (serve && n) { // the slot stays ours until its last packet has been handed out (release_held)
+		std::unique_lock<std::mutex> g(s->pmu);
+		s->served_pcm = pcm;
+		s->slot_held = true;
+		s->staged.pop_front();
+		s->pcv.notify_all();
+		return LW_OK;
+	}
 	(void)lw_ring_release(s->ring);
 	{
 		std::unique_lock<std::mutex> g(s->pmu);
