@@ -48,3 +48,58 @@ def test_random_setups_at_512_4096_and_256_4096():
         total += checked
         kernels |= ks
     assert total > 600 and "k_long12" in kernels, kernels
+
+
+@pytest.mark.parametrize("first", [900, 910])
+def test_random_setups_through_the_ogg_reader_with_read_ahead(first):
+    """random setups wrapped in Ogg pages: OggStreamReader.read_dec_packet served from batches decoded ahead (both entropy tiers where
+    the stream is eligible) against the oracle's reader, call for call -- samples or the BadAudio code, granule position"""
+    from lewton_amd import inside_ogg as IO
+    from lewton_amd import ogg
+    from lewton_amd import streamgen as sg
+    from oracle import pyogg
+    total = 0
+    for seed in range(first, first + 10):
+        rng = np.random.default_rng(seed)
+        setup = sg.random_setup(rng)
+        pk = sg.random_stream(setup, rng, 60, seed=seed, p_floor_unused=0.05, p_damage=0.05)
+        idp, cmt, stp = setup.headers()
+        o_id = po.Ident(idp)
+        o_st = po.Setup(stp, o_id)
+        w = ogg.PageWriter(seed)
+        w.add_packet(idp, 0, flush=True)
+        w.add_packet(cmt, 0)
+        w.add_packet(stp, 0, flush=True)
+        gp = 0
+        for i, p in enumerate(pk):
+            try:
+                gp += po.get_decoded_sample_count(o_id, o_st, p) if i else 0
+            except po.OracleError:
+                pass
+            w.add_packet(p, gp, flush=(i % 7 == 6), eos=(i == len(pk) - 1))
+        data = w.bytes()
+        for k, dev in ((5, False), (64, True)):
+            s, o = IO.OggStreamReader(data), pyogg.OggStreamReader(data)
+            s.set_read_ahead(k, 2)
+            s.set_entropy_on_device(dev)
+            while True:
+                ea = eb = a = b = None
+                try:
+                    a = s.read_dec_packet()
+                except IO.VorbisError as e:
+                    ea = e
+                try:
+                    b = o.read_dec_packet()
+                except pyogg.VorbisError as e:
+                    eb = e
+                assert (ea is None) == (eb is None), (seed, ea, eb)
+                if ea is not None:
+                    assert ea.kind == eb.kind == "BadAudio" and ea.code == eb.inner, (seed, ea, eb)
+                else:
+                    assert (a is None) == (b is None), seed
+                    if a is None:
+                        break
+                    assert a.shape == b.shape and np.array_equal(a, b), seed
+                    total += 1
+                assert s.get_last_absgp() == o.get_last_absgp(), seed
+    assert total > 500
