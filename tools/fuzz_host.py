@@ -108,6 +108,18 @@ with tempfile.TemporaryDirectory() as tmp:
             f.write(data)
         for mode in (["seq"], ["ahead", "7"], ["skip", str(int(rng.integers(0, 30000)))], ["seek", str(int(rng.integers(0, 40000)))]):
             r = subprocess.run([exe, path] + mode, capture_output=True, text=True, timeout=300)
+            if r.returncode == 0 and mode[0] in ("seq", "skip", "seek"):
+                # the same calls with the packet-by-packet call served from batches decoded ahead (lw_ogg_stream_set_read_ahead):
+                # the same trace, whatever the damage
+                ra = subprocess.run([exe, path] + mode, capture_output=True, text=True, timeout=300,
+                                    env=dict(os.environ, LW_OSH_READ_AHEAD=str(int(rng.choice([1, 3, 40])))))
+                if ra.returncode == 0 and ra.stdout != r.stdout:
+                    keep = os.path.join(ROOT, "gpurun_out", "fuzz_readahead_%d_%s.ogg" % (t, mode[0]))
+                    os.makedirs(os.path.dirname(keep), exist_ok=True)
+                    open(keep, "wb").write(data)
+                    raise SystemExit("read-ahead trace differs in mode %s, input kept as %s" % (mode, keep))
+                if ra.returncode != 0:
+                    r = ra
             if r.returncode != 0:
                 keep = os.path.join(ROOT, "gpurun_out", "fuzz_crash_%d_%s.ogg" % (t, mode[0]))
                 os.makedirs(os.path.dirname(keep), exist_ok=True)
@@ -144,6 +156,6 @@ with tempfile.TemporaryDirectory() as tmp:
                     open(keep, "wb").write(data)
                     print("trace differs from the oracle's; input kept as", keep)
                     raise
-    print("stream layer: %d mutated files x 4 modes without a sanitizer report; %d opened, %d read to a clean end, all traces equal "
+    print("stream layer: %d mutated files x 4 modes (three of them also with the read-ahead on: identical traces) without a sanitizer report; %d opened, %d read to a clean end, all traces equal "
           "to the oracle (%d damaged comment headers rejected by the product's parser only: the oracle has none)" % (
               args.stream_cases, opened, agree, comment_rejects))
