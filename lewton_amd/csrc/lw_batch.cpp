@@ -415,6 +415,9 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 	// in the long-block kernel's EDGE form (lw_fast.hpp)
 	const bool short_ok10 = ((b->use_l10 && b->l10_cls == 1) || b->use_l12) && b->l10_mode != 1 && blk_ok[0] && (d->blkp[0].bs == 8 || d->blkp[0].bs == 9);
 	const bool short_ok = (d->fast.eligible && blk_ok[0] && d->blkp[0].bs == 8) || short_ok10;
+	// ... and where they have none (short blocks of another size, or on the generic kernels): the wave kernel's time-domain block
+	// and the generic overlap-add (LW_RF_TDONLY); l10_mode 1 (test hook) sends such blocks to the generic kernels altogether
+	const bool td_ok10 = ((b->use_l10 && b->l10_cls == 1) || b->use_l12) && b->l10_mode != 1 && !short_ok10 && id.bs0 != id.bs1;
 	b->edge_mode = false; // set when the batch has a long block with a short slope (an all-(1,1) batch keeps the plain k_long)
 	const uint32_t n0h = (1u << id.bs0) / 2, n1h = (1u << id.bs1) / 2;
 	// equal block sizes with a flagged mode: one block shape (full slopes on both sides whatever the flags say), one class -- every
@@ -497,6 +500,15 @@ int lw_batch_entropy(lw_batch *b, const lw_packet *pkts, size_t n, int n_threads
 				b->fast_idx.push_back((uint32_t)i);
 				b->fast_slot.push_back((uint32_t)pw->slot);
 			}
+		} else if (blk_ok[1] && p.blockflag && (d->blkp[1].short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) && td_ok10 &&
+				!(p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h))) {
+			// a long block of k_long10 / k_long12 with a short slope (or a stored right part of another length) where the short blocks
+			// have no edge form: floor, inverse coupling and transform stay in the wave kernel, which writes the whole time-domain block;
+			// k_ola_generic does the window / overlap-add / state (LW_RF_TDONLY, as next to k_long)
+			r.flags |= LW_RF_FAST | LW_RF_TDONLY;
+			b->has_tdonly = true;
+			b->blk_idx[1].push_back((uint32_t)i);
+			b->blk_slot[1].push_back((uint32_t)pw->slot);
 		} else if (blk_ok[1] && p.blockflag && (d->blkp[1].short_mode_mask[p.mode >> 3] & (1u << (p.mode & 7))) &&
 				(short_ok10 ? (r.prev == -1 || r.plen == (p.prev_flag ? n1h : n0h))
 				            : (p.prev_flag && p.next_flag && (r.prev == -1 || r.plen == n1h)))) {
@@ -1098,7 +1110,8 @@ static int batch_launch(lw_batch *b, void *d_out, hipStream_t st, bool all_gener
 	const int fast_cls = b->use_l10 ? b->l10_cls : 1; // the block class of the wave-pipeline kernel's packets
 	if (run_generic) {
 		HIP_TRY(lw_launch_generic_imdct(d->T, B, tap, st, b->max_n, d->any_coupling, all_generic));
-		b->last_kernels += d->any_coupling && (!d->T.pair_coupling || tap) ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
+		if (all_generic || b->n_gen_small + b->n_gen_large) // (else only k_ola_generic has work: LW_RF_TDONLY packets)
+			b->last_kernels += d->any_coupling && (!d->T.pair_coupling || tap) ? "k_decouple,k_imdct_generic," : "k_imdct_generic,";
 	}
 	LwFastLaunch L{};
 	if (run_fast) {

@@ -379,6 +379,8 @@ size_t lw_debug_plan_census(const lw_ident *id, const lw_setup *s, char *dst, si
 			edge = "edge form";
 		else if (fast.eligible)
 			edge = "k_long + k_ola_generic";
+		else if (use_l10 || use_l12) // (the wave kernel's time-domain block, the generic overlap-add: LW_RF_TDONLY)
+			edge = use_l12 ? "k_long12 + k_ola_generic" : "k_long10 + k_ola_generic";
 		else
 			edge = "generic";
 	}

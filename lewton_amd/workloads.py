@@ -100,6 +100,10 @@ def configs(packets: int = 4096) -> List[Workload]:
         # k_long12's EDGE form
         Workload("20", "mixed 512/4096", lambda: sg.stereo_setup(44100, 9, 12), "LLLSSSLLLL", 256, per,
                  "blocksize 9 / 12; long blocks with short slopes on either side of every run of short blocks"),
+        # a pair of block sizes without an edge form (no encoder writes it): the long blocks next to short ones keep their transform in
+        # k_long12 and take the window / overlap-add from k_ola_generic (LW_RF_TDONLY)
+        Workload("21", "mixed 1024/4096", lambda: sg.stereo_setup(44100, 10, 12), "LLLSSSLLLL", 256, per,
+                 "blocksize 10 / 12; short blocks in k_short<32>, long blocks with short slopes: k_long12's time-domain block + k_ola_generic"),
         # round 6: a stream shape behind the canonicalising pre-pass; SURVEY 8(d) config 3 as written (ONE stream, state carried
         # through the whole launch: audio.rs:1082-1154, examples/perf.rs:35-44) and its all-long counterpart
         Workload("16", "5.1 @ 48 kHz long blocks, libvorbis' coupling steps (a channel in three steps)", surround51_libvorbis_coupling,

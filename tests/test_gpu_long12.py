@@ -73,7 +73,8 @@ def test_long12_forced_rounds_hand_over_paths(rounds):
 def test_long12_mixed_short_long_streams(name, fmt):
     """short blocks of 256 / 512 points: long blocks with a short slope stay in k_long12 (its EDGE form: the raw edges go to
     k_short<8 / 16> through the edge buffer) -- no packet of such a stream on the generic kernels; 1024-point short blocks
-    (k_short<32> has no edge form): those long blocks through the generic kernels, time-domain blocks exchanged both ways"""
+    (k_short<32> has no edge form): those long blocks keep floor, coupling and transform in k_long12, which writes their whole
+    time-domain block, and take window / overlap-add / state from k_ola_generic (LW_RF_TDONLY); no k_imdct_generic either way"""
     setup = L12_SETUPS[name]()
     audio, dec = _decoder(setup)
     pats = ["LLLSSSLLLL", "LLSLLLSSLLLLL", "LSSSSSSLLL", "LLLLLLLSL", "SLSLLSSL"]
@@ -84,6 +85,7 @@ def test_long12_mixed_short_long_streams(name, fmt):
     assert "k_long12" in seen and "k_short" in seen, seen
     edge = setup.bs0 in (8, 9)
     assert any("generic" in k for k in seen) == (not edge), seen
+    assert "k_imdct_generic" not in seen and "k_decouple" not in seen, seen
     _compare(got, want, fmt, name)
     for s in range(len(streams)):
         assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
@@ -114,3 +116,30 @@ def test_long12_dense_bench_shapes():
     for packets in (4096, 8192):
         bad, kernels, n = _run_dense("11", "i16", packets=packets)
         assert n == packets and bad == 0 and kernels == "k_long12", (bad, kernels)
+
+
+@pytest.mark.parametrize("bs", [(7, 10), (6, 10), (10, 12), (7, 12), (11, 12)])
+@pytest.mark.parametrize("fmt", ["i16", "f32", "i16_interleaved"])
+def test_short_slopes_without_an_edge_form_keep_the_transform_in_the_wave_kernel(bs, fmt):
+    """long blocks of k_long10 / k_long12 next to short blocks that have no edge form (64- / 128-point and 2048-point short blocks run on
+    the generic kernels, 1024-point ones on k_short<32>): floor, inverse coupling and transform stay in the wave kernel, which writes
+    the block's whole time-domain samples; k_ola_generic does window / overlap-add / state (LW_RF_TDONLY, as next to k_long).
+    Against the oracle, and against the route with that switched off (lw_debug_batch_set_long10(1): k_decouple + k_imdct_generic)."""
+    setup = sg.stereo_setup(44100, *bs)
+    audio, dec = _decoder(setup)
+    pats = ["LLLSSSLLLL", "LLSLLLSSLLLLL", "LSSSSSSLLL", "LLLLLLLSL", "SLSLLSSL"]
+    streams = [sg.make_stream(setup, pats[s % 5], 24 + s % 3, seed=5900 + s, p_floor_unused=0.05) for s in range(9)]
+    streams[4][10] = streams[4][10][: len(streams[4][10]) // 3]
+    want, wstates = _oracle(setup, streams, fmt)
+    cuts = [0, 1, 2, 3, 4, 5, 6, 15, 27]
+    got, seen, states = _decode(dec, audio, streams, cuts, fmt)
+    wave = "k_long10" if bs[1] == 10 else "k_long12"
+    assert wave in seen and "k_ola_generic" in seen, seen
+    _compare(got, want, fmt, "%s/%s" % bs)
+    for s in range(len(streams)):
+        assert np.array_equal(states[s].view(np.uint32), wstates[s].view(np.uint32)), s
+    got2, seen2, _ = _decode(dec, audio, streams, cuts, fmt, l10=1)
+    assert "k_imdct_generic" in seen2, seen2
+    _compare(got2, want, fmt, "%s/%s (generic route)" % bs)
+    if bs[0] == 10:     # k_short<32> takes the short blocks: nothing of the stream's transforms is left to the generic kernels
+        assert "k_imdct_generic" not in seen and "k_decouple" not in seen, seen
