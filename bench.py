@@ -405,6 +405,7 @@ def main():
                     ("14", "mixed 512/1024 (blocksize 9 / 10, LLLSSSLLLL)", 4096, False),
                     ("15", "mixed 256/1024 (blocksize 8 / 10, LLLSSSLLLL)", 4096, False),
                     ("20", "mixed 512/4096 (blocksize 9 / 12, LLLSSSLLLL: libvorbis' sizes below ~64 kbit/s at 44.1 kHz)", 4096, False),
+                    ("21", "mixed 1024/4096 (blocksize 10 / 12: no edge form, the transition blocks' overlap-add on the generic kernel)", 4096, False),
                     # round 6: SURVEY 8(d) config 3 as written (ONE stream), its all-long counterpart, a stream shape behind the
                     # canonicalising pre-pass (libvorbis' 5.1 coupling steps), the fallback every specialised kernel is measured
                     # against, and the mixed shapes at the batch size the library's own staging ring runs with

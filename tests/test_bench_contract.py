@@ -71,8 +71,11 @@ def test_committed_bench_line_has_the_contract_fields(name):
         # kernels), SURVEY 8(d)'s config 3 as written (ONE stream) and its all-long counterpart, a stream shape behind the
         # canonicalising pre-pass, libvorbis' 5.1 coupling inside k_long's waves at >= 30 %, the mixed shapes at 16 384 packets
         oc = d["other_configs"]
-        gen = [label for label, e in oc.items() if "generic" in e["kernels"]]
+        gen = [label for label, e in oc.items() if "k_imdct_generic" in e["kernels"]]
         assert gen == ["generic fallback (stereo 8/11 long blocks, forced)"] and oc[gen[0]]["frac"] < 0.08
+        # a pair of block sizes without an edge form: only the transition blocks' overlap-add is left to a generic kernel
+        td = [e for label, e in oc.items() if "1024/4096" in label]
+        assert len(td) == 1 and td[0]["kernels"] == "k_long12,k_short,k_ola_generic" and td[0]["frac"] >= 0.14
         one = [e for label, e in oc.items() if "ONE stream" in label]
         assert len(one) == 2 and all(e["packets_per_launch"] == 4096 for e in one)
         assert any(e["kernels"] == "k_prep,k_long" for e in oc.values())

@@ -14,7 +14,7 @@ tail -6 $D/pytest.txt
 tail -4 $D/bench.err
 timeout 400 bash tools/prof.sh r06_final --steps 20 --warmup 5 --no-end-to-end --no-other-configs > $D/prof_summary.txt 2>&1
 timeout 600 bash tools/pmc.sh r06_final --no-end-to-end --no-other-configs > $D/pmc_stdout.txt 2>&1
-timeout 900 python tools/bench_configs.py --only 3,4,5,6,7,10,11,12,13,14,15,16,17,18,19,20 --steps 600 > $D/other_configs.jsonl 2> $D/other_configs.err
+timeout 900 python tools/bench_configs.py --only 3,4,5,6,7,10,11,12,13,14,15,16,17,18,19,20,21 --steps 600 > $D/other_configs.jsonl 2> $D/other_configs.err
 timeout 300 python tools/bench_configs.py --only 9 --packets 2048 --force-generic --steps 100 >> $D/other_configs.jsonl 2>> $D/other_configs.err
 timeout 400 python tools/bench_configs.py --only 3,11,12,14,15,16,20 --packets 16384 --steps 300 >> $D/other_configs.jsonl 2>> $D/other_configs.err
 timeout 400 python tools/bench_configs.py --only 3,12,14 --packets 65536 --steps 100 >> $D/other_configs.jsonl 2>> $D/other_configs.err
