@@ -181,6 +181,13 @@ static const char *plan_units(const Ident &id, const Setup &s, bool blockflag, s
 		} else if (s.floors[fl].f1.sorted_x.size() > max_posts) {
 			if (!why)
 				why = "a floor with more posts than the kernel's lanes take";
+		} else if (!s.floors[fl].f1.sorted_x.empty() && s.floors[fl].f1.sorted_x.back() > LW_FLOOR_EXACT_ADX) {
+			// (rangebits 13 .. 15, header.rs:871-873: posts up to x = 32768 whatever the block size.  A line between two active
+			// posts may then span more bins than the kernels' two-FMA form of render_line is exact for -- proven for adx <= 4096,
+			// tests/test_fast_model.py, test_big_model.py; round 6's random-setup campaign met a line of 32 638 bins that came out one
+			// step off in a few bins.  k_prep evaluates such floors: its form falls back to the integer division beyond 4096.)
+			if (!why)
+				why = "a floor with posts beyond x = 4096";
 		} else {
 			native[c] = fl;
 			use[fl]++;

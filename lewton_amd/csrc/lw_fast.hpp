@@ -10,6 +10,7 @@
 
 #define LW_FAST_BS 11          // the kernel is specialised for blocksize_1 = 11 (n = 2048)
 #define LW_FAST_MAX_FLOORS 2   // distinct floor-1 configurations staged in LDS
+#define LW_FLOOR_EXACT_ADX 4096u // longest line (in bins) the kernels' closed form of render_line is proven exact for
 #define LW_FAST_WAVES 16       // waves (packet-units) per workgroup and round: 4 per SIMD, <= 128 VGPRs each
 #define LW_FAST_MAX_ROUNDS 16  // rounds per workgroup (chunk = rounds * packets per round consecutive items)
 

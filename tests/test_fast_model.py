@@ -125,6 +125,21 @@ def test_floor_by_two_fmas_and_a_mask_is_exact():
                 assert np.array_equal(got, y0 + off), (adx, rinv)
 
 
+def test_floor_by_two_fmas_is_not_exact_for_lines_beyond_4096_bins():
+    """why floors with posts beyond x = 4096 (range bits 13 .. 15) are evaluated by k_prep, whose form falls back to the integer
+    division there (lw_fast.cpp: plan_units): the line of 32 638 bins from (130, 198) to (32768, 22) that round 6's random-setup
+    campaign met (setup 607025) comes out one step off in its first bin -- (adx - t) |dy| + 7 adx / 8 - 1 / 2 needs 25 bits there"""
+    f = np.float32
+    x0, y0, adx, dy = 130, 198, 32638, -176
+    k = np.arange(x0, 1024, dtype=np.int64)
+    want = y0 - (176 * (k - x0)) // adx
+    c0 = f(f(f(0.875) * f(adx)) - f(0.5)) - f(f(x0 + adx) * f(dy))
+    inner = (k.astype(np.float64) * float(dy) + float(c0)).astype(np.float32)
+    tt = (inner.astype(np.float64) * float(f(1.0) / f(adx)) + float(f(y0 + dy) + f(2097153.0))).astype(np.float32)
+    got = ((tt.view(np.uint32) & 0x7FC) >> 2).astype(np.int64) - 1
+    assert list(np.flatnonzero(got != want)) == [0] and got[0] == want[0] + 1
+
+
 def test_packed_op_model_bit_exact():
     """The v_pk_mul/add formulation (op_sel / neg modifiers emulated in numpy) == oracle, incl. window/overlap-add."""
     blob, offs, _, _ = _image(SETUPS["stereo"]())

@@ -43,6 +43,18 @@ def three_floor_configurations(bs0=8, bs1=11):
     return st
 
 
+def floor_posts_beyond_the_block(bs0=8, bs1=11):
+    """range bits 15 (header.rs:871-873): posts at x = 5000 ... 32768 whatever the block size.  A line from a post inside the block to
+    one of those spans more bins than the kernels' two-FMA form of render_line is exact for (adx <= 4096): the random-setup campaign
+    of round 6 met a line of 32 638 bins whose first bin came out one step off in k_long.  Such floors are evaluated by k_prep."""
+    st = sg.stereo_setup(44100, bs0, bs1)
+    f = st.floors[1]
+    f.rangebits = 15
+    f.x_rest = list(f.x_rest[:-4]) + [5000, 20000, 31880, 131]
+    assert len(set(f.x_list)) == len(f.x_list)
+    return st
+
+
 CASES = {
     "surround51_libvorbis_coupling": (surround51_libvorbis_coupling, "a channel takes part in more than one coupling step"),
     "surround51_libvorbis_coupling_9_12": (lambda: surround51_libvorbis_coupling(9, 12), "a channel takes part"),
@@ -51,6 +63,7 @@ CASES = {
     "three_channels": (three_channels, "a channel takes part"),
     "two_long_modes": (two_long_modes, "long modes with different"),
     "floor_of_65_posts": (floor_of_65_posts, "more posts"),
+    "floor_posts_beyond_the_block": (floor_posts_beyond_the_block, "posts beyond x = 4096"),
     "three_floor_configurations": (three_floor_configurations, "floor"),
     "floor0_long_blocks": (lambda: sg.floor0_setup(8, 11, 44100, mixed=True), "floor type 0"),
     # blocksize_0 = blocksize_1 with a flagged and an unflagged mode: one block shape, every mode planned as the long class; the two
